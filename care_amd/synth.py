@@ -1,0 +1,150 @@
+"""Deterministic synthetic weights and inputs.
+
+No dataset or checkpoint of the reference exists offline, so every test, fixture and
+benchmark runs on tensors produced here.  The generator is pure integer arithmetic
+(splitmix64 keyed by ``(seed, tensor name, element index)``) followed by one exact
+int->float64 scaling, so it yields bit-identical tensors on every machine: the
+reference model in the build container, the CPU oracle and the HIP path on the GPU
+box all load the very same numbers.
+
+The value *distributions* follow the reference initialiser (`models/Framework.py:115-134`:
+xavier-uniform Linear/Embedding weights, zero PAD row) but biases, LayerNorm affine
+parameters and `hybrid_bias` are made non-trivial so that parity tests exercise them.
+"""
+import hashlib
+import math
+from typing import Dict, Iterable, Tuple
+
+import numpy as np
+import torch
+
+GENERATOR_VERSION = 3
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """Vectorised splitmix64 finaliser on uint64 (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _key(seed: int, name: str) -> np.uint64:
+    digest = hashlib.sha256("{}|{}|v{}".format(seed, name, GENERATOR_VERSION).encode()).digest()
+    return np.uint64(int.from_bytes(digest[:8], "little"))
+
+
+def uniform(seed: int, name: str, shape: Tuple[int, ...]) -> np.ndarray:
+    """float64 array, i.i.d. uniform in (-1, 1), fully determined by (seed, name, shape)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        bits = _splitmix64((idx * np.uint64(0xD1342543DE82EF95) + _key(seed, name)) & _M64)
+    u = (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)  # [0,1)
+    return (2.0 * u - 1.0).reshape(shape)
+
+
+def normalish(seed: int, name: str, shape: Tuple[int, ...]) -> np.ndarray:
+    """Unit-variance, bell-shaped values (sum of 4 uniforms, exact and portable)."""
+    acc = np.zeros(shape, dtype=np.float64)
+    for k in range(4):
+        acc += uniform(seed, "{}#{}".format(name, k), shape)
+    return acc * math.sqrt(3.0 / 4.0)
+
+
+def _tensor(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
+
+
+def synth_value(seed: int, name: str, shape: Tuple[int, ...]) -> torch.Tensor:
+    """Synthetic value of the state-dict entry `name` with `shape` (fp32 CPU tensor)."""
+    shape = tuple(int(s) for s in shape)
+    leaf = name.rsplit(".", 1)[-1]
+    if "hybrid_bias" in name:
+        return _tensor(0.5 * uniform(seed, name, shape))
+    if "LayerNorm" in name or _is_seq_layernorm(name, shape):
+        if leaf == "weight":
+            return _tensor(1.0 + 0.1 * uniform(seed, name, shape))
+        return _tensor(0.05 * uniform(seed, name, shape))
+    if leaf == "bias":
+        return _tensor(0.02 * uniform(seed, name, shape))
+    if len(shape) == 2:
+        bound = math.sqrt(6.0 / (shape[0] + shape[1]))
+        # Two deliberate departures from xavier so that decoding depends on the previous
+        # tokens (with xavier scales the position / concept terms swamp the word
+        # embedding and every clip decodes the same sentence): word embeddings are made
+        # as large as position embeddings, the global concept vector comparably small.
+        if name.endswith("decoder.embedding.word_embeddings.weight"):
+            bound = 0.15
+        elif name.endswith("semantic2hidden.weight"):
+            bound = 0.02
+        elif name.startswith("predictor.") and name.endswith(".prj.weight"):
+            bound *= 3.0  # concept probabilities spread over (0,1) like a trained detector
+        w = bound * uniform(seed, name, shape)
+        if name.endswith("decoder.embedding.word_embeddings.weight"):
+            w[0] = 0.0  # padding_idx = PAD row (Embeddings.py:106, Framework.py:129-130)
+        return _tensor(w)
+    return _tensor(0.1 * uniform(seed, name, shape))
+
+
+def _is_seq_layernorm(name: str, shape: Tuple[int, ...]) -> bool:
+    # `Embedder` wraps Linear/LayerNorm in nn.Sequential: keys `encoder.Encoder_X.1.{weight,bias}`
+    # are LayerNorm parameters (Encoder.py:165-168); they are the only 1-D `.weight`s.
+    return len(shape) == 1 and name.rsplit(".", 1)[-1] == "weight"
+
+
+def synth_state_dict(seed: int, names_and_shapes: Iterable[Tuple[str, Tuple[int, ...]]],
+                     row_scale: Dict[str, Dict[int, float]] = None) -> Dict[str, torch.Tensor]:
+    """State dict for the given (name, shape) list; LayerNorm biases are found by pairing.
+
+    `row_scale` = {tensor name: {row index: factor}} multiplies single rows after
+    generation; the crafted parity cases use it to make EOS / PAD likely outputs
+    (e.g. {"cls_head.tgt_word_prj.weight": {3: 4.0}}), which random weights never do.
+    """
+    items = list(names_and_shapes)
+    ln_prefixes = {n.rsplit(".", 1)[0] for n, s in items if _is_seq_layernorm(n, tuple(s)) or "LayerNorm" in n}
+    out = {}
+    for name, shape in items:
+        shape = tuple(int(s) for s in shape)
+        prefix, leaf = name.rsplit(".", 1) if "." in name else ("", name)
+        if prefix in ln_prefixes and leaf == "bias":
+            out[name] = _tensor(0.05 * uniform(seed, name, shape))
+        else:
+            out[name] = synth_value(seed, name, shape)
+    for name, rows in (row_scale or {}).items():
+        for row, factor in rows.items():
+            out[name][int(row)] *= float(factor)
+    return out
+
+
+def synth_feats(seed: int, shapes) -> list:
+    """`batch['feats']`: one fp32 `[B, n, dim_x]` tensor per modality, unit variance."""
+    return [_tensor(normalish(seed, "feats{}".format(i), tuple(s))) for i, s in enumerate(shapes)]
+
+
+def synth_input_ids(seed: int, batch: int, length: int, vocab_size: int, pad_tail: bool = True) -> torch.Tensor:
+    """Teacher-forcing `input_ids [B, length]`: BOS, words, EOS, then PAD (dataloader.py:661-675)."""
+    from .constants import BOS, EOS, PAD
+
+    u = uniform(seed, "input_ids", (batch, length))
+    ids = (6 + np.floor((u * 0.5 + 0.5) * (vocab_size - 6))).astype(np.int64)
+    ids = np.clip(ids, 6, vocab_size - 1)
+    ids[:, 0] = BOS
+    if pad_tail:
+        lens = uniform(seed, "input_lens", (batch,))
+        for b in range(batch):
+            n = int(4 + math.floor((lens[b] * 0.5 + 0.5) * (length - 4)))  # sentence length incl. BOS
+            n = min(max(n, 3), length)
+            if n < length:
+                ids[b, n] = EOS
+                ids[b, n + 1:] = PAD
+    return torch.from_numpy(ids)
+
+
+def tensor_sha256(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()

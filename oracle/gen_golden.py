@@ -1,0 +1,129 @@
+"""Generate tests/golden/*.npz by running the GENUINE reference in the build container.
+
+    python -m oracle.gen_golden            # needs /root/reference (read-only)
+
+The reference ships no tests or golden vectors, so parity is pinned on
+outputs of the reference itself: for each case below the reference model is built from
+an explicit `opt` (care_amd/configs.py), loaded with the deterministic synthetic state
+dict (care_amd/synth.py), run on deterministic synthetic inputs, and its outputs are
+stored.  Only data (inputs are regenerated from seeds, outputs stored) and this script
+are committed; no reference source or bytecode enters the repo.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from care_amd.configs import feat_shapes, make_opt
+from care_amd.synth import GENERATOR_VERSION, synth_feats, synth_input_ids, synth_state_dict, tensor_sha256
+from oracle.ref_import import import_reference
+
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+EOS_ROW, PAD_ROW = 3, 0
+VOCAB_W = "cls_head.tgt_word_prj.weight"
+
+# name, config, B, seed, opt overrides, row_scale
+CASES = [
+    ("msvd_base_i_b10", "msvd_base_i", 10, 11, {}, {}),
+    ("msrvtt_base_ami_b2", "msrvtt_base_ami", 2, 12, {}, {}),
+    ("msrvtt_base_ami_eos_b4", "msrvtt_base_ami", 4, 13, {}, {VOCAB_W: {EOS_ROW: 4.0, PAD_ROW: 3.0}}),
+    ("msrvtt_care_b2", "msrvtt_care", 2, 14, {}, {}),
+    ("msrvtt_care_eos_b4", "msrvtt_care", 4, 15, {}, {VOCAB_W: {EOS_ROW: 6.0, PAD_ROW: 3.0}}),
+    ("vatex_care_large_b2", "vatex_care_large", 2, 16, {}, {}),
+    ("msrvtt_care_beam5_b3", "msrvtt_care_beam5", 3, 17, {}, {}),
+    ("msrvtt_care_beam5_eos_b4", "msrvtt_care_beam5", 4, 15, {"topk": 3}, {VOCAB_W: {EOS_ROW: 4.0, PAD_ROW: 3.0}}),
+    ("msrvtt_care_beam5_eos2_b4", "msrvtt_care_beam5", 4, 32, {"topk": 3}, {VOCAB_W: {EOS_ROW: 6.0, PAD_ROW: 3.0}}),
+    ("msrvtt_care_beam5_eos_b1", "msrvtt_care_beam5", 1, 15, {}, {VOCAB_W: {EOS_ROW: 4.0, PAD_ROW: 3.0}}),
+    ("msrvtt_base_ami_beam5_eos_b3", "msrvtt_base_ami", 3, 20, {"beam_size": 5}, {VOCAB_W: {EOS_ROW: 3.5}}),
+    ("care_median_gelu_b2", "care_median_gelu", 2, 21, {}, {}),
+    ("base_ami_mte_b2", "base_ami_mte", 2, 22, {}, {}),
+]
+
+
+def pad_hyps(hyps, width):
+    """List[B][n_best][<=width] -> int32 [B, n_best_max, width] (-1 fill) + lengths."""
+    nb = max(len(h) for h in hyps)
+    arr = -np.ones((len(hyps), nb, width), dtype=np.int32)
+    lens = np.zeros((len(hyps), nb), dtype=np.int32)
+    for i, hs in enumerate(hyps):
+        for j, h in enumerate(hs):
+            arr[i, j, : len(h)] = h
+            lens[i, j] = len(h)
+    return arr, lens
+
+
+def run_case(get_framework, get_translator, name, cfg, B, seed, overrides, row_scale):
+    opt = make_opt(cfg, **overrides)
+    torch.manual_seed(0)
+    model = get_framework(opt).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    sd = synth_state_dict(seed, shapes, row_scale=row_scale)
+    model.load_state_dict(sd, strict=True)
+    feats = synth_feats(seed, feat_shapes(opt, B))
+    T = opt["max_len"] - 1
+    input_ids = synth_input_ids(seed, B, T, opt["vocab_size"])
+
+    rec = {}
+    with torch.no_grad():
+        enc = model.encoding_phase([f.clone() for f in feats])
+        # memory rows of clip 0 only (keeps the fixture small); the per-modality means
+        # below cover every clip, and the concept rows are the tail of the memory.
+        rec["encoder_hidden_states_clip0"] = enc["encoder_hidden_states"][0].numpy()
+        for i, m in enumerate(enc["mean_encoder_hidden_states"]):
+            rec["mean_encoder_hidden_states_%d" % i] = m.numpy()
+        for k in ("preds_attr", "avg_prob_attr", "semantic_labels", "semantic_hidden_states"):
+            if enc.get(k) is not None:
+                rec[k] = enc[k].numpy()
+        if "preds_attr" in enc:
+            top = enc["preds_attr"].topk(opt["use_attr_topk"] + 1, dim=1)[0]
+            rec["concept_topk_min_gap"] = np.float64((top[:, :-1] - top[:, 1:]).min().item())
+
+        out = model.feedforward_step({"feats": [f.clone() for f in feats], "input_ids": input_ids})
+        rec["tf_input_ids"] = input_ids.numpy()
+        rec["tf_hidden_states"] = out["hidden_states"][: min(B, 4)].numpy()
+        logits = out["logits"]
+        rec["tf_logits_lse"] = torch.logsumexp(logits, dim=-1).numpy()
+        top = logits.topk(8, dim=-1)
+        rec["tf_logits_top8_val"] = top[0].numpy()
+        rec["tf_logits_top8_idx"] = top[1].numpy().astype(np.int32)
+
+        translator = get_translator(opt)
+        hyps, scores = translator.translate_batch([model], {"feats": [f.clone() for f in feats]})
+        arr, lens = pad_hyps(hyps, T)
+        rec["hyps"] = arr
+        rec["hyp_lens"] = lens
+        sc = np.full(lens.shape, np.nan, dtype=np.float64)
+        for i, s in enumerate(scores):
+            sc[i, : len(s)] = s
+        rec["hyp_scores"] = sc
+
+    meta = dict(name=name, config=cfg, batch=B, seed=seed, overrides=overrides,
+                row_scale={k: {str(r): f for r, f in v.items()} for k, v in row_scale.items()},
+                generator_version=GENERATOR_VERSION,
+                state_dict=[[k, list(s)] for k, s in shapes],
+                n_params=int(sum(p.numel() for p in model.parameters())),
+                sha256={"feats0": tensor_sha256(feats[0]), VOCAB_W: tensor_sha256(sd[VOCAB_W]),
+                        "input_ids": tensor_sha256(input_ids)},
+                torch_version=torch.__version__)
+    rec["meta_json"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **rec)
+    lens_s = lens.tolist()
+    print("{:32s} params={} hyp_lens={} size={:.0f}KB".format(name, meta["n_params"], lens_s, os.path.getsize(path) / 1024))
+
+
+def main():
+    get_framework, get_translator = import_reference()
+    os.makedirs(OUT_DIR, exist_ok=True)
+    only = set(sys.argv[1:])
+    for case in CASES:
+        if only and case[0] not in only:
+            continue
+        run_case(get_framework, get_translator, *case)
+
+
+if __name__ == "__main__":
+    main()
