@@ -1,0 +1,159 @@
+// attention.hip - single-query-row scaled-dot-product attention, head dim 64 (HBM-bound).
+//
+// The decode step reads, per (row, head), Lk keys and Lk values of 64 elements once and
+// does 2*2*Lk*64 flops on them: ~1 flop/byte, so this is a pure streaming kernel and the
+// matrix cores are not involved (north_star: "MFMA only for the dense GEMMs").
+//
+// Mapping: one 64-lane wave per (query row, head); 4 waves per workgroup.
+//   * A wave-wide 16-byte load covers 8 keys x 64 elements (bf16) - lane = (key & 7) * 8 +
+//     dim_chunk - i.e. 1 KiB of contiguous-per-key, full-line traffic per instruction.
+//   * q.k: 8 FMAs per lane, then a 3-step xor-shuffle over the 8 dim chunks.
+//   * softmax over the <= 128 scores a lane group holds in registers: row max / row sum via
+//     xor shuffles across the 8 key slots (8,16,32) - no LDS at all.
+//   * P.V: each lane accumulates its 8 dims over its key slot, 3 xor-shuffles merge the 8
+//     slots, lanes 0-7 store 256 contiguous bytes of context.
+//   * NKB (key blocks of 8) is a template parameter so all K loads of a wave are issued
+//     back to back (up to 16 KiB in flight per wave) before the first use.
+// Masking follows the reference exactly: masked keys get -1e9 (not -inf), the hybrid bias
+// is added AFTER the mask (models/components/Attention.py:104-111).
+#include "care_common.h"
+
+namespace {
+
+struct AttnArgs {
+  const float* Q; int64_t ldq;
+  const void* K; const void* V;
+  int64_t kv_batch_stride, kv_row_stride;
+  int rows_per_kv;
+  const int32_t* anc; int anc_stride;
+  int nkeys, causal, seq, causal_off;
+  const int32_t* pad_tok; int pad_stride, pad_id;
+  const float* bias; int bias_ld;
+  float* ctx; int64_t ldctx;
+  int rows, heads;
+};
+
+template <typename KT, int NKB>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= p.rows * p.heads) return;
+  const int r = item / p.heads, h = item % p.heads;
+  const int slot = lane >> 3, chunk = lane & 7;
+
+  int nk = p.nkeys;
+  if (p.causal) nk = min(nk, (r % p.seq) + 1 + p.causal_off);
+  const int kvb_default = r / p.rows_per_kv;
+
+  float q[8];
+  care_load8(p.Q + (int64_t)r * p.ldq + h * 64 + chunk * 8, q);
+
+  const KT* Kb = reinterpret_cast<const KT*>(p.K) + h * 64 + chunk * 8;
+  const KT* Vb = reinterpret_cast<const KT*>(p.V) + h * 64 + chunk * 8;
+
+  // ---- scores
+  float s[NKB];
+  int64_t off[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int j = kb * 8 + slot;
+    const bool valid = j < nk;
+    const int jj = valid ? j : 0;
+    const int kvb = p.anc ? p.anc[(int64_t)r * p.anc_stride + jj] : kvb_default;
+    off[kb] = (int64_t)kvb * p.kv_batch_stride + (int64_t)jj * p.kv_row_stride;
+    float kv[8];
+    care_load8(Kb + off[kb], kv);
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d = fmaf(q[i], kv[i], d);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    d *= 0.125f;  // 1/sqrt(64), exact
+    if (valid) {
+      if (p.pad_tok) {
+        const int ptb = p.anc ? kvb : kvb_default;
+        if (p.pad_tok[(int64_t)ptb * p.pad_stride + j] == p.pad_id) d = -1e9f;
+      }
+      if (p.bias) d += p.bias[h * p.bias_ld + j];
+    } else {
+      d = -INFINITY;
+    }
+    s[kb] = d;
+  }
+
+  // ---- softmax over all keys (each score is replicated on the 8 chunk lanes of its slot)
+  float m = s[0];
+#pragma unroll
+  for (int kb = 1; kb < NKB; ++kb) m = fmaxf(m, s[kb]);
+  m = fmaxf(m, __shfl_xor(m, 8, 64));
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    s[kb] = expf(s[kb] - m);  // -inf -> 0 for the padding slots
+    sum += s[kb];
+  }
+  sum += __shfl_xor(sum, 8, 64);
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+
+  // ---- context
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    float vv[8];
+    care_load8(Vb + off[kb], vv);
+    const float pw = s[kb] * inv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(pw, vv[i], acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] += __shfl_xor(acc[i], 8, 64);
+    acc[i] += __shfl_xor(acc[i], 16, 64);
+    acc[i] += __shfl_xor(acc[i], 32, 64);
+  }
+  if (slot == 0) {
+    float* o = p.ctx + (int64_t)r * p.ldctx + h * 64 + chunk * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+template <typename KT>
+int launch_attention(const AttnArgs& p, hipStream_t st) {
+  const int items = p.rows * p.heads;
+  const dim3 grid((items + 3) / 4), block(256);
+  if (p.nkeys <= 32) hipLaunchKernelGGL((attention_kernel<KT, 4>), grid, block, 0, st, p);
+  else if (p.nkeys <= 88) hipLaunchKernelGGL((attention_kernel<KT, 11>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((attention_kernel<KT, 16>), grid, block, 0, st, p);
+  return care_launch_status();
+}
+
+}  // namespace
+
+extern "C" int care_attention(const float* Q, int64_t ldq, const void* K, const void* V, int kv_dtype,
+                              int64_t kv_batch_stride, int64_t kv_row_stride, int rows_per_kv, const int32_t* anc,
+                              int anc_stride, int nkeys, int causal, int seq, int causal_off, const int32_t* pad_tok,
+                              int pad_stride, int pad_id, const float* bias, int bias_ld, float* ctx, int64_t ldctx,
+                              int rows, int heads, void* stream) {
+  if (!Q || !K || !V || !ctx || rows <= 0 || heads <= 0 || nkeys <= 0 || rows_per_kv <= 0 || seq <= 0)
+    return CARE_EINVAL;
+  if (nkeys > 128) return CARE_ESHAPE;
+  if (kv_dtype != CARE_F32 && kv_dtype != CARE_BF16) return CARE_EDTYPE;
+  if ((ldq % 4) || (ldctx % 4) || (kv_batch_stride % 8) || (kv_row_stride % 8) || !care_aligned16(Q) ||
+      !care_aligned16(K) || !care_aligned16(V) || !care_aligned16(ctx))
+    return CARE_EALIGN;
+  AttnArgs p{};
+  p.Q = Q; p.ldq = ldq; p.K = K; p.V = V;
+  p.kv_batch_stride = kv_batch_stride; p.kv_row_stride = kv_row_stride; p.rows_per_kv = rows_per_kv;
+  p.anc = anc; p.anc_stride = anc_stride;
+  p.nkeys = nkeys; p.causal = causal; p.seq = seq; p.causal_off = causal_off;
+  p.pad_tok = pad_tok; p.pad_stride = pad_stride; p.pad_id = pad_id;
+  p.bias = bias; p.bias_ld = bias_ld; p.ctx = ctx; p.ldctx = ldctx; p.rows = rows; p.heads = heads;
+  hipStream_t st = (hipStream_t)stream;
+  return kv_dtype == CARE_BF16 ? launch_attention<bf16_t>(p, st) : launch_attention<float>(p, st);
+}

@@ -1,0 +1,210 @@
+// beam.hip - beam-search step on the device (beam_size > 1).
+//
+// Replaces, per decode step, Translator_ARFormer.predict_word's log_softmax
+// (models/Translator.py:127) and Beam.advance (misc/Decoding/Beam.py:45-85) for every clip,
+// without the per-step D2H sync / .item() loop of the reference.  Two kernels:
+//
+//   care_beam_select : per row of logits [rows, V]: log-sum-exp and the beam_size best
+//                      columns as log-probabilities (value desc, index asc).  The global top
+//                      beam_size of a clip's beam_size x V candidates always lies inside the
+//                      union of the per-row top beam_size, so nothing else leaves this kernel.
+//   care_beam_advance: one thread per clip runs the beam state machine on those
+//                      beam_size^2 candidates, including every quirk the reference has
+//                      (first step looks at row 0 only; a beam that ended with EOS offers no
+//                      continuation; hypotheses are collected in beam order until `need` are
+//                      finished; forced finish at max_steps), and rewires the ancestor table
+//                      that the incremental self-attention K/V cache is addressed through.
+//
+// Ancestor table: anc[row][j] = PHYSICAL row that holds position j (token, self-attn K/V) of the
+// hypothesis currently living in beam slot `row`.  Re-ordering beams is a copy of <= 30 ints per
+// row instead of a gather over the whole K/V cache.
+#include "care_common.h"
+
+namespace {
+
+constexpr int MAXBM = 8;
+
+__global__ __launch_bounds__(256) void beam_select_kernel(const float* logits, int64_t ldl, int V, int bm,
+                                                          float* cand_val, int32_t* cand_idx, int rows) {
+  __shared__ float sval[256 * MAXBM];
+  __shared__ int sidx[256 * MAXBM];
+  __shared__ float sred[8];
+  __shared__ int sredi[8];
+  __shared__ float s_bcast[2];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (int64_t)r * ldl;
+
+  // pass 1: row max + thread-local top-bm (sorted: value desc, index asc)
+  float tv[MAXBM];
+  int ti[MAXBM];
+#pragma unroll
+  for (int j = 0; j < MAXBM; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+  float mx = -INFINITY;
+  for (int c = tid; c < V; c += 256) {
+    const float v = x[c];
+    mx = fmaxf(mx, v);
+    if (v > tv[bm - 1]) {  // strictly greater: equal values keep the earlier (lower) index
+      float cv = v; int ci = c;
+#pragma unroll
+      for (int j = 0; j < MAXBM; ++j) {
+        if (j < bm && (cv > tv[j])) {
+          const float ov = tv[j]; const int oi = ti[j];
+          tv[j] = cv; ti[j] = ci; cv = ov; ci = oi;
+        }
+      }
+    }
+  }
+  mx = care_wave_max(mx);
+  if (lane == 0) sred[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  __syncthreads();
+  // pass 2: sum exp(x - max)
+  float se = 0.f;
+  for (int c = tid; c < V; c += 256) se += expf(x[c] - mx);
+  se = care_wave_sum(se);
+  if (lane == 0) sred[wave] = se;
+#pragma unroll
+  for (int j = 0; j < MAXBM; ++j) { sval[tid * MAXBM + j] = tv[j]; sidx[tid * MAXBM + j] = ti[j]; }
+  __syncthreads();
+  const float logsum = logf((sred[0] + sred[1]) + (sred[2] + sred[3]));
+  __syncthreads();
+
+  // bm rounds of block-wide arg-best over the 256 thread-local list heads
+  int head = 0;  // next unconsumed entry of this thread's sorted list
+  for (int k = 0; k < bm; ++k) {
+    float v = head < bm ? sval[tid * MAXBM + head] : -INFINITY;
+    int id = head < bm ? sidx[tid * MAXBM + head] : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(id, o, 64);
+      if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; }
+    }
+    if (lane == 0) { sred[wave] = v; sredi[wave] = id; }
+    __syncthreads();
+    if (tid == 0) {
+      float bv = sred[0]; int bi = sredi[0];
+      for (int w = 1; w < 4; ++w)
+        if (sred[w] > bv || (sred[w] == bv && sredi[w] < bi)) { bv = sred[w]; bi = sredi[w]; }
+      s_bcast[0] = bv; sredi[4] = bi;
+      cand_val[(int64_t)r * bm + k] = (bv - mx) - logsum;  // log_softmax = (x - max) - log(sum)
+      cand_idx[(int64_t)r * bm + k] = bi;
+    }
+    __syncthreads();
+    const int win = sredi[4];
+    if (head < bm && sidx[tid * MAXBM + head] == win) ++head;  // column indices are unique
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void beam_advance_kernel(
+    const float* cand_val, const int32_t* cand_idx, float* scores, int bm, int32_t* tokphys, const int32_t* anc_old,
+    int32_t* anc_new, int32_t* done, int32_t* n_fin, float* fin_score, int32_t* fin_len, int32_t* fin_hyp, int fin_cap,
+    int t, int max_steps, int need, int eos_id, int V, int stride, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int row0 = b * bm;
+  int parent[MAXBM], tok[MAXBM];
+  float sc[MAXBM];
+
+  if (done[b]) {
+    // frozen clip: keep the tables valid so the (ignored) rows keep reading defined memory
+    for (int i = 0; i < bm; ++i) {
+      for (int j = 0; j < t; ++j) anc_new[(int64_t)(row0 + i) * stride + j] = anc_old[(int64_t)(row0 + i) * stride + j];
+      anc_new[(int64_t)(row0 + i) * stride + t] = row0 + i;
+      tokphys[(int64_t)(row0 + i) * stride + t] = eos_id;
+    }
+    return;
+  }
+
+  // --- candidate pool: (value, flat index i*V + col); ended beams offer nothing (Beam.py:52-54)
+  const int n_src = (t == 1) ? 1 : bm;  // first step: row 0 only (Beam.py:55-56)
+  bool used[MAXBM * MAXBM];
+  for (int c = 0; c < bm * bm; ++c) used[c] = false;
+  for (int k = 0; k < bm; ++k) {
+    float bv = -INFINITY; long bflat = 0x7fffffffffffffffL; int bc = -1;
+    for (int i = 0; i < n_src; ++i) {
+      if (t > 1) {
+        const int prow = anc_old[(int64_t)(row0 + i) * stride + (t - 1)];
+        if (tokphys[(int64_t)prow * stride + (t - 1)] == eos_id) continue;
+      }
+      for (int j = 0; j < bm; ++j) {
+        const int c = i * bm + j;
+        if (used[c]) continue;
+        float v = cand_val[(int64_t)(row0 + i) * bm + j];
+        if (t > 1) v = v + scores[row0 + i];
+        const long flat = (long)i * V + cand_idx[(int64_t)(row0 + i) * bm + j];
+        if (v > bv || (v == bv && flat < bflat)) { bv = v; bflat = flat; bc = c; }
+      }
+    }
+    if (bc < 0) {  // fewer live candidates than beams (cannot happen while topk <= beam_size)
+      sc[k] = -1e20f; parent[k] = 0; tok[k] = eos_id;
+    } else {
+      used[bc] = true;
+      sc[k] = bv; parent[k] = bc / bm; tok[k] = cand_idx[(int64_t)(row0 + parent[k]) * bm + (bc % bm)];
+    }
+  }
+
+  // --- rewire ancestors, record tokens and scores
+  for (int i = 0; i < bm; ++i) {
+    const int64_t dst = (int64_t)(row0 + i) * stride, src = (int64_t)(row0 + parent[i]) * stride;
+    for (int j = 0; j < t; ++j) anc_new[dst + j] = anc_old[src + j];
+    anc_new[dst + t] = row0 + i;
+    tokphys[dst + t] = tok[i];
+    scores[row0 + i] = sc[i];
+  }
+
+  // --- finished hypotheses, in beam order, stop as soon as `need` are collected (Beam.py:72-77)
+  int nf = n_fin[b];
+  bool is_done = false;
+  auto record = [&](int i) {
+    if (nf < fin_cap) {
+      const int64_t slot = (int64_t)b * fin_cap + nf;
+      fin_score[slot] = sc[i];
+      fin_len[slot] = t;
+      for (int j = 1; j <= t; ++j) {
+        const int prow = anc_new[(int64_t)(row0 + i) * stride + j];
+        fin_hyp[slot * stride + (j - 1)] = tokphys[(int64_t)prow * stride + j];
+      }
+    }
+    ++nf;
+  };
+  for (int i = 0; i < bm && !is_done; ++i)
+    if (tok[i] == eos_id) {
+      record(i);
+      if (nf >= need) is_done = true;
+    }
+  if (!is_done && t >= max_steps) {  // Beam.py:79-84
+    is_done = true;
+    if (nf == 0)
+      for (int i = 0; i < bm; ++i) record(i);
+  }
+  n_fin[b] = nf;
+  if (is_done) done[b] = 1;
+}
+
+}  // namespace
+
+extern "C" int care_beam_select(const float* logits, int64_t ldl, int V, int bm, float* cand_val, int32_t* cand_idx,
+                                int rows, void* stream) {
+  if (!logits || !cand_val || !cand_idx || rows <= 0 || V <= 0) return CARE_EINVAL;
+  if (bm <= 0 || bm > MAXBM || bm > V) return CARE_ESHAPE;
+  hipLaunchKernelGGL(beam_select_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, bm, cand_val,
+                     cand_idx, rows);
+  return care_launch_status();
+}
+
+extern "C" int care_beam_advance(const float* cand_val, const int32_t* cand_idx, float* scores, int bm,
+                                 int32_t* tokphys, const int32_t* anc_old, int32_t* anc_new, int32_t* done,
+                                 int32_t* n_fin, int fin_cap, float* fin_score, int32_t* fin_len, int32_t* fin_hyp,
+                                 int t, int max_steps, int need, int eos_id, int V, int stride, int B, void* stream) {
+  if (!cand_val || !cand_idx || !scores || !tokphys || !anc_old || !anc_new || !done || !n_fin || !fin_score ||
+      !fin_len || !fin_hyp || B <= 0)
+    return CARE_EINVAL;
+  if (bm <= 0 || bm > MAXBM || t <= 0 || t >= stride || need > fin_cap) return CARE_ESHAPE;
+  hipLaunchKernelGGL(beam_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx,
+                     scores, bm, tokphys, anc_old, anc_new, done, n_fin, fin_score, fin_len, fin_hyp, fin_cap, t,
+                     max_steps, need, eos_id, V, stride, B);
+  return care_launch_status();
+}

@@ -1,0 +1,44 @@
+// care_common.h - shared device helpers for the gfx950 kernels of libcare_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/care_hip.h"
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define CARE_WAVE 64
+
+static inline int care_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+static inline bool care_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+__device__ __forceinline__ float care_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float care_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// load 8 consecutive elements of a K/V row as fp32
+__device__ __forceinline__ void care_load8(const float* p, float (&o)[8]) {
+  float4 a = *reinterpret_cast<const float4*>(p);
+  float4 b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+  o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void care_load8(const bf16_t* p, float (&o)[8]) {
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}

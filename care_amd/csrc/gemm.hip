@@ -1,0 +1,281 @@
+// gemm.hip - C = act(A * W^T + bias) on the gfx950 matrix cores.
+//
+// One templated kernel serves every nn.Linear of the path (see include/care_hip.h).
+//   * A is fp32 in HBM.  WT = float : exact f32 MFMA (v_mfma_f32_16x16x4_f32), the parity mode.
+//                        WT = bf16  : A is rounded to bf16 while it is staged into LDS,
+//                                     v_mfma_f32_16x16x32_bf16 with fp32 accumulation.
+//   * Both operand tiles are kept in LDS as rows of 128 bytes (32 f32 / 64 bf16 along K),
+//     XOR-swizzled in 16-byte chunks (chunk ^= row & 7) so that the ds_read_b128 of an MFMA
+//     fragment (16 rows x one chunk per 16-lane group) is bank-conflict free.
+//   * 256 threads = 4 waves in a 2x2 grid; each wave owns a (BM/2)x(BN/2) block of 16x16
+//     MFMA tiles.  Global->register->LDS staging, double-buffered: the loads of K-step
+//     t+1 are in flight while step t is multiplied.
+//   * f32 K order: lane group g = lane>>4 supplies k = 16*kk + 4*g + j to MFMA j of read kk
+//     for BOTH operands, so each lane reads 16 contiguous bytes; only the summation order
+//     differs from ascending k.
+//   * Epilogues: bias + activation + (split) store, or the fused per-row
+//     (max, argmax, sum-exp) of the greedy vocabulary projection.
+#include "care_common.h"
+
+namespace {
+
+struct GemmArgs {
+  const float* A; int64_t lda;
+  const void* W;
+  const float* bias;
+  void* C0; int64_t ldc0; int c0_bf16;
+  void* C1; int64_t ldc1; int c1_bf16;
+  int n_split;
+  int M, N, K;
+  int act;
+  float* pmax; int32_t* pidx; float* psum; int parts;
+};
+
+template <typename WT> struct KTraits;
+template <> struct KTraits<float>  { static constexpr int BK = 32; };
+template <> struct KTraits<bf16_t> { static constexpr int BK = 64; };
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == CARE_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == CARE_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+
+__device__ __forceinline__ void store_out(void* C, int64_t ld, int is_bf16, int row, int col, float v) {
+  if (is_bf16) reinterpret_cast<bf16_t*>(C)[(int64_t)row * ld + col] = (bf16_t)v;
+  else reinterpret_cast<float*>(C)[(int64_t)row * ld + col] = v;
+}
+
+template <typename WT, int BM, int BN, bool ARGMAX>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+  constexpr int BK = KTraits<WT>::BK;
+  constexpr bool BF = sizeof(WT) == 2;
+  constexpr int MT = BM / 32, NT = BN / 32;
+  // A staging: f32 mode 8 16-byte chunks per row, bf16 mode 16 float4 per row (-> 8 bytes each)
+  constexpr int A_CH = BF ? 16 : 8;
+  constexpr int A_IT = BM * A_CH / 256;
+  constexpr int W_IT = BN * 8 / 256;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;                    // 2 x BM x 128
+  unsigned char* sB = smem + 2 * BM * 128;     // 2 x BN x 128
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM;
+  const int n0 = (blockIdx.x % tiles_n) * BN;
+
+  float4 ra[A_IT];
+  uint4 rw[W_IT];
+
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int c = i * 256 + tid;
+      int row = c / A_CH, ch = c % A_CH;
+      int gr = m0 + row;
+      if (gr < p.M) ra[i] = *reinterpret_cast<const float4*>(p.A + (int64_t)gr * p.lda + k0 + ch * 4);
+      else ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      int c = i * 256 + tid;
+      int row = c >> 3, ch = c & 7;
+      int gn = n0 + row;
+      if (gn < p.N)
+        rw[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.W) +
+                                                ((int64_t)gn * p.K + k0) * sizeof(WT) + ch * 16);
+      else rw[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* a = sA + buf * BM * 128;
+    unsigned char* b = sB + buf * BN * 128;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int c = i * 256 + tid;
+      int row = c / A_CH, ch = c % A_CH;
+      if constexpr (BF) {
+        bf16x4 v;
+        v[0] = (bf16_t)ra[i].x; v[1] = (bf16_t)ra[i].y; v[2] = (bf16_t)ra[i].z; v[3] = (bf16_t)ra[i].w;
+        *reinterpret_cast<bf16x4*>(a + row * 128 + ((((ch >> 1) ^ (row & 7))) << 4) + (ch & 1) * 8) = v;
+      } else {
+        *reinterpret_cast<float4*>(a + row * 128 + ((ch ^ (row & 7)) << 4)) = ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      int c = i * 256 + tid;
+      int row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(b + row * 128 + ((ch ^ (row & 7)) << 4)) = rw[i];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    const unsigned char* a = sA + buf * BM * 128 + (wm * (BM / 2) + fr) * 128;
+    const unsigned char* b = sB + buf * BN * 128 + (wn * (BN / 2) + fr) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int off = ((kk * 4 + fg) ^ (fr & 7)) << 4;
+      if constexpr (BF) {
+        bf16x8 fa[MT], fb[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const bf16x8*>(a + m * 16 * 128 + off);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(b + n * 16 * 128 + off);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+      } else {
+        f32x4 fa[MT], fb[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const f32x4*>(a + m * 16 * 128 + off);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const f32x4*>(b + n * 16 * 128 + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][j], fb[n][j], acc[m][n], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const int row_base = m0 + wm * (BM / 2) + fg * 4;
+  const int col_base = n0 + wn * (BN / 2) + fr;
+  if constexpr (!ARGMAX) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = col_base + n * 16;
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.0f;
+      const bool second = col >= p.n_split;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = row_base + m * 16 + j;
+          if (row >= p.M) continue;
+          float v = apply_act(acc[m][n][j] + bv, p.act);
+          if (!second) store_out(p.C0, p.ldc0, p.c0_bf16, row, col, v);
+          else store_out(p.C1, p.ldc1, p.c1_bf16, row, col - p.n_split, v);
+        }
+    }
+  } else {
+    // per row of this wave's (BM/2) x (BN/2) block: max, first argmax, sum exp(x - max)
+    const int part = (n0 / BN) * 2 + wn;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int col = col_base + n * 16;
+          const float v = col < p.N ? acc[m][n][j] : -INFINITY;
+          if (v > best) { best = v; bi = col; }   // columns ascend with n: first max kept
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          const float ov = __shfl_xor(best, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int col = col_base + n * 16;
+          if (col < p.N) s += __expf(acc[m][n][j] - best);
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+        const int row = row_base + m * 16 + j;
+        if (fr == 0 && row < p.M) {
+          const int64_t o = (int64_t)row * p.parts + part;
+          p.pmax[o] = best; p.pidx[o] = bi; p.psum[o] = s;
+        }
+      }
+  }
+}
+
+template <typename WT, int BM, int BN, bool ARGMAX>
+int launch(const GemmArgs& p, hipStream_t st) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const size_t lds = 2 * (BM + BN) * 128;
+  hipLaunchKernelGGL((gemm_kernel<WT, BM, BN, ARGMAX>), dim3(tiles), dim3(256), lds, st, p);
+  return care_launch_status();
+}
+
+int check_common(const float* A, int64_t lda, const void* W, int wdtype, int M, int N, int K) {
+  if (!A || !W || M <= 0 || N <= 0 || K <= 0) return CARE_EINVAL;
+  if (wdtype != CARE_F32 && wdtype != CARE_BF16) return CARE_EDTYPE;
+  if (K % (wdtype == CARE_BF16 ? 64 : 32) != 0) return CARE_ESHAPE;
+  if (!care_aligned16(A) || !care_aligned16(W) || (lda % 4) != 0) return CARE_EALIGN;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int care_gemm(const float* A, int64_t lda, const void* W, int wdtype, const float* bias,
+                         void* C0, int64_t ldc0, int c0_dtype, void* C1, int64_t ldc1, int c1_dtype,
+                         int n_split, int M, int N, int K, int act, void* stream) {
+  int rc = check_common(A, lda, W, wdtype, M, N, K);
+  if (rc) return rc;
+  if (!C0 || n_split <= 0 || n_split > N || (n_split < N && !C1)) return CARE_EINVAL;
+  if (n_split % 16 != 0 && n_split != N) return CARE_ESHAPE;
+  if (act < CARE_ACT_NONE || act > CARE_ACT_GELU) return CARE_EDTYPE;
+  if ((c0_dtype != CARE_F32 && c0_dtype != CARE_BF16) || (C1 && c1_dtype != CARE_F32 && c1_dtype != CARE_BF16))
+    return CARE_EDTYPE;
+  GemmArgs p{};
+  p.A = A; p.lda = lda; p.W = W; p.bias = bias;
+  p.C0 = C0; p.ldc0 = ldc0; p.c0_bf16 = c0_dtype == CARE_BF16;
+  p.C1 = C1; p.ldc1 = ldc1; p.c1_bf16 = c1_dtype == CARE_BF16;
+  p.n_split = n_split; p.M = M; p.N = N; p.K = K; p.act = act;
+  hipStream_t st = (hipStream_t)stream;
+  const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const bool big = big_tiles >= 192;
+  if (wdtype == CARE_BF16)
+    return big ? launch<bf16_t, 128, 128, false>(p, st) : launch<bf16_t, 64, 64, false>(p, st);
+  return big ? launch<float, 128, 128, false>(p, st) : launch<float, 64, 64, false>(p, st);
+}
+
+extern "C" int care_argmax_parts(int N) { return N > 0 ? 2 * ((N + 127) / 128) : CARE_EINVAL; }
+
+extern "C" int care_gemm_argmax(const float* A, int64_t lda, const void* W, int wdtype, float* pmax,
+                                int32_t* pidx, float* psum, int M, int N, int K, void* stream) {
+  int rc = check_common(A, lda, W, wdtype, M, N, K);
+  if (rc) return rc;
+  if (!pmax || !pidx || !psum) return CARE_EINVAL;
+  GemmArgs p{};
+  p.A = A; p.lda = lda; p.W = W; p.M = M; p.N = N; p.K = K; p.n_split = N;
+  p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.parts = care_argmax_parts(N);
+  hipStream_t st = (hipStream_t)stream;
+  const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const bool big = big_tiles >= 192;
+  if (wdtype == CARE_BF16)
+    return big ? launch<bf16_t, 128, 128, true>(p, st) : launch<bf16_t, 64, 128, true>(p, st);
+  return big ? launch<float, 128, 128, true>(p, st) : launch<float, 64, 128, true>(p, st);
+}

@@ -1,0 +1,279 @@
+// rowops.hip - HBM-bound row kernels: LayerNorm epilogues, embeddings, concept head, greedy state.
+//
+// All of these move a few KB per row and do O(d) work, so the design rule is simply:
+// one 64-lane wave per row, every access a coalesced float4, statistics in fp32 via
+// wave shuffles (no LDS), 4 rows per 256-thread workgroup.  A row of d <= 2048 fp32
+// stays in registers between the statistics and the normalisation (read once, write once).
+#include "care_common.h"
+
+namespace {
+
+constexpr int MAXV = 8;  // float4 per lane: d <= 64 * 4 * 8 = 2048
+
+// LayerNorm of one row held as v[0..nv) float4 per lane (chunk index = lane + 64*i).
+__device__ __forceinline__ void row_layernorm(float4 (&v)[MAXV], int nv4, int lane, int d,
+                                              const float* gamma, const float* beta, float eps,
+                                              float* out) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (lane + 64 * i < nv4) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = care_wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (lane + 64 * i < nv4) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + e * e);
+    }
+  const float var = care_wave_sum(q) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < nv4) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      *reinterpret_cast<float4*>(out + c4 * 4) = o;
+    }
+  }
+}
+
+__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+__global__ __launch_bounds__(256) void add_ln_kernel(const float* x, int64_t ldx, const float* res, int64_t ldres,
+                                                     const float* pos, const float* gamma, const float* beta,
+                                                     float eps, float* out, int64_t ldo, int rows, int d, int grp,
+                                                     int out_grp_rows, int out_row_off) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int nv4 = d >> 2;
+  float4 v[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < nv4) {
+      v[i] = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + c4 * 4);
+      if (res) add4(v[i], *reinterpret_cast<const float4*>(res + (int64_t)r * ldres + c4 * 4));
+      if (pos) add4(v[i], *reinterpret_cast<const float4*>(pos + (int64_t)(r % grp) * d + c4 * 4));
+    }
+  }
+  const int64_t orow = (int64_t)(r / grp) * out_grp_rows + out_row_off + (r % grp);
+  row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + orow * ldo);
+}
+
+__global__ __launch_bounds__(256) void group_mean_kernel(const float* x, int64_t ldx, int in_grp_rows, int in_row_off,
+                                                         int grp, float* out, int64_t ldo, int col_off, int groups,
+                                                         int d) {
+  // one thread per (group, float4 column): consecutive threads read consecutive float4
+  const int nv4 = d >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)groups * nv4) return;
+  const int g = (int)(idx / nv4), c4 = (int)(idx % nv4);
+  const float* p = x + ((int64_t)g * in_grp_rows + in_row_off) * ldx + c4 * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < grp; ++i) add4(s, *reinterpret_cast<const float4*>(p + (int64_t)i * ldx));
+  const float inv = 1.0f / (float)grp;
+  s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+  *reinterpret_cast<float4*>(out + (int64_t)g * ldo + col_off + c4 * 4) = s;
+}
+
+__global__ __launch_bounds__(256) void concept_finish_kernel(const float* scores, int64_t lds, float* preds,
+                                                             int64_t ldp, float* avg, int B, int k) {
+  // one wave per clip
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float psum = 0.f;
+  for (int c = lane; c < ldp; c += 64) {
+    float out = 0.f;
+    if (c < k) {
+      const float s = scores[(int64_t)b * lds + c];
+      const float p = 1.0f / (1.0f + expf(-s));
+      psum += p;
+      const float raw = logf(fminf(fmaxf(1.0f - p, 1e-12f), 1.0f));
+      out = 1.0f - expf(raw);
+    }
+    preds[(int64_t)b * ldp + c] = out;
+  }
+  psum = care_wave_sum(psum);
+  if (lane == 0) avg[b] = psum / (float)k;
+}
+
+__global__ __launch_bounds__(256) void concept_topk_embed_kernel(const float* preds, int64_t ldp, int k, int topk,
+                                                                 const float* word, const float* pos,
+                                                                 const float* gamma, const float* beta, float eps,
+                                                                 int64_t* labels, float* out, int64_t ldo,
+                                                                 int out_grp_rows, int out_row_off, int d) {
+  // one workgroup per clip.  Rank by counting: rank(i) = #{j : v[j] > v[i] or (v[j] == v[i] and j < i)};
+  // the element of rank r < topk is label r (value desc, index asc) - no iterative selection.
+  __shared__ float sv[1024];
+  __shared__ int slab[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < k; i += 256) sv[i] = preds[(int64_t)b * ldp + i];
+  __syncthreads();
+  for (int i = tid; i < k; i += 256) {
+    const float vi = sv[i];
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const float vj = sv[j];
+      rank += (vj > vi) || (vj == vi && j < i);
+    }
+    if (rank < topk) slab[rank] = i;
+  }
+  __syncthreads();
+  if (tid < topk) labels[(int64_t)b * topk + tid] = slab[tid];
+  const int lane = tid & 63, wave = tid >> 6, nv4 = d >> 2;
+  for (int j = wave; j < topk; j += 4) {
+    const float* w = word + (int64_t)slab[j] * d;
+    const float* pp = pos + (int64_t)j * d;
+    float4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < nv4) {
+        v[i] = *reinterpret_cast<const float4*>(w + c4 * 4);
+        add4(v[i], *reinterpret_cast<const float4*>(pp + c4 * 4));
+      }
+    }
+    row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + ((int64_t)b * out_grp_rows + out_row_off + j) * ldo);
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* tokens, int tok_stride, int tok_off,
+                                                       const int32_t* anc, int anc_stride, const float* word,
+                                                       const float* pos, int pos0, const float* sem, int sem_div,
+                                                       const float* gamma, const float* beta, float eps, float* out,
+                                                       int64_t ldo, int rows, int seq, int d) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int s = r / seq, i = r % seq, col = tok_off + i;
+  const int trow = anc ? anc[(int64_t)s * anc_stride + col] : s;
+  const int tok = tokens[(int64_t)trow * tok_stride + col];
+  const float* w = word + (int64_t)tok * d;
+  const float* pp = pos + (int64_t)(pos0 + i) * d;
+  const float* sm = sem ? sem + (int64_t)(r / sem_div) * d : nullptr;
+  const int nv4 = d >> 2;
+  float4 v[MAXV];
+#pragma unroll
+  for (int c = 0; c < MAXV; ++c) {
+    const int c4 = lane + 64 * c;
+    if (c4 < nv4) {
+      v[c] = *reinterpret_cast<const float4*>(w + c4 * 4);
+      add4(v[c], *reinterpret_cast<const float4*>(pp + c4 * 4));
+      if (sm) add4(v[c], *reinterpret_cast<const float4*>(sm + c4 * 4));
+    }
+  }
+  row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + (int64_t)r * ldo);
+}
+
+__global__ __launch_bounds__(256) void greedy_update_kernel(const float* pmax, const int32_t* pidx, const float* psum,
+                                                            int parts, int32_t* fed, int fed_stride, float* score,
+                                                            int32_t* length, int32_t* finished, int t, int max_steps,
+                                                            int eos_id, int rows) {
+  // one wave per row: reduce the column-group partials (lowest index wins ties)
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < parts; c += 64) {
+    const float v = pmax[(int64_t)r * parts + c];
+    const int id = pidx[(int64_t)r * parts + c];
+    if (v > best || (v == best && id < bi)) { best = v; bi = id; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  float s = 0.f;
+  for (int c = lane; c < parts; c += 64)
+    s += psum[(int64_t)r * parts + c] * expf(pmax[(int64_t)r * parts + c] - best);
+  s = care_wave_sum(s);
+  if (lane == 0) {
+    fed[(int64_t)r * fed_stride + t] = bi;  // always feed the token: frozen rows still run
+    if (!finished[r]) {
+      score[r] += -logf(s);
+      length[r] = t;
+      if (bi == eos_id || t >= max_steps) finished[r] = 1;
+    }
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int care_add_ln(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* pos,
+                           const float* gamma, const float* beta, float eps, float* out, int64_t ldo, int rows,
+                           int d, int grp, int out_grp_rows, int out_row_off, void* stream) {
+  if (!x || !gamma || !beta || !out || rows <= 0 || d <= 0 || grp <= 0) return CARE_EINVAL;
+  if (d % 4 != 0 || d > 2048) return CARE_ESHAPE;
+  if ((ldx % 4) || (ldo % 4) || (res && (ldres % 4)) || !care_aligned16(x) || !care_aligned16(out)) return CARE_EALIGN;
+  hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, x, ldx, res, ldres, pos, gamma, beta, eps,
+                     out, ldo, rows, d, grp, out_grp_rows, out_row_off);
+  return care_launch_status();
+}
+
+extern "C" int care_group_mean(const float* x, int64_t ldx, int in_grp_rows, int in_row_off, int grp, float* out,
+                               int64_t ldo, int col_off, int groups, int d, void* stream) {
+  if (!x || !out || groups <= 0 || d <= 0 || grp <= 0) return CARE_EINVAL;
+  if (d % 4 != 0) return CARE_ESHAPE;
+  if ((ldx % 4) || (ldo % 4) || (col_off % 4)) return CARE_EALIGN;
+  const int64_t n = (int64_t)groups * (d / 4);
+  hipLaunchKernelGGL(group_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, x, ldx, in_grp_rows,
+                     in_row_off, grp, out, ldo, col_off, groups, d);
+  return care_launch_status();
+}
+
+extern "C" int care_concept_finish(const float* scores, int64_t lds, float* preds, int64_t ldp, float* avg, int B,
+                                   int k, void* stream) {
+  if (!scores || !preds || !avg || B <= 0 || k <= 0 || ldp < k) return CARE_EINVAL;
+  hipLaunchKernelGGL(concept_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, scores, lds, preds, ldp, avg, B, k);
+  return care_launch_status();
+}
+
+extern "C" int care_concept_topk_embed(const float* preds, int64_t ldp, int k, int topk, const float* word,
+                                       const float* pos, const float* gamma, const float* beta, float eps,
+                                       int64_t* labels, float* out, int64_t ldo, int out_grp_rows, int out_row_off,
+                                       int B, int d, void* stream) {
+  if (!preds || !word || !pos || !gamma || !beta || !labels || !out || B <= 0) return CARE_EINVAL;
+  if (k <= 0 || k > 1024 || topk <= 0 || topk > 64 || topk > k || d % 4 != 0 || d > 2048) return CARE_ESHAPE;
+  hipLaunchKernelGGL(concept_topk_embed_kernel, dim3(B), dim3(256), 0, ST, preds, ldp, k, topk, word, pos, gamma, beta,
+                     eps, labels, out, ldo, out_grp_rows, out_row_off, d);
+  return care_launch_status();
+}
+
+extern "C" int care_embed_ln(const int32_t* tokens, int tok_stride, int tok_off, const int32_t* anc, int anc_stride,
+                             const float* word, const float* pos, int pos0, const float* sem, int sem_div,
+                             const float* gamma, const float* beta, float eps, float* out, int64_t ldo, int rows,
+                             int seq, int d, void* stream) {
+  if (!tokens || !word || !pos || !gamma || !beta || !out || rows <= 0 || seq <= 0 || sem_div <= 0) return CARE_EINVAL;
+  if (d % 4 != 0 || d > 2048) return CARE_ESHAPE;
+  if (ldo % 4) return CARE_EALIGN;
+  hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, tokens, tok_stride, tok_off, anc,
+                     anc_stride, word, pos, pos0, sem, sem_div, gamma, beta, eps, out, ldo, rows, seq, d);
+  return care_launch_status();
+}
+
+extern "C" int care_greedy_update(const float* pmax, const int32_t* pidx, const float* psum, int parts, int32_t* fed,
+                                  int fed_stride, float* score, int32_t* length, int32_t* finished, int t,
+                                  int max_steps, int eos_id, int rows, void* stream) {
+  if (!pmax || !pidx || !psum || !fed || !score || !length || !finished || rows <= 0 || parts <= 0) return CARE_EINVAL;
+  if (t <= 0 || t >= fed_stride) return CARE_ESHAPE;
+  hipLaunchKernelGGL(greedy_update_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, pmax, pidx, psum, parts, fed,
+                     fed_stride, score, length, finished, t, max_steps, eos_id, rows);
+  return care_launch_status();
+}
+
+extern "C" int care_version(void) { return CARE_ABI_VERSION; }
+extern "C" const char* care_arch(void) { return "gfx950"; }

@@ -1,0 +1,433 @@
+"""Host-side orchestration of the HIP kernels for the captioning forward path.
+
+`HipEngine` owns the packed device weights and the workspaces, and issues the kernels of
+libcare_hip.so (include/care_hip.h) on torch's current HIP stream.  PyTorch is used for
+device memory and streams only; every FLOP of the path runs in hand-written kernels.
+There is no CPU or eager fallback: without the library or a GPU, calls raise.
+
+Compared with the reference the engine
+  * projects the cross-attention K/V of the static memory ONCE per clip and shares them
+    between the beams of a clip (reference: every step, every beam copy);
+  * keeps an incremental self-attention K/V cache (reference: full-prefix recompute);
+  * keeps greedy/beam state on the device for all 29 steps (reference: D2H sync per step);
+  * writes the encoder streams and concept rows straight into the [B, Lk, d] memory
+    (reference: torch.cat copies).
+These are numerically equivalent re-orderings of the same math (decoder is causal and
+post-LN, eval-mode dropout is identity).
+"""
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_CODES, CARE_BF16, CARE_F32, call, ptr
+from .constants import BOS, EOS, PAD
+
+
+def _code(t: Optional[torch.Tensor]) -> int:
+    return CARE_BF16 if (t is not None and t.dtype == torch.bfloat16) else CARE_F32
+
+
+class HipEngine:
+    def __init__(self, opt: dict, dtype: str = "fp32"):
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError("compute dtype must be 'fp32' or 'bf16', got {!r}".format(dtype))
+        self.opt = opt
+        self.dtype = dtype
+        self.wt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.d = int(opt["dim_hidden"])
+        self.H = int(opt["num_attention_heads"])
+        if self.d != self.H * 64:
+            raise ValueError("the attention kernel is specialised for head dim 64 (archs.yaml:15-26)")
+        self.ff = int(opt["intermediate_size"])
+        self.V = int(opt["vocab_size"])
+        self.T = int(opt["max_len"]) - 1
+        self.eps = float(opt["layer_norm_eps"])
+        self.act = ACT_CODES[opt["hidden_act"]]
+        self.modality = opt["modality"]
+        self.dec_mod = opt.get("modality_for_decoder") or self.modality
+        self.pred_mod = opt.get("modality_for_predictor") or self.modality
+        self.has_concepts = "attribute" in opt.get("crits", [])
+        self.has_container = "SemanticContainer" in opt.get("predictors_to_be_added", [])
+        self.use_attr_type = opt.get("use_attr_type", "") if self.has_container else ""
+        self.concat = "concat" in self.use_attr_type
+        self.sem = "emb" in self.use_attr_type
+        self.topk = int(opt.get("use_attr_topk", 30))
+        self.k_attr = int(opt.get("attribute_prediction_k", 500))
+        self.n_layers = int(opt["num_hidden_layers_decoder"])
+        self.rows_of = {ch: (int(opt["retrieval_topk"]) if ch == "r" else int(opt["n_frames"])) for ch in self.modality}
+        self.mem_off = {}
+        off = 0
+        for ch in self.modality:
+            if ch in self.dec_mod:
+                self.mem_off[ch] = off
+                off += self.rows_of[ch]
+        self.concept_off = off
+        self.Lk = off + (self.topk if self.concat else 0)
+        if self.Lk > 128:
+            raise ValueError("memory length {} > 128 keys is outside the attention kernel".format(self.Lk))
+        self.w: Dict[str, torch.Tensor] = {}
+        self.device = None
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._graphs: Dict[tuple, object] = {}
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, sd: Dict[str, torch.Tensor], device) -> None:
+        """Pack a reference-named state dict into the device layout the kernels read."""
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.CareHipError("no HIP device: the captioning path has no CPU fallback")
+        self.device = torch.device(device)
+        f32 = lambda t: t.detach().to(self.device, torch.float32).contiguous()
+        wt = lambda t: t.detach().to(self.device, torch.float32).to(self.wt).contiguous()
+        w = {}
+        opt, d = self.opt, self.d
+        for ch in self.modality:
+            p = "encoder.Encoder_{}".format(ch.upper())
+            w["enc_w_" + ch], w["enc_b_" + ch] = wt(sd[p + ".0.weight"]), f32(sd[p + ".0.bias"])
+            if opt["encoder"] == "Embedder":
+                w["enc_g_" + ch], w["enc_be_" + ch] = f32(sd[p + ".1.weight"]), f32(sd[p + ".1.bias"])
+            elif opt["encoder"] == "MultiTransformerEncoder":
+                q = p + ".1"
+                if opt.get("trainable_pe", False):
+                    w["enc_pos_" + ch] = f32(sd[q + ".position_embeddings.weight"])
+                else:
+                    w["enc_pos_" + ch] = f32(sd[q + ".position_embeddings.pe"][0])
+                w["enc_g_" + ch], w["enc_be_" + ch] = f32(sd[q + ".LayerNorm.weight"]), f32(sd[q + ".LayerNorm.bias"])
+                for li in range(int(opt["num_hidden_layers_encoder"])):
+                    self._pack_attn(w, sd, "{}.layers.{}.intra_attention".format(q, li), "enc{}{}_sa".format(ch, li), True, wt, f32)
+                    self._pack_ffn(w, sd, "{}.layers.{}.ffn".format(q, li), "enc{}{}_ffn".format(ch, li), wt, f32)
+            else:
+                raise ValueError("encoder `{}` is outside the hot path (SURVEY.md 8(a))".format(opt["encoder"]))
+        if self.has_concepts:
+            if not (opt.get("attribute_prediction_mean_pooling") and opt.get("attribute_prediction_channel_concat")):
+                raise ValueError("only the CARE concept head (mean pooling + channel concat) is on the hot path")
+            w["attr_w"], w["attr_b"] = f32(sd["predictor.nets.0.prj.weight"]), f32(sd["predictor.nets.0.prj.bias"])
+            if self.has_container:
+                sp = "predictor.nets.1"
+                w["attr_word"] = f32(sd[sp + ".attr_embs.word_embeddings.weight"])
+                w["attr_pos"] = f32(sd[sp + ".attr_embs.position_embeddings.weight"])
+                w["attr_g"], w["attr_be"] = f32(sd[sp + ".attr_embs.LayerNorm.weight"]), f32(sd[sp + ".attr_embs.LayerNorm.bias"])
+                if self.sem:
+                    kp = self._kpad()
+                    s2h = torch.zeros(d, kp, device=self.device, dtype=torch.float32)
+                    s2h[:, : self.k_attr] = f32(sd[sp + ".semantic2hidden.weight"])
+                    w["s2h_w"] = s2h
+                    b = sd.get(sp + ".semantic2hidden.bias")
+                    w["s2h_b"] = f32(b) if b is not None else None
+        e = "decoder.embedding"
+        w["word"] = f32(sd[e + ".word_embeddings.weight"])
+        if opt.get("trainable_pe", False):
+            w["pos"] = f32(sd[e + ".position_embeddings.weight"])
+        else:
+            w["pos"] = f32(sd[e + ".position_embeddings.pe"][0])
+        w["emb_g"], w["emb_be"] = f32(sd[e + ".LayerNorm.weight"]), f32(sd[e + ".LayerNorm.bias"])
+        for li in range(self.n_layers):
+            lp = "decoder.layers.{}".format(li)
+            self._pack_attn(w, sd, lp + ".intra_attention", "d{}_sa".format(li), True, wt, f32)
+            self._pack_attn(w, sd, lp + ".inter_attention", "d{}_ca".format(li), False, wt, f32)
+            hb = sd.get(lp + ".inter_attention.SDPA.hybrid_bias")
+            if hb is not None and hb.shape[1] != self.Lk:
+                raise ValueError("hybrid_bias length {} != memory length {}".format(hb.shape[1], self.Lk))
+            w["d{}_hb".format(li)] = f32(hb) if hb is not None else None
+            self._pack_ffn(w, sd, lp + ".ffn", "d{}_ffn".format(li), wt, f32)
+        w["vocab"] = wt(sd["cls_head.tgt_word_prj.weight"])
+        self.w = w
+        self._graphs.clear()
+
+    def _pack_attn(self, w, sd, p, name, self_attn, wt, f32):
+        wq, wk, wv = (sd[p + ".SDPA.{}.weight".format(n)] for n in ("query", "key", "value"))
+        bq, bk, bv = (sd.get(p + ".SDPA.{}.bias".format(n)) for n in ("query", "key", "value"))
+        zeros = lambda m: torch.zeros(m.shape[0], dtype=torch.float32)
+        bq, bk, bv = (b if b is not None else zeros(m) for b, m in ((bq, wq), (bk, wk), (bv, wv)))
+        if self_attn:  # one [3d, d] projection
+            w[name + "_qkv_w"] = wt(torch.cat([wq, wk, wv], 0))
+            w[name + "_qkv_b"] = f32(torch.cat([bq, bk, bv], 0))
+        else:
+            w[name + "_q_w"], w[name + "_q_b"] = wt(wq), f32(bq)
+            w[name + "_kv_w"], w[name + "_kv_b"] = wt(torch.cat([wk, wv], 0)), f32(torch.cat([bk, bv], 0))
+        w[name + "_o_w"], w[name + "_o_b"] = wt(sd[p + ".dense.weight"]), f32(sd[p + ".dense.bias"])
+        w[name + "_g"], w[name + "_be"] = f32(sd[p + ".LayerNorm.weight"]), f32(sd[p + ".LayerNorm.bias"])
+
+    def _pack_ffn(self, w, sd, p, name, wt, f32):
+        w[name + "_w1"], w[name + "_b1"] = wt(sd[p + ".dense1.weight"]), f32(sd[p + ".dense1.bias"])
+        w[name + "_w2"], w[name + "_b2"] = wt(sd[p + ".dense2.weight"]), f32(sd[p + ".dense2.bias"])
+        w[name + "_g"], w[name + "_be"] = f32(sd[p + ".LayerNorm.weight"]), f32(sd[p + ".LayerNorm.bias"])
+
+    def _kpad(self) -> int:
+        return (self.k_attr + 31) // 32 * 32
+
+    # ------------------------------------------------------------------ helpers
+    def ws(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        """Named, cached workspace (allocated on first use, reused afterwards)."""
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.empty(shape, device=self.device, dtype=dtype)
+            self._ws[key] = t
+        return t
+
+    def gemm(self, A, W, bias, out, act=0, out2=None, n_split=None):
+        M, K = A.shape
+        N = W.shape[0]
+        assert W.shape[1] == K and A.stride(1) == 1 and out.stride(-1) == 1
+        call("care_gemm", ptr(A), A.stride(0), ptr(W), _code(W), ptr(bias), ptr(out), out.stride(0), _code(out),
+             ptr(out2), out2.stride(0) if out2 is not None else 0, _code(out2), N if n_split is None else n_split,
+             M, N, K, act)
+        return out
+
+    def add_ln(self, x, res, g, be, out, grp=None, out_grp_rows=None, out_row_off=0, pos=None):
+        rows, d = x.shape
+        grp = rows if grp is None else grp
+        out_grp_rows = grp if out_grp_rows is None else out_grp_rows
+        call("care_add_ln", ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(pos), ptr(g),
+             ptr(be), self.eps, ptr(out), out.stride(-2), rows, d, grp, out_grp_rows, out_row_off)
+        return out
+
+    def attention(self, Q, K, V, ctx, kv_batch_stride, kv_row_stride, rows_per_kv, nkeys, anc=None, causal=False,
+                  seq=1, pad_tok=None, bias=None):
+        rows = Q.shape[0]
+        call("care_attention", ptr(Q), Q.stride(0), ptr(K), ptr(V), _code(K), kv_batch_stride, kv_row_stride,
+             rows_per_kv, ptr(anc), anc.stride(0) if anc is not None else 0, nkeys, 1 if causal else 0, seq, 0,
+             ptr(pad_tok), pad_tok.stride(0) if pad_tok is not None else 0, PAD, ptr(bias),
+             bias.stride(0) if bias is not None else 0, ptr(ctx), ctx.stride(0), rows, self.H)
+        return ctx
+
+    def _mha_self_full(self, name, x, seq, pad_tok, causal, tag):
+        """Self-attention sub-block over whole sequences (teacher forcing / encoder)."""
+        rows, d = x.shape
+        w = self.w
+        qkv = self.gemm(x, w[name + "_qkv_w"], w[name + "_qkv_b"], self.ws(tag + "qkv", (rows, 3 * d)))
+        ctx = self.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], self.ws(tag + "ctx", (rows, d)), seq * 3 * d, 3 * d,
+                             seq, seq, causal=causal, seq=seq, pad_tok=pad_tok)
+        o = self.gemm(ctx, w[name + "_o_w"], w[name + "_o_b"], self.ws(tag + "o", (rows, d)))
+        return self.add_ln(o, x, w[name + "_g"], w[name + "_be"], self.ws(tag + "x1", (rows, d)))
+
+    def _ffn(self, name, x, out, tag, **ln_kw):
+        rows, d = x.shape
+        w = self.w
+        h = self.gemm(x, w[name + "_w1"], w[name + "_b1"], self.ws(tag + "h", (rows, self.ff)), act=self.act)
+        f = self.gemm(h, w[name + "_w2"], w[name + "_b2"], self.ws(tag + "f", (rows, d)))
+        return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, **ln_kw)
+
+    # ------------------------------------------------------------------ encoder + concept head
+    def encode(self, feats: List[torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """`Seq2SeqBase.encoding_phase` (models/Framework.py:150-187); outputs are fresh tensors."""
+        w, d, opt = self.w, self.d, self.opt
+        if len(feats) < len(self.modality):
+            raise ValueError("expected {} feature tensors, got {}".format(len(self.modality), len(feats)))
+        B = feats[0].shape[0]
+        mem = torch.empty(B, self.Lk, d, device=self.device)
+        means = torch.empty(B, len(self.modality) * d, device=self.device)
+        for mi, ch in enumerate(self.modality):
+            x = feats[mi].to(self.device, torch.float32).contiguous()
+            n = x.shape[1]
+            if n != self.rows_of[ch]:
+                raise ValueError("modality `{}`: {} rows, expected {}".format(ch, n, self.rows_of[ch]))
+            x2 = x.view(B * n, x.shape[2])
+            lin = self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch], self.ws("enc_lin", (B * n, d)))
+            in_mem = ch in self.dec_mod
+            if in_mem:
+                dst, grp_rows, off = mem, self.Lk, self.mem_off[ch]
+            else:
+                dst, grp_rows, off = self.ws("enc_side_" + ch, (B, n, d)), n, 0
+            ln_kw = dict(grp=n, out_grp_rows=grp_rows, out_row_off=off)
+            if opt["encoder"] == "Embedder":
+                self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], dst, **ln_kw)
+            else:  # MultiTransformerEncoder
+                h = self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], self.ws("enc_h0", (B * n, d)),
+                                grp=n, pos=w["enc_pos_" + ch])
+                n_enc = int(opt["num_hidden_layers_encoder"])
+                for li in range(n_enc):
+                    nm = "enc{}{}".format(ch, li)
+                    h1 = self._mha_self_full(nm + "_sa", h, n, None, False, "enc_")
+                    last = li == n_enc - 1
+                    h = self._ffn(nm + "_ffn", h1, dst if last else self.ws("enc_h%d" % (li + 1), (B * n, d)), "enc_",
+                                  **(ln_kw if last else {}))
+            call("care_group_mean", ptr(dst), d, grp_rows, off, n, ptr(means), means.stride(0), mi * d, B, d)
+        out: Dict[str, torch.Tensor] = {"encoder_hidden_states": mem}
+        out["mean_encoder_hidden_states"] = [means[:, mi * d:(mi + 1) * d] for mi, ch in enumerate(self.modality)
+                                             if ch in self.dec_mod]
+        if self.has_concepts:
+            if self.pred_mod == self.modality:
+                pm = means
+            else:
+                pm = torch.cat([means[:, mi * d:(mi + 1) * d] for mi, ch in enumerate(self.modality)
+                                if ch in self.pred_mod], dim=1).contiguous()
+            kp = self._kpad()
+            scores = self.gemm(pm, w["attr_w"], w["attr_b"], self.ws("attr_scores", (B, kp)))
+            preds = torch.empty(B, kp, device=self.device)
+            avg = torch.empty(B, device=self.device)
+            call("care_concept_finish", ptr(scores), kp, ptr(preds), kp, ptr(avg), B, self.k_attr)
+            out["preds_attr"] = preds[:, : self.k_attr]
+            out["avg_prob_attr"] = avg
+            if self.has_container:
+                labels = torch.empty(B, self.topk, device=self.device, dtype=torch.int64)
+                if self.concat:
+                    dst, grp_rows, off = mem, self.Lk, self.concept_off
+                else:
+                    dst, grp_rows, off = torch.empty(B, self.topk, d, device=self.device), self.topk, 0
+                call("care_concept_topk_embed", ptr(preds), kp, self.k_attr, self.topk, ptr(w["attr_word"]),
+                     ptr(w["attr_pos"]), ptr(w["attr_g"]), ptr(w["attr_be"]), self.eps, ptr(labels), ptr(dst), d,
+                     grp_rows, off, B, d)
+                out["semantic_labels"] = labels
+                out["semantic_embs"] = dst[:, off: off + self.topk]
+                if self.sem:
+                    out["semantic_hidden_states"] = self.gemm(preds, w["s2h_w"], w["s2h_b"],
+                                                              torch.empty(B, d, device=self.device))
+                else:
+                    out["semantic_hidden_states"] = None
+        return out
+
+    # ------------------------------------------------------------------ cross K/V (once per clip)
+    def cross_kv(self, mem: torch.Tensor, tag="ckv") -> List[torch.Tensor]:
+        """K/V of the static memory for every decoder layer: [B, Lk, 2d] in the weight dtype.
+
+        The reference re-projects them at every step for every beam copy
+        (Attention.py:63-67 called from Layers.py:206-213); here once per clip.
+        """
+        B, Lk, d = mem.shape
+        mem2 = mem.contiguous().view(B * Lk, d)
+        out = []
+        for li in range(self.n_layers):
+            nm = "d{}_ca".format(li)
+            kv = self.ws("{}{}".format(tag, li), (B * Lk, 2 * d), self.wt)
+            out.append(self.gemm(mem2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv))
+        return out
+
+    # ------------------------------------------------------------------ teacher-forced decoder
+    def decode_full(self, input_ids: torch.Tensor, mem: torch.Tensor, sem: Optional[torch.Tensor],
+                    want_logits: str = "all") -> Dict[str, torch.Tensor]:
+        """`TransformerDecoder.forward` + `NaiveHead` on whole sequences (Lq = t).
+
+        Used by feedforward_step (Framework.py:215-234) and by the stateless
+        `decoding_phase` API.  `mem` may hold fewer clips than `input_ids` has rows
+        (rows_per_clip = N / B consecutive rows share a clip).
+        """
+        w, d = self.w, self.d
+        N, t = input_ids.shape
+        B, Lk = mem.shape[0], mem.shape[1]
+        assert N % B == 0 and t <= self.T + 1
+        per_clip = N // B
+        rows = N * t
+        ids32 = input_ids.to(self.device, torch.int32).contiguous()
+        if sem is not None:
+            sem = sem.to(self.device, torch.float32).contiguous()
+            assert sem.shape[0] in (B, N)
+            sem_div = t * (per_clip if sem.shape[0] == B else 1)
+        x = self.ws("tf_x0", (rows, d))
+        call("care_embed_ln", ptr(ids32), t, 0, None, 0, ptr(w["word"]), ptr(w["pos"]), 0, ptr(sem),
+             sem_div if sem is not None else 1, ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(x), d, rows, t, d)
+        ckv = self.cross_kv(mem, tag="tf_ckv")
+        for li in range(self.n_layers):
+            x1 = self._mha_self_full("d{}_sa".format(li), x, t, ids32, True, "tf_")
+            nm = "d{}_ca".format(li)
+            q = self.gemm(x1, w[nm + "_q_w"], w[nm + "_q_b"], self.ws("tf_q", (rows, d)))
+            kv = ckv[li]
+            ctx = self.attention(q, kv, kv[:, d:], self.ws("tf_ctx", (rows, d)), Lk * 2 * d, 2 * d, per_clip * t, Lk,
+                                 bias=w["d{}_hb".format(li)])
+            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws("tf_o", (rows, d)))
+            x2 = self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], self.ws("tf_x2", (rows, d)))
+            last = li == self.n_layers - 1
+            x = self._ffn("d{}_ffn".format(li), x2, torch.empty(rows, d, device=self.device) if last
+                          else self.ws("tf_x3", (rows, d)), "tf_")
+        hidden = x.view(N, t, d)
+        out = {"hidden_states": hidden}
+        if want_logits == "all":
+            out["logits"] = self.gemm(x, w["vocab"], None, torch.empty(rows, self.V, device=self.device)).view(N, t, self.V)
+        elif want_logits == "last":
+            last_rows = hidden[:, -1, :]
+            out["logits"] = self.gemm(last_rows, w["vocab"], None, torch.empty(N, self.V, device=self.device))
+        return out
+
+    # ------------------------------------------------------------------ incremental decode step
+    def _decode_step(self, t, N, rows_per_clip, tok, anc, sem, ckv, skv, Lk, tag):
+        """One decoder step for N rows: new token at position t-1 -> final hidden [N, d]."""
+        w, d, T = self.w, self.d, self.T
+        x = self.ws(tag + "x0", (N, d))
+        call("care_embed_ln", ptr(tok), tok.stride(0), t - 1, ptr(anc), anc.stride(0) if anc is not None else 0,
+             ptr(w["word"]), ptr(w["pos"]), t - 1, ptr(sem), rows_per_clip, ptr(w["emb_g"]), ptr(w["emb_be"]),
+             self.eps, ptr(x), d, N, 1, d)
+        for li in range(self.n_layers):
+            nm = "d{}_sa".format(li)
+            cache = skv[li]  # [N, T, 2d]
+            q = self.ws(tag + "q", (N, d))
+            self.gemm(x, w[nm + "_qkv_w"], w[nm + "_qkv_b"], q, out2=cache[:, t - 1, :], n_split=d)
+            flat = cache.view(N * T, 2 * d)
+            ctx = self.attention(q, flat, flat[:, d:], self.ws(tag + "ctx", (N, d)), T * 2 * d, 2 * d, 1, t, anc=anc,
+                                 pad_tok=tok)
+            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)))
+            x1 = self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], self.ws(tag + "x1", (N, d)))
+            nm = "d{}_ca".format(li)
+            q2 = self.gemm(x1, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)))
+            kv = ckv[li]
+            ctx = self.attention(q2, kv, kv[:, d:], self.ws(tag + "ctx", (N, d)), Lk * 2 * d, 2 * d, rows_per_clip, Lk,
+                                 bias=w["d{}_hb".format(li)])
+            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)))
+            x2 = self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], self.ws(tag + "x2", (N, d)))
+            x = self._ffn("d{}_ffn".format(li), x2, self.ws(tag + "x3_%d" % (li & 1), (N, d)), tag)
+        return x
+
+    def greedy(self, mem: torch.Tensor, sem: Optional[torch.Tensor], steps: Optional[int] = None):
+        """Greedy decoding (= beam search with beam_size 1, models/Wrapper.py:34-35) of B clips.
+
+        Returns device tensors: fed int32 [B, T+1] (column 0 = BOS), length int32 [B],
+        score fp32 [B] (sum of chosen log-probs).  No host synchronisation inside.
+        """
+        B, Lk, d = mem.shape
+        T = self.T
+        steps = T if steps is None else steps
+        mem = mem.to(self.device, torch.float32)
+        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
+        fed = self.ws("g_fed", (B, T + 1), torch.int32)
+        score = self.ws("g_score", (B,))
+        length = self.ws("g_len", (B,), torch.int32)
+        fin = self.ws("g_fin", (B,), torch.int32)
+        fed.zero_(); fed[:, 0] = BOS
+        score.zero_(); length.zero_(); fin.zero_()
+        ckv = self.cross_kv(mem)
+        skv = [self.ws("g_skv%d" % li, (B, T, 2 * d), self.wt) for li in range(self.n_layers)]
+        parts = _lib.argmax_parts(self.V)
+        pmax = self.ws("g_pmax", (B, parts))
+        pidx = self.ws("g_pidx", (B, parts), torch.int32)
+        psum = self.ws("g_psum", (B, parts))
+        for t in range(1, steps + 1):
+            x = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_")
+            call("care_gemm_argmax", ptr(x), d, ptr(self.w["vocab"]), _code(self.w["vocab"]), ptr(pmax), ptr(pidx),
+                 ptr(psum), B, self.V, d)
+            call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
+                 ptr(length), ptr(fin), t, T, EOS, B)
+        return fed, length, score
+
+    def beam(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int):
+        """Beam search of B clips x bm beams, state on the device (csrc/beam.hip)."""
+        B, Lk, d = mem.shape
+        T, N = self.T, mem.shape[0] * bm
+        mem = mem.to(self.device, torch.float32)
+        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
+        cap = need + bm
+        tok = self.ws("b_tok", (N, T + 1), torch.int32)
+        anc = [self.ws("b_anc%d" % i, (N, T + 1), torch.int32) for i in range(2)]
+        tok.fill_(EOS); tok[:, 0] = BOS
+        rows = torch.arange(N, device=self.device, dtype=torch.int32)
+        for a in anc:
+            a.copy_(rows.unsqueeze(1).expand(N, T + 1))
+        scores = self.ws("b_scores", (N,)); scores.zero_()
+        done = self.ws("b_done", (B,), torch.int32); done.zero_()
+        nfin = self.ws("b_nfin", (B,), torch.int32); nfin.zero_()
+        fscore = self.ws("b_fscore", (B, cap)); fscore.zero_()
+        flen = self.ws("b_flen", (B, cap), torch.int32); flen.zero_()
+        fhyp = self.ws("b_fhyp", (B, cap, T + 1), torch.int32); fhyp.zero_()
+        cval = self.ws("b_cval", (N, bm))
+        cidx = self.ws("b_cidx", (N, bm), torch.int32)
+        logits = self.ws("b_logits", (N, self.V))
+        ckv = self.cross_kv(mem)
+        skv = [self.ws("b_skv%d" % li, (N, T, 2 * d), self.wt) for li in range(self.n_layers)]
+        for t in range(1, T + 1):
+            a_old, a_new = anc[(t - 1) & 1], anc[t & 1]
+            x = self._decode_step(t, N, bm, tok, a_old, sem, ckv, skv, Lk, "b_")
+            self.gemm(x, self.w["vocab"], None, logits)
+            call("care_beam_select", ptr(logits), self.V, self.V, bm, ptr(cval), ptr(cidx), N)
+            call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
+                 ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
+        return nfin, fscore, flen, fhyp

@@ -1,0 +1,358 @@
+"""Drop-in for the reference's `models.Framework.get_framework` (models/Framework.py:14-51).
+
+`get_framework(opt)` returns an nn.Module with the attribute surface the reference's
+callers touch (`backbone, encoder, predictor, decoder, cls_head, pointer,
+input_keys_for_decoder, opt`; `encoding_phase / prepare_inputs_for_decoder /
+decoding_phase / feedforward_step / forward / get_keys_to_device`) and a
+`state_dict()` whose keys and shapes equal the reference's, so its checkpoints load with
+strict=True.  The sub-modules below are *parameter containers* that reproduce the
+reference's parameter naming; the arithmetic is done by `HipEngine` (care_amd/engine.py)
+through the C ABI of libcare_hip.so.  There is no eager/CPU fallback: a forward call
+without the HIP library or a GPU raises.
+
+Training (autograd) is not implemented in this round: the kernels are forward-only, so a
+module in `.train()` mode raises NotImplementedError instead of silently running a
+different path.
+"""
+import math
+import os
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .constants import PAD
+from .engine import HipEngine
+
+
+# --------------------------------------------------------------------------- parameter containers
+class _SDPA(nn.Module):
+    """Parameters of ScaledDotProductAttention (models/components/Attention.py:11-61)."""
+
+    def __init__(self, d, heads, bias=True, hybrid_length=0):
+        super().__init__()
+        if hybrid_length:
+            self.hybrid_bias = nn.Parameter(torch.zeros(heads, hybrid_length))
+        self.query = nn.Linear(d, d, bias=bias)
+        self.key = nn.Linear(d, d, bias=bias)
+        self.value = nn.Linear(d, d, bias=bias)
+
+
+class _MHA(nn.Module):
+    """Parameters of MultiHeadAttention (models/components/SubLayers.py:11-38)."""
+
+    def __init__(self, opt, hybrid_length=0):
+        super().__init__()
+        d = opt["dim_hidden"]
+        self.SDPA = _SDPA(d, opt["num_attention_heads"], not opt.get("mha_exclude_bias", False), hybrid_length)
+        self.dense = nn.Linear(d, d)
+        self.LayerNorm = nn.LayerNorm(d, eps=opt["layer_norm_eps"])
+
+
+class _FFN(nn.Module):
+    """Parameters of PositionwiseFeedForward (SubLayers.py:108-135)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        d, ff = opt["dim_hidden"], opt["intermediate_size"]
+        self.dense1 = nn.Linear(d, ff)
+        self.dense2 = nn.Linear(ff, d)
+        self.LayerNorm = nn.LayerNorm(d, eps=opt["layer_norm_eps"])
+
+
+class _FixedPE(nn.Module):
+    """Sinusoidal table stored as a frozen parameter `pe` (Embeddings.py:11-27)."""
+
+    def __init__(self, max_len, d):
+        super().__init__()
+        pe = torch.zeros(max_len, d)
+        position = torch.arange(0, max_len).float().unsqueeze(1)
+        div = (torch.arange(0, d, 2).float() * -(math.log(10000.0) / d)).exp()
+        pe[:, 0::2] = torch.sin(position * div)
+        pe[:, 1::2] = torch.cos(position * div)
+        self.pe = nn.Parameter(pe.unsqueeze(0), requires_grad=False)
+
+
+def _position_table(opt, n):
+    return nn.Embedding(n, opt["dim_hidden"]) if opt.get("trainable_pe", False) else _FixedPE(n, opt["dim_hidden"])
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.intra_attention = _MHA(opt)
+        self.ffn = _FFN(opt)
+
+
+class _TransformerEncoderBase(nn.Module):
+    """Parameters of TransformerEncoderBase (models/Encoder.py:244-262)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.position_embeddings = _position_table(opt, opt["n_frames"])
+        self.LayerNorm = nn.LayerNorm(opt["dim_hidden"], eps=opt["layer_norm_eps"])
+        self.layers = nn.ModuleList([_EncoderLayer(opt) for _ in range(opt["num_hidden_layers_encoder"])])
+
+
+class Embedder(nn.Module):
+    """MultipleStreams with per-modality Linear->LayerNorm->Dropout (Encoder.py:51-83,165-168)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        for ch in opt["modality"].lower():
+            dim = opt.get("dim_" + ch)
+            if dim is None:
+                raise AssertionError("The modality is {}, but dim_{} can not be found in opt".format(opt["modality"], ch))
+            self.add_module("Encoder_%s" % ch.upper(), self._stream(dim, opt))
+
+    @staticmethod
+    def _stream(dim, opt):
+        return nn.Sequential(nn.Linear(dim, opt["dim_hidden"]), nn.LayerNorm(opt["dim_hidden"], eps=opt["layer_norm_eps"]),
+                             nn.Dropout(opt.get("encoder_dropout_prob", 0.5)))
+
+
+class MultiTransformerEncoder(Embedder):
+    """Per-modality Linear -> TransformerEncoderBase (Encoder.py:190-193)."""
+
+    @staticmethod
+    def _stream(dim, opt):
+        return nn.Sequential(nn.Linear(dim, opt["dim_hidden"]), _TransformerEncoderBase(opt))
+
+
+_ENCODERS = {"Embedder": Embedder, "MultiTransformerEncoder": MultiTransformerEncoder}
+
+
+class Predictor_attribute(nn.Module):
+    """Concept-detection head parameters (models/Predictor/pred_attribute.py:49-76)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        modality = opt.get("modality_for_predictor", None) or opt["modality"]
+        if not (opt.get("attribute_prediction_share_prj", False) or len(opt["attribute_prediction_flags"]) == 1):
+            raise ValueError("per-flag concept projections are outside the hot path (pred_attribute.py:66-70)")
+        n = len(modality) if opt.get("attribute_prediction_channel_concat", False) else 1
+        self.prj = nn.Linear(opt["dim_hidden"] * n, opt["attribute_prediction_k"])
+
+
+class _NaiveEmbeddings(nn.Module):
+    def __init__(self, n_words, n_positions, d, eps, padding_idx=None):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(n_words, d, padding_idx=padding_idx)
+        self.position_embeddings = nn.Embedding(n_positions, d)
+        self.LayerNorm = nn.LayerNorm(d, eps=eps)
+
+
+class SemanticContainer(nn.Module):
+    """Concept embedding + global guidance parameters (pred_attribute.py:239-261)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        if "L0" in opt.get("use_attr_flags", ""):
+            raise ValueError("use_attr_flags with L0 (no local guidance) is outside the hot path")
+        self.attr_embs = _NaiveEmbeddings(opt["attribute_prediction_k"], opt["use_attr_topk"], opt["dim_hidden"],
+                                          opt["layer_norm_eps"])
+        if "emb" in opt.get("use_attr_type", ""):
+            self.semantic2hidden = nn.Linear(opt["attribute_prediction_k"], opt["dim_hidden"],
+                                             bias="pp_emb" in opt.get("use_attr_type", ""))
+
+
+class Predictor(nn.Module):
+    def __init__(self, nets):
+        super().__init__()
+        self.nets = nn.ModuleList(nets)
+
+
+def _get_predictor(opt) -> Optional[nn.Module]:
+    """`get_predictor` (models/Predictor/__init__.py:26-60) for the in-scope predictors."""
+    table = {"Predictor_attribute": Predictor_attribute, "SemanticContainer": SemanticContainer}
+    nets = []
+    for crit in opt["crits"]:
+        if crit == "lang":
+            continue
+        name = "Predictor_{}".format(crit)
+        if name not in table:
+            raise ValueError("We can not find the class `{}` in {}".format(name, __file__))
+        nets.append(table[name](opt))
+    for name in opt.get("predictors_to_be_added", []):
+        if name not in table:
+            raise ValueError("We can not find the class `{}` in {}".format(name, __file__))
+        nets.append(table[name](opt))
+    return Predictor(nets) if nets else None
+
+
+class _DecoderEmbeddings(nn.Module):
+    """Parameters of Embeddings (models/components/Embeddings.py:90-132)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(opt["vocab_size"], opt["dim_hidden"], padding_idx=PAD)
+        self.position_embeddings = _position_table(opt, opt["max_len"])
+        self.LayerNorm = nn.LayerNorm(opt["dim_hidden"], eps=opt["layer_norm_eps"])
+
+
+class _DecoderLayer(nn.Module):
+    """Parameters of DecoderLayer (models/components/Layers.py:55-135), CARE / Base variants."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.intra_attention = _MHA(opt)
+        modality = opt["modality"] if opt.get("modality_for_decoder", None) is None else opt["modality_for_decoder"]
+        hybrid_length = opt["n_frames"] * len(modality) + opt.get("use_attr_topk", 30)
+        if "r" in modality:
+            hybrid_length += opt["retrieval_topk"] - opt["n_frames"]
+        self.inter_attention = _MHA(opt, hybrid_length if opt.get("add_hybrid_attention_bias", False) else 0)
+        if opt.get("use_attr", False) and "att" in opt.get("use_attr_type", "att"):
+            raise ValueError("the attr_attention (CABase) variant is a later round (SURVEY.md 8(f) item 3)")
+        self.ffn = _FFN(opt)
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        if opt.get("transformer_pre_ln", False):
+            raise ValueError("pre-LN decoders are outside the hot path (opts.py:68 default False)")
+        self.embedding = _DecoderEmbeddings(opt)
+        self.layers = nn.ModuleList([_DecoderLayer(opt) for _ in range(opt["num_hidden_layers_decoder"])])
+
+    def get_word_embeddings(self):
+        return self.embedding.word_embeddings
+
+    def get_embeddings(self):
+        return self.embedding
+
+
+class NaiveHead(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.tgt_word_prj = nn.Linear(opt["dim_hidden"], opt["vocab_size"], bias=False)
+
+    def get_word_embeddings(self):
+        return self.tgt_word_prj
+
+
+# --------------------------------------------------------------------------- framework
+def get_framework(opt: Dict[str, Any]) -> nn.Module:
+    """Same contract as models/Framework.py:14-51 for the Transformer branch."""
+    if "rnn" in opt["decoder"].lower():
+        raise ValueError("RNN decoders are outside the hot path (SURVEY.md section 2, row 14)")
+    for key, table in (("encoder", _ENCODERS), ("decoder", {"TransformerDecoder": TransformerDecoder}),
+                       ("cls_head", {"NaiveHead": NaiveHead})):
+        if opt[key] not in table:
+            raise ValueError("We can not find the class `{}` in {}".format(opt[key], __file__))
+    if opt.get("with_backbones") or opt.get("pointer") or opt.get("with_category"):
+        raise ValueError("backbones / pointer / category inputs are outside the hot path")
+    keys = ["encoder_hidden_states"]
+    if opt.get("use_attr", False) and ("prefix" in opt["use_attr_type"] or "att" in opt["use_attr_type"].lower()):
+        keys += ["semantic_embs"]
+    if "emb" in opt.get("use_attr_type", ""):
+        keys += ["semantic_hidden_states"]
+    return TransformerSeq2Seq(opt, keys)
+
+
+class TransformerSeq2Seq(nn.Module):
+    """`Seq2SeqBase` + `TransformerSeq2Seq` (models/Framework.py:54-269) on the HIP engine."""
+
+    def __init__(self, opt: Dict[str, Any], input_keys_for_decoder: List[str]):
+        super().__init__()
+        self.backbone = None
+        self.encoder = _ENCODERS[opt["encoder"]](opt)
+        self.predictor = _get_predictor(opt)
+        self.decoder = TransformerDecoder(opt)
+        self.pointer = None
+        self.cls_head = NaiveHead(opt)
+        self.input_keys_for_decoder = input_keys_for_decoder
+        self.opt = opt
+        self._init_weights()
+        self._engine: Optional[HipEngine] = None
+        self._engine_stamp = None
+        self._compute_dtype = opt.get("care_compute_dtype") or os.environ.get("CARE_AMD_DTYPE", "fp32")
+
+    # -- initialisation: same distributions as models/Framework.py:115-134
+    def _init_weights(self):
+        for module in self.modules():
+            if isinstance(module, nn.Linear):
+                nn.init.xavier_uniform_(module.weight)
+                if module.bias is not None:
+                    module.bias.data.zero_()
+            elif isinstance(module, nn.Embedding):
+                nn.init.xavier_uniform_(module.weight)
+                if module.padding_idx is not None:
+                    module.weight.data[module.padding_idx].zero_()
+            elif isinstance(module, nn.LayerNorm):
+                module.weight.data.fill_(1.0)
+                module.bias.data.zero_()
+
+    # -- engine management
+    def set_compute_dtype(self, dtype: str) -> "TransformerSeq2Seq":
+        """'fp32' (exact f32 MFMA, parity mode) or 'bf16' (bf16 MFMA, fp32 accumulation)."""
+        if dtype != self._compute_dtype:
+            self._compute_dtype = dtype
+            self._engine = None
+        return self
+
+    @property
+    def compute_dtype(self) -> str:
+        return self._compute_dtype
+
+    def engine(self) -> HipEngine:
+        if self.training:
+            raise NotImplementedError(
+                "care_amd kernels are forward-only in this round: call .eval() "
+                "(training needs autograd and is not routed to a different implementation)")
+        params = list(self.parameters())
+        device = params[0].device
+        stamp = (device, self._compute_dtype, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        if self._engine is None or self._engine_stamp != stamp:
+            if device.type != "cuda":
+                raise RuntimeError("the model is on `{}`: move it to the MI355X (model.to('cuda')); "
+                                   "there is no CPU fallback".format(device))
+            if self._engine is None or self._engine.dtype != self._compute_dtype:
+                self._engine = HipEngine(self.opt, self._compute_dtype)
+            self._engine.load_weights(self.state_dict(), device)
+            self._engine_stamp = stamp
+        return self._engine
+
+    # -- reference API
+    def get_keys_to_device(self, teacher_forcing=False, **kwargs):
+        keys = ["feats", "input_ids"]
+        for k in self.input_keys_for_decoder:
+            if "hidden_states" not in k:
+                keys.append(k)
+        return keys
+
+    def encoding_phase(self, feats: List[torch.Tensor], **kwargs) -> Dict[str, torch.Tensor]:
+        n_mod = len(self.opt["modality"])
+        with torch.no_grad():
+            out = self.engine().encode(list(feats[:n_mod]))
+        if self.predictor is not None:
+            out["attribute_prediction_prj"] = self.predictor.nets[0].prj
+        return out
+
+    def prepare_inputs_for_decoder(self, encoding_phase_outputs, batch) -> Dict[str, torch.Tensor]:
+        inputs = {}
+        for key in self.input_keys_for_decoder:
+            if key not in encoding_phase_outputs.keys() and key not in batch.keys():
+                raise KeyError("the input key `{}` can not be found in `encoding_phase_outputs` {} nor `batch` {}".format(
+                    key, encoding_phase_outputs.keys(), batch.keys()))
+            src = batch if key not in encoding_phase_outputs.keys() else encoding_phase_outputs
+            inputs[key] = src[key]
+        return inputs
+
+    def decoding_phase(self, input_ids, inputs_for_decoder, last_time_step_logits: bool = False, **kwargs):
+        """Stateless decoder call on a full prefix (Framework.py:240-269)."""
+        mem = inputs_for_decoder["encoder_hidden_states"]
+        if isinstance(mem, list):
+            assert len(mem) == 1
+            mem = mem[0]
+        with torch.no_grad():
+            return self.engine().decode_full(input_ids, mem, inputs_for_decoder.get("semantic_hidden_states"),
+                                             want_logits="last" if last_time_step_logits else "all")
+
+    def feedforward_step(self, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
+        enc = self.encoding_phase(batch["feats"], **kwargs)
+        inputs = self.prepare_inputs_for_decoder(enc, batch)
+        dec = self.decoding_phase(batch["input_ids"], inputs, **kwargs)
+        return {**enc, **dec, "schedule_sampling_prob": 0}
+
+    def forward(self, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
+        return self.feedforward_step(batch, **kwargs)

@@ -1,0 +1,213 @@
+/*
+ * care_hip.h - C ABI of libcare_hip.so: hand-written gfx950 (MI355X) kernels for the
+ * captioning forward path of yangbang18/CARE.
+ *
+ * The reference has NO native/FFI boundary on this path (it is pure PyTorch, SURVEY.md
+ * 8(b)); its seam is the two Python factories `get_framework` / `get_translator`
+ * (models/Framework.py:14-51, models/Translator.py:14-19).  The host mirror of that seam
+ * lives in care_amd/framework.py and care_amd/translator.py and calls the entry points
+ * below through ctypes.  Each entry point names the reference code it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers are DEVICE pointers; sizes/strides are in ELEMENTS unless noted;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - returns 0 on success, a negative CARE_E* code for a rejected argument, or a
+ *     positive hipError_t from the launch;
+ *   - never allocates, frees or synchronises; no host-visible global state; safe to
+ *     capture into a hipGraph;
+ *   - activations are fp32; `wdtype` selects the storage type of weights and of the
+ *     K/V caches: CARE_F32 (exact f32 MFMA, parity mode) or CARE_BF16 (bf16 MFMA with
+ *     fp32 accumulation, throughput mode).  LayerNorm / softmax statistics, the concept
+ *     head and all accumulators are always fp32.
+ */
+#ifndef CARE_HIP_H
+#define CARE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CARE_ABI_VERSION 1
+
+enum { CARE_F32 = 0, CARE_BF16 = 1 };
+enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
+enum {
+  CARE_EINVAL = -1,      /* null pointer / non-positive size */
+  CARE_EALIGN = -2,      /* pointer or leading dimension not 16-byte aligned */
+  CARE_ESHAPE = -3,      /* shape outside what the kernels support (stated per function) */
+  CARE_EDTYPE = -4       /* unknown dtype / activation code */
+};
+
+/* ABI version of the loaded library (== CARE_ABI_VERSION). */
+int care_version(void);
+
+/* Name of the code-object architecture the library was built for ("gfx950"). */
+const char* care_arch(void);
+
+/*
+ * care_gemm:  C = act(A * W^T + bias), optionally split over two destinations.
+ *   Replaces every nn.Linear on the path: Embedder Linear (models/Encoder.py:167),
+ *   SDPA query/key/value (models/components/Attention.py:53-56,63-67), MHA dense
+ *   (SubLayers.py:35,69), FFN dense1/dense2 (SubLayers.py:129-130,143-145), concept
+ *   prj / semantic2hidden (models/Predictor/pred_attribute.py:62-65,260) and the vocab
+ *   projection when all logits are needed (models/Head.py:26-32, Framework.py:258-259).
+ *   A [M,K] fp32 row-major, leading dim lda.  W [N,K] row-major (nn.Linear layout,
+ *   leading dim K) of type wdtype.  bias [N] fp32 or NULL.
+ *   Columns [0,n_split) go to C0 (leading dim ldc0, type c0_dtype), columns
+ *   [n_split,N) go to C1 at column (col - n_split) (ldc1, c1_dtype); pass n_split = N
+ *   and C1 = NULL for a single destination.  n_split must be a multiple of 16.
+ *   Requires K % 32 == 0 (f32) or K % 64 == 0 (bf16), lda % 4 == 0, 16-byte aligned A, W.
+ */
+int care_gemm(const float* A, int64_t lda, const void* W, int wdtype, const float* bias,
+              void* C0, int64_t ldc0, int c0_dtype, void* C1, int64_t ldc1, int c1_dtype,
+              int n_split, int M, int N, int K, int act, void* stream);
+
+/*
+ * care_gemm_argmax: per-row (max, argmax, sum exp) of A * W^T without writing the logits.
+ *   Replaces NaiveHead + log_softmax + the top-1 of Beam.advance for greedy decoding
+ *   (models/Head.py:26-32, models/Translator.py:127, misc/Decoding/Beam.py:58-70).
+ *   Writes partial results for `care_argmax_parts(N)` column groups per row:
+ *   pmax/psum fp32 [M, parts], pidx int32 [M, parts]; psum = sum exp(x - pmax) over the
+ *   group's columns.  Ties resolve to the lowest column index.
+ */
+int care_argmax_parts(int N);
+int care_gemm_argmax(const float* A, int64_t lda, const void* W, int wdtype,
+                     float* pmax, int32_t* pidx, float* psum, int M, int N, int K, void* stream);
+
+/*
+ * care_greedy_update: finish the argmax over the partials and advance the greedy state.
+ *   Replaces Beam.advance / Beam.done for beam_size == 1 (misc/Decoding/Beam.py:45-85)
+ *   and the bookkeeping of Translator_ARFormer.beam_decode_step
+ *   (models/Translator.py:91-109,135-143) without the per-step host sync.
+ *   For every row r: tok = argmax, logp = -log(sum exp(x - max)).  If the row is not
+ *   finished: fed[r, t] = tok, score[r] += logp, length[r] = t, and the row finishes
+ *   when tok == eos_id or t == max_steps.  `fed` is int32 [rows, fed_stride]; column 0
+ *   holds BOS.  Finished rows keep running (rows are independent) but are frozen.
+ */
+int care_greedy_update(const float* pmax, const int32_t* pidx, const float* psum, int parts,
+                       int32_t* fed, int fed_stride, float* score, int32_t* length,
+                       int32_t* finished, int t, int max_steps, int eos_id, int rows,
+                       void* stream);
+
+/*
+ * care_add_ln: out = LayerNorm(x + res) * gamma + beta, row-wise over d columns.
+ *   Replaces nn.LayerNorm after the Embedder Linear (models/Encoder.py:167) and the
+ *   post-LN residual epilogues of MultiHeadAttention / PositionwiseFeedForward
+ *   (SubLayers.py:73-79,147-150).  res may be NULL.  If pos is non-NULL, pos[(r % grp), :]
+ *   is added as well (TransformerEncoderBase position embedding, Encoder.py:265-279).
+ *   Output row of input row r: (r / grp) * out_grp_rows + out_row_off + (r % grp), so an
+ *   encoder stream lands directly inside the [B, Lk, d] cross-attention memory
+ *   (the torch.cat of Encoder.py:148-149 and Framework.py:184-185 becomes an offset).
+ *   d % 4 == 0, d <= 2048.
+ */
+int care_add_ln(const float* x, int64_t ldx, const float* res, int64_t ldres,
+                const float* pos, const float* gamma, const float* beta, float eps,
+                float* out, int64_t ldo, int rows, int d, int grp, int out_grp_rows,
+                int out_row_off, void* stream);
+
+/*
+ * care_group_mean: out[g, col_off + c] = mean over the grp rows of group g of x[., c].
+ *   Replaces `item.mean(1)` per modality (models/Encoder.py:106); with ldo = n_mod * d and
+ *   col_off = m * d it also performs the channel concat of pred_attribute.py:88-89.
+ *   Input row of (g, i): g * in_grp_rows + in_row_off + i.
+ */
+int care_group_mean(const float* x, int64_t ldx, int in_grp_rows, int in_row_off, int grp,
+                    float* out, int64_t ldo, int col_off, int groups, int d, void* stream);
+
+/*
+ * care_concept_finish: concept probabilities from concept scores.
+ *   Replaces prepare_merged_probs for seq_len == 1, restated literally
+ *   (models/Predictor/pred_attribute.py:17-46): p = sigmoid(s);
+ *   preds = 1 - exp(log(clamp(1 - p, 1e-12, 1))); avg = mean_k p.
+ *   scores [B, lds] fp32 (k valid columns) -> preds [B, ldp] (columns >= k zeroed up to
+ *   ldp so the buffer can feed care_gemm with K = ldp), avg [B].
+ */
+int care_concept_finish(const float* scores, int64_t lds, float* preds, int64_t ldp,
+                        float* avg, int B, int k, void* stream);
+
+/*
+ * care_concept_topk_embed: top-`topk` concepts -> embedded concept rows in the memory.
+ *   Replaces SemanticContainer.forward's topk + NaiveEmbeddings
+ *   (models/Predictor/pred_attribute.py:262-270, models/components/Embeddings.py:53-87):
+ *   labels[b, j] = index of the j-th largest preds[b, :] (order: value desc, index asc;
+ *   torch leaves the order of exact ties unspecified);
+ *   out[b * out_grp_rows + out_row_off + j, :] = LN(word[labels[b,j]] + pos[j]).
+ *   k <= 1024, topk <= 64, d % 4 == 0, d <= 2048.
+ */
+int care_concept_topk_embed(const float* preds, int64_t ldp, int k, int topk,
+                            const float* word, const float* pos, const float* gamma,
+                            const float* beta, float eps, int64_t* labels, float* out,
+                            int64_t ldo, int out_grp_rows, int out_row_off, int B, int d,
+                            void* stream);
+
+/*
+ * care_embed_ln: decoder input embedding.
+ *   Replaces Embeddings.forward (models/components/Embeddings.py:134-188):
+ *   out[r] = LN(word[tok(r)] + pos[pos0 + r % seq] + sem[r / sem_div]) with
+ *   tok(r) = tokens[(r / seq) * tok_stride + tok_off + r % seq] (int32).  sem may be NULL
+ *   (no global semantic guidance).  seq = 1 for an incremental decode step.
+ *   If anc is non-NULL (beam search) the token row is anc[(r / seq) * anc_stride + col]
+ *   instead of (r / seq), col = tok_off + r % seq.
+ */
+int care_embed_ln(const int32_t* tokens, int tok_stride, int tok_off, const int32_t* anc,
+                  int anc_stride, const float* word, const float* pos, int pos0,
+                  const float* sem, int sem_div, const float* gamma, const float* beta,
+                  float eps, float* out, int64_t ldo, int rows, int seq, int d, void* stream);
+
+/*
+ * care_attention: scaled-dot-product attention for single query rows, head dim 64.
+ *   Replaces ScaledDotProductAttention.forward after the projections
+ *   (models/components/Attention.py:83-131): scores = q.k / 8 -> masked_fill(-1e9) ->
+ *   + hybrid_bias[h, j] -> softmax -> P.V, for every (row, head).
+ *   Q [rows, ldq] fp32 (head h at columns h*64..).  K and V of type kv_dtype; key j of
+ *   query row r lives at  base + kvb * kv_batch_stride + j * kv_row_stride + h * 64  with
+ *   kvb = anc ? anc[r * anc_stride + j] : r / rows_per_kv.
+ *   Number of keys of row r: causal ? min(nkeys, r % seq + 1 + causal_off) : nkeys.
+ *   pad_tok (int32, optional): key j of row r is masked when
+ *   pad_tok[ptb * pad_stride + j] == pad_id, ptb = anc ? anc[r*anc_stride + j] : r / rows_per_kv
+ *   (the key-pad mask of models/Decoder/Transformer.py:15-28,169-174).
+ *   bias (optional) fp32 [H, bias_ld].  ctx [rows, ldctx] fp32.  nkeys <= 128.
+ */
+int care_attention(const float* Q, int64_t ldq, const void* K, const void* V, int kv_dtype,
+                   int64_t kv_batch_stride, int64_t kv_row_stride, int rows_per_kv,
+                   const int32_t* anc, int anc_stride, int nkeys, int causal, int seq,
+                   int causal_off, const int32_t* pad_tok, int pad_stride, int pad_id,
+                   const float* bias, int bias_ld, float* ctx, int64_t ldctx, int rows,
+                   int heads, void* stream);
+
+/*
+ * care_beam_select: per row of logits [rows, ldl] (V valid columns): the beam_size best
+ *   columns as log-probabilities.  Replaces torch.log_softmax(logits, dim=1)
+ *   (models/Translator.py:127) plus the per-row part of the flattened topk of
+ *   Beam.advance (misc/Decoding/Beam.py:60): cand_val[r, k] = (x - max) - log(sum exp(x - max))
+ *   of the k-th best column (value desc, index asc), cand_idx[r, k] its column.  bm <= 8.
+ */
+int care_beam_select(const float* logits, int64_t ldl, int V, int bm, float* cand_val,
+                     int32_t* cand_idx, int rows, void* stream);
+
+/*
+ * care_beam_advance: one beam-search step for every clip (B clips x bm beams), on device.
+ *   Replaces Beam.advance / Beam.done (misc/Decoding/Beam.py:38-85), the re-ordering of the
+ *   beams' prefixes (Beam.get_tentative_hypothesis, :112-117) and the removal of finished
+ *   clips (models/Translator.py:145-209; clips are frozen instead, rows are independent).
+ *   State, all device arrays: scores fp32 [B*bm]; tokphys int32 [B*bm, stride] physical
+ *   token store (column 0 = BOS); anc_old -> anc_new int32 [B*bm, stride] ancestor tables
+ *   (anc[row, j] = physical row holding position j of the hypothesis in beam slot `row`;
+ *   initialise anc[row, 0] = row); done / n_fin int32 [B]; finished hypotheses
+ *   fin_score fp32, fin_len int32 [B, fin_cap], fin_hyp int32 [B, fin_cap, stride]
+ *   (tokens without BOS), recorded in the reference's order.  t = 1-based step,
+ *   max_steps = max_len - 1, need = max(beam_size, topk) <= fin_cap, V = vocabulary size
+ *   (ties between equal candidates resolve to the lower flattened index beam*V + column).
+ */
+int care_beam_advance(const float* cand_val, const int32_t* cand_idx, float* scores, int bm,
+                      int32_t* tokphys, const int32_t* anc_old, int32_t* anc_new,
+                      int32_t* done, int32_t* n_fin, int fin_cap, float* fin_score,
+                      int32_t* fin_len, int32_t* fin_hyp, int t, int max_steps, int need,
+                      int eos_id, int V, int stride, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARE_HIP_H */
