@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -24,18 +24,22 @@ _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "care_gemm": [_P, _L, _P, _I, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_gemm_argmax": [_P, _L, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "care_gemm_bf16": [_P, _L, _I, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "care_gemm_argmax_bf16": [_P, _L, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     "care_greedy_update": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
-    "care_add_ln": [_P, _L, _P, _L, _P, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _P],
+    "care_add_ln": [_P, _L, _P, _L, _P, _P, _P, _F, _P, _P, _L, _I, _I, _I, _I, _I, _I, _L, _P],
+    "care_gemm_bf16_splitk": [_P, _L, _I, _P, _P, _P, _L, _L, _I, _I, _I, _P],
     "care_group_mean": [_P, _L, _I, _I, _I, _P, _L, _I, _I, _I, _P],
     "care_concept_finish": [_P, _L, _P, _L, _P, _I, _I, _P],
-    "care_concept_topk_embed": [_P, _L, _I, _I, _P, _P, _P, _P, _F, _P, _P, _L, _I, _I, _I, _I, _P],
-    "care_embed_ln": [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _I, _I, _P],
+    "care_concept_topk_embed": [_P, _L, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "care_embed_ln": [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _F, _P, _P, _L, _I, _I, _I, _P],
     "care_attention": [_P, _L, _P, _P, _I, _L, _L, _I, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _L,
-                       _I, _I, _P],
+                       _I, _I, _I, _P],
     "care_beam_select": [_P, _L, _I, _I, _P, _P, _I, _P],
     "care_beam_advance": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
-PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_argmax_parts": (c_int, [c_int])}
+PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_argmax_parts": (c_int, [c_int]),
+         "care_argmax_parts_bf16": (c_int, [c_int, c_int])}
 
 _lib = None
 
@@ -79,13 +83,27 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
-def call(name: str, *args):
+# When set to a dict, every tagged launch is bracketed by HIP events recorded on the
+# launch stream (torch's current stream): TIMING[tag] = [(start_event, end_event), ...].
+# bench.py uses it to measure per-kernel durations live; it is None in normal operation.
+TIMING = None
+
+
+def call(name: str, *args, tag: str = None):
     """Invoke an ABI function on torch's current stream; raise on any non-zero status."""
-    rc = getattr(load(), name)(*args, stream_ptr())
+    fn = getattr(load(), name)
+    if TIMING is not None and tag is not None:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        rc = fn(*args, stream_ptr())
+        end.record()
+        TIMING.setdefault(tag, []).append((start, end))
+    else:
+        rc = fn(*args, stream_ptr())
     if rc != 0:
         what = _ERRORS.get(rc, "hipError_t {}".format(rc))
         raise CareHipError("{} failed: {}".format(name, what))
 
 
-def argmax_parts(n: int) -> int:
-    return load().care_argmax_parts(n)
+def argmax_parts(n: int, m: int = 0, bf16: bool = False) -> int:
+    return load().care_argmax_parts_bf16(m, n) if bf16 else load().care_argmax_parts(n)

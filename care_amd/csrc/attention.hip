@@ -29,7 +29,7 @@ struct AttnArgs {
   int nkeys, causal, seq, causal_off;
   const int32_t* pad_tok; int pad_stride, pad_id;
   const float* bias; int bias_ld;
-  float* ctx; int64_t ldctx;
+  void* ctx; int64_t ldctx; int ctx_bf16;
   int rows, heads;
 };
 
@@ -117,9 +117,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     acc[i] += __shfl_xor(acc[i], 32, 64);
   }
   if (slot == 0) {
-    float* o = p.ctx + (int64_t)r * p.ldctx + h * 64 + chunk * 8;
-    *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    const int64_t o = (int64_t)r * p.ldctx + h * 64 + chunk * 8;
+    if (p.ctx_bf16) {  // context feeds a bf16 GEMM only: store it rounded, half the bytes
+      bf16x8 ob;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ob[i] = (bf16_t)acc[i];
+      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.ctx) + o) = ob;
+    } else {
+      float* of = reinterpret_cast<float*>(p.ctx) + o;
+      *reinterpret_cast<float4*>(of) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(of + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
   }
 }
 
@@ -138,13 +146,14 @@ int launch_attention(const AttnArgs& p, hipStream_t st) {
 extern "C" int care_attention(const float* Q, int64_t ldq, const void* K, const void* V, int kv_dtype,
                               int64_t kv_batch_stride, int64_t kv_row_stride, int rows_per_kv, const int32_t* anc,
                               int anc_stride, int nkeys, int causal, int seq, int causal_off, const int32_t* pad_tok,
-                              int pad_stride, int pad_id, const float* bias, int bias_ld, float* ctx, int64_t ldctx,
-                              int rows, int heads, void* stream) {
+                              int pad_stride, int pad_id, const float* bias, int bias_ld, void* ctx, int64_t ldctx,
+                              int ctx_dtype, int rows, int heads, void* stream) {
   if (!Q || !K || !V || !ctx || rows <= 0 || heads <= 0 || nkeys <= 0 || rows_per_kv <= 0 || seq <= 0)
     return CARE_EINVAL;
   if (nkeys > 128) return CARE_ESHAPE;
   if (kv_dtype != CARE_F32 && kv_dtype != CARE_BF16) return CARE_EDTYPE;
-  if ((ldq % 4) || (ldctx % 4) || (kv_batch_stride % 8) || (kv_row_stride % 8) || !care_aligned16(Q) ||
+  if (ctx_dtype != CARE_F32 && ctx_dtype != CARE_BF16) return CARE_EDTYPE;
+  if ((ldq % 4) || (ldctx % 8) || (kv_batch_stride % 8) || (kv_row_stride % 8) || !care_aligned16(Q) ||
       !care_aligned16(K) || !care_aligned16(V) || !care_aligned16(ctx))
     return CARE_EALIGN;
   AttnArgs p{};
@@ -153,7 +162,8 @@ extern "C" int care_attention(const float* Q, int64_t ldq, const void* K, const 
   p.anc = anc; p.anc_stride = anc_stride;
   p.nkeys = nkeys; p.causal = causal; p.seq = seq; p.causal_off = causal_off;
   p.pad_tok = pad_tok; p.pad_stride = pad_stride; p.pad_id = pad_id;
-  p.bias = bias; p.bias_ld = bias_ld; p.ctx = ctx; p.ldctx = ldctx; p.rows = rows; p.heads = heads;
+  p.bias = bias; p.bias_ld = bias_ld; p.ctx = ctx; p.ldctx = ldctx; p.ctx_bf16 = ctx_dtype == CARE_BF16;
+  p.rows = rows; p.heads = heads;
   hipStream_t st = (hipStream_t)stream;
   return kv_dtype == CARE_BF16 ? launch_attention<bf16_t>(p, st) : launch_attention<float>(p, st);
 }

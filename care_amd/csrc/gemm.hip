@@ -74,19 +74,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     for (int i = 0; i < A_IT; ++i) {
       int c = i * 256 + tid;
       int row = c / A_CH, ch = c % A_CH;
-      int gr = m0 + row;
-      if (gr < p.M) ra[i] = *reinterpret_cast<const float4*>(p.A + (int64_t)gr * p.lda + k0 + ch * 4);
-      else ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // rows past M are clamped, not branched around: their products are never stored, and a
+      // branch per unrolled load would serialise the loads behind vmcnt(0) waits
+      const int gr = min(m0 + row, p.M - 1);
+      ra[i] = *reinterpret_cast<const float4*>(p.A + (int64_t)gr * p.lda + k0 + ch * 4);
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       int c = i * 256 + tid;
       int row = c >> 3, ch = c & 7;
-      int gn = n0 + row;
-      if (gn < p.N)
-        rw[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.W) +
-                                                ((int64_t)gn * p.K + k0) * sizeof(WT) + ch * 16);
-      else rw[i] = make_uint4(0u, 0u, 0u, 0u);
+      const int gn = min(n0 + row, p.N - 1);
+      rw[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.W) +
+                                              ((int64_t)gn * p.K + k0) * sizeof(WT) + ch * 16);
     }
   };
   auto store_tile = [&](int buf) {

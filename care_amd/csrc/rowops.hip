@@ -11,9 +11,10 @@ namespace {
 constexpr int MAXV = 8;  // float4 per lane: d <= 64 * 4 * 8 = 2048
 
 // LayerNorm of one row held as v[0..nv) float4 per lane (chunk index = lane + 64*i).
+// `outb` (optional): bf16 mirror of the normalised row, the A operand of the next bf16 GEMM.
 __device__ __forceinline__ void row_layernorm(float4 (&v)[MAXV], int nv4, int lane, int d,
                                               const float* gamma, const float* beta, float eps,
-                                              float* out) {
+                                              float* out, bf16_t* outb = nullptr) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
@@ -40,6 +41,11 @@ __device__ __forceinline__ void row_layernorm(float4 (&v)[MAXV], int nv4, int la
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
       *reinterpret_cast<float4*>(out + c4 * 4) = o;
+      if (outb) {
+        bf16x4 ob;
+        ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
+        *reinterpret_cast<bf16x4*>(outb + c4 * 4) = ob;
+      }
     }
   }
 }
@@ -48,8 +54,9 @@ __device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.
 
 __global__ __launch_bounds__(256) void add_ln_kernel(const float* x, int64_t ldx, const float* res, int64_t ldres,
                                                      const float* pos, const float* gamma, const float* beta,
-                                                     float eps, float* out, int64_t ldo, int rows, int d, int grp,
-                                                     int out_grp_rows, int out_row_off) {
+                                                     float eps, float* out, bf16_t* outb, int64_t ldo, int rows, int d,
+                                                     int grp, int out_grp_rows, int out_row_off, int nslab,
+                                                     int64_t slab_stride) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -60,12 +67,14 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* x, int64_t ldx
     const int c4 = lane + 64 * i;
     if (c4 < nv4) {
       v[i] = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + c4 * 4);
+      for (int sl = 1; sl < nslab; ++sl)  // split-K partial products of the preceding GEMM
+        add4(v[i], *reinterpret_cast<const float4*>(x + sl * slab_stride + (int64_t)r * ldx + c4 * 4));
       if (res) add4(v[i], *reinterpret_cast<const float4*>(res + (int64_t)r * ldres + c4 * 4));
       if (pos) add4(v[i], *reinterpret_cast<const float4*>(pos + (int64_t)(r % grp) * d + c4 * 4));
     }
   }
   const int64_t orow = (int64_t)(r / grp) * out_grp_rows + out_row_off + (r % grp);
-  row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + orow * ldo);
+  row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + orow * ldo, outb ? outb + orow * ldo : nullptr);
 }
 
 __global__ __launch_bounds__(256) void group_mean_kernel(const float* x, int64_t ldx, int in_grp_rows, int in_row_off,
@@ -109,8 +118,9 @@ __global__ __launch_bounds__(256) void concept_finish_kernel(const float* scores
 __global__ __launch_bounds__(256) void concept_topk_embed_kernel(const float* preds, int64_t ldp, int k, int topk,
                                                                  const float* word, const float* pos,
                                                                  const float* gamma, const float* beta, float eps,
-                                                                 int64_t* labels, float* out, int64_t ldo,
-                                                                 int out_grp_rows, int out_row_off, int d) {
+                                                                 int64_t* labels, float* out, bf16_t* outb,
+                                                                 int64_t ldo, int out_grp_rows, int out_row_off,
+                                                                 int d) {
   // one workgroup per clip.  Rank by counting: rank(i) = #{j : v[j] > v[i] or (v[j] == v[i] and j < i)};
   // the element of rank r < topk is label r (value desc, index asc) - no iterative selection.
   __shared__ float sv[1024];
@@ -142,7 +152,8 @@ __global__ __launch_bounds__(256) void concept_topk_embed_kernel(const float* pr
         add4(v[i], *reinterpret_cast<const float4*>(pp + c4 * 4));
       }
     }
-    row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + ((int64_t)b * out_grp_rows + out_row_off + j) * ldo);
+    const int64_t orow = (int64_t)b * out_grp_rows + out_row_off + j;
+    row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + orow * ldo, outb ? outb + orow * ldo : nullptr);
   }
 }
 
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* tokens, in
                                                        const int32_t* anc, int anc_stride, const float* word,
                                                        const float* pos, int pos0, const float* sem, int sem_div,
                                                        const float* gamma, const float* beta, float eps, float* out,
-                                                       int64_t ldo, int rows, int seq, int d) {
+                                                       bf16_t* outb, int64_t ldo, int rows, int seq, int d) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* tokens, in
       if (sm) add4(v[c], *reinterpret_cast<const float4*>(sm + c4 * 4));
     }
   }
-  row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + (int64_t)r * ldo);
+  row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + (int64_t)r * ldo, outb ? outb + (int64_t)r * ldo : nullptr);
 }
 
 __global__ __launch_bounds__(256) void greedy_update_kernel(const float* pmax, const int32_t* pidx, const float* psum,
@@ -214,13 +225,16 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(const float* pmax, c
 #define ST ((hipStream_t)stream)
 
 extern "C" int care_add_ln(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* pos,
-                           const float* gamma, const float* beta, float eps, float* out, int64_t ldo, int rows,
-                           int d, int grp, int out_grp_rows, int out_row_off, void* stream) {
+                           const float* gamma, const float* beta, float eps, float* out, void* out_bf16,
+                           int64_t ldo, int rows, int d, int grp, int out_grp_rows, int out_row_off, int nslab,
+                           int64_t slab_stride, void* stream) {
   if (!x || !gamma || !beta || !out || rows <= 0 || d <= 0 || grp <= 0) return CARE_EINVAL;
-  if (d % 4 != 0 || d > 2048) return CARE_ESHAPE;
-  if ((ldx % 4) || (ldo % 4) || (res && (ldres % 4)) || !care_aligned16(x) || !care_aligned16(out)) return CARE_EALIGN;
+  if (d % 4 != 0 || d > 2048 || nslab < 1 || nslab > 16) return CARE_ESHAPE;
+  if ((ldx % 4) || (ldo % 4) || (res && (ldres % 4)) || (slab_stride % 4) || !care_aligned16(x) || !care_aligned16(out))
+    return CARE_EALIGN;
   hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, x, ldx, res, ldres, pos, gamma, beta, eps,
-                     out, ldo, rows, d, grp, out_grp_rows, out_row_off);
+                     out, reinterpret_cast<bf16_t*>(out_bf16), ldo, rows, d, grp, out_grp_rows, out_row_off, nslab,
+                     slab_stride);
   return care_launch_status();
 }
 
@@ -244,24 +258,25 @@ extern "C" int care_concept_finish(const float* scores, int64_t lds, float* pred
 
 extern "C" int care_concept_topk_embed(const float* preds, int64_t ldp, int k, int topk, const float* word,
                                        const float* pos, const float* gamma, const float* beta, float eps,
-                                       int64_t* labels, float* out, int64_t ldo, int out_grp_rows, int out_row_off,
-                                       int B, int d, void* stream) {
+                                       int64_t* labels, float* out, void* out_bf16, int64_t ldo, int out_grp_rows,
+                                       int out_row_off, int B, int d, void* stream) {
   if (!preds || !word || !pos || !gamma || !beta || !labels || !out || B <= 0) return CARE_EINVAL;
   if (k <= 0 || k > 1024 || topk <= 0 || topk > 64 || topk > k || d % 4 != 0 || d > 2048) return CARE_ESHAPE;
   hipLaunchKernelGGL(concept_topk_embed_kernel, dim3(B), dim3(256), 0, ST, preds, ldp, k, topk, word, pos, gamma, beta,
-                     eps, labels, out, ldo, out_grp_rows, out_row_off, d);
+                     eps, labels, out, reinterpret_cast<bf16_t*>(out_bf16), ldo, out_grp_rows, out_row_off, d);
   return care_launch_status();
 }
 
 extern "C" int care_embed_ln(const int32_t* tokens, int tok_stride, int tok_off, const int32_t* anc, int anc_stride,
                              const float* word, const float* pos, int pos0, const float* sem, int sem_div,
-                             const float* gamma, const float* beta, float eps, float* out, int64_t ldo, int rows,
-                             int seq, int d, void* stream) {
+                             const float* gamma, const float* beta, float eps, float* out, void* out_bf16,
+                             int64_t ldo, int rows, int seq, int d, void* stream) {
   if (!tokens || !word || !pos || !gamma || !beta || !out || rows <= 0 || seq <= 0 || sem_div <= 0) return CARE_EINVAL;
   if (d % 4 != 0 || d > 2048) return CARE_ESHAPE;
   if (ldo % 4) return CARE_EALIGN;
   hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, tokens, tok_stride, tok_off, anc,
-                     anc_stride, word, pos, pos0, sem, sem_div, gamma, beta, eps, out, ldo, rows, seq, d);
+                     anc_stride, word, pos, pos0, sem, sem_div, gamma, beta, eps, out, reinterpret_cast<bf16_t*>(out_bf16),
+                     ldo, rows, seq, d);
   return care_launch_status();
 }
 

@@ -167,48 +167,82 @@ class HipEngine:
             self._ws[key] = t
         return t
 
-    def gemm(self, A, W, bias, out, act=0, out2=None, n_split=None):
+    @property
+    def bf(self) -> bool:
+        return self.wt == torch.bfloat16
+
+    def wsb(self, name: str, shape) -> Optional[torch.Tensor]:
+        """bf16 mirror workspace of a GEMM-input activation (None in fp32 mode)."""
+        return self.ws(name + "#bf", shape, torch.bfloat16) if self.bf else None
+
+    def gemm(self, A, W, bias, out, act=0, out2=None, n_split=None, tag=None):
+        """out = act(A @ W^T + bias).  bf16 weights + bf16 A -> A-stationary kernel
+        (csrc/gemm_as.hip); anything else -> the generic LDS-tiled kernel (csrc/gemm.hip)."""
         M, K = A.shape
         N = W.shape[0]
         assert W.shape[1] == K and A.stride(1) == 1 and out.stride(-1) == 1
-        call("care_gemm", ptr(A), A.stride(0), ptr(W), _code(W), ptr(bias), ptr(out), out.stride(0), _code(out),
-             ptr(out2), out2.stride(0) if out2 is not None else 0, _code(out2), N if n_split is None else n_split,
-             M, N, K, act)
+        tail = (ptr(bias), ptr(out), out.stride(0), _code(out), ptr(out2),
+                out2.stride(0) if out2 is not None else 0, _code(out2), N if n_split is None else n_split, M, N, K, act)
+        if W.dtype == torch.bfloat16 and A.dtype == torch.bfloat16 and K % 128 == 0 and A.stride(0) % 8 == 0:
+            call("care_gemm_bf16", ptr(A), A.stride(0), _code(A), ptr(W), *tail, tag=tag)
+        else:
+            if A.dtype != torch.float32:
+                raise ValueError("generic GEMM takes fp32 activations")
+            call("care_gemm", ptr(A), A.stride(0), ptr(W), _code(W), *tail, tag=tag)
         return out
 
-    def add_ln(self, x, res, g, be, out, grp=None, out_grp_rows=None, out_row_off=0, pos=None):
-        rows, d = x.shape
+    def add_ln(self, x, res, g, be, out, outb=None, grp=None, out_grp_rows=None, out_row_off=0, pos=None, nslab=1):
+        """out = LN(sum of the nslab slabs of x + res); x is [rows, d] or [nslab, rows, d]."""
+        rows, d = x.shape[-2], x.shape[-1]
         grp = rows if grp is None else grp
         out_grp_rows = grp if out_grp_rows is None else out_grp_rows
-        call("care_add_ln", ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(pos), ptr(g),
-             ptr(be), self.eps, ptr(out), out.stride(-2), rows, d, grp, out_grp_rows, out_row_off)
+        call("care_add_ln", ptr(x), x.stride(-2), ptr(res), res.stride(0) if res is not None else 0, ptr(pos), ptr(g),
+             ptr(be), self.eps, ptr(out), ptr(outb), out.stride(-2), rows, d, grp, out_grp_rows, out_row_off,
+             nslab, x.stride(0) if nslab > 1 else 0)
         return out
 
     def attention(self, Q, K, V, ctx, kv_batch_stride, kv_row_stride, rows_per_kv, nkeys, anc=None, causal=False,
-                  seq=1, pad_tok=None, bias=None):
+                  seq=1, pad_tok=None, bias=None, tag=None):
         rows = Q.shape[0]
         call("care_attention", ptr(Q), Q.stride(0), ptr(K), ptr(V), _code(K), kv_batch_stride, kv_row_stride,
              rows_per_kv, ptr(anc), anc.stride(0) if anc is not None else 0, nkeys, 1 if causal else 0, seq, 0,
              ptr(pad_tok), pad_tok.stride(0) if pad_tok is not None else 0, PAD, ptr(bias),
-             bias.stride(0) if bias is not None else 0, ptr(ctx), ctx.stride(0), rows, self.H)
+             bias.stride(0) if bias is not None else 0, ptr(ctx), ctx.stride(0), _code(ctx), rows, self.H, tag=tag)
         return ctx
 
-    def _mha_self_full(self, name, x, seq, pad_tok, causal, tag):
-        """Self-attention sub-block over whole sequences (teacher forcing / encoder)."""
+    def _ctx(self, tag, rows):
+        """Attention context buffer: only ever read by the output projection GEMM."""
+        return self.ws(tag + "ctx", (rows, self.d), self.wt)
+
+    def _mha_self_full(self, name, x, xb, seq, pad_tok, causal, tag):
+        """Self-attention sub-block over whole sequences (teacher forcing / encoder).
+        x fp32 (residual), xb its bf16 mirror or None.  Returns (x1, x1b)."""
         rows, d = x.shape
         w = self.w
-        qkv = self.gemm(x, w[name + "_qkv_w"], w[name + "_qkv_b"], self.ws(tag + "qkv", (rows, 3 * d)))
-        ctx = self.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], self.ws(tag + "ctx", (rows, d)), seq * 3 * d, 3 * d,
+        qkv = self.gemm(xb if xb is not None else x, w[name + "_qkv_w"], w[name + "_qkv_b"],
+                        self.ws(tag + "qkv", (rows, 3 * d)))
+        ctx = self.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], self._ctx(tag, rows), seq * 3 * d, 3 * d,
                              seq, seq, causal=causal, seq=seq, pad_tok=pad_tok)
         o = self.gemm(ctx, w[name + "_o_w"], w[name + "_o_b"], self.ws(tag + "o", (rows, d)))
-        return self.add_ln(o, x, w[name + "_g"], w[name + "_be"], self.ws(tag + "x1", (rows, d)))
+        x1, x1b = self.ws(tag + "x1", (rows, d)), self.wsb(tag + "x1", (rows, d))
+        self.add_ln(o, x, w[name + "_g"], w[name + "_be"], x1, x1b)
+        return x1, x1b
 
-    def _ffn(self, name, x, out, tag, **ln_kw):
+    def _ffn(self, name, x, xb, out, outb, tag, gemm_tag=None, **ln_kw):
         rows, d = x.shape
         w = self.w
-        h = self.gemm(x, w[name + "_w1"], w[name + "_b1"], self.ws(tag + "h", (rows, self.ff)), act=self.act)
-        f = self.gemm(h, w[name + "_w2"], w[name + "_b2"], self.ws(tag + "f", (rows, d)))
-        return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, **ln_kw)
+        h = self.gemm(xb if xb is not None else x, w[name + "_w1"], w[name + "_b1"],
+                      self.ws(tag + "h", (rows, self.ff), self.wt), act=self.act, tag=gemm_tag)
+        w2 = w[name + "_w2"]
+        if self.bf and self.ff % 512 == 0 and self.ff >= 1024 and rows <= 8192:
+            # small M: split K = ff over blocks; the LayerNorm kernel sums the slabs
+            ns = self.ff // 512
+            f = self.ws(tag + "fslab", (ns, rows, d))
+            call("care_gemm_bf16_splitk", ptr(h), h.stride(0), _code(h), ptr(w2), ptr(w[name + "_b2"]), ptr(f), d,
+                 f.stride(0), rows, d, self.ff, tag=gemm_tag)
+            return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, nslab=ns, **ln_kw)
+        f = self.gemm(h, w2, w[name + "_b2"], self.ws(tag + "f", (rows, d)), tag=gemm_tag)
+        return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, **ln_kw)
 
     # ------------------------------------------------------------------ encoder + concept head
     def encode(self, feats: List[torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -218,6 +252,7 @@ class HipEngine:
             raise ValueError("expected {} feature tensors, got {}".format(len(self.modality), len(feats)))
         B = feats[0].shape[0]
         mem = torch.empty(B, self.Lk, d, device=self.device)
+        memb = torch.empty(B, self.Lk, d, device=self.device, dtype=torch.bfloat16) if self.bf else None
         means = torch.empty(B, len(self.modality) * d, device=self.device)
         for mi, ch in enumerate(self.modality):
             x = feats[mi].to(self.device, torch.float32).contiguous()
@@ -225,25 +260,27 @@ class HipEngine:
             if n != self.rows_of[ch]:
                 raise ValueError("modality `{}`: {} rows, expected {}".format(ch, n, self.rows_of[ch]))
             x2 = x.view(B * n, x.shape[2])
-            lin = self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch], self.ws("enc_lin", (B * n, d)))
+            lin = self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch], self.ws("enc_lin", (B * n, d)), tag="enc_gemm")
             in_mem = ch in self.dec_mod
             if in_mem:
-                dst, grp_rows, off = mem, self.Lk, self.mem_off[ch]
+                dst, dstb, grp_rows, off = mem, memb, self.Lk, self.mem_off[ch]
             else:
-                dst, grp_rows, off = self.ws("enc_side_" + ch, (B, n, d)), n, 0
+                dst, dstb, grp_rows, off = self.ws("enc_side_" + ch, (B, n, d)), None, n, 0
             ln_kw = dict(grp=n, out_grp_rows=grp_rows, out_row_off=off)
             if opt["encoder"] == "Embedder":
-                self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], dst, **ln_kw)
+                self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], dst, dstb, **ln_kw)
             else:  # MultiTransformerEncoder
-                h = self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], self.ws("enc_h0", (B * n, d)),
-                                grp=n, pos=w["enc_pos_" + ch])
+                h, hb = self.ws("enc_h0", (B * n, d)), self.wsb("enc_h0", (B * n, d))
+                self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], h, hb, grp=n, pos=w["enc_pos_" + ch])
                 n_enc = int(opt["num_hidden_layers_encoder"])
                 for li in range(n_enc):
                     nm = "enc{}{}".format(ch, li)
-                    h1 = self._mha_self_full(nm + "_sa", h, n, None, False, "enc_")
-                    last = li == n_enc - 1
-                    h = self._ffn(nm + "_ffn", h1, dst if last else self.ws("enc_h%d" % (li + 1), (B * n, d)), "enc_",
-                                  **(ln_kw if last else {}))
+                    h1, h1b = self._mha_self_full(nm + "_sa", h, hb, n, None, False, "enc_")
+                    if li == n_enc - 1:
+                        self._ffn(nm + "_ffn", h1, h1b, dst, dstb, "enc_", **ln_kw)
+                    else:
+                        h, hb = self.ws("enc_h%d" % (li + 1), (B * n, d)), self.wsb("enc_h%d" % (li + 1), (B * n, d))
+                        self._ffn(nm + "_ffn", h1, h1b, h, hb, "enc_")
             call("care_group_mean", ptr(dst), d, grp_rows, off, n, ptr(means), means.stride(0), mi * d, B, d)
         out: Dict[str, torch.Tensor] = {"encoder_hidden_states": mem}
         out["mean_encoder_hidden_states"] = [means[:, mi * d:(mi + 1) * d] for mi, ch in enumerate(self.modality)
@@ -264,12 +301,12 @@ class HipEngine:
             if self.has_container:
                 labels = torch.empty(B, self.topk, device=self.device, dtype=torch.int64)
                 if self.concat:
-                    dst, grp_rows, off = mem, self.Lk, self.concept_off
+                    dst, dstb, grp_rows, off = mem, memb, self.Lk, self.concept_off
                 else:
-                    dst, grp_rows, off = torch.empty(B, self.topk, d, device=self.device), self.topk, 0
+                    dst, dstb, grp_rows, off = torch.empty(B, self.topk, d, device=self.device), None, self.topk, 0
                 call("care_concept_topk_embed", ptr(preds), kp, self.k_attr, self.topk, ptr(w["attr_word"]),
-                     ptr(w["attr_pos"]), ptr(w["attr_g"]), ptr(w["attr_be"]), self.eps, ptr(labels), ptr(dst), d,
-                     grp_rows, off, B, d)
+                     ptr(w["attr_pos"]), ptr(w["attr_g"]), ptr(w["attr_be"]), self.eps, ptr(labels), ptr(dst),
+                     ptr(dstb), d, grp_rows, off, B, d)
                 out["semantic_labels"] = labels
                 out["semantic_embs"] = dst[:, off: off + self.topk]
                 if self.sem:
@@ -277,6 +314,8 @@ class HipEngine:
                                                               torch.empty(B, d, device=self.device))
                 else:
                     out["semantic_hidden_states"] = None
+        # bf16 mirror of the memory: the A operand of the cross-K/V projection (internal)
+        self._mem_mirror = (mem.data_ptr(), memb)
         return out
 
     # ------------------------------------------------------------------ cross K/V (once per clip)
@@ -287,12 +326,15 @@ class HipEngine:
         (Attention.py:63-67 called from Layers.py:206-213); here once per clip.
         """
         B, Lk, d = mem.shape
-        mem2 = mem.contiguous().view(B * Lk, d)
+        mem = mem.contiguous()
+        mirror = getattr(self, "_mem_mirror", (None, None))
+        src = mirror[1] if (self.bf and mirror[0] == mem.data_ptr() and mirror[1] is not None) else mem
+        src2 = src.view(B * Lk, d)
         out = []
         for li in range(self.n_layers):
             nm = "d{}_ca".format(li)
             kv = self.ws("{}{}".format(tag, li), (B * Lk, 2 * d), self.wt)
-            out.append(self.gemm(mem2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv))
+            out.append(self.gemm(src2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv, tag="cross_kv_gemm"))
         return out
 
     # ------------------------------------------------------------------ teacher-forced decoder
@@ -306,67 +348,77 @@ class HipEngine:
         """
         w, d = self.w, self.d
         N, t = input_ids.shape
+        mem = mem.to(self.device, torch.float32)
         B, Lk = mem.shape[0], mem.shape[1]
         assert N % B == 0 and t <= self.T + 1
         per_clip = N // B
         rows = N * t
         ids32 = input_ids.to(self.device, torch.int32).contiguous()
+        sem_div = 1
         if sem is not None:
             sem = sem.to(self.device, torch.float32).contiguous()
             assert sem.shape[0] in (B, N)
             sem_div = t * (per_clip if sem.shape[0] == B else 1)
-        x = self.ws("tf_x0", (rows, d))
-        call("care_embed_ln", ptr(ids32), t, 0, None, 0, ptr(w["word"]), ptr(w["pos"]), 0, ptr(sem),
-             sem_div if sem is not None else 1, ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(x), d, rows, t, d)
+        x, xb = self.ws("tf_x0", (rows, d)), self.wsb("tf_x0", (rows, d))
+        call("care_embed_ln", ptr(ids32), t, 0, None, 0, ptr(w["word"]), ptr(w["pos"]), 0, ptr(sem), sem_div,
+             ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(x), ptr(xb), d, rows, t, d)
         ckv = self.cross_kv(mem, tag="tf_ckv")
         for li in range(self.n_layers):
-            x1 = self._mha_self_full("d{}_sa".format(li), x, t, ids32, True, "tf_")
+            x1, x1b = self._mha_self_full("d{}_sa".format(li), x, xb, t, ids32, True, "tf_")
             nm = "d{}_ca".format(li)
-            q = self.gemm(x1, w[nm + "_q_w"], w[nm + "_q_b"], self.ws("tf_q", (rows, d)))
+            q = self.gemm(x1b if x1b is not None else x1, w[nm + "_q_w"], w[nm + "_q_b"], self.ws("tf_q", (rows, d)))
             kv = ckv[li]
-            ctx = self.attention(q, kv, kv[:, d:], self.ws("tf_ctx", (rows, d)), Lk * 2 * d, 2 * d, per_clip * t, Lk,
+            ctx = self.attention(q, kv, kv[:, d:], self._ctx("tf_", rows), Lk * 2 * d, 2 * d, per_clip * t, Lk,
                                  bias=w["d{}_hb".format(li)])
             o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws("tf_o", (rows, d)))
-            x2 = self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], self.ws("tf_x2", (rows, d)))
+            x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
+            self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
             last = li == self.n_layers - 1
-            x = self._ffn("d{}_ffn".format(li), x2, torch.empty(rows, d, device=self.device) if last
-                          else self.ws("tf_x3", (rows, d)), "tf_")
+            x = torch.empty(rows, d, device=self.device) if last else self.ws("tf_x3", (rows, d))
+            xb = self.wsb("tf_x3", (rows, d))
+            self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, "tf_")
         hidden = x.view(N, t, d)
         out = {"hidden_states": hidden}
         if want_logits == "all":
-            out["logits"] = self.gemm(x, w["vocab"], None, torch.empty(rows, self.V, device=self.device)).view(N, t, self.V)
+            out["logits"] = self.gemm(xb if xb is not None else x, w["vocab"], None,
+                                      torch.empty(rows, self.V, device=self.device)).view(N, t, self.V)
         elif want_logits == "last":
-            last_rows = hidden[:, -1, :]
-            out["logits"] = self.gemm(last_rows, w["vocab"], None, torch.empty(N, self.V, device=self.device))
+            src = (xb if xb is not None else x).view(N, t, d)[:, -1, :]
+            out["logits"] = self.gemm(src, w["vocab"], None, torch.empty(N, self.V, device=self.device))
         return out
 
     # ------------------------------------------------------------------ incremental decode step
     def _decode_step(self, t, N, rows_per_clip, tok, anc, sem, ckv, skv, Lk, tag):
-        """One decoder step for N rows: new token at position t-1 -> final hidden [N, d]."""
+        """One decoder step for N rows: new token at position t-1 -> final hidden (fp32, bf16 mirror)."""
         w, d, T = self.w, self.d, self.T
-        x = self.ws(tag + "x0", (N, d))
+        x, xb = self.ws(tag + "x0", (N, d)), self.wsb(tag + "x0", (N, d))
         call("care_embed_ln", ptr(tok), tok.stride(0), t - 1, ptr(anc), anc.stride(0) if anc is not None else 0,
              ptr(w["word"]), ptr(w["pos"]), t - 1, ptr(sem), rows_per_clip, ptr(w["emb_g"]), ptr(w["emb_be"]),
-             self.eps, ptr(x), d, N, 1, d)
+             self.eps, ptr(x), ptr(xb), d, N, 1, d)
+        g = lambda f32, b16: b16 if b16 is not None else f32  # GEMM input: the bf16 mirror when it exists
         for li in range(self.n_layers):
             nm = "d{}_sa".format(li)
             cache = skv[li]  # [N, T, 2d]
             q = self.ws(tag + "q", (N, d))
-            self.gemm(x, w[nm + "_qkv_w"], w[nm + "_qkv_b"], q, out2=cache[:, t - 1, :], n_split=d)
+            self.gemm(g(x, xb), w[nm + "_qkv_w"], w[nm + "_qkv_b"], q, out2=cache[:, t - 1, :], n_split=d,
+                      tag="step_qkv_gemm")
             flat = cache.view(N * T, 2 * d)
-            ctx = self.attention(q, flat, flat[:, d:], self.ws(tag + "ctx", (N, d)), T * 2 * d, 2 * d, 1, t, anc=anc,
-                                 pad_tok=tok)
-            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)))
-            x1 = self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], self.ws(tag + "x1", (N, d)))
+            ctx = self.attention(q, flat, flat[:, d:], self._ctx(tag, N), T * 2 * d, 2 * d, 1, t, anc=anc,
+                                 pad_tok=tok, tag="step_self_attn")
+            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
+            x1, x1b = self.ws(tag + "x1", (N, d)), self.wsb(tag + "x1", (N, d))
+            self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b)
             nm = "d{}_ca".format(li)
-            q2 = self.gemm(x1, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)))
+            q2 = self.gemm(g(x1, x1b), w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)), tag="step_dxd_gemm")
             kv = ckv[li]
-            ctx = self.attention(q2, kv, kv[:, d:], self.ws(tag + "ctx", (N, d)), Lk * 2 * d, 2 * d, rows_per_clip, Lk,
-                                 bias=w["d{}_hb".format(li)])
-            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)))
-            x2 = self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], self.ws(tag + "x2", (N, d)))
-            x = self._ffn("d{}_ffn".format(li), x2, self.ws(tag + "x3_%d" % (li & 1), (N, d)), tag)
-        return x
+            ctx = self.attention(q2, kv, kv[:, d:], self._ctx(tag, N), Lk * 2 * d, 2 * d, rows_per_clip, Lk,
+                                 bias=w["d{}_hb".format(li)], tag="step_cross_attn")
+            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
+            x2, x2b = self.ws(tag + "x2", (N, d)), self.wsb(tag + "x2", (N, d))
+            self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
+            x, xb = self.ws(tag + "x3_%d" % (li & 1), (N, d)), self.wsb(tag + "x3_%d" % (li & 1), (N, d))
+            self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, tag, gemm_tag="step_ffn_gemm")
+        return x, xb
 
     def greedy(self, mem: torch.Tensor, sem: Optional[torch.Tensor], steps: Optional[int] = None):
         """Greedy decoding (= beam search with beam_size 1, models/Wrapper.py:34-35) of B clips.
@@ -387,17 +439,57 @@ class HipEngine:
         score.zero_(); length.zero_(); fin.zero_()
         ckv = self.cross_kv(mem)
         skv = [self.ws("g_skv%d" % li, (B, T, 2 * d), self.wt) for li in range(self.n_layers)]
-        parts = _lib.argmax_parts(self.V)
+        bf = self.wt == torch.bfloat16 and d <= 512
+        parts = _lib.argmax_parts(self.V, B, bf)
         pmax = self.ws("g_pmax", (B, parts))
         pidx = self.ws("g_pidx", (B, parts), torch.int32)
         psum = self.ws("g_psum", (B, parts))
         for t in range(1, steps + 1):
-            x = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_")
-            call("care_gemm_argmax", ptr(x), d, ptr(self.w["vocab"]), _code(self.w["vocab"]), ptr(pmax), ptr(pidx),
-                 ptr(psum), B, self.V, d)
+            x, xb = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_")
+            if bf:
+                call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(pmax), ptr(pidx),
+                     ptr(psum), B, self.V, d, tag="step_vocab_argmax")
+            else:
+                call("care_gemm_argmax", ptr(x), d, ptr(self.w["vocab"]), _code(self.w["vocab"]), ptr(pmax),
+                     ptr(pidx), ptr(psum), B, self.V, d, tag="step_vocab_argmax")
             call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
                  ptr(length), ptr(fin), t, T, EOS, B)
         return fed, length, score
+
+    def translate_greedy(self, feats: List[torch.Tensor], use_graph: bool = True):
+        """encode + greedy decode of one batch; replayed from a hipGraph when possible.
+
+        One pass issues ~430 kernel launches (14 per step); driven from Python that is
+        host-bound, so the whole pass is captured once per (batch, input buffers) into a
+        hipGraph (torch.cuda.CUDAGraph on the same stream capture) and replayed.  The graph
+        is keyed on the input pointers: callers that re-use their feature buffers (bench,
+        pinned double-buffered loaders) replay; a first-seen buffer set runs eagerly.
+        Returns (enc_outputs, fed, length, score) - static tensors when replayed.
+        """
+        feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        if not use_graph:
+            enc = self.encode(feats)
+            return (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states")))
+        key = ("greedy", tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        entry = self._graphs.get(key)
+        if entry is None:
+            enc = self.encode(feats)  # eager pass: allocates every workspace
+            out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states")))
+            self._graphs[key] = "seen"
+            return out
+        if entry == "seen":
+            if len(self._graphs) > 8:
+                self._graphs = {k: v for k, v in self._graphs.items() if k == key}
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                enc = self.encode(feats)
+                out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states")))
+            entry = (graph, out)
+            self._graphs[key] = entry
+        graph, out = entry
+        graph.replay()
+        return out
 
     def beam(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int):
         """Beam search of B clips x bm beams, state on the device (csrc/beam.hip)."""
@@ -425,8 +517,8 @@ class HipEngine:
         skv = [self.ws("b_skv%d" % li, (N, T, 2 * d), self.wt) for li in range(self.n_layers)]
         for t in range(1, T + 1):
             a_old, a_new = anc[(t - 1) & 1], anc[t & 1]
-            x = self._decode_step(t, N, bm, tok, a_old, sem, ckv, skv, Lk, "b_")
-            self.gemm(x, self.w["vocab"], None, logits)
+            x, xb = self._decode_step(t, N, bm, tok, a_old, sem, ckv, skv, Lk, "b_")
+            self.gemm(xb if xb is not None else x, self.w["vocab"], None, logits)
             call("care_beam_select", ptr(logits), self.V, self.V, bm, ptr(cval), ptr(cidx), N)
             call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
                  ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)

@@ -46,16 +46,14 @@ class Translator_ARFormer(object):
             engine = model.engine()
             if engine.T != self.max_len - 1:
                 raise ValueError("translator max_len {} != model max_len {}".format(self.max_len, engine.T + 1))
+            if self.beam_size == 1:
+                return self._greedy(engine, feats, kwargs.get("use_graph", True))
             enc = model.encoding_phase(feats)
             inputs = model.prepare_inputs_for_decoder(enc, batch)
-            mem = inputs["encoder_hidden_states"]
-            sem = inputs.get("semantic_hidden_states")
-            if self.beam_size == 1:
-                return self._greedy(engine, mem, sem)
-            return self._beam(engine, mem, sem)
+            return self._beam(engine, inputs["encoder_hidden_states"], inputs.get("semantic_hidden_states"))
 
-    def _greedy(self, engine, mem, sem):
-        fed, length, score = engine.greedy(mem, sem)
+    def _greedy(self, engine, feats, use_graph):
+        _, fed, length, score = engine.translate_greedy(list(feats), use_graph=use_graph)
         fed, length, score = fed.cpu(), length.cpu().tolist(), score.cpu()
         hyps, scores = [], []
         n_best = self.topk

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 1
+#define CARE_ABI_VERSION 3
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -77,6 +77,31 @@ int care_gemm_argmax(const float* A, int64_t lda, const void* W, int wdtype,
                      float* pmax, int32_t* pidx, float* psum, int M, int N, int K, void* stream);
 
 /*
+ * care_gemm_bf16 / care_gemm_argmax_bf16: the same contracts as care_gemm /
+ *   care_gemm_argmax for bf16 weights, implemented by the A-stationary kernel
+ *   (csrc/gemm_as.hip: A panel resident in registers, W streamed through LDS by LDS-DMA).
+ *   A may be fp32 (rounded to bf16 on load) or bf16 (a_dtype); lda in elements of A.
+ *   Requires K % 128 == 0 and lda % 8 == 0; care_gemm_argmax_bf16 additionally K <= 512.
+ *   The number of partial column groups of the argmax variant depends on M as well:
+ *   care_argmax_parts_bf16(M, N).
+ */
+int care_gemm_bf16(const void* A, int64_t lda, int a_dtype, const void* W, const float* bias,
+                   void* C0, int64_t ldc0, int c0_dtype, void* C1, int64_t ldc1, int c1_dtype,
+                   int n_split, int M, int N, int K, int act, void* stream);
+int care_argmax_parts_bf16(int M, int N);
+/*
+ * care_gemm_bf16_splitk: K > 512 at small M (the decode-step FFN dense2, SubLayers.py:143-145):
+ *   K/512 slices; slice s writes A[:, 512s:512s+512] * W[:, 512s:512s+512]^T (+ bias when
+ *   s == 0) to the fp32 slab C + s * slab_stride.  The slabs are summed by the consumer,
+ *   care_add_ln(nslab = K / 512, slab_stride), so no reduction pass exists.  K % 512 == 0.
+ */
+int care_gemm_bf16_splitk(const void* A, int64_t lda, int a_dtype, const void* W,
+                          const float* bias, float* C, int64_t ldc, int64_t slab_stride,
+                          int M, int N, int K, void* stream);
+int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
+                          int32_t* pidx, float* psum, int M, int N, int K, void* stream);
+
+/*
  * care_greedy_update: finish the argmax over the partials and advance the greedy state.
  *   Replaces Beam.advance / Beam.done for beam_size == 1 (misc/Decoding/Beam.py:45-85)
  *   and the bookkeeping of Translator_ARFormer.beam_decode_step
@@ -100,12 +125,16 @@ int care_greedy_update(const float* pmax, const int32_t* pidx, const float* psum
  *   Output row of input row r: (r / grp) * out_grp_rows + out_row_off + (r % grp), so an
  *   encoder stream lands directly inside the [B, Lk, d] cross-attention memory
  *   (the torch.cat of Encoder.py:148-149 and Framework.py:184-185 becomes an offset).
+ *   out_bf16 (optional, same layout and ldo as out): a bf16 mirror of the result, the A
+ *   operand of the next bf16 GEMM (the same rounding that GEMM would apply on load).
+ *   nslab > 1: x is the sum of nslab fp32 slabs spaced slab_stride elements apart (the
+ *   split-K partial products of care_gemm_bf16_splitk); nslab = 1 otherwise.
  *   d % 4 == 0, d <= 2048.
  */
 int care_add_ln(const float* x, int64_t ldx, const float* res, int64_t ldres,
                 const float* pos, const float* gamma, const float* beta, float eps,
-                float* out, int64_t ldo, int rows, int d, int grp, int out_grp_rows,
-                int out_row_off, void* stream);
+                float* out, void* out_bf16, int64_t ldo, int rows, int d, int grp,
+                int out_grp_rows, int out_row_off, int nslab, int64_t slab_stride, void* stream);
 
 /*
  * care_group_mean: out[g, col_off + c] = mean over the grp rows of group g of x[., c].
@@ -139,8 +168,8 @@ int care_concept_finish(const float* scores, int64_t lds, float* preds, int64_t 
 int care_concept_topk_embed(const float* preds, int64_t ldp, int k, int topk,
                             const float* word, const float* pos, const float* gamma,
                             const float* beta, float eps, int64_t* labels, float* out,
-                            int64_t ldo, int out_grp_rows, int out_row_off, int B, int d,
-                            void* stream);
+                            void* out_bf16, int64_t ldo, int out_grp_rows, int out_row_off,
+                            int B, int d, void* stream);
 
 /*
  * care_embed_ln: decoder input embedding.
@@ -154,7 +183,8 @@ int care_concept_topk_embed(const float* preds, int64_t ldp, int k, int topk,
 int care_embed_ln(const int32_t* tokens, int tok_stride, int tok_off, const int32_t* anc,
                   int anc_stride, const float* word, const float* pos, int pos0,
                   const float* sem, int sem_div, const float* gamma, const float* beta,
-                  float eps, float* out, int64_t ldo, int rows, int seq, int d, void* stream);
+                  float eps, float* out, void* out_bf16, int64_t ldo, int rows, int seq, int d,
+                  void* stream);
 
 /*
  * care_attention: scaled-dot-product attention for single query rows, head dim 64.
@@ -168,14 +198,15 @@ int care_embed_ln(const int32_t* tokens, int tok_stride, int tok_off, const int3
  *   pad_tok (int32, optional): key j of row r is masked when
  *   pad_tok[ptb * pad_stride + j] == pad_id, ptb = anc ? anc[r*anc_stride + j] : r / rows_per_kv
  *   (the key-pad mask of models/Decoder/Transformer.py:15-28,169-174).
- *   bias (optional) fp32 [H, bias_ld].  ctx [rows, ldctx] fp32.  nkeys <= 128.
+ *   bias (optional) fp32 [H, bias_ld].  ctx [rows, ldctx] of type ctx_dtype (bf16 when the
+ *   context only feeds a bf16 GEMM).  nkeys <= 128.
  */
 int care_attention(const float* Q, int64_t ldq, const void* K, const void* V, int kv_dtype,
                    int64_t kv_batch_stride, int64_t kv_row_stride, int rows_per_kv,
                    const int32_t* anc, int anc_stride, int nkeys, int causal, int seq,
                    int causal_off, const int32_t* pad_tok, int pad_stride, int pad_id,
-                   const float* bias, int bias_ld, float* ctx, int64_t ldctx, int rows,
-                   int heads, void* stream);
+                   const float* bias, int bias_ld, void* ctx, int64_t ldctx, int ctx_dtype,
+                   int rows, int heads, void* stream);
 
 /*
  * care_beam_select: per row of logits [rows, ldl] (V valid columns): the beam_size best

@@ -1,0 +1,267 @@
+"""GPU: each entry point of the C ABI against a plain PyTorch fp32 reference of the same op.
+
+bf16 kernels are compared with the same math on bf16-ROUNDED operands accumulated in
+fp32/fp64 (that is what the MFMA computes), so the tolerance only has to cover summation
+order: 2e-3 absolute on O(1..30) outputs.  fp32 kernels: 1e-4 at K <= 2048.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _call(name, *args):
+    from care_amd import _lib
+
+    _lib.call(name, *args)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + int(np.prod(shape)) % 9973)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+GEMM_SHAPES = [
+    (1, 512, 512), (5, 10547, 512), (64, 512, 512), (100, 1536, 512), (257, 2048, 512), (300, 512, 2048),
+    (1024, 512, 128), (28 * 7, 512, 2048), (130, 640, 640), (96, 500, 2048), (200, 768, 768),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_as_f32A", "bf16_as_bf16A"])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm(M, N, K, mode, act):
+    if mode != "f32" and act == 2 and M > 64:
+        pytest.skip("activation covered on small shapes")
+    A = _rand(M, K, seed=1)
+    W = _rand(N, K, seed=2, scale=1 / math.sqrt(K))
+    bias = _rand(N, seed=3)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    if mode == "f32":
+        _call("care_gemm", _p(A), K, _p(W), 0, _p(bias), _p(out), N, 0, None, 0, 0, N, M, N, K, act)
+        ref = A.double() @ W.double().t() + bias.double()
+        tol = 2e-4
+    else:
+        Wb = W.to(torch.bfloat16).contiguous()
+        ref = _bf(A).double() @ _bf(W).double().t() + bias.double()
+        tol = 3e-3
+        if mode == "bf16_generic":
+            if K % 64:
+                pytest.skip("generic bf16 kernel needs K % 64 == 0")
+            _call("care_gemm", _p(A), K, _p(Wb), 1, _p(bias), _p(out), N, 0, None, 0, 0, N, M, N, K, act)
+        else:
+            if K % 128:
+                pytest.skip("A-stationary kernel needs K % 128 == 0")
+            Ain = A if mode == "bf16_as_f32A" else A.to(torch.bfloat16).contiguous()
+            _call("care_gemm_bf16", _p(Ain), K, 0 if mode == "bf16_as_f32A" else 1, _p(Wb), _p(bias), _p(out), N, 0,
+                  None, 0, 0, N, M, N, K, act)
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    torch.cuda.synchronize()
+    err = (out.double() - ref).abs().max().item()
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("kernel", ["care_gemm", "care_gemm_bf16"])
+def test_gemm_split_destinations_and_bf16_out(kernel):
+    M, K, d = 77, 512, 512
+    A, W, bias = _rand(M, K, seed=4), _rand(3 * d, K, seed=5, scale=0.05), _rand(3 * d, seed=6)
+    Wb = W.to(torch.bfloat16).contiguous()
+    q = torch.zeros(M, d, device=DEV)
+    cache = torch.zeros(M, 29, 2 * d, device=DEV, dtype=torch.bfloat16)
+    dst = cache[:, 7, :]
+    if kernel == "care_gemm":
+        _call(kernel, _p(A), K, _p(Wb), 1, _p(bias), _p(q), d, 0, _p(dst), dst.stride(0), 1, d, M, 3 * d, K, 0)
+    else:
+        _call(kernel, _p(A), K, 0, _p(Wb), _p(bias), _p(q), d, 0, _p(dst), dst.stride(0), 1, d, M, 3 * d, K, 0)
+    ref = _bf(A) @ _bf(W).t() + bias
+    torch.cuda.synchronize()
+    assert (q - ref[:, :d]).abs().max().item() < 3e-3
+    assert (cache[:, 7, :].float() - ref[:, d:]).abs().max().item() < 2e-2  # bf16 output rounding
+    assert cache[:, 6, :].abs().max().item() == 0 and cache[:, 8, :].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("M", [1, 3, 64, 129, 1000])
+@pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_as"])
+def test_gemm_argmax(M, mode):
+    from care_amd import _lib
+
+    N, K = 10547, 512
+    A = _rand(M, K, seed=7)
+    W = _rand(N, K, seed=8, scale=0.05)
+    if mode == "f32":
+        parts = _lib.argmax_parts(N)
+        ref = A.double() @ W.double().t()
+        Wd, code = W, 0
+    else:
+        Wd, code = W.to(torch.bfloat16).contiguous(), 1
+        parts = _lib.argmax_parts(N, M, mode == "bf16_as")
+        ref = _bf(A).double() @ _bf(W).double().t()
+    pmax = torch.empty(M, parts, device=DEV)
+    pidx = torch.empty(M, parts, device=DEV, dtype=torch.int32)
+    psum = torch.empty(M, parts, device=DEV)
+    if mode == "bf16_as":
+        _call("care_gemm_argmax_bf16", _p(A), K, 0, _p(Wd), _p(pmax), _p(pidx), _p(psum), M, N, K)
+    else:
+        _call("care_gemm_argmax", _p(A), K, _p(Wd), code, _p(pmax), _p(pidx), _p(psum), M, N, K)
+    fed = torch.zeros(M, 30, device=DEV, dtype=torch.int32)
+    score = torch.zeros(M, device=DEV)
+    length = torch.zeros(M, device=DEV, dtype=torch.int32)
+    fin = torch.zeros(M, device=DEV, dtype=torch.int32)
+    _call("care_greedy_update", _p(pmax), _p(pidx), _p(psum), parts, _p(fed), 30, _p(score), _p(length), _p(fin), 1,
+          29, 3, M)
+    torch.cuda.synchronize()
+    top2 = ref.topk(2, dim=1)
+    safe = (top2[0][:, 0] - top2[0][:, 1]) > (1e-5 if mode == "f32" else 1e-3)
+    assert torch.equal(fed[:, 1][safe].long(), top2[1][:, 0][safe])
+    logp = torch.log_softmax(ref, dim=1).gather(1, fed[:, 1:2].long()).squeeze(1)
+    assert (score.double() - logp).abs().max().item() < (1e-4 if mode == "f32" else 2e-3)
+    assert torch.all(length == 1)
+
+
+def test_add_ln_group_mean_embed():
+    rows, d, grp = 56, 512, 28
+    x, res = _rand(rows, d, seed=9), _rand(rows, d, seed=10)
+    g, b = _rand(d, seed=11), _rand(d, seed=12)
+    out = torch.zeros(2, 100, d, device=DEV)
+    outb = torch.zeros(2, 100, d, device=DEV, dtype=torch.bfloat16)
+    _call("care_add_ln", _p(x), d, _p(res), d, None, _p(g), _p(b), 1e-12, _p(out), _p(outb), d, rows, d, grp, 100, 30, 1, 0)
+    ref = torch.nn.functional.layer_norm(x + res, (d,), g, b, 1e-12).view(2, grp, d)
+    torch.cuda.synchronize()
+    assert (out[:, 30:58] - ref).abs().max().item() < 1e-5
+    assert out[:, :30].abs().max().item() == 0 and out[:, 58:].abs().max().item() == 0
+    assert torch.equal(outb, out.to(torch.bfloat16))  # the mirror is the fp32 result rounded once
+    means = torch.zeros(2, 3 * d, device=DEV)
+    _call("care_group_mean", _p(out), d, 100, 30, grp, _p(means), 3 * d, d, 2, d)
+    torch.cuda.synchronize()
+    assert (means[:, d:2 * d] - ref.mean(1)).abs().max().item() < 1e-6
+    # embedding: tokens [3, 29], teacher-forced layout, with a global semantic vector
+    V, T = 1000, 29
+    word, pos, sem = _rand(V, d, seed=13), _rand(30, d, seed=14), _rand(3, d, seed=15)
+    tok = torch.randint(0, V, (3, T), dtype=torch.int32).to(DEV)
+    o2 = torch.zeros(3 * T, d, device=DEV)
+    _call("care_embed_ln", _p(tok), T, 0, None, 0, _p(word), _p(pos), 0, _p(sem), T, _p(g), _p(b), 1e-12, _p(o2), None,
+          d, 3 * T, T, d)
+    ref2 = torch.nn.functional.layer_norm(word[tok.long()] + pos[:T].unsqueeze(0) + sem.unsqueeze(1), (d,), g, b, 1e-12)
+    torch.cuda.synchronize()
+    assert (o2.view(3, T, d) - ref2).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("kv_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ctx_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nkeys,causal", [(114, False), (84, False), (29, True), (7, False)])
+def test_attention(kv_dtype, ctx_dtype, nkeys, causal):
+    B, H, d, per = 3, 8, 512, (29 if causal else 5)
+    rows = B * per
+    q = _rand(rows, d, seed=16)
+    kv = (_rand(B * nkeys, 2 * d, seed=17)).to(kv_dtype).contiguous()
+    bias = _rand(H, nkeys, seed=18)
+    tok = torch.randint(0, 4, (B, nkeys), dtype=torch.int32).to(DEV)
+    tok[:, 0] = 2
+    ctx = torch.zeros(rows, d, device=DEV, dtype=ctx_dtype)
+    _call("care_attention", _p(q), d, _p(kv), _p(kv[:, d:]), 1 if kv_dtype == torch.bfloat16 else 0, nkeys * 2 * d,
+          2 * d, per, None, 0, nkeys, 1 if causal else 0, per, 0, _p(tok), nkeys, 0, _p(bias), nkeys, _p(ctx), d,
+          1 if ctx_dtype == torch.bfloat16 else 0, rows, H)
+    kvf = kv.float().view(B, nkeys, 2, H, 64)
+    k, v = kvf[:, :, 0].permute(0, 2, 1, 3), kvf[:, :, 1].permute(0, 2, 1, 3)        # [B,H,Lk,64]
+    qh = q.view(B, per, H, 64).permute(0, 2, 1, 3)
+    s = qh @ k.transpose(-1, -2) / 8.0
+    mask = tok.eq(0).view(B, 1, 1, nkeys).expand(B, H, per, nkeys).clone()
+    if causal:
+        mask |= torch.triu(torch.ones(per, nkeys, dtype=torch.bool, device=DEV), 1).view(1, 1, per, nkeys)
+    s = s.masked_fill(mask, -1e9) + bias.view(1, H, 1, nkeys)
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(rows, d)
+    torch.cuda.synchronize()
+    assert (ctx.float() - ref).abs().max().item() < (2e-5 if ctx_dtype == torch.float32 else 2e-2)
+
+
+def test_concept_kernels():
+    B, k, kp, d, topk = 5, 500, 512, 512, 30
+    scores = _rand(B, kp, seed=19, scale=1.5)
+    preds = torch.full((B, kp), float("nan"), device=DEV)
+    avg = torch.zeros(B, device=DEV)
+    _call("care_concept_finish", _p(scores), kp, _p(preds), kp, _p(avg), B, k)
+    p = torch.sigmoid(scores[:, :k])
+    ref = 1.0 - torch.exp(torch.log(torch.clamp(1.0 - p, 1e-12, 1)))
+    torch.cuda.synchronize()
+    assert (preds[:, :k] - ref).abs().max().item() < 1e-6
+    assert preds[:, k:].abs().max().item() == 0
+    assert (avg - p.mean(1)).abs().max().item() < 1e-6
+    word, pos = _rand(k, d, seed=20), _rand(topk, d, seed=21)
+    g, b = _rand(d, seed=22), _rand(d, seed=23)
+    preds[1, 17] = preds[1, 3] = 0.999  # an exact tie: order must be index-ascending
+    labels = torch.zeros(B, topk, device=DEV, dtype=torch.int64)
+    mem = torch.zeros(B, 114, d, device=DEV)
+    _call("care_concept_topk_embed", _p(preds), kp, k, topk, _p(word), _p(pos), _p(g), _p(b), 1e-12, _p(labels),
+          _p(mem), None, d, 114, 84, B, d)
+    torch.cuda.synchronize()
+    pr = preds[:, :k].cpu().numpy()
+    for i in range(B):
+        order = sorted(range(k), key=lambda j: (-pr[i, j], j))[:topk]
+        assert labels[i].tolist() == order
+    ref_e = torch.nn.functional.layer_norm(word[labels] + pos.unsqueeze(0), (d,), g, b, 1e-12)
+    assert (mem[:, 84:] - ref_e).abs().max().item() < 1e-5
+    assert mem[:, :84].abs().max().item() == 0
+
+
+def test_beam_select():
+    rows, V, bm = 7, 10547, 5
+    logits = _rand(rows, V, seed=24, scale=2.0)
+    logits[2, 100] = logits[2, 5000] = logits[2].max() + 1.0  # tie for the top spot
+    cv = torch.zeros(rows, bm, device=DEV)
+    ci = torch.zeros(rows, bm, device=DEV, dtype=torch.int32)
+    _call("care_beam_select", _p(logits), V, V, bm, _p(cv), _p(ci), rows)
+    lp = torch.log_softmax(logits, dim=1)
+    torch.cuda.synchronize()
+    x = logits.cpu().numpy()
+    for r in range(rows):
+        order = sorted(range(V), key=lambda j: (-x[r, j], j))[:bm]
+        assert ci[r].tolist() == order
+    assert (cv - lp.gather(1, ci.long())).abs().max().item() < 1e-5
+
+
+def test_rejected_arguments_raise():
+    from care_amd import _lib
+
+    A = _rand(4, 48)
+    W = _rand(8, 48)
+    out = torch.zeros(4, 8, device=DEV)
+    with pytest.raises(_lib.CareHipError, match="ESHAPE"):
+        _call("care_gemm", _p(A), 48, _p(W), 0, None, _p(out), 8, 0, None, 0, 0, 8, 4, 8, 48, 0)
+    with pytest.raises(_lib.CareHipError, match="EINVAL"):
+        _call("care_gemm", None, 48, _p(W), 0, None, _p(out), 8, 0, None, 0, 0, 8, 4, 8, 64, 0)
+
+
+@pytest.mark.parametrize("M", [5, 300, 1024])
+def test_gemm_splitk_slabs_summed_by_add_ln(M):
+    N, K = 512, 2048
+    A = _rand(M, K, seed=30).to(torch.bfloat16)
+    W = _rand(N, K, seed=31, scale=0.03)
+    Wb = W.to(torch.bfloat16).contiguous()
+    bias, res = _rand(N, seed=32), _rand(M, N, seed=33)
+    g, b = _rand(N, seed=34), _rand(N, seed=35)
+    slabs = torch.full((K // 512, M, N), float("nan"), device=DEV)
+    _call("care_gemm_bf16_splitk", _p(A), K, 1, _p(Wb), _p(bias), _p(slabs), N, slabs.stride(0), M, N, K)
+    out = torch.zeros(M, N, device=DEV)
+    _call("care_add_ln", _p(slabs), N, _p(res), N, None, _p(g), _p(b), 1e-12, _p(out), None, N, M, N, M, M, 0,
+          K // 512, slabs.stride(0))
+    y = A.float().double() @ _bf(W).double().t() + bias.double()
+    ref = torch.nn.functional.layer_norm(y.float() + res, (N,), g, b, 1e-12)
+    torch.cuda.synchronize()
+    assert (slabs.sum(0).double() - y).abs().max().item() < 3e-3
+    assert (out - ref).abs().max().item() < 3e-3
