@@ -93,15 +93,16 @@ def main():
     feats = [f.to(dev) for f in synth_feats(1000 + rank, feat_shapes(opt, B))]
     torch.cuda.synchronize()
 
+    from care_amd.sharding import all_gather_records, pack_records
+
     gathered = None
     if world > 1:
-        gathered = [torch.empty(B, eng.T + 3, device=dev, dtype=torch.int32) for _ in range(world)]
+        gathered = [torch.empty(B, eng.T + 4, device=dev, dtype=torch.int32) for _ in range(world)]
 
     def step():
         _, fed, length, score = eng.translate_greedy(feats, use_graph=not args.no_graph)
-        if world > 1:
-            rec = torch.cat([fed, length.view(-1, 1), score.view(torch.int32).view(-1, 1)], dim=1)
-            dist.all_gather(gathered, rec)
+        if world > 1:  # metrics-step exchange over RCCL: every rank gets every caption
+            all_gather_records(pack_records(fed, length, score, B), gathered)
         return fed, length, score
 
     def barrier():

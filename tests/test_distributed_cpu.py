@@ -1,0 +1,79 @@
+"""CPU, 2 processes, gloo: the batch-sharded path's exchange step (care_amd/sharding.py).
+
+The GPU run uses the same code with backend nccl (= RCCL over xGMI).  Each rank
+"translates" its shard with the CPU oracle (standing in for the device decode, which needs
+a GPU) and the metrics-step all-gather must reproduce the single-process result exactly.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_clips, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from care_amd.configs import feat_shapes, make_opt
+        from care_amd.sharding import gather_captions, shard_feats
+        from care_amd.synth import synth_feats, synth_state_dict
+        from oracle import care_cpu
+        from conftest import GoldenCase
+
+        meta = GoldenCase("msvd_base_i_b10").meta
+        opt = make_opt("msvd_base_i", max_len=8)
+        P = synth_state_dict(5, [(k, tuple(s)) for k, s in meta["state_dict"] if "position_embeddings" not in k] +
+                             [("decoder.embedding.position_embeddings.weight", (8, 512))])
+        feats = synth_feats(5, feat_shapes(opt, n_clips))
+        mine = shard_feats(feats, rank, world)
+        T = opt["max_len"] - 1
+        n = mine[0].shape[0]
+        fed = torch.zeros(n, T + 1, dtype=torch.int32)
+        fed[:, 0] = 2
+        length = torch.zeros(n, dtype=torch.int32)
+        score = torch.zeros(n)
+        if n:
+            hyps, scores = care_cpu.translate_batch(P, opt, mine)
+            for i, (h, s) in enumerate(zip(hyps, scores)):
+                fed[i, 1: len(h[0]) + 1] = torch.tensor(h[0], dtype=torch.int32)
+                length[i] = len(h[0])
+                score[i] = s[0]
+        g_fed, g_len, g_score = gather_captions(fed, length, score, n_clips)
+        if rank == 0:
+            torch.save({"fed": g_fed, "len": g_len, "score": g_score, "P": None}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [5, 4])
+def test_sharded_translate_equals_single_process(tmp_path, n_clips):
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_feats, synth_state_dict
+    from oracle import care_cpu
+    from conftest import GoldenCase
+
+    out_path = str(tmp_path / "gathered.pt")
+    mp.spawn(_worker, args=(2, _free_port(), n_clips, out_path), nprocs=2, join=True)
+    got = torch.load(out_path)
+
+    meta = GoldenCase("msvd_base_i_b10").meta
+    opt = make_opt("msvd_base_i", max_len=8)
+    P = synth_state_dict(5, [(k, tuple(s)) for k, s in meta["state_dict"] if "position_embeddings" not in k] +
+                         [("decoder.embedding.position_embeddings.weight", (8, 512))])
+    hyps, scores = care_cpu.translate_batch(P, opt, synth_feats(5, feat_shapes(opt, n_clips)))
+    assert got["fed"].shape[0] == n_clips          # the padded tail of the ragged shard was dropped
+    for i in range(n_clips):
+        n = int(got["len"][i])
+        assert got["fed"][i, 1: n + 1].tolist() == hyps[i][0]
+        assert abs(float(got["score"][i]) - scores[i][0]) < 1e-6

@@ -1,0 +1,164 @@
+"""CPU: host-side logic, the drop-in seam, and the C-ABI library (no compute calls)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_matches_reference_inventory(golden):
+    """Keys and shapes equal the reference's (captured by gen_golden.py), so its checkpoints load strict."""
+    from care_amd import get_framework
+    from care_amd.configs import make_opt
+
+    m = golden.meta
+    model = get_framework(make_opt(m["config"], **m["overrides"]))
+    ours = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+    assert sorted(ours) == sorted((k, s) for k, s in m["state_dict"])
+    assert sum(p.numel() for p in model.parameters()) == m["n_params"]
+    opt, P, _, _ = golden.build()
+    model.load_state_dict(P, strict=True)
+
+
+def test_reference_recorded_parameter_count():
+    # notebooks/retrieval_robustness.ipynb:186-187: 18,218,884 parameters, vocab 10,547
+    from care_amd import get_framework
+    from care_amd.configs import make_opt
+
+    model = get_framework(make_opt("msrvtt_care"))
+    assert sum(p.numel() for p in model.parameters()) == 18218884
+    assert model.backbone is None and model.pointer is None
+    assert model.input_keys_for_decoder == ["encoder_hidden_states", "semantic_hidden_states"]
+    assert model.get_keys_to_device() == ["feats", "input_ids"]
+    assert get_framework(make_opt("msrvtt_base_ami")).input_keys_for_decoder == ["encoder_hidden_states"]
+
+
+def test_init_weights_follow_reference_scheme():
+    # models/Framework.py:115-134: LN = (1, 0), Linear bias 0, PAD embedding row 0, hybrid_bias 0
+    from care_amd import get_framework
+    from care_amd.configs import make_opt
+
+    sd = get_framework(make_opt("msrvtt_care")).state_dict()
+    assert torch.all(sd["decoder.embedding.LayerNorm.weight"] == 1) and torch.all(sd["decoder.embedding.LayerNorm.bias"] == 0)
+    assert torch.all(sd["decoder.embedding.word_embeddings.weight"][0] == 0)
+    assert torch.all(sd["decoder.layers.0.ffn.dense1.bias"] == 0)
+    assert torch.all(sd["decoder.layers.0.inter_attention.SDPA.hybrid_bias"] == 0)
+    assert sd["decoder.layers.0.inter_attention.SDPA.hybrid_bias"].shape == (8, 114)
+
+
+def test_factory_errors_match_reference():
+    from care_amd import get_framework, get_translator
+    from care_amd.configs import make_opt
+
+    with pytest.raises(ValueError, match="can not find the class"):
+        get_framework(make_opt("msrvtt_base_ami", encoder="NoSuchEncoder"))
+    with pytest.raises(ValueError, match="can not find the class"):
+        get_translator(make_opt("msrvtt_base_ami", decoding_type="NARFormer"))
+    with pytest.raises(ValueError):
+        get_framework(make_opt("msrvtt_base_ami", decoder="SingleLayerRNNDecoder"))
+    model = get_framework(make_opt("msrvtt_care"))
+    with pytest.raises(KeyError, match="semantic_hidden_states"):
+        model.prepare_inputs_for_decoder({"encoder_hidden_states": torch.zeros(1)}, {"feats": []})
+
+
+def test_no_silent_fallback_on_cpu_or_in_training():
+    from care_amd import get_framework, get_translator
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_feats
+
+    opt = make_opt("msvd_base_i")
+    model = get_framework(opt).eval()
+    feats = synth_feats(0, feat_shapes(opt, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.encoding_phase(feats)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        get_translator(opt).translate_batch([model], {"feats": feats})
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        model.train().feedforward_step({"feats": feats, "input_ids": torch.zeros(2, 29, dtype=torch.long)})
+    with pytest.raises(TypeError):
+        get_translator(opt).translate_batch([torch.nn.Linear(2, 2)], {"feats": feats})
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "care_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """The .so loads and exports exactly the entry points include/care_hip.h declares."""
+    import ctypes
+
+    from care_amd import _lib, build
+
+    build.build()
+    header = open(os.path.join(ROOT, "include", "care_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(care_\w+)\s*\(", header, re.M))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.exported_symbols())
+    loaded = _lib.load()
+    assert loaded.care_version() == int(re.search(r"#define CARE_ABI_VERSION (\d+)", header).group(1))
+    assert loaded.care_arch() == b"gfx950"
+    assert loaded.care_argmax_parts(10547) == 166
+    assert loaded.care_argmax_parts_bf16(1024, 10547) % 8 == 0
+
+
+def test_synth_generator_is_deterministic_and_portable():
+    from care_amd.synth import synth_state_dict, tensor_sha256, uniform
+
+    u = uniform(7, "x", (4,))
+    np.testing.assert_array_equal(u, uniform(7, "x", (4,)))
+    assert not np.array_equal(u, uniform(8, "x", (4,)))
+    sd = synth_state_dict(3, [("a.LayerNorm.weight", (8,)), ("a.LayerNorm.bias", (8,)), ("a.dense.weight", (8, 8)),
+                              ("a.dense.bias", (8,))], row_scale={"a.dense.weight": {2: 10.0}})
+    assert abs(float(sd["a.LayerNorm.weight"].mean()) - 1.0) < 0.1
+    assert float(sd["a.dense.weight"][2].abs().max()) > float(sd["a.dense.weight"][1].abs().max())
+    # pinned digest: any change of the generator invalidates tests/golden (regenerate with oracle/gen_golden.py)
+    assert tensor_sha256(sd["a.dense.weight"]) == tensor_sha256(synth_state_dict(
+        3, [("a.dense.weight", (8, 8))], row_scale={"a.dense.weight": {2: 10.0}})["a.dense.weight"])
+
+
+def test_translator_result_assembly_matches_reference_quirks():
+    """Host-side assembly (no GPU): n_best shrinks across clips exactly like Translator.py:211-220."""
+    from care_amd.translator import Translator_ARFormer
+
+    tr = Translator_ARFormer({"beam_size": 5, "topk": 3, "beam_alpha": 1.0, "max_len": 30})
+
+    class FakeEngine:
+        T = 29
+
+        def beam(self, mem, sem, bm, need):
+            nfin = torch.tensor([5, 1, 5], dtype=torch.int32)
+            fscore = torch.tensor([[-4.0, -2.0, -9.0, -8.0, -7.0, 0, 0, 0, 0, 0],
+                                   [-3.0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+                                   [-1.0, -2.0, -3.0, -4.0, -5.0, 0, 0, 0, 0, 0]])
+            flen = torch.tensor([[2, 2, 3, 4, 7, 0, 0, 0, 0, 0], [3, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+                                 [1, 1, 1, 1, 1, 0, 0, 0, 0, 0]], dtype=torch.int32)
+            fhyp = torch.arange(3 * 10 * 30, dtype=torch.int32).view(3, 10, 30)
+            return nfin, fscore, flen, fhyp
+
+    hyps, scores = tr._beam(FakeEngine(), None, None)
+    assert [len(h) for h in hyps] == [3, 1, 1]          # clip 1 has one hypothesis -> clip 2 is cut to one
+    assert scores[0] == [-1.0, -1.0, -2.0]              # -2/2, -7/7 (stable order), -4/2
+    assert hyps[0][0] == [30, 31] and hyps[0][1] == list(range(120, 127))
+    assert scores[2] == [-1.0]
+
+
+def test_sharding_bounds_and_records():
+    from care_amd.sharding import pack_records, shard_bounds, unpack_records
+
+    assert [shard_bounds(10, r, 4) for r in range(4)] == [(0, 3, 3), (3, 6, 3), (6, 9, 3), (9, 10, 3)]
+    assert shard_bounds(2, 3, 4) == (2, 2, 1)
+    fed = torch.arange(2 * 30, dtype=torch.int32).view(2, 30)
+    rec = pack_records(fed, torch.tensor([5, 7]), torch.tensor([-1.5, -2.25]), per=3)
+    assert rec.shape == (3, 33) and rec[2].abs().sum() == 0
+    f, l, s = unpack_records(rec)
+    assert torch.equal(f, fed) and l.tolist() == [5, 7] and s.tolist() == [-1.5, -2.25]
