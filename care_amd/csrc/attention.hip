@@ -12,10 +12,12 @@
 //     xor shuffles across the 8 key slots (8,16,32) - no LDS at all.
 //   * P.V: each lane accumulates its 8 dims over its key slot, 3 xor-shuffles merge the 8
 //     slots, lanes 0-7 store 256 contiguous bytes of context.
-//   * NKB (key blocks of 8) is a template parameter so all K loads of a wave are issued
-//     back to back (up to 16 KiB in flight per wave) before the first use.
+//   * NKB (key blocks of 8) is a template parameter so ALL K and V loads of a wave are issued
+//     back to back (up to 32 KiB in flight per wave) before the first use.
 // Masking follows the reference exactly: masked keys get -1e9 (not -inf), the hybrid bias
 // is added AFTER the mask (models/components/Attention.py:104-111).
+#include <type_traits>
+
 #include "care_common.h"
 
 namespace {
@@ -50,19 +52,53 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 
   const KT* Kb = reinterpret_cast<const KT*>(p.K) + h * 64 + chunk * 8;
   const KT* Vb = reinterpret_cast<const KT*>(p.V) + h * 64 + chunk * 8;
+  static_assert(sizeof(KT) == 2 || sizeof(KT) == 4, "bf16 or fp32 K/V");
 
-  // ---- scores
-  float s[NKB];
-  int64_t off[NKB];
+  // ---- issue every K and V load of this (row, head) before the first use: 2*NKB 16-byte
+  // loads per lane in flight, so the HBM latency is paid once, not once for K and once for V
+  using Frag = typename std::conditional<sizeof(KT) == 2, bf16x8, float4>::type;
+  constexpr int FPK = sizeof(KT) == 2 ? 1 : 2;  // 16-byte pieces per 8 elements
+  Frag kf[NKB][FPK], vf[NKB][FPK];
+  bool valid[NKB];
+  int kvbs[NKB];
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
     const int j = kb * 8 + slot;
-    const bool valid = j < nk;
-    const int jj = valid ? j : 0;
-    const int kvb = p.anc ? p.anc[(int64_t)r * p.anc_stride + jj] : kvb_default;
-    off[kb] = (int64_t)kvb * p.kv_batch_stride + (int64_t)jj * p.kv_row_stride;
+    valid[kb] = j < nk;
+    const int jj = valid[kb] ? j : 0;
+    kvbs[kb] = p.anc ? p.anc[(int64_t)r * p.anc_stride + jj] : kvb_default;
+  }
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int jj = valid[kb] ? kb * 8 + slot : 0;
+    const int64_t off = (int64_t)kvbs[kb] * p.kv_batch_stride + (int64_t)jj * p.kv_row_stride;
+#pragma unroll
+    for (int f = 0; f < FPK; ++f) kf[kb][f] = *reinterpret_cast<const Frag*>(Kb + off + f * 4);
+  }
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int jj = valid[kb] ? kb * 8 + slot : 0;
+    const int64_t off = (int64_t)kvbs[kb] * p.kv_batch_stride + (int64_t)jj * p.kv_row_stride;
+#pragma unroll
+    for (int f = 0; f < FPK; ++f) vf[kb][f] = *reinterpret_cast<const Frag*>(Vb + off + f * 4);
+  }
+  auto unpack = [](const Frag (&fr)[FPK], float (&o)[8]) {
+    if constexpr (sizeof(KT) == 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (float)fr[0][i];
+    } else {
+      o[0] = fr[0].x; o[1] = fr[0].y; o[2] = fr[0].z; o[3] = fr[0].w;
+      o[4] = fr[1].x; o[5] = fr[1].y; o[6] = fr[1].z; o[7] = fr[1].w;
+    }
+  };
+
+  // ---- scores
+  float s[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int j = kb * 8 + slot;
     float kv[8];
-    care_load8(Kb + off[kb], kv);
+    unpack(kf[kb], kv);
     float d = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) d = fmaf(q[i], kv[i], d);
@@ -70,11 +106,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     d += __shfl_xor(d, 2, 64);
     d += __shfl_xor(d, 4, 64);
     d *= 0.125f;  // 1/sqrt(64), exact
-    if (valid) {
-      if (p.pad_tok) {
-        const int ptb = p.anc ? kvb : kvb_default;
-        if (p.pad_tok[(int64_t)ptb * p.pad_stride + j] == p.pad_id) d = -1e9f;
-      }
+    if (valid[kb]) {
+      if (p.pad_tok && p.pad_tok[(int64_t)kvbs[kb] * p.pad_stride + j] == p.pad_id) d = -1e9f;
       if (p.bias) d += p.bias[h * p.bias_ld + j];
     } else {
       d = -INFINITY;
@@ -105,7 +138,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
     float vv[8];
-    care_load8(Vb + off[kb], vv);
+    unpack(vf[kb], vv);
     const float pw = s[kb] * inv;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = fmaf(pw, vv[i], acc[i]);

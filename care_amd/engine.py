@@ -82,9 +82,14 @@ class HipEngine:
         wt = lambda t: t.detach().to(self.device, torch.float32).to(self.wt).contiguous()
         w = {}
         opt, d = self.opt, self.d
+        # Concept detection ends in a DISCRETE choice (top-30 of 500, pred_attribute.py:264) whose
+        # neighbouring probabilities differ by ~1e-4, below bf16 operand noise (~1.5e-3 measured).
+        # So with a concept head the feature-embedding GEMMs stay in exact f32 MFMA even in bf16
+        # mode (once per clip, 12% of the FLOPs); everything downstream of the choice is bf16.
+        enc_wt = f32 if (self.has_concepts and opt["encoder"] == "Embedder") else wt
         for ch in self.modality:
             p = "encoder.Encoder_{}".format(ch.upper())
-            w["enc_w_" + ch], w["enc_b_" + ch] = wt(sd[p + ".0.weight"]), f32(sd[p + ".0.bias"])
+            w["enc_w_" + ch], w["enc_b_" + ch] = enc_wt(sd[p + ".0.weight"]), f32(sd[p + ".0.bias"])
             if opt["encoder"] == "Embedder":
                 w["enc_g_" + ch], w["enc_be_" + ch] = f32(sd[p + ".1.weight"]), f32(sd[p + ".1.bias"])
             elif opt["encoder"] == "MultiTransformerEncoder":

@@ -70,3 +70,58 @@ def test_translate_batch_fp32(golden):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
         assert all(isinstance(s, float) for s in a)
     assert all(isinstance(t, int) for hs in hyps for h in hs for t in h)
+
+
+# ----------------------------------------------------------------------------- bf16 mode
+# A bf16 rounding of an O(1) activation is already up to 2^-8 = 3.9e-3, so the 1e-3 of the
+# north star is not attainable by any path that stores or multiplies bf16.
+# Bars asserted here, measured on MI355X with margin: hidden states max-abs <= 4e-2 and
+# mean-abs <= 5e-3 against the fp32 reference; concept outputs exact (they stay fp32);
+# logsumexp of the logits <= 1e-3; greedy ids identical wherever the reference's own
+# top-1/top-2 margin exceeds the bf16 noise (audited against the oracle's margins).
+BF16_MAX, BF16_MEAN = 4e-2, 5e-3
+
+
+def test_encoding_and_teacher_forced_bf16(golden):
+    opt, P, feats, ids = golden.build()
+    z = golden.z
+    model = _model(opt, P, "bf16")
+    enc = model.encoding_phase(_dev(feats))
+    if "preds_attr" in z and opt["encoder"] == "Embedder":
+        # concept path is exact even in bf16 mode: same labels, same probabilities
+        assert _maxdiff(enc["preds_attr"], z["preds_attr"]) < ATOL_FP32
+        assert np.array_equal(enc["semantic_labels"].cpu().numpy(), z["semantic_labels"])
+        assert _maxdiff(enc["encoder_hidden_states"][0], z["encoder_hidden_states_clip0"]) < ATOL_FP32
+    else:
+        assert _maxdiff(enc["encoder_hidden_states"][0], z["encoder_hidden_states_clip0"]) < BF16_MAX
+    out = model.feedforward_step({"feats": _dev(feats), "input_ids": ids.to("cuda:0")})
+    n = z["tf_hidden_states"].shape[0]
+    diff = np.abs(out["hidden_states"][:n].float().cpu().numpy() - z["tf_hidden_states"])
+    assert diff.max() < BF16_MAX and diff.mean() < BF16_MEAN, (diff.max(), diff.mean())
+    assert _maxdiff(torch.logsumexp(out["logits"], -1), z["tf_logits_lse"]) < 1e-3
+
+
+def test_greedy_bf16_matches_up_to_near_ties(golden):
+    """bf16 greedy ids vs the oracle: any divergence must start at a step where the oracle's
+    own top-1/top-2 log-prob margin is tiny (random-init logits are nearly flat)."""
+    from care_amd import get_translator
+    from oracle import care_cpu
+
+    opt, P, feats, _ = golden.build()
+    if opt.get("beam_size", 1) != 1:
+        pytest.skip("greedy audit")
+    hyps, _ = get_translator(opt).translate_batch([_model(opt, P, "bf16")], {"feats": _dev(feats)})
+    ref_hyps, _ = golden.hyps()
+    enc = care_cpu.encoding_phase(P, opt, feats)
+    inputs = care_cpu.inputs_for_decoder(opt, enc)
+    for i, (h, r) in enumerate(zip(hyps, ref_hyps)):
+        h, r = h[0], r[0]
+        if h == r:
+            continue
+        t = next(k for k in range(min(len(h), len(r))) if h[k] != r[k])
+        prefix = torch.tensor([[2] + r[:t]])
+        one = {k: v[i:i + 1] for k, v in inputs.items()}
+        logp = torch.log_softmax(care_cpu.decoding_phase(P, opt, prefix, one, True)["logits"], dim=1)[0]
+        top2 = logp.topk(2)[0]
+        assert float(top2[0] - top2[1]) < 5e-3, "bf16 greedy diverged at a clear-margin step"
+        assert float(logp.max() - logp[h[t]]) < 5e-3
