@@ -17,7 +17,7 @@ ABI_VERSION = 3
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcare_hip.so")
+LIB_PATH = os.environ.get("CARE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcare_hip.so")
 
 # name -> argtypes, in the exact order of include/care_hip.h
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float

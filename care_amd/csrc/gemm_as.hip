@@ -5,30 +5,52 @@
 // N-tile and synchronises every k-step; at K = 512 that is all prologue.  Here instead:
 //
 //   * a workgroup owns a panel of 128 rows (4 waves x 32 rows).  Each wave loads the MFMA
-//     A-fragments of its 32 rows for a whole K-chunk of 512 ONCE, straight from global memory
+//     A-fragments of its 32 rows for the whole K (<= 512) ONCE, straight from global memory
 //     into 128 VGPRs (all 32 loads in flight at once), and keeps them there;
-//   * W is streamed in tiles of 32 output columns x 512 k (32 KiB) through a double-buffered
-//     LDS ring with LDS-DMA (global_load_lds, 16 B per lane, one 1-KiB W row per
-//     wave-instruction).  The LDS image is lane-linear, so the bank-conflict swizzle
-//     (16-byte chunk ^= row & 15) is applied to the per-lane SOURCE address and again on the
-//     ds_read_b128 of the B fragment (conflict-free: see the group analysis in DESIGN.md);
-//   * one barrier per W tile (64 MFMA 16x16x32 per wave between barriers); the next tile's
-//     DMA is issued right after the barrier and lands during the MFMAs;
-//   * block -> (panel, column range) mapping is XCD-aware: the 8 XCDs each take 1/8 of the
-//     column ranges and walk the panels, so every XCD L2 streams its slice of W once.
+//   * W is streamed in tiles of 16 output columns x 512 k (16 KiB) through a 4-deep LDS ring
+//     filled by LDS-DMA (global_load_lds, 16 B per lane, one 1-KiB W row per
+//     wave-instruction) with THREE tiles in flight: the DMA latency (~2 us under load) is
+//     several times the 32 MFMAs a wave spends on a tile, so one tile of prefetch leaves the
+//     kernel latency-bound (measured: 18 % MFMA occupancy).  Waits are counted
+//     (s_waitcnt vmcnt(N) with N = the exact number of younger VM operations, output stores
+//     included) and the barrier is a raw s_barrier, so neither the in-flight DMA nor the
+//     previous tiles' stores are drained;
+//   * the LDS image is lane-linear, so the bank-conflict swizzle (16-byte chunk ^= row & 15)
+//     is applied to the per-lane SOURCE address and again on the ds_read_b128 of the B
+//     fragment (conflict-free for every 16-lane read group);
+//   * in the store mode the MFMA operands are swapped (D = tile of (A W^T)^T), so a lane holds
+//     4 consecutive output columns of one row: one 16-byte (fp32) / 8-byte (bf16) store per
+//     16x16 tile per lane;
+//   * block -> (panel, column range) mapping is XCD-aware: the sharers of the bigger operand
+//     are XCD neighbours (tall A: the blocks of a panel; wide W: the panels walking one range).
 //
-// MODES  STREAM_STORE : K <= 512, any N: bias + activation + (split) store per tile.
-//        STREAM_ARGMAX: K <= 512: running per-row (max, argmax, sum-exp) over the block's
-//                       column range (greedy vocabulary projection; logits never stored).
-//        MULTI_STORE  : K > 512 (FFN2, wide feature embedders): 4 tiles (128 columns) per
-//                       block with accumulators persistent over the K-chunks.
-// A may be bf16 (no conversion) or fp32 (rounded to bf16 on load, exactly what the generic
-// kernel does while staging).  W is bf16 [N, K].  Requires K % 128 == 0.
+// MODES  STREAM_STORE : bias + activation + (split) store per tile; with kslices > 1 it is
+//                       the split-K form (slice s -> fp32 slab s, summed by care_add_ln).
+//        STREAM_ARGMAX: running per-row (max, argmax, sum-exp) over the block's column range
+//                       (greedy vocabulary projection; the logits are never stored).
+// A may be bf16 (no conversion) or fp32 (rounded to bf16 on load).  W is bf16 [N, ldw].
+// Requires K % 128 == 0 and K <= 512 per slice.
+#include <cstdlib>
+
 #include "care_common.h"
+
+// Ablation builds only (tools/gemm_bench.py): -DCARE_AS_DBG=<bits> 1 no stores, 2 no MFMA, 4 no W DMA,
+// 8 no A loads.  Compile-time so that the shipped kernel carries no debug branches.
+#ifndef CARE_AS_DBG
+#define CARE_AS_DBG 0
+#endif
 
 namespace {
 
-enum { STREAM_STORE = 0, STREAM_ARGMAX = 1, MULTI_STORE = 2 };
+enum { STREAM_STORE = 0, STREAM_ARGMAX = 1 };
+
+constexpr int TILE_N = 16;             // output columns per W tile
+constexpr int TILE_BYTES = TILE_N * 1024;
+constexpr int RING = 4;                // LDS ring slots
+constexpr int AHEAD = 3;               // tiles in flight
+constexpr int BIAS_OFF = RING * TILE_BYTES;
+constexpr int BIAS_MAX = 2048;         // bias columns a block can stage
+constexpr int LDS_BYTES = BIAS_OFF + BIAS_MAX * 4;
 
 struct AsArgs {
   const void* A; int64_t lda;
@@ -38,17 +60,15 @@ struct AsArgs {
   void* C1; int64_t ldc1; int c1_bf16;
   int n_split, M, N, K, act;
   int panels, ns;        // grid decomposition
+  int panel_major;       // 1: blocks sharing an A panel are XCD neighbours; 0: blocks sharing a W range are
   int kslices;           // split-K: slice s multiplies K range [512 s, 512 s + 512) into slab s of C0
   int64_t ldw;           // row stride of W in elements (== full K)
   int64_t slab_stride;   // elements between consecutive fp32 slabs of C0
   float* pmax; int32_t* pidx; float* psum;
+  int total_items;       // kslices * per-slice items (grid may be smaller: persistent blocks)
 };
 
-__device__ __forceinline__ float as_act(float v, int act) {
-  if (act == CARE_ACT_RELU) return fmaxf(v, 0.0f);
-  if (act == CARE_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-  return v;
-}
+__device__ __forceinline__ float as_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 template <typename AT>
 __device__ __forceinline__ bf16x8 load_a_frag(const AT* p);
@@ -66,264 +86,307 @@ __device__ __forceinline__ bf16x8 load_a_frag<float>(const float* p) {
   return v;
 }
 
-// FULL: K % 512 == 0, every K-chunk has all 16 k-steps.  The unrolled loads/MFMAs then carry
-// no run-time predicate: a predicate (even wave-uniform) makes hipcc branch around every
-// load and wait vmcnt(0) per element - 32 dependent round trips instead of 32 loads in flight.
+// s_waitcnt vmcnt(n) needs an immediate: dispatch over the even counts that can occur.
+// lgkmcnt(0) rides along so this wave's LDS writes/reads are complete before the barrier.
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    case 20: asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// FULL: K == 512, every unrolled load / MFMA is unpredicated.  A run-time predicate (even a
+// wave-uniform one) makes hipcc branch around every load and wait vmcnt(0) per element.
 template <typename AT, int MODE, bool FULL>
 __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x 32 KiB W tiles
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
 
-  // ---- XCD-aware block decomposition (blocks b and b+8 share an XCD)
-  const int per_slice = (MODE == MULTI_STORE) ? (int)gridDim.x : p.panels * p.ns;
-  const int slice = blockIdx.x / per_slice, bslot = blockIdx.x % per_slice;
+  // ---- persistent workgroups: the grid is at most ~2 blocks per CU and each block walks work
+  // items (K slice, A panel, column range) with stride gridDim.x (a multiple of 8, so a block
+  // keeps its XCD class).  Launching one tiny workgroup per item is dispatch-bound: 21 504
+  // workgroups of the cross-K/V projection cost 406 us with every instruction ablated.
+  const int per_slice = p.total_items / p.kslices;
+  for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+  const int slice = item / per_slice, bslot = item % per_slice;
   const int xcd = bslot & 7, idx = bslot >> 3;
   int panel, ns;
-  if (MODE == MULTI_STORE) {  // blocks that share an A panel are neighbours on one XCD
-    ns = idx % p.ns;
-    panel = (idx / p.ns) * 8 + xcd;
-  } else {                    // blocks that share a W column range are neighbours on one XCD
-    panel = idx % p.panels;
-    ns = (idx / p.panels) * 8 + xcd;
-  }
-  if (panel >= p.panels || ns >= p.ns) return;
-  const int tiles_total = (p.N + 31) >> 5;
-  int t0, t1;
-  if (MODE == MULTI_STORE) { t0 = ns * 4; t1 = min(t0 + 4, tiles_total); }
-  else {
-    const int tpb = (tiles_total + p.ns - 1) / p.ns;
-    t0 = ns * tpb; t1 = min(t0 + tpb, tiles_total);
-  }
+  if (p.panel_major) { ns = idx % p.ns; panel = (idx / p.ns) * 8 + xcd; }
+  else { panel = idx % p.panels; ns = (idx / p.panels) * 8 + xcd; }
+  if (panel >= p.panels || ns >= p.ns) continue;
+  const int tiles_total = (p.N + TILE_N - 1) / TILE_N;
+  const int tpb = (tiles_total + p.ns - 1) / p.ns;
+  const int t0 = ns * tpb, t1 = min(t0 + tpb, tiles_total);
   const int m0 = panel * 128 + wave * 32;
   if (t0 >= t1) {  // empty column range (ns is rounded up to a multiple of 8)
     if (MODE == STREAM_ARGMAX && lane < 32 && m0 + lane < p.M) {
       const int64_t o = (int64_t)(m0 + lane) * p.ns + ns;
       p.pmax[o] = -INFINITY; p.pidx[o] = 0x7fffffff; p.psum[o] = 0.f;
     }
-    return;
+    continue;
   }
+  // every wave must be done reading the ring (and the bias) of the previous item
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
   const AT* Ap = reinterpret_cast<const AT*>(p.A) + slice * 512;
   const bf16_t* Wp = p.W + slice * 512;
   const float* biasp = slice == 0 ? p.bias : nullptr;
+  const int ksn = FULL ? 16 : (p.K >> 5);
+  const int kbytes = FULL ? 1024 : p.K * 2;
+
+  // ---- A fragments of this wave's 32 rows, whole K, resident for the life of the block
   int arow[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) arow[mt] = min(m0 + mt * 16 + fr, p.M - 1);
-
   bf16x8 a[2][16];
-  auto load_a = [&](int kc) {
-    const int ksn = FULL ? 16 : min(16, (p.K - kc * 512) >> 5);
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      if (FULL || ks < ksn) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          a[mt][ks] = load_a_frag<AT>(Ap + (int64_t)arow[mt] * p.lda + kc * 512 + ks * 32 + fg * 8);
-      }
-  };
 
-  // stage W tile `tile`, K-chunk kc into LDS buffer `buf`: wave w copies rows 8w..8w+7,
-  // one 1-KiB row per LDS-DMA instruction; lane = chunk slot, source chunk = slot ^ (row & 15)
-  auto stage = [&](int tile, int kc, int buf) {
-    const int kbytes = FULL ? 1024 : min(512, p.K - kc * 512) * 2;
+  // ---- bias slice of this block's column range -> LDS (read back with an asm ds_read, see below)
+  const int col0 = t0 * TILE_N;
+  if (MODE == STREAM_STORE && biasp) {
+    float* sb = reinterpret_cast<float*>(smem + BIAS_OFF);
+    const int nb = min((t1 - t0) * TILE_N, p.N - col0);
+    for (int i = tid; i < ((nb + 3) & ~3); i += 256) sb[i] = i < nb ? biasp[col0 + i] : 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);  // the bias loads are waited for HERE, before any DMA is in flight
+
+  // stage W tile `tile` into ring slot `slot`: wave w copies rows 4w..4w+3, one 1-KiB row per
+  // LDS-DMA instruction; lane = chunk slot, source chunk = slot ^ (row & 15).  4 VM ops / wave.
+  // per-lane source pointers of this wave's 4 rows at tile 0; tile t adds t * 16 rows
+  const unsigned char* wrow[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = wave * 8 + i;
-      const int n = min(tile * 32 + row, p.N - 1);
-      const int src_chunk = lane ^ (row & 15);
-      if (FULL || src_chunk * 16 < kbytes) {
-        const unsigned char* g = reinterpret_cast<const unsigned char*>(Wp + (int64_t)n * p.ldw + kc * 512) + src_chunk * 16;
+  for (int i = 0; i < 4; ++i)
+    wrow[i] = reinterpret_cast<const unsigned char*>(Wp + (int64_t)(wave * 4 + i) * p.ldw) + ((lane ^ (wave * 4 + i)) << 4);
+  const int64_t wtile = (int64_t)TILE_N * p.ldw * 2;  // bytes between consecutive tiles
+  auto stage = [&](int tile, int slot) {
+    if (CARE_AS_DBG & 4) return;
+    const bool whole = tile * TILE_N + TILE_N <= p.N;  // uniform; only the last tile can be ragged
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 4 + i;
+      if (FULL || (lane ^ row) * 16 < kbytes) {
+        const unsigned char* g = wrow[i] + (int64_t)tile * wtile;
+        if (!whole) g -= (int64_t)max(tile * TILE_N + row - (p.N - 1), 0) * p.ldw * 2;  // clamp to the last W row
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(smem + buf * 32768 + row * 1024),
+                                         (__attribute__((address_space(3))) void*)(smem + slot * TILE_BYTES + row * 1024),
                                          16, 0, 0);
       }
     }
   };
 
-  f32x4 acc[MODE == MULTI_STORE ? 4 : 1][2][2];
-  auto zero_acc = [&](int q) {
+  f32x4 acc[2];
+  // B fragments are read BDEPTH k-steps ahead of the MFMAs that use them: one ds_read_b128 has
+  // ~130+ cycles of latency but feeds only 32 cycles of MFMA, so a shallow prefetch leaves the
+  // loop LDS-latency-bound (measured: ~2600 cycles per tile instead of ~600).
+  constexpr int BDEPTH = 8;
+  // chunk (ks*4 + fg) ^ fr  ==  (ks & ~3)*4 + ((ks & 3) ^ (fr >> 2))*4 + (fg ^ (fr & 3)): per lane
+  // only FOUR distinct byte offsets (r = ks & 3) plus the compile-time 256 * (ks >> 2).
+  int boff[4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+  for (int r = 0; r < 4; ++r) boff[r] = fr * 1024 + (((r ^ (fr >> 2)) * 4 + (fg ^ (fr & 3))) << 4);
+  auto compute = [&](int slot) {
+    const unsigned char* sb = smem + slot * TILE_BYTES;
+    bf16x8 fb[BDEPTH];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[q][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  // B fragments are read one k-step ahead of the MFMAs that use them, so the LDS latency
-  // is covered by the previous step's four MFMAs instead of being exposed before each group.
-  auto compute = [&](int buf, int kc, int q) {
-    const int ksn = FULL ? 16 : min(16, (p.K - kc * 512) >> 5);
-    const unsigned char* b0 = smem + buf * 32768 + fr * 1024;
-    bf16x8 fb[2][2];
-    fb[0][0] = *reinterpret_cast<const bf16x8*>(b0 + ((fg ^ fr) << 4));
-    fb[0][1] = *reinterpret_cast<const bf16x8*>(b0 + 16 * 1024 + ((fg ^ fr) << 4));
+    for (int ks = 0; ks < BDEPTH; ++ks)
+      if (FULL || ks < ksn) fb[ks] = *reinterpret_cast<const bf16x8*>(sb + boff[ks & 3] + (ks >> 2) * 256);
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
       if (FULL || ks < ksn) {
-        if (ks + 1 < 16 && (FULL || ks + 1 < ksn)) {
-          const int off = (((ks + 1) * 4 + fg) ^ fr) << 4;
-          fb[(ks + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(b0 + off);
-          fb[(ks + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(b0 + 16 * 1024 + off);
+        const bf16x8 b = fb[ks % BDEPTH];
+        if (ks + BDEPTH < 16 && (FULL || ks + BDEPTH < ksn))
+          fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff[ks & 3] + ((ks + BDEPTH) >> 2) * 256);
+        if (CARE_AS_DBG & 2) { asm volatile("" :: "v"(b)); continue; }
+        if constexpr (MODE == STREAM_ARGMAX) {  // D[row of A][col = W row]: a lane sees 1 column, 4 rows
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], b, acc[1], 0, 0, 0);
+        } else {  // swapped: a lane holds 4 CONSECUTIVE output columns of one row
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[0][ks], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[1][ks], acc[1], 0, 0, 0);
         }
-        acc[q][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], fb[ks & 1][0], acc[q][0][0], 0, 0, 0);
-        acc[q][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], fb[ks & 1][0], acc[q][1][0], 0, 0, 0);
-        acc[q][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], fb[ks & 1][1], acc[q][0][1], 0, 0, 0);
-        acc[q][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], fb[ks & 1][1], acc[q][1][1], 0, 0, 0);
       }
   };
-  // Epilogue.  Everything that selects a destination is wave-uniform (a 16-column MFMA tile
-  // never straddles n_split), the bias comes from LDS (a global load here would make hipcc
-  // drain the in-flight LDS-DMA of the next tile with vmcnt(0)), and interior tiles take a
-  // guard-free path.
-  const float* sbias = reinterpret_cast<const float*>(smem + 65536);
-  const int bias0 = t0 * 32;
-  auto store_tile = [&](int tile, int q) {
-    const bool interior = (m0 + 32 <= p.M) && (tile * 32 + 32 <= p.N);
+
+  // Store mode: acc[mt][j] = C[row m0 + 16 mt + fr][col 16 tile + 4 fg + j].  Everything that
+  // selects a destination is wave-uniform (a 16-column tile never straddles n_split).
+  // Returns the number of VM store instructions issued when that number is exact (2), else -1.
+  auto store_tile = [&](int tile, float4 bv) -> int {
+    const int cbase = tile * TILE_N;
+    const bool second = cbase >= p.n_split;
+    unsigned char* C = reinterpret_cast<unsigned char*>(second ? p.C1 : p.C0) + (int64_t)slice * p.slab_stride * 4;
+    const int64_t ld = second ? p.ldc1 : p.ldc0;
+    const bool isb = (second ? p.c1_bf16 : p.c0_bf16) != 0;
+    const int col = cbase + fg * 4;
+    const int cc = col - (second ? p.n_split : 0);
+    const bool vec = (m0 + 32 <= p.M) && (cbase + TILE_N <= p.N) && (ld % 4 == 0);
+    if (CARE_AS_DBG & 1) { asm volatile("" :: "v"(acc[0]), "v"(acc[1])); return 0; }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int cbase = tile * 32 + nt * 16;
-      if (cbase >= p.N) continue;
-      const bool second = cbase >= p.n_split;
-      unsigned char* C = reinterpret_cast<unsigned char*>(second ? p.C1 : p.C0) + (int64_t)slice * p.slab_stride * 4;
-      const int64_t ld = second ? p.ldc1 : p.ldc0;
-      const bool isb = (second ? p.c1_bf16 : p.c0_bf16) != 0;
-      const int col = cbase + fr;
-      const int cc = col - (second ? p.n_split : 0);
-      const float bv = biasp ? sbias[col - bias0] : 0.0f;
-      float v[2][4];
+    for (int mt = 0; mt < 2; ++mt) {
+      float v[4] = {acc[mt][0] + bv.x, acc[mt][1] + bv.y, acc[mt][2] + bv.z, acc[mt][3] + bv.w};
+      if (p.act == CARE_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+      } else if (p.act == CARE_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = as_gelu(v[j]);
+      }
+      const int row = m0 + mt * 16 + fr;
+      const int64_t o = (int64_t)row * ld + cc;
+      if (vec) {
+        if (isb) {
+          bf16x4 ob;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)v[j];
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(C) + o) = ob;
+        } else {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + o) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else if (row < p.M) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col + j < p.N) {
+            if (isb) reinterpret_cast<bf16_t*>(C)[o + j] = (bf16_t)v[j];
+            else reinterpret_cast<float*>(C)[o + j] = v[j];
+          }
+      }
+    }
+    return vec ? 2 : -1;
+  };
+
+  // running (max, argmax, sum-exp) of the 8 rows this lane sees, over its column residue
+  float rm[8], rs[8];
+  int ri[8];
+  if constexpr (MODE == STREAM_ARGMAX) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { rm[i] = -INFINITY; rs[i] = 0.f; ri[i] = 0x7fffffff; }
+  }
+
+  // ---- prologue: up to AHEAD tiles in flight (4 VM ops each), then the A loads: one combined latency
+  const int ntl = t1 - t0;
+  const int npro = min(AHEAD, ntl);
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i)
+    if (i < ntl) stage(t0 + i, i);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // A fragment loads: issued right behind the prologue DMAs so both latencies overlap
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+    if (FULL || ks < ksn) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if (CARE_AS_DBG & 8) { a[mt][ks] = bf16x8{}; asm volatile("" : "+v"(a[mt][ks])); }
+        else a[mt][ks] = load_a_frag<AT>(Ap + (int64_t)arow[mt] * p.lda + ks * 32 + fg * 8);
+      }
+    }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // VM operations this wave issued in each of the last AHEAD iterations, oldest first:
+  // DMA count and store count (-1 = unknown: guarded scalar stores -> fall back to vmcnt(0)).
+  int hist_dma[AHEAD], hist_st[AHEAD];
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i) { hist_dma[i] = 0; hist_st[i] = 0; }
+
+  for (int t = t0; t < t1; ++t) {
+    const int it = t - t0;
+    const int slot = it % RING;
+    // ---- wait until tile t's DMA has landed, leaving every YOUNGER VM op in flight.
+    // Tile t was staged in iteration it-AHEAD before that iteration's stores (or in the
+    // prologue).  Younger ops = stores(it-AHEAD) + sum over the AHEAD-1 iterations since of
+    // (DMA + stores) + the prologue tiles staged after tile t (first AHEAD iterations only).
+    int younger = it < AHEAD ? 4 * (npro - 1 - it) : 0;
+    bool exact = true;
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) {
+      if (hist_st[i] < 0) exact = false;
+      younger += hist_st[i] + (i > 0 ? hist_dma[i] : 0);
+    }
+    // iteration 0 drains everything (A fragments + prologue tiles were issued together)
+    wait_vm(exact && it > 0 ? younger : 0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // bias of this lane's 4 columns: an asm ds_read (hipcc would put a vmcnt(0) drain in front
+    // of a C++ LDS read because the in-flight LDS-DMA might alias it)
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == STREAM_STORE && biasp) {
+      const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+      const unsigned addr = base + (unsigned)(BIAS_OFF + ((t * TILE_N - col0) + fg * 4) * 4);
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(bv) : "v"(addr) : "memory");
+    }
+
+    // ---- refill the ring slot consumed in the previous iteration
+    int n_dma = 0;
+    if (t + AHEAD < t1) { stage(t + AHEAD, (it + AHEAD) % RING); n_dma = 4; }
+    __builtin_amdgcn_sched_barrier(0);
+
+    compute(slot);
+
+    int n_st = 0;
+    if constexpr (MODE == STREAM_STORE) {
+      __builtin_amdgcn_sched_barrier(0);
+      n_st = store_tile(t, bv);
+    } else {
+      const int c0 = t * TILE_N + fr;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[mt][j] = acc[q][mt][nt][j] + bv;
-      if (p.act == CARE_ACT_RELU) {  // one uniform branch per tile, not one per element
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[mt][j] = fmaxf(v[mt][j], 0.0f);
-      } else if (p.act == CARE_ACT_GELU) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[mt][j] = as_act(v[mt][j], CARE_ACT_GELU);
-      }
-      const int64_t rb = (int64_t)(m0 + fg * 4) * ld + cc;
-      if (interior) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int64_t o = rb + (int64_t)(mt * 16 + j) * ld;
-            if (isb) reinterpret_cast<bf16_t*>(C)[o] = (bf16_t)v[mt][j];
-            else reinterpret_cast<float*>(C)[o] = v[mt][j];
-          }
-      } else {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int row = m0 + mt * 16 + fg * 4 + j;
-            if (row < p.M && col < p.N) {
-              const int64_t o = rb + (int64_t)(mt * 16 + j) * ld;
-              if (isb) reinterpret_cast<bf16_t*>(C)[o] = (bf16_t)v[mt][j];
-              else reinterpret_cast<float*>(C)[o] = v[mt][j];
-            }
-          }
-      }
+        for (int j = 0; j < 4; ++j) {
+          const int i = mt * 4 + j;
+          const float v0 = c0 < p.N ? acc[mt][j] : -INFINITY;
+          const float mn = fmaxf(rm[i], v0);
+          rs[i] = rs[i] * __expf(rm[i] - mn) + __expf(v0 - mn);
+          ri[i] = v0 > rm[i] ? c0 : ri[i];
+          rm[i] = mn;
+        }
     }
-  };
-  if (MODE != STREAM_ARGMAX && biasp) {  // this block's bias slice -> LDS (<= 2048 columns)
-    float* sb = reinterpret_cast<float*>(smem + 65536);
-    const int nb = min((t1 - t0) * 32, p.N - bias0);
-    for (int i = tid; i < nb; i += 256) sb[i] = biasp[bias0 + i];
+#pragma unroll
+    for (int i = 0; i + 1 < AHEAD; ++i) { hist_dma[i] = hist_dma[i + 1]; hist_st[i] = hist_st[i + 1]; }
+    hist_dma[AHEAD - 1] = n_dma;
+    hist_st[AHEAD - 1] = n_st;
   }
 
-  if constexpr (MODE == MULTI_STORE) {
-    const int nkc = (p.K + 511) / 512, ntl = t1 - t0, total = nkc * ntl;
+  if constexpr (MODE == STREAM_ARGMAX) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) zero_acc(q);
-    stage(t0, 0, 0);
-    int cur = 0;
-    for (int kc = 0; kc < nkc; ++kc) {
-      load_a(kc);
+    for (int i = 0; i < 8; ++i) {
+      float m = rm[i], s = rs[i];
+      int id = ri[i];
 #pragma unroll
-      for (int tl = 0; tl < 4; ++tl) {
-        if (tl < ntl) {
-          __syncthreads();
-          const int nxt = kc * ntl + tl + 1;
-          if (nxt < total) stage(t0 + nxt % ntl, nxt / ntl, cur ^ 1);
-          compute(cur, kc, tl);
-          cur ^= 1;
-        }
+      for (int o = 1; o < 16; o <<= 1) {
+        const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
+        const int oi = __shfl_xor(id, o, 64);
+        const float mn = fmaxf(m, om);
+        s = s * __expf(m - mn) + os * __expf(om - mn);
+        if (om > m || (om == m && oi < id)) id = oi;
+        m = mn;
       }
-    }
-#pragma unroll
-    for (int tl = 0; tl < 4; ++tl)
-      if (tl < ntl) store_tile(t0 + tl, tl);
-  } else {
-    load_a(0);
-    // running (max, argmax, sum-exp) of the 8 rows this lane sees, over its column residue
-    float rm[8], rs[8];
-    int ri[8];
-    if constexpr (MODE == STREAM_ARGMAX) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { rm[i] = -INFINITY; rs[i] = 0.f; ri[i] = 0x7fffffff; }
-    }
-    stage(t0, 0, 0);
-    int cur = 0;
-    for (int t = t0; t < t1; ++t) {
-      __syncthreads();
-      if (t + 1 < t1) stage(t + 1, 0, cur ^ 1);
-      zero_acc(0);
-      compute(cur, 0, 0);
-      if constexpr (MODE == STREAM_STORE) {
-        store_tile(t, 0);
-      } else {
-        const int c0 = t * 32 + fr, c1 = c0 + 16;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int i = mt * 4 + j;
-            const float v0 = c0 < p.N ? acc[0][mt][0][j] : -INFINITY;
-            const float v1 = c1 < p.N ? acc[0][mt][1][j] : -INFINITY;
-            const float tm = fmaxf(v0, v1);
-            const int ti = v1 > v0 ? c1 : c0;
-            const float mn = fmaxf(rm[i], tm);
-            rs[i] = rs[i] * __expf(rm[i] - mn) + __expf(v0 - mn) + __expf(v1 - mn);
-            ri[i] = tm > rm[i] ? ti : ri[i];
-            rm[i] = mn;
-          }
-      }
-      cur ^= 1;
-    }
-    if constexpr (MODE == STREAM_ARGMAX) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float m = rm[i], s = rs[i];
-        int id = ri[i];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
-          const int oi = __shfl_xor(id, o, 64);
-          const float mn = fmaxf(m, om);
-          s = s * __expf(m - mn) + os * __expf(om - mn);
-          if (om > m || (om == m && oi < id)) id = oi;
-          m = mn;
-        }
-        const int row = m0 + (i >> 2) * 16 + fg * 4 + (i & 3);
-        if (fr == 0 && row < p.M) {
-          const int64_t o = (int64_t)row * p.ns + ns;
-          p.pmax[o] = m; p.pidx[o] = id; p.psum[o] = s;
-        }
+      const int row = m0 + (i >> 2) * 16 + fg * 4 + (i & 3);
+      if (fr == 0 && row < p.M) {
+        const int64_t o = (int64_t)row * p.ns + ns;
+        p.pmax[o] = m; p.pidx[o] = id; p.psum[o] = s;
       }
     }
   }
+  }  // work items
 }
 
 template <typename AT, int MODE>
 int launch_as(const AsArgs& p, int blocks, hipStream_t st) {
-  if (p.K % 512 == 0) hipLaunchKernelGGL((gemm_as_kernel<AT, MODE, true>), dim3(blocks), dim3(256), 65536 + 8192, st, p);
-  else hipLaunchKernelGGL((gemm_as_kernel<AT, MODE, false>), dim3(blocks), dim3(256), 65536 + 8192, st, p);
+  if (p.K == 512) hipLaunchKernelGGL((gemm_as_kernel<AT, MODE, true>), dim3(blocks), dim3(256), LDS_BYTES, st, p);
+  else hipLaunchKernelGGL((gemm_as_kernel<AT, MODE, false>), dim3(blocks), dim3(256), LDS_BYTES, st, p);
   return care_launch_status();
 }
 
@@ -335,11 +398,29 @@ int as_check(const void* A, int64_t lda, int a_dtype, const void* W, int M, int 
   return 0;
 }
 
-// number of column ranges: a multiple of 8 (one share per XCD) giving >= ~2 blocks per CU
+// Number of column ranges per panel.  Every extra range re-loads the panel's A fragments (the
+// expensive, fragment-shaped loads), so with >= 512 panels there is no N split at all; otherwise
+// a multiple of 8 (one share per XCD) giving ~2 workgroups per CU.
 int pick_ns(int panels, int tiles_total) {
+  if (const char* e = getenv("CARE_AS_NS")) return atoi(e);  // tuning override (tools/gemm_bench.py)
+  if (panels >= 512) return 1;
   int ns = 8;
   while (ns < tiles_total && (long)panels * ns < 512) ns += 8;
   return ns;
+}
+
+// Grid size and XCD mapping of a launch.  The sharers of the BIGGER operand are made XCD
+// neighbours; panel-major needs the panel count rounded up to a multiple of 8.
+int plan_stream(AsArgs& p, bool has_bias) {
+  const int tiles_total = (p.N + TILE_N - 1) / TILE_N;
+  while (has_bias && ((tiles_total + p.ns - 1) / p.ns) * TILE_N > BIAS_MAX) p.ns += 8;
+  p.panel_major = ((long)p.M > (long)p.N || p.ns % 8 != 0) ? 1 : 0;
+  if (const char* e = getenv("CARE_AS_MAP")) p.panel_major = atoi(e);
+  const int per_slice = p.panel_major ? ((p.panels + 7) / 8) * 8 * p.ns : p.panels * p.ns;
+  p.total_items = per_slice * p.kslices;
+  int max_blocks = 512;  // 2 workgroups per CU (LDS 72 KiB, <= 256 VGPRs each)
+  if (const char* e = getenv("CARE_AS_BLOCKS")) max_blocks = atoi(e);
+  return p.total_items < max_blocks ? p.total_items : max_blocks;
 }
 
 }  // namespace
@@ -349,6 +430,7 @@ extern "C" int care_gemm_bf16(const void* A, int64_t lda, int a_dtype, const voi
                               int N, int K, int act, void* stream) {
   int rc = as_check(A, lda, a_dtype, W, M, N, K);
   if (rc) return rc;
+  if (K > 512) return CARE_ESHAPE;  // use care_gemm_bf16_splitk
   if (!C0 || n_split <= 0 || n_split > N || (n_split < N && !C1)) return CARE_EINVAL;
   if (n_split % 16 != 0 && n_split != N) return CARE_ESHAPE;
   if (act < CARE_ACT_NONE || act > CARE_ACT_GELU) return CARE_EDTYPE;
@@ -359,24 +441,16 @@ extern "C" int care_gemm_bf16(const void* A, int64_t lda, int a_dtype, const voi
   p.n_split = n_split; p.M = M; p.N = N; p.K = K; p.act = act;
   p.panels = (M + 127) / 128;
   p.kslices = 1; p.ldw = K; p.slab_stride = 0;
-  const int tiles_total = (N + 31) / 32;
+  p.ns = pick_ns(p.panels, (N + TILE_N - 1) / TILE_N);
+  const int blocks = plan_stream(p, bias != nullptr);
   hipStream_t st = (hipStream_t)stream;
-  if (K > 512) {
-    p.ns = (tiles_total + 3) / 4;
-    const int blocks = ((p.panels + 7) / 8) * 8 * p.ns;
-    return a_dtype == CARE_BF16 ? launch_as<bf16_t, MULTI_STORE>(p, blocks, st)
-                                : launch_as<float, MULTI_STORE>(p, blocks, st);
-  }
-  p.ns = pick_ns(p.panels, tiles_total);
-  while (bias && (tiles_total + p.ns - 1) / p.ns > 64) p.ns += 8;  // bias slice must fit its LDS region
-  const int blocks = p.panels * p.ns;
   return a_dtype == CARE_BF16 ? launch_as<bf16_t, STREAM_STORE>(p, blocks, st)
                               : launch_as<float, STREAM_STORE>(p, blocks, st);
 }
 
 extern "C" int care_argmax_parts_bf16(int M, int N) {
   if (M <= 0 || N <= 0) return CARE_EINVAL;
-  return pick_ns((M + 127) / 128, (N + 31) / 32);
+  return pick_ns((M + 127) / 128, (N + TILE_N - 1) / TILE_N);
 }
 
 extern "C" int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
@@ -390,30 +464,29 @@ extern "C" int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, co
   p.kslices = 1; p.ldw = K;
   p.pmax = pmax; p.pidx = pidx; p.psum = psum;
   p.panels = (M + 127) / 128;
-  p.ns = pick_ns(p.panels, (N + 31) / 32);
-  const int blocks = p.panels * p.ns;
+  p.ns = pick_ns(p.panels, (N + TILE_N - 1) / TILE_N);
+  const int blocks = plan_stream(p, false);
   hipStream_t st = (hipStream_t)stream;
   return a_dtype == CARE_BF16 ? launch_as<bf16_t, STREAM_ARGMAX>(p, blocks, st)
                               : launch_as<float, STREAM_ARGMAX>(p, blocks, st);
 }
 
-// Split-K variant for K > 512 at small M (FFN dense2 of a decode step): K/512 slices, slice s
-// writes its partial product (bias in slice 0) to fp32 slab s = C + s * slab_stride.  The
-// consumer (care_add_ln with nslab = K/512) sums the slabs, so no separate reduction pass.
+// Split-K form for K > 512 (FFN dense2, wide feature embedders): K/512 slices, slice s writes its
+// partial product (bias in slice 0) to fp32 slab s = C + s * slab_stride.  The consumer
+// (care_add_ln with nslab = K/512) sums the slabs, so no separate reduction pass exists.
 extern "C" int care_gemm_bf16_splitk(const void* A, int64_t lda, int a_dtype, const void* W, const float* bias,
                                      float* C, int64_t ldc, int64_t slab_stride, int M, int N, int K, void* stream) {
   int rc = as_check(A, lda, a_dtype, W, M, N, K);
   if (rc) return rc;
-  if (!C || K % 512 != 0 || K < 1024) return C ? CARE_ESHAPE : CARE_EINVAL;
+  if (!C) return CARE_EINVAL;
+  if (K % 512 != 0 || K < 1024) return CARE_ESHAPE;
   AsArgs p{};
   p.A = A; p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.bias = bias;
   p.C0 = C; p.ldc0 = ldc; p.c0_bf16 = 0; p.n_split = N; p.M = M; p.N = N; p.K = 512; p.act = CARE_ACT_NONE;
   p.panels = (M + 127) / 128;
   p.kslices = K / 512; p.ldw = K; p.slab_stride = slab_stride;
-  const int tiles_total = (N + 31) / 32;
-  p.ns = pick_ns(p.panels * p.kslices, tiles_total);
-  while (bias && (tiles_total + p.ns - 1) / p.ns > 64) p.ns += 8;
-  const int blocks = p.panels * p.ns * p.kslices;
+  p.ns = pick_ns(p.panels * p.kslices, (N + TILE_N - 1) / TILE_N);
+  const int blocks = plan_stream(p, bias != nullptr);
   hipStream_t st = (hipStream_t)stream;
   return a_dtype == CARE_BF16 ? launch_as<bf16_t, STREAM_STORE>(p, blocks, st)
                               : launch_as<float, STREAM_STORE>(p, blocks, st);

@@ -176,9 +176,21 @@ class HipEngine:
     def bf(self) -> bool:
         return self.wt == torch.bfloat16
 
+    @property
+    def as_ok(self) -> bool:
+        """bf16 mode AND d_model fits the A-stationary kernel (K = d <= 512, d % 128 == 0):
+        GEMM-input activations then live as bf16 mirrors.  Otherwise (fp32 mode, d = 768/1024)
+        every GEMM takes fp32 activations through the generic kernel."""
+        return self.bf and self.d <= 512 and self.d % 128 == 0
+
+    @property
+    def act_dtype(self):
+        """dtype of activations that are ONLY GEMM inputs (attention context, FFN hidden)."""
+        return torch.bfloat16 if self.as_ok else torch.float32
+
     def wsb(self, name: str, shape) -> Optional[torch.Tensor]:
-        """bf16 mirror workspace of a GEMM-input activation (None in fp32 mode)."""
-        return self.ws(name + "#bf", shape, torch.bfloat16) if self.bf else None
+        """bf16 mirror workspace of a GEMM-input activation (None unless as_ok)."""
+        return self.ws(name + "#bf", shape, torch.bfloat16) if self.as_ok else None
 
     def gemm(self, A, W, bias, out, act=0, out2=None, n_split=None, tag=None):
         """out = act(A @ W^T + bias).  bf16 weights + bf16 A -> A-stationary kernel
@@ -188,7 +200,9 @@ class HipEngine:
         assert W.shape[1] == K and A.stride(1) == 1 and out.stride(-1) == 1
         tail = (ptr(bias), ptr(out), out.stride(0), _code(out), ptr(out2),
                 out2.stride(0) if out2 is not None else 0, _code(out2), N if n_split is None else n_split, M, N, K, act)
-        if W.dtype == torch.bfloat16 and A.dtype == torch.bfloat16 and K % 128 == 0 and A.stride(0) % 8 == 0:
+        if W.dtype == torch.bfloat16 and A.dtype == torch.bfloat16:
+            if K > 512 or K % 128 or A.stride(0) % 8:
+                raise ValueError("bf16 A operand needs K <= 512, K % 128 == 0 (got K = {})".format(K))
             call("care_gemm_bf16", ptr(A), A.stride(0), _code(A), ptr(W), *tail, tag=tag)
         else:
             if A.dtype != torch.float32:
@@ -217,7 +231,7 @@ class HipEngine:
 
     def _ctx(self, tag, rows):
         """Attention context buffer: only ever read by the output projection GEMM."""
-        return self.ws(tag + "ctx", (rows, self.d), self.wt)
+        return self.ws(tag + "ctx", (rows, self.d), self.act_dtype)
 
     def _mha_self_full(self, name, x, xb, seq, pad_tok, causal, tag):
         """Self-attention sub-block over whole sequences (teacher forcing / encoder).
@@ -236,11 +250,13 @@ class HipEngine:
     def _ffn(self, name, x, xb, out, outb, tag, gemm_tag=None, **ln_kw):
         rows, d = x.shape
         w = self.w
+        split = self.as_ok and self.ff % 512 == 0 and self.ff >= 1024
         h = self.gemm(xb if xb is not None else x, w[name + "_w1"], w[name + "_b1"],
-                      self.ws(tag + "h", (rows, self.ff), self.wt), act=self.act, tag=gemm_tag)
+                      self.ws(tag + "h", (rows, self.ff), torch.bfloat16 if split else torch.float32),
+                      act=self.act, tag=gemm_tag)
         w2 = w[name + "_w2"]
-        if self.bf and self.ff % 512 == 0 and self.ff >= 1024 and rows <= 8192:
-            # small M: split K = ff over blocks; the LayerNorm kernel sums the slabs
+        if split:
+            # K = ff > 512: split K over blocks into fp32 slabs; the LayerNorm kernel sums them
             ns = self.ff // 512
             f = self.ws(tag + "fslab", (ns, rows, d))
             call("care_gemm_bf16_splitk", ptr(h), h.stride(0), _code(h), ptr(w2), ptr(w[name + "_b2"]), ptr(f), d,
@@ -257,7 +273,7 @@ class HipEngine:
             raise ValueError("expected {} feature tensors, got {}".format(len(self.modality), len(feats)))
         B = feats[0].shape[0]
         mem = torch.empty(B, self.Lk, d, device=self.device)
-        memb = torch.empty(B, self.Lk, d, device=self.device, dtype=torch.bfloat16) if self.bf else None
+        memb = torch.empty(B, self.Lk, d, device=self.device, dtype=torch.bfloat16) if self.as_ok else None
         means = torch.empty(B, len(self.modality) * d, device=self.device)
         for mi, ch in enumerate(self.modality):
             x = feats[mi].to(self.device, torch.float32).contiguous()
@@ -333,7 +349,7 @@ class HipEngine:
         B, Lk, d = mem.shape
         mem = mem.contiguous()
         mirror = getattr(self, "_mem_mirror", (None, None))
-        src = mirror[1] if (self.bf and mirror[0] == mem.data_ptr() and mirror[1] is not None) else mem
+        src = mirror[1] if (self.as_ok and mirror[0] == mem.data_ptr() and mirror[1] is not None) else mem
         src2 = src.view(B * Lk, d)
         out = []
         for li in range(self.n_layers):
@@ -444,7 +460,7 @@ class HipEngine:
         score.zero_(); length.zero_(); fin.zero_()
         ckv = self.cross_kv(mem)
         skv = [self.ws("g_skv%d" % li, (B, T, 2 * d), self.wt) for li in range(self.n_layers)]
-        bf = self.wt == torch.bfloat16 and d <= 512
+        bf = self.as_ok
         parts = _lib.argmax_parts(self.V, B, bf)
         pmax = self.ws("g_pmax", (B, parts))
         pidx = self.ws("g_pidx", (B, parts), torch.int32)

@@ -37,6 +37,7 @@ def _bf(x):
 GEMM_SHAPES = [
     (1, 512, 512), (5, 10547, 512), (64, 512, 512), (100, 1536, 512), (257, 2048, 512), (300, 512, 2048),
     (1024, 512, 128), (28 * 7, 512, 2048), (130, 640, 640), (96, 500, 2048), (200, 768, 768),
+    (1000, 48, 512), (129, 1040, 256), (4096, 512, 512), (513, 10547, 384),
 ]
 
 
@@ -63,8 +64,8 @@ def test_gemm(M, N, K, mode, act):
                 pytest.skip("generic bf16 kernel needs K % 64 == 0")
             _call("care_gemm", _p(A), K, _p(Wb), 1, _p(bias), _p(out), N, 0, None, 0, 0, N, M, N, K, act)
         else:
-            if K % 128:
-                pytest.skip("A-stationary kernel needs K % 128 == 0")
+            if K % 128 or K > 512:
+                pytest.skip("A-stationary kernel needs K % 128 == 0 and K <= 512 (K > 512: split-K entry point)")
             Ain = A if mode == "bf16_as_f32A" else A.to(torch.bfloat16).contiguous()
             _call("care_gemm_bf16", _p(Ain), K, 0 if mode == "bf16_as_f32A" else 1, _p(Wb), _p(bias), _p(out), N, 0,
                   None, 0, 0, N, M, N, K, act)

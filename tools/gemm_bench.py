@@ -1,0 +1,45 @@
+"""Micro-benchmark of the GEMM entry points on decode-step shapes (run on the GPU box)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from care_amd import _lib
+
+DEV = "cuda:0"
+
+
+def time_call(fn, iters=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / iters
+
+
+def main():
+    import os
+    shapes = [(1024, 512, 512), (4096, 512, 512), (4096, 1536, 512), (4096, 2048, 512), (4096, 10547, 512),
+              (8192, 512, 512), (4096 * 84, 1024, 512), (4096 * 28, 512, 512)]
+    if len(sys.argv) > 1:
+        shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
+    print("CARE_AS_NS=%s CARE_AS_MAP=%s" % (os.environ.get("CARE_AS_NS"), os.environ.get("CARE_AS_MAP")))
+    for M, N, K in shapes:
+        A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        Af = A.float()
+        W = (torch.randn(N, K, device=DEV) * 0.05).to(torch.bfloat16)
+        bias = torch.randn(N, device=DEV)
+        out = torch.empty(M, N, device=DEV)
+        p = lambda t: t.data_ptr()
+        t_as = time_call(lambda: _lib.call("care_gemm_bf16", p(A), K, 1, p(W), p(bias), p(out), N, 0, None, 0, 0, N, M, N, K, 0))
+        t_gen = time_call(lambda: _lib.call("care_gemm", p(Af), K, p(W), 1, p(bias), p(out), N, 0, None, 0, 0, N, M, N, K, 0))
+        fl = 2.0 * M * N * K
+        print("M=%6d N=%5d K=%4d  A-stationary %7.1f us (%6.1f TF)   generic(fp32 A) %7.1f us (%6.1f TF)" %
+              (M, N, K, t_as, fl / t_as / 1e6, t_gen, fl / t_gen / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()
