@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--config", default="msrvtt_base_ami")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-batch", type=int, default=128)
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="torch threads for the CPU oracle (16 was the fastest of 8..128 on the 2x64-core host)")
     return ap.parse_args()
 
 
@@ -145,6 +147,11 @@ def main():
     step_tags = [t for t in kernels if t.startswith("step_")]
     dom = max(step_tags, key=lambda t: kernels[t]["total_ms"])
     km = kernel_model(dom, eng, B, args.dtype)
+    # `achieved` uses the IN-SITU duration: the average over the kernel's launches inside the
+    # pass, each bracketed by HIP events on the launch stream (agrees with rocprofv3's kernel
+    # trace, profiles/).  The back-to-back re-launch (same arguments, 50x between two events) is
+    # reported beside it; it is faster because consecutive launches re-read a warm L2/MALL.
+    dom_b2b_us = _lib.relaunch_avg_us(dom, 50)
     dur_s = kernels[dom]["avg_us"] * 1e-6
     if km["bound"] == "hbm":
         achieved, peak, unit = km["bytes"] / dur_s / 1e9, HBM_PEAK_GBS, "GB/s"
@@ -157,7 +164,8 @@ def main():
         traffic = tj.get("{}|{}|B{}|{}".format(args.config, args.dtype, B, dom))
     roofline = dict(kernel=dom, bound=km["bound"], achieved=round(achieved, 2), peak=peak, unit=unit,
                     frac=round(achieved / peak, 4), traffic=traffic,
-                    avg_launch_us=round(kernels[dom]["avg_us"], 2), launches=kernels[dom]["launches"],
+                    avg_launch_us=round(kernels[dom]["avg_us"], 2), avg_launch_us_back_to_back=round(dom_b2b_us, 2),
+                    launches=kernels[dom]["launches"],
                     algorithmic_bytes_per_launch=int(km["bytes"]), algorithmic_flops_per_launch=int(km["flops"]))
     per_kernel = {}
     for tag, k in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"]):
@@ -180,17 +188,19 @@ def main():
         from oracle import care_cpu  # timed baseline only (never on the product path)
 
         cb = args.cpu_batch
+        torch.set_num_threads(args.cpu_threads)
         cfeats = synth_feats(2000, feat_shapes(opt, cb))
         care_cpu.translate_batch(P, opt, cfeats)  # warm-up
         t1 = time.perf_counter()
         passes = 0
-        while passes < 5 and (time.perf_counter() - t1 < 12.0 or passes < 2):
+        while passes < 30 and (time.perf_counter() - t1 < 12.0 or passes < 2):
             care_cpu.translate_batch(P, opt, cfeats)
             passes += 1
         cpu_s = (time.perf_counter() - t1) / passes
         cpu = dict(value=round(cb / cpu_s, 2), unit="captions/s", cores=torch.get_num_threads(), kind="port",
                    sample="{} passes of greedy translate_batch, B={} clips, fp32, full-prefix recompute as in the "
-                          "reference; {:.0f} us per decoder step".format(passes, cb, cpu_s / T * 1e6),
+                          "reference; {:.0f} us per decoder step; {} torch threads (fastest of 8..128 on this "
+                          "host)".format(passes, cb, cpu_s / T * 1e6, args.cpu_threads),
                    host_cpus=os.cpu_count())
 
     line = dict(

@@ -87,6 +87,7 @@ def stream_ptr():
 # launch stream (torch's current stream): TIMING[tag] = [(start_event, end_event), ...].
 # bench.py uses it to measure per-kernel durations live; it is None in normal operation.
 TIMING = None
+LAST_CALL = {}  # tag -> (function name, args): lets bench.py re-launch one kernel back to back
 
 
 def call(name: str, *args, tag: str = None):
@@ -98,6 +99,7 @@ def call(name: str, *args, tag: str = None):
         rc = fn(*args, stream_ptr())
         end.record()
         TIMING.setdefault(tag, []).append((start, end))
+        LAST_CALL[tag] = (name, args)
     else:
         rc = fn(*args, stream_ptr())
     if rc != 0:
@@ -107,3 +109,19 @@ def call(name: str, *args, tag: str = None):
 
 def argmax_parts(n: int, m: int = 0, bf16: bool = False) -> int:
     return load().care_argmax_parts_bf16(m, n) if bf16 else load().care_argmax_parts(n)
+
+
+def relaunch_avg_us(tag: str, iters: int = 50) -> float:
+    """Average duration of the last launch recorded under `tag`, re-issued `iters` times back to
+    back on the current stream between two HIP events (kernels on the path are idempotent)."""
+    name, args = LAST_CALL[tag]
+    fn = getattr(load(), name)
+    for _ in range(3):
+        fn(*args, stream_ptr())
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn(*args, stream_ptr())
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) * 1e3 / iters
