@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=16384, help="clips per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--config", default="msrvtt_base_ami")
     ap.add_argument("--no-graph", action="store_true")

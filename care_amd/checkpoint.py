@@ -1,0 +1,151 @@
+"""Checkpoint + `opt` ingestion without PyTorch-Lightning.
+
+The reference saves Lightning checkpoints (`train.py:76-96`, `models/Wrapper.py:27`):
+a pickled dict with `state_dict` (model keys prefixed `captioner.`; criterion buffers may
+sit beside them) and `hyper_parameters = {'opt': {...}, 'new_opt_used_to_override': {...}}`.
+`models/__init__.py:93-152` loads them through `LightningModule.load_from_checkpoint`,
+merges `{**opt, **new_opt_used_to_override}` (`Wrapper.py:29,402-403`) and rewrites the
+dataset paths stored in `opt`.  Lightning is not needed for any of that; this module reads
+the same file with a restricted unpickler (Lightning's `AttributeDict` becomes a dict) and
+returns a `CaptionRunner` that owns the care_amd captioner and translator.
+"""
+import os
+import pickle
+from typing import Any, Dict, Optional
+
+import torch
+
+from .framework import get_framework
+from .translator import get_translator
+
+PATH_KEYS = ["feats_a", "feats_m", "feats_i", "feats_o", "feats_t", "feats_r", "reference", "info_corpus"]
+DEFAULT_BASE_DATA_PATH = "/data/video_datasets"  # config/Constants.py:21
+
+
+class _AttrDict(dict):
+    """Stand-in for pytorch_lightning.utilities.parsing.AttributeDict (a dict subclass)."""
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.update(state)
+
+
+class _Unpickler(pickle.Unpickler):
+    """pickle.Unpickler that never imports Lightning: its container classes map to dict."""
+
+    def find_class(self, module, name):
+        if module.split(".")[0] in ("pytorch_lightning", "lightning", "lightning_fabric", "lightning_utilities"):
+            return _AttrDict
+        return super().find_class(module, name)
+
+
+class _PickleModule:
+    """Duck-typed `pickle_module` for torch.load."""
+    __name__ = "care_amd_checkpoint_pickle"
+    Unpickler = _Unpickler
+    load = staticmethod(lambda f, **kw: _Unpickler(f, **kw).load())
+    loads = staticmethod(pickle.loads)
+    dump, dumps = staticmethod(pickle.dump), staticmethod(pickle.dumps)
+
+
+def read_checkpoint(path: str) -> Dict[str, Any]:
+    """Return {'state_dict': captioner weights (prefix stripped), 'opt', 'new_opt', 'extra_keys'}."""
+    ckpt = torch.load(path, map_location="cpu", pickle_module=_PickleModule, weights_only=False)
+    if "state_dict" not in ckpt or "hyper_parameters" not in ckpt:
+        raise ValueError("{} is not a Lightning checkpoint of the reference (state_dict / hyper_parameters)".format(path))
+    hp = ckpt["hyper_parameters"]
+    if "opt" not in hp:
+        raise ValueError("hyper_parameters has no `opt` (Wrapper.py:27 saves opt and new_opt_used_to_override)")
+    sd, extra = {}, []
+    for k, v in ckpt["state_dict"].items():
+        if k.startswith("captioner."):
+            sd[k[len("captioner."):]] = v
+        else:
+            extra.append(k)
+    return {"state_dict": sd, "opt": dict(hp["opt"]), "new_opt": dict(hp.get("new_opt_used_to_override", {}) or {}),
+            "extra_keys": extra}
+
+
+def replace_data_paths(opt: Dict[str, Any], base_data_path: Optional[str]) -> Dict[str, Any]:
+    """models/__init__.py:127-148: re-root the stored dataset paths under `base_data_path`."""
+    if "info_corpus" not in opt:
+        return opt
+    ori = os.path.dirname(opt["info_corpus"])
+    if os.path.basename(ori) != opt.get("dataset"):
+        raise AssertionError("info_corpus `{}` does not live in a `{}` directory".format(opt["info_corpus"], opt.get("dataset")))
+    ori = os.path.dirname(ori)
+    now = base_data_path if base_data_path is not None else DEFAULT_BASE_DATA_PATH
+
+    def rep(item):
+        if isinstance(item, (list, tuple)):
+            return [rep(x) for x in item]
+        if not isinstance(item, str):
+            raise AssertionError("path entries must be str")
+        return item.replace(ori, now)
+
+    opt = dict(opt)
+    for key in PATH_KEYS:
+        if key in opt:
+            opt[key] = rep(opt[key])
+    return opt
+
+
+class CaptionRunner:
+    """Minimal non-Lightning stand-in for `models.Wrapper.ModelBase` around the hot path.
+
+    Holds `captioner` (get_framework) and `translator` (get_translator) exactly like
+    `ModelBase.__init__` (Wrapper.py:29-36) and offers `get_opt`, `get_keys_to_device`,
+    `translate_step` (Wrapper.py:158-212 without the metric bookkeeping).
+    """
+
+    def __init__(self, opt: Dict[str, Any], new_opt_used_to_override: Optional[Dict[str, Any]] = None):
+        self.opt = dict(opt)
+        self.new_opt_used_to_override = dict(new_opt_used_to_override or {})
+        newest = self.get_opt()
+        self.captioner = get_framework(newest)
+        self.translator = get_translator(newest)
+
+    def get_opt(self) -> Dict[str, Any]:
+        return {**self.opt, **self.new_opt_used_to_override}
+
+    def get_keys_to_device(self, *args, **kwargs):
+        return self.captioner.get_keys_to_device(*args, **kwargs)
+
+    def eval(self):
+        self.captioner.eval()
+        return self
+
+    def to(self, device):
+        self.captioner.to(device)
+        return self
+
+    def translate_step(self, batch: Dict[str, Any], vocab: Optional[Dict[int, str]] = None):
+        from .text import to_sentence
+
+        hyps, scores = self.translator.translate_batch(models=[self.captioner], batch=batch, vocab=vocab)
+        if vocab is None:
+            return hyps, scores
+        out = []
+        for i, (hs, ss) in enumerate(zip(hyps, scores)):
+            vid = batch["video_ids"][i] if "video_ids" in batch else i
+            out.append({"image_id": vid, "caption": to_sentence(hs[0], vocab), "score": ss[0]})
+        return out
+
+
+def load_model(checkpoint_path: str, new_opt_used_to_override: Optional[Dict[str, Any]] = None, device="cuda:0",
+               strict: bool = True, replace_paths: bool = True, base_data_path: Optional[str] = None,
+               compute_dtype: Optional[str] = None) -> CaptionRunner:
+    """`models.load_model` (models/__init__.py:93-152) for a single checkpoint."""
+    if isinstance(checkpoint_path, (list, tuple)):
+        raise NotImplementedError("ModelEnsemble (several checkpoints) is outside the hot path")
+    ck = read_checkpoint(checkpoint_path)
+    override = ck["new_opt"] if new_opt_used_to_override is None else dict(new_opt_used_to_override)
+    opt = replace_data_paths(ck["opt"], base_data_path) if replace_paths else ck["opt"]
+    runner = CaptionRunner(opt, override)
+    missing, unexpected = runner.captioner.load_state_dict(ck["state_dict"], strict=strict)
+    if strict and (missing or unexpected):
+        raise RuntimeError("checkpoint / model key mismatch: missing {} unexpected {}".format(missing, unexpected))
+    if compute_dtype is not None:
+        runner.captioner.set_compute_dtype(compute_dtype)
+    runner.eval()
+    return runner.to(device) if device is not None else runner

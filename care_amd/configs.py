@@ -86,7 +86,8 @@ def make_opt(name: str, **overrides) -> dict:
     Names (BASELINE.json `configs`, in order): ``msvd_base_i``, ``msrvtt_base_ami``,
     ``msrvtt_care``, ``vatex_care_large``, ``msrvtt_care_beam5``; plus variants used by
     the parity tests: ``care_median_gelu`` (archs.yaml:21-26 with GELU) and
-    ``base_ami_mte`` (the working self-attention encoder, Encoder.py:190-193).
+    ``base_ami_mte`` (the working self-attention encoder, Encoder.py:190-193) and ``msrvtt_cabase``
+    (the `attr_attention` local-guidance variant, Layers.py:117-119,139-154,218-225).
     """
     opt = deepcopy(_COMMON)
     if name == "msvd_base_i":
@@ -103,6 +104,14 @@ def make_opt(name: str, **overrides) -> dict:
     elif name == "care_median_gelu":
         opt.update(_ARCH["median"], **deepcopy(_CARE))
         opt.update(hidden_act="gelu")
+    elif name == "msrvtt_cabase":
+        # config/tasks.yaml:56-61 (CABase): no global guidance, local guidance by a third attention
+        # over the concept embeddings ("Cross -> Semantic"), visual-driven concept detection, no bias
+        opt.update(_ARCH["base"], **deepcopy(_CARE))
+        opt.update(modality="ami", modality_for_decoder="ami", modality_for_predictor="mi",
+                   use_attr_flags="G0L1", use_attr_type="_att", attr_layer_pos="cross2attr",
+                   add_hybrid_attention_bias=False)
+        opt.pop("dim_r", None)
     elif name == "base_ami_mte":
         opt.update(_ARCH["base"], modality="ami", encoder="MultiTransformerEncoder")
     else:
@@ -119,6 +128,7 @@ CONFIG_NAMES = (
     "msrvtt_care_beam5",
     "care_median_gelu",
     "base_ami_mte",
+    "msrvtt_cabase",
 )
 
 

@@ -152,17 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   for (int mt = 0; mt < 2; ++mt) arow[mt] = min(m0 + mt * 16 + fr, p.M - 1);
   bf16x8 a[2][16];
 
-  // ---- bias slice of this block's column range -> LDS (read back with an asm ds_read, see below)
   const int col0 = t0 * TILE_N;
-  if (MODE == STREAM_STORE && biasp) {
-    float* sb = reinterpret_cast<float*>(smem + BIAS_OFF);
-    const int nb = min((t1 - t0) * TILE_N, p.N - col0);
-    for (int i = tid; i < ((nb + 3) & ~3); i += 256) sb[i] = i < nb ? biasp[col0 + i] : 0.f;
-  }
-  __builtin_amdgcn_sched_barrier(0);  // the bias loads are waited for HERE, before any DMA is in flight
-
-  // stage W tile `tile` into ring slot `slot`: wave w copies rows 4w..4w+3, one 1-KiB row per
-  // LDS-DMA instruction; lane = chunk slot, source chunk = slot ^ (row & 15).  4 VM ops / wave.
   // per-lane source pointers of this wave's 4 rows at tile 0; tile t adds t * 16 rows
   const unsigned char* wrow[4];
 #pragma unroll
@@ -293,6 +283,18 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
       }
     }
   __builtin_amdgcn_sched_barrier(0);
+
+  // ---- bias slice of this block's column range -> LDS, issued BEHIND the prologue DMAs and the A
+  // loads so that all three latencies overlap (iteration 0 drains everything anyway); read back
+  // with an asm ds_read, see below
+  if (MODE == STREAM_STORE && biasp) {
+    float* sb = reinterpret_cast<float*>(smem + BIAS_OFF);
+    const int nb = min((t1 - t0) * TILE_N, p.N - col0);
+    for (int i = tid; i < ((nb + 3) & ~3); i += 256) sb[i] = i < nb ? biasp[col0 + i] : 0.f;
+  }
+
+  // stage W tile `tile` into ring slot `slot`: wave w copies rows 4w..4w+3, one 1-KiB row per
+  // LDS-DMA instruction; lane = chunk slot, source chunk = slot ^ (row & 15).  4 VM ops / wave.
 
   // VM operations this wave issued in each of the last AHEAD iterations, oldest first:
   // DMA count and store count (-1 = unknown: guarded scalar stores -> fall back to vmcnt(0)).

@@ -1,0 +1,106 @@
+"""Input format of the path: per-video feature tables -> `batch['feats']`.
+
+Restates the evaluation branch of `VideoOnlyDataset` (dataloader.py:142-190,232-282): per
+modality a table `video<id> -> [60, dim]` (HDF5 in the reference; any Mapping here, h5py is
+absent from this image), 28 of the 60 rows picked by `get_uniform_ids_from_k_snippets`
+(misc/utils.py:311-317) for `load_feats_type == 0`, retrieval features = the first
+`retrieval_topk` rows (dataloader.py:808-814), missing videos = zeros.  `FeaturePrefetcher`
+adds what the reference lacks: pinned double-buffered host staging with the H2D copy on a
+side stream, so an 8-GPU node is not input-bound (301 KB per clip over PCIe).
+"""
+from typing import Dict, List, Mapping, Sequence
+
+import numpy as np
+import torch
+
+N_TOTAL_FRAMES = 60  # config/Constants.py:27
+
+
+def get_uniform_ids_from_k_snippets(length: int, k: int, offset: int = 0) -> List[int]:
+    """Middle frame of each of k equal snippets (misc/utils.py:311-317)."""
+    bound = [int(i) for i in np.linspace(0, length, k + 1)]
+    return [(bound[i] + bound[i + 1]) // 2 + offset for i in range(k)]
+
+
+def resampling(source_length: int, target_length: int) -> List[int]:
+    """misc/utils.py:307-308."""
+    return [round(i * (source_length - 1) / (target_length - 1)) for i in range(target_length)]
+
+
+def load_modality(tables: Sequence[Mapping], vid: str, dim: int, n_frames: int, frame_ids: Sequence[int]) -> np.ndarray:
+    """`_load_feats` for load_feats_type 0 (dataloader.py:232-262): concat tables on the channel axis."""
+    parts, pre_len = [], None
+    for table in tables:
+        if vid not in table:
+            return np.zeros((n_frames, dim), dtype=np.float32)
+        data = np.asarray(table[vid])
+        if data.ndim == 1:
+            data = data[np.newaxis, :].repeat(pre_len if pre_len is not None else N_TOTAL_FRAMES, axis=0)
+        else:
+            pre_len = data.shape[0]
+        parts.append(data)
+    feats = np.concatenate(parts, axis=1)
+    return np.ascontiguousarray(feats[list(frame_ids)], dtype=np.float32)
+
+
+def load_video_feats(databases: Dict[str, Sequence[Mapping]], vid: str, opt: dict) -> List[np.ndarray]:
+    """One video's `feats` list in `opt['modality']` order (get_video_features_by_vid, dataloader.py:142-190)."""
+    frame_ids = get_uniform_ids_from_k_snippets(N_TOTAL_FRAMES, opt["n_frames"])
+    out = []
+    for ch in opt["modality"].lower():
+        if ch == "r":
+            feats = np.asarray(databases[ch][0][vid])[: opt["retrieval_topk"], :].astype(np.float32)
+        elif ch == "t":
+            raise ValueError("retrieved-caption token inputs (`t`) belong to the pointer network, out of scope")
+        else:
+            feats = load_modality(databases[ch], vid, opt["dim_" + ch], opt["n_frames"], frame_ids)
+        out.append(feats)
+    return out
+
+
+def collate_feats(per_video: Sequence[List[np.ndarray]]) -> List[torch.Tensor]:
+    """default_collate of the `feats` lists: one [B, n, dim] fp32 tensor per modality."""
+    n_mod = len(per_video[0])
+    return [torch.from_numpy(np.stack([v[m] for v in per_video], axis=0)) for m in range(n_mod)]
+
+
+class FeaturePrefetcher:
+    """Double-buffered pinned staging + asynchronous H2D on a side stream.
+
+    `for feats in FeaturePrefetcher(batches, device)` yields device tensors; the copy of batch
+    i+1 overlaps the compute on batch i.  The yielded tensors are reused every other batch, so
+    the hipGraph keyed on their addresses (engine.translate_greedy) replays.
+    """
+
+    def __init__(self, batches, device, depth: int = 2):
+        self.batches, self.device, self.depth = iter(batches), torch.device(device), depth
+        self.stream = torch.cuda.Stream(self.device)
+        self.slots = []
+
+    def _slot(self, i, like):
+        while len(self.slots) <= i:
+            self.slots.append(None)
+        if self.slots[i] is None or any(a.shape != b.shape for a, (b, _) in zip(like, self.slots[i])):
+            self.slots[i] = [(torch.empty(t.shape, dtype=torch.float32).pin_memory(),
+                              torch.empty(t.shape, dtype=torch.float32, device=self.device)) for t in like]
+        return self.slots[i]
+
+    def __iter__(self):
+        pending, i = None, 0
+        for batch in self.batches:
+            slot = self._slot(i % self.depth, batch)
+            event = torch.cuda.Event()
+            with torch.cuda.stream(self.stream):
+                for src, (pin, dev) in zip(batch, slot):
+                    pin.copy_(src)
+                    dev.copy_(pin, non_blocking=True)
+                event.record(self.stream)
+            if pending is not None:
+                ev, devs = pending
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                yield devs
+            pending, i = (event, [dev for _, dev in slot]), i + 1
+        if pending is not None:
+            ev, devs = pending
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            yield devs

@@ -52,6 +52,7 @@ class HipEngine:
         self.use_attr_type = opt.get("use_attr_type", "") if self.has_container else ""
         self.concat = "concat" in self.use_attr_type
         self.sem = "emb" in self.use_attr_type
+        self.attr_att = bool(opt.get("use_attr", False)) and "att" in self.use_attr_type.lower()
         self.topk = int(opt.get("use_attr_topk", 30))
         self.k_attr = int(opt.get("attribute_prediction_k", 500))
         self.n_layers = int(opt["num_hidden_layers_decoder"])
@@ -135,6 +136,8 @@ class HipEngine:
             if hb is not None and hb.shape[1] != self.Lk:
                 raise ValueError("hybrid_bias length {} != memory length {}".format(hb.shape[1], self.Lk))
             w["d{}_hb".format(li)] = f32(hb) if hb is not None else None
+            if self.attr_att:
+                self._pack_attn(w, sd, lp + ".attr_attention", "d{}_aa".format(li), False, wt, f32)
             self._pack_ffn(w, sd, lp + ".ffn", "d{}_ffn".format(li), wt, f32)
         w["vocab"] = wt(sd["cls_head.tgt_word_prj.weight"])
         self.w = w
@@ -358,9 +361,40 @@ class HipEngine:
             out.append(self.gemm(src2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv, tag="cross_kv_gemm"))
         return out
 
+    def attr_kv(self, sem_embs: torch.Tensor, tag="akv") -> Optional[List[torch.Tensor]]:
+        """K/V of the concept embeddings [B, topk, d] for the attr_attention block (CABase)."""
+        if not self.attr_att:
+            return None
+        B, n, d = sem_embs.shape
+        src = sem_embs.to(self.device, torch.float32).contiguous().view(B * n, d)
+        if self.as_ok:  # the A-stationary kernel wants a bf16 operand
+            srcb = self.ws(tag + "_srcb", (B * n, d), torch.bfloat16)
+            srcb.copy_(src)
+            src = srcb
+        out = []
+        for li in range(self.n_layers):
+            nm = "d{}_aa".format(li)
+            kv = self.ws("{}{}".format(tag, li), (B * n, 2 * d), self.wt)
+            out.append(self.gemm(src, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv))
+        return out
+
+    def _attr_block(self, li, x, xb, akv, rows_per_clip, tag):
+        """Third post-LN attention block over the concept rows (Layers.py:139-154,218-225)."""
+        w, d = self.w, self.d
+        rows = x.shape[0]
+        nm = "d{}_aa".format(li)
+        q = self.gemm(xb if xb is not None else x, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q3", (rows, d)))
+        kv = akv[li]
+        ctx = self.attention(q, kv, kv[:, d:], self._ctx(tag, rows), self.topk * 2 * d, 2 * d, rows_per_clip,
+                             self.topk)
+        o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (rows, d)))
+        y, yb = self.ws(tag + "x2a", (rows, d)), self.wsb(tag + "x2a", (rows, d))
+        self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], y, yb)
+        return y, yb
+
     # ------------------------------------------------------------------ teacher-forced decoder
     def decode_full(self, input_ids: torch.Tensor, mem: torch.Tensor, sem: Optional[torch.Tensor],
-                    want_logits: str = "all") -> Dict[str, torch.Tensor]:
+                    want_logits: str = "all", sem_embs: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """`TransformerDecoder.forward` + `NaiveHead` on whole sequences (Lq = t).
 
         Used by feedforward_step (Framework.py:215-234) and by the stateless
@@ -384,6 +418,9 @@ class HipEngine:
         call("care_embed_ln", ptr(ids32), t, 0, None, 0, ptr(w["word"]), ptr(w["pos"]), 0, ptr(sem), sem_div,
              ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(x), ptr(xb), d, rows, t, d)
         ckv = self.cross_kv(mem, tag="tf_ckv")
+        if self.attr_att and sem_embs is None:
+            raise KeyError("this model attends to `semantic_embs` (use_attr_type={!r})".format(self.use_attr_type))
+        akv = self.attr_kv(sem_embs, tag="tf_akv") if self.attr_att else None
         for li in range(self.n_layers):
             x1, x1b = self._mha_self_full("d{}_sa".format(li), x, xb, t, ids32, True, "tf_")
             nm = "d{}_ca".format(li)
@@ -394,6 +431,8 @@ class HipEngine:
             o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws("tf_o", (rows, d)))
             x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
             self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
+            if self.attr_att:
+                x2, x2b = self._attr_block(li, x2, x2b, akv, per_clip * t, "tf_")
             last = li == self.n_layers - 1
             x = torch.empty(rows, d, device=self.device) if last else self.ws("tf_x3", (rows, d))
             xb = self.wsb("tf_x3", (rows, d))
@@ -409,7 +448,7 @@ class HipEngine:
         return out
 
     # ------------------------------------------------------------------ incremental decode step
-    def _decode_step(self, t, N, rows_per_clip, tok, anc, sem, ckv, skv, Lk, tag):
+    def _decode_step(self, t, N, rows_per_clip, tok, anc, sem, ckv, skv, Lk, tag, akv=None):
         """One decoder step for N rows: new token at position t-1 -> final hidden (fp32, bf16 mirror)."""
         w, d, T = self.w, self.d, self.T
         x, xb = self.ws(tag + "x0", (N, d)), self.wsb(tag + "x0", (N, d))
@@ -437,11 +476,14 @@ class HipEngine:
             o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
             x2, x2b = self.ws(tag + "x2", (N, d)), self.wsb(tag + "x2", (N, d))
             self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
+            if self.attr_att:
+                x2, x2b = self._attr_block(li, x2, x2b, akv, rows_per_clip, tag)
             x, xb = self.ws(tag + "x3_%d" % (li & 1), (N, d)), self.wsb(tag + "x3_%d" % (li & 1), (N, d))
             self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, tag, gemm_tag="step_ffn_gemm")
         return x, xb
 
-    def greedy(self, mem: torch.Tensor, sem: Optional[torch.Tensor], steps: Optional[int] = None):
+    def greedy(self, mem: torch.Tensor, sem: Optional[torch.Tensor], steps: Optional[int] = None,
+               sem_embs: Optional[torch.Tensor] = None):
         """Greedy decoding (= beam search with beam_size 1, models/Wrapper.py:34-35) of B clips.
 
         Returns device tensors: fed int32 [B, T+1] (column 0 = BOS), length int32 [B],
@@ -459,6 +501,7 @@ class HipEngine:
         fed.zero_(); fed[:, 0] = BOS
         score.zero_(); length.zero_(); fin.zero_()
         ckv = self.cross_kv(mem)
+        akv = self.attr_kv(sem_embs) if self.attr_att else None
         skv = [self.ws("g_skv%d" % li, (B, T, 2 * d), self.wt) for li in range(self.n_layers)]
         bf = self.as_ok
         parts = _lib.argmax_parts(self.V, B, bf)
@@ -466,7 +509,7 @@ class HipEngine:
         pidx = self.ws("g_pidx", (B, parts), torch.int32)
         psum = self.ws("g_psum", (B, parts))
         for t in range(1, steps + 1):
-            x, xb = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_")
+            x, xb = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_", akv=akv)
             if bf:
                 call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(pmax), ptr(pidx),
                      ptr(psum), B, self.V, d, tag="step_vocab_argmax")
@@ -490,12 +533,14 @@ class HipEngine:
         feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
         if not use_graph:
             enc = self.encode(feats)
-            return (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states")))
+            return (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
+                                              sem_embs=enc.get("semantic_embs")))
         key = ("greedy", tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
         entry = self._graphs.get(key)
         if entry is None:
             enc = self.encode(feats)  # eager pass: allocates every workspace
-            out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states")))
+            out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
+                                             sem_embs=enc.get("semantic_embs")))
             self._graphs[key] = "seen"
             return out
         if entry == "seen":
@@ -505,14 +550,16 @@ class HipEngine:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 enc = self.encode(feats)
-                out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states")))
+                out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
+                                                 sem_embs=enc.get("semantic_embs")))
             entry = (graph, out)
             self._graphs[key] = entry
         graph, out = entry
         graph.replay()
         return out
 
-    def beam(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int):
+    def beam(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int,
+             sem_embs: Optional[torch.Tensor] = None):
         """Beam search of B clips x bm beams, state on the device (csrc/beam.hip)."""
         B, Lk, d = mem.shape
         T, N = self.T, mem.shape[0] * bm
@@ -535,10 +582,11 @@ class HipEngine:
         cidx = self.ws("b_cidx", (N, bm), torch.int32)
         logits = self.ws("b_logits", (N, self.V))
         ckv = self.cross_kv(mem)
+        akv = self.attr_kv(sem_embs) if self.attr_att else None
         skv = [self.ws("b_skv%d" % li, (N, T, 2 * d), self.wt) for li in range(self.n_layers)]
         for t in range(1, T + 1):
             a_old, a_new = anc[(t - 1) & 1], anc[t & 1]
-            x, xb = self._decode_step(t, N, bm, tok, a_old, sem, ckv, skv, Lk, "b_")
+            x, xb = self._decode_step(t, N, bm, tok, a_old, sem, ckv, skv, Lk, "b_", akv=akv)
             self.gemm(xb if xb is not None else x, self.w["vocab"], None, logits)
             call("care_beam_select", ptr(logits), self.V, self.V, bm, ptr(cval), ptr(cidx), N)
             call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),

@@ -200,9 +200,13 @@ class _DecoderLayer(nn.Module):
         hybrid_length = opt["n_frames"] * len(modality) + opt.get("use_attr_topk", 30)
         if "r" in modality:
             hybrid_length += opt["retrieval_topk"] - opt["n_frames"]
-        self.inter_attention = _MHA(opt, hybrid_length if opt.get("add_hybrid_attention_bias", False) else 0)
+        hb = hybrid_length if opt.get("add_hybrid_attention_bias", False) else 0
+        self.inter_attention = _MHA(opt, hb)
         if opt.get("use_attr", False) and "att" in opt.get("use_attr_type", "att"):
-            raise ValueError("the attr_attention (CABase) variant is a later round (SURVEY.md 8(f) item 3)")
+            # Layers.py:117-119: attr_attention = deepcopy(inter_attention) -> same parameter tree
+            if opt.get("attr_layer_pos", "cross2attr") != "cross2attr":
+                raise ValueError("only attr_layer_pos='cross2attr' (tasks.yaml:58) is on the path")
+            self.attr_attention = _MHA(opt, hb)
         self.ffn = _FFN(opt)
 
 
@@ -346,7 +350,8 @@ class TransformerSeq2Seq(nn.Module):
             mem = mem[0]
         with torch.no_grad():
             return self.engine().decode_full(input_ids, mem, inputs_for_decoder.get("semantic_hidden_states"),
-                                             want_logits="last" if last_time_step_logits else "all")
+                                             want_logits="last" if last_time_step_logits else "all",
+                                             sem_embs=inputs_for_decoder.get("semantic_embs"))
 
     def feedforward_step(self, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
         enc = self.encoding_phase(batch["feats"], **kwargs)

@@ -210,6 +210,11 @@ def decoder_forward(P, opt: dict, input_ids: torch.Tensor, inputs: Dict[str, tor
         lp = "decoder.layers.{}".format(li)
         h = attention_block(P, lp + ".intra_attention", opt, h, None, self_mask)
         h = attention_block(P, lp + ".inter_attention", opt, h, memory, None)
+        if (lp + ".attr_attention.dense.weight") in P:
+            # CABase, attr_layer_pos = 'cross2attr' (Layers.py:139-154,218-225): a third post-LN
+            # attention block whose keys/values are the concept embeddings, no mask
+            assert opt.get("attr_layer_pos", "cross2attr") == "cross2attr"
+            h = attention_block(P, lp + ".attr_attention", opt, h, inputs["semantic_embs"], None)
         h = ffn_block(P, lp + ".ffn", opt, h)
     return h
 
@@ -226,6 +231,8 @@ def decoding_phase(P, opt: dict, input_ids: torch.Tensor, inputs: Dict[str, torc
 def inputs_for_decoder(opt: dict, enc: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """`get_framework` key list (Framework.py:20-33) + `prepare_inputs_for_decoder` (:189-204)."""
     keys = ["encoder_hidden_states"]
+    if opt.get("use_attr", False) and ("prefix" in opt["use_attr_type"] or "att" in opt["use_attr_type"].lower()):
+        keys.append("semantic_embs")
     if "emb" in opt.get("use_attr_type", ""):
         keys.append("semantic_hidden_states")
     return {k: enc[k] for k in keys}

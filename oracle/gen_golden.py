@@ -40,6 +40,8 @@ CASES = [
     ("msrvtt_base_ami_beam5_eos_b3", "msrvtt_base_ami", 3, 20, {"beam_size": 5}, {VOCAB_W: {EOS_ROW: 3.5}}),
     ("care_median_gelu_b2", "care_median_gelu", 2, 21, {}, {}),
     ("base_ami_mte_b2", "base_ami_mte", 2, 22, {}, {}),
+    ("msrvtt_cabase_b3", "msrvtt_cabase", 3, 23, {}, {VOCAB_W: {EOS_ROW: 4.0}}),
+    ("msrvtt_cabase_beam5_b2", "msrvtt_cabase", 2, 24, {"beam_size": 5}, {VOCAB_W: {EOS_ROW: 3.5}}),
 ]
 
 
@@ -77,6 +79,8 @@ def run_case(get_framework, get_translator, name, cfg, B, seed, overrides, row_s
         for k in ("preds_attr", "avg_prob_attr", "semantic_labels", "semantic_hidden_states"):
             if enc.get(k) is not None:
                 rec[k] = enc[k].numpy()
+        if enc.get("semantic_embs") is not None and "concat" not in opt.get("use_attr_type", ""):
+            rec["semantic_embs_clip0"] = enc["semantic_embs"][0].numpy()  # not part of the memory here
         if "preds_attr" in enc:
             top = enc["preds_attr"].topk(opt["use_attr_topk"] + 1, dim=1)[0]
             rec["concept_topk_min_gap"] = np.float64((top[:, :-1] - top[:, 1:]).min().item())
@@ -115,10 +119,30 @@ def run_case(get_framework, get_translator, name, cfg, B, seed, overrides, row_s
     print("{:32s} params={} hyp_lens={} size={:.0f}KB".format(name, meta["n_params"], lens_s, os.path.getsize(path) / 1024))
 
 
+def host_helpers_golden():
+    """Known answers of the host-side helpers next to the path: frame sampling
+    (misc/utils.py:307-317) and detokenisation (misc/utils.py:117-137), from the reference itself."""
+    from misc.utils import get_uniform_ids_from_k_snippets, resampling, to_sentence
+
+    vocab = {i: "w%d" % i for i in range(20)}
+    hyps = [[7, 8, 9, 3, 5], [7, 0, 9], [3], [], [6, 6, 3, 3], [11, 12, 13]]
+    cases = {
+        "uniform": {"%d,%d" % (l, k): get_uniform_ids_from_k_snippets(l, k)
+                    for l, k in [(60, 28), (60, 8), (60, 60), (32, 28), (100, 7)]},
+        "resampling": {"%d,%d" % (a, b): resampling(a, b) for a, b in [(10, 28), (27, 28), (60, 28)]},
+        "to_sentence": [{"hyp": h, "plain": to_sentence(h, vocab), "add_eos": to_sentence(h, vocab, add_eos=True)}
+                        for h in hyps],
+    }
+    json.dump(cases, open(os.path.join(OUT_DIR, "host_helpers.json"), "w"))
+    print("host_helpers.json written")
+
+
 def main():
     get_framework, get_translator = import_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
     only = set(sys.argv[1:])
+    if not only or "host_helpers" in only:
+        host_helpers_golden()
     for case in CASES:
         if only and case[0] not in only:
             continue

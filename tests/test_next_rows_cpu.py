@@ -1,0 +1,115 @@
+"""CPU: the rows next to the hot path: checkpoint/opt ingestion, feature batching, detokenisation."""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_helpers.json")
+
+
+def _fake_lightning_checkpoint(path, opt, state_dict, new_opt):
+    """A file laid out like the reference's Lightning checkpoints, incl. Lightning's AttributeDict class."""
+    mod = types.ModuleType("pytorch_lightning.utilities.parsing")
+
+    AttributeDict = type("AttributeDict", (dict,), {"__module__": "pytorch_lightning.utilities.parsing",
+                                                     "__qualname__": "AttributeDict"})
+    mod.AttributeDict = AttributeDict
+    pkgs = {"pytorch_lightning": types.ModuleType("pytorch_lightning"),
+            "pytorch_lightning.utilities": types.ModuleType("pytorch_lightning.utilities"),
+            "pytorch_lightning.utilities.parsing": mod}
+    saved = {k: sys.modules.get(k) for k in pkgs}
+    sys.modules.update(pkgs)
+    try:
+        ckpt = {"epoch": 3, "global_step": 1234, "pytorch-lightning_version": "1.6.5",
+                "state_dict": {**{"captioner." + k: v for k, v in state_dict.items()},
+                               "criterion.some_buffer": torch.zeros(3)},
+                "hyper_parameters": AttributeDict(opt=opt, new_opt_used_to_override=new_opt)}
+        torch.save(ckpt, path)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_checkpoint_roundtrip_without_lightning(tmp_path):
+    from care_amd.checkpoint import load_model, read_checkpoint
+    from care_amd.configs import make_opt
+    from care_amd.framework import get_framework
+    from care_amd.synth import synth_state_dict
+
+    opt = make_opt("msrvtt_care", dataset="MSRVTT", info_corpus="/old/root/MSRVTT/info_corpus.pkl",
+                   reference="/old/root/MSRVTT/refs.pkl", feats_i=["/old/root/MSRVTT/feats/CLIP_ViT-B-32.hdf5"])
+    sd = synth_state_dict(9, [(k, tuple(v.shape)) for k, v in get_framework(opt).state_dict().items()])
+    path = str(tmp_path / "best.ckpt")
+    _fake_lightning_checkpoint(path, opt, sd, {"beam_size": 5})
+    assert "pytorch_lightning" not in sys.modules
+    ck = read_checkpoint(path)
+    assert ck["extra_keys"] == ["criterion.some_buffer"] and ck["new_opt"] == {"beam_size": 5}
+    assert type(ck["opt"]) is dict and ck["opt"]["dim_hidden"] == 512
+
+    runner = load_model(path, new_opt_used_to_override={"beam_size": 1, "topk": 1}, device=None,
+                        base_data_path="/new/base")
+    assert runner.translator.beam_size == 1                       # override wins (Wrapper.py:29)
+    assert runner.get_opt()["info_corpus"] == "/new/base/MSRVTT/info_corpus.pkl"
+    assert runner.get_opt()["feats_i"] == ["/new/base/MSRVTT/feats/CLIP_ViT-B-32.hdf5"]
+    assert not runner.captioner.training
+    got = runner.captioner.state_dict()
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    assert runner.get_keys_to_device() == ["feats", "input_ids"]
+
+    bad = dict(sd)
+    bad.pop("cls_head.tgt_word_prj.weight")
+    _fake_lightning_checkpoint(path, opt, bad, {})
+    with pytest.raises(RuntimeError):
+        load_model(path, device=None)
+    load_model(path, device=None, strict=False)
+
+
+def test_frame_sampling_and_detokenisation_match_reference():
+    from care_amd.data import get_uniform_ids_from_k_snippets, resampling
+    from care_amd.text import to_sentence
+
+    g = json.load(open(GOLDEN))
+    for key, ids in g["uniform"].items():
+        l, k = map(int, key.split(","))
+        assert get_uniform_ids_from_k_snippets(l, k) == ids
+    for key, ids in g["resampling"].items():
+        a, b = map(int, key.split(","))
+        assert resampling(a, b) == ids
+    vocab = {i: "w%d" % i for i in range(20)}
+    for case in g["to_sentence"]:
+        assert to_sentence(case["hyp"], vocab) == case["plain"]
+        assert to_sentence(case["hyp"], vocab, add_eos=True) == case["add_eos"]
+
+
+def test_feature_tables_to_batch():
+    from care_amd.configs import make_opt
+    from care_amd.data import collate_feats, get_uniform_ids_from_k_snippets, load_video_feats
+
+    opt = make_opt("msrvtt_care")
+    rng = np.random.default_rng(0)
+    tables = {"a": [{"video0": rng.normal(size=(60, 128)).astype(np.float32)}],
+              "m": [{"video0": rng.normal(size=(60, 2048)).astype(np.float32),
+                     "video1": rng.normal(size=(60, 2048)).astype(np.float32)}],
+              "i": [{"video0": rng.normal(size=(60, 256)).astype(np.float32)},       # two tables: channel concat
+                    {"video0": rng.normal(size=(256,)).astype(np.float32)}],         # a per-video vector is tiled
+              "r": [{"video0": rng.normal(size=(50, 512)).astype(np.float32),
+                     "video1": rng.normal(size=(50, 512)).astype(np.float32)}]}
+    f0 = load_video_feats(tables, "video0", opt)
+    ids = get_uniform_ids_from_k_snippets(60, 28)
+    assert [x.shape for x in f0] == [(28, 128), (28, 2048), (28, 512), (20, 512)]
+    np.testing.assert_array_equal(f0[1], tables["m"][0]["video0"][ids])
+    np.testing.assert_array_equal(f0[2][:, :256], tables["i"][0]["video0"][ids])
+    np.testing.assert_array_equal(f0[2][5, 256:], tables["i"][1]["video0"])
+    np.testing.assert_array_equal(f0[3], tables["r"][0]["video0"][:20])
+    f1 = load_video_feats(tables, "video1", opt)
+    assert np.all(f1[0] == 0) and np.all(f1[2] == 0)                                  # missing video -> zeros
+    batch = collate_feats([f0, f1])
+    assert [tuple(t.shape) for t in batch] == [(2, 28, 128), (2, 28, 2048), (2, 28, 512), (2, 20, 512)]
+    assert batch[0].dtype == torch.float32

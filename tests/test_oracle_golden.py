@@ -29,7 +29,10 @@ def test_encoding_phase_matches_reference(golden):
         _close(enc["preds_attr"], z["preds_attr"])
         _close(enc["avg_prob_attr"], z["avg_prob_attr"])
         assert np.array_equal(enc["semantic_labels"].numpy(), z["semantic_labels"])
-        _close(enc["semantic_hidden_states"], z["semantic_hidden_states"])
+        if "semantic_hidden_states" in z:
+            _close(enc["semantic_hidden_states"], z["semantic_hidden_states"])
+        if "semantic_embs_clip0" in z:
+            _close(enc["semantic_embs"][0], z["semantic_embs_clip0"])
         assert float(z["concept_topk_min_gap"]) > 0.0, "fixture has an exact concept tie (parity unpinned there)"
     else:
         assert "preds_attr" not in enc

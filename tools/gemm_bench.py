@@ -7,17 +7,24 @@ from care_amd import _lib
 DEV = "cuda:0"
 
 
-def time_call(fn, iters=30):
+def time_call(fn, iters=20):
+    """GPU time per launch: `iters` launches captured in a hipGraph (no host launch overhead)."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(5):
+        g.replay()
     e.record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) * 1e3 / iters
+    return s.elapsed_time(e) * 1e3 / (5 * iters)
 
 
 def main():
