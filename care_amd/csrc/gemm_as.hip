@@ -65,6 +65,7 @@ struct AsArgs {
   int64_t ldw;           // row stride of W in elements (== full K)
   int64_t slab_stride;   // elements between consecutive fp32 slabs of C0
   float* pmax; int32_t* pidx; float* psum;
+  const int32_t* labels; float* plab;   // optional (ARGMAX): logit of column labels[row] per partial
   int total_items;       // kslices * per-slice items (grid may be smaller: persistent blocks)
 };
 
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
     if (MODE == STREAM_ARGMAX && lane < 32 && m0 + lane < p.M) {
       const int64_t o = (int64_t)(m0 + lane) * p.ns + ns;
       p.pmax[o] = -INFINITY; p.pidx[o] = 0x7fffffff; p.psum[o] = 0.f;
+      if (p.plab) p.plab[o] = -INFINITY;
     }
     continue;
   }
@@ -257,11 +259,15 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   };
 
   // running (max, argmax, sum-exp) of the 8 rows this lane sees, over its column residue
-  float rm[8], rs[8];
-  int ri[8];
+  float rm[8], rs[8], rl[8];
+  int ri[8], lab[8];
   if constexpr (MODE == STREAM_ARGMAX) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { rm[i] = -INFINITY; rs[i] = 0.f; ri[i] = 0x7fffffff; }
+    for (int i = 0; i < 8; ++i) {
+      rm[i] = -INFINITY; rs[i] = 0.f; ri[i] = 0x7fffffff; rl[i] = -INFINITY;
+      const int row = min(m0 + (i >> 2) * 16 + fg * 4 + (i & 3), p.M - 1);
+      lab[i] = p.labels ? p.labels[row] : -1;
+    }
   }
 
   // ---- prologue: up to AHEAD tiles in flight (4 VM ops each), then the A loads: one combined latency
@@ -353,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
           rs[i] = rs[i] * __expf(rm[i] - mn) + __expf(v0 - mn);
           ri[i] = v0 > rm[i] ? c0 : ri[i];
           rm[i] = mn;
+          rl[i] = c0 == lab[i] ? v0 : rl[i];
         }
     }
 #pragma unroll
@@ -364,10 +371,11 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   if constexpr (MODE == STREAM_ARGMAX) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      float m = rm[i], s = rs[i];
+      float m = rm[i], s = rs[i], lv = rl[i];
       int id = ri[i];
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) {
+        lv = fmaxf(lv, __shfl_xor(lv, o, 64));
         const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
         const int oi = __shfl_xor(id, o, 64);
         const float mn = fmaxf(m, om);
@@ -379,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
       if (fr == 0 && row < p.M) {
         const int64_t o = (int64_t)row * p.ns + ns;
         p.pmax[o] = m; p.pidx[o] = id; p.psum[o] = s;
+        if (p.plab) p.plab[o] = lv;
       }
     }
   }
@@ -456,15 +465,16 @@ extern "C" int care_argmax_parts_bf16(int M, int N) {
 }
 
 extern "C" int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
-                                     int32_t* pidx, float* psum, int M, int N, int K, void* stream) {
+                                     int32_t* pidx, float* psum, const int32_t* labels, float* plab, int M, int N,
+                                     int K, void* stream) {
   int rc = as_check(A, lda, a_dtype, W, M, N, K);
   if (rc) return rc;
-  if (!pmax || !pidx || !psum) return CARE_EINVAL;
+  if (!pmax || !pidx || !psum || ((labels != nullptr) != (plab != nullptr))) return CARE_EINVAL;
   if (K > 512) return CARE_ESHAPE;
   AsArgs p{};
   p.A = A; p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.M = M; p.N = N; p.K = K; p.n_split = N;
   p.kslices = 1; p.ldw = K;
-  p.pmax = pmax; p.pidx = pidx; p.psum = psum;
+  p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.labels = labels; p.plab = plab;
   p.panels = (M + 127) / 128;
   p.ns = pick_ns(p.panels, (N + TILE_N - 1) / TILE_N);
   const int blocks = plan_stream(p, false);

@@ -220,6 +220,73 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(const float* pmax, c
   }
 }
 
+// teacher-forced scoring from the fused vocabulary partials: per row the arg-max column and the
+// log-probability of the label column, log_softmax(x)[label] = x[label] - max - log(sum exp(x - max))
+__global__ __launch_bounds__(256) void score_partials_kernel(const float* pmax, const int32_t* pidx, const float* psum,
+                                                             const float* plab, int parts, float* logp, int32_t* pred,
+                                                             int rows) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float best = -INFINITY, lv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < parts; c += 64) {
+    const float v = pmax[(int64_t)r * parts + c];
+    const int id = pidx[(int64_t)r * parts + c];
+    if (v > best || (v == best && id < bi)) { best = v; bi = id; }
+    lv = fmaxf(lv, plab[(int64_t)r * parts + c]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    lv = fmaxf(lv, __shfl_xor(lv, o, 64));
+  }
+  float s = 0.f;
+  for (int c = lane; c < parts; c += 64)
+    s += psum[(int64_t)r * parts + c] * expf(pmax[(int64_t)r * parts + c] - best);
+  s = care_wave_sum(s);
+  if (lane == 0) { logp[r] = (lv - best) - logf(s); pred[r] = bi; }
+}
+
+// the same from materialised logits [rows, ld] (fp32 mode, and the checker of the fused form)
+__global__ __launch_bounds__(256) void score_logits_kernel(const float* logits, int64_t ld, int V, const int32_t* labels,
+                                                           float* logp, int32_t* pred, int rows) {
+  __shared__ float sm[4];
+  __shared__ int si[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (int64_t)r * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = tid; c < V; c += 256) {
+    const float v = x[c];
+    if (v > best) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { sm[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  best = sm[0]; bi = si[0];
+  for (int w = 1; w < 4; ++w)
+    if (sm[w] > best || (sm[w] == best && si[w] < bi)) { best = sm[w]; bi = si[w]; }
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid; c < V; c += 256) s += expf(x[c] - best);
+  s = care_wave_sum(s);
+  if (lane == 0) sm[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const float tot = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    logp[r] = (x[labels[r]] - best) - logf(tot);
+    pred[r] = bi;
+  }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -287,6 +354,21 @@ extern "C" int care_greedy_update(const float* pmax, const int32_t* pidx, const 
   if (t <= 0 || t >= fed_stride) return CARE_ESHAPE;
   hipLaunchKernelGGL(greedy_update_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, pmax, pidx, psum, parts, fed,
                      fed_stride, score, length, finished, t, max_steps, eos_id, rows);
+  return care_launch_status();
+}
+
+extern "C" int care_score_partials(const float* pmax, const int32_t* pidx, const float* psum, const float* plab,
+                                   int parts, float* logp, int32_t* pred, int rows, void* stream) {
+  if (!pmax || !pidx || !psum || !plab || !logp || !pred || rows <= 0 || parts <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(score_partials_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, pmax, pidx, psum, plab, parts,
+                     logp, pred, rows);
+  return care_launch_status();
+}
+
+extern "C" int care_score_logits(const float* logits, int64_t ld, int V, const int32_t* labels, float* logp,
+                                 int32_t* pred, int rows, void* stream) {
+  if (!logits || !labels || !logp || !pred || rows <= 0 || V <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(score_logits_kernel, dim3(rows), dim3(256), 0, ST, logits, ld, V, labels, logp, pred, rows);
   return care_launch_status();
 }
 

@@ -438,6 +438,7 @@ class HipEngine:
             xb = self.wsb("tf_x3", (rows, d))
             self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, "tf_")
         hidden = x.view(N, t, d)
+        self._last_tf_bf16 = xb
         out = {"hidden_states": hidden}
         if want_logits == "all":
             out["logits"] = self.gemm(xb if xb is not None else x, w["vocab"], None,
@@ -446,6 +447,33 @@ class HipEngine:
             src = (xb if xb is not None else x).view(N, t, d)[:, -1, :]
             out["logits"] = self.gemm(src, w["vocab"], None, torch.empty(N, self.V, device=self.device))
         return out
+
+    def score_teacher_forced(self, input_ids, labels, mem, sem, sem_embs=None):
+        """Metrics step (crit_lang.py:75-103): per position log p(label) and arg-max token.
+
+        bf16 A-stationary path: the vocabulary GEMM keeps running (max, argmax, sum-exp, label
+        logit) per row and never writes the [B*T, V] logits; otherwise logits are materialised
+        and scored by care_score_logits.  Returns (logp fp32 [N, t], pred int32 [N, t]).
+        """
+        N, t = input_ids.shape
+        rows = N * t
+        lab32 = labels.to(self.device, torch.int32).contiguous().view(rows)
+        logp = torch.empty(rows, device=self.device)
+        pred = torch.empty(rows, device=self.device, dtype=torch.int32)
+        if self.as_ok:
+            out = self.decode_full(input_ids, mem, sem, want_logits="none", sem_embs=sem_embs)
+            xb = self._last_tf_bf16
+            parts = _lib.argmax_parts(self.V, rows, True)
+            pm, pi = self.ws("sc_pmax", (rows, parts)), self.ws("sc_pidx", (rows, parts), torch.int32)
+            ps, pl = self.ws("sc_psum", (rows, parts)), self.ws("sc_plab", (rows, parts))
+            call("care_gemm_argmax_bf16", ptr(xb), self.d, _code(xb), ptr(self.w["vocab"]), ptr(pm), ptr(pi), ptr(ps),
+                 ptr(lab32), ptr(pl), rows, self.V, self.d)
+            call("care_score_partials", ptr(pm), ptr(pi), ptr(ps), ptr(pl), parts, ptr(logp), ptr(pred), rows)
+        else:
+            out = self.decode_full(input_ids, mem, sem, want_logits="all", sem_embs=sem_embs)
+            lg = out["logits"].view(rows, self.V)
+            call("care_score_logits", ptr(lg), lg.stride(0), self.V, ptr(lab32), ptr(logp), ptr(pred), rows)
+        return logp.view(N, t), pred.view(N, t)
 
     # ------------------------------------------------------------------ incremental decode step
     def _decode_step(self, t, N, rows_per_clip, tok, anc, sem, ckv, skv, Lk, tag, akv=None):
@@ -512,7 +540,7 @@ class HipEngine:
             x, xb = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_", akv=akv)
             if bf:
                 call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(pmax), ptr(pidx),
-                     ptr(psum), B, self.V, d, tag="step_vocab_argmax")
+                     ptr(psum), None, None, B, self.V, d, tag="step_vocab_argmax")
             else:
                 call("care_gemm_argmax", ptr(x), d, ptr(self.w["vocab"]), _code(self.w["vocab"]), ptr(pmax),
                      ptr(pidx), ptr(psum), B, self.V, d, tag="step_vocab_argmax")

@@ -146,5 +146,23 @@ def synth_input_ids(seed: int, batch: int, length: int, vocab_size: int, pad_tai
     return torch.from_numpy(ids)
 
 
+def synth_labels(input_ids: torch.Tensor) -> torch.Tensor:
+    """Next-token labels of teacher forcing: labels[:, t] = input_ids[:, t+1], PAD at the end
+    (dataloader.py:661-675 builds input_ids = tokens[:-1], labels = tokens[1:])."""
+    from .constants import PAD
+
+    labels = torch.full_like(input_ids, PAD)
+    labels[:, :-1] = input_ids[:, 1:]
+    return labels
+
+
+def synth_labels_attr(seed: int, batch: int, k: int) -> torch.Tensor:
+    """Multi-hot concept labels [B, k] (about 4% positives, at least one per clip)."""
+    u = uniform(seed, "labels_attr", (batch, k))
+    lab = (u > 0.92).astype(np.float32)
+    lab[:, 0] = np.maximum(lab[:, 0], (lab.sum(1) == 0).astype(np.float32))
+    return torch.from_numpy(lab)
+
+
 def tensor_sha256(t: torch.Tensor) -> str:
     return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 3
+#define CARE_ABI_VERSION 4
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -99,7 +99,25 @@ int care_gemm_bf16_splitk(const void* A, int64_t lda, int a_dtype, const void* W
                           const float* bias, float* C, int64_t ldc, int64_t slab_stride,
                           int M, int N, int K, void* stream);
 int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
-                          int32_t* pidx, float* psum, int M, int N, int K, void* stream);
+                          int32_t* pidx, float* psum, const int32_t* labels, float* plab,
+                          int M, int N, int K, void* stream);
+
+/*
+ * Teacher-forced scoring (the metrics step): log-probability of the label token and the arg-max
+ *   token of every row.  Replaces log_softmax + gather / max of LanguageGeneration
+ *   (misc/Crit/crit_lang.py:75-103: word accuracy, perplexity) for the eval metrics step
+ *   (models/Wrapper.py:182-184).
+ *   care_gemm_argmax_bf16 with labels/plab non-NULL also records, per column group, the logit
+ *   of column labels[row] (-inf where the group does not contain it);
+ *   care_score_partials reduces the groups: logp[r] = x[label] - max - log(sum exp(x - max)),
+ *   pred[r] = arg-max column.  The [rows, V] logits are never written.
+ *   care_score_logits does the same from materialised logits [rows, ld] (fp32 mode / checker).
+ */
+int care_score_partials(const float* pmax, const int32_t* pidx, const float* psum,
+                        const float* plab, int parts, float* logp, int32_t* pred, int rows,
+                        void* stream);
+int care_score_logits(const float* logits, int64_t ld, int V, const int32_t* labels, float* logp,
+                      int32_t* pred, int rows, void* stream);
 
 /*
  * care_greedy_update: finish the argmax over the partials and advance the greedy state.

@@ -17,7 +17,8 @@ import numpy as np
 import torch
 
 from care_amd.configs import feat_shapes, make_opt
-from care_amd.synth import GENERATOR_VERSION, synth_feats, synth_input_ids, synth_state_dict, tensor_sha256
+from care_amd.synth import (GENERATOR_VERSION, synth_feats, synth_input_ids, synth_labels, synth_labels_attr,
+                            synth_state_dict, tensor_sha256)
 from oracle.ref_import import import_reference
 
 OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -93,6 +94,24 @@ def run_case(get_framework, get_translator, name, cfg, B, seed, overrides, row_s
         top = logits.topk(8, dim=-1)
         rec["tf_logits_top8_val"] = top[0].numpy()
         rec["tf_logits_top8_idx"] = top[1].numpy().astype(np.int32)
+
+        # metrics step with the reference's OWN criteria (misc/Crit/crit_lang.py, crit_attribute.py)
+        from misc.Crit.crit_attribute import NoisyOrMIL
+        from misc.Crit.crit_lang import LanguageGeneration
+
+        labels = synth_labels(input_ids)
+        lang = LanguageGeneration({**opt, "label_smoothing": 0.0})
+        lang.reset_recorder()
+        lang({"logits": logits, "labels": labels})
+        rec["tf_labels"] = labels.numpy()
+        rec["metrics_lang"] = np.asarray(lang.get_info()[1], dtype=np.float64)      # [Word Acc0, Perplexity]
+        if "preds_attr" in out and out["preds_attr"] is not None:
+            labels_attr = synth_labels_attr(seed, B, opt["attribute_prediction_k"])
+            crit = NoisyOrMIL({**opt, "calculate_mAP": True})
+            crit.reset_recorder()
+            crit({"preds_attr": out["preds_attr"], "avg_prob_attr": out["avg_prob_attr"], "labels_attr": labels_attr})
+            rec["labels_attr"] = labels_attr.numpy()
+            rec["metrics_attr"] = np.asarray(crit.get_info()[1], dtype=np.float64)  # F1@5..50, mAP
 
         translator = get_translator(opt)
         hyps, scores = translator.translate_batch([model], {"feats": [f.clone() for f in feats]})

@@ -117,7 +117,7 @@ def test_gemm_argmax(M, mode):
     pidx = torch.empty(M, parts, device=DEV, dtype=torch.int32)
     psum = torch.empty(M, parts, device=DEV)
     if mode == "bf16_as":
-        _call("care_gemm_argmax_bf16", _p(A), K, 0, _p(Wd), _p(pmax), _p(pidx), _p(psum), M, N, K)
+        _call("care_gemm_argmax_bf16", _p(A), K, 0, _p(Wd), _p(pmax), _p(pidx), _p(psum), None, None, M, N, K)
     else:
         _call("care_gemm_argmax", _p(A), K, _p(Wd), code, _p(pmax), _p(pidx), _p(psum), M, N, K)
     fed = torch.zeros(M, 30, device=DEV, dtype=torch.int32)
@@ -266,3 +266,30 @@ def test_gemm_splitk_slabs_summed_by_add_ln(M):
     torch.cuda.synchronize()
     assert (slabs.sum(0).double() - y).abs().max().item() < 3e-3
     assert (out - ref).abs().max().item() < 3e-3
+
+
+@pytest.mark.parametrize("M", [3, 200, 1030])
+def test_fused_label_scoring(M):
+    from care_amd import _lib
+
+    N, K = 10547, 512
+    A = _rand(M, K, seed=40).to(torch.bfloat16)
+    W = (_rand(N, K, seed=41, scale=0.05)).to(torch.bfloat16).contiguous()
+    labels = torch.randint(0, N, (M,), dtype=torch.int32).to(DEV)
+    labels[0] = N - 1
+    parts = _lib.argmax_parts(N, M, True)
+    pm, ps, pl = (torch.empty(M, parts, device=DEV) for _ in range(3))
+    pi = torch.empty(M, parts, device=DEV, dtype=torch.int32)
+    _call("care_gemm_argmax_bf16", _p(A), K, 1, _p(W), _p(pm), _p(pi), _p(ps), _p(labels), _p(pl), M, N, K)
+    logp, pred = torch.empty(M, device=DEV), torch.empty(M, device=DEV, dtype=torch.int32)
+    _call("care_score_partials", _p(pm), _p(pi), _p(ps), _p(pl), parts, _p(logp), _p(pred), M)
+    logits = (A.float() @ W.float().t()).contiguous()
+    ref = torch.log_softmax(logits.double(), dim=1).gather(1, labels.long().unsqueeze(1)).squeeze(1)
+    logp2, pred2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV, dtype=torch.int32)
+    _call("care_score_logits", _p(logits), N, N, _p(labels), _p(logp2), _p(pred2), M)
+    torch.cuda.synchronize()
+    assert (logp.double() - ref).abs().max().item() < 2e-3
+    assert (logp2.double() - ref).abs().max().item() < 1e-4
+    top2 = logits.topk(2, dim=1)[0]
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-3
+    assert torch.equal(pred[safe].long(), logits.argmax(1)[safe]) and torch.equal(pred2.long(), logits.argmax(1))

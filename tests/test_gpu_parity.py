@@ -152,3 +152,27 @@ def test_checkpoint_ingestion_and_prefetcher_gpu(tmp_path):
     vocab = {i: "w%d" % i for i in range(opt["vocab_size"])}
     out = runner.translate_step({"feats": _dev(feats), "video_ids": ["video%d" % i for i in range(4)]}, vocab=vocab)
     assert out[0]["image_id"] == "video0" and isinstance(out[0]["caption"], str) and isinstance(out[0]["score"], float)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_metrics_step_gpu(golden, dtype):
+    """Fused teacher-forced scoring (no logits in HBM in bf16 mode) -> word accuracy / perplexity;
+    concept F1@k / mAP on the device predictions; both against the reference's own criteria."""
+    from care_amd.metrics import concept_metrics, language_metrics
+
+    opt, P, feats, ids = golden.build()
+    z = golden.z
+    model = _model(opt, P, dtype)
+    enc = model.encoding_phase(_dev(feats))
+    labels = torch.from_numpy(z["tf_labels"])
+    logp, pred = model.engine().score_teacher_forced(ids.to("cuda:0"), labels, enc["encoder_hidden_states"],
+                                                     enc.get("semantic_hidden_states"), enc.get("semantic_embs"))
+    m = language_metrics(logp, pred, labels)
+    tol = 1e-4 if dtype == "fp32" else 3e-3
+    assert abs(m["Perplexity"] / z["metrics_lang"][1] - 1) < tol
+    if dtype == "fp32":
+        assert abs(m["Word Acc0"] - z["metrics_lang"][0]) < 1e-6
+    if "metrics_attr" in z and (dtype == "fp32" or opt["encoder"] == "Embedder"):
+        c = concept_metrics(enc["preds_attr"], torch.from_numpy(z["labels_attr"]))
+        got = [c["F1-%02d" % k] for k in (5, 10, 20, 30, 40, 50)] + [c["mAP"]]
+        np.testing.assert_allclose(got, z["metrics_attr"], rtol=1e-4, atol=1e-6)

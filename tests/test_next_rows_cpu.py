@@ -113,3 +113,24 @@ def test_feature_tables_to_batch():
     batch = collate_feats([f0, f1])
     assert [tuple(t.shape) for t in batch] == [(2, 28, 128), (2, 28, 2048), (2, 28, 512), (2, 20, 512)]
     assert batch[0].dtype == torch.float32
+
+
+def test_metric_formulas_match_reference_criteria(golden):
+    """care_amd.metrics on the ORACLE's outputs equals the reference's own criteria (fixtures)."""
+    from care_amd.metrics import concept_metrics, language_metrics
+    from oracle import care_cpu
+
+    opt, P, feats, ids = golden.build()
+    z = golden.z
+    with torch.no_grad():
+        out = care_cpu.feedforward_step(P, opt, feats, ids)
+    labels = torch.from_numpy(z["tf_labels"])
+    lsm = torch.log_softmax(out["logits"], dim=-1)
+    logp = lsm.gather(2, labels.unsqueeze(2)).squeeze(2)
+    m = language_metrics(logp, lsm.argmax(-1), labels)
+    assert abs(m["Word Acc0"] - z["metrics_lang"][0]) < 1e-6
+    assert abs(m["Perplexity"] / z["metrics_lang"][1] - 1) < 1e-5
+    if "metrics_attr" in z:
+        c = concept_metrics(out["preds_attr"], torch.from_numpy(z["labels_attr"]))
+        got = [c["F1-%02d" % k] for k in (5, 10, 20, 30, 40, 50)] + [c["mAP"]]
+        np.testing.assert_allclose(got, z["metrics_attr"], rtol=1e-5, atol=1e-7)
