@@ -58,8 +58,10 @@ def kernel_model(tag, eng, B, dtype):
         return dict(bytes=B * d * 4 + V * d * es, flops=2.0 * B * d * V, bound="mfma")
     if tag == "step_ffn_gemm":
         return dict(bytes=B * (d + ff) * 4 + d * ff * es, flops=2.0 * B * d * ff, bound="mfma")
-    if tag == "step_dxd_gemm":
+    if tag in ("step_dxd_gemm", "step_dxd_ln"):
         return dict(bytes=B * 2 * d * 4 + d * d * es, flops=2.0 * B * d * d, bound="mfma")
+    if tag == "step_ffn_gemm_ln":
+        return dict(bytes=B * (ff * es + 3 * d * 4) + d * ff * es, flops=2.0 * B * d * ff, bound="mfma")
     if tag == "step_qkv_gemm":
         return dict(bytes=B * (d * 4 + d * 4 + 2 * d * es) + 3 * d * d * es, flops=2.0 * B * d * 3 * d, bound="mfma")
     if tag == "cross_kv_gemm":

@@ -15,6 +15,8 @@
 //     differs from ascending k.
 //   * Epilogues: bias + activation + (split) store, or the fused per-row
 //     (max, argmax, sum-exp) of the greedy vocabulary projection.
+#include <cstdlib>
+
 #include "care_common.h"
 
 namespace {
@@ -255,7 +257,8 @@ extern "C" int care_gemm(const float* A, int64_t lda, const void* W, int wdtype,
   p.n_split = n_split; p.M = M; p.N = N; p.K = K; p.act = act;
   hipStream_t st = (hipStream_t)stream;
   const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-  const bool big = big_tiles >= 192;
+  bool big = big_tiles >= 192;
+  if (const char* e = getenv("CARE_GEMM_TILE")) big = atoi(e) >= 128;  // tuning override
   if (wdtype == CARE_BF16)
     return big ? launch<bf16_t, 128, 128, false>(p, st) : launch<bf16_t, 64, 64, false>(p, st);
   return big ? launch<float, 128, 128, false>(p, st) : launch<float, 64, 64, false>(p, st);

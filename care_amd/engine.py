@@ -223,6 +223,21 @@ class HipEngine:
              nslab, x.stride(0) if nslab > 1 else 0)
         return out
 
+    def ln_fusable(self, rows: int) -> bool:
+        """Whether dense -> (+res) -> LayerNorm runs as ONE kernel (csrc/gemm_ln.hip): bf16 mode,
+        d_model = 512, and enough 64-row panels to occupy the chip (below that the A-stationary
+        GEMM + LayerNorm kernel pair is faster)."""
+        return self.as_ok and self.d == 512 and rows >= 8192
+
+    def gemm_ln(self, A, W, bias, res, g, be, out, outb, grp=None, out_grp_rows=None, out_row_off=0, pos=None, tag=None):
+        rows, K = A.shape
+        grp = rows if grp is None else grp
+        out_grp_rows = grp if out_grp_rows is None else out_grp_rows
+        call("care_gemm_ln", ptr(A), A.stride(0), _code(A), ptr(W), ptr(bias), ptr(res),
+             res.stride(0) if res is not None else 0, ptr(pos), ptr(g), ptr(be), self.eps, ptr(out), ptr(outb),
+             out.stride(-2), rows, self.d, K, grp, out_grp_rows, out_row_off, tag=tag)
+        return out
+
     def attention(self, Q, K, V, ctx, kv_batch_stride, kv_row_stride, rows_per_kv, nkeys, anc=None, causal=False,
                   seq=1, pad_tok=None, bias=None, tag=None):
         rows = Q.shape[0]
@@ -258,6 +273,10 @@ class HipEngine:
                       self.ws(tag + "h", (rows, self.ff), torch.bfloat16 if split else torch.float32),
                       act=self.act, tag=gemm_tag)
         w2 = w[name + "_w2"]
+        if split and self.ln_fusable(rows) and not ln_kw.get("pos"):
+            # dense2 + bias + residual + LayerNorm in one kernel: no split-K slabs at all
+            return self.gemm_ln(h, w2, w[name + "_b2"], x, w[name + "_g"], w[name + "_be"], out, outb,
+                                tag=(gemm_tag + "_ln") if gemm_tag else None, **ln_kw)
         if split:
             # K = ff > 512: split K over blocks into fp32 slabs; the LayerNorm kernel sums them
             ns = self.ff // 512
@@ -284,14 +303,20 @@ class HipEngine:
             if n != self.rows_of[ch]:
                 raise ValueError("modality `{}`: {} rows, expected {}".format(ch, n, self.rows_of[ch]))
             x2 = x.view(B * n, x.shape[2])
-            lin = self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch], self.ws("enc_lin", (B * n, d)), tag="enc_gemm")
+            fused = (opt["encoder"] == "Embedder" and self.as_ok and d == 512 and
+                     w["enc_w_" + ch].dtype == torch.bfloat16 and x2.shape[1] % 32 == 0)
+            lin = None if fused else self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch],
+                                               self.ws("enc_lin", (B * n, d)), tag="enc_gemm")
             in_mem = ch in self.dec_mod
             if in_mem:
                 dst, dstb, grp_rows, off = mem, memb, self.Lk, self.mem_off[ch]
             else:
                 dst, dstb, grp_rows, off = self.ws("enc_side_" + ch, (B, n, d)), None, n, 0
             ln_kw = dict(grp=n, out_grp_rows=grp_rows, out_row_off=off)
-            if opt["encoder"] == "Embedder":
+            if fused:  # Linear + bias + LayerNorm in one kernel, raw fp32 features streamed by LDS-DMA
+                self.gemm_ln(x2, w["enc_w_" + ch], w["enc_b_" + ch], None, w["enc_g_" + ch], w["enc_be_" + ch],
+                             dst, dstb, tag="enc_gemm", **ln_kw)
+            elif opt["encoder"] == "Embedder":
                 self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], dst, dstb, **ln_kw)
             else:  # MultiTransformerEncoder
                 h, hb = self.ws("enc_h0", (B * n, d)), self.wsb("enc_h0", (B * n, d))
@@ -493,17 +518,25 @@ class HipEngine:
             flat = cache.view(N * T, 2 * d)
             ctx = self.attention(q, flat, flat[:, d:], self._ctx(tag, N), T * 2 * d, 2 * d, 1, t, anc=anc,
                                  pad_tok=tok, tag="step_self_attn")
-            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
             x1, x1b = self.ws(tag + "x1", (N, d)), self.wsb(tag + "x1", (N, d))
-            self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b)
+            if self.ln_fusable(N):
+                self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x, w[nm + "_g"], w[nm + "_be"], x1, x1b,
+                             tag="step_dxd_ln")
+            else:
+                o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
+                self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b)
             nm = "d{}_ca".format(li)
             q2 = self.gemm(g(x1, x1b), w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)), tag="step_dxd_gemm")
             kv = ckv[li]
             ctx = self.attention(q2, kv, kv[:, d:], self._ctx(tag, N), Lk * 2 * d, 2 * d, rows_per_clip, Lk,
                                  bias=w["d{}_hb".format(li)], tag="step_cross_attn")
-            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
             x2, x2b = self.ws(tag + "x2", (N, d)), self.wsb(tag + "x2", (N, d))
-            self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
+            if self.ln_fusable(N):
+                self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x1, w[nm + "_g"], w[nm + "_be"], x2, x2b,
+                             tag="step_dxd_ln")
+            else:
+                o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
+                self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
             if self.attr_att:
                 x2, x2b = self._attr_block(li, x2, x2b, akv, rows_per_clip, tag)
             x, xb = self.ws(tag + "x3_%d" % (li & 1), (N, d)), self.wsb(tag + "x3_%d" % (li & 1), (N, d))

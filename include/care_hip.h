@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 4
+#define CARE_ABI_VERSION 5
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -153,6 +153,22 @@ int care_add_ln(const float* x, int64_t ldx, const float* res, int64_t ldres,
                 const float* pos, const float* gamma, const float* beta, float eps,
                 float* out, void* out_bf16, int64_t ldo, int rows, int d, int grp,
                 int out_grp_rows, int out_row_off, int nslab, int64_t slab_stride, void* stream);
+
+/*
+ * care_gemm_ln: out = LayerNorm(A W^T + bias + res + pos) * gamma + beta with N = d_model = 512,
+ *   one workgroup owning full output rows (csrc/gemm_ln.hip).  Fuses the Linear -> LayerNorm of
+ *   the Embedder (models/Encoder.py:167) and the dense -> dropout -> +residual -> LayerNorm
+ *   epilogues of MultiHeadAttention / PositionwiseFeedForward (SubLayers.py:69-79,143-150).
+ *   A [M, K] fp32 (raw features; rounded to bf16 when multiplied) or bf16; W bf16 [512, K];
+ *   bias/gamma/beta fp32 [512]; res (optional) fp32 [M, ldres]; pos (optional) fp32 [grp, 512]
+ *   added per row r as pos[r % grp].  Output rows are remapped exactly like care_add_ln
+ *   (grp / out_grp_rows / out_row_off); out fp32 and optional bf16 mirror share ldo.
+ *   Requires N == 512, K % 32 == 0.
+ */
+int care_gemm_ln(const void* A, int64_t lda, int a_dtype, const void* W, const float* bias,
+                 const float* res, int64_t ldres, const float* pos, const float* gamma,
+                 const float* beta, float eps, float* out, void* out_bf16, int64_t ldo, int M,
+                 int N, int K, int grp, int out_grp_rows, int out_row_off, void* stream);
 
 /*
  * care_group_mean: out[g, col_off + c] = mean over the grp rows of group g of x[., c].

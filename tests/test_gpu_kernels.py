@@ -293,3 +293,29 @@ def test_fused_label_scoring(M):
     top2 = logits.topk(2, dim=1)[0]
     safe = (top2[:, 0] - top2[:, 1]) > 1e-3
     assert torch.equal(pred[safe].long(), logits.argmax(1)[safe]) and torch.equal(pred2.long(), logits.argmax(1))
+
+
+@pytest.mark.parametrize("a_f32", [True, False])
+@pytest.mark.parametrize("M,K", [(7, 128), (64, 512), (200, 2048), (28 * 300, 512), (128 * 300 + 5, 128), (40000, 2048)])
+def test_gemm_ln_fused(a_f32, M, K):
+    d, grp = 512, 28 if M % 28 == 0 else M
+    A = _rand(M, K, seed=50)
+    W = _rand(d, K, seed=51, scale=1 / math.sqrt(K))
+    bias, g, b = _rand(d, seed=52), _rand(d, seed=53), _rand(d, seed=54)
+    res = _rand(M, d, seed=55)
+    pos = _rand(grp, d, seed=56) if grp == 28 else None
+    Ain = A if a_f32 else A.to(torch.bfloat16).contiguous()
+    Wb = W.to(torch.bfloat16).contiguous()
+    ngrp = M // grp
+    out = torch.zeros(ngrp, grp + 9, d, device=DEV)
+    outb = torch.zeros(ngrp, grp + 9, d, device=DEV, dtype=torch.bfloat16)
+    _call("care_gemm_ln", _p(Ain), K, 0 if a_f32 else 1, _p(Wb), _p(bias), _p(res), d, _p(pos), _p(g), _p(b), 1e-12,
+          _p(out), _p(outb), d, M, d, K, grp, grp + 9, 4)
+    y = (_bf(A).double() @ _bf(W).double().t()).float() + bias + res
+    if pos is not None:
+        y = (y.view(ngrp, grp, d) + pos.unsqueeze(0)).view(M, d)
+    ref = torch.nn.functional.layer_norm(y, (d,), g, b, 1e-12).view(ngrp, grp, d)
+    torch.cuda.synchronize()
+    assert (out[:, 4:4 + grp] - ref).abs().max().item() < 4e-3
+    assert out[:, :4].abs().max().item() == 0 and out[:, 4 + grp:].abs().max().item() == 0
+    assert torch.equal(outb, out.to(torch.bfloat16))

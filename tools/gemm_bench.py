@@ -41,12 +41,37 @@ def main():
         bias = torch.randn(N, device=DEV)
         out = torch.empty(M, N, device=DEV)
         p = lambda t: t.data_ptr()
-        t_as = time_call(lambda: _lib.call("care_gemm_bf16", p(A), K, 1, p(W), p(bias), p(out), N, 0, None, 0, 0, N, M, N, K, 0))
+        if K <= 512:
+            t_as = time_call(lambda: _lib.call("care_gemm_bf16", p(A), K, 1, p(W), p(bias), p(out), N, 0, None, 0, 0, N, M, N, K, 0))
+        else:
+            t_as = float("nan")
         t_gen = time_call(lambda: _lib.call("care_gemm", p(Af), K, p(W), 1, p(bias), p(out), N, 0, None, 0, 0, N, M, N, K, 0))
         fl = 2.0 * M * N * K
         print("M=%6d N=%5d K=%4d  A-stationary %7.1f us (%6.1f TF)   generic(fp32 A) %7.1f us (%6.1f TF)" %
               (M, N, K, t_as, fl / t_as / 1e6, t_gen, fl / t_gen / 1e6), flush=True)
 
 
+def ln_main():
+    """care_gemm_ln (fused LayerNorm epilogue) on embedder / decode shapes."""
+    import os
+    print("CARE_LN_RG=%s" % os.environ.get("CARE_LN_RG"))
+    for M, K, f32 in [(458752, 2048, True), (458752, 512, True), (458752, 128, True), (16384, 512, False),
+                      (16384, 2048, False), (4096, 512, False), (4096, 2048, False)]:
+        A = torch.randn(M, K, device=DEV)
+        Ain = A if f32 else A.to(torch.bfloat16)
+        W = (torch.randn(512, K, device=DEV) * 0.05).to(torch.bfloat16)
+        bias, g, b = (torch.randn(512, device=DEV) for _ in range(3))
+        res = torch.randn(M, 512, device=DEV)
+        out = torch.empty(M, 512, device=DEV)
+        outb = torch.empty(M, 512, device=DEV, dtype=torch.bfloat16)
+        p = lambda t: t.data_ptr()
+        t = time_call(lambda: _lib.call("care_gemm_ln", p(Ain), K, 0 if f32 else 1, p(W), p(bias), p(res), 512, None,
+                                        p(g), p(b), 1e-12, p(out), p(outb), 512, M, 512, K, M, M, 0), iters=5)
+        print("gemm_ln M=%6d K=%4d A=%s: %8.1f us (%6.1f TF)" % (M, K, "f32" if f32 else "bf16", t, 2.0 * M * 512 * K / t / 1e6), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "ln":
+        ln_main()
+    else:
+        main()
