@@ -16,9 +16,9 @@
 //     tiles (128 accumulator VGPRs), so every B fragment feeds 4 MFMAs and every A fragment 8;
 //   * waits are counted (vmcnt(N) = the DMA instructions of the one younger stage) with a raw
 //     s_barrier per K step;
-//   * accumulators use the swapped operand order (a lane holds 4 consecutive columns of a row):
-//     row statistics need 2 shuffles + one LDS exchange between the 4 column groups, and every
-//     store is 16 bytes (fp32) / 8 bytes (bf16 mirror).
+//   * epilogue: the accumulators (swapped operand order: a lane holds 4 consecutive columns of a
+//     row) are parked in LDS and finished row-wise, one wave per row, so every residual / bias /
+//     gamma / beta load and both stores are coalesced and the statistics are wave shuffles.
 #include <cstdlib>
 
 #include "care_common.h"
@@ -157,82 +157,89 @@ __global__ __launch_bounds__(256 * RG, RG == 1 ? 1 : 2) void gemm_ln_kernel(LnAr
   }
 
   // ------------------------------------------------------------------ epilogue
-  // acc[mt][nt][j] = C[row m0 + 64 rg + 16 mt + fr][col 128 cg + 16 nt + 4 fg + j]
-  __syncthreads();  // every wave is done with the ring: reuse it for the row statistics
-  float* red = reinterpret_cast<float*>(smem);  // [BM][4] partial sums of the 4 column groups
-  int rows[4];
-  int64_t orow[4];
+  // acc[mt][nt][j] = C[row 64 rg + 16 mt + fr][col 128 cg + 16 nt + 4 fg + j] (block-local row).
+  // The accumulators are parked in LDS (64 rows x 512 fp32 = 128 KiB, one row group at a time,
+  // 16-byte chunk index ^= row & 15 against bank conflicts) and the rest is done ROW-WISE: one wave
+  // per full row, lane l owning columns [4l, 4l+4) and [256+4l, 256+4l+4).  Bias / residual /
+  // position / gamma / beta loads and both stores are then fully coalesced 16-byte accesses and
+  // the LayerNorm statistics are plain wave shuffles (no spills, no partial-line stores).
+  float* tile = reinterpret_cast<float*>(smem);
+  float4 gm[2], bt[2], bs[2];  // row-invariant vectors of this lane's 2 x 4 columns
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    rows[mt] = m0 + rg * 64 + mt * 16 + fr;
-    const int rc = min(rows[mt], p.M - 1);
-    orow[mt] = (int64_t)(rc / p.grp) * p.out_grp_rows + p.out_row_off + (rc % p.grp);
+  for (int h = 0; h < 2; ++h) {
+    const int col = (h * 64 + lane) * 4;
+    gm[h] = *reinterpret_cast<const float4*>(p.gamma + col);
+    bt[h] = *reinterpret_cast<const float4*>(p.beta + col);
+    bs[h] = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+#pragma unroll 1
+  for (int g = 0; g < RG; ++g) {
+    __syncthreads();  // ring (or the previous row group's tile) no longer read by any wave
+    if (rg == g) {
 #pragma unroll
-  for (int nt = 0; nt < 8; ++nt) {
-    const int col = cg * 128 + nt * 16 + fg * 4;
-    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int rc = min(rows[mt], p.M - 1);
-      float4 add = bv;
-      if (p.res) {
-        const float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)rc * p.ldres + col);
-        add.x += r.x; add.y += r.y; add.z += r.z; add.w += r.w;
-      }
-      if (p.pos) {
-        const float4 r = *reinterpret_cast<const float4*>(p.pos + (int64_t)(rc % p.grp) * LN_N + col);
-        add.x += r.x; add.y += r.y; add.z += r.z; add.w += r.w;
-      }
-      acc[mt][nt][0] += add.x; acc[mt][nt][1] += add.y; acc[mt][nt][2] += add.z; acc[mt][nt][3] += add.w;
-    }
-  }
-  float mean[4], rstd[4];
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      float s = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float d = pass == 0 ? acc[mt][nt][j] : acc[mt][nt][j] - mean[mt];
-          s += pass == 0 ? d : d * d;
+        for (int nt = 0; nt < 8; ++nt) {
+          const int row = mt * 16 + fr;
+          const int chunk = (cg * 32 + nt * 4 + fg) ^ fr;
+          *reinterpret_cast<f32x4*>(tile + row * LN_N + chunk * 4) = acc[mt][nt];
         }
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (fg == 0) red[(rg * 64 + mt * 16 + fr) * 4 + cg] = s;
     }
     __syncthreads();
+    // 4 rows per iteration with every load issued before the first use: with one workgroup per
+    // CU nothing else hides the residual-load latency (one row at a time cost ~2 us per row).
+    constexpr int UNR = 4, RPW = 64 / NW;  // rows per wave: 16 (RG = 1) or 8 (RG = 2)
+#pragma unroll 1
+    for (int rb = 0; rb < RPW; rb += UNR) {
+      float4 v[UNR][2], rs[UNR][2], ps[UNR][2];
+      int grow[UNR];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const float4 t = *reinterpret_cast<const float4*>(red + (rg * 64 + mt * 16 + fr) * 4);
-      const float tot = (t.x + t.y) + (t.z + t.w);
-      if (pass == 0) mean[mt] = tot * (1.0f / LN_N);
-      else rstd[mt] = 1.0f / sqrtf(tot * (1.0f / LN_N) + p.eps);
-    }
-    __syncthreads();
-  }
+      for (int u = 0; u < UNR; ++u) {
+        const int r = wave * RPW + rb + u;
+        grow[u] = m0 + g * 64 + r;
+        const int gc = min(grow[u], p.M - 1);
 #pragma unroll
-  for (int nt = 0; nt < 8; ++nt) {
-    const int col = cg * 128 + nt * 16 + fg * 4;
-    const float4 g = *reinterpret_cast<const float4*>(p.gamma + col);
-    const float4 b = *reinterpret_cast<const float4*>(p.beta + col);
+        for (int h = 0; h < 2; ++h) {
+          const int chunk = h * 64 + lane;
+          v[u][h] = *reinterpret_cast<const float4*>(tile + r * LN_N + ((chunk ^ (r & 15)) * 4));
+          if (p.res) rs[u][h] = *reinterpret_cast<const float4*>(p.res + (int64_t)gc * p.ldres + chunk * 4);
+          if (p.pos) ps[u][h] = *reinterpret_cast<const float4*>(p.pos + (int64_t)(gc % p.grp) * LN_N + chunk * 4);
+        }
+      }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      if (rows[mt] >= p.M) continue;
-      float4 o;
-      o.x = (acc[mt][nt][0] - mean[mt]) * rstd[mt] * g.x + b.x;
-      o.y = (acc[mt][nt][1] - mean[mt]) * rstd[mt] * g.y + b.y;
-      o.z = (acc[mt][nt][2] - mean[mt]) * rstd[mt] * g.z + b.z;
-      o.w = (acc[mt][nt][3] - mean[mt]) * rstd[mt] * g.w + b.w;
-      const int64_t off = orow[mt] * p.ldo + col;
-      *reinterpret_cast<float4*>(p.out + off) = o;
-      if (p.outb) {
-        bf16x4 ob;
-        ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
-        *reinterpret_cast<bf16x4*>(p.outb + off) = ob;
+      for (int u = 0; u < UNR; ++u) {
+        if (grow[u] >= p.M) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          v[u][h].x += bs[h].x; v[u][h].y += bs[h].y; v[u][h].z += bs[h].z; v[u][h].w += bs[h].w;
+          if (p.res) { v[u][h].x += rs[u][h].x; v[u][h].y += rs[u][h].y; v[u][h].z += rs[u][h].z; v[u][h].w += rs[u][h].w; }
+          if (p.pos) { v[u][h].x += ps[u][h].x; v[u][h].y += ps[u][h].y; v[u][h].z += ps[u][h].z; v[u][h].w += ps[u][h].w; }
+        }
+        const float s = ((v[u][0].x + v[u][0].y) + (v[u][0].z + v[u][0].w)) + ((v[u][1].x + v[u][1].y) + (v[u][1].z + v[u][1].w));
+        const float mean = care_wave_sum(s) * (1.0f / LN_N);
+        float q = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float a = v[u][h].x - mean, b = v[u][h].y - mean, c = v[u][h].z - mean, e = v[u][h].w - mean;
+          q += (a * a + b * b) + (c * c + e * e);
+        }
+        const float rstd = 1.0f / sqrtf(care_wave_sum(q) * (1.0f / LN_N) + p.eps);
+        const int64_t orow = (int64_t)(grow[u] / p.grp) * p.out_grp_rows + p.out_row_off + (grow[u] % p.grp);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int col = (h * 64 + lane) * 4;
+          float4 o;
+          o.x = (v[u][h].x - mean) * rstd * gm[h].x + bt[h].x;
+          o.y = (v[u][h].y - mean) * rstd * gm[h].y + bt[h].y;
+          o.z = (v[u][h].z - mean) * rstd * gm[h].z + bt[h].z;
+          o.w = (v[u][h].w - mean) * rstd * gm[h].w + bt[h].w;
+          *reinterpret_cast<float4*>(p.out + orow * p.ldo + col) = o;
+          if (p.outb) {
+            bf16x4 ob;
+            ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
+            *reinterpret_cast<bf16x4*>(p.outb + orow * p.ldo + col) = ob;
+          }
+        }
       }
     }
   }
@@ -241,7 +248,8 @@ __global__ __launch_bounds__(256 * RG, RG == 1 ? 1 : 2) void gemm_ln_kernel(LnAr
 template <bool AF32, int RG>
 int launch_ln(const LnArgs& p, hipStream_t st) {
   constexpr int BM = 64 * RG;
-  constexpr size_t lds = 3 * (BM * (AF32 ? 128 : 64) + LN_N * 64);
+  constexpr size_t ring = 3 * (BM * (AF32 ? 128 : 64) + LN_N * 64);
+  constexpr size_t lds = ring > 64 * LN_N * 4 ? ring : 64 * LN_N * 4;  // the epilogue parks 64 x 512 fp32
   const int blocks = (p.M + BM - 1) / BM;
   hipLaunchKernelGGL((gemm_ln_kernel<AF32, RG>), dim3(blocks), dim3(256 * RG), lds, st, p);
   return care_launch_status();
