@@ -78,7 +78,8 @@ def main():
         raise SystemExit("--gpus {} but WORLD_SIZE {} (launch with torch.distributed.run)".format(args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CARE_BENCH_FORCE_DIST") == "1"  # forced: 1-rank RCCL self-test
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     from care_amd import _lib, get_framework
@@ -93,24 +94,28 @@ def main():
     model.set_compute_dtype(args.dtype)
     model.to(dev)
     eng = model.engine()
-    # per-rank inputs: rank r holds clips [r*B, (r+1)*B) of the global batch (weak scaling)
-    feats = [f.to(dev) for f in synth_feats(1000 + rank, feat_shapes(opt, B))]
+    # per-rank inputs: rank r holds clips [r*B, (r+1)*B) of the global batch (weak scaling).
+    # Unit-variance features generated ON the device (seeded per rank); the portable CPU generator
+    # (care_amd.synth) would spend a minute producing 1.2 G values for B = 16384.
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    feats = [torch.randn(shape, generator=gen, device=dev, dtype=torch.float32) for shape in feat_shapes(opt, B)]
     torch.cuda.synchronize()
 
     from care_amd.sharding import all_gather_records, pack_records
 
     gathered = None
-    if world > 1:
+    if use_dist:
         gathered = [torch.empty(B, eng.T + 4, device=dev, dtype=torch.int32) for _ in range(world)]
 
     def step():
         _, fed, length, score = eng.translate_greedy(feats, use_graph=not args.no_graph)
-        if world > 1:  # metrics-step exchange over RCCL: every rank gets every caption
+        if use_dist:  # metrics-step exchange over RCCL: every rank gets every caption
             all_gather_records(pack_records(fed, length, score, B), gathered)
         return fed, length, score
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -122,7 +127,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -130,7 +135,7 @@ def main():
     value = world * B * args.steps / elapsed
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -186,7 +191,7 @@ def main():
 
     # ---- CPU baseline: the oracle (reference algorithm as written) on the host cores
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # contract: rank 0 at N=1 only
         from oracle import care_cpu  # timed baseline only (never on the product path)
 
         cb = args.cpu_batch
@@ -222,7 +227,7 @@ def main():
         pass_tflops=round(total_fl * value / 1e12, 2),
         roofline=roofline, kernels=per_kernel, cpu_baseline=cpu)
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -168,7 +168,11 @@ template <typename KT>
 int launch_attention(const AttnArgs& p, hipStream_t st) {
   const int items = p.rows * p.heads;
   const dim3 grid((items + 3) / 4), block(256);
-  if (p.nkeys <= 32) hipLaunchKernelGGL((attention_kernel<KT, 4>), grid, block, 0, st, p);
+  // key-block count specialised to the prefix length: a step-1 self-attention loads 8 key slots, not 32
+  if (p.nkeys <= 8) hipLaunchKernelGGL((attention_kernel<KT, 1>), grid, block, 0, st, p);
+  else if (p.nkeys <= 16) hipLaunchKernelGGL((attention_kernel<KT, 2>), grid, block, 0, st, p);
+  else if (p.nkeys <= 24) hipLaunchKernelGGL((attention_kernel<KT, 3>), grid, block, 0, st, p);
+  else if (p.nkeys <= 32) hipLaunchKernelGGL((attention_kernel<KT, 4>), grid, block, 0, st, p);
   else if (p.nkeys <= 88) hipLaunchKernelGGL((attention_kernel<KT, 11>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((attention_kernel<KT, 16>), grid, block, 0, st, p);
   return care_launch_status();

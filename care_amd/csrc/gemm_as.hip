@@ -354,10 +354,14 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int i = mt * 4 + j;
+          // online (max, sum-exp) with ONE exp per logit: e = exp(-|m - v|) is the rescale factor
+          // when v is the new max and the new term otherwise
           const float v0 = c0 < p.N ? acc[mt][j] : -INFINITY;
-          const float mn = fmaxf(rm[i], v0);
-          rs[i] = rs[i] * __expf(rm[i] - mn) + __expf(v0 - mn);
-          ri[i] = v0 > rm[i] ? c0 : ri[i];
+          const bool up = v0 > rm[i];
+          const float mn = up ? v0 : rm[i];
+          const float e = __expf((up ? rm[i] : v0) - mn);
+          rs[i] = up ? fmaf(rs[i], e, 1.0f) : rs[i] + e;
+          ri[i] = up ? c0 : ri[i];
           rm[i] = mn;
           rl[i] = c0 == lab[i] ? v0 : rl[i];
         }

@@ -49,7 +49,7 @@ def unpack_records(rec: torch.Tensor):
 
 def all_gather_records(rec: torch.Tensor, out: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
     """All-gather equal-size record blocks; returns the [world * per, cols] concatenation."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return rec
     world = dist.get_world_size()
     if out is None:

@@ -176,3 +176,22 @@ def test_metrics_step_gpu(golden, dtype):
         c = concept_metrics(enc["preds_attr"], torch.from_numpy(z["labels_attr"]))
         got = [c["F1-%02d" % k] for k in (5, 10, 20, 30, 40, 50)] + [c["mAP"]]
         np.testing.assert_allclose(got, z["metrics_attr"], rtol=1e-4, atol=1e-6)
+
+
+def test_bench_under_torchrun_with_rccl():
+    """bench.py launched the way the driver launches it (torch.distributed.run, nccl = RCCL):
+    one rank on the one GPU of this box, the process group and the all-gather forced on."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CARE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "2", "--batch", "256", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
