@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--config", default="msrvtt_base_ami")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--beam", type=int, default=1, help="beam size > 1: time the beam-search pass instead (extra, "
+                    "not the BASELINE metric; no roofline/cpu legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--cpu-threads", type=int, default=16,
@@ -107,6 +109,21 @@ def main():
     gathered = None
     if use_dist:
         gathered = [torch.empty(B, eng.T + 4, device=dev, dtype=torch.int32) for _ in range(world)]
+
+    if args.beam > 1:
+        for _ in range(3):
+            eng.translate_beam(feats, args.beam, args.beam, use_graph=not args.no_graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.translate_beam(feats, args.beam, args.beam, use_graph=not args.no_graph)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        print(json.dumps(dict(metric="captions/sec (beam %d)" % args.beam, value=round(B / dt, 1), unit="captions/s",
+                              n_gpus=1, steps=args.steps, ms_per_step=round(dt * 1e3, 3), dtype=args.dtype,
+                              config=dict(config_name=args.config, clips_per_gpu_per_step=B, beam_size=args.beam,
+                                          rows_per_decoder_step=B * args.beam))), flush=True)
+        return
 
     def step():
         _, fed, length, score = eng.translate_greedy(feats, use_graph=not args.no_graph)

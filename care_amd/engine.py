@@ -15,6 +15,7 @@ Compared with the reference the engine
 These are numerically equivalent re-orderings of the same math (decoder is causal and
 post-LN, eval-mode dropout is identity).
 """
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -363,8 +364,9 @@ class HipEngine:
                                                               torch.empty(B, d, device=self.device))
                 else:
                     out["semantic_hidden_states"] = None
-        # bf16 mirror of the memory: the A operand of the cross-K/V projection (internal)
-        self._mem_mirror = (mem.data_ptr(), memb)
+        # bf16 mirror of the memory: the A operand of the cross-K/V projection (internal).  Matched by
+        # tensor IDENTITY (weakref), not by address: another tensor may later live at the same address.
+        self._mem_mirror = (weakref.ref(mem), memb)
         return out
 
     # ------------------------------------------------------------------ cross K/V (once per clip)
@@ -376,8 +378,8 @@ class HipEngine:
         """
         B, Lk, d = mem.shape
         mem = mem.contiguous()
-        mirror = getattr(self, "_mem_mirror", (None, None))
-        src = mirror[1] if (self.as_ok and mirror[0] == mem.data_ptr() and mirror[1] is not None) else mem
+        ref, memb = getattr(self, "_mem_mirror", (None, None))
+        src = memb if (self.as_ok and memb is not None and ref is not None and ref() is mem) else mem
         src2 = src.view(B * Lk, d)
         out = []
         for li in range(self.n_layers):
@@ -619,6 +621,36 @@ class HipEngine:
         graph.replay()
         return out
 
+    def translate_beam(self, feats: List[torch.Tensor], bm: int, need: int, use_graph: bool = True):
+        """encode + beam search of one batch, replayed from a hipGraph when the input buffers repeat
+        (same policy as translate_greedy).  Returns (enc_outputs, nfin, fscore, flen, fhyp)."""
+        feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+
+        def run():
+            enc = self.encode(feats)
+            return (enc,) + tuple(self.beam(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need,
+                                            sem_embs=enc.get("semantic_embs")))
+
+        if not use_graph:
+            return run()
+        key = ("beam", bm, need, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        entry = self._graphs.get(key)
+        if entry is None:
+            self._graphs[key] = "seen"
+            return run()
+        if entry == "seen":
+            if len(self._graphs) > 8:
+                self._graphs = {k: v for k, v in self._graphs.items() if k == key}
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = run()
+            entry = (graph, out)
+            self._graphs[key] = entry
+        graph, out = entry
+        graph.replay()
+        return out
+
     def beam(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int,
              sem_embs: Optional[torch.Tensor] = None):
         """Beam search of B clips x bm beams, state on the device (csrc/beam.hip)."""
@@ -641,7 +673,8 @@ class HipEngine:
         fhyp = self.ws("b_fhyp", (B, cap, T + 1), torch.int32); fhyp.zero_()
         cval = self.ws("b_cval", (N, bm))
         cidx = self.ws("b_cidx", (N, bm), torch.int32)
-        logits = self.ws("b_logits", (N, self.V))
+        vpad = (self.V + 63) // 64 * 64  # 16-byte aligned row stride -> the GEMM's vector store path
+        logits = self.ws("b_logits", (N, vpad))[:, : self.V]
         ckv = self.cross_kv(mem)
         akv = self.attr_kv(sem_embs) if self.attr_att else None
         skv = [self.ws("b_skv%d" % li, (N, T, 2 * d), self.wt) for li in range(self.n_layers)]
@@ -649,7 +682,7 @@ class HipEngine:
             a_old, a_new = anc[(t - 1) & 1], anc[t & 1]
             x, xb = self._decode_step(t, N, bm, tok, a_old, sem, ckv, skv, Lk, "b_", akv=akv)
             self.gemm(xb if xb is not None else x, self.w["vocab"], None, logits)
-            call("care_beam_select", ptr(logits), self.V, self.V, bm, ptr(cval), ptr(cidx), N)
+            call("care_beam_select", ptr(logits), logits.stride(0), self.V, bm, ptr(cval), ptr(cidx), N)
             call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
                  ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
         return nfin, fscore, flen, fhyp

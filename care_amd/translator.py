@@ -48,10 +48,7 @@ class Translator_ARFormer(object):
                 raise ValueError("translator max_len {} != model max_len {}".format(self.max_len, engine.T + 1))
             if self.beam_size == 1:
                 return self._greedy(engine, feats, kwargs.get("use_graph", True))
-            enc = model.encoding_phase(feats)
-            inputs = model.prepare_inputs_for_decoder(enc, batch)
-            return self._beam(engine, inputs["encoder_hidden_states"], inputs.get("semantic_hidden_states"),
-                              inputs.get("semantic_embs"))
+            return self._beam(engine, feats, kwargs.get("use_graph", True))
 
     def _greedy(self, engine, feats, use_graph):
         _, fed, length, score = engine.translate_greedy(list(feats), use_graph=use_graph)
@@ -64,11 +61,11 @@ class Translator_ARFormer(object):
             scores.append([score[i].item() / (n ** self.beam_alpha)][:n_best])
         return hyps, scores
 
-    def _beam(self, engine, mem, sem, sem_embs=None):
+    def _beam(self, engine, feats, use_graph=True):
         if self.topk > self.beam_size:
             raise ValueError("topk > beam_size is not supported")
         need = max(self.beam_size, self.topk)
-        nfin, fscore, flen, fhyp = engine.beam(mem, sem, self.beam_size, need, sem_embs=sem_embs)
+        _, nfin, fscore, flen, fhyp = engine.translate_beam(list(feats), self.beam_size, need, use_graph=use_graph)
         nfin, fscore, flen, fhyp = nfin.cpu().tolist(), fscore.cpu(), flen.cpu(), fhyp.cpu()
         hyps, scores = [], []
         n_best = self.topk

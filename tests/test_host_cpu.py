@@ -135,7 +135,7 @@ def test_translator_result_assembly_matches_reference_quirks():
     class FakeEngine:
         T = 29
 
-        def beam(self, mem, sem, bm, need, sem_embs=None):
+        def translate_beam(self, feats, bm, need, use_graph=True):
             nfin = torch.tensor([5, 1, 5], dtype=torch.int32)
             fscore = torch.tensor([[-4.0, -2.0, -9.0, -8.0, -7.0, 0, 0, 0, 0, 0],
                                    [-3.0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
@@ -143,9 +143,9 @@ def test_translator_result_assembly_matches_reference_quirks():
             flen = torch.tensor([[2, 2, 3, 4, 7, 0, 0, 0, 0, 0], [3, 0, 0, 0, 0, 0, 0, 0, 0, 0],
                                  [1, 1, 1, 1, 1, 0, 0, 0, 0, 0]], dtype=torch.int32)
             fhyp = torch.arange(3 * 10 * 30, dtype=torch.int32).view(3, 10, 30)
-            return nfin, fscore, flen, fhyp
+            return None, nfin, fscore, flen, fhyp
 
-    hyps, scores = tr._beam(FakeEngine(), None, None)
+    hyps, scores = tr._beam(FakeEngine(), [])
     assert [len(h) for h in hyps] == [3, 1, 1]          # clip 1 has one hypothesis -> clip 2 is cut to one
     assert scores[0] == [-1.0, -1.0, -2.0]              # -2/2, -7/7 (stable order), -4/2
     assert hyps[0][0] == [30, 31] and hyps[0][1] == list(range(120, 127))
