@@ -1,0 +1,94 @@
+"""GPU: size-independent properties of the HIP path at batch sizes the CPU oracle cannot reach.
+
+* batch-composition invariance: a clip's caption does not depend on what else is in the batch
+  (rows are independent end to end) - big batch vs the same clips in small chunks;
+* two implementations, one answer: beam search with beam_size = 1 through the beam kernels
+  (full logits + beam_select + beam_advance + ancestor tables) equals the fused greedy path;
+* hipGraph replay equals the eager launch sequence; repeated runs are bit-identical;
+* a sample of the big batch is checked against the CPU oracle.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(config, B, dtype, seed=77, boost=None):
+    from care_amd import get_framework
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_state_dict
+
+    opt = make_opt(config)
+    model = get_framework(opt).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    P = synth_state_dict(seed, shapes, row_scale=boost or {})
+    model.load_state_dict(P, strict=True)
+    model.set_compute_dtype(dtype)
+    model.to("cuda:0")
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(seed)
+    feats = [torch.randn(s, generator=gen, device="cuda:0") for s in feat_shapes(opt, B)]
+    return opt, P, model, feats
+
+
+def _greedy(model, feats, use_graph=False):
+    _, fed, length, score = model.engine().translate_greedy(feats, use_graph=use_graph)
+    return fed.clone(), length.clone(), score.clone()
+
+
+@pytest.mark.parametrize("config,dtype,B", [("msrvtt_base_ami", "fp32", 512), ("msrvtt_base_ami", "bf16", 2048),
+                                            ("msrvtt_care", "fp32", 256), ("msrvtt_care", "bf16", 1024)])
+def test_batch_composition_invariance_and_determinism(config, dtype, B):
+    boost = {"cls_head.tgt_word_prj.weight": {3: 4.0, 0: 3.0}}  # early EOS and generated PADs
+    opt, P, model, feats = _setup(config, B, dtype, boost=boost)
+    fed, length, score = _greedy(model, feats)
+    fed2, length2, score2 = _greedy(model, feats)
+    assert torch.equal(fed, fed2) and torch.equal(length, length2) and torch.equal(score, score2)
+    assert 1 < int(length.min()) + 1 and int(length.max()) <= 29 and len(set(length.tolist())) > 3
+    chunk = 64
+    for lo in range(0, B, B // 4):  # four chunks spread over the batch
+        sub = [f[lo:lo + chunk].contiguous() for f in feats]
+        f_s, l_s, s_s = _greedy(model, sub)
+        n = l_s.shape[0]
+        assert torch.equal(l_s, length[lo:lo + n])
+        for i in range(n):
+            k = int(l_s[i]) + 1
+            assert torch.equal(f_s[i, :k], fed[lo + i, :k])
+        tol = 1e-4 if dtype == "fp32" else 2e-2
+        assert (s_s - score[lo:lo + n]).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("config,dtype", [("msrvtt_base_ami", "fp32"), ("msrvtt_care", "fp32"), ("msrvtt_base_ami", "bf16")])
+def test_beam_size_one_equals_greedy(config, dtype):
+    boost = {"cls_head.tgt_word_prj.weight": {3: 4.0}}
+    opt, P, model, feats = _setup(config, 384, dtype, boost=boost)
+    fed, length, score = _greedy(model, feats)
+    eng = model.engine()
+    _, nfin, fscore, flen, fhyp = eng.translate_beam(feats, 1, 1, use_graph=False)
+    assert torch.all(nfin == 1)
+    assert torch.equal(flen[:, 0], length)
+    for i in range(384):
+        n = int(length[i])
+        assert torch.equal(fhyp[i, 0, :n], fed[i, 1:n + 1])
+    assert (fscore[:, 0] - score).abs().max().item() < (1e-4 if dtype == "fp32" else 5e-3)
+
+
+def test_graph_replay_equals_eager_and_oracle_sample():
+    from oracle import care_cpu
+
+    opt, P, model, feats = _setup("msrvtt_base_ami", 1024, "fp32")
+    eager = _greedy(model, feats)
+    _greedy(model, feats, use_graph=True)          # first sight of these buffers: eager + bookkeeping
+    replay1 = _greedy(model, feats, use_graph=True)  # captured here
+    replay2 = _greedy(model, feats, use_graph=True)  # replayed
+    for a, b in zip(eager, replay1):
+        assert torch.equal(a, b)
+    for a, b in zip(eager, replay2):
+        assert torch.equal(a, b)
+    idx = [0, 17, 511, 1023]
+    sample = [f[idx].cpu() for f in feats]
+    hyps, scores = care_cpu.translate_batch(P, opt, sample)
+    for j, i in enumerate(idx):
+        n = int(eager[1][i])
+        assert eager[0][i, 1:n + 1].tolist() == hyps[j][0]
+        assert abs(float(eager[2][i]) / n - scores[j][0]) < 1e-4
