@@ -414,11 +414,14 @@ int as_check(const void* A, int64_t lda, int a_dtype, const void* W, int M, int 
 }
 
 // Number of column ranges per panel.  Every extra range re-loads the panel's A fragments (the
-// expensive, fragment-shaped loads), so with >= 512 panels there is no N split at all; otherwise
-// a multiple of 8 (one share per XCD) giving ~2 workgroups per CU.
+// expensive, fragment-shaped loads), so the split is the SMALLEST that gives 512 work items
+// (2 workgroups per CU): 1, 2 or 4 (panel-major mapping only) when the panels alone nearly fill
+// the chip, otherwise a multiple of 8 (one share per XCD).  Measured at M = 16384 (128 panels):
+// ns = 4 beats ns = 8 by 10-19% on N = 512 / 1536 / 2048.
 int pick_ns(int panels, int tiles_total) {
   if (const char* e = getenv("CARE_AS_NS")) return atoi(e);  // tuning override (tools/gemm_bench.py)
-  if (panels >= 512) return 1;
+  for (int ns = 1; ns <= 4; ns *= 2)
+    if ((long)panels * ns >= 512 && ns <= tiles_total) return ns;
   int ns = 8;
   while (ns < tiles_total && (long)panels * ns < 512) ns += 8;
   return ns;

@@ -169,7 +169,7 @@ class HipEngine:
     # ------------------------------------------------------------------ helpers
     def ws(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         """Named, cached workspace (allocated on first use, reused afterwards)."""
-        key = (name, tuple(shape), dtype)
+        key = (getattr(self, "_lane", 0), name, tuple(shape), dtype)
         t = self._ws.get(key)
         if t is None:
             t = torch.empty(shape, device=self.device, dtype=dtype)
@@ -594,6 +594,10 @@ class HipEngine:
         Returns (enc_outputs, fed, length, score) - static tensors when replayed.
         """
         feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        import os as _os
+        lanes = int(_os.environ.get("CARE_LANES", "1"))
+        if lanes > 1 and use_graph:
+            return self._translate_greedy_lanes(feats, lanes)
         if not use_graph:
             enc = self.encode(feats)
             return (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
@@ -615,6 +619,46 @@ class HipEngine:
                 enc = self.encode(feats)
                 out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
                                                  sem_embs=enc.get("semantic_embs")))
+            entry = (graph, out)
+            self._graphs[key] = entry
+        graph, out = entry
+        graph.replay()
+        return out
+
+    def _translate_greedy_lanes(self, feats, lanes):
+        """EXPERIMENT: the batch split over `lanes` streams inside one graph."""
+        B = feats[0].shape[0]
+        bounds = [(B * i // lanes, B * (i + 1) // lanes) for i in range(lanes)]
+        if not hasattr(self, "_lane_streams"):
+            self._lane_streams = [torch.cuda.Stream() for _ in range(lanes)]
+
+        def run():
+            cur = torch.cuda.current_stream()
+            outs = []
+            for i, (lo, hi) in enumerate(bounds):
+                s = self._lane_streams[i]
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    self._lane = i + 1
+                    sub = [f[lo:hi] for f in feats]
+                    enc = self.encode(sub)
+                    outs.append((enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
+                                                           sem_embs=enc.get("semantic_embs"))))
+            self._lane = 0
+            for s in self._lane_streams:
+                cur.wait_stream(s)
+            return (outs[0][0],) + tuple(torch.cat([o[k] for o in outs], 0) for k in (1, 2, 3))
+
+        key = ("greedy_lanes", lanes, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        entry = self._graphs.get(key)
+        if entry is None:
+            self._graphs[key] = "seen"
+            return run()
+        if entry == "seen":
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = run()
             entry = (graph, out)
             self._graphs[key] = entry
         graph, out = entry
