@@ -12,8 +12,9 @@
 //     xor shuffles across the 8 key slots (8,16,32) - no LDS at all.
 //   * P.V: each lane accumulates its 8 dims over its key slot, 3 xor-shuffles merge the 8
 //     slots, lanes 0-7 store 256 contiguous bytes of context.
-//   * NKB (key blocks of 8) is a template parameter so ALL K and V loads of a wave are issued
-//     back to back (up to 32 KiB in flight per wave) before the first use.
+//   * NKB (key blocks of 8) is a template parameter: the key loop is fully unrolled, K and V loads
+//     are issued ahead of the arithmetic, and no load inside the loop forces a vmcnt(0) drain
+//     (the mask / bias values are fetched first, see EXTRA below).
 // Masking follows the reference exactly: masked keys get -1e9 (not -inf), the hybrid bias
 // is added AFTER the mask (models/components/Attention.py:104-111).
 #include <type_traits>
@@ -35,7 +36,12 @@ struct AttnArgs {
   int rows, heads;
 };
 
-template <typename KT, int NKB>
+// EXTRA = the launch has a key-padding mask and/or an additive bias.  Their per-key values are
+// fetched BEFORE the K/V loads (vmcnt retires in order, so a load issued inside the score loop
+// would wait for every K/V byte and then cost one memory round trip per key block): lane
+// (slot, chunk) fetches the values of key blocks `chunk` and `chunk + 8` of its slot, and the score
+// loop pulls them across the 8 chunk lanes with one shuffle each.
+template <typename KT, int NKB, bool ANC, bool EXTRA>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -46,6 +52,24 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
   int nk = p.nkeys;
   if (p.causal) nk = min(nk, (r % p.seq) + 1 + p.causal_off);
   const int kvb_default = r / p.rows_per_kv;
+
+  constexpr int NX = NKB > 8 ? 2 : 1;
+  float xbias[NX];
+  int xpad[NX];
+  if constexpr (EXTRA) {
+#pragma unroll
+    for (int x = 0; x < NX; ++x) {
+      const int j = (x * 8 + chunk) * 8 + slot;
+      const int jc = j < nk ? j : 0;
+      xbias[x] = p.bias ? p.bias[h * p.bias_ld + jc] : 0.f;
+      int tok = p.pad_id + 1;
+      if (p.pad_tok) {
+        const int kvb = ANC ? p.anc[(int64_t)r * p.anc_stride + jc] : kvb_default;
+        tok = p.pad_tok[(int64_t)kvb * p.pad_stride + jc];
+      }
+      xpad[x] = tok == p.pad_id;
+    }
+  }
 
   float q[8];
   care_load8(p.Q + (int64_t)r * p.ldq + h * 64 + chunk * 8, q);
@@ -59,29 +83,40 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
   using Frag = typename std::conditional<sizeof(KT) == 2, bf16x8, float4>::type;
   constexpr int FPK = sizeof(KT) == 2 ? 1 : 2;  // 16-byte pieces per 8 elements
   Frag kf[NKB][FPK], vf[NKB][FPK];
-  bool valid[NKB];
-  int kvbs[NKB];
+  // ANC (beam search): key j of row r lives in the cache row anc[r][j]; otherwise every key of
+  // the row comes from one K/V block and no per-key index is kept in registers
+  int kvbs[ANC ? NKB : 1];
+  if constexpr (ANC) {
 #pragma unroll
-  for (int kb = 0; kb < NKB; ++kb) {
-    const int j = kb * 8 + slot;
-    valid[kb] = j < nk;
-    const int jj = valid[kb] ? j : 0;
-    kvbs[kb] = p.anc ? p.anc[(int64_t)r * p.anc_stride + jj] : kvb_default;
+    for (int kb = 0; kb < NKB; ++kb) {
+      const int j = kb * 8 + slot;
+      kvbs[kb] = p.anc[(int64_t)r * p.anc_stride + (j < nk ? j : 0)];
+    }
+  } else {
+    kvbs[0] = kvb_default;
   }
+  auto kv_off = [&](int kb) {
+    const int j = kb * 8 + slot;
+    return (int64_t)kvbs[ANC ? kb : 0] * p.kv_batch_stride + (int64_t)(j < nk ? j : 0) * p.kv_row_stride;
+  };
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
-    const int jj = valid[kb] ? kb * 8 + slot : 0;
-    const int64_t off = (int64_t)kvbs[kb] * p.kv_batch_stride + (int64_t)jj * p.kv_row_stride;
+    const int64_t off = kv_off(kb);
 #pragma unroll
     for (int f = 0; f < FPK; ++f) kf[kb][f] = *reinterpret_cast<const Frag*>(Kb + off + f * 4);
   }
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
-    const int jj = valid[kb] ? kb * 8 + slot : 0;
-    const int64_t off = (int64_t)kvbs[kb] * p.kv_batch_stride + (int64_t)jj * p.kv_row_stride;
+    const int64_t off = kv_off(kb);
 #pragma unroll
     for (int f = 0; f < FPK; ++f) vf[kb][f] = *reinterpret_cast<const Frag*>(Vb + off + f * 4);
   }
+#ifdef CARE_ATT_PIN
+  // Ablation: pin every load above this line (all K/V bytes of the wave in flight at once, ~40 more
+  // VGPRs, one wave per SIMD fewer).  Measured SLOWER than letting the scheduler sink some loads
+  // towards their use: Lk = 114 bf16 677 us vs 649 us per launch at 16384 rows (same box).
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   auto unpack = [](const Frag (&fr)[FPK], float (&o)[8]) {
     if constexpr (sizeof(KT) == 2) {
 #pragma unroll
@@ -106,13 +141,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     d += __shfl_xor(d, 2, 64);
     d += __shfl_xor(d, 4, 64);
     d *= 0.125f;  // 1/sqrt(64), exact
-    if (valid[kb]) {
-      if (p.pad_tok && p.pad_tok[(int64_t)kvbs[kb] * p.pad_stride + j] == p.pad_id) d = -1e9f;
-      if (p.bias) d += p.bias[h * p.bias_ld + j];
-    } else {
-      d = -INFINITY;
+    if constexpr (EXTRA) {
+      const int src = (lane & 56) | (kb & 7);
+      const int padded = __shfl(xpad[kb >> 3], src, 64);
+      const float bj = __shfl(xbias[kb >> 3], src, 64);
+      if (padded) d = -1e9f;  // masked_fill(-1e9) first, the hybrid bias is added after it
+      d += bj;
     }
-    s[kb] = d;
+    s[kb] = j < nk ? d : -INFINITY;
   }
 
   // ---- softmax over all keys (each score is replicated on the 8 chunk lanes of its slot)
@@ -169,12 +205,27 @@ int launch_attention(const AttnArgs& p, hipStream_t st) {
   const int items = p.rows * p.heads;
   const dim3 grid((items + 3) / 4), block(256);
   // key-block count specialised to the prefix length: a step-1 self-attention loads 8 key slots, not 32
-  if (p.nkeys <= 8) hipLaunchKernelGGL((attention_kernel<KT, 1>), grid, block, 0, st, p);
-  else if (p.nkeys <= 16) hipLaunchKernelGGL((attention_kernel<KT, 2>), grid, block, 0, st, p);
-  else if (p.nkeys <= 24) hipLaunchKernelGGL((attention_kernel<KT, 3>), grid, block, 0, st, p);
-  else if (p.nkeys <= 32) hipLaunchKernelGGL((attention_kernel<KT, 4>), grid, block, 0, st, p);
-  else if (p.nkeys <= 88) hipLaunchKernelGGL((attention_kernel<KT, 11>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((attention_kernel<KT, 16>), grid, block, 0, st, p);
+  const bool extra = p.pad_tok || p.bias;
+#define CARE_ATT_LAUNCH2(NKB, ANC)                                                               \
+  do {                                                                                            \
+    if (extra) hipLaunchKernelGGL((attention_kernel<KT, NKB, ANC, true>), grid, block, 0, st, p); \
+    else hipLaunchKernelGGL((attention_kernel<KT, NKB, ANC, false>), grid, block, 0, st, p);      \
+  } while (0)
+#define CARE_ATT_LAUNCH(NKB)            \
+  do {                                  \
+    if (p.anc) CARE_ATT_LAUNCH2(NKB, true); \
+    else CARE_ATT_LAUNCH2(NKB, false);  \
+  } while (0)
+  if (p.nkeys <= 8) CARE_ATT_LAUNCH(1);
+  else if (p.nkeys <= 16) CARE_ATT_LAUNCH(2);
+  else if (p.nkeys <= 24) CARE_ATT_LAUNCH(3);
+  else if (p.nkeys <= 32) CARE_ATT_LAUNCH(4);
+  else if (p.nkeys <= 88) CARE_ATT_LAUNCH(11);
+  else if (p.nkeys <= 104) CARE_ATT_LAUNCH(13);
+  else if (p.nkeys <= 120) CARE_ATT_LAUNCH(15);
+  else CARE_ATT_LAUNCH(16);
+#undef CARE_ATT_LAUNCH
+#undef CARE_ATT_LAUNCH2
   return care_launch_status();
 }
 
