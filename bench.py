@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--beam", type=int, default=1, help="beam size > 1: time the beam-search pass instead (extra, "
                     "not the BASELINE metric; no roofline/cpu legs)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="batch lanes on separate HIP streams inside the captured graph (engine.lanes_for): 2 gives "
+                         "+5-8%% at B >= 4096; the default 1 keeps every kernel alone on the chip so that the "
+                         "per-kernel roofline and profiles/ describe the timed pass exactly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--cpu-threads", type=int, default=16,
@@ -96,6 +100,7 @@ def main():
     model.set_compute_dtype(args.dtype)
     model.to(dev)
     eng = model.engine()
+    eng.lanes = args.lanes
     # per-rank inputs: rank r holds clips [r*B, (r+1)*B) of the global batch (weak scaling).
     # Unit-variance features generated ON the device (seeded per rank); the portable CPU generator
     # (care_amd.synth) would spend a minute producing 1.2 G values for B = 16384.
@@ -234,7 +239,7 @@ def main():
         config=dict(workload="MSRVTT Transformer/base task=Base feats=ViT modality=ami greedy "
                              "(BASELINE.json configs[1]): [B,28,128]+[B,28,2048]+[B,28,512] fp32 feats, d=512, "
                              "V=10547, 29 decoder steps" if args.config == "msrvtt_base_ami" else args.config,
-                    config_name=args.config, clips_per_gpu_per_step=B, global_batch=B * world,
+                    config_name=args.config, clips_per_gpu_per_step=B, global_batch=B * world, lanes=args.lanes,
                     parallelism="batch-sharded dp{} (no data-path collective; all-gather of results)".format(world),
                     hip_graph=not args.no_graph),
         decoder_step_us=round(ms_per_step * 1e3 * (1 - (kernels.get("enc_gemm", {"total_ms": 0})["total_ms"] +

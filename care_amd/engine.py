@@ -15,6 +15,7 @@ Compared with the reference the engine
 These are numerically equivalent re-orderings of the same math (decoder is causal and
 post-LN, eval-mode dropout is identity).
 """
+import os
 import weakref
 from typing import Dict, List, Optional
 
@@ -27,6 +28,40 @@ from .constants import BOS, EOS, PAD
 
 def _code(t: Optional[torch.Tensor]) -> int:
     return CARE_BF16 if (t is not None and t.dtype == torch.bfloat16) else CARE_F32
+
+
+class _LaneOutputs(dict):
+    """Encoder outputs of a pass that ran as several batch lanes.  Every value is per clip (first
+    dim = clips of the lane), so the full-batch tensor is the concatenation of the lanes'; it is
+    built on access only - the captioning loop never reads these (translator.py), and
+    `encoder_hidden_states` alone is 2.9 GB at B = 16384."""
+
+    def __init__(self, parts):
+        super().__init__((k, None) for k in parts[0])
+        self._parts = parts
+
+    @staticmethod
+    def _join(vals):
+        if vals[0] is None:
+            return None
+        if isinstance(vals[0], (list, tuple)):
+            return [torch.cat([v[i] for v in vals], 0) for i in range(len(vals[0]))]
+        return torch.cat(vals, 0)
+
+    def __getitem__(self, k):
+        super().__getitem__(k)  # KeyError for unknown names
+        # joined on EVERY access: the lanes' tensors are static graph outputs that the next replay
+        # overwrites, so a cached concatenation would go stale
+        return self._join([pt[k] for pt in self._parts])
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self]
+
+    def values(self):
+        return [self[k] for k in self]
 
 
 class HipEngine:
@@ -72,6 +107,8 @@ class HipEngine:
         self.device = None
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, object] = {}
+        self._lane = 0
+        self.lanes = 1  # batch lanes of a graph-replayed greedy pass (lanes_for)
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, sd: Dict[str, torch.Tensor], device) -> None:
@@ -168,8 +205,9 @@ class HipEngine:
 
     # ------------------------------------------------------------------ helpers
     def ws(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
-        """Named, cached workspace (allocated on first use, reused afterwards)."""
-        key = (getattr(self, "_lane", 0), name, tuple(shape), dtype)
+        """Named, cached workspace (allocated on first use, reused afterwards); one namespace per
+        batch lane (lanes_for), so concurrent lanes never share a buffer."""
+        key = (self._lane, name, tuple(shape), dtype)
         t = self._ws.get(key)
         if t is None:
             t = torch.empty(shape, device=self.device, dtype=dtype)
@@ -594,9 +632,8 @@ class HipEngine:
         Returns (enc_outputs, fed, length, score) - static tensors when replayed.
         """
         feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
-        import os as _os
-        lanes = int(_os.environ.get("CARE_LANES", "1"))
-        if lanes > 1 and use_graph:
+        lanes = self.lanes_for(feats[0].shape[0]) if use_graph else 1
+        if lanes > 1:
             return self._translate_greedy_lanes(feats, lanes)
         if not use_graph:
             enc = self.encode(feats)
@@ -625,36 +662,61 @@ class HipEngine:
         graph.replay()
         return out
 
+    def lanes_for(self, B: int) -> int:
+        """Batch lanes of a graph-replayed greedy pass.
+
+        A pass alternates HBM-bound kernels (attention, 44% of the time at B = 16384) with
+        MFMA-bound ones (the GEMMs); two half-batches on two HIP streams inside the one captured
+        graph let the one kind fill the other's idle unit and hide every kernel's tail.  Measured
+        (bf16 Base `ami`, one MI355X): +8% at B = 4096, +5% at 8192/16384; at B <= 2048 the
+        kernels are too short and the extra graph edges cost more than they hide (-3%..-30%), and
+        4 lanes are never better than 2.
+
+        A tuning knob, OFF by default (`self.lanes` = 1; `CARE_LANES` or `engine.lanes = 2` turn it
+        on): with two lanes the kernels share the chip, so per-kernel durations - and with them the
+        roofline accounting of bench.py and profiles/ - no longer describe a kernel on its own.
+        """
+        env = os.environ.get("CARE_LANES")
+        n = int(env) if env else int(self.lanes)
+        return max(1, min(n, B))
+
     def _translate_greedy_lanes(self, feats, lanes):
-        """EXPERIMENT: the batch split over `lanes` streams inside one graph."""
+        """translate_greedy with the batch cut into `lanes` contiguous clip ranges, each with its own
+        workspaces and HIP stream, forked from and joined to the capture stream inside ONE hipGraph.
+        Clips are independent, so the results are those of the single-lane pass."""
         B = feats[0].shape[0]
         bounds = [(B * i // lanes, B * (i + 1) // lanes) for i in range(lanes)]
-        if not hasattr(self, "_lane_streams"):
-            self._lane_streams = [torch.cuda.Stream() for _ in range(lanes)]
+        if len(getattr(self, "_lane_streams", ())) < lanes:
+            self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
 
         def run():
             cur = torch.cuda.current_stream()
-            outs = []
-            for i, (lo, hi) in enumerate(bounds):
-                s = self._lane_streams[i]
-                s.wait_stream(cur)
-                with torch.cuda.stream(s):
-                    self._lane = i + 1
-                    sub = [f[lo:hi] for f in feats]
-                    enc = self.encode(sub)
-                    outs.append((enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
-                                                           sem_embs=enc.get("semantic_embs"))))
-            self._lane = 0
-            for s in self._lane_streams:
-                cur.wait_stream(s)
-            return (outs[0][0],) + tuple(torch.cat([o[k] for o in outs], 0) for k in (1, 2, 3))
+            parts = []
+            try:
+                for i, (lo, hi) in enumerate(bounds):
+                    st = self._lane_streams[i]
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        self._lane = i + 1  # workspace namespace of this lane (see ws)
+                        enc = self.encode([f[lo:hi] for f in feats])
+                        parts.append((enc,) + tuple(self.greedy(enc["encoder_hidden_states"],
+                                                                enc.get("semantic_hidden_states"),
+                                                                sem_embs=enc.get("semantic_embs"))))
+            finally:
+                self._lane = 0
+            for st in self._lane_streams[:lanes]:
+                cur.wait_stream(st)
+            return (_LaneOutputs([pt[0] for pt in parts]),) + tuple(torch.cat([pt[k] for pt in parts], 0)
+                                                                     for k in (1, 2, 3))
 
-        key = ("greedy_lanes", lanes, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        key = ("greedy", lanes, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
         entry = self._graphs.get(key)
         if entry is None:
             self._graphs[key] = "seen"
-            return run()
+            return run()  # eager: allocates every lane's workspaces
         if entry == "seen":
+            if len(self._graphs) > 8:
+                self._graphs = {k: v for k, v in self._graphs.items() if k == key}
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):

@@ -92,3 +92,41 @@ def test_graph_replay_equals_eager_and_oracle_sample():
         n = int(eager[1][i])
         assert eager[0][i, 1:n + 1].tolist() == hyps[j][0]
         assert abs(float(eager[2][i]) / n - scores[j][0]) < 1e-4
+
+
+@pytest.mark.parametrize("config,dtype,B,lanes", [("msrvtt_base_ami", "bf16", 777, 2), ("msrvtt_care", "bf16", 300, 3),
+                                                  ("msrvtt_care", "fp32", 130, 2)])
+def test_batch_lanes_equal_single_lane(config, dtype, B, lanes):
+    """engine.lanes: the batch cut into lanes on separate HIP streams inside one hipGraph gives
+    the single-lane captions (clips are independent), for ragged splits too; the lazily joined
+    encoder outputs equal the single-lane ones and track the replays."""
+    boost = {"cls_head.tgt_word_prj.weight": {3: 4.0, 0: 3.0}}
+    opt, P, model, feats = _setup(config, B, dtype, boost=boost)
+    eng = model.engine()
+    enc1, fed1, len1, sc1 = eng.translate_greedy(feats, use_graph=False)
+    fed1, len1, sc1 = fed1.clone(), len1.clone(), sc1.clone()
+    mem1 = enc1["encoder_hidden_states"].clone()
+    labels1 = enc1["semantic_labels"].clone() if "semantic_labels" in enc1 else None
+    eng.lanes = lanes
+    try:
+        for it in range(3):  # eager (first sight), capture, replay
+            enc2, fed2, len2, sc2 = eng.translate_greedy(feats, use_graph=True)
+            assert fed2.shape == fed1.shape and torch.equal(len2, len1)
+            for i in range(B):
+                k = int(len1[i]) + 1
+                assert torch.equal(fed2[i, :k], fed1[i, :k])
+            assert (sc2 - sc1).abs().max().item() < (1e-4 if dtype == "fp32" else 2e-2)
+            assert enc2["encoder_hidden_states"].shape == mem1.shape
+            assert (enc2["encoder_hidden_states"] - mem1).abs().max().item() < (1e-5 if dtype == "fp32" else 1e-2)
+            assert len(enc2["mean_encoder_hidden_states"]) == len(enc1["mean_encoder_hidden_states"])
+            if labels1 is not None:
+                assert torch.equal(enc2["semantic_labels"], labels1)
+                assert enc2.get("preds_attr").shape[0] == B
+        # new inputs in the SAME buffers: the replay (and the joined outputs) must follow them
+        for f in feats:
+            f.copy_(f.flip(0))
+        enc3, fed3, len3, _ = eng.translate_greedy(feats, use_graph=True)
+        assert torch.equal(len3, len1.flip(0))
+        assert (enc3["encoder_hidden_states"] - mem1.flip(0)).abs().max().item() < (1e-5 if dtype == "fp32" else 1e-2)
+    finally:
+        eng.lanes = 1
