@@ -68,8 +68,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int m0 = (blockIdx.x / tiles_n) * BM;
   const int n0 = (blockIdx.x % tiles_n) * BN;
 
-  float4 ra[A_IT];
-  uint4 rw[W_IT];
+  // native vector types: arrays of HIP's struct-based float4/uint4 are not promoted to registers
+  // here (the staging then lives in scratch memory and every tile waits for its global loads)
+  f32x4 ra[A_IT];
+  u32x4 rw[W_IT];
 
   auto load_tile = [&](int k0) {
 #pragma unroll
@@ -79,14 +81,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       // rows past M are clamped, not branched around: their products are never stored, and a
       // branch per unrolled load would serialise the loads behind vmcnt(0) waits
       const int gr = min(m0 + row, p.M - 1);
-      ra[i] = *reinterpret_cast<const float4*>(p.A + (int64_t)gr * p.lda + k0 + ch * 4);
+      ra[i] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)gr * p.lda + k0 + ch * 4);
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       int c = i * 256 + tid;
       int row = c >> 3, ch = c & 7;
       const int gn = min(n0 + row, p.N - 1);
-      rw[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.W) +
+      rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.W) +
                                               ((int64_t)gn * p.K + k0) * sizeof(WT) + ch * 16);
     }
   };
@@ -99,17 +101,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       int row = c / A_CH, ch = c % A_CH;
       if constexpr (BF) {
         bf16x4 v;
-        v[0] = (bf16_t)ra[i].x; v[1] = (bf16_t)ra[i].y; v[2] = (bf16_t)ra[i].z; v[3] = (bf16_t)ra[i].w;
+        v[0] = (bf16_t)ra[i][0]; v[1] = (bf16_t)ra[i][1]; v[2] = (bf16_t)ra[i][2]; v[3] = (bf16_t)ra[i][3];
         *reinterpret_cast<bf16x4*>(a + row * 128 + ((((ch >> 1) ^ (row & 7))) << 4) + (ch & 1) * 8) = v;
       } else {
-        *reinterpret_cast<float4*>(a + row * 128 + ((ch ^ (row & 7)) << 4)) = ra[i];
+        *reinterpret_cast<f32x4*>(a + row * 128 + ((ch ^ (row & 7)) << 4)) = ra[i];
       }
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       int c = i * 256 + tid;
       int row = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(b + row * 128 + ((ch ^ (row & 7)) << 4)) = rw[i];
+      *reinterpret_cast<u32x4*>(b + row * 128 + ((ch ^ (row & 7)) << 4)) = rw[i];
     }
   };
 
@@ -127,7 +129,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int fr = lane & 15, fg = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    // unconditional prefetch (the last iteration re-loads its own tile): a conditional one keeps
+    // the staging registers in scratch memory and exposes the whole global-load latency
+    load_tile(min(kt + 1, nk - 1) * BK);
     const unsigned char* a = sA + buf * BM * 128 + (wm * (BM / 2) + fr) * 128;
     const unsigned char* b = sB + buf * BN * 128 + (wn * (BN / 2) + fr) * 128;
 #pragma unroll
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
               acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][j], fb[n][j], acc[m][n], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    store_tile(buf ^ 1);
     __syncthreads();
   }
 

@@ -70,8 +70,23 @@ def ln_main():
         print("gemm_ln M=%6d K=%4d A=%s: %8.1f us (%6.1f TF)" % (M, K, "f32" if f32 else "bf16", t, 2.0 * M * 512 * K / t / 1e6), flush=True)
 
 
+def f32_main():
+    """care_gemm with f32 weights (exact f32 MFMA): the embedder of the concept models and the fp32 parity mode."""
+    for M, N, K in [(458752, 512, 2048), (458752, 512, 512), (458752, 512, 128), (16384, 512, 1536), (16384, 2048, 512)]:
+        A = torch.randn(M, K, device=DEV)
+        W = torch.randn(N, K, device=DEV) * 0.05
+        bias = torch.randn(N, device=DEV)
+        out = torch.empty(M, N, device=DEV)
+        p = lambda t: t.data_ptr()
+        t = time_call(lambda: _lib.call("care_gemm", p(A), K, p(W), 0, p(bias), p(out), N, 0, None, 0, 0, N, M, N, K, 0), iters=5)
+        fl = 2.0 * M * N * K
+        print("f32 M=%6d N=%5d K=%4d  %8.1f us (%6.1f TF of 157.3)" % (M, N, K, t, fl / t / 1e6), flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ln":
         ln_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "f32":
+        f32_main()
     else:
         main()
