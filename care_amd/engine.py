@@ -109,6 +109,7 @@ class HipEngine:
         self._graphs: Dict[tuple, object] = {}
         self._lane = 0
         self.lanes = 1  # batch lanes of a graph-replayed greedy pass (lanes_for)
+        self.latent = os.environ.get("CARE_LATENT", "1") != "0"
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, sd: Dict[str, torch.Tensor], device) -> None:
@@ -192,6 +193,14 @@ class HipEngine:
         else:
             w[name + "_q_w"], w[name + "_q_b"] = wt(wq), f32(bq)
             w[name + "_kv_w"], w[name + "_kv_b"] = wt(torch.cat([wk, wv], 0)), f32(torch.cat([bk, bv], 0))
+            if self.latent_capable:
+                # absorbed cross-attention (csrc/attention_latent.hip): W_k moves to the query side as
+                # wkt[h][c][e] = W_k[h*64+e][c] / sqrt(64) (b_k only shifts every score of a head by one
+                # constant, which the softmax cancels); W_v, b_v are applied to the latent context
+                H = self.H
+                wkt = wk.detach().to(torch.float32).view(H, 64, self.d).permute(0, 2, 1) * 0.125
+                w[name + "_wkt"] = wkt.contiguous().to(self.device, torch.bfloat16)
+                w[name + "_v_w"], w[name + "_v_b"] = wt(wv), f32(bv)
         w[name + "_o_w"], w[name + "_o_b"] = wt(sd[p + ".dense.weight"]), f32(sd[p + ".dense.bias"])
         w[name + "_g"], w[name + "_be"] = f32(sd[p + ".LayerNorm.weight"]), f32(sd[p + ".LayerNorm.bias"])
 
@@ -224,6 +233,17 @@ class HipEngine:
         GEMM-input activations then live as bf16 mirrors.  Otherwise (fp32 mode, d = 768/1024)
         every GEMM takes fp32 activations through the generic kernel."""
         return self.bf and self.d <= 512 and self.d % 128 == 0
+
+    @property
+    def latent_capable(self) -> bool:
+        """Shapes / dtype the absorbed cross-attention kernels cover: bf16 mode, d_model = 512, head dim 64."""
+        return self.as_ok and self.d == 512 and self.H * 64 == self.d and self.H <= 16
+
+    @property
+    def latent_ok(self) -> bool:
+        """Absorbed cross-attention (one bf16 copy of the memory instead of projected K and V) is in
+        use; `self.latent = False` (or CARE_LATENT=0) keeps the projected-K/V kernels."""
+        return bool(self.latent) and self.latent_capable
 
     @property
     def act_dtype(self):
@@ -426,6 +446,18 @@ class HipEngine:
             out.append(self.gemm(src2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv, tag="cross_kv_gemm"))
         return out
 
+    def cross_src(self, mem: torch.Tensor):
+        """What the decoder's cross-attention reads at every step: per-layer projected K/V
+        (cross_kv), or - absorbed form - the bf16 memory itself, shared by all layers."""
+        if not self.latent_ok:
+            return self.cross_kv(mem)
+        mem = mem.contiguous()
+        ref, memb = getattr(self, "_mem_mirror", (None, None))
+        if not (memb is not None and ref is not None and ref() is mem):
+            memb = self.ws("lat_mem", tuple(mem.shape), torch.bfloat16)
+            memb.copy_(mem)
+        return [memb] * self.n_layers
+
     def attr_kv(self, sem_embs: torch.Tensor, tag="akv") -> Optional[List[torch.Tensor]]:
         """K/V of the concept embeddings [B, topk, d] for the attr_attention block (CABase)."""
         if not self.attr_att:
@@ -566,10 +598,25 @@ class HipEngine:
                 o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
                 self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b)
             nm = "d{}_ca".format(li)
-            q2 = self.gemm(g(x1, x1b), w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)), tag="step_dxd_gemm")
-            kv = ckv[li]
-            ctx = self.attention(q2, kv, kv[:, d:], self._ctx(tag, N), Lk * 2 * d, 2 * d, rows_per_clip, Lk,
-                                 bias=w["d{}_hb".format(li)], tag="step_cross_attn")
+            hb = w["d{}_hb".format(li)]
+            if self.latent_ok:
+                H = self.H
+                q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2b", (N, d), torch.bfloat16),
+                               tag="step_dxd_gemm")
+                qt = self.ws(tag + "qt", (N, H * d), torch.bfloat16)
+                call("care_head_expand", ptr(q2), d, ptr(w[nm + "_wkt"]), ptr(qt), H * d, N, H, tag="step_head_expand")
+                ct = self.ws(tag + "ct", (N, H * d), torch.bfloat16)
+                call("care_attention_latent", ptr(qt), H * d, ptr(ckv[li]), Lk * d, d, rows_per_clip, Lk, ptr(hb),
+                     hb.stride(0) if hb is not None else 0, ptr(ct), H * d, N, H, d, tag="step_cross_attn")
+                ctx = self._ctx(tag, N)
+                call("care_head_reduce", ptr(ct), H * d, ptr(w[nm + "_v_w"]), ptr(w[nm + "_v_b"]), ptr(ctx), d, N, H,
+                     tag="step_head_reduce")
+            else:
+                q2 = self.gemm(g(x1, x1b), w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)),
+                               tag="step_dxd_gemm")
+                kv = ckv[li]
+                ctx = self.attention(q2, kv, kv[:, d:], self._ctx(tag, N), Lk * 2 * d, 2 * d, rows_per_clip, Lk,
+                                     bias=hb, tag="step_cross_attn")
             x2, x2b = self.ws(tag + "x2", (N, d)), self.wsb(tag + "x2", (N, d))
             if self.ln_fusable(N):
                 self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x1, w[nm + "_g"], w[nm + "_be"], x2, x2b,
@@ -601,7 +648,7 @@ class HipEngine:
         fin = self.ws("g_fin", (B,), torch.int32)
         fed.zero_(); fed[:, 0] = BOS
         score.zero_(); length.zero_(); fin.zero_()
-        ckv = self.cross_kv(mem)
+        ckv = self.cross_src(mem)
         akv = self.attr_kv(sem_embs) if self.attr_att else None
         skv = [self.ws("g_skv%d" % li, (B, T, 2 * d), self.wt) for li in range(self.n_layers)]
         bf = self.as_ok
@@ -639,7 +686,7 @@ class HipEngine:
             enc = self.encode(feats)
             return (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
                                               sem_embs=enc.get("semantic_embs")))
-        key = ("greedy", tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        key = ("greedy", self.latent_ok, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
         entry = self._graphs.get(key)
         if entry is None:
             enc = self.encode(feats)  # eager pass: allocates every workspace
@@ -709,7 +756,7 @@ class HipEngine:
             return (_LaneOutputs([pt[0] for pt in parts]),) + tuple(torch.cat([pt[k] for pt in parts], 0)
                                                                      for k in (1, 2, 3))
 
-        key = ("greedy", lanes, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        key = ("greedy", lanes, self.latent_ok, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
         entry = self._graphs.get(key)
         if entry is None:
             self._graphs[key] = "seen"
@@ -739,7 +786,7 @@ class HipEngine:
 
         if not use_graph:
             return run()
-        key = ("beam", bm, need, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        key = ("beam", bm, need, self.latent_ok, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
         entry = self._graphs.get(key)
         if entry is None:
             self._graphs[key] = "seen"
@@ -781,7 +828,7 @@ class HipEngine:
         cidx = self.ws("b_cidx", (N, bm), torch.int32)
         vpad = (self.V + 63) // 64 * 64  # 16-byte aligned row stride -> the GEMM's vector store path
         logits = self.ws("b_logits", (N, vpad))[:, : self.V]
-        ckv = self.cross_kv(mem)
+        ckv = self.cross_src(mem)
         akv = self.attr_kv(sem_embs) if self.attr_att else None
         skv = [self.ws("b_skv%d" % li, (N, T, 2 * d), self.wt) for li in range(self.n_layers)]
         for t in range(1, T + 1):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 5
+#define CARE_ABI_VERSION 6
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -241,6 +241,37 @@ int care_attention(const float* Q, int64_t ldq, const void* K, const void* V, in
                    int causal_off, const int32_t* pad_tok, int pad_stride, int pad_id,
                    const float* bias, int bias_ld, void* ctx, int64_t ldctx, int ctx_dtype,
                    int rows, int heads, void* stream);
+
+/*
+ * care_attention_latent: the cross-attention of a decoder step with W_k / W_v absorbed into
+ *   the query / context side (bf16 mode, d_model = 512).  Same reference lines as
+ *   care_attention (models/components/Attention.py:63-67,83-131), re-associated:
+ *     scores[h][j] = (W_k,h^T q_h / 8) . mem_j   (+ a per-head constant the softmax cancels)
+ *     ct[h]        = sum_j softmax_j(scores[h][j] + bias[h][j]) mem_j
+ *   so every step reads ONE bf16 copy of the memory row instead of projected K and V.
+ *   qt  bf16 [rows, heads, 512] (row stride ldq): the expanded, pre-scaled queries.
+ *   mem bf16: key j of row r at  mem + (r / rows_per_kv) * mem_batch_stride + j * mem_row_stride.
+ *   bias fp32 [heads, bias_ld] or NULL.  ct bf16 [rows, heads, 512] (row stride ldc); the caller
+ *   finishes ctx_h = W_v,h ct[h] + b_v,h.  nkeys <= 128, heads <= 16, d == 512.
+ */
+int care_attention_latent(const void* qt, int64_t ldq, const void* mem, int64_t mem_batch_stride,
+                          int64_t mem_row_stride, int rows_per_kv, int nkeys, const float* bias,
+                          int bias_ld, void* ct, int64_t ldc, int rows, int heads, int d,
+                          void* stream);
+
+/*
+ * care_head_expand / care_head_reduce: the per-head projections on either side of
+ *   care_attention_latent (the key / value halves of models/components/Attention.py:63-67 moved
+ *   from the memory to the query / context):
+ *     qt[r][h][c]     = sum_e q[r][h*64+e] * wkt[h][c][e]        wkt = W_k,h^T / 8, bf16 [H][512][64]
+ *     ctx[r][h*64+e]  = sum_c ct[r][h][c] * wv[h*64+e][c] + bv   wv = W_v bf16 [512][512], bv fp32 or NULL
+ *   q bf16 [rows, ldq], qt / ct bf16 [rows, heads, 512] (row strides ldo / ldc), ctx bf16 [rows, ldo].
+ *   d_model = 512, head dim 64.
+ */
+int care_head_expand(const void* q, int64_t ldq, const void* wkt, void* qt, int64_t ldo, int rows,
+                     int heads, void* stream);
+int care_head_reduce(const void* ct, int64_t ldc, const void* wv, const float* bv, void* ctx,
+                     int64_t ldo, int rows, int heads, void* stream);
 
 /*
  * care_beam_select: per row of logits [rows, ldl] (V valid columns): the beam_size best
