@@ -319,3 +319,70 @@ def test_gemm_ln_fused(a_f32, M, K):
     assert (out[:, 4:4 + grp] - ref).abs().max().item() < 4e-3
     assert out[:, :4].abs().max().item() == 0 and out[:, 4 + grp:].abs().max().item() == 0
     assert torch.equal(outb, out.to(torch.bfloat16))
+
+
+# --------------------------------------------------------------------------------------------
+# absorbed cross-attention (attention_latent.hip, heads.hip)
+@pytest.mark.parametrize("rows,heads", [(1, 8), (7, 8), (16, 8), (250, 8), (1029, 8), (33, 4)])
+def test_head_expand_and_reduce(rows, heads):
+    d = heads * 64 if heads == 8 else 512
+    q = _rand(rows, 512, seed=1).to(torch.bfloat16)
+    wkt = _rand(heads, 512, 64, seed=2, scale=0.05).to(torch.bfloat16)
+    qt = torch.full((rows, heads, 512), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _call("care_head_expand", _p(q), 512, _p(wkt), _p(qt), heads * 512, rows, heads)
+    ref = torch.einsum("rhe,hce->rhc", q.float()[:, : heads * 64].reshape(rows, heads, 64), wkt.float())
+    assert torch.isfinite(qt.float()).all()
+    assert (qt.float() - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
+
+    ct = _rand(rows, heads, 512, seed=3).to(torch.bfloat16)
+    wv = _rand(512, 512, seed=4, scale=0.05).to(torch.bfloat16)
+    bv = _rand(512, seed=5)
+    for bias in (bv, None):
+        ctx = torch.full((rows, 512), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _call("care_head_reduce", _p(ct), heads * 512, _p(wv), _p(bias), _p(ctx), 512, rows, heads)
+        ref = torch.einsum("rhc,hec->rhe", ct.float(), wv.float()[: heads * 64].reshape(heads, 64, 512)).reshape(rows, -1)
+        if bias is not None:
+            ref = ref + bias[: heads * 64]
+        got = ctx.float()[:, : heads * 64]
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() < 8e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("rows,nkeys,rows_per_kv,use_bias", [(1, 84, 1, True), (5, 7, 1, False), (37, 16, 1, True),
+                                                             (130, 114, 1, True), (100, 84, 5, True),
+                                                             (1030, 128, 1, False), (64, 33, 2, True)])
+def test_attention_latent(rows, nkeys, rows_per_kv, use_bias):
+    """ct[r][h] = softmax_j(qt[r][h] . mem[clip][j] + bias[h][j]) . mem[clip] against torch on the same
+    bf16 operands (the kernel rounds the probabilities and the output to bf16)."""
+    H, d = 8, 512
+    clips = (rows + rows_per_kv - 1) // rows_per_kv
+    mem = _rand(clips, nkeys, d, seed=11).to(torch.bfloat16)
+    qt = _rand(rows, H, d, seed=12, scale=0.12).to(torch.bfloat16)
+    bias = _rand(H, nkeys, seed=13, scale=0.7) if use_bias else None
+    ct = torch.full((rows, H, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _call("care_attention_latent", _p(qt), H * d, _p(mem), nkeys * d, d, rows_per_kv, nkeys, _p(bias), nkeys, _p(ct),
+          H * d, rows, H, d)
+    clip_of = torch.arange(rows, device=DEV) // rows_per_kv
+    m = mem.float()[clip_of]
+    s = torch.einsum("rhc,rjc->rhj", qt.float(), m)
+    if use_bias:
+        s = s + bias[None]
+    ref = torch.einsum("rhj,rjc->rhc", torch.softmax(s, -1), m)
+    assert torch.isfinite(ct.float()).all()
+    err = (ct.float() - ref).abs()
+    assert err.max().item() < 1.2e-2 * max(1.0, ref.abs().max().item()) and err.mean().item() < 2e-3
+
+
+def test_attention_latent_rejects_bad_arguments():
+    from care_amd import _lib
+
+    H, d = 8, 512
+    mem = _rand(2, 20, d).to(torch.bfloat16)
+    qt = _rand(2, H, d).to(torch.bfloat16)
+    ct = torch.empty(2, H, d, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(_lib.CareHipError):  # d_model other than 512
+        _call("care_attention_latent", _p(qt), H * d, _p(mem), 20 * d, d, 1, 20, None, 0, _p(ct), H * d, 2, H, 768)
+    with pytest.raises(_lib.CareHipError):  # more than 128 keys
+        _call("care_attention_latent", _p(qt), H * d, _p(mem), 20 * d, d, 1, 129, None, 0, _p(ct), H * d, 2, H, d)
+    with pytest.raises(_lib.CareHipError):  # misaligned query
+        _call("care_attention_latent", _p(qt) + 2, H * d, _p(mem), 20 * d, d, 1, 20, None, 0, _p(ct), H * d, 2, H, d)
