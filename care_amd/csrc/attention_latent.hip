@@ -26,6 +26,10 @@
 // bf16 mode only (the fp32 parity mode keeps projected K/V and csrc/attention.hip).
 #include "care_common.h"
 
+#ifndef CARE_LAT_DBG
+#define CARE_LAT_DBG 0  // ablation builds (tools/latent_probe.py): 1 no ct stores, 2 no qt loads, 4 no arithmetic
+#endif
+
 namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -103,12 +107,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
     bf16x8 qf[16];
     const bf16_t* qrow = p.qt + (int64_t)row * p.ldq + headc * LAT_D + fg * 8;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32);
+    for (int ks = 0; ks < 16; ++ks) {
+      if (CARE_LAT_DBG & 2) { qf[ks] = bf16x8{}; asm volatile("" : "+v"(qf[ks])); }
+      else qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32);
+    }
 
     f32x4 acc[32];
 #pragma unroll
     for (int m = 0; m < 32; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_part = 0.f;
+    float m_ref = -INFINITY, l_part = 0.f;
 
     for (int c = 0; c < nch; ++c, ++t) {
       const int slot = t % NSLOT;
@@ -125,6 +132,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
       }
       __builtin_amdgcn_sched_barrier(0);
       const unsigned char* sb = ring + slot * CH_BYTES;
+      if (CARE_LAT_DBG & 4) continue;
 
       // ---- S^T[key][head] for the 16 keys of the chunk
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -136,25 +144,32 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
       // lane (head fr, group fg) holds keys c*16 + fg*4 + r
       s += *reinterpret_cast<const f32x4*>(sbias + fr * 128 + c * CH_KEYS + fg * 4);
 
-      // ---- online softmax over the keys of each head
+      // ---- online softmax over the keys of each head, with a LAZY reference maximum: the
+      // exponentials are taken against m_ref, which only moves (and only then are the 128
+      // accumulator registers rescaled) when a chunk's maximum exceeds it by more than 16 -
+      // softmax is shift-invariant, exp(16) ~ 9e6 is harmless in fp32/bf16, and in the common case
+      // the accumulators are touched by nothing but the MFMAs (they stay in AGPRs).
       float cm = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
       cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
       cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
-      const float m_new = fmaxf(m_run, cm);
-      const float alpha = __expf(m_run - m_new);  // first chunk: exp(-inf) = 0
-      m_run = m_new;
+      if (__any(cm > m_ref + 16.0f)) {  // wave-uniform; always taken on a row's first chunk (m_ref = -inf)
+        const float m_new = fmaxf(m_ref, cm);
+        const float alpha = __expf(m_ref - m_new);  // exp(-inf) = 0 on the first chunk
+        m_ref = m_new;
+        l_part *= alpha;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) acc[m] *= alpha;
+      }
       s16x4 pb;
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pr = __expf(s[r] - m_new);
+        const float pr = __expf(s[r] - m_ref);
         psum += pr;
         const bf16_t h = (bf16_t)pr;
         pb[r] = __builtin_bit_cast(short, h);
       }
-      l_part = l_part * alpha + psum;
-#pragma unroll
-      for (int m = 0; m < 32; ++m) acc[m] *= alpha;
+      l_part += psum;
 
       // ---- ct^T[dim][head] += mem_chunk^T . P^T
       // The transposed reads are asm: through the intrinsic hipcc puts an s_waitcnt vmcnt(0) in
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    if (fr < p.heads) {
+    if (fr < p.heads && !(CARE_LAT_DBG & 1)) {
       bf16_t* out = p.ct + (int64_t)row * p.ldc + fr * LAT_D + fg * 4;
 #pragma unroll
       for (int m = 0; m < 32; ++m) {
@@ -203,6 +218,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
       }
     }
   }
+}
+
+template <int WAVES, int NSLOT>
+int launch_latent(const LatArgs& p, hipStream_t st) {
+  constexpr int LDS = WAVES * NSLOT * CH_BYTES + 16 * 128 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_latent_kernel<WAVES, NSLOT>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int blocks = min((p.rows + WAVES - 1) / WAVES, 256);
+  hipLaunchKernelGGL((attention_latent_kernel<WAVES, NSLOT>), dim3(blocks), dim3(WAVES * 64), LDS, st, p);
+  return care_launch_status();
 }
 
 }  // namespace
@@ -221,15 +250,11 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
   p.rows_per_kv = rows_per_kv; p.nkeys = nkeys; p.bias = bias; p.bias_ld = bias_ld;
   p.ct = reinterpret_cast<bf16_t*>(ct); p.ldc = ldc; p.rows = rows; p.heads = heads;
   hipStream_t st = (hipStream_t)stream;
-  constexpr int WAVES = 4, NSLOT = 2;
-  const int blocks = min((rows + WAVES - 1) / WAVES, 256);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_latent_kernel<WAVES, NSLOT>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, WAVES * NSLOT * CH_BYTES + 16 * 128 * 4);
-    attr_set = true;
+  static int cfg = -1;
+  if (cfg < 0) {
+    const char* e = getenv("CARE_LAT_CFG");  // tuning: 0 = 4 waves x 2 slots, 1 = 3 waves x 3 slots
+    cfg = e ? atoi(e) : 0;
   }
-  hipLaunchKernelGGL((attention_latent_kernel<WAVES, NSLOT>), dim3(blocks), dim3(WAVES * 64),
-                     WAVES * NSLOT * CH_BYTES + 16 * 128 * 4, st, p);
-  return care_launch_status();
+  if (cfg == 1) return launch_latent<3, 3>(p, st);
+  return launch_latent<4, 2>(p, st);
 }

@@ -42,7 +42,7 @@
 
 namespace {
 
-enum { STREAM_STORE = 0, STREAM_ARGMAX = 1 };
+enum { STREAM_STORE = 0, STREAM_ARGMAX = 1, STREAM_ARGMAX_LAB = 2 };  // _LAB: also the logit of a label column
 
 constexpr int TILE_N = 16;             // output columns per W tile
 constexpr int TILE_BYTES = TILE_N * 1024;
@@ -110,6 +110,8 @@ __device__ __forceinline__ void wait_vm(int n) {
 template <typename AT, int MODE, bool FULL>
 __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool IS_ARGMAX = MODE != STREAM_STORE;
+  constexpr bool HAS_LAB = MODE == STREAM_ARGMAX_LAB;  // 16 more live VGPRs: its own instantiation
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
@@ -131,10 +133,10 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   const int t0 = ns * tpb, t1 = min(t0 + tpb, tiles_total);
   const int m0 = panel * 128 + wave * 32;
   if (t0 >= t1) {  // empty column range (ns is rounded up to a multiple of 8)
-    if (MODE == STREAM_ARGMAX && lane < 32 && m0 + lane < p.M) {
+    if (IS_ARGMAX && lane < 32 && m0 + lane < p.M) {
       const int64_t o = (int64_t)(m0 + lane) * p.ns + ns;
       p.pmax[o] = -INFINITY; p.pidx[o] = 0x7fffffff; p.psum[o] = 0.f;
-      if (p.plab) p.plab[o] = -INFINITY;
+      if (HAS_LAB && p.plab) p.plab[o] = -INFINITY;
     }
     continue;
   }
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   // B fragments are read BDEPTH k-steps ahead of the MFMAs that use them: one ds_read_b128 has
   // ~130+ cycles of latency but feeds only 32 cycles of MFMA, so a shallow prefetch leaves the
   // loop LDS-latency-bound (measured: ~2600 cycles per tile instead of ~600).
-  constexpr int BDEPTH = 8;
+  constexpr int BDEPTH = IS_ARGMAX ? 6 : 8;  // the argmax modes need the 8 registers (they would spill)
   // chunk (ks*4 + fg) ^ fr  ==  (ks & ~3)*4 + ((ks & 3) ^ (fr >> 2))*4 + (fg ^ (fr & 3)): per lane
   // only FOUR distinct byte offsets (r = ks & 3) plus the compile-time 256 * (ks >> 2).
   int boff[4];
@@ -200,9 +202,9 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
       if (FULL || ks < ksn) {
         const bf16x8 b = fb[ks % BDEPTH];
         if (ks + BDEPTH < 16 && (FULL || ks + BDEPTH < ksn))
-          fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff[ks & 3] + ((ks + BDEPTH) >> 2) * 256);
+          fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff[(ks + BDEPTH) & 3] + ((ks + BDEPTH) >> 2) * 256);
         if (CARE_AS_DBG & 2) { asm volatile("" :: "v"(b)); continue; }
-        if constexpr (MODE == STREAM_ARGMAX) {  // D[row of A][col = W row]: a lane sees 1 column, 4 rows
+        if constexpr (IS_ARGMAX) {  // D[row of A][col = W row]: a lane sees 1 column, 4 rows
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b, acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], b, acc[1], 0, 0, 0);
         } else {  // swapped: a lane holds 4 CONSECUTIVE output columns of one row
@@ -259,16 +261,64 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   };
 
   // running (max, argmax, sum-exp) of the 8 rows this lane sees, over its column residue
-  float rm[8], rs[8], rl[8];
-  int ri[8], lab[8];
-  if constexpr (MODE == STREAM_ARGMAX) {
+  float rm[8], rs[8], rl[HAS_LAB ? 8 : 1];
+  int ri[8], lab[HAS_LAB ? 8 : 1];
+  if constexpr (IS_ARGMAX) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      rm[i] = -INFINITY; rs[i] = 0.f; ri[i] = 0x7fffffff; rl[i] = -INFINITY;
+      // finite sentinel, not -inf: an update with a masked (-inf) logit then gives exp(-inf) = 0, not NaN
+      rm[i] = -1e30f; rs[i] = 0.f; ri[i] = 0x7fffffff;
       const int row = min(m0 + (i >> 2) * 16 + fg * 4 + (i & 3), p.M - 1);
-      lab[i] = p.labels ? p.labels[row] : -1;
+      if constexpr (HAS_LAB) { rl[i] = -INFINITY; lab[i] = p.labels ? p.labels[row] : -1; }
     }
   }
+
+  // online (max, sum-exp) of logit i (= m-tile i>>2, register i&3) of a finished tile, with ONE exp
+  // per logit: e = exp(-|m - v|) is the rescale factor when v is the new max and the new term otherwise
+  auto argmax_one = [&](const f32x4 (&av)[2], int c0, int i) {
+    const float v0 = c0 < p.N ? av[i >> 2][i & 3] : -INFINITY;
+    const bool up = v0 > rm[i];
+    const float mn = up ? v0 : rm[i];
+    const float e = __expf((up ? rm[i] : v0) - mn);
+    rs[i] = up ? fmaf(rs[i], e, 1.0f) : rs[i] + e;
+    ri[i] = up ? c0 : ri[i];
+    rm[i] = mn;
+    if constexpr (HAS_LAB) rl[HAS_LAB ? i : 0] = c0 == lab[HAS_LAB ? i : 0] ? v0 : rl[HAS_LAB ? i : 0];
+  };
+  auto argmax_update = [&](const f32x4 (&av)[2], int tile) {
+    const int c0 = tile * TILE_N + fr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) argmax_one(av, c0, i);
+  };
+  // Software pipeline of the argmax mode: the MFMAs of tile t with the statistics of tile t-1 (held
+  // in accp) woven in by hand, one logit after every second k-step, and the order PINNED by a
+  // sched_barrier per k-step.  Left to the scheduler (statistics in the same region as the MFMAs)
+  // hipcc issues the 16 dependent MFMAs of one accumulator back to back - each then waits out the
+  // full MFMA latency and the tile takes 1.8x as long; done strictly after the MFMAs the statistics
+  // cost about as many issue cycles again (13 VALU ops + 1 exp per logit vs 32 MFMAs).
+  f32x4 accp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  auto compute_woven = [&](int slot, int prev_tile) {
+    const unsigned char* sb = smem + slot * TILE_BYTES;
+    const int c0 = prev_tile * TILE_N + fr;
+    bf16x8 fb[BDEPTH];
+#pragma unroll
+    for (int ks = 0; ks < BDEPTH; ++ks)
+      if (FULL || ks < ksn) fb[ks] = *reinterpret_cast<const bf16x8*>(sb + boff[ks & 3] + (ks >> 2) * 256);
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      if (FULL || ks < ksn) {
+        const bf16x8 b = fb[ks % BDEPTH];
+        if (ks + BDEPTH < 16 && (FULL || ks + BDEPTH < ksn))
+          fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff[(ks + BDEPTH) & 3] + ((ks + BDEPTH) >> 2) * 256);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], b, acc[1], 0, 0, 0);
+      }
+      if (ks & 1) argmax_one(accp, c0, ks >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
   // ---- prologue: up to AHEAD tiles in flight (4 VM ops each), then the A loads: one combined latency
   const int ntl = t1 - t0;
@@ -341,30 +391,18 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
     if (t + AHEAD < t1) { stage(t + AHEAD, (it + AHEAD) % RING); n_dma = 4; }
     __builtin_amdgcn_sched_barrier(0);
 
-    compute(slot);
-
     int n_st = 0;
     if constexpr (MODE == STREAM_STORE) {
+      compute(slot);
       __builtin_amdgcn_sched_barrier(0);
       n_st = store_tile(t, bv);
+    } else if constexpr (HAS_LAB) {  // 16 more live registers: no room for a second accumulator pair
+      compute(slot);
+      argmax_update(acc, t);
     } else {
-      const int c0 = t * TILE_N + fr;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = mt * 4 + j;
-          // online (max, sum-exp) with ONE exp per logit: e = exp(-|m - v|) is the rescale factor
-          // when v is the new max and the new term otherwise
-          const float v0 = c0 < p.N ? acc[mt][j] : -INFINITY;
-          const bool up = v0 > rm[i];
-          const float mn = up ? v0 : rm[i];
-          const float e = __expf((up ? rm[i] : v0) - mn);
-          rs[i] = up ? fmaf(rs[i], e, 1.0f) : rs[i] + e;
-          ri[i] = up ? c0 : ri[i];
-          rm[i] = mn;
-          rl[i] = c0 == lab[i] ? v0 : rl[i];
-        }
+      // iteration 0 has no previous tile: a column index past N masks the dummy statistics (no branch)
+      compute_woven(slot, it > 0 ? t - 1 : (1 << 26));
+      accp[0] = acc[0]; accp[1] = acc[1];
     }
 #pragma unroll
     for (int i = 0; i + 1 < AHEAD; ++i) { hist_dma[i] = hist_dma[i + 1]; hist_st[i] = hist_st[i + 1]; }
@@ -372,14 +410,15 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
     hist_st[AHEAD - 1] = n_st;
   }
 
-  if constexpr (MODE == STREAM_ARGMAX) {
+  if constexpr (IS_ARGMAX) {
+    if constexpr (!HAS_LAB) argmax_update(accp, t1 - 1);  // the last tile's statistics
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      float m = rm[i], s = rs[i], lv = rl[i];
+      float m = rm[i], s = rs[i], lv = HAS_LAB ? rl[HAS_LAB ? i : 0] : 0.f;
       int id = ri[i];
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) {
-        lv = fmaxf(lv, __shfl_xor(lv, o, 64));
+        if constexpr (HAS_LAB) lv = fmaxf(lv, __shfl_xor(lv, o, 64));
         const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
         const int oi = __shfl_xor(id, o, 64);
         const float mn = fmaxf(m, om);
@@ -391,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
       if (fr == 0 && row < p.M) {
         const int64_t o = (int64_t)row * p.ns + ns;
         p.pmax[o] = m; p.pidx[o] = id; p.psum[o] = s;
-        if (p.plab) p.plab[o] = lv;
+        if (HAS_LAB && p.plab) p.plab[o] = lv;
       }
     }
   }
@@ -486,6 +525,9 @@ extern "C" int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, co
   p.ns = pick_ns(p.panels, (N + TILE_N - 1) / TILE_N);
   const int blocks = plan_stream(p, false);
   hipStream_t st = (hipStream_t)stream;
+  if (labels && plab)
+    return a_dtype == CARE_BF16 ? launch_as<bf16_t, STREAM_ARGMAX_LAB>(p, blocks, st)
+                                : launch_as<float, STREAM_ARGMAX_LAB>(p, blocks, st);
   return a_dtype == CARE_BF16 ? launch_as<bf16_t, STREAM_ARGMAX>(p, blocks, st)
                               : launch_as<float, STREAM_ARGMAX>(p, blocks, st);
 }

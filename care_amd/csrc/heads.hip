@@ -13,18 +13,22 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // expand: block = (head, row-tile stride); wave w owns output columns [128 w, 128 w + 128).
 // D = W_frag (row operand: column c) x q_frag (column operand: batch row), so a lane ends up with
-// 4 consecutive output columns of one batch row (8-byte bf16 stores).
+// consecutive output columns of one batch row (16-byte bf16 stores, see the column permutation).
 __global__ __launch_bounds__(256) void head_expand_kernel(const bf16_t* q, int64_t ldq, const bf16_t* wkt, bf16_t* qt,
                                                           int64_t ldo, int rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int h = blockIdx.x;
-  const bf16_t* wh = wkt + (int64_t)h * 512 * 64 + (int64_t)(wave * 128 + fr) * 64 + fg * 8;
+  // MFMA tile nt, D row i computes output column  (nt>>1)*32 + (i>>2)*8 + (nt&1)*4 + (i&3)  of the
+  // wave's 128, so that after tiles 2k and 2k+1 a lane (D rows 4 fg .. 4 fg + 3 of each) holds the
+  // 8 CONSECUTIVE columns k*32 + fg*8 .. +7: one 16-byte store per tile pair.
+  const bf16_t* wh = wkt + (int64_t)h * 512 * 64 + (int64_t)(wave * 128 + (fr >> 2) * 8 + (fr & 3)) * 64 + fg * 8;
   bf16x8 bw[8][2];
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) bw[nt][ks] = *reinterpret_cast<const bf16x8*>(wh + nt * 16 * 64 + ks * 32);
+    for (int ks = 0; ks < 2; ++ks)
+      bw[nt][ks] = *reinterpret_cast<const bf16x8*>(wh + ((nt >> 1) * 32 + (nt & 1) * 4) * 64 + ks * 32);
 
   const int tiles = (rows + 15) / 16;
   const bf16_t* qh = q + h * 64 + fg * 8;
@@ -40,17 +44,20 @@ __global__ __launch_bounds__(256) void head_expand_kernel(const bf16_t* q, int64
     const int Tn = T + gridDim.y;
     load_a(min(Tn, tiles - 1), an);  // prefetch (the last iteration re-reads its own tile)
     const int r = T * 16 + fr;
-    bf16_t* out = qt + (int64_t)min(r, rows - 1) * ldo + h * 512 + wave * 128 + fg * 4;
+    // rows past the end are clamped to the last row: they recompute and rewrite ITS values
+    bf16_t* out = qt + (int64_t)min(r, rows - 1) * ldo + h * 512 + wave * 128 + fg * 8;
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[nt][0], af[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[nt][1], af[1], acc, 0, 0, 0);
-      bf16x4 o;
+    for (int k = 0; k < 4; ++k) {
+      bf16x8 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16_t)acc[j];
-      // rows past the end are clamped to the last row: they recompute and rewrite ITS values
-      *reinterpret_cast<bf16x4*>(out + nt * 16) = o;
+      for (int half = 0; half < 2; ++half) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[2 * k + half][0], af[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[2 * k + half][1], af[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[half * 4 + j] = (bf16_t)acc[j];
+      }
+      *reinterpret_cast<bf16x8*>(out + k * 32) = o;
     }
     af[0] = an[0]; af[1] = an[1];
   }
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const bf16_t* ct, int6
 extern "C" int care_head_expand(const void* q, int64_t ldq, const void* wkt, void* qt, int64_t ldo, int rows, int heads,
                                 void* stream) {
   if (!q || !wkt || !qt || rows <= 0 || heads <= 0) return CARE_EINVAL;
-  if ((ldq % 8) || (ldo % 4) || !care_aligned16(q) || !care_aligned16(wkt) || !care_aligned16(qt)) return CARE_EALIGN;
+  if ((ldq % 8) || (ldo % 8) || !care_aligned16(q) || !care_aligned16(wkt) || !care_aligned16(qt)) return CARE_EALIGN;
   const int tiles = (rows + 15) / 16;
   const int nb = min(tiles, max(1, 1024 / heads));
   hipLaunchKernelGGL(head_expand_kernel, dim3(heads, nb), dim3(256), 0, (hipStream_t)stream,
