@@ -24,6 +24,15 @@
 //     SOURCE address, the LDS image itself is lane-linear) makes the transposed reads conflict-free
 //     and leaves the row reads 2-way.
 // bf16 mode only (the fp32 parity mode keeps projected K/V and csrc/attention.hip).
+//
+// What bounds it (measured, 16384 rows, Lk = 84, 1.68 GB per launch): the DMA ring alone (no
+// arithmetic, no stores) streams the memory at 6.2 TB/s; with q~ loads and c~ stores 296 us; the
+// full kernel 316-334 us = 5.0-5.3 TB/s.  Removing the per-chunk accumulator copies (fixed softmax
+// reference, slow-path redo) and coalescing the stores through LDS changed NOTHING on the same box:
+// the arithmetic sits in slack.  The limit is bytes in flight - the 128 KiB of LDS ring per CU is
+// ~27 MB chip-wide, which at the ~5 us loaded latency is ~5 TB/s (the K/V kernel buffers 264 KiB
+// per CU in registers and reaches 6.1).  3 waves x 3 slots is slower (fewer waves), a fifth wave
+// does not fit the 160 KiB.
 #include "care_common.h"
 
 #ifndef CARE_LAT_DBG
