@@ -56,7 +56,7 @@ def kernel_model(tag, eng, B, dtype):
     """Algorithmic bytes and flops of ONE launch of a tagged kernel."""
     d, H, ff, V, Lk, T = eng.d, eng.H, eng.ff, eng.V, eng.Lk, eng.T
     es = 2 if dtype == "bf16" else 4
-    if tag == "step_cross_attn" and eng.latent_ok:
+    if tag == "step_cross_attn" and eng.latent_for(B):
         # absorbed form: ONE bf16 copy of the clip's memory, expanded query in, latent context out
         return dict(bytes=B * (Lk * d * 2 + 2 * H * d * 2), flops=B * 4.0 * H * Lk * d, bound="hbm")
     if tag == "step_head_expand":  # q [B,d] bf16 in, [B,H,d] bf16 out
@@ -248,7 +248,7 @@ def main():
                              "V=10547, 29 decoder steps" if args.config == "msrvtt_base_ami" else args.config,
                     config_name=args.config, clips_per_gpu_per_step=B, global_batch=B * world, lanes=args.lanes,
                     parallelism="batch-sharded dp{} (no data-path collective; all-gather of results)".format(world),
-                    hip_graph=not args.no_graph, absorbed_cross_attention=bool(eng.latent_ok)),
+                    hip_graph=not args.no_graph, absorbed_cross_attention=bool(eng.latent_for(B))),
         decoder_step_us=round(ms_per_step * 1e3 * (1 - (kernels.get("enc_gemm", {"total_ms": 0})["total_ms"] +
                                                          kernels.get("cross_kv_gemm", {"total_ms": 0})["total_ms"]) /
                                                     max(tagged_ms, 1e-9)) / T, 2),

@@ -104,16 +104,26 @@ def test_encoding_and_teacher_forced_bf16(golden):
     assert _maxdiff(torch.logsumexp(out["logits"], -1), z["tf_logits_lse"]) < 1e-3
 
 
-def test_greedy_bf16_matches_up_to_near_ties(golden):
+@pytest.mark.parametrize("absorbed", [False, True])
+def test_greedy_bf16_matches_up_to_near_ties(golden, absorbed):
     """bf16 greedy ids vs the oracle: any divergence must start at a step where the oracle's
-    own top-1/top-2 log-prob margin is tiny (random-init logits are nearly flat)."""
+    own top-1/top-2 log-prob margin is tiny (random-init logits are nearly flat).  Both forms of
+    the cross-attention: projected K/V (what these small batches use by default) and the absorbed
+    form (engine.latent_for, forced here by dropping its row threshold)."""
     from care_amd import get_translator
     from oracle import care_cpu
 
     opt, P, feats, _ = golden.build()
     if opt.get("beam_size", 1) != 1:
         pytest.skip("greedy audit")
-    hyps, _ = get_translator(opt).translate_batch([_model(opt, P, "bf16")], {"feats": _dev(feats)})
+    model = _model(opt, P, "bf16")
+    eng = model.engine()
+    if absorbed:
+        if not eng.latent_capable:
+            pytest.skip("absorbed cross-attention covers d_model = 512 only")
+        eng.LATENT_MIN_ROWS = 1
+    assert eng.latent_for(feats[0].shape[0]) == absorbed
+    hyps, _ = get_translator(opt).translate_batch([model], {"feats": _dev(feats)})
     ref_hyps, _ = golden.hyps()
     enc = care_cpu.encoding_phase(P, opt, feats)
     inputs = care_cpu.inputs_for_decoder(opt, enc)

@@ -25,6 +25,10 @@ def _setup(config, B, dtype, seed=77, boost=None):
     model.load_state_dict(P, strict=True)
     model.set_compute_dtype(dtype)
     model.to("cuda:0")
+    # one cross-attention form for every batch size of a test (the engine switches to the absorbed
+    # form at 2048 rows by itself; a property that compares a big batch with small chunks of it would
+    # otherwise compare two roundings)
+    model.engine().LATENT_MIN_ROWS = 1
     gen = torch.Generator(device="cuda:0")
     gen.manual_seed(seed)
     feats = [torch.randn(s, generator=gen, device="cuda:0") for s in feat_shapes(opt, B)]
@@ -161,3 +165,16 @@ def test_absorbed_cross_attention_equals_projected_kv(config, B):
             assert abs(float(out[True][2][i]) - float(out[False][2][i])) < 0.05 * max(1, n)
     # both are within bf16 noise of the fp32 result; they may part ways at a near-tie only
     assert same >= 0.93 * B, "only {}/{} captions agree".format(same, B)
+
+
+def test_absorbed_form_switches_on_at_2048_rows():
+    from care_amd.engine import HipEngine
+
+    opt, P, model, feats = _setup("msrvtt_base_ami", 8, "bf16")
+    eng = model.engine()
+    eng.LATENT_MIN_ROWS = HipEngine.LATENT_MIN_ROWS
+    assert eng.latent_capable and not eng.latent_for(2047) and eng.latent_for(2048)
+    eng.latent = False
+    assert not eng.latent_for(1 << 20)
+    opt, P, model, feats = _setup("msrvtt_base_ami", 8, "fp32")
+    assert not model.engine().latent_capable and not model.engine().latent_for(1 << 20)
