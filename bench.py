@@ -197,7 +197,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        traffic = tj.get("{}|{}|B{}|{}".format(args.config, args.dtype, B, dom))
+        key = "{}|{}|B{}|{}".format(args.config, args.dtype, B, dom)
+        if dom == "step_cross_attn" and not eng.latent_for(B):
+            key += "|projected_kv"  # the K/V-reading kernel (CARE_LATENT=0, fp32, or < 2048 rows)
+        traffic = tj.get(key)
     roofline = dict(kernel=dom, bound=km["bound"], achieved=round(achieved, 2), peak=peak, unit=unit,
                     frac=round(achieved / peak, 4), traffic=traffic,
                     avg_launch_us=round(kernels[dom]["avg_us"], 2), avg_launch_us_back_to_back=round(dom_b2b_us, 2),
