@@ -19,6 +19,12 @@
 //   * epilogue: the accumulators (swapped operand order: a lane holds 4 consecutive columns of a
 //     row) are parked in LDS and finished row-wise, one wave per row, so every residual / bias /
 //     gamma / beta load and both stores are coalesced and the statistics are wave shuffles.
+//
+// Tried and dropped (round 1): an A-stationary variant with 16 rows per wave and the accumulators
+// of all 512 columns in registers (W streamed once per 64-row block through 16-KiB DMA tiles,
+// LayerNorm finished in registers).  One MFMA per 1-KiB B-fragment read makes it LDS-read bound:
+// 43.7 us (K = 512) / 103.6 us (K = 2048) at M = 16384 against 37 / 75 us here, where a wave's
+// 64 x 128 tile feeds 32 MFMAs from 12 fragment reads.
 #include <cstdlib>
 
 #include "care_common.h"
