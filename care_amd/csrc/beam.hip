@@ -98,6 +98,80 @@ __global__ __launch_bounds__(256) void beam_select_kernel(const float* logits, i
   }
 }
 
+// One WAVE per row, one pass: 16-byte loads, online (max, sum-exp) with a single exp per logit,
+// a thread-local sorted top-bm behind a threshold test, then bm rounds of wave-wide arg-best
+// (value desc, index asc) - no LDS, no barrier.  The 256-thread two-pass kernel above scans the
+// [rows, V] logits at 1.2 TB/s (735 us for 20480 x 10547: 28% of a beam-5 pass); it stays as the
+// fallback for rows that are not 16-byte aligned.
+__global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logits, int64_t ldl, int V, int bm,
+                                                               float* cand_val, int32_t* cand_idx, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* x = logits + (int64_t)r * ldl;
+  float tv[MAXBM];
+  int ti[MAXBM];
+#pragma unroll
+  for (int j = 0; j < MAXBM; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+  float m = -1e30f, s = 0.f;  // finite sentinel: a lane that saw nothing merges as exp(-1e30 - max) = 0
+  auto take = [&](float v, int c) {
+    const bool up = v > m;
+    const float mn = up ? v : m;
+    const float e = expf((up ? m : v) - mn);  // rescale factor if v is the new max, else the new term
+    s = up ? fmaf(s, e, 1.0f) : s + e;
+    m = mn;
+    if (v > tv[bm - 1]) {  // strictly greater: a lane meets its columns in ascending order
+      float cv = v; int ci = c;
+#pragma unroll
+      for (int j = 0; j < MAXBM; ++j) {
+        if (j < bm && cv > tv[j]) {
+          const float ov = tv[j]; const int oi = ti[j];
+          tv[j] = cv; ti[j] = ci; cv = ov; ci = oi;
+        }
+      }
+    }
+  };
+  const int nv4 = V >> 2;
+  int c4 = lane;
+  for (; c4 + 192 < nv4; c4 += 256) {  // four 1-KiB loads of the wave in flight
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (int64_t)(c4 + u * 64) * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) take(v[u][j], (c4 + u * 64) * 4 + j);
+  }
+  for (; c4 < nv4; c4 += 64) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)c4 * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) take(v[j], c4 * 4 + j);
+  }
+  if (nv4 * 4 + lane < V) take(x[nv4 * 4 + lane], nv4 * 4 + lane);
+
+  const float mx = care_wave_max(m);
+  const float logsum = logf(care_wave_sum(s * expf(m - mx)));
+  for (int k = 0; k < bm; ++k) {
+    float v = tv[0];
+    int id = ti[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(id, o, 64);
+      if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; }
+    }
+    if (lane == 0) {
+      cand_val[(int64_t)r * bm + k] = (v - mx) - logsum;  // log_softmax = (x - max) - log(sum)
+      cand_idx[(int64_t)r * bm + k] = id;
+    }
+    if (ti[0] == id) {  // column indices are unique: exactly one lane pops its head
+#pragma unroll
+      for (int j = 0; j + 1 < MAXBM; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+      tv[MAXBM - 1] = -INFINITY; ti[MAXBM - 1] = 0x7fffffff;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void beam_advance_kernel(
     const float* cand_val, const int32_t* cand_idx, float* scores, int bm, int32_t* tokphys, const int32_t* anc_old,
     int32_t* anc_new, int32_t* done, int32_t* n_fin, float* fin_score, int32_t* fin_len, int32_t* fin_hyp, int fin_cap,
@@ -190,8 +264,12 @@ extern "C" int care_beam_select(const float* logits, int64_t ldl, int V, int bm,
                                 int rows, void* stream) {
   if (!logits || !cand_val || !cand_idx || rows <= 0 || V <= 0) return CARE_EINVAL;
   if (bm <= 0 || bm > MAXBM || bm > V) return CARE_ESHAPE;
-  hipLaunchKernelGGL(beam_select_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, bm, cand_val,
-                     cand_idx, rows);
+  if ((ldl % 4) == 0 && care_aligned16(logits))
+    hipLaunchKernelGGL(beam_select_wave_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl,
+                       V, bm, cand_val, cand_idx, rows);
+  else
+    hipLaunchKernelGGL(beam_select_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, bm, cand_val,
+                       cand_idx, rows);
   return care_launch_status();
 }
 

@@ -220,20 +220,29 @@ def test_concept_kernels():
     assert mem[:, :84].abs().max().item() == 0
 
 
-def test_beam_select():
-    rows, V, bm = 7, 10547, 5
-    logits = _rand(rows, V, seed=24, scale=2.0)
-    logits[2, 100] = logits[2, 5000] = logits[2].max() + 1.0  # tie for the top spot
+@pytest.mark.parametrize("rows,V,ld,bm", [(7, 10547, 10547, 5), (7, 10547, 10560, 5), (130, 10547, 10560, 8),
+                                          (5, 300, 320, 1), (9, 17, 20, 5), (3, 5, 8, 5), (4, 1029, 1032, 3)])
+def test_beam_select(rows, V, ld, bm):
+    """Both kernels behind care_beam_select: the wave-per-row one (16-byte aligned rows) and the
+    block-per-row fallback (ld % 4 != 0): top-bm (value desc, index asc) as log-probabilities."""
+    buf = torch.full((rows, ld), float("nan"), device=DEV)
+    logits = buf[:, :V]
+    logits.copy_(_rand(rows, V, seed=24 + V, scale=2.0))
+    if V > 5000:
+        logits[2, 100] = logits[2, 5000] = logits[2].max() + 1.0  # tie for the top spot, far apart
+        logits[3, 64] = logits[3, 65] = logits[3, 4 * 64 + 1] = logits[3].max() + 0.5  # ties within / across lanes
+    if V >= 17:
+        logits[1, 3] = float("-inf")
     cv = torch.zeros(rows, bm, device=DEV)
     ci = torch.zeros(rows, bm, device=DEV, dtype=torch.int32)
-    _call("care_beam_select", _p(logits), V, V, bm, _p(cv), _p(ci), rows)
-    lp = torch.log_softmax(logits, dim=1)
+    _call("care_beam_select", _p(buf), ld, V, bm, _p(cv), _p(ci), rows)
+    lp = torch.log_softmax(logits.double(), dim=1)
     torch.cuda.synchronize()
     x = logits.cpu().numpy()
     for r in range(rows):
         order = sorted(range(V), key=lambda j: (-x[r, j], j))[:bm]
         assert ci[r].tolist() == order
-    assert (cv - lp.gather(1, ci.long())).abs().max().item() < 1e-5
+    assert (cv.double() - lp.gather(1, ci.long())).abs().max().item() < 1e-5
 
 
 def test_rejected_arguments_raise():
