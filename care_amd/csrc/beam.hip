@@ -258,6 +258,120 @@ __global__ __launch_bounds__(64) void beam_advance_kernel(
   if (is_done) done[b] = 1;
 }
 
+// One WAVE per clip: the bm x bm candidates one per lane (bm rounds of wave-wide arg-best: value
+// desc, flat index asc - the flattened topk order of Beam.py:60), the ancestor rows copied one
+// position per lane.  The one-thread-per-clip kernel above runs ~200 dependent memory operations
+// in series (195 us per step for 4096 clips, 9% of a beam-5 pass); it stays as the fallback for
+// tables wider than a wave (stride > 64).
+__global__ __launch_bounds__(256) void beam_advance_wave_kernel(
+    const float* cand_val, const int32_t* cand_idx, float* scores, int bm, int32_t* tokphys, const int32_t* anc_old,
+    int32_t* anc_new, int32_t* done, int32_t* n_fin, float* fin_score, int32_t* fin_len, int32_t* fin_hyp, int fin_cap,
+    int t, int max_steps, int need, int eos_id, int V, int stride, int B) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;  // wave-uniform
+  const int row0 = b * bm;
+
+  if (done[b]) {
+    // frozen clip: keep the tables valid so the (ignored) rows keep reading defined memory
+    for (int i = 0; i < bm; ++i) {
+      const int64_t o = (int64_t)(row0 + i) * stride;
+      if (lane < t) anc_new[o + lane] = anc_old[o + lane];
+      if (lane == 0) { anc_new[o + t] = row0 + i; tokphys[o + t] = eos_id; }
+    }
+    return;
+  }
+
+  // --- candidate pool, lane c = i * bm + j: (value, flat index i*V + col); ended beams offer nothing
+  // (Beam.py:52-54); first step: row 0 only (Beam.py:55-56)
+  const int n_src = (t == 1) ? 1 : bm;
+  const int ci = lane / bm, cj = lane % bm;
+  bool live = lane < n_src * bm;
+  if (live && t > 1) {
+    const int prow = anc_old[(int64_t)(row0 + ci) * stride + (t - 1)];
+    if (tokphys[(int64_t)prow * stride + (t - 1)] == eos_id) live = false;
+  }
+  float v = -INFINITY;
+  int col = 0;
+  long flat = 0x7fffffffffffffffL;
+  if (live) {
+    v = cand_val[(int64_t)(row0 + ci) * bm + cj];
+    col = cand_idx[(int64_t)(row0 + ci) * bm + cj];
+    if (t > 1) v = v + scores[row0 + ci];
+    flat = (long)ci * V + col;
+  }
+  float sc[MAXBM];
+  int parent[MAXBM], tok[MAXBM];
+#pragma unroll
+  for (int k = 0; k < MAXBM; ++k) {
+    sc[k] = -1e20f; parent[k] = 0; tok[k] = eos_id;
+    if (k < bm) {
+      float bv = live ? v : -INFINITY;
+      long bf = live ? flat : 0x7fffffffffffffffL;
+      int bl = live ? lane : -1;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int olo = __shfl_xor((int)(bf & 0xffffffffL), o, 64), ohi = __shfl_xor((int)(bf >> 32), o, 64);
+        const int ol = __shfl_xor(bl, o, 64);
+        const long of = ((long)ohi << 32) | (unsigned int)olo;
+        // a lane without a candidate (-1) never wins; among candidates: value desc, flat index asc
+        if (ol >= 0 && (bl < 0 || ov > bv || (ov == bv && of < bf))) { bv = ov; bf = of; bl = ol; }
+      }
+      if (bl >= 0) {  // (fewer live candidates than beams cannot happen while topk <= beam_size)
+        sc[k] = bv; parent[k] = bl / bm; tok[k] = __shfl(col, bl, 64);
+        if (lane == bl) live = false;
+      }
+    }
+  }
+
+  // --- rewire ancestors (lane = position), record tokens and scores
+  int anew[MAXBM];  // anc_new[row0 + i][lane] for lane < t
+#pragma unroll
+  for (int i = 0; i < MAXBM; ++i) {
+    anew[i] = 0;
+    if (i < bm) {
+      const int64_t dst = (int64_t)(row0 + i) * stride, src = (int64_t)(row0 + parent[i]) * stride;
+      if (lane < t) { anew[i] = anc_old[src + lane]; anc_new[dst + lane] = anew[i]; }
+      if (lane == 0) { anc_new[dst + t] = row0 + i; tokphys[dst + t] = tok[i]; scores[row0 + i] = sc[i]; }
+    }
+  }
+
+  // --- finished hypotheses, in beam order, stop as soon as `need` are collected (Beam.py:72-77)
+  int nf = n_fin[b];
+  bool is_done = false;
+  auto record = [&](int i_anew, int i_tok, float i_sc) {  // hypothesis of one beam: positions 1..t, one per lane
+    if (nf < fin_cap) {
+      const int64_t slot = (int64_t)b * fin_cap + nf;
+      if (lane == 0) { fin_score[slot] = i_sc; fin_len[slot] = t; }
+      if (lane >= 1 && lane <= t) {
+        // position t is the token just chosen (not read back from memory this wave has just written)
+        const int token = lane < t ? tokphys[(int64_t)i_anew * stride + lane] : i_tok;
+        fin_hyp[slot * stride + (lane - 1)] = token;
+      }
+    }
+    ++nf;
+  };
+#pragma unroll
+  for (int i = 0; i < MAXBM; ++i)
+    if (i < bm && !is_done && tok[i] == eos_id) {
+      record(anew[i], tok[i], sc[i]);
+      if (nf >= need) is_done = true;
+    }
+  if (!is_done && t >= max_steps) {  // Beam.py:79-84
+    is_done = true;
+    if (nf == 0) {
+#pragma unroll
+      for (int i = 0; i < MAXBM; ++i)
+        if (i < bm) record(anew[i], tok[i], sc[i]);
+    }
+  }
+  if (lane == 0) {
+    n_fin[b] = nf;
+    if (is_done) done[b] = 1;
+  }
+}
+
 }  // namespace
 
 extern "C" int care_beam_select(const float* logits, int64_t ldl, int V, int bm, float* cand_val, int32_t* cand_idx,
@@ -281,8 +395,13 @@ extern "C" int care_beam_advance(const float* cand_val, const int32_t* cand_idx,
       !fin_len || !fin_hyp || B <= 0)
     return CARE_EINVAL;
   if (bm <= 0 || bm > MAXBM || t <= 0 || t >= stride || need > fin_cap) return CARE_ESHAPE;
-  hipLaunchKernelGGL(beam_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx,
-                     scores, bm, tokphys, anc_old, anc_new, done, n_fin, fin_score, fin_len, fin_hyp, fin_cap, t,
-                     max_steps, need, eos_id, V, stride, B);
+  if (stride <= 64)
+    hipLaunchKernelGGL(beam_advance_wave_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, cand_val,
+                       cand_idx, scores, bm, tokphys, anc_old, anc_new, done, n_fin, fin_score, fin_len, fin_hyp,
+                       fin_cap, t, max_steps, need, eos_id, V, stride, B);
+  else
+    hipLaunchKernelGGL(beam_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx,
+                       scores, bm, tokphys, anc_old, anc_new, done, n_fin, fin_score, fin_len, fin_hyp, fin_cap, t,
+                       max_steps, need, eos_id, V, stride, B);
   return care_launch_status();
 }
