@@ -98,77 +98,178 @@ __global__ __launch_bounds__(256) void beam_select_kernel(const float* logits, i
   }
 }
 
-// One WAVE per row, one pass: 16-byte loads, online (max, sum-exp) with a single exp per logit,
-// a thread-local sorted top-bm behind a threshold test, then bm rounds of wave-wide arg-best
-// (value desc, index asc) - no LDS, no barrier.  The 256-thread two-pass kernel above scans the
-// [rows, V] logits at 1.2 TB/s (735 us for 20480 x 10547: 28% of a beam-5 pass); it stays as the
-// fallback for rows that are not 16-byte aligned.
+// One WAVE per row, one pass over HBM.  The row is taken in chunks of 64 logits per lane held in
+// registers (16 x 16-byte loads issued together: 16 KiB of the row in flight per wave):
+//   A. branch-free per logit: online (max, sum-exp) with a single exp, and the lane's chunk maximum;
+//   B. a threshold tau = max(k-th entry of the wave's top-bm list so far, k-th largest of the 64 lane
+//      maxima of this chunk) - both are lower bounds of the final k-th best, so nothing >= the final
+//      k-th best is dropped - and every logit >= tau is appended to a per-wave LDS list (a divergent
+//      branch that is almost never taken: ~10 candidates per chunk);
+//   C. ONE rolled copy of the exact selection: the listed candidates, one per lane, enter the wave's
+//      sorted top-bm list (replicated in every lane) by best-first rounds of wave arg-best
+//      (value desc, index asc).
+// If a chunk lists more candidates than the LDS list holds (thousands of equal logits), the chunk is
+// re-scanned from memory 64 logits at a time through the same rounds.
+// Measured for 20480 x 10547 (a beam-5 step of 4096 clips): 251 us = 3.4 TB/s.  History: 256-thread
+// two-pass kernel (above, still the fallback for rows that are not 16-byte aligned) 735 us = 28% of
+// a beam-5 pass; per-lane top-bm lists 406 us (the divergent insertion path runs in nearly every
+// iteration); the rounds inlined per logit: 32 K instructions, slower still (instruction fetch);
+// this structure with xor-shuffle reductions for the threshold and arg-best rounds for the listed
+// candidates 350-420 us - each such reduction is six DEPENDENT ds_bpermute round trips, so the
+// threshold now uses a DPP maximum (care_wave_max_dpp), only in the first chunk, and the listed
+// candidates are inserted from LDS broadcast reads.  Ablation: streaming skeleton ~200 us,
+// statistics ~45 us with the fast exp (accurate expf: +57 us; the fp32 beam fixtures do not move).
+constexpr int BS_CAP = 192;  // candidates per wave and chunk
+#ifndef CARE_BS_DBG
+#define CARE_BS_DBG 0  // ablation builds (tools/beam_select_probe.py): 1 no statistics, 2 no candidate list / selection, 4 accurate expf
+#endif
+#if CARE_BS_DBG & 4
+#define BS_EXP expf
+#else
+#define BS_EXP __expf
+#endif
+
 __global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logits, int64_t ldl, int V, int bm,
                                                                float* cand_val, int32_t* cand_idx, int rows) {
-  const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
+  __shared__ float lval[4][BS_CAP];
+  __shared__ int lidx[4][BS_CAP];
+  __shared__ int lcnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= rows) return;  // wave-uniform; no block-wide barrier below
   const float* x = logits + (int64_t)r * ldl;
-  float tv[MAXBM];
+  float tv[MAXBM];  // the wave's top-bm so far, identical in all lanes, sorted (value desc, index asc)
   int ti[MAXBM];
 #pragma unroll
   for (int j = 0; j < MAXBM; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
   float m = -1e30f, s = 0.f;  // finite sentinel: a lane that saw nothing merges as exp(-1e30 - max) = 0
-  auto take = [&](float v, int c) {
-    const bool up = v > m;
-    const float mn = up ? v : m;
-    const float e = expf((up ? m : v) - mn);  // rescale factor if v is the new max, else the new term
-    s = up ? fmaf(s, e, 1.0f) : s + e;
-    m = mn;
-    if (v > tv[bm - 1]) {  // strictly greater: a lane meets its columns in ascending order
-      float cv = v; int ci = c;
+
+  auto insert = [&](float cv, int ci) {  // wave-uniform (cv, ci) into the sorted list
+#pragma unroll
+    for (int j = 0; j < MAXBM; ++j) {
+      if (j < bm && (cv > tv[j] || (cv == tv[j] && ci < ti[j]))) {
+        const float ov = tv[j]; const int oi = ti[j];
+        tv[j] = cv; ti[j] = ci; cv = ov; ci = oi;
+      }
+    }
+  };
+  // best-first rounds: every lane may hold one candidate (v, c); c = INT_MAX means none
+  auto rounds = [&](float v, int c) {
+    bool cand = c != 0x7fffffff && (v > tv[bm - 1] || (v == tv[bm - 1] && c < ti[bm - 1]));
+    while (__any(cand)) {
+      float bv = cand ? v : -INFINITY;
+      int bc = cand ? c : 0x7fffffff;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oc = __shfl_xor(bc, o, 64);
+        if (oc != 0x7fffffff && (bc == 0x7fffffff || ov > bv || (ov == bv && oc < bc))) { bv = ov; bc = oc; }
+      }
+      float cv = bv;
+      int ci = bc;
 #pragma unroll
       for (int j = 0; j < MAXBM; ++j) {
-        if (j < bm && cv > tv[j]) {
+        if (j < bm && (cv > tv[j] || (cv == tv[j] && ci < ti[j]))) {
           const float ov = tv[j]; const int oi = ti[j];
           tv[j] = cv; ti[j] = ci; cv = ov; ci = oi;
         }
       }
+      cand = cand && c != bc && (v > tv[bm - 1] || (v == tv[bm - 1] && c < ti[bm - 1]));
     }
   };
-  const int nv4 = V >> 2;
-  int c4 = lane;
-  for (; c4 + 192 < nv4; c4 += 256) {  // four 1-KiB loads of the wave in flight
-    f32x4 v[4];
+
+  const int nv4 = V >> 2;  // whole 16-byte groups; the V % 4 tail is handled at the end
+  for (int base = 0; base < nv4; base += 1024) {  // 16 groups per lane: group (base + u*64 + lane)
+    f32x4 v[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (int64_t)(c4 + u * 64) * 4);
+    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (int64_t)min(base + u * 64 + lane, nv4 - 1) * 4);
+    // ---- A: statistics
+    float qmax[4];  // maximum of each quarter of the chunk (16 logits per lane)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int q = 0; q < 4; ++q) qmax[q] = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) take(v[u][j], (c4 + u * 64) * 4 + j);
+    for (int u = 0; u < 16; ++u) {
+      if (base + u * 64 + lane >= nv4) v[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e0 = v[u][j];
+        qmax[u >> 2] = fmaxf(qmax[u >> 2], e0);
+        if (CARE_BS_DBG & 1) continue;
+        const bool up = e0 > m;
+        const float mn = up ? e0 : m;
+        const float e = BS_EXP((up ? m : e0) - mn);  // rescale factor if e0 is the new max, else the new term
+        s = up ? fmaf(s, e, 1.0f) : s + e;
+        m = mn;
+      }
+    }
+    const float lmax = fmaxf(fmaxf(qmax[0], qmax[1]), fmaxf(qmax[2], qmax[3]));
+    // ---- B: threshold and candidate list
+    float tau = tv[bm - 1];
+    if (base == 0) {  // first chunk: the list is empty; k-th largest lane maximum (ties only make it more conservative)
+      float y = lmax, kth = -INFINITY;
+      for (int k = 0; k < bm; ++k) {
+        kth = care_wave_max_dpp(y);
+        if (y == kth) y = -INFINITY;
+      }
+      tau = kth;
+    }
+    if (lane == 0) lcnt[wave] = 0;
+    if (CARE_BS_DBG & 2) { m = fmaxf(m, tau); continue; }
+    // one wave-uniform test per quarter (a skipped per-logit branch is a TAKEN branch: 192 of them per
+    // row cost more than the statistics); only a quarter that holds a candidate in some lane is scanned
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (__builtin_expect(__any(qmax[q] >= tau && qmax[q] > -INFINITY), 0)) {
+#pragma unroll
+        for (int u = q * 4; u < q * 4 + 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (__builtin_expect(v[u][j] >= tau && v[u][j] > -INFINITY, 0)) {
+              const int pos = atomicAdd(&lcnt[wave], 1);
+              if (pos < BS_CAP) { lval[wave][pos] = v[u][j]; lidx[wave][pos] = (base + u * 64 + lane) * 4 + j; }
+            }
+      }
+    const int n = lcnt[wave];  // same wave: LDS operations complete in order
+    // ---- C: selection.  The listed candidates enter the list one after the other, read by every
+    // lane from the same LDS address (broadcast) - no cross-lane reduction (an arg-best round is six
+    // dependent ds_bpermute round trips; ~20 of them per row cost more than the statistics).
+    if (n <= BS_CAP) {
+      for (int i = 0; i < n; ++i) insert(lval[wave][i], lidx[wave][i]);
+    } else {  // list overflow: the chunk again, from memory
+      const int c_end = min((base + 1024) * 4, nv4 * 4);
+      for (int c0 = base * 4; c0 < c_end; c0 += 64) {
+        const int c = c0 + lane;
+        rounds(c < c_end ? x[c < c_end ? c : 0] : 0.f, c < c_end ? c : 0x7fffffff);
+      }
+    }
   }
-  for (; c4 < nv4; c4 += 64) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)c4 * 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) take(v[j], c4 * 4 + j);
+  {  // the V % 4 tail logits
+    const int c = nv4 * 4 + lane;
+    const bool in = c < V;
+    const float e0 = in ? x[in ? c : 0] : -INFINITY;
+    const bool up = e0 > m;
+    const float mn = up ? e0 : m;
+    const float e = BS_EXP((up ? m : e0) - mn);
+    s = up ? fmaf(s, e, 1.0f) : s + e;
+    m = mn;
+    if (lane == 0) lcnt[wave] = 0;
+    if (in && (e0 > tv[bm - 1] || (e0 == tv[bm - 1] && c < ti[bm - 1]))) {
+      const int pos = atomicAdd(&lcnt[wave], 1);  // at most 3 entries
+      lval[wave][pos] = e0; lidx[wave][pos] = c;
+    }
+    const int n = lcnt[wave];
+    for (int i = 0; i < n; ++i) insert(lval[wave][i], lidx[wave][i]);
   }
-  if (nv4 * 4 + lane < V) take(x[nv4 * 4 + lane], nv4 * 4 + lane);
 
   const float mx = care_wave_max(m);
-  const float logsum = logf(care_wave_sum(s * expf(m - mx)));
-  for (int k = 0; k < bm; ++k) {
-    float v = tv[0];
-    int id = ti[0];
+  const float logsum = logf(care_wave_sum(s * BS_EXP(m - mx)));
+  if (lane == 0) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(v, o, 64);
-      const int oi = __shfl_xor(id, o, 64);
-      if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; }
-    }
-    if (lane == 0) {
-      cand_val[(int64_t)r * bm + k] = (v - mx) - logsum;  // log_softmax = (x - max) - log(sum)
-      cand_idx[(int64_t)r * bm + k] = id;
-    }
-    if (ti[0] == id) {  // column indices are unique: exactly one lane pops its head
-#pragma unroll
-      for (int j = 0; j + 1 < MAXBM; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
-      tv[MAXBM - 1] = -INFINITY; ti[MAXBM - 1] = 0x7fffffff;
-    }
+    for (int k = 0; k < MAXBM; ++k)
+      if (k < bm) {
+        cand_val[(int64_t)r * bm + k] = (tv[k] - mx) - logsum;  // log_softmax = (x - max) - log(sum)
+        cand_idx[(int64_t)r * bm + k] = ti[k];
+      }
   }
 }
 

@@ -31,6 +31,25 @@ __device__ __forceinline__ float care_wave_max(float v) {
   return v;
 }
 
+// Wave-wide maximum through the DPP data path: an inclusive max-scan along each row of 16 lanes
+// (row_shr 1, 2, 4, 8), then row_bcast15 / row_bcast31 carry the row results to lane 63, which is
+// broadcast.  ~8 VALU operations; the xor-shuffle version is 6 DEPENDENT ds_bpermute round trips
+// through the LDS crossbar (~100 cycles each).  All 64 lanes must be active.
+__device__ __forceinline__ float care_wave_max_dpp(float v) {
+#define CARE_DPP_MAX(CTRL, ROWMASK)                                                                       \
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),          \
+                                                                     __builtin_bit_cast(int, v), CTRL, ROWMASK, \
+                                                                     0xF, false)))
+  CARE_DPP_MAX(0x111, 0xF);  // row_shr:1
+  CARE_DPP_MAX(0x112, 0xF);  // row_shr:2
+  CARE_DPP_MAX(0x114, 0xF);  // row_shr:4
+  CARE_DPP_MAX(0x118, 0xF);  // row_shr:8 -> lane 15 of every row holds the row maximum
+  CARE_DPP_MAX(0x142, 0xA);  // row_bcast15 into rows 1 and 3
+  CARE_DPP_MAX(0x143, 0xC);  // row_bcast31 into rows 2 and 3 -> lane 63 holds the wave maximum
+#undef CARE_DPP_MAX
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // load 8 consecutive elements of a K/V row as fp32
 __device__ __forceinline__ void care_load8(const float* p, float (&o)[8]) {
   float4 a = *reinterpret_cast<const float4*>(p);
