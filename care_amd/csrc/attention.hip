@@ -137,9 +137,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     float d = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) d = fmaf(q[i], kv[i], d);
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
+    // 8-lane sum through DPP (quad_perm, quad_perm, row_half_mirror): the xor-shuffle version is
+    // three dependent ds_bpermute round trips per key block
+    d += care_dpp_x1(d);
+    d += care_dpp_x2(d);
+    d += care_dpp_m8(d);
     d *= 0.125f;  // 1/sqrt(64), exact
     if constexpr (EXTRA) {
       const int src = (lane & 56) | (kb & 7);
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
   float m = s[0];
 #pragma unroll
   for (int kb = 1; kb < NKB; ++kb) m = fmaxf(m, s[kb]);
-  m = fmaxf(m, __shfl_xor(m, 8, 64));
+  m = fmaxf(m, care_dpp_x8(m));
   m = fmaxf(m, __shfl_xor(m, 16, 64));
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float sum = 0.f;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     s[kb] = expf(s[kb] - m);  // -inf -> 0 for the padding slots
     sum += s[kb];
   }
-  sum += __shfl_xor(sum, 8, 64);
+  sum += care_dpp_x8(sum);
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    acc[i] += __shfl_xor(acc[i], 8, 64);
+    acc[i] += care_dpp_x8(acc[i]);
     acc[i] += __shfl_xor(acc[i], 16, 64);
     acc[i] += __shfl_xor(acc[i], 32, 64);
   }

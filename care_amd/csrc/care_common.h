@@ -50,6 +50,21 @@ __device__ __forceinline__ float care_wave_max_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Lane exchanges through the DPP data path (no LDS-crossbar round trip), for reductions:
+//   care_dpp_x1 / _x2 : the value of lane ^ 1 / lane ^ 2 (quad_perm);
+//   care_dpp_m8       : the value of the mirrored lane of the 8-lane group (row_half_mirror) - after
+//                       the x1, x2 steps of a sum / max every quad holds one value, so this is the
+//                       lane ^ 4 step of the reduction, bit for bit;
+//   care_dpp_x8       : the value of lane ^ 8 (row_ror:8).
+template <int CTRL>
+__device__ __forceinline__ float care_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float care_dpp_x1(float v) { return care_dpp<0xB1>(v); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float care_dpp_x2(float v) { return care_dpp<0x4E>(v); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float care_dpp_m8(float v) { return care_dpp<0x141>(v); }  // row_half_mirror
+__device__ __forceinline__ float care_dpp_x8(float v) { return care_dpp<0x128>(v); }  // row_ror:8
+
 // load 8 consecutive elements of a K/V row as fp32
 __device__ __forceinline__ void care_load8(const float* p, float (&o)[8]) {
   float4 a = *reinterpret_cast<const float4*>(p);
