@@ -24,7 +24,9 @@
 // of all 512 columns in registers (W streamed once per 64-row block through 16-KiB DMA tiles,
 // LayerNorm finished in registers).  One MFMA per 1-KiB B-fragment read makes it LDS-read bound:
 // 43.7 us (K = 512) / 103.6 us (K = 2048) at M = 16384 against 37 / 75 us here, where a wave's
-// 64 x 128 tile feeds 32 MFMAs from 12 fragment reads.
+// 64 x 128 tile feeds 32 MFMAs from 12 fragment reads.  With 32 rows per wave (256 accumulator
+// registers in AGPRs, one wave per SIMD) for the embedder shape (M = 458752, fp32 features) it is
+// not LDS-bound any more and still loses: 2.41 ms (K = 2048) / 0.90 ms (K = 512) against 2.09 / 0.80.
 #include <cstdlib>
 
 #include "care_common.h"

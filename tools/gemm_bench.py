@@ -65,7 +65,8 @@ def ln_main():
         out = torch.empty(M, 512, device=DEV)
         outb = torch.empty(M, 512, device=DEV, dtype=torch.bfloat16)
         p = lambda t: t.data_ptr()
-        t = time_call(lambda: _lib.call("care_gemm_ln", p(Ain), K, 0 if f32 else 1, p(W), p(bias), p(res), 512, None,
+        resp = None if f32 else p(res)  # the embedder (raw fp32 features) has no residual
+        t = time_call(lambda: _lib.call("care_gemm_ln", p(Ain), K, 0 if f32 else 1, p(W), p(bias), resp, 512, None,
                                         p(g), p(b), 1e-12, p(out), p(outb), 512, M, 512, K, M, M, 0), iters=5)
         print("gemm_ln M=%6d K=%4d A=%s: %8.1f us (%6.1f TF)" % (M, K, "f32" if f32 else "bf16", t, 2.0 * M * 512 * K / t / 1e6), flush=True)
 
