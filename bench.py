@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16384, help="clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=32768, help="clips per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--config", default="msrvtt_base_ami")
     ap.add_argument("--no-graph", action="store_true")
@@ -110,7 +110,7 @@ def main():
     eng.lanes = args.lanes
     # per-rank inputs: rank r holds clips [r*B, (r+1)*B) of the global batch (weak scaling).
     # Unit-variance features generated ON the device (seeded per rank); the portable CPU generator
-    # (care_amd.synth) would spend a minute producing 1.2 G values for B = 16384.
+    # (care_amd.synth) would spend minutes producing 2.5 G values for B = 32768.
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
     feats = [torch.randn(shape, generator=gen, device=dev, dtype=torch.float32) for shape in feat_shapes(opt, B)]
