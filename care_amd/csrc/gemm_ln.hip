@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256 * RG, RG == 1 ? 1 : 2) void gemm_ln_kernel(LnAr
           o.y = (v[u][h].y - mean) * rstd * gm[h].y + bt[h].y;
           o.z = (v[u][h].z - mean) * rstd * gm[h].z + bt[h].z;
           o.w = (v[u][h].w - mean) * rstd * gm[h].w + bt[h].w;
-          *reinterpret_cast<float4*>(p.out + orow * p.ldo + col) = o;
+          if (p.out) *reinterpret_cast<float4*>(p.out + orow * p.ldo + col) = o;
           if (p.outb) {
             bf16x4 ob;
             ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
@@ -269,11 +269,12 @@ extern "C" int care_gemm_ln(const void* A, int64_t lda, int a_dtype, const void*
                             const float* res, int64_t ldres, const float* pos, const float* gamma, const float* beta,
                             float eps, float* out, void* out_bf16, int64_t ldo, int M, int N, int K, int grp,
                             int out_grp_rows, int out_row_off, void* stream) {
-  if (!A || !W || !gamma || !beta || !out || M <= 0 || K <= 0 || grp <= 0) return CARE_EINVAL;
+  if (!A || !W || !gamma || !beta || (!out && !out_bf16) || M <= 0 || K <= 0 || grp <= 0) return CARE_EINVAL;
   if (a_dtype != CARE_F32 && a_dtype != CARE_BF16) return CARE_EDTYPE;
   if (N != LN_N || K % 32 != 0) return CARE_ESHAPE;
   if (!care_aligned16(A) || !care_aligned16(W) || (lda % (a_dtype == CARE_BF16 ? 8 : 4)) || (ldo % 4) ||
-      (res && (ldres % 4)) || !care_aligned16(out) || (bias && !care_aligned16(bias)))
+      (res && (ldres % 4)) || (out && !care_aligned16(out)) || (out_bf16 && !care_aligned16(out_bf16)) ||
+      (bias && !care_aligned16(bias)))
     return CARE_EALIGN;
   LnArgs p{};
   p.A = A; p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.bias = bias; p.res = res; p.ldres = ldres;

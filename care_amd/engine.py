@@ -294,7 +294,7 @@ class HipEngine:
         out_grp_rows = grp if out_grp_rows is None else out_grp_rows
         call("care_gemm_ln", ptr(A), A.stride(0), _code(A), ptr(W), ptr(bias), ptr(res),
              res.stride(0) if res is not None else 0, ptr(pos), ptr(g), ptr(be), self.eps, ptr(out), ptr(outb),
-             out.stride(-2), rows, self.d, K, grp, out_grp_rows, out_row_off, tag=tag)
+             (out if out is not None else outb).stride(-2), rows, self.d, K, grp, out_grp_rows, out_row_off, tag=tag)
         return out
 
     def attention(self, Q, K, V, ctx, kv_batch_stride, kv_row_stride, rows_per_kv, nkeys, anc=None, causal=False,
@@ -347,15 +347,28 @@ class HipEngine:
         return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, **ln_kw)
 
     # ------------------------------------------------------------------ encoder + concept head
-    def encode(self, feats: List[torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """`Seq2SeqBase.encoding_phase` (models/Framework.py:150-187); outputs are fresh tensors."""
+    @property
+    def lean_ok(self) -> bool:
+        """The captioning loop of a model WITHOUT a concept head consumes nothing of the encoder but the
+        bf16 memory (the A operand of the cross-K/V projection, or what the absorbed cross-attention
+        reads).  `encode(..., lean=True)` then skips what nobody reads: the fp32 copy of the memory
+        (5.6 GB of stores at B = 32768) and the per-modality frame means (a second pass over it)."""
+        if os.environ.get("CARE_LEAN", "1") == "0":  # A/B switch
+            return False
+        return (self.as_ok and self.d == 512 and not self.has_concepts and self.opt["encoder"] == "Embedder" and
+                all(ch in self.dec_mod and int(self.opt["dim_" + ch]) % 32 == 0 for ch in self.modality))
+
+    def encode(self, feats: List[torch.Tensor], lean: bool = False) -> Dict[str, torch.Tensor]:
+        """`Seq2SeqBase.encoding_phase` (models/Framework.py:150-187); outputs are fresh tensors.
+        lean (translate path only, see lean_ok): returns just {"encoder_hidden_states": bf16 memory}."""
         w, d, opt = self.w, self.d, self.opt
         if len(feats) < len(self.modality):
             raise ValueError("expected {} feature tensors, got {}".format(len(self.modality), len(feats)))
         B = feats[0].shape[0]
-        mem = torch.empty(B, self.Lk, d, device=self.device)
+        lean = lean and self.lean_ok
+        mem = None if lean else torch.empty(B, self.Lk, d, device=self.device)
         memb = torch.empty(B, self.Lk, d, device=self.device, dtype=torch.bfloat16) if self.as_ok else None
-        means = torch.empty(B, len(self.modality) * d, device=self.device)
+        means = None if lean else torch.empty(B, len(self.modality) * d, device=self.device)
         for mi, ch in enumerate(self.modality):
             x = feats[mi].to(self.device, torch.float32).contiguous()
             n = x.shape[1]
@@ -389,7 +402,10 @@ class HipEngine:
                     else:
                         h, hb = self.ws("enc_h%d" % (li + 1), (B * n, d)), self.wsb("enc_h%d" % (li + 1), (B * n, d))
                         self._ffn(nm + "_ffn", h1, h1b, h, hb, "enc_")
-            call("care_group_mean", ptr(dst), d, grp_rows, off, n, ptr(means), means.stride(0), mi * d, B, d)
+            if not lean:
+                call("care_group_mean", ptr(dst), d, grp_rows, off, n, ptr(means), means.stride(0), mi * d, B, d)
+        if lean:
+            return {"encoder_hidden_states": memb}
         out: Dict[str, torch.Tensor] = {"encoder_hidden_states": mem}
         out["mean_encoder_hidden_states"] = [means[:, mi * d:(mi + 1) * d] for mi, ch in enumerate(self.modality)
                                              if ch in self.dec_mod]
@@ -461,6 +477,8 @@ class HipEngine:
         if not self.latent_for(rows):
             return self.cross_kv(mem)
         mem = mem.contiguous()
+        if mem.dtype == torch.bfloat16:  # lean encode: the bf16 memory is all there is
+            return (mem,) * self.n_layers
         ref, memb = getattr(self, "_mem_mirror", (None, None))
         if not (memb is not None and ref is not None and ref() is mem):
             memb = self.ws("lat_mem", tuple(mem.shape), torch.bfloat16)
@@ -649,7 +667,7 @@ class HipEngine:
         B, Lk, d = mem.shape
         T = self.T
         steps = T if steps is None else steps
-        mem = mem.to(self.device, torch.float32)
+        mem = mem.to(self.device, mem.dtype if mem.dtype == torch.bfloat16 else torch.float32)  # bf16: lean encode
         sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
         fed = self.ws("g_fed", (B, T + 1), torch.int32)
         score = self.ws("g_score", (B,))
@@ -677,7 +695,7 @@ class HipEngine:
                  ptr(length), ptr(fin), t, T, EOS, B)
         return fed, length, score
 
-    def translate_greedy(self, feats: List[torch.Tensor], use_graph: bool = True):
+    def translate_greedy(self, feats: List[torch.Tensor], use_graph: bool = True, lean: bool = False):
         """encode + greedy decode of one batch; replayed from a hipGraph when possible.
 
         One pass issues ~430 kernel launches (14 per step); driven from Python that is
@@ -686,19 +704,20 @@ class HipEngine:
         is keyed on the input pointers: callers that re-use their feature buffers (bench,
         pinned double-buffered loaders) replay; a first-seen buffer set runs eagerly.
         Returns (enc_outputs, fed, length, score) - static tensors when replayed.
+        lean: the caller reads nothing of enc_outputs (the Translator): encode(..., lean=True).
         """
         feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
         lanes = self.lanes_for(feats[0].shape[0]) if use_graph else 1
         if lanes > 1:
-            return self._translate_greedy_lanes(feats, lanes)
+            return self._translate_greedy_lanes(feats, lanes, lean)
         if not use_graph:
-            enc = self.encode(feats)
+            enc = self.encode(feats, lean)
             return (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
                                               sem_embs=enc.get("semantic_embs")))
-        key = ("greedy", self.latent_ok, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        key = ("greedy", self.latent_ok, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
         entry = self._graphs.get(key)
         if entry is None:
-            enc = self.encode(feats)  # eager pass: allocates every workspace
+            enc = self.encode(feats, lean)  # eager pass: allocates every workspace
             out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
                                              sem_embs=enc.get("semantic_embs")))
             self._graphs[key] = "seen"
@@ -709,7 +728,7 @@ class HipEngine:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                enc = self.encode(feats)
+                enc = self.encode(feats, lean)
                 out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
                                                  sem_embs=enc.get("semantic_embs")))
             entry = (graph, out)
@@ -736,7 +755,7 @@ class HipEngine:
         n = int(env) if env else int(self.lanes)
         return max(1, min(n, B))
 
-    def _translate_greedy_lanes(self, feats, lanes):
+    def _translate_greedy_lanes(self, feats, lanes, lean=False):
         """translate_greedy with the batch cut into `lanes` contiguous clip ranges, each with its own
         workspaces and HIP stream, forked from and joined to the capture stream inside ONE hipGraph.
         Clips are independent, so the results are those of the single-lane pass."""
@@ -754,7 +773,7 @@ class HipEngine:
                     st.wait_stream(cur)
                     with torch.cuda.stream(st):
                         self._lane = i + 1  # workspace namespace of this lane (see ws)
-                        enc = self.encode([f[lo:hi] for f in feats])
+                        enc = self.encode([f[lo:hi] for f in feats], lean)
                         parts.append((enc,) + tuple(self.greedy(enc["encoder_hidden_states"],
                                                                 enc.get("semantic_hidden_states"),
                                                                 sem_embs=enc.get("semantic_embs"))))
@@ -765,7 +784,7 @@ class HipEngine:
             return (_LaneOutputs([pt[0] for pt in parts]),) + tuple(torch.cat([pt[k] for pt in parts], 0)
                                                                      for k in (1, 2, 3))
 
-        key = ("greedy", lanes, self.latent_ok, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        key = ("greedy", lanes, self.latent_ok, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
         entry = self._graphs.get(key)
         if entry is None:
             self._graphs[key] = "seen"
@@ -783,19 +802,19 @@ class HipEngine:
         graph.replay()
         return out
 
-    def translate_beam(self, feats: List[torch.Tensor], bm: int, need: int, use_graph: bool = True):
+    def translate_beam(self, feats: List[torch.Tensor], bm: int, need: int, use_graph: bool = True, lean: bool = False):
         """encode + beam search of one batch, replayed from a hipGraph when the input buffers repeat
         (same policy as translate_greedy).  Returns (enc_outputs, nfin, fscore, flen, fhyp)."""
         feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
 
         def run():
-            enc = self.encode(feats)
+            enc = self.encode(feats, lean)
             return (enc,) + tuple(self.beam(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need,
                                             sem_embs=enc.get("semantic_embs")))
 
         if not use_graph:
             return run()
-        key = ("beam", bm, need, self.latent_ok, tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        key = ("beam", bm, need, self.latent_ok, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
         entry = self._graphs.get(key)
         if entry is None:
             self._graphs[key] = "seen"
@@ -818,7 +837,7 @@ class HipEngine:
         """Beam search of B clips x bm beams, state on the device (csrc/beam.hip)."""
         B, Lk, d = mem.shape
         T, N = self.T, mem.shape[0] * bm
-        mem = mem.to(self.device, torch.float32)
+        mem = mem.to(self.device, mem.dtype if mem.dtype == torch.bfloat16 else torch.float32)  # bf16: lean encode
         sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
         cap = need + bm
         tok = self.ws("b_tok", (N, T + 1), torch.int32)

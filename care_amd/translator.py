@@ -51,7 +51,7 @@ class Translator_ARFormer(object):
             return self._beam(engine, feats, kwargs.get("use_graph", True))
 
     def _greedy(self, engine, feats, use_graph):
-        _, fed, length, score = engine.translate_greedy(list(feats), use_graph=use_graph)
+        _, fed, length, score = engine.translate_greedy(list(feats), use_graph=use_graph, lean=True)
         fed, length, score = fed.cpu(), length.cpu().tolist(), score.cpu()
         hyps, scores = [], []
         n_best = self.topk
@@ -65,7 +65,8 @@ class Translator_ARFormer(object):
         if self.topk > self.beam_size:
             raise ValueError("topk > beam_size is not supported")
         need = max(self.beam_size, self.topk)
-        _, nfin, fscore, flen, fhyp = engine.translate_beam(list(feats), self.beam_size, need, use_graph=use_graph)
+        _, nfin, fscore, flen, fhyp = engine.translate_beam(list(feats), self.beam_size, need, use_graph=use_graph,
+                                                             lean=True)
         nfin, fscore, flen, fhyp = nfin.cpu().tolist(), fscore.cpu(), flen.cpu(), fhyp.cpu()
         hyps, scores = [], []
         n_best = self.topk

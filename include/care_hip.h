@@ -162,8 +162,9 @@ int care_add_ln(const float* x, int64_t ldx, const float* res, int64_t ldres,
  *   A [M, K] fp32 (raw features; rounded to bf16 when multiplied) or bf16; W bf16 [512, K];
  *   bias/gamma/beta fp32 [512]; res (optional) fp32 [M, ldres]; pos (optional) fp32 [grp, 512]
  *   added per row r as pos[r % grp].  Output rows are remapped exactly like care_add_ln
- *   (grp / out_grp_rows / out_row_off); out fp32 and optional bf16 mirror share ldo.
- *   Requires N == 512, K % 32 == 0.
+ *   (grp / out_grp_rows / out_row_off); out fp32 and the bf16 mirror share ldo; either may be
+ *   NULL (not both): a caller that only feeds bf16 GEMMs / the absorbed cross-attention needs no
+ *   fp32 copy.  Requires N == 512, K % 32 == 0.
  */
 int care_gemm_ln(const void* A, int64_t lda, int a_dtype, const void* W, const float* bias,
                  const float* res, int64_t ldres, const float* pos, const float* gamma,

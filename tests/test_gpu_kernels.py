@@ -395,3 +395,22 @@ def test_attention_latent_rejects_bad_arguments():
         _call("care_attention_latent", _p(qt), H * d, _p(mem), 20 * d, d, 1, 129, None, 0, _p(ct), H * d, 2, H, d)
     with pytest.raises(_lib.CareHipError):  # misaligned query
         _call("care_attention_latent", _p(qt) + 2, H * d, _p(mem), 20 * d, d, 1, 20, None, 0, _p(ct), H * d, 2, H, d)
+
+
+@pytest.mark.parametrize("M,K,a_f32", [(200, 2048, True), (28 * 300, 512, True), (1030, 512, False)])
+def test_gemm_ln_bf16_only_output(M, K, a_f32):
+    """care_gemm_ln with out = NULL: only the bf16 mirror is written, with the same values."""
+    A = _rand(M, K, seed=31)
+    Ain = A if a_f32 else A.to(torch.bfloat16)
+    W = _rand(512, K, seed=32, scale=0.05).to(torch.bfloat16)
+    bias, g, b = _rand(512, seed=33), _rand(512, seed=34), _rand(512, seed=35)
+    out = torch.empty(M, 512, device=DEV)
+    ob1 = torch.empty(M, 512, device=DEV, dtype=torch.bfloat16)
+    ob2 = torch.full((M, 512), float("nan"), device=DEV, dtype=torch.bfloat16)
+    args = (_p(Ain), K, 0 if a_f32 else 1, _p(W), _p(bias), None, 0, None, _p(g), _p(b), 1e-12)
+    _call("care_gemm_ln", *args, _p(out), _p(ob1), 512, M, 512, K, M, M, 0)
+    _call("care_gemm_ln", *args, None, _p(ob2), 512, M, 512, K, M, M, 0)
+    assert torch.equal(ob1, ob2)
+    from care_amd import _lib
+    with pytest.raises(_lib.CareHipError):
+        _call("care_gemm_ln", *args, None, None, 512, M, 512, K, M, M, 0)

@@ -178,3 +178,28 @@ def test_absorbed_form_switches_on_at_2048_rows():
     assert not eng.latent_for(1 << 20)
     opt, P, model, feats = _setup("msrvtt_base_ami", 8, "fp32")
     assert not model.engine().latent_capable and not model.engine().latent_for(1 << 20)
+
+
+@pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 300), ("msvd_base_i", 64), ("msrvtt_care", 40)])
+def test_lean_encode_gives_identical_captions(config, B):
+    """translate_greedy / translate_beam with lean=True (what the Translator asks for) skip the fp32
+    copy of the memory and the frame means for models without a concept head; the captions are
+    bit-identical, and models with a concept head ignore the flag."""
+    opt, P, model, feats = _setup(config, B, "bf16", boost={"cls_head.tgt_word_prj.weight": {3: 4.0}})
+    eng = model.engine()
+    assert eng.lean_ok == (config != "msrvtt_care")
+    enc_f, fed_f, len_f, sc_f = eng.translate_greedy(feats, use_graph=False, lean=False)
+    fed_f, len_f, sc_f = fed_f.clone(), len_f.clone(), sc_f.clone()
+    assert enc_f["encoder_hidden_states"].dtype == torch.float32 and "mean_encoder_hidden_states" in enc_f
+    enc_l, fed_l, len_l, sc_l = eng.translate_greedy(feats, use_graph=False, lean=True)
+    assert torch.equal(fed_l, fed_f) and torch.equal(len_l, len_f) and torch.equal(sc_l, sc_f)
+    if eng.lean_ok:
+        assert list(enc_l) == ["encoder_hidden_states"] and enc_l["encoder_hidden_states"].dtype == torch.bfloat16
+    for _ in range(3):  # eager, capture, replay
+        _, fed_g, len_g, sc_g = eng.translate_greedy(feats, use_graph=True, lean=True)
+        assert torch.equal(fed_g, fed_f) and torch.equal(len_g, len_f)
+    _, nfin_f, fsc_f, flen_f, fhyp_f = eng.translate_beam(feats, 3, 2, use_graph=False, lean=False)
+    nfin_f, fsc_f, flen_f, fhyp_f = nfin_f.clone(), fsc_f.clone(), flen_f.clone(), fhyp_f.clone()
+    _, nfin_l, fsc_l, flen_l, fhyp_l = eng.translate_beam(feats, 3, 2, use_graph=False, lean=True)
+    assert torch.equal(nfin_l, nfin_f) and torch.equal(flen_l, flen_f) and torch.equal(fhyp_l, fhyp_f)
+    assert torch.equal(fsc_l, fsc_f)
