@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void beam_select_kernel(const float* logits, i
         if (sred[w] > bv || (sred[w] == bv && sredi[w] < bi)) { bv = sred[w]; bi = sredi[w]; }
       s_bcast[0] = bv; sredi[4] = bi;
       cand_val[(int64_t)r * bm + k] = (bv - mx) - logsum;  // log_softmax = (x - max) - log(sum)
-      cand_idx[(int64_t)r * bm + k] = bi;
+      cand_idx[(int64_t)r * bm + k] = bi == 0x7fffffff ? 0 : bi;  // fewer than bm finite logits: (-inf, 0)
     }
     __syncthreads();
     const int win = sredi[4];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logi
   };
   // best-first rounds: every lane may hold one candidate (v, c); c = INT_MAX means none
   auto rounds = [&](float v, int c) {
-    bool cand = c != 0x7fffffff && (v > tv[bm - 1] || (v == tv[bm - 1] && c < ti[bm - 1]));
+    bool cand = c != 0x7fffffff && v > -INFINITY && (v > tv[bm - 1] || (v == tv[bm - 1] && c < ti[bm - 1]));
     while (__any(cand)) {
       float bv = cand ? v : -INFINITY;
       int bc = cand ? c : 0x7fffffff;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logi
     s = up ? fmaf(s, e, 1.0f) : s + e;
     m = mn;
     if (lane == 0) lcnt[wave] = 0;
-    if (in && (e0 > tv[bm - 1] || (e0 == tv[bm - 1] && c < ti[bm - 1]))) {
+    if (in && e0 > -INFINITY && (e0 > tv[bm - 1] || (e0 == tv[bm - 1] && c < ti[bm - 1]))) {  // -inf is never a candidate
       const int pos = atomicAdd(&lcnt[wave], 1);  // at most 3 entries
       lval[wave][pos] = e0; lidx[wave][pos] = c;
     }
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logi
     for (int k = 0; k < MAXBM; ++k)
       if (k < bm) {
         cand_val[(int64_t)r * bm + k] = (tv[k] - mx) - logsum;  // log_softmax = (x - max) - log(sum)
-        cand_idx[(int64_t)r * bm + k] = ti[k];
+        cand_idx[(int64_t)r * bm + k] = ti[k] == 0x7fffffff ? 0 : ti[k];  // fewer than bm finite logits: (-inf, 0)
       }
   }
 }

@@ -414,3 +414,35 @@ def test_gemm_ln_bf16_only_output(M, K, a_f32):
     from care_amd import _lib
     with pytest.raises(_lib.CareHipError):
         _call("care_gemm_ln", *args, None, None, 512, M, 512, K, M, M, 0)
+
+
+def test_beam_select_massive_ties_take_the_overflow_path():
+    """All-equal rows (every logit reaches the threshold: the per-wave candidate list overflows and
+    the chunk is re-scanned from memory), rows with a plateau of ties around the k-th best, and a row
+    that is -inf except for three entries: the order is still (value desc, index asc)."""
+    rows, V, ld, bm = 6, 10547, 10560, 5
+    buf = torch.zeros(rows, ld, device=DEV)
+    logits = buf[:, :V]
+    logits[1] = -3.25
+    logits[2] = _rand(V, seed=77)
+    logits[2, 2000:2600] = logits[2].max() + 1.0       # a 600-wide plateau at the top
+    logits[3] = _rand(V, seed=78)
+    logits[3, 5:9000:3] = 9.0                          # ~3000 ties spread over all chunks
+    logits[4] = float("-inf")
+    logits[4, [7, 4100, 10546]] = torch.tensor([1.0, 2.0, 1.0], device=DEV)
+    logits[5] = _rand(V, seed=79)
+    cv = torch.zeros(rows, bm, device=DEV)
+    ci = torch.zeros(rows, bm, device=DEV, dtype=torch.int32)
+    _call("care_beam_select", _p(buf), ld, V, bm, _p(cv), _p(ci), rows)
+    torch.cuda.synchronize()
+    x = logits.cpu().numpy()
+    lp = torch.log_softmax(logits.double(), dim=1)
+    for r in range(rows):
+        order = sorted(range(V), key=lambda j: (-x[r, j], j))[:bm]
+        got, ref = cv[r].double().cpu(), lp[r, order].cpu()
+        fin = torch.isfinite(ref)
+        nf = int(fin.sum())
+        # -inf is never a candidate: with fewer than bm finite logits the remaining slots are (-inf, 0)
+        assert ci[r].tolist() == order[:nf] + [0] * (bm - nf), (r, ci[r].tolist(), order)
+        assert torch.equal(torch.isfinite(got), fin)
+        assert (got[fin] - ref[fin]).abs().max().item() < 1e-5
