@@ -260,8 +260,13 @@ extern "C" int care_gemm(const float* A, int64_t lda, const void* W, int wdtype,
   p.C1 = C1; p.ldc1 = ldc1; p.c1_bf16 = c1_dtype == CARE_BF16;
   p.n_split = n_split; p.M = M; p.N = N; p.K = K; p.act = act;
   hipStream_t st = (hipStream_t)stream;
+  // 128 x 128 tiles only when they fill the chip at least twice over (or exactly once, bf16):
+  // *measured* (M = 4096, K = 1024 bf16 / 512 f32) the 64 x 64 tile wins below that - 256 big
+  // tiles leave half the 512 (bf16, 2 per CU) / 768 (f32, 3 per CU) workgroup slots empty
+  // (43.5 vs 29.5 us), 768 run as one and a half waves (77.9 vs 67.7 us).
   const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-  bool big = big_tiles >= 192;
+  const long slots = wdtype == CARE_BF16 ? 512 : 768;
+  bool big = big_tiles >= 2 * slots || (wdtype == CARE_BF16 && big_tiles >= slots && big_tiles % slots == 0);
   if (const char* e = getenv("CARE_GEMM_TILE")) big = atoi(e) >= 128;  // tuning override
   if (wdtype == CARE_BF16)
     return big ? launch<bf16_t, 128, 128, false>(p, st) : launch<bf16_t, 64, 64, false>(p, st);
