@@ -251,7 +251,8 @@ def main():
                              "V=10547, 29 decoder steps" if args.config == "msrvtt_base_ami" else args.config,
                     config_name=args.config, clips_per_gpu_per_step=B, global_batch=B * world, lanes=args.lanes,
                     parallelism="batch-sharded dp{} (no data-path collective; all-gather of results)".format(world),
-                    hip_graph=not args.no_graph, absorbed_cross_attention=bool(eng.latent_for(B))),
+                    hip_graph=not args.no_graph, absorbed_cross_attention=bool(eng.latent_for(B)),
+                    lean_encode=bool(eng.lean_ok)),  # the Translator's call: bf16 memory only, no unused fp32 copy / frame means
         decoder_step_us=round(ms_per_step * 1e3 * (1 - (kernels.get("enc_gemm", {"total_ms": 0})["total_ms"] +
                                                          kernels.get("cross_kv_gemm", {"total_ms": 0})["total_ms"]) /
                                                     max(tagged_ms, 1e-9)) / T, 2),
