@@ -55,7 +55,7 @@ def ln_main():
     """care_gemm_ln (fused LayerNorm epilogue) on embedder / decode shapes."""
     import os
     print("CARE_LN_RG=%s" % os.environ.get("CARE_LN_RG"))
-    for M, K, f32 in [(458752, 2048, True), (458752, 512, True), (458752, 128, True), (16384, 512, False),
+    for M, K, f32 in [(458752, 2048, True), (458752, 512, True), (458752, 128, True), (32768, 512, False), (32768, 2048, False), (16384, 512, False),
                       (16384, 2048, False), (4096, 512, False), (4096, 2048, False)]:
         A = torch.randn(M, K, device=DEV)
         Ain = A if f32 else A.to(torch.bfloat16)
