@@ -234,8 +234,9 @@ int launch_latent(const LatArgs& p, hipStream_t st) {
   constexpr int LDS = WAVES * NSLOT * CH_BYTES + 16 * 128 * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_latent_kernel<WAVES, NSLOT>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_latent_kernel<WAVES, NSLOT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int blocks = min((p.rows + WAVES - 1) / WAVES, 256);
