@@ -135,7 +135,7 @@ def test_translator_result_assembly_matches_reference_quirks():
     class FakeEngine:
         T = 29
 
-        def translate_beam(self, feats, bm, need, use_graph=True):
+        def translate_beam(self, feats, bm, need, use_graph=True, lean=False):
             nfin = torch.tensor([5, 1, 5], dtype=torch.int32)
             fscore = torch.tensor([[-4.0, -2.0, -9.0, -8.0, -7.0, 0, 0, 0, 0, 0],
                                    [-3.0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
