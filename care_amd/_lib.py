@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -29,6 +29,8 @@ SIGNATURES = {
     "care_score_partials": [_P, _P, _P, _P, _I, _P, _P, _I, _P],
     "care_score_logits": [_P, _L, _I, _P, _P, _P, _I, _P],
     "care_greedy_update": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "care_greedy_update_embed": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _F,
+                                 _P, _P, _L, _I, _P],
     "care_add_ln": [_P, _L, _P, _L, _P, _P, _P, _F, _P, _P, _L, _I, _I, _I, _I, _I, _I, _L, _P],
     "care_gemm_ln": [_P, _L, _I, _P, _P, _P, _L, _P, _P, _P, _F, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_gemm_bf16_splitk": [_P, _L, _I, _P, _P, _P, _L, _L, _I, _I, _I, _P],

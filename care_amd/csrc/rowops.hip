@@ -220,6 +220,60 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(const float* pmax, c
   }
 }
 
+// greedy_update + the NEXT step's embedding: after the token of step t is chosen the same wave embeds
+// it (word + position t [+ semantic row]) and LayerNorms it into the activations of step t+1 - one
+// launch per step less (a decode step is launch-latency bound at the reference's batch sizes).
+__global__ __launch_bounds__(256) void greedy_update_embed_kernel(
+    const float* pmax, const int32_t* pidx, const float* psum, int parts, int32_t* fed, int fed_stride, float* score,
+    int32_t* length, int32_t* finished, int t, int max_steps, int eos_id, int rows, const float* word, const float* pos,
+    const float* sem, int sem_div, const float* gamma, const float* beta, float eps, float* out, bf16_t* outb,
+    int64_t ldo, int d) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < parts; c += 64) {
+    const float v = pmax[(int64_t)r * parts + c];
+    const int id = pidx[(int64_t)r * parts + c];
+    if (v > best || (v == best && id < bi)) { best = v; bi = id; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  float s = 0.f;
+  for (int c = lane; c < parts; c += 64)
+    s += psum[(int64_t)r * parts + c] * expf(pmax[(int64_t)r * parts + c] - best);
+  s = care_wave_sum(s);
+  if (lane == 0) {
+    fed[(int64_t)r * fed_stride + t] = bi;  // always feed the token: frozen rows still run
+    if (!finished[r]) {
+      score[r] += -logf(s);
+      length[r] = t;
+      if (bi == eos_id || t >= max_steps) finished[r] = 1;
+    }
+  }
+  // ---- embedding of that token at position t: the input of decode step t + 1
+  const float* w = word + (int64_t)bi * d;
+  const float* pp = pos + (int64_t)t * d;
+  const float* sm = sem ? sem + (int64_t)(r / sem_div) * d : nullptr;
+  const int nv4 = d >> 2;
+  float4 v[MAXV];
+#pragma unroll
+  for (int c = 0; c < MAXV; ++c) {
+    const int c4 = lane + 64 * c;
+    if (c4 < nv4) {
+      v[c] = *reinterpret_cast<const float4*>(w + c4 * 4);
+      add4(v[c], *reinterpret_cast<const float4*>(pp + c4 * 4));
+      if (sm) add4(v[c], *reinterpret_cast<const float4*>(sm + c4 * 4));
+    }
+  }
+  row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + (int64_t)r * ldo, outb ? outb + (int64_t)r * ldo : nullptr);
+}
+
 // teacher-forced scoring from the fused vocabulary partials: per row the arg-max column and the
 // log-probability of the label column, log_softmax(x)[label] = x[label] - max - log(sum exp(x - max))
 __global__ __launch_bounds__(256) void score_partials_kernel(const float* pmax, const int32_t* pidx, const float* psum,
@@ -354,6 +408,23 @@ extern "C" int care_greedy_update(const float* pmax, const int32_t* pidx, const 
   if (t <= 0 || t >= fed_stride) return CARE_ESHAPE;
   hipLaunchKernelGGL(greedy_update_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, pmax, pidx, psum, parts, fed,
                      fed_stride, score, length, finished, t, max_steps, eos_id, rows);
+  return care_launch_status();
+}
+
+extern "C" int care_greedy_update_embed(const float* pmax, const int32_t* pidx, const float* psum, int parts, int32_t* fed,
+                                        int fed_stride, float* score, int32_t* length, int32_t* finished, int t,
+                                        int max_steps, int eos_id, int rows, const float* word, const float* pos,
+                                        const float* sem, int sem_div, const float* gamma, const float* beta, float eps,
+                                        float* out, void* out_bf16, int64_t ldo, int d, void* stream) {
+  if (!pmax || !pidx || !psum || !fed || !score || !length || !finished || rows <= 0 || parts <= 0 || !word || !pos ||
+      !gamma || !beta || !out)
+    return CARE_EINVAL;
+  if (t <= 0 || t >= fed_stride || d <= 0 || d > 64 * 4 * MAXV || (d % 4) || (sem && sem_div <= 0)) return CARE_ESHAPE;
+  if ((ldo % 4) || !care_aligned16(word) || !care_aligned16(pos) || !care_aligned16(out) || (sem && !care_aligned16(sem)))
+    return CARE_EALIGN;
+  hipLaunchKernelGGL(greedy_update_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, pmax, pidx, psum, parts, fed,
+                     fed_stride, score, length, finished, t, max_steps, eos_id, rows, word, pos, sem, sem_div, gamma, beta,
+                     eps, out, reinterpret_cast<bf16_t*>(out_bf16), ldo, d);
   return care_launch_status();
 }
 

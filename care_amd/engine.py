@@ -600,13 +600,15 @@ class HipEngine:
         return logp.view(N, t), pred.view(N, t)
 
     # ------------------------------------------------------------------ incremental decode step
-    def _decode_step(self, t, N, rows_per_clip, tok, anc, sem, ckv, skv, Lk, tag, akv=None):
-        """One decoder step for N rows: new token at position t-1 -> final hidden (fp32, bf16 mirror)."""
+    def _decode_step(self, t, N, rows_per_clip, tok, anc, sem, ckv, skv, Lk, tag, akv=None, embedded=False):
+        """One decoder step for N rows: new token at position t-1 -> final hidden (fp32, bf16 mirror).
+        embedded: the step's input activations were already written by care_greedy_update_embed."""
         w, d, T = self.w, self.d, self.T
         x, xb = self.ws(tag + "x0", (N, d)), self.wsb(tag + "x0", (N, d))
-        call("care_embed_ln", ptr(tok), tok.stride(0), t - 1, ptr(anc), anc.stride(0) if anc is not None else 0,
-             ptr(w["word"]), ptr(w["pos"]), t - 1, ptr(sem), rows_per_clip, ptr(w["emb_g"]), ptr(w["emb_be"]),
-             self.eps, ptr(x), ptr(xb), d, N, 1, d)
+        if not embedded:
+            call("care_embed_ln", ptr(tok), tok.stride(0), t - 1, ptr(anc), anc.stride(0) if anc is not None else 0,
+                 ptr(w["word"]), ptr(w["pos"]), t - 1, ptr(sem), rows_per_clip, ptr(w["emb_g"]), ptr(w["emb_be"]),
+                 self.eps, ptr(x), ptr(xb), d, N, 1, d)
         g = lambda f32, b16: b16 if b16 is not None else f32  # GEMM input: the bf16 mirror when it exists
         for li in range(self.n_layers):
             nm = "d{}_sa".format(li)
@@ -683,16 +685,22 @@ class HipEngine:
         pmax = self.ws("g_pmax", (B, parts))
         pidx = self.ws("g_pidx", (B, parts), torch.int32)
         psum = self.ws("g_psum", (B, parts))
+        x0, x0b = self.ws("g_x0", (B, d)), self.wsb("g_x0", (B, d))  # the workspaces _decode_step embeds into
         for t in range(1, steps + 1):
-            x, xb = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_", akv=akv)
+            x, xb = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_", akv=akv, embedded=t > 1)
             if bf:
                 call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(pmax), ptr(pidx),
                      ptr(psum), None, None, B, self.V, d, tag="step_vocab_argmax")
             else:
                 call("care_gemm_argmax", ptr(x), d, ptr(self.w["vocab"]), _code(self.w["vocab"]), ptr(pmax),
                      ptr(pidx), ptr(psum), B, self.V, d, tag="step_vocab_argmax")
-            call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
-                 ptr(length), ptr(fin), t, T, EOS, B)
+            if t < steps:  # the token choice and, in the same launch, its embedding = the input of step t + 1
+                call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
+                     ptr(length), ptr(fin), t, T, EOS, B, ptr(self.w["word"]), ptr(self.w["pos"]), ptr(sem), 1,
+                     ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps, ptr(x0), ptr(x0b), d, d)
+            else:
+                call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
+                     ptr(length), ptr(fin), t, T, EOS, B)
         return fed, length, score
 
     def translate_greedy(self, feats: List[torch.Tensor], use_graph: bool = True, lean: bool = False):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 6
+#define CARE_ABI_VERSION 7
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -133,6 +133,20 @@ int care_greedy_update(const float* pmax, const int32_t* pidx, const float* psum
                        int32_t* fed, int fed_stride, float* score, int32_t* length,
                        int32_t* finished, int t, int max_steps, int eos_id, int rows,
                        void* stream);
+
+/*
+ * care_greedy_update_embed: care_greedy_update for step t, and in the same launch the embedding of
+ *   the chosen token at position t - word[token] + pos[t] (+ sem[r / sem_div]) -> LayerNorm ->
+ *   out / out_bf16 - i.e. the care_embed_ln call of decode step t + 1 (Embeddings.forward,
+ *   models/components/Embeddings.py) fused behind Beam.advance's token choice.  One launch per
+ *   decoder step less.  word fp32 [V, d], pos fp32 [>= t + 1, d], sem (optional) fp32.
+ */
+int care_greedy_update_embed(const float* pmax, const int32_t* pidx, const float* psum, int parts,
+                             int32_t* fed, int fed_stride, float* score, int32_t* length,
+                             int32_t* finished, int t, int max_steps, int eos_id, int rows,
+                             const float* word, const float* pos, const float* sem, int sem_div,
+                             const float* gamma, const float* beta, float eps, float* out,
+                             void* out_bf16, int64_t ldo, int d, void* stream);
 
 /*
  * care_add_ln: out = LayerNorm(x + res) * gamma + beta, row-wise over d columns.

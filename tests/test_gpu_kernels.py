@@ -446,3 +446,34 @@ def test_beam_select_massive_ties_take_the_overflow_path():
         assert ci[r].tolist() == order[:nf] + [0] * (bm - nf), (r, ci[r].tolist(), order)
         assert torch.equal(torch.isfinite(got), fin)
         assert (got[fin] - ref[fin]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("rows,parts,d,with_sem", [(5, 7, 512, True), (130, 166, 512, False), (33, 512, 1024, True)])
+def test_greedy_update_embed_equals_the_two_kernels(rows, parts, d, with_sem):
+    """care_greedy_update_embed == care_greedy_update followed by the next step's care_embed_ln."""
+    V, T, t = 300, 29, 4
+    pmax = _rand(rows, parts, seed=41)
+    psum = _rand(rows, parts, seed=42).abs() + 0.1
+    pidx = torch.randint(0, V, (rows, parts), device=DEV, dtype=torch.int32)
+    word, pos = _rand(V, d, seed=43), _rand(T + 1, d, seed=44)
+    sem = _rand(rows, d, seed=45) if with_sem else None
+    g, b = _rand(d, seed=46), _rand(d, seed=47)
+
+    def state():
+        fed = torch.zeros(rows, T + 1, device=DEV, dtype=torch.int32)
+        score = _rand(rows, seed=48).clone()
+        length = torch.zeros(rows, device=DEV, dtype=torch.int32)
+        fin = (torch.arange(rows, device=DEV) % 3 == 0).to(torch.int32)
+        return fed, score, length, fin
+
+    f1, s1, l1, n1 = state()
+    x1 = torch.empty(rows, d, device=DEV); x1b = torch.empty(rows, d, device=DEV, dtype=torch.bfloat16)
+    _call("care_greedy_update", _p(pmax), _p(pidx), _p(psum), parts, _p(f1), T + 1, _p(s1), _p(l1), _p(n1), t, T, 3, rows)
+    _call("care_embed_ln", _p(f1), T + 1, t, None, 0, _p(word), _p(pos), t, _p(sem), 1, _p(g), _p(b), 1e-12, _p(x1),
+          _p(x1b), d, rows, 1, d)
+    f2, s2, l2, n2 = state()
+    x2 = torch.empty(rows, d, device=DEV); x2b = torch.empty(rows, d, device=DEV, dtype=torch.bfloat16)
+    _call("care_greedy_update_embed", _p(pmax), _p(pidx), _p(psum), parts, _p(f2), T + 1, _p(s2), _p(l2), _p(n2), t, T,
+          3, rows, _p(word), _p(pos), _p(sem), 1, _p(g), _p(b), 1e-12, _p(x2), _p(x2b), d, d)
+    assert torch.equal(f1, f2) and torch.equal(s1, s2) and torch.equal(l1, l2) and torch.equal(n1, n2)
+    assert torch.equal(x1, x2) and torch.equal(x1b, x2b)
