@@ -706,7 +706,7 @@ class HipEngine:
     def translate_greedy(self, feats: List[torch.Tensor], use_graph: bool = True, lean: bool = False):
         """encode + greedy decode of one batch; replayed from a hipGraph when possible.
 
-        One pass issues ~430 kernel launches (14 per step); driven from Python that is
+        One pass issues ~360-440 kernel launches (12-15 per step); driven from Python that is
         host-bound, so the whole pass is captured once per (batch, input buffers) into a
         hipGraph (torch.cuda.CUDAGraph on the same stream capture) and replayed.  The graph
         is keyed on the input pointers: callers that re-use their feature buffers (bench,
