@@ -473,6 +473,110 @@ __global__ __launch_bounds__(256) void beam_advance_wave_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused beam selection (bf16 mode): no [rows, V] logits in HBM.
+//   pass 1  care_gemm_argmax_bf16_min : the fused-statistics vocabulary GEMM with >= 8 column ranges
+//           per row -> per range (max, argmax, sum-exp);
+//   care_beam_threshold               : tau[row] = the bm-th largest of the row's range maxima - bm
+//           distinct logits are >= tau, so tau is a lower bound of the row's bm-th best - and the
+//           candidate counter is reset;
+//   pass 2  care_gemm_collect_bf16    : the same GEMM, epilogue = append every logit >= tau[row] to the
+//           row's candidate list (about 10 per row);
+//   care_beam_pick                    : the top bm of the list (value desc, column asc) as log-probs.
+// A row whose list overflows (a plateau of equal logits at the threshold) is recomputed exactly: the
+// pick kernel evaluates its V dot products itself.
+__global__ __launch_bounds__(256) void beam_threshold_kernel(const float* pmax, int parts, int bm, float* thr,
+                                                             int32_t* cnt, int rows) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float tv[MAXBM];
+#pragma unroll
+  for (int j = 0; j < MAXBM; ++j) tv[j] = -INFINITY;
+  for (int c = 0; c < parts; ++c) {
+    float cv = pmax[(int64_t)r * parts + c];
+#pragma unroll
+    for (int j = 0; j < MAXBM; ++j)
+      if (j < bm && cv > tv[j]) { const float o = tv[j]; tv[j] = cv; cv = o; }
+  }
+  float t = tv[0];
+#pragma unroll
+  for (int j = 1; j < MAXBM; ++j)
+    if (j < bm) t = tv[j];
+  thr[r] = t;  // -inf when fewer than bm ranges hold a finite maximum: everything is a candidate -> exact path
+  cnt[r] = 0;
+}
+
+template <typename AT>
+__global__ __launch_bounds__(256) void beam_pick_kernel(const float* pmax, const float* psum, int parts, const int32_t* cnt,
+                                                        const float* cval, const int32_t* cidx, int cap, int bm,
+                                                        const AT* A, int64_t lda, const bf16_t* W, int V, int K,
+                                                        float* cand_val, int32_t* cand_idx, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  // log-sum-exp of the row from the pass-1 partials
+  float m = -INFINITY;
+  for (int c = lane; c < parts; c += 64) m = fmaxf(m, pmax[(int64_t)r * parts + c]);
+  const float mx = care_wave_max(m);
+  float se = 0.f;
+  for (int c = lane; c < parts; c += 64) se += psum[(int64_t)r * parts + c] * expf(pmax[(int64_t)r * parts + c] - mx);
+  const float logsum = logf(care_wave_sum(se));
+
+  float tv[MAXBM];  // per-LANE sorted top-bm of the candidates this lane holds
+  int ti[MAXBM];
+#pragma unroll
+  for (int j = 0; j < MAXBM; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+  auto take = [&](float v, int c) {
+    float cv = v; int ci = c;
+#pragma unroll
+    for (int j = 0; j < MAXBM; ++j)
+      if (j < bm && (cv > tv[j] || (cv == tv[j] && ci < ti[j]))) {
+        const float ov = tv[j]; const int oi = ti[j];
+        tv[j] = cv; ti[j] = ci; cv = ov; ci = oi;
+      }
+  };
+  const int n = cnt[r];
+  if (n <= cap) {
+    for (int i = lane; i < n; i += 64) take(cval[(int64_t)r * cap + i], cidx[(int64_t)r * cap + i]);
+  } else {
+    // overflow: the exact answer from the row's logits, recomputed here (fp32 accumulation of the
+    // same bf16 products; only rows with thousands of tied logits come this way)
+    const AT* a = A + (int64_t)r * lda;
+    for (int c = lane; c < V; c += 64) {
+      const bf16_t* w = W + (int64_t)c * K;
+      float d = 0.f;
+      for (int k = 0; k < K; k += 8) {
+        float av[8], wv[8];
+        care_load8(a + k, av);
+        care_load8(w + k, wv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d = fmaf((float)(bf16_t)av[i], wv[i], d);
+      }
+      take(d, c);
+    }
+  }
+  // merge the lanes' lists: bm rounds of wave-wide arg-best over the heads
+  for (int k = 0; k < bm; ++k) {
+    float v = tv[0];
+    int id = ti[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(id, o, 64);
+      if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; }
+    }
+    if (lane == 0) {
+      cand_val[(int64_t)r * bm + k] = (v - mx) - logsum;
+      cand_idx[(int64_t)r * bm + k] = id == 0x7fffffff ? 0 : id;
+    }
+    if (ti[0] == id && id != 0x7fffffff) {  // column indices are unique: exactly one lane pops its head
+#pragma unroll
+      for (int j = 0; j + 1 < MAXBM; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+      tv[MAXBM - 1] = -INFINITY; ti[MAXBM - 1] = 0x7fffffff;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int care_beam_select(const float* logits, int64_t ldl, int V, int bm, float* cand_val, int32_t* cand_idx,
@@ -485,6 +589,37 @@ extern "C" int care_beam_select(const float* logits, int64_t ldl, int V, int bm,
   else
     hipLaunchKernelGGL(beam_select_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, bm, cand_val,
                        cand_idx, rows);
+  return care_launch_status();
+}
+
+extern "C" int care_beam_threshold(const float* pmax, int parts, int bm, float* thr, int32_t* cnt, int rows,
+                                   void* stream) {
+  if (!pmax || !thr || !cnt || rows <= 0 || parts <= 0) return CARE_EINVAL;
+  if (bm <= 0 || bm > MAXBM) return CARE_ESHAPE;
+  hipLaunchKernelGGL(beam_threshold_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, pmax, parts,
+                     bm, thr, cnt, rows);
+  return care_launch_status();
+}
+
+extern "C" int care_beam_pick(const float* pmax, const float* psum, int parts, const int32_t* cnt, const float* cval,
+                              const int32_t* cidx, int cap, int bm, const void* A, int64_t lda, int a_dtype,
+                              const void* W, int V, int K, float* cand_val, int32_t* cand_idx, int rows,
+                              void* stream) {
+  if (!pmax || !psum || !cnt || !cval || !cidx || !A || !W || !cand_val || !cand_idx || rows <= 0 || parts <= 0 ||
+      cap <= 0 || V <= 0 || K <= 0)
+    return CARE_EINVAL;
+  if (bm <= 0 || bm > MAXBM || bm > V || (K % 8)) return CARE_ESHAPE;
+  if (a_dtype != CARE_F32 && a_dtype != CARE_BF16) return CARE_EDTYPE;
+  if (!care_aligned16(A) || !care_aligned16(W) || (lda % 8)) return CARE_EALIGN;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (a_dtype == CARE_BF16)
+    hipLaunchKernelGGL(beam_pick_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, pmax, psum, parts, cnt, cval, cidx,
+                       cap, bm, reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), V, K,
+                       cand_val, cand_idx, rows);
+  else
+    hipLaunchKernelGGL(beam_pick_kernel<float>, grid, block, 0, (hipStream_t)stream, pmax, psum, parts, cnt, cval, cidx,
+                       cap, bm, reinterpret_cast<const float*>(A), lda, reinterpret_cast<const bf16_t*>(W), V, K,
+                       cand_val, cand_idx, rows);
   return care_launch_status();
 }
 

@@ -42,7 +42,9 @@
 
 namespace {
 
-enum { STREAM_STORE = 0, STREAM_ARGMAX = 1, STREAM_ARGMAX_LAB = 2 };  // _LAB: also the logit of a label column
+// _LAB: also the logit of a label column.  _COLLECT: no statistics; every logit >= its row's threshold is
+// appended to a small per-row candidate list (second pass of the fused beam-search selection).
+enum { STREAM_STORE = 0, STREAM_ARGMAX = 1, STREAM_ARGMAX_LAB = 2, STREAM_COLLECT = 3 };
 
 constexpr int TILE_N = 16;             // output columns per W tile
 constexpr int TILE_BYTES = TILE_N * 1024;
@@ -66,6 +68,9 @@ struct AsArgs {
   int64_t slab_stride;   // elements between consecutive fp32 slabs of C0
   float* pmax; int32_t* pidx; float* psum;
   const int32_t* labels; float* plab;   // optional (ARGMAX): logit of column labels[row] per partial
+  // COLLECT mode re-uses idle fields (a bigger kernel-argument block costs the ARGMAX kernel a spill):
+  //   bias = threshold per row, pidx = count per row, pmax = candidate values [M, cap],
+  //   C1 = candidate columns int32 [M, cap], act = cap
   int total_items;       // kslices * per-slice items (grid may be smaller: persistent blocks)
 };
 
@@ -110,7 +115,8 @@ __device__ __forceinline__ void wait_vm(int n) {
 template <typename AT, int MODE, bool FULL>
 __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr bool IS_ARGMAX = MODE != STREAM_STORE;
+  constexpr bool IS_ARGMAX = MODE == STREAM_ARGMAX || MODE == STREAM_ARGMAX_LAB;
+  constexpr bool IS_COLLECT = MODE == STREAM_COLLECT;
   constexpr bool HAS_LAB = MODE == STREAM_ARGMAX_LAB;  // 16 more live VGPRs: its own instantiation
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
         if (ks + BDEPTH < 16 && (FULL || ks + BDEPTH < ksn))
           fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff[(ks + BDEPTH) & 3] + ((ks + BDEPTH) >> 2) * 256);
         if (CARE_AS_DBG & 2) { asm volatile("" :: "v"(b)); continue; }
-        if constexpr (IS_ARGMAX) {  // D[row of A][col = W row]: a lane sees 1 column, 4 rows
+        if constexpr (MODE != STREAM_STORE) {  // D[row of A][col = W row]: a lane sees 1 column, 4 rows
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b, acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], b, acc[1], 0, 0, 0);
         } else {  // swapped: a lane holds 4 CONSECUTIVE output columns of one row
@@ -272,6 +278,31 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
       if constexpr (HAS_LAB) { rl[i] = -INFINITY; lab[i] = p.labels ? p.labels[row] : -1; }
     }
   }
+
+  // COLLECT: the thresholds of the 8 rows this lane sees (+inf for rows past M: nothing is appended)
+  float cth[IS_COLLECT ? 8 : 1];
+  if constexpr (IS_COLLECT) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = m0 + (i >> 2) * 16 + fg * 4 + (i & 3);
+      cth[i] = row < p.M ? p.bias[row] : INFINITY;
+    }
+  }
+  auto collect = [&](const f32x4 (&av)[2], int tile) {
+    const int c0 = tile * TILE_N + fr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v0 = av[i >> 2][i & 3];
+      if (__builtin_expect(c0 < p.N && v0 >= cth[IS_COLLECT ? i : 0], 0)) {
+        const int row = m0 + (i >> 2) * 16 + fg * 4 + (i & 3);
+        const int pos = atomicAdd(&p.pidx[row], 1);
+        if (pos < p.act) {
+          p.pmax[(int64_t)row * p.act + pos] = v0;
+          reinterpret_cast<int32_t*>(p.C1)[(int64_t)row * p.act + pos] = c0;
+        }
+      }
+    }
+  };
 
   // online (max, sum-exp) of logit i (= m-tile i>>2, register i&3) of a finished tile, with ONE exp
   // per logit: e = exp(-|m - v|) is the rescale factor when v is the new max and the new term otherwise
@@ -399,6 +430,10 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
     } else if constexpr (HAS_LAB) {  // 16 more live registers: no room for a second accumulator pair
       compute(slot);
       argmax_update(acc, t);
+    } else if constexpr (IS_COLLECT) {
+      // appends are rare extra VM operations: the counted waits then over-wait (never under-wait)
+      compute(slot);
+      collect(acc, t);
     } else {
       // iteration 0 has no previous tile: a column index past N masks the dummy statistics (no branch)
       compute_woven(slot, it > 0 ? t - 1 : (1 << 26));
@@ -505,14 +540,25 @@ extern "C" int care_gemm_bf16(const void* A, int64_t lda, int a_dtype, const voi
                               : launch_as<float, STREAM_STORE>(p, blocks, st);
 }
 
+// at least `min_parts` column ranges (the fused beam selection needs >= beam_size sub-maxima per row)
+static int pick_ns_min(int panels, int tiles_total, int min_parts) {
+  const int ns = pick_ns(panels, tiles_total);
+  return ns >= min_parts ? ns : (min_parts + 7) / 8 * 8;
+}
+
 extern "C" int care_argmax_parts_bf16(int M, int N) {
   if (M <= 0 || N <= 0) return CARE_EINVAL;
   return pick_ns((M + 127) / 128, (N + TILE_N - 1) / TILE_N);
 }
 
-extern "C" int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
-                                     int32_t* pidx, float* psum, const int32_t* labels, float* plab, int M, int N,
-                                     int K, void* stream) {
+extern "C" int care_argmax_parts_bf16_min(int M, int N, int min_parts) {
+  if (M <= 0 || N <= 0 || min_parts <= 0) return CARE_EINVAL;
+  return pick_ns_min((M + 127) / 128, (N + TILE_N - 1) / TILE_N, min_parts);
+}
+
+static int gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax, int32_t* pidx,
+                           float* psum, const int32_t* labels, float* plab, int M, int N, int K, int min_parts,
+                           void* stream) {
   int rc = as_check(A, lda, a_dtype, W, M, N, K);
   if (rc) return rc;
   if (!pmax || !pidx || !psum || ((labels != nullptr) != (plab != nullptr))) return CARE_EINVAL;
@@ -522,7 +568,7 @@ extern "C" int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, co
   p.kslices = 1; p.ldw = K;
   p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.labels = labels; p.plab = plab;
   p.panels = (M + 127) / 128;
-  p.ns = pick_ns(p.panels, (N + TILE_N - 1) / TILE_N);
+  p.ns = pick_ns_min(p.panels, (N + TILE_N - 1) / TILE_N, min_parts);
   const int blocks = plan_stream(p, false);
   hipStream_t st = (hipStream_t)stream;
   if (labels && plab)
@@ -530,6 +576,36 @@ extern "C" int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, co
                                 : launch_as<float, STREAM_ARGMAX_LAB>(p, blocks, st);
   return a_dtype == CARE_BF16 ? launch_as<bf16_t, STREAM_ARGMAX>(p, blocks, st)
                               : launch_as<float, STREAM_ARGMAX>(p, blocks, st);
+}
+
+extern "C" int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
+                                     int32_t* pidx, float* psum, const int32_t* labels, float* plab, int M, int N,
+                                     int K, void* stream) {
+  return gemm_argmax_bf16(A, lda, a_dtype, W, pmax, pidx, psum, labels, plab, M, N, K, 1, stream);
+}
+
+extern "C" int care_gemm_argmax_bf16_min(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
+                                         int32_t* pidx, float* psum, int M, int N, int K, int min_parts,
+                                         void* stream) {
+  if (min_parts <= 0) return CARE_EINVAL;
+  return gemm_argmax_bf16(A, lda, a_dtype, W, pmax, pidx, psum, nullptr, nullptr, M, N, K, min_parts, stream);
+}
+
+extern "C" int care_gemm_collect_bf16(const void* A, int64_t lda, int a_dtype, const void* W, const float* thr,
+                                      int32_t* cnt, float* cval, int32_t* cidx, int cap, int M, int N, int K,
+                                      void* stream) {
+  int rc = as_check(A, lda, a_dtype, W, M, N, K);
+  if (rc) return rc;
+  if (!thr || !cnt || !cval || !cidx || cap <= 0) return CARE_EINVAL;
+  if (K > 512 || a_dtype != CARE_BF16) return CARE_ESHAPE;
+  AsArgs p{};
+  p.A = A; p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.M = M; p.N = N; p.K = K; p.n_split = N;
+  p.kslices = 1; p.ldw = K;
+  p.bias = thr; p.pidx = cnt; p.pmax = cval; p.C1 = cidx; p.act = cap;  // see AsArgs
+  p.panels = (M + 127) / 128;
+  p.ns = pick_ns(p.panels, (N + TILE_N - 1) / TILE_N);
+  const int blocks = plan_stream(p, false);
+  return launch_as<bf16_t, STREAM_COLLECT>(p, blocks, (hipStream_t)stream);
 }
 
 // Split-K form for K > 512 (FFN dense2, wide feature embedders): K/512 slices, slice s writes its

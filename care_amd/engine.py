@@ -863,13 +863,36 @@ class HipEngine:
         cval = self.ws("b_cval", (N, bm))
         cidx = self.ws("b_cidx", (N, bm), torch.int32)
         vpad = (self.V + 63) // 64 * 64  # 16-byte aligned row stride -> the GEMM's vector store path
-        logits = self.ws("b_logits", (N, vpad))[:, : self.V]
+        fused_sel = self.as_ok and os.environ.get("CARE_BEAM_FUSED", "1") != "0"
+        if fused_sel:
+            s_parts = _lib.load().care_argmax_parts_bf16_min(N, self.V, 8)
+            s_cap = 64
+            s_pmax, s_psum = self.ws("b_spmax", (N, s_parts)), self.ws("b_spsum", (N, s_parts))
+            s_pidx = self.ws("b_spidx", (N, s_parts), torch.int32)
+            s_thr, s_cnt = self.ws("b_sthr", (N,)), self.ws("b_scnt", (N,), torch.int32)
+            s_cval, s_cidx = self.ws("b_scval", (N, s_cap)), self.ws("b_scidx", (N, s_cap), torch.int32)
+            logits = None
+        else:
+            logits = self.ws("b_logits", (N, vpad))[:, : self.V]
         ckv = self.cross_src(mem, N)
         akv = self.attr_kv(sem_embs) if self.attr_att else None
         skv = [self.ws("b_skv%d" % li, (N, T, 2 * d), self.wt) for li in range(self.n_layers)]
         for t in range(1, T + 1):
             a_old, a_new = anc[(t - 1) & 1], anc[t & 1]
             x, xb = self._decode_step(t, N, bm, tok, a_old, sem, ckv, skv, Lk, "b_", akv=akv)
+            if fused_sel:
+                # fused selection (csrc/beam.hip): statistics GEMM -> threshold -> candidate GEMM -> pick;
+                # the [N, V] logits never exist
+                call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax), ptr(s_pidx),
+                     ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
+                call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
+                call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
+                     ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
+                call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
+                     bm, ptr(xb), d, _code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
+                call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
+                     ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
+                continue
             # vocabulary logits -> per-row top-bm, in row chunks whose logits (chunk x vpad x 4 B) stay
             # inside the 256 MB Infinity Cache between the GEMM's stores and beam_select's loads
             src = xb if xb is not None else x

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 7
+#define CARE_ABI_VERSION 8
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -297,6 +297,34 @@ int care_head_reduce(const void* ct, int64_t ldc, const void* wv, const float* b
  */
 int care_beam_select(const float* logits, int64_t ldl, int V, int bm, float* cand_val,
                      int32_t* cand_idx, int rows, void* stream);
+
+/*
+ * Fused beam selection (bf16 mode): the per-row top beam_size of log_softmax(x W^T) without the
+ *   [rows, V] logits in memory.  Replaces torch.log_softmax (models/Translator.py:127) + the per-row
+ *   part of Beam.advance's top-k (misc/Decoding/Beam.py:60) exactly like care_beam_select does:
+ *     1. care_gemm_argmax_bf16_min : care_gemm_argmax_bf16 with at least `min_parts` column ranges
+ *        (care_argmax_parts_bf16_min gives the count) -> pmax / pidx / psum [M, parts];
+ *     2. care_beam_threshold      : thr[r] = bm-th largest range maximum of row r (a lower bound of
+ *        the row's bm-th best logit); cnt[r] = 0;
+ *     3. care_gemm_collect_bf16   : the same product; every logit >= thr[r] is appended to row r's
+ *        candidate list cval / cidx [M, cap] (cnt[r] counts them, also past cap);
+ *     4. care_beam_pick           : cand_val / cand_idx [rows, bm] = the bm best candidates (value
+ *        desc, column asc) as log-probabilities; a row with cnt > cap is recomputed exactly from
+ *        A and W inside the kernel.
+ */
+int care_argmax_parts_bf16_min(int M, int N, int min_parts);
+int care_gemm_argmax_bf16_min(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
+                              int32_t* pidx, float* psum, int M, int N, int K, int min_parts,
+                              void* stream);
+int care_beam_threshold(const float* pmax, int parts, int bm, float* thr, int32_t* cnt, int rows,
+                        void* stream);
+int care_gemm_collect_bf16(const void* A, int64_t lda, int a_dtype, const void* W, const float* thr,
+                           int32_t* cnt, float* cval, int32_t* cidx, int cap, int M, int N, int K,
+                           void* stream);
+int care_beam_pick(const float* pmax, const float* psum, int parts, const int32_t* cnt,
+                   const float* cval, const int32_t* cidx, int cap, int bm, const void* A, int64_t lda,
+                   int a_dtype, const void* W, int V, int K, float* cand_val, int32_t* cand_idx,
+                   int rows, void* stream);
 
 /*
  * care_beam_advance: one beam-search step for every clip (B clips x bm beams), on device.

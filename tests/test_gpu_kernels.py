@@ -477,3 +477,50 @@ def test_greedy_update_embed_equals_the_two_kernels(rows, parts, d, with_sem):
           3, rows, _p(word), _p(pos), _p(sem), 1, _p(g), _p(b), 1e-12, _p(x2), _p(x2b), d, d)
     assert torch.equal(f1, f2) and torch.equal(s1, s2) and torch.equal(l1, l2) and torch.equal(n1, n2)
     assert torch.equal(x1, x2) and torch.equal(x1b, x2b)
+
+
+@pytest.mark.parametrize("M,V,bm", [(5, 10547, 5), (300, 10547, 5), (130, 700, 8), (64, 10547, 1)])
+def test_fused_beam_selection_equals_logits_plus_beam_select(M, V, bm):
+    """statistics GEMM -> threshold -> candidate GEMM -> pick  ==  store-mode GEMM + care_beam_select,
+    including rows with tied logits (duplicated vocabulary rows) and a plateau of > 64 ties at the
+    top, which overflows the candidate list and takes the exact in-kernel recomputation."""
+    from care_amd import _lib
+
+    K = 512
+    A = _rand(M, K, seed=51).to(torch.bfloat16)
+    W = _rand(V, K, seed=52, scale=0.05).to(torch.bfloat16)
+    W[17] = W[400]                       # an exact tie between two columns for every row
+    if V > 5000:
+        W[3000:3100] = W[2999]           # a 101-column plateau: ties everywhere it reaches the top
+        A[1] = (W[2999].float() * 40).to(torch.bfloat16)   # row 1: the plateau IS the top -> overflow path
+    ld = (V + 63) // 64 * 64
+    logits = torch.empty(M, ld, device=DEV)
+    _call("care_gemm_bf16", _p(A), K, 1, _p(W), None, _p(logits), ld, 0, None, 0, 0, V, M, V, K, 0)
+    ref_v = torch.zeros(M, bm, device=DEV); ref_i = torch.zeros(M, bm, device=DEV, dtype=torch.int32)
+    _call("care_beam_select", _p(logits), ld, V, bm, _p(ref_v), _p(ref_i), M)
+
+    parts = _lib.load().care_argmax_parts_bf16_min(M, V, 8)
+    assert parts >= 8
+    pmax = torch.empty(M, parts, device=DEV); psum = torch.empty(M, parts, device=DEV)
+    pidx = torch.empty(M, parts, device=DEV, dtype=torch.int32)
+    thr = torch.empty(M, device=DEV); cnt = torch.full((M,), -1, device=DEV, dtype=torch.int32)
+    cap = 64
+    cval = torch.empty(M, cap, device=DEV); cidx = torch.empty(M, cap, device=DEV, dtype=torch.int32)
+    got_v = torch.zeros(M, bm, device=DEV); got_i = torch.zeros(M, bm, device=DEV, dtype=torch.int32)
+    _call("care_gemm_argmax_bf16_min", _p(A), K, 1, _p(W), _p(pmax), _p(pidx), _p(psum), M, V, K, 8)
+    _call("care_beam_threshold", _p(pmax), parts, bm, _p(thr), _p(cnt), M)
+    _call("care_gemm_collect_bf16", _p(A), K, 1, _p(W), _p(thr), _p(cnt), _p(cval), _p(cidx), cap, M, V, K)
+    _call("care_beam_pick", _p(pmax), _p(psum), parts, _p(cnt), _p(cval), _p(cidx), cap, bm, _p(A), K, 1, _p(W), V, K,
+          _p(got_v), _p(got_i), M)
+    torch.cuda.synchronize()
+    assert int(cnt.min()) >= bm                      # at least bm candidates reach every threshold
+    if V > 5000:
+        assert int(cnt[1]) > cap                     # the plateau row did overflow
+    over = cnt > cap
+    assert torch.equal(got_i[~over], ref_i[~over])   # bit-identical logits -> identical order, ties included
+    assert (got_v[~over] - ref_v[~over]).abs().max().item() < 2e-5
+    # overflow rows: recomputed with an fp32 fma chain instead of the MFMA - same columns unless two
+    # non-identical columns differ by rounding; the duplicated columns stay tied (column asc)
+    if bool(over.any()):
+        assert torch.equal(got_i[over], ref_i[over])
+        assert (got_v[over] - ref_v[over]).abs().max().item() < 1e-3
