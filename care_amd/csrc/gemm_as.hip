@@ -149,6 +149,13 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   // every wave must be done reading the ring (and the bias) of the previous item
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if constexpr (MODE == STREAM_COLLECT) {  // candidate staging count (see collect); ordered by the first tile's barrier
+    if (tid == 0) {
+      const unsigned cb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + BIAS_OFF;
+      const int zero = 0;
+      asm volatile("ds_write_b32 %0, %1" :: "v"(cb), "v"(zero) : "memory");
+    }
+  }
 
   const AT* Ap = reinterpret_cast<const AT*>(p.A) + slice * 512;
   const bf16_t* Wp = p.W + slice * 512;
@@ -217,6 +224,9 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[0][ks], acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[1][ks], acc[1], 0, 0, 0);
         }
+#ifndef CARE_AS_NOPIN
+        __builtin_amdgcn_sched_barrier(0);  // pinned k-step order (see compute_woven)
+#endif
       }
   };
 
@@ -288,19 +298,60 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
       cth[i] = row < p.M ? p.bias[row] : INFINITY;
     }
   }
+  // Candidates are staged in the block's LDS bias area (idle in this mode): [0] = count, then
+  // (value, row-in-panel << 24 | column) pairs, flushed to the global lists once per work item.  A
+  // global atomic with return inside the tile loop is a full memory round trip that also drains the
+  // W tiles in flight, and about every second tile of a wave holds a candidate (417 us per launch
+  // against 257 us for the statistics pass); LDS atomics do not touch vmcnt (asm: through C++ hipcc
+  // would put a vmcnt(0) in front of them, possible alias with the LDS-DMA).
+  constexpr int LCAP = (BIAS_MAX * 4 - 8) / 8;
+  const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + BIAS_OFF;
+  auto append_global = [&](int row, float v0, int c0) {
+    const int pos = atomicAdd(&p.pidx[row], 1);
+    if (pos < p.act) {
+      p.pmax[(int64_t)row * p.act + pos] = v0;
+      reinterpret_cast<int32_t*>(p.C1)[(int64_t)row * p.act + pos] = c0;
+    }
+  };
   auto collect = [&](const f32x4 (&av)[2], int tile) {
     const int c0 = tile * TILE_N + fr;
+    // ONE wave-uniform test per tile: a divergent branch per logit costs more than the MFMAs
+    bool hit = false;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float v0 = av[i >> 2][i & 3];
-      if (__builtin_expect(c0 < p.N && v0 >= cth[IS_COLLECT ? i : 0], 0)) {
-        const int row = m0 + (i >> 2) * 16 + fg * 4 + (i & 3);
-        const int pos = atomicAdd(&p.pidx[row], 1);
-        if (pos < p.act) {
-          p.pmax[(int64_t)row * p.act + pos] = v0;
-          reinterpret_cast<int32_t*>(p.C1)[(int64_t)row * p.act + pos] = c0;
+    for (int i = 0; i < 8; ++i) hit |= av[i >> 2][i & 3] >= cth[IS_COLLECT ? i : 0];
+    if (__builtin_expect(__any(hit && c0 < p.N), 0)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v0 = av[i >> 2][i & 3];
+        if (c0 < p.N && v0 >= cth[IS_COLLECT ? i : 0]) {
+          const int rloc = wave * 32 + (i >> 2) * 16 + fg * 4 + (i & 3);
+          int pos;
+          const int one = 1;
+          asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(lbase), "v"(one) : "memory");
+          if (pos < LCAP) {
+            const unsigned a = lbase + 8 + (unsigned)pos * 8;
+            const int packed = (rloc << 24) | c0;
+            asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(a), "v"(v0), "v"(packed) : "memory");
+          } else {
+            append_global(m0 - wave * 32 + rloc, v0, c0);  // staging area full
+          }
         }
       }
+    }
+  };
+  // flush of the staged candidates: after the tile loop of the item, all 256 threads
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  auto collect_flush = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int n;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(n) : "v"(lbase) : "memory");
+    n = min(n, LCAP);
+    for (int e = tid; e < n; e += 256) {
+      i32x2 pr;
+      const unsigned a = lbase + 8 + (unsigned)e * 8;
+      asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pr) : "v"(a) : "memory");
+      append_global(m0 - wave * 32 + (int)((unsigned)pr[1] >> 24), __builtin_bit_cast(float, pr[0]), pr[1] & 0xffffff);
     }
   };
 
@@ -445,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
     hist_st[AHEAD - 1] = n_st;
   }
 
+  if constexpr (IS_COLLECT) collect_flush();
   if constexpr (IS_ARGMAX) {
     if constexpr (!HAS_LAB) argmax_update(accp, t1 - 1);  // the last tile's statistics
 #pragma unroll
@@ -597,7 +649,7 @@ extern "C" int care_gemm_collect_bf16(const void* A, int64_t lda, int a_dtype, c
   int rc = as_check(A, lda, a_dtype, W, M, N, K);
   if (rc) return rc;
   if (!thr || !cnt || !cval || !cidx || cap <= 0) return CARE_EINVAL;
-  if (K > 512 || a_dtype != CARE_BF16) return CARE_ESHAPE;
+  if (K > 512 || a_dtype != CARE_BF16 || N >= (1 << 24)) return CARE_ESHAPE;  // columns are staged in 24 bits
   AsArgs p{};
   p.A = A; p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.M = M; p.N = N; p.K = K; p.n_split = N;
   p.kslices = 1; p.ldw = K;
