@@ -273,97 +273,11 @@ __global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logi
   }
 }
 
-__global__ __launch_bounds__(64) void beam_advance_kernel(
-    const float* cand_val, const int32_t* cand_idx, float* scores, int bm, int32_t* tokphys, const int32_t* anc_old,
-    int32_t* anc_new, int32_t* done, int32_t* n_fin, float* fin_score, int32_t* fin_len, int32_t* fin_hyp, int fin_cap,
-    int t, int max_steps, int need, int eos_id, int V, int stride, int B) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
-  const int row0 = b * bm;
-  int parent[MAXBM], tok[MAXBM];
-  float sc[MAXBM];
-
-  if (done[b]) {
-    // frozen clip: keep the tables valid so the (ignored) rows keep reading defined memory
-    for (int i = 0; i < bm; ++i) {
-      for (int j = 0; j < t; ++j) anc_new[(int64_t)(row0 + i) * stride + j] = anc_old[(int64_t)(row0 + i) * stride + j];
-      anc_new[(int64_t)(row0 + i) * stride + t] = row0 + i;
-      tokphys[(int64_t)(row0 + i) * stride + t] = eos_id;
-    }
-    return;
-  }
-
-  // --- candidate pool: (value, flat index i*V + col); ended beams offer nothing (Beam.py:52-54)
-  const int n_src = (t == 1) ? 1 : bm;  // first step: row 0 only (Beam.py:55-56)
-  bool used[MAXBM * MAXBM];
-  for (int c = 0; c < bm * bm; ++c) used[c] = false;
-  for (int k = 0; k < bm; ++k) {
-    float bv = -INFINITY; long bflat = 0x7fffffffffffffffL; int bc = -1;
-    for (int i = 0; i < n_src; ++i) {
-      if (t > 1) {
-        const int prow = anc_old[(int64_t)(row0 + i) * stride + (t - 1)];
-        if (tokphys[(int64_t)prow * stride + (t - 1)] == eos_id) continue;
-      }
-      for (int j = 0; j < bm; ++j) {
-        const int c = i * bm + j;
-        if (used[c]) continue;
-        float v = cand_val[(int64_t)(row0 + i) * bm + j];
-        if (t > 1) v = v + scores[row0 + i];
-        const long flat = (long)i * V + cand_idx[(int64_t)(row0 + i) * bm + j];
-        if (v > bv || (v == bv && flat < bflat)) { bv = v; bflat = flat; bc = c; }
-      }
-    }
-    if (bc < 0) {  // fewer live candidates than beams (cannot happen while topk <= beam_size)
-      sc[k] = -1e20f; parent[k] = 0; tok[k] = eos_id;
-    } else {
-      used[bc] = true;
-      sc[k] = bv; parent[k] = bc / bm; tok[k] = cand_idx[(int64_t)(row0 + parent[k]) * bm + (bc % bm)];
-    }
-  }
-
-  // --- rewire ancestors, record tokens and scores
-  for (int i = 0; i < bm; ++i) {
-    const int64_t dst = (int64_t)(row0 + i) * stride, src = (int64_t)(row0 + parent[i]) * stride;
-    for (int j = 0; j < t; ++j) anc_new[dst + j] = anc_old[src + j];
-    anc_new[dst + t] = row0 + i;
-    tokphys[dst + t] = tok[i];
-    scores[row0 + i] = sc[i];
-  }
-
-  // --- finished hypotheses, in beam order, stop as soon as `need` are collected (Beam.py:72-77)
-  int nf = n_fin[b];
-  bool is_done = false;
-  auto record = [&](int i) {
-    if (nf < fin_cap) {
-      const int64_t slot = (int64_t)b * fin_cap + nf;
-      fin_score[slot] = sc[i];
-      fin_len[slot] = t;
-      for (int j = 1; j <= t; ++j) {
-        const int prow = anc_new[(int64_t)(row0 + i) * stride + j];
-        fin_hyp[slot * stride + (j - 1)] = tokphys[(int64_t)prow * stride + j];
-      }
-    }
-    ++nf;
-  };
-  for (int i = 0; i < bm && !is_done; ++i)
-    if (tok[i] == eos_id) {
-      record(i);
-      if (nf >= need) is_done = true;
-    }
-  if (!is_done && t >= max_steps) {  // Beam.py:79-84
-    is_done = true;
-    if (nf == 0)
-      for (int i = 0; i < bm; ++i) record(i);
-  }
-  n_fin[b] = nf;
-  if (is_done) done[b] = 1;
-}
-
 // One WAVE per clip: the bm x bm candidates one per lane (bm rounds of wave-wide arg-best: value
 // desc, flat index asc - the flattened topk order of Beam.py:60), the ancestor rows copied one
-// position per lane.  The one-thread-per-clip kernel above runs ~200 dependent memory operations
-// in series (195 us per step for 4096 clips, 9% of a beam-5 pass); it stays as the fallback for
-// tables wider than a wave (stride > 64).
+// position per lane.  (A one-thread-per-clip version ran ~200 dependent memory operations in series:
+// 195 us per step for 4096 clips, 9% of a beam-5 pass.)  The ancestor table must fit a wave:
+// stride = max_len <= 64.
 __global__ __launch_bounds__(256) void beam_advance_wave_kernel(
     const float* cand_val, const int32_t* cand_idx, float* scores, int bm, int32_t* tokphys, const int32_t* anc_old,
     int32_t* anc_new, int32_t* done, int32_t* n_fin, float* fin_score, int32_t* fin_len, int32_t* fin_hyp, int fin_cap,
@@ -630,14 +544,9 @@ extern "C" int care_beam_advance(const float* cand_val, const int32_t* cand_idx,
   if (!cand_val || !cand_idx || !scores || !tokphys || !anc_old || !anc_new || !done || !n_fin || !fin_score ||
       !fin_len || !fin_hyp || B <= 0)
     return CARE_EINVAL;
-  if (bm <= 0 || bm > MAXBM || t <= 0 || t >= stride || need > fin_cap) return CARE_ESHAPE;
-  if (stride <= 64)
-    hipLaunchKernelGGL(beam_advance_wave_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, cand_val,
-                       cand_idx, scores, bm, tokphys, anc_old, anc_new, done, n_fin, fin_score, fin_len, fin_hyp,
-                       fin_cap, t, max_steps, need, eos_id, V, stride, B);
-  else
-    hipLaunchKernelGGL(beam_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx,
-                       scores, bm, tokphys, anc_old, anc_new, done, n_fin, fin_score, fin_len, fin_hyp, fin_cap, t,
-                       max_steps, need, eos_id, V, stride, B);
+  if (bm <= 0 || bm > MAXBM || t <= 0 || t >= stride || stride > 64 || need > fin_cap) return CARE_ESHAPE;
+  hipLaunchKernelGGL(beam_advance_wave_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, cand_val,
+                     cand_idx, scores, bm, tokphys, anc_old, anc_new, done, n_fin, fin_score, fin_len, fin_hyp,
+                     fin_cap, t, max_steps, need, eos_id, V, stride, B);
   return care_launch_status();
 }

@@ -339,6 +339,7 @@ int care_beam_pick(const float* pmax, const float* psum, int parts, const int32_
  *   (tokens without BOS), recorded in the reference's order.  t = 1-based step,
  *   max_steps = max_len - 1, need = max(beam_size, topk) <= fin_cap, V = vocabulary size
  *   (ties between equal candidates resolve to the lower flattened index beam*V + column).
+ *   One wave per clip: stride (= max_len) <= 64, bm <= 8.
  */
 int care_beam_advance(const float* cand_val, const int32_t* cand_idx, float* scores, int bm,
                       int32_t* tokphys, const int32_t* anc_old, int32_t* anc_new,
