@@ -281,7 +281,12 @@ extern "C" int care_gemm_ln(const void* A, int64_t lda, int a_dtype, const void*
   p.pos = pos; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out = out; p.outb = reinterpret_cast<bf16_t*>(out_bf16);
   p.ldo = ldo; p.M = M; p.K = K; p.grp = grp; p.out_grp_rows = out_grp_rows; p.out_row_off = out_row_off;
   hipStream_t st = (hipStream_t)stream;
-  bool big = (M + 127) / 128 >= 256;  // enough 128-row panels to fill the chip
+  // 64-row blocks (RG = 1) or 128-row blocks (RG = 2, one launch round of them takes ~1.3x as long):
+  // whichever needs less time in whole rounds over the 256 CUs.  *Measured* K = 512: M = 16384
+  // 38 vs 44 us (RG 1 wins, one round each), M = 20480 68 vs 47.5 us (RG 1 needs two rounds),
+  // M = 32768 70 vs 53 us.
+  const long rounds1 = ((M + 63) / 64 + 255) / 256, rounds2 = ((M + 127) / 128 + 255) / 256;
+  bool big = 10 * rounds1 > 13 * rounds2;
   if (const char* e = getenv("CARE_LN_RG")) big = atoi(e) >= 2;  // tuning override
   if (a_dtype == CARE_F32) return big ? launch_ln<true, 2>(p, st) : launch_ln<true, 1>(p, st);
   return big ? launch_ln<false, 2>(p, st) : launch_ln<false, 1>(p, st);
