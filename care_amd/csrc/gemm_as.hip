@@ -540,17 +540,26 @@ int as_check(const void* A, int64_t lda, int a_dtype, const void* W, int M, int 
 }
 
 // Number of column ranges per panel.  Every extra range re-loads the panel's A fragments (the
-// expensive, fragment-shaped loads), so the split is the SMALLEST that gives 512 work items
-// (2 workgroups per CU): 1, 2 or 4 (panel-major mapping only) when the panels alone nearly fill
-// the chip, otherwise a multiple of 8 (one share per XCD).  Measured at M = 16384 (128 panels):
-// ns = 4 beats ns = 8 by 10-19% on N = 512 / 1536 / 2048.
+// expensive, fragment-shaped loads, worth ~24 W tiles of time), every launch "round" of 512
+// persistent workgroups (2 per CU) costs one item time, and an item sweeps tiles / ns tiles:
+//     cost(ns) = ceil(panels * ns / 512) * (24 + tiles / ns)
+// minimised over ns in {1, 2, 4} (panel-major mapping only) and the multiples of 8 (one share per
+// XCD); ties go to the smaller split.  It reproduces the measured optima - 1 panel: as many ranges
+// as there are tiles (<= 512), 32 panels: ns = 16, 128 panels: ns = 4 (N = 512 .. 10547), 256 panels:
+// ns = 2 - and picks ns = 8 for the vocabulary GEMM at 160 panels, where 4 gives 1.25 rounds of big
+// items (measured: +5% on the beam pass).
 int pick_ns(int panels, int tiles_total) {
   if (const char* e = getenv("CARE_AS_NS")) return atoi(e);  // tuning override (tools/gemm_bench.py)
-  for (int ns = 1; ns <= 4; ns *= 2)
-    if ((long)panels * ns >= 512 && ns <= tiles_total) return ns;
-  int ns = 8;
-  while (ns < tiles_total && (long)panels * ns < 512) ns += 8;
-  return ns;
+  auto cost = [&](int ns) {
+    const long rounds = ((long)panels * ns + 511) / 512;
+    return (double)rounds * (24.0 + (double)tiles_total / ns);
+  };
+  auto next = [](int ns) { return ns < 4 ? ns * 2 : (ns == 4 ? 8 : ns + 8); };
+  double best = 1e30;
+  for (int ns = 1; ns <= tiles_total && ns <= 512; ns = next(ns)) best = cost(ns) < best ? cost(ns) : best;
+  for (int ns = 1; ns <= tiles_total && ns <= 512; ns = next(ns))
+    if (cost(ns) <= best) return ns;  // the smallest split among the best
+  return 1;
 }
 
 // Grid size and XCD mapping of a launch.  The sharers of the BIGGER operand are made XCD
