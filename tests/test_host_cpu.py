@@ -109,6 +109,10 @@ def test_abi_library_exports_every_declared_symbol():
     assert loaded.care_arch() == b"gfx950"
     assert loaded.care_argmax_parts(10547) == 166
     assert loaded.care_argmax_parts_bf16(1024, 10547) % 8 == 0
+    # the column split of the A-stationary GEMM (csrc/gemm_as.hip: pick_ns), at its measured optima
+    for rows, parts in [(1, 512), (4096, 16), (8192, 8), (16384, 4), (20480, 8), (32768, 2), (65536, 1)]:
+        assert loaded.care_argmax_parts_bf16(rows, 10547) == parts, rows
+    assert loaded.care_argmax_parts_bf16_min(32768, 10547, 8) == 8
 
 
 def test_synth_generator_is_deterministic_and_portable():
