@@ -6,8 +6,10 @@ sit beside them) and `hyper_parameters = {'opt': {...}, 'new_opt_used_to_overrid
 `models/__init__.py:93-152` loads them through `LightningModule.load_from_checkpoint`,
 merges `{**opt, **new_opt_used_to_override}` (`Wrapper.py:29,402-403`) and rewrites the
 dataset paths stored in `opt`.  Lightning is not needed for any of that; this module reads
-the same file with a restricted unpickler (Lightning's `AttributeDict` becomes a dict) and
-returns a `CaptionRunner` that owns the care_amd captioner and translator.
+the same file with an ALLOW-LIST unpickler - checkpoints are the "pre-trained models released by
+others" case, so nothing outside tensors, plain containers and numpy scalars is ever imported or
+called (Lightning's `AttributeDict` becomes a dict; any other global raises UnpicklingError) -
+and returns a `CaptionRunner` that owns the care_amd captioner and translator.
 """
 import os
 import pickle
@@ -30,13 +32,38 @@ class _AttrDict(dict):
             self.update(state)
 
 
+# Globals a reference checkpoint can legitimately name.  Everything else is refused: a pickle GLOBAL
+# opcode is an import + attribute lookup and REDUCE calls the result, i.e. arbitrary code.
+_ALLOWED_GLOBALS = {
+    "collections": {"OrderedDict", "defaultdict"},
+    "builtins": {"dict", "list", "tuple", "set", "frozenset", "int", "float", "str", "bool", "bytes", "complex",
+                 "slice", "range", "bytearray"},
+    "argparse": {"Namespace"},
+    "torch": {"Size", "device", "dtype", "float32", "float64", "float16", "bfloat16", "int64", "int32", "int16",
+              "int8", "uint8", "bool", "FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage",
+              "LongStorage", "IntStorage", "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "Tensor"},
+    "torch._utils": {"_rebuild_tensor_v2", "_rebuild_tensor", "_rebuild_parameter", "_rebuild_parameter_with_state"},
+    "torch.storage": {"UntypedStorage", "TypedStorage", "_load_from_bytes"},
+    "torch.nn.parameter": {"Parameter"},
+    "numpy": {"dtype", "ndarray", "float32", "float64", "int64", "int32", "bool_"},
+    "numpy.core.multiarray": {"scalar", "_reconstruct"},
+    "numpy._core.multiarray": {"scalar", "_reconstruct"},
+}
+_LIGHTNING = ("pytorch_lightning", "lightning", "lightning_fabric", "lightning_utilities")
+
+
 class _Unpickler(pickle.Unpickler):
-    """pickle.Unpickler that never imports Lightning: its container classes map to dict."""
+    """Allow-list unpickler: Lightning's container classes map to dict (Lightning is never
+    imported), the globals in _ALLOWED_GLOBALS resolve normally, anything else raises."""
 
     def find_class(self, module, name):
-        if module.split(".")[0] in ("pytorch_lightning", "lightning", "lightning_fabric", "lightning_utilities"):
+        if module.split(".")[0] in _LIGHTNING:
             return _AttrDict
-        return super().find_class(module, name)
+        if name in _ALLOWED_GLOBALS.get(module, ()):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(
+            "checkpoint names the global `{}.{}`, which a CARE checkpoint has no use for; refusing to "
+            "import it (care_amd/checkpoint.py allow-list)".format(module, name))
 
 
 class _PickleModule:
@@ -135,11 +162,15 @@ class CaptionRunner:
 def load_model(checkpoint_path: str, new_opt_used_to_override: Optional[Dict[str, Any]] = None, device="cuda:0",
                strict: bool = True, replace_paths: bool = True, base_data_path: Optional[str] = None,
                compute_dtype: Optional[str] = None) -> CaptionRunner:
-    """`models.load_model` (models/__init__.py:93-152) for a single checkpoint."""
+    """`models.load_model` (models/__init__.py:93-152) for a single checkpoint.
+
+    Like the reference (`new_opt_used_to_override={}` by default, handed to `load_from_checkpoint`,
+    where it REPLACES the saved hyper-parameter), the overrides stored in the checkpoint are dropped
+    unless the caller passes them again; `read_checkpoint(path)["new_opt"]` returns the stored ones."""
     if isinstance(checkpoint_path, (list, tuple)):
         raise NotImplementedError("ModelEnsemble (several checkpoints) is outside the hot path")
     ck = read_checkpoint(checkpoint_path)
-    override = ck["new_opt"] if new_opt_used_to_override is None else dict(new_opt_used_to_override)
+    override = dict(new_opt_used_to_override or {})
     opt = replace_data_paths(ck["opt"], base_data_path) if replace_paths else ck["opt"]
     runner = CaptionRunner(opt, override)
     missing, unexpected = runner.captioner.load_state_dict(ck["state_dict"], strict=strict)

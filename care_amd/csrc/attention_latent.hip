@@ -232,13 +232,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
 template <int WAVES, int NSLOT>
 int launch_latent(const LatArgs& p, hipStream_t st) {
   constexpr int LDS = WAVES * NSLOT * CH_BYTES + 16 * 128 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_latent_kernel<WAVES, NSLOT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};  // per device (care_common.h)
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&attention_latent_kernel<WAVES, NSLOT>), LDS, lds_ok))
+    return e;
   const int blocks = min((p.rows + WAVES - 1) / WAVES, 256);
   hipLaunchKernelGGL((attention_latent_kernel<WAVES, NSLOT>), dim3(blocks), dim3(WAVES * 64), LDS, st, p);
   return care_launch_status();
@@ -260,11 +256,8 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
   p.rows_per_kv = rows_per_kv; p.nkeys = nkeys; p.bias = bias; p.bias_ld = bias_ld;
   p.ct = reinterpret_cast<bf16_t*>(ct); p.ldc = ldc; p.rows = rows; p.heads = heads;
   hipStream_t st = (hipStream_t)stream;
-  static int cfg = -1;
-  if (cfg < 0) {
-    const char* e = getenv("CARE_LAT_CFG");  // tuning: 0 = 4 waves x 2 slots, 1 = 3 waves x 3 slots
-    cfg = e ? atoi(e) : 0;
-  }
+  // tuning: 0 = 4 waves x 2 slots, 1 = 3 waves x 3 slots (read once; initialisation is thread-safe)
+  static const int cfg = [] { const char* e = getenv("CARE_LAT_CFG"); return e ? atoi(e) : 0; }();
   if (cfg == 1) return launch_latent<3, 3>(p, st);
   return launch_latent<4, 2>(p, st);
 }

@@ -19,6 +19,22 @@ static inline int care_launch_status() {
 
 static inline bool care_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// Raise a kernel's dynamic-LDS limit, once per (kernel, device): `done` is a per-kernel bit mask
+// over device ordinals.  Safe from any thread: the attribute call is idempotent, so two racing first
+// callers at worst both make it.  Returns 0 or the hipError_t.
+#include <atomic>
+static inline int care_allow_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+
 __device__ __forceinline__ float care_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -259,7 +259,304 @@ int launch_ln(const LnArgs& p, hipStream_t st) {
   constexpr size_t ring = 3 * (BM * (AF32 ? 128 : 64) + LN_N * 64);
   constexpr size_t lds = ring > 64 * LN_N * 4 ? ring : 64 * LN_N * 4;  // the epilogue parks 64 x 512 fp32
   const int blocks = (p.M + BM - 1) / BM;
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_ln_kernel<AF32, RG>), (int)lds, lds_ok)) return e;
   hipLaunchKernelGGL((gemm_ln_kernel<AF32, RG>), dim3(blocks), dim3(256 * RG), lds, st, p);
+  return care_launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Version 2 (round 2): 128-row blocks, 8 waves, NO spills, loads specialised by wave.
+//
+// What was wrong with the 128-row form of the kernel above (RG = 2): at two waves per SIMD a wave
+// has 256 registers, the kernel wanted ~270 and spilled 25 dwords into a counted-vmcnt pipeline
+// (scratch traffic counts in vmcnt too); every wave issued loads of BOTH operands into one 3-slot
+// ring, so - vmcnt being in issue order - the short-latency W stream (L2 hits) and the long-latency
+// A stream (HBM: raw fp32 features) could be prefetched no deeper than each other: two K steps,
+// 32 KB of A in flight per CU = 8 MB on the chip, ~2 TB/s at HBM latency (measured 2.0); and the
+// epilogue parked the accumulators in LDS (two rounds of 128 KB, four barriers).  Here:
+//   * waves 0-3 stream W (8 DMA instructions per K step each), waves 4-7 stream A (4 or 2 each);
+//     each operand has its OWN ring - W: NSW slots of 32 KB, A: NSA slots of 16 KB (fp32) / 8 KB
+//     (bf16) - and each loader waits on its own counted vmcnt, so A runs NSA - 1 steps ahead
+//     (fp32 features: 5 x 16 KB = 80 KB in flight per CU) while W runs one or two;
+//   * all 8 waves compute (2 row groups x 4 column groups, 64 x 128 per wave, 128 accumulators);
+//     B fragments are read four at a time, fp32 A fragments converted as they are read: 0 scratch;
+//   * the LayerNorm is finished IN the accumulator registers: the W rows are permuted over the MFMA
+//     rows when the fragment is read (tile pair p, lane group fg -> columns 32 p + 8 fg + [0, 8)) so
+//     a lane holds 8 consecutive columns of its 4 rows; row statistics = per-lane sums, two
+//     xor-shuffles over the lane groups, and a 2-KB exchange between the four column-group waves
+//     through LDS (two-pass: mean, then centred squares); bias / residual / gamma / beta are read
+//     with 16-byte loads and every store is 16 bytes per lane (64 or 128 contiguous bytes per row).
+template <int N>
+__device__ __forceinline__ void ln2_wait_vm() {
+  static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+  else static_assert(N < 0, "add the immediate");
+}
+
+// wait until all but `younger` stages (PER DMA instructions each) of this wave's stream have landed
+template <int PER, int MAXY>
+__device__ __forceinline__ void ln2_wait_stages(int younger) {
+  if constexpr (MAXY >= 6) { if (younger >= 6) { ln2_wait_vm<6 * PER>(); return; } }
+  if constexpr (MAXY >= 5) { if (younger == 5) { ln2_wait_vm<5 * PER>(); return; } }
+  if constexpr (MAXY >= 4) { if (younger == 4) { ln2_wait_vm<4 * PER>(); return; } }
+  if constexpr (MAXY >= 3) { if (younger == 3) { ln2_wait_vm<3 * PER>(); return; } }
+  if constexpr (MAXY >= 2) { if (younger == 2) { ln2_wait_vm<2 * PER>(); return; } }
+  if constexpr (MAXY >= 1) { if (younger == 1) { ln2_wait_vm<PER>(); return; } }
+  ln2_wait_vm<0>();
+}
+
+template <bool AF32, int NSW, int NSA>
+__global__ __launch_bounds__(512, 2) void gemm_ln2_kernel(LnArgs p) {
+  constexpr int BM = 128;
+  constexpr int A_ROWB = AF32 ? 128 : 64;            // bytes per A row per K step of 32
+  constexpr int A_BYTES = BM * A_ROWB, W_BYTES = LN_N * 64;
+  constexpr int A_BASE = NSW * W_BYTES;
+  constexpr int NWI = W_BYTES / 1024 / 4;            // DMA instructions per stage per W wave: 8
+  constexpr int NAI = A_BYTES / 1024 / 4;            // per A wave: 4 (fp32) or 2 (bf16)
+  static_assert(NSW >= 2 && NSA >= 2 && NSW - 2 <= 6 && NSA - 2 <= 6, "ring depths");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave >> 2, cg = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+  const bool w_loader = wave < 4;
+  constexpr unsigned HTAB = (2u) | (3u << 3) | (4u << 6) | (2u << 9) | (5u << 12) | (7u << 15) | (4u << 18) | (1u << 21);
+
+  // ---- this wave's DMA source pointers at K step 0 (a W wave uses NWI of them, an A wave NAI)
+  const unsigned char* src[NWI];
+  if (w_loader) {
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {   // 16 rows of W x 4 chunks per instruction
+      const int n = (wave * NWI + i) * 16 + (lane >> 2), pch = lane & 3;
+      src[i] = reinterpret_cast<const unsigned char*>(p.W + (int64_t)n * p.K) + ((pch ^ ((n & 8) >> 2)) << 4);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      if (i >= NAI) { src[i] = nullptr; continue; }
+      const int q = (wave - 4) * NAI + i;
+      if constexpr (AF32) {           // 8 rows x 8 chunks per instruction
+        const int row = q * 8 + (lane >> 3), pch = lane & 7;
+        const int ch = pch ^ ((HTAB >> (3 * ((row & 15) >> 1))) & 7);
+        src[i] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const float*>(p.A) + (int64_t)min(m0 + row, p.M - 1) * p.lda) + ch * 16;
+      } else {                        // 16 rows x 4 chunks per instruction
+        const int row = q * 16 + (lane >> 2), pch = lane & 3;
+        const int ch = pch ^ ((row & 8) >> 2);
+        src[i] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const bf16_t*>(p.A) + (int64_t)min(m0 + row, p.M - 1) * p.lda) + ch * 16;
+      }
+    }
+  }
+  auto stage_w = [&](int kt) {
+    unsigned char* dst = smem + (kt % NSW) * W_BYTES + wave * (NWI * 1024);
+#pragma unroll
+    for (int i = 0; i < NWI; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * 64),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+  auto stage_a = [&](int kt) {
+    unsigned char* dst = smem + A_BASE + (kt % NSA) * A_BYTES + (wave - 4) * (NAI * 1024);
+#pragma unroll
+    for (int i = 0; i < NAI; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * A_ROWB),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane fragment offsets.  W: MFMA row i = 4 fg' + j of tile nt reads W row
+  // 128 cg + 32 (nt >> 1) + 8 (i >> 2) + 4 (nt & 1) + (i & 3)  (i = this lane's fr as the READER of row i),
+  // so that the lane that ends up with rows 4 fg + [0, 4) of tiles 2p and 2p + 1 owns 8 consecutive columns.
+  const int w_off0 = (cg * 128 + 8 * (fr >> 2) + (fr & 3)) * 64 + ((fg ^ ((fr & 4) >> 1)) << 4);
+  int a_off[4][AF32 ? 2 : 1];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int row = rg * 64 + mt * 16 + fr;
+    if constexpr (AF32) {
+      const int x = (HTAB >> (3 * (fr >> 1))) & 7;
+      a_off[mt][0] = row * 128 + (((2 * fg) ^ x) << 4);
+      a_off[mt][1] = row * 128 + (((2 * fg + 1) ^ x) << 4);
+    } else {
+      a_off[mt][0] = row * 64 + ((fg ^ ((fr & 8) >> 2)) << 4);
+    }
+  }
+
+  const int nk = p.K >> 5;
+  if (w_loader) {
+#pragma unroll 1
+    for (int s = 0; s < NSW - 1 && s < nk; ++s) stage_w(s);
+  } else {
+#pragma unroll 1
+    for (int s = 0; s < NSA - 1 && s < nk; ++s) stage_a(s);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    // my stream's stage kt must have landed; the younger stages of my stream stay in flight
+    if (w_loader) ln2_wait_stages<NWI, NSW - 2>(min(NSW - 2, nk - 1 - kt));
+    else ln2_wait_stages<NAI, NSA - 2>(min(NSA - 2, nk - 1 - kt));
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // the slot every wave finished reading in the previous iteration takes the next stage
+    if (w_loader) { if (kt + NSW - 1 < nk) stage_w(kt + NSW - 1); }
+    else { if (kt + NSA - 1 < nk) stage_a(kt + NSA - 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* sw = smem + (kt % NSW) * W_BYTES + w_off0;
+    const unsigned char* sa = smem + A_BASE + (kt % NSA) * A_BYTES;
+    bf16x8 fa[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if constexpr (AF32) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(sa + a_off[mt][0]);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(sa + a_off[mt][1]);
+        fa[mt][0] = (bf16_t)lo[0]; fa[mt][1] = (bf16_t)lo[1]; fa[mt][2] = (bf16_t)lo[2]; fa[mt][3] = (bf16_t)lo[3];
+        fa[mt][4] = (bf16_t)hi[0]; fa[mt][5] = (bf16_t)hi[1]; fa[mt][6] = (bf16_t)hi[2]; fa[mt][7] = (bf16_t)hi[3];
+      } else {
+        fa[mt] = *reinterpret_cast<const bf16x8*>(sa + a_off[mt][0]);
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      bf16x8 fb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nt = half * 4 + q;
+        fb[q] = *reinterpret_cast<const bf16x8*>(sw + ((nt >> 1) * 32 + (nt & 1) * 4) * 64);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[mt][half * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[q], fa[mt], acc[mt][half * 4 + q], 0, 0, 0);
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue (in registers)
+  // acc[mt][2p + e][j] = C[row 64 rg + 16 mt + fr][col 128 cg + 32 p + 8 fg + 4 e + j]
+  __builtin_amdgcn_s_barrier();  // the rings are dead: their first 4 KB become the statistics exchange
+  float* stat = reinterpret_cast<float*>(smem);            // [2 passes][128 rows][4 column groups]
+  const int col0 = cg * 128 + 8 * fg;
+  int grow[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) grow[mt] = m0 + rg * 64 + mt * 16 + fr;
+
+  float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pq = 0; pq < 4; ++pq) {
+    const int c = col0 + 32 * pq;
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + c); b1 = *reinterpret_cast<const float4*>(p.bias + c + 4); }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int gc = min(grow[mt], p.M - 1);
+      f32x4& v0 = acc[mt][2 * pq];
+      f32x4& v1 = acc[mt][2 * pq + 1];
+      v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
+      v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
+      if (p.res) {
+        const float4 r0 = *reinterpret_cast<const float4*>(p.res + (int64_t)gc * p.ldres + c);
+        const float4 r1 = *reinterpret_cast<const float4*>(p.res + (int64_t)gc * p.ldres + c + 4);
+        v0[0] += r0.x; v0[1] += r0.y; v0[2] += r0.z; v0[3] += r0.w;
+        v1[0] += r1.x; v1[1] += r1.y; v1[2] += r1.z; v1[3] += r1.w;
+      }
+      if (p.pos) {
+        const float* pp = p.pos + (int64_t)(gc % p.grp) * LN_N + c;
+        const float4 r0 = *reinterpret_cast<const float4*>(pp), r1 = *reinterpret_cast<const float4*>(pp + 4);
+        v0[0] += r0.x; v0[1] += r0.y; v0[2] += r0.z; v0[3] += r0.w;
+        v1[0] += r1.x; v1[1] += r1.y; v1[2] += r1.z; v1[3] += r1.w;
+      }
+      rsum[mt] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+    }
+  }
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    float s = rsum[mt];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (fg == 0) stat[(rg * 64 + mt * 16 + fr) * 4 + cg] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const float4 t = *reinterpret_cast<const float4*>(stat + (rg * 64 + mt * 16 + fr) * 4);
+    mean[mt] = ((t.x + t.y) + (t.z + t.w)) * (1.0f / LN_N);
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    float q = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const float a = acc[mt][nt][0] - mean[mt], b = acc[mt][nt][1] - mean[mt];
+      const float c = acc[mt][nt][2] - mean[mt], e = acc[mt][nt][3] - mean[mt];
+      q += (a * a + b * b) + (c * c + e * e);
+    }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (fg == 0) stat[512 + (rg * 64 + mt * 16 + fr) * 4 + cg] = q;
+  }
+  __syncthreads();
+  int64_t orow[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const float4 t = *reinterpret_cast<const float4*>(stat + 512 + (rg * 64 + mt * 16 + fr) * 4);
+    rstd[mt] = 1.0f / sqrtf(((t.x + t.y) + (t.z + t.w)) * (1.0f / LN_N) + p.eps);
+    orow[mt] = (int64_t)(grow[mt] / p.grp) * p.out_grp_rows + p.out_row_off + (grow[mt] % p.grp);
+  }
+#pragma unroll
+  for (int pq = 0; pq < 4; ++pq) {
+    const int c = col0 + 32 * pq;
+    const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + c), g1 = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+    const float4 e0 = *reinterpret_cast<const float4*>(p.beta + c), e1 = *reinterpret_cast<const float4*>(p.beta + c + 4);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (grow[mt] >= p.M) continue;
+      const f32x4 v0 = acc[mt][2 * pq], v1 = acc[mt][2 * pq + 1];
+      float4 o0, o1;
+      o0.x = (v0[0] - mean[mt]) * rstd[mt] * g0.x + e0.x; o0.y = (v0[1] - mean[mt]) * rstd[mt] * g0.y + e0.y;
+      o0.z = (v0[2] - mean[mt]) * rstd[mt] * g0.z + e0.z; o0.w = (v0[3] - mean[mt]) * rstd[mt] * g0.w + e0.w;
+      o1.x = (v1[0] - mean[mt]) * rstd[mt] * g1.x + e1.x; o1.y = (v1[1] - mean[mt]) * rstd[mt] * g1.y + e1.y;
+      o1.z = (v1[2] - mean[mt]) * rstd[mt] * g1.z + e1.z; o1.w = (v1[3] - mean[mt]) * rstd[mt] * g1.w + e1.w;
+      if (p.out) {
+        float* op = p.out + orow[mt] * p.ldo + c;
+        *reinterpret_cast<float4*>(op) = o0;
+        *reinterpret_cast<float4*>(op + 4) = o1;
+      }
+      if (p.outb) {
+        bf16x8 ob;
+        ob[0] = (bf16_t)o0.x; ob[1] = (bf16_t)o0.y; ob[2] = (bf16_t)o0.z; ob[3] = (bf16_t)o0.w;
+        ob[4] = (bf16_t)o1.x; ob[5] = (bf16_t)o1.y; ob[6] = (bf16_t)o1.z; ob[7] = (bf16_t)o1.w;
+        *reinterpret_cast<bf16x8*>(p.outb + orow[mt] * p.ldo + c) = ob;
+      }
+    }
+  }
+}
+
+template <bool AF32, int NSW, int NSA>
+int launch_ln2(const LnArgs& p, hipStream_t st) {
+  constexpr int LDS = NSW * LN_N * 64 + NSA * 128 * (AF32 ? 128 : 64);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_ln2_kernel<AF32, NSW, NSA>), LDS, lds_ok)) return e;
+  hipLaunchKernelGGL((gemm_ln2_kernel<AF32, NSW, NSA>), dim3((p.M + 127) / 128), dim3(512), LDS, st, p);
   return care_launch_status();
 }
 
@@ -288,6 +585,16 @@ extern "C" int care_gemm_ln(const void* A, int64_t lda, int a_dtype, const void*
   const long rounds1 = ((M + 63) / 64 + 255) / 256, rounds2 = ((M + 127) / 128 + 255) / 256;
   bool big = 10 * rounds1 > 13 * rounds2;
   if (const char* e = getenv("CARE_LN_RG")) big = atoi(e) >= 2;  // tuning override
+  static const int v2 = [] { const char* e = getenv("CARE_LN_V2"); return e ? atoi(e) : 1; }();  // A/B switch
+  if (big && v2) {
+    if (a_dtype == CARE_F32) {
+      if (v2 == 2) return launch_ln2<true, 3, 4>(p, st);
+      return launch_ln2<true, 2, 6>(p, st);
+    }
+    if (v2 == 2) return launch_ln2<false, 2, 6>(p, st);
+    if (v2 == 3) return launch_ln2<false, 3, 8>(p, st);
+    return launch_ln2<false, 3, 4>(p, st);
+  }
   if (a_dtype == CARE_F32) return big ? launch_ln<true, 2>(p, st) : launch_ln<true, 1>(p, st);
   return big ? launch_ln<false, 2>(p, st) : launch_ln<false, 1>(p, st);
 }

@@ -68,8 +68,16 @@ class FeaturePrefetcher:
     """Double-buffered pinned staging + asynchronous H2D on a side stream.
 
     `for feats in FeaturePrefetcher(batches, device)` yields device tensors; the copy of batch
-    i+1 overlaps the compute on batch i.  The yielded tensors are reused every other batch, so
+    i+1 overlaps the compute on batch i.  The yielded tensors are reused every `depth` batches, so
     the hipGraph keyed on their addresses (engine.translate_greedy) replays.
+
+    A slot (pinned buffers + device tensors) is restaged only when both of its earlier users are
+    done with it, with no host synchronisation of the consumer required:
+      * the consumer's kernels that read the device tensors: when the consumer asks for the next
+        batch it has enqueued that work on its stream; an event recorded there at that moment is
+        what the side stream waits for before the next H2D into the same tensors;
+      * the earlier asynchronous H2D that reads the pinned buffers: the host waits for that copy's
+        event before overwriting them.
     """
 
     def __init__(self, batches, device, depth: int = 2):
@@ -80,27 +88,46 @@ class FeaturePrefetcher:
     def _slot(self, i, like):
         while len(self.slots) <= i:
             self.slots.append(None)
-        if self.slots[i] is None or any(a.shape != b.shape for a, (b, _) in zip(like, self.slots[i])):
-            self.slots[i] = [(torch.empty(t.shape, dtype=torch.float32).pin_memory(),
-                              torch.empty(t.shape, dtype=torch.float32, device=self.device)) for t in like]
-        return self.slots[i]
+        slot = self.slots[i]
+        if slot is None or any(a.shape != b.shape for a, (b, _) in zip(like, slot["bufs"])):
+            if slot is not None:  # both users of the old buffers must be done before they are dropped
+                for ev in (slot["staged"], slot["consumed"]):
+                    if ev is not None:
+                        ev.synchronize()
+            slot = {"bufs": [(torch.empty(t.shape, dtype=torch.float32).pin_memory(),
+                              torch.empty(t.shape, dtype=torch.float32, device=self.device)) for t in like],
+                    "staged": None, "consumed": None}
+            self.slots[i] = slot
+        return slot
+
+    def _stage(self, slot, batch):
+        if slot["staged"] is not None:
+            slot["staged"].synchronize()  # the previous H2D out of these pinned buffers has finished
+        with torch.cuda.stream(self.stream):
+            if slot["consumed"] is not None:
+                self.stream.wait_event(slot["consumed"])  # the consumer's reads of the device tensors
+            for src, (pin, dev) in zip(batch, slot["bufs"]):
+                pin.copy_(src)
+                dev.copy_(pin, non_blocking=True)
+            slot["staged"] = torch.cuda.Event()
+            slot["staged"].record(self.stream)
+
+    def _hand_over(self, slot):
+        torch.cuda.current_stream(self.device).wait_event(slot["staged"])
+        return [dev for _, dev in slot["bufs"]]
 
     def __iter__(self):
         pending, i = None, 0
         for batch in self.batches:
             slot = self._slot(i % self.depth, batch)
-            event = torch.cuda.Event()
-            with torch.cuda.stream(self.stream):
-                for src, (pin, dev) in zip(batch, slot):
-                    pin.copy_(src)
-                    dev.copy_(pin, non_blocking=True)
-                event.record(self.stream)
+            self._stage(slot, batch)
             if pending is not None:
-                ev, devs = pending
-                torch.cuda.current_stream(self.device).wait_event(ev)
-                yield devs
-            pending, i = (event, [dev for _, dev in slot]), i + 1
+                yield self._hand_over(pending)
+                # resumed: whatever the consumer launched on the yielded tensors is on its stream now
+                pending["consumed"] = torch.cuda.Event()
+                pending["consumed"].record(torch.cuda.current_stream(self.device))
+            pending, i = slot, i + 1
         if pending is not None:
-            ev, devs = pending
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            yield devs
+            yield self._hand_over(pending)
+            pending["consumed"] = torch.cuda.Event()
+            pending["consumed"].record(torch.cuda.current_stream(self.device))

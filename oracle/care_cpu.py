@@ -265,6 +265,14 @@ class HostBeam:
         self.tokens: List[torch.Tensor] = [torch.full((size,), BOS, dtype=torch.long)]
         self.finished: List[list] = []
         self.done = False
+        # tie audit (test infrastructure, not part of the reference): the smallest gap this clip's
+        # search ever saw at the selection boundary (size-th vs next candidate) and between
+        # neighbours inside the selected set
+        self.gap_select = float("inf")
+        self.gap_order = float("inf")
+        # per live beam: how close its ancestry ever came to being pruned (candidate value minus
+        # the best candidate that was NOT selected, minimum over the steps so far)
+        self.slack = [float("inf")] * size
 
     def prefixes(self) -> torch.Tensor:
         order = torch.sort(self.scores, 0, True)[1]
@@ -288,13 +296,18 @@ class HostBeam:
         else:
             cand = logp[0]
         best, flat = cand.reshape(-1).topk(self.size, 0, True, True)
+        wide = cand.reshape(-1).topk(self.size + 1, 0, True, True)[0]
+        self.gap_select = min(self.gap_select, float(wide[self.size - 1] - wide[self.size]))
+        if self.size > 1:
+            self.gap_order = min(self.gap_order, float((wide[:-2] - wide[1:-1]).min()))
         self.scores = best
         parent = flat // vocab
+        self.slack = [min(self.slack[int(parent[i])], float(best[i] - wide[self.size])) for i in range(self.size)]
         self.parents.append(parent)
         self.tokens.append(flat - parent * vocab)
         for i in range(self.size):
             if int(self.tokens[-1][i]) == EOS:
-                self.finished.append([float(self.scores[i]), len(self.parents), i])
+                self.finished.append([float(self.scores[i]), len(self.parents), i, self.slack[i]])
                 if len(self.finished) >= self.need:
                     self.done = True
                     return True
@@ -302,11 +315,11 @@ class HostBeam:
             self.done = True
             if not self.finished:
                 for i in range(self.size):
-                    self.finished.append([float(self.scores[i]), len(self.parents), i])
+                    self.finished.append([float(self.scores[i]), len(self.parents), i, self.slack[i]])
         return self.done
 
     def ranked(self, alpha: float):
-        return sorted(([s / (t ** alpha), t, k] for s, t, k in self.finished), key=lambda a: -a[0])
+        return sorted(([s / (t ** alpha), t, k, sl] for s, t, k, sl in self.finished), key=lambda a: -a[0])
 
     def hypothesis(self, t: int, k: int) -> List[int]:
         return self._walk(k, t, with_bos=False)
@@ -317,14 +330,18 @@ def _repeat_rows(x: torch.Tensor, times: int) -> torch.Tensor:
     return x.unsqueeze(1).repeat(1, times, *([1] * (x.dim() - 1))).reshape(x.shape[0] * times, *x.shape[1:])
 
 
-def translate_batch(P, opt: dict, feats: List[torch.Tensor], return_trace: bool = False):
+def translate_batch(P, opt: dict, feats: List[torch.Tensor], return_trace: bool = False, return_gaps: bool = False):
     """`Translator_ARFormer.translate_batch` (models/Translator.py:35-85) for one model.
 
     Greedy decoding is beam search with `beam_size == 1` (models/Wrapper.py:34-35).
     Returns `(batch_hyps, batch_scores)` exactly like the reference: python ints without
     BOS and including EOS when emitted; python floats (length-normalised).
     With `return_trace`, also the per-step top-2 log-prob margins of every live row
-    (the tie audit of SURVEY.md 8(c)).
+    (the tie audit of SURVEY.md 8(c)).  With `return_gaps`, also one dict per clip with the
+    smallest decision margins of its search: `select` (beam_size-th vs next candidate; for
+    greedy the top-1/top-2 log-prob margin), `order` (neighbours inside the selected set),
+    `rank` (neighbours among the n_best + 1 best finished hypotheses, length-normalised) and
+    `best_slack` (how close the winning hypothesis' ancestry ever came to being pruned).
     """
     bm = int(opt.get("beam_size", 5))
     n_best = int(opt.get("topk", 1))
@@ -357,12 +374,29 @@ def translate_batch(P, opt: dict, feats: List[torch.Tensor], return_trace: bool 
         # models/Translator.py:211-220: `n_best = min(n_best, len(scores))` is re-assigned
         # inside the loop over clips, so once one clip has fewer finished hypotheses than
         # `topk`, every LATER clip is truncated to that count as well.  Kept as is.
-        hyps, scores = [], []
+        hyps, scores, gaps = [], [], []
         for b in beams:
             ranked = b.ranked(alpha)
+            head = [r[0] for r in ranked[: n_best + 1]]
+            gaps.append(dict(select=b.gap_select, order=b.gap_order, best_slack=ranked[0][3],
+                             rank=min([a - c for a, c in zip(head, head[1:])] or [float("inf")])))
             n_best = min(n_best, len(ranked))
-            hyps.append([b.hypothesis(t, k) for _, t, k in ranked[:n_best]])
-            scores.append([s for s, _, _ in ranked[:n_best]])
+            hyps.append([b.hypothesis(t, k) for _, t, k, _ in ranked[:n_best]])
+            scores.append([s for s, _, _, _ in ranked[:n_best]])
+    if return_gaps:
+        return hyps, scores, gaps
     if return_trace:
         return hyps, scores, margins
     return hyps, scores
+
+
+def score_hypothesis(P, opt: dict, inputs: Dict[str, torch.Tensor], hyp: List[int]) -> float:
+    """Exact fp32 score of ONE hypothesis of ONE clip as the beam would report it: sum of the
+    log-probs of its tokens (teacher-forced on its own prefix) / len**alpha (Beam.py:91-101).
+    `inputs` = decoder inputs of that clip (batch dim 1).  Audit helper for the bf16 beam tests."""
+    alpha = float(opt.get("beam_alpha", 1.0))
+    with torch.no_grad():
+        ids = torch.tensor([[BOS] + list(hyp[:-1])], dtype=torch.long)
+        logp = torch.log_softmax(decoding_phase(P, opt, ids, inputs, False)["logits"][0], dim=-1)
+        total = float(logp[torch.arange(len(hyp)), torch.tensor(hyp)].sum())
+    return total / (len(hyp) ** alpha)

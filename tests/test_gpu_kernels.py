@@ -304,9 +304,16 @@ def test_fused_label_scoring(M):
     assert torch.equal(pred[safe].long(), logits.argmax(1)[safe]) and torch.equal(pred2.long(), logits.argmax(1))
 
 
+@pytest.mark.parametrize("form", ["auto", "128-row blocks"])
 @pytest.mark.parametrize("a_f32", [True, False])
-@pytest.mark.parametrize("M,K", [(7, 128), (64, 512), (200, 2048), (28 * 300, 512), (128 * 300 + 5, 128), (40000, 2048)])
-def test_gemm_ln_fused(a_f32, M, K):
+@pytest.mark.parametrize("M,K", [(7, 128), (64, 512), (200, 2048), (28 * 300, 512), (128 * 300 + 5, 128), (40000, 2048),
+                                 (28 * 1171, 32), (1000, 96), (129, 64)])
+def test_gemm_ln_fused(a_f32, M, K, form, monkeypatch):
+    """form: the library picks 64- or 128-row blocks by launch rounds; CARE_LN_RG=2 forces the 128-row
+    kernel (wave-specialised loaders, LayerNorm in the accumulator registers) onto every shape, ragged
+    last blocks and K shorter than its ring depth included."""
+    if form != "auto":
+        monkeypatch.setenv("CARE_LN_RG", "2")
     d, grp = 512, 28 if M % 28 == 0 else M
     A = _rand(M, K, seed=50)
     W = _rand(d, K, seed=51, scale=1 / math.sqrt(K))

@@ -78,11 +78,26 @@ def test_translate_batch_fp32(golden):
 # ----------------------------------------------------------------------------- bf16 mode
 # A bf16 rounding of an O(1) activation is already up to 2^-8 = 3.9e-3, so the 1e-3 of the
 # north star is not attainable by any path that stores or multiplies bf16.
-# Bars asserted here, measured on MI355X with margin: hidden states max-abs <= 4e-2 and
-# mean-abs <= 5e-3 against the fp32 reference; concept outputs exact (they stay fp32);
+# Bars asserted here = the worst value MEASURED over the fixtures on MI355X + 25% (max-abs,
+# mean-abs of the teacher-forced hidden states against the fp32 reference; bench.py reports the same
+# two numbers for the benchmarked model in its JSON line); concept outputs exact (they stay fp32);
 # logsumexp of the logits <= 1e-3; greedy ids identical wherever the reference's own
 # top-1/top-2 margin exceeds the bf16 noise (audited against the oracle's margins).
 BF16_MAX, BF16_MEAN = 4e-2, 5e-3
+# logsumexp of the logits: bf16 noise of a logit scales with the norm of its vocabulary row, so the
+# `peaked` fixtures (rows scaled by 12 / 20, logits up to +-30) get a bar of their own
+BF16_LSE, BF16_LSE_PEAKED = 1e-3, 3.5e-2
+
+
+def _record(name, **values):
+    """Measured errors -> gpurun_out/bf16_err.jsonl (scratch; the bars above are set from it)."""
+    import json
+    import os
+
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "bf16_err.jsonl"), "a") as f:
+            f.write(json.dumps(dict(case=name, **values)) + "\n")
 
 
 def test_encoding_and_teacher_forced_bf16(golden):
@@ -100,16 +115,41 @@ def test_encoding_and_teacher_forced_bf16(golden):
     out = model.feedforward_step({"feats": _dev(feats), "input_ids": ids.to("cuda:0")})
     n = z["tf_hidden_states"].shape[0]
     diff = np.abs(out["hidden_states"][:n].float().cpu().numpy() - z["tf_hidden_states"])
+    lse = _maxdiff(torch.logsumexp(out["logits"], -1), z["tf_logits_lse"])
+    _record(golden.name, hidden_max=float(diff.max()), hidden_mean=float(diff.mean()), lse_max=lse,
+            mem_max=_maxdiff(enc["encoder_hidden_states"][0], z["encoder_hidden_states_clip0"]))
     assert diff.max() < BF16_MAX and diff.mean() < BF16_MEAN, (diff.max(), diff.mean())
-    assert _maxdiff(torch.logsumexp(out["logits"], -1), z["tf_logits_lse"]) < 1e-3
+    assert lse < (BF16_LSE_PEAKED if "peaked" in golden.name else BF16_LSE), lse
+
+
+def _audit_greedy(P, opt, one, h, r, tol):
+    """A bf16 greedy caption `h` that differs from the oracle's `r`: the first differing step must be
+    a near-tie of the ORACLE's distribution on the common prefix (margin < tol), and the token the
+    GPU took must be within tol of the best."""
+    from oracle import care_cpu
+
+    t = next((k for k in range(min(len(h), len(r))) if h[k] != r[k]), None)
+    assert t is not None, "one caption is a prefix of the other: {} vs {}".format(h, r)
+    prefix = torch.tensor([[2] + r[:t]])
+    logp = torch.log_softmax(care_cpu.decoding_phase(P, opt, prefix, one, True)["logits"], dim=1)[0]
+    top2 = logp.topk(2)[0]
+    assert float(top2[0] - top2[1]) < tol, "bf16 greedy diverged at a clear-margin step ({:.4f})".format(
+        float(top2[0] - top2[1]))
+    assert float(logp.max() - logp[h[t]]) < tol
+
+
+GREEDY_TIE_TOL = 5e-3   # log-prob units; a step decided by less than this may flip in bf16
+CLEAR_MARGIN = 0.1      # a clip whose every step is decided by more than this must be bit-exact
 
 
 @pytest.mark.parametrize("absorbed", [False, True])
 def test_greedy_bf16_matches_up_to_near_ties(golden, absorbed):
-    """bf16 greedy ids vs the oracle: any divergence must start at a step where the oracle's
-    own top-1/top-2 log-prob margin is tiny (random-init logits are nearly flat).  Both forms of
-    the cross-attention: projected K/V (what these small batches use by default) and the absorbed
-    form (engine.latent_for, forced here by dropping its row threshold)."""
+    """bf16 greedy ids vs the oracle.  A clip whose reference search never saw a margin below
+    CLEAR_MARGIN (fixture `gap_select`) must come out bit-exact - that is every clip of the `peaked`
+    fixtures; any other divergence must start at a step where the oracle's own top-1/top-2 log-prob
+    margin is below GREEDY_TIE_TOL (random-init logits are nearly flat).  Both forms of the
+    cross-attention: projected K/V (what these small batches use by default) and the absorbed form
+    (engine.latent_for, forced here by dropping its row threshold)."""
     from care_amd import get_translator
     from oracle import care_cpu
 
@@ -123,21 +163,76 @@ def test_greedy_bf16_matches_up_to_near_ties(golden, absorbed):
             pytest.skip("absorbed cross-attention covers d_model = 512 only")
         eng.LATENT_MIN_ROWS = 1
     assert eng.latent_for(feats[0].shape[0]) == absorbed
-    hyps, _ = get_translator(opt).translate_batch([model], {"feats": _dev(feats)})
-    ref_hyps, _ = golden.hyps()
+    hyps, scores = get_translator(opt).translate_batch([model], {"feats": _dev(feats)})
+    ref_hyps, ref_scores = golden.hyps()
+    gap = golden.z["gap_select"]
     enc = care_cpu.encoding_phase(P, opt, feats)
     inputs = care_cpu.inputs_for_decoder(opt, enc)
     for i, (h, r) in enumerate(zip(hyps, ref_hyps)):
         h, r = h[0], r[0]
+        if gap[i] >= CLEAR_MARGIN:
+            assert h == r, "clip {}: every reference step decided by >= {} but bf16 ids differ".format(i, gap[i])
         if h == r:
+            assert abs(scores[i][0] - ref_scores[i][0]) < (BF16_LSE_PEAKED if "peaked" in golden.name else 2e-2)
             continue
-        t = next(k for k in range(min(len(h), len(r))) if h[k] != r[k])
-        prefix = torch.tensor([[2] + r[:t]])
+        _audit_greedy(P, opt, {k: v[i:i + 1] for k, v in inputs.items()}, h, r, GREEDY_TIE_TOL)
+    if "peaked" in golden.name:
+        assert hyps == ref_hyps
+
+
+BEAM_SCORE_TOL = 2e-2   # length-normalised log-prob: bf16 noise on a hypothesis' own score
+BEAM_TIE_TOL = 2e-2     # how close two hypotheses / a pruning decision must be to count as a tie
+
+
+@pytest.mark.parametrize("absorbed", [False, True])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_beam_bf16_vs_oracle(golden, absorbed, use_graph):
+    """bf16 beam search (fused two-pass selection, device beam state) vs the reference, per clip:
+      * the score the GPU reports for its best hypothesis is that hypothesis' exact fp32 score
+        (oracle teacher-forced rescoring) within bf16 noise - whatever path the search took;
+      * if the best hypothesis differs from the reference's, the two are a near-tie under exact
+        scoring, or the reference's winner was within BEAM_TIE_TOL of being pruned at some step
+        (fixture `gap_best_slack`), or its final lead over the runner-up was that small (`gap_rank`);
+      * a clip with clear margins everywhere (the `peaked` fixture) must be bit-exact.
+    use_graph: the hipGraph-captured pass (third call on the same buffers replays) vs eager."""
+    from care_amd import get_translator
+    from oracle import care_cpu
+
+    opt, P, feats, _ = golden.build()
+    if opt.get("beam_size", 1) == 1:
+        pytest.skip("beam audit")
+    model = _model(opt, P, "bf16")
+    eng = model.engine()
+    if absorbed:
+        if not eng.latent_capable:
+            pytest.skip("absorbed cross-attention covers d_model = 512 only")
+        eng.LATENT_MIN_ROWS = 1
+    dev = _dev(feats)
+    tr = get_translator(opt)
+    for _ in range(3 if use_graph else 1):  # first sight (eager), capture, replay
+        hyps, scores = tr.translate_batch([model], {"feats": dev}, use_graph=use_graph)
+    if use_graph:
+        assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] == "beam"), "beam pass was not captured"
+    ref_hyps, ref_scores = golden.hyps()
+    z = golden.z
+    enc = care_cpu.encoding_phase(P, opt, feats)
+    inputs = care_cpu.inputs_for_decoder(opt, enc)
+    for i, (hs, rs) in enumerate(zip(hyps, ref_hyps)):
         one = {k: v[i:i + 1] for k, v in inputs.items()}
-        logp = torch.log_softmax(care_cpu.decoding_phase(P, opt, prefix, one, True)["logits"], dim=1)[0]
-        top2 = logp.topk(2)[0]
-        assert float(top2[0] - top2[1]) < 5e-3, "bf16 greedy diverged at a clear-margin step"
-        assert float(logp.max() - logp[h[t]]) < 5e-3
+        h, r = hs[0], rs[0]
+        exact_h = care_cpu.score_hypothesis(P, opt, one, h)
+        assert abs(scores[i][0] - exact_h) < (BF16_LSE_PEAKED if "peaked" in golden.name else BEAM_SCORE_TOL), \
+            (i, scores[i][0], exact_h)
+        clear = z["gap_best_slack"][i] >= CLEAR_MARGIN and z["gap_rank"][i] >= 0.05
+        if clear:
+            assert h == r, "clip {}: clear reference margins but the bf16 beam winner differs".format(i)
+        if h != r:
+            near_tie = abs(exact_h - ref_scores[i][0]) < BEAM_TIE_TOL
+            assert near_tie or z["gap_best_slack"][i] < BEAM_TIE_TOL or z["gap_rank"][i] < BEAM_TIE_TOL, \
+                "clip {}: bf16 beam winner {} (exact {:.4f}) vs reference {} ({:.4f}) with clear margins".format(
+                    i, h, exact_h, r, ref_scores[i][0])
+    if "peaked" in golden.name:
+        assert [h[0] for h in hyps] == [r[0] for r in ref_hyps]
 
 
 def test_checkpoint_ingestion_and_prefetcher_gpu(tmp_path):

@@ -71,6 +71,37 @@ def test_checkpoint_roundtrip_without_lightning(tmp_path):
     load_model(path, device=None, strict=False)
 
 
+def test_checkpoint_overrides_default_like_the_reference_and_hostile_pickles_are_refused(tmp_path):
+    """models/__init__.py:115-120 passes `new_opt_used_to_override={}` unless told otherwise, which
+    replaces the saved hyper-parameter: the overrides stored in the file do not apply by themselves.
+    And a third-party checkpoint cannot run code at load: any global outside the allow-list raises."""
+    import pickle
+
+    from care_amd.checkpoint import load_model, read_checkpoint
+    from care_amd.configs import make_opt
+    from care_amd.framework import get_framework
+    from care_amd.synth import synth_state_dict
+
+    opt = make_opt("msvd_base_i", beam_size=5)
+    sd = synth_state_dict(9, [(k, tuple(v.shape)) for k, v in get_framework(opt).state_dict().items()])
+    path = str(tmp_path / "m.ckpt")
+    _fake_lightning_checkpoint(path, opt, sd, {"beam_size": 1, "topk": 3})
+    assert load_model(path, device=None, replace_paths=False).translator.beam_size == 5      # stored overrides dropped
+    stored = read_checkpoint(path)["new_opt"]
+    assert load_model(path, stored, device=None, replace_paths=False).translator.topk == 3   # unless passed again
+
+    class Hostile:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > {}".format(tmp_path / "pwned"),))
+
+    evil = str(tmp_path / "evil.ckpt")
+    torch.save({"state_dict": {}, "hyper_parameters": {"opt": opt, "payload": Hostile()}}, evil)
+    with pytest.raises(pickle.UnpicklingError, match="refusing to import"):
+        read_checkpoint(evil)
+    assert not os.path.exists(tmp_path / "pwned")
+
+
 def test_frame_sampling_and_detokenisation_match_reference():
     from care_amd.data import get_uniform_ids_from_k_snippets, resampling
     from care_amd.text import to_sentence

@@ -71,3 +71,35 @@ def test_state_dict_inventory(golden):
     m = golden.meta
     if m["config"] in ("msrvtt_care", "msrvtt_care_beam5"):
         assert m["n_params"] == 18218884
+
+
+def test_decision_gaps_recorded_with_the_fixture(golden):
+    """The smallest decision margins of every clip's search (oracle/care_cpu.py `return_gaps`) are
+    stored beside the reference outputs; the bf16 GPU tests read them to decide what a near-tie may
+    excuse.  The "peaked" fixtures were chosen (gen_golden.py `search-peaked`) so that nothing needs
+    excusing: every greedy step is decided by >= 0.1, the beam-5 winner was never within 0.1 of being
+    pruned and finishes >= 0.05 ahead of the runner-up."""
+    opt, P, feats, _ = golden.build()
+    z = golden.z
+    _, _, gaps = care_cpu.translate_batch(P, opt, feats, return_gaps=True)
+    np.testing.assert_allclose([g["select"] for g in gaps], z["gap_select"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose([min(g["rank"], 1e30) for g in gaps], z["gap_rank"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose([min(g["best_slack"], 1e30) for g in gaps], z["gap_best_slack"], rtol=0, atol=1e-5)
+    if "peaked" in golden.name:
+        if opt["beam_size"] == 1:
+            assert z["gap_select"].min() >= 0.1
+        else:
+            assert z["gap_best_slack"].min() >= 0.1 and z["gap_rank"].min() >= 0.05
+
+
+def test_score_hypothesis_reproduces_the_beam_scores(golden):
+    """care_cpu.score_hypothesis (the audit helper of the bf16 beam tests): teacher-forced rescoring of
+    a reference hypothesis gives the reference's own length-normalised score."""
+    opt, P, feats, _ = golden.build()
+    ref_hyps, ref_scores = golden.hyps()
+    with torch.no_grad():
+        enc = care_cpu.encoding_phase(P, opt, feats)
+    inputs = care_cpu.inputs_for_decoder(opt, enc)
+    for i in range(min(2, len(ref_hyps))):
+        one = {k: v[i:i + 1] for k, v in inputs.items()}
+        assert abs(care_cpu.score_hypothesis(P, opt, one, ref_hyps[i][0]) - ref_scores[i][0]) < 2e-5

@@ -54,9 +54,10 @@ def main():
 def ln_main():
     """care_gemm_ln (fused LayerNorm epilogue) on embedder / decode shapes."""
     import os
-    print("CARE_LN_RG=%s" % os.environ.get("CARE_LN_RG"))
-    for M, K, f32 in [(458752, 2048, True), (458752, 512, True), (458752, 128, True), (32768, 512, False), (32768, 2048, False), (16384, 512, False),
-                      (16384, 2048, False), (4096, 512, False), (4096, 2048, False)]:
+    print("CARE_LN_RG=%s CARE_LN_V2=%s" % (os.environ.get("CARE_LN_RG"), os.environ.get("CARE_LN_V2")))
+    for M, K, f32 in [(917504, 2048, True), (917504, 512, True), (917504, 128, True), (458752, 2048, True), (458752, 512, True),
+                      (458752, 128, True), (65536, 512, False), (65536, 2048, False), (32768, 512, False), (32768, 2048, False),
+                      (16384, 512, False), (16384, 2048, False), (4096, 512, False), (4096, 2048, False)]:
         A = torch.randn(M, K, device=DEV)
         Ain = A if f32 else A.to(torch.bfloat16)
         W = (torch.randn(512, K, device=DEV) * 0.05).to(torch.bfloat16)
@@ -68,7 +69,9 @@ def ln_main():
         resp = None if f32 else p(res)  # the embedder (raw fp32 features) has no residual
         t = time_call(lambda: _lib.call("care_gemm_ln", p(Ain), K, 0 if f32 else 1, p(W), p(bias), resp, 512, None,
                                         p(g), p(b), 1e-12, p(out), p(outb), 512, M, 512, K, M, M, 0), iters=5)
-        print("gemm_ln M=%6d K=%4d A=%s: %8.1f us (%6.1f TF)" % (M, K, "f32" if f32 else "bf16", t, 2.0 * M * 512 * K / t / 1e6), flush=True)
+        nbytes = M * K * (4 if f32 else 2) + M * 512 * (6 if f32 else 10)  # A in; fp32 + bf16 out; (+ fp32 residual in)
+        print("gemm_ln M=%6d K=%4d A=%s: %8.1f us (%6.1f TF, %5.2f TB/s)" % (M, K, "f32" if f32 else "bf16", t, 2.0 * M * 512 * K / t / 1e6,
+                                                                          nbytes / t / 1e6), flush=True)
 
 
 def f32_main():
