@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -33,6 +33,8 @@ SIGNATURES = {
                                  _P, _P, _L, _I, _P],
     "care_add_ln": [_P, _L, _P, _L, _P, _P, _P, _F, _P, _P, _L, _I, _I, _I, _I, _I, _I, _L, _P],
     "care_gemm_ln": [_P, _L, _I, _P, _P, _P, _L, _P, _P, _P, _F, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "care_gemm_ln_packed": [_P, _L, _I, _P, _P, _P, _L, _P, _P, _F, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "care_pack_ln_weight": [_P, _P, _I, _I, _P],
     "care_gemm_bf16_splitk": [_P, _L, _I, _P, _P, _P, _L, _L, _I, _I, _I, _P],
     "care_group_mean": [_P, _L, _I, _I, _I, _P, _L, _I, _I, _I, _P],
     "care_concept_finish": [_P, _L, _P, _L, _P, _I, _I, _P],

@@ -28,6 +28,7 @@
 // registers in AGPRs, one wave per SIMD) for the embedder shape (M = 458752, fp32 features) it is
 // not LDS-bound any more and still loses: 2.41 ms (K = 2048) / 0.90 ms (K = 512) against 2.09 / 0.80.
 #include <cstdlib>
+#include <type_traits>
 
 #include "care_common.h"
 
@@ -42,6 +43,7 @@ struct LnArgs {
   const float* gamma; const float* beta; float eps;
   float* out; bf16_t* outb; int64_t ldo;
   int M, K, grp, out_grp_rows, out_row_off;
+  int w_packed;  // W is in the K-step-major DMA order of care_pack_ln_weight (version-2 kernels only)
 };
 
 template <int N>
@@ -267,47 +269,51 @@ int launch_ln(const LnArgs& p, hipStream_t st) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Version 2 (round 2): 128-row blocks, 8 waves, NO spills, loads specialised by wave.
+// Version 2 (round 2): 64- or 128-row blocks (RG = 1, 2), loads specialised by wave, LayerNorm
+// finished in the accumulator registers, fragment reads software-pipelined across the K-step barrier.
 //
-// What was wrong with the 128-row form of the kernel above (RG = 2): at two waves per SIMD a wave
-// has 256 registers, the kernel wanted ~270 and spilled 25 dwords into a counted-vmcnt pipeline
-// (scratch traffic counts in vmcnt too); every wave issued loads of BOTH operands into one 3-slot
-// ring, so - vmcnt being in issue order - the short-latency W stream (L2 hits) and the long-latency
-// A stream (HBM: raw fp32 features) could be prefetched no deeper than each other: two K steps,
-// 32 KB of A in flight per CU = 8 MB on the chip, ~2 TB/s at HBM latency (measured 2.0); and the
-// epilogue parked the accumulators in LDS (two rounds of 128 KB, four barriers).  Here:
-//   * waves 0-3 stream W (8 DMA instructions per K step each), waves 4-7 stream A (4 or 2 each);
-//     each operand has its OWN ring - W: NSW slots of 32 KB, A: NSA slots of 16 KB (fp32) / 8 KB
-//     (bf16) - and each loader waits on its own counted vmcnt, so A runs NSA - 1 steps ahead
-//     (fp32 features: 5 x 16 KB = 80 KB in flight per CU) while W runs one or two;
-//   * all 8 waves compute (2 row groups x 4 column groups, 64 x 128 per wave, 128 accumulators);
-//     B fragments are read four at a time, fp32 A fragments converted as they are read: 0 scratch;
+// What was wrong with the kernel above: (1) its fp32-A form read LDS through HIP's `float4`, and for
+// such a read hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front while an LDS-DMA is in flight
+// (ext_vector types do not trigger it): every prefetched stage was drained before the K step could
+// start - the embedder ran at 2.0 TB/s; (2) at two waves per SIMD (RG = 2) it wanted ~270 registers
+// of 256 and spilled; (3) every wave issued loads of BOTH operands into one ring, so - vmcnt being
+// in issue order - the short-latency W stream (L2 hits) and the long-latency A stream (HBM) could be
+// prefetched no deeper than each other; (4) the epilogue parked the accumulators in LDS (128 KB per
+// row group, four barriers).  Here:
+//   * the first half of the waves streams W, the second half streams A; each operand has its OWN
+//     ring (W: NSW slots of 32 KB; A: NSA slots of 64 RG x 128 B (fp32) or 64 B (bf16)) and each
+//     loader waits on its own counted vmcnt, so raw fp32 features run NSA - 1 K steps ahead;
+//   * ONE barrier per K step, in the MIDDLE of the step's MFMAs: a wave reads the second half of the
+//     step's B fragments at the top, issues half of the MFMAs, then waits for its own stream's next
+//     stage, meets the barrier, reads the A fragments and first B half of the NEXT step and issues the
+//     other half of the MFMAs - so LDS reads and barrier skew are covered by matrix work of the same
+//     wave; the DMA instructions of the stage that takes the slot freed at that barrier are issued
+//     one by one between those MFMAs (a burst costs ~150 cycles per instruction up front);
+//   * all waves compute (RG row groups x 4 column groups, 64 x 128 per wave, 128 accumulators);
 //   * the LayerNorm is finished IN the accumulator registers: the W rows are permuted over the MFMA
 //     rows when the fragment is read (tile pair p, lane group fg -> columns 32 p + 8 fg + [0, 8)) so
 //     a lane holds 8 consecutive columns of its 4 rows; row statistics = per-lane sums, two
-//     xor-shuffles over the lane groups, and a 2-KB exchange between the four column-group waves
+//     xor-shuffles over the lane groups, and a small exchange between the four column-group waves
 //     through LDS (two-pass: mean, then centred squares); bias / residual / gamma / beta are read
 //     with 16-byte loads and every store is 16 bytes per lane (64 or 128 contiguous bytes per row).
+//     The per-row arithmetic does not depend on RG: a row's result is bit-identical whatever block
+//     size the launch rule picks (batch-composition invariance, tests/test_gpu_properties.py).
+#ifndef CARE_LN_A_AUX
+#define CARE_LN_A_AUX 0  // cache policy of the A stream's DMA (2 = nt: every A byte is read once)
+#endif
+#ifndef CARE_LN_DBG
+#define CARE_LN_DBG 0  // ablation builds (tools/ln_ablate.sh): 1 no MFMA, 2 no W DMA, 4 no A DMA, 8 no fragment reads
+#endif
 template <int N>
 __device__ __forceinline__ void ln2_wait_vm() {
   static_assert(N >= 0 && N <= 63, "vmcnt immediate");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-  else static_assert(N < 0, "add the immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // wait until all but `younger` stages (PER DMA instructions each) of this wave's stream have landed
 template <int PER, int MAXY>
 __device__ __forceinline__ void ln2_wait_stages(int younger) {
+  static_assert(MAXY * PER <= 63, "vmcnt range");
   if constexpr (MAXY >= 6) { if (younger >= 6) { ln2_wait_vm<6 * PER>(); return; } }
   if constexpr (MAXY >= 5) { if (younger == 5) { ln2_wait_vm<5 * PER>(); return; } }
   if constexpr (MAXY >= 4) { if (younger == 4) { ln2_wait_vm<4 * PER>(); return; } }
@@ -317,15 +323,23 @@ __device__ __forceinline__ void ln2_wait_stages(int younger) {
   ln2_wait_vm<0>();
 }
 
-template <bool AF32, int NSW, int NSA>
-__global__ __launch_bounds__(512, 2) void gemm_ln2_kernel(LnArgs p) {
-  constexpr int BM = 128;
-  constexpr int A_ROWB = AF32 ? 128 : 64;            // bytes per A row per K step of 32
+// EPI: which optional epilogue operand exists - 0: none (the Embedder), 1: the residual (decoder
+// sub-blocks); a position table goes to the round-1 kernel (nothing on the path uses one here).
+// A template parameter because a run-time condition per load makes hipcc branch around every load and
+// wait for it on the spot, and duplicating the epilogue behind ONE run-time branch made it spill the
+// 128 accumulators (700 B of scratch per lane).
+template <bool AF32, int RG, int NSW, int NSA, int EPI>
+__global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
+  constexpr int BM = 64 * RG, NW = 4 * RG, NLD = NW / 2;  // NLD loader waves per operand
+  // A moves in MACRO stages of 256 contiguous bytes per row (2 K steps of fp32, 4 of bf16): with 128
+  // (64) bytes per row and step every DRAM page was visited for one cache line at a time and the raw
+  // feature stream ran at 3.8 TB/s even with nothing else in the kernel (ablation, round 2)
+  constexpr int A_ROWB = 256, KSUB = AF32 ? 2 : 4;   // bytes per A row per macro stage; K steps per macro stage
   constexpr int A_BYTES = BM * A_ROWB, W_BYTES = LN_N * 64;
   constexpr int A_BASE = NSW * W_BYTES;
-  constexpr int NWI = W_BYTES / 1024 / 4;            // DMA instructions per stage per W wave: 8
-  constexpr int NAI = A_BYTES / 1024 / 4;            // per A wave: 4 (fp32) or 2 (bf16)
-  static_assert(NSW >= 2 && NSA >= 2 && NSW - 2 <= 6 && NSA - 2 <= 6, "ring depths");
+  constexpr int NWI = W_BYTES / 1024 / NLD;          // DMA instructions per stage per W wave: 16 / 8
+  constexpr int NAI = A_BYTES / 1024 / NLD;          // per macro stage per A wave: 8
+  static_assert(NSW >= 2 && NSA >= 3, "ring depths");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -333,46 +347,41 @@ __global__ __launch_bounds__(512, 2) void gemm_ln2_kernel(LnArgs p) {
   const int rg = wave >> 2, cg = wave & 3;
   const int fr = lane & 15, fg = lane >> 4;
   const int m0 = blockIdx.x * BM;
-  const bool w_loader = wave < 4;
+  const bool w_loader = wave < NLD;
   constexpr unsigned HTAB = (2u) | (3u << 3) | (4u << 6) | (2u << 9) | (5u << 12) | (7u << 15) | (4u << 18) | (1u << 21);
 
-  // ---- this wave's DMA source pointers at K step 0 (a W wave uses NWI of them, an A wave NAI)
-  const unsigned char* src[NWI];
-  if (w_loader) {
+  // ---- DMA sources.  W: instruction q of a stage covers W rows [16 q, 16 q + 16) x 4 chunks; the lane's
+  // part of the address - row (lane >> 2) of the 16, swizzled chunk - is the same for every q, so one
+  // 32-bit lane offset + a wave-uniform base per instruction (SGPR base + VGPR offset addressing); a
+  // PACKED W (care_pack_ln_weight) is the LDS image of every stage back to back: 1 KB per instruction,
+  // lane-linear, full cache lines.  A: 4 rows x 16 chunks per instruction (256 contiguous bytes per
+  // row), LDS position (row, c) takes source chunk c ^ (row & 15); rows clamped to the last one.
+  const unsigned w_lane = p.w_packed ? (unsigned)lane * 16u
+                                     : (unsigned)(lane >> 2) * (unsigned)p.K * 2u + (unsigned)(((lane & 3) ^ (((lane >> 2) & 8) >> 2)) << 4);
+  unsigned a_src[NAI];  // byte offset from the block's first row (< 128 rows x lda: 32 bits; wave-uniform 64-bit base)
 #pragma unroll
-    for (int i = 0; i < NWI; ++i) {   // 16 rows of W x 4 chunks per instruction
-      const int n = (wave * NWI + i) * 16 + (lane >> 2), pch = lane & 3;
-      src[i] = reinterpret_cast<const unsigned char*>(p.W + (int64_t)n * p.K) + ((pch ^ ((n & 8) >> 2)) << 4);
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < NWI; ++i) {
-      if (i >= NAI) { src[i] = nullptr; continue; }
-      const int q = (wave - 4) * NAI + i;
-      if constexpr (AF32) {           // 8 rows x 8 chunks per instruction
-        const int row = q * 8 + (lane >> 3), pch = lane & 7;
-        const int ch = pch ^ ((HTAB >> (3 * ((row & 15) >> 1))) & 7);
-        src[i] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const float*>(p.A) + (int64_t)min(m0 + row, p.M - 1) * p.lda) + ch * 16;
-      } else {                        // 16 rows x 4 chunks per instruction
-        const int row = q * 16 + (lane >> 2), pch = lane & 3;
-        const int ch = pch ^ ((row & 8) >> 2);
-        src[i] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const bf16_t*>(p.A) + (int64_t)min(m0 + row, p.M - 1) * p.lda) + ch * 16;
-      }
-    }
+  for (int i = 0; i < NAI; ++i) {
+    const int row = ((w_loader ? 0 : wave - NLD) * NAI + i) * 4 + (lane >> 4);
+    const int ch = (lane & 15) ^ (row & 15);
+    a_src[i] = (unsigned)(min(m0 + row, p.M - 1) - m0) * (unsigned)p.lda * (AF32 ? 4u : 2u) + (unsigned)ch * 16u;
   }
-  auto stage_w = [&](int kt) {
-    unsigned char* dst = smem + (kt % NSW) * W_BYTES + wave * (NWI * 1024);
-#pragma unroll
-    for (int i = 0; i < NWI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * 64),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  const unsigned char* a_blk = reinterpret_cast<const unsigned char*>(p.A) + (int64_t)m0 * p.lda * (AF32 ? 4 : 2);
+  // one DMA instruction i of stage kt (W) / macro stage m (A) of this wave's stream
+  // (stage to fetch, ring position it takes - they differ only past the end of K, see the schedule)
+  auto dma_w = [&](int kt, int slot, int i) {
+    if (CARE_LN_DBG & 2) return;
+    const int q = wave * NWI + i;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(p.W) +
+                                (p.w_packed ? (int64_t)kt * W_BYTES + q * 1024 : (int64_t)(q * 16) * p.K * 2 + (int64_t)kt * 64);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + w_lane),
+                                     (__attribute__((address_space(3))) void*)(smem + (slot % NSW) * W_BYTES + q * 1024),
+                                     16, 0, 0);
   };
-  auto stage_a = [&](int kt) {
-    unsigned char* dst = smem + A_BASE + (kt % NSA) * A_BYTES + (wave - 4) * (NAI * 1024);
-#pragma unroll
-    for (int i = 0; i < NAI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * A_ROWB),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  auto dma_a = [&](int m, int slot, int i) {
+    if (CARE_LN_DBG & 4) return;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_blk + (int64_t)m * A_ROWB + a_src[i]),
+                                     (__attribute__((address_space(3))) void*)(smem + A_BASE + (slot % NSA) * A_BYTES + ((wave - NLD) * NAI + i) * 1024),
+                                     16, 0, CARE_LN_A_AUX);
   };
 
   f32x4 acc[4][8];
@@ -385,105 +394,204 @@ __global__ __launch_bounds__(512, 2) void gemm_ln2_kernel(LnArgs p) {
   // 128 cg + 32 (nt >> 1) + 8 (i >> 2) + 4 (nt & 1) + (i & 3)  (i = this lane's fr as the READER of row i),
   // so that the lane that ends up with rows 4 fg + [0, 4) of tiles 2p and 2p + 1 owns 8 consecutive columns.
   const int w_off0 = (cg * 128 + 8 * (fr >> 2) + (fr & 3)) * 64 + ((fg ^ ((fr & 4) >> 1)) << 4);
-  int a_off[4][AF32 ? 2 : 1];
+  // A: tile mt is rows 64 rg + 16 mt + fr and (row & 15) = fr for every tile, so tile mt = tile 0 +
+  // mt * 16 rows (an immediate).  K step j of a macro stage: fp32 chunks 8 j + 2 fg, + 1; bf16 chunk
+  // 4 j + fg; swizzled by ^ fr - all XORs, so step j is the lane offset ^ (j * 128) (^ (j * 64)) and
+  // the second fp32 chunk is ^ 16.  Conflict-free for the 16-lane groups of ds_read_b128: lanes
+  // {0-3, 12-15} of lane group 0 and {4-11} of lane group 1 land on 16 distinct 16-byte slots.
+  const int a_lane = A_BASE + (rg * 64 + fr) * A_ROWB + (((AF32 ? 2 * fg : fg) ^ fr) << 4);
+  // raw fragment reads (no conversion, no waits): B half h of step kt; A tiles [2 part, 2 part + 2) of step kt
+  auto read_b = [&](int kt, int h, bf16x8 (&f)[4]) {
+    if (CARE_LN_DBG & 8) { for (int q = 0; q < 4; ++q) { f[q] = bf16x8{}; asm volatile("" : "+v"(f[q])); } return; }
+    const unsigned char* sw = smem + (kt % NSW) * W_BYTES + w_off0;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int row = rg * 64 + mt * 16 + fr;
-    if constexpr (AF32) {
-      const int x = (HTAB >> (3 * (fr >> 1))) & 7;
-      a_off[mt][0] = row * 128 + (((2 * fg) ^ x) << 4);
-      a_off[mt][1] = row * 128 + (((2 * fg + 1) ^ x) << 4);
-    } else {
-      a_off[mt][0] = row * 64 + ((fg ^ ((fr & 8) >> 2)) << 4);
+    for (int q = 0; q < 4; ++q) {
+      const int nt = h * 4 + q;
+      f[q] = *reinterpret_cast<const bf16x8*>(sw + ((nt >> 1) * 32 + (nt & 1) * 4) * 64);
     }
-  }
+  };
+  using araw_t = typename std::conditional<AF32, f32x4, bf16x8>::type;  // [tile][AF32 ? lo/hi : 1]
+  auto read_a = [&](int kt, int part, araw_t (&r)[2][AF32 ? 2 : 1]) {
+    if (CARE_LN_DBG & 8) { for (int t = 0; t < 2; ++t) for (int c = 0; c < (AF32 ? 2 : 1); ++c) { r[t][c] = araw_t{}; asm volatile("" : "+v"(r[t][c])); } return; }
+    const int jx = (kt % KSUB) * (AF32 ? 128 : 64);
+    const unsigned char* sa = smem + ((kt / KSUB) % NSA) * A_BYTES + (a_lane ^ jx);
+    const unsigned char* sx = smem + ((kt / KSUB) % NSA) * A_BYTES + (a_lane ^ jx ^ 16);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      r[t][0] = *reinterpret_cast<const araw_t*>(sa + (2 * part + t) * 16 * A_ROWB);
+      if constexpr (AF32) r[t][1] = *reinterpret_cast<const araw_t*>(sx + (2 * part + t) * 16 * A_ROWB);
+    }
+  };
+  auto cvt_a = [&](const araw_t (&r)[2][AF32 ? 2 : 1], bf16x8 (&f)[4], int part) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if constexpr (AF32) {  // pairs -> one v_cvt_pk_bf16_f32 each
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const bf16x2 pr = __builtin_convertvector(f32x2{r[t][c][e], r[t][c][e + 1]}, bf16x2);
+            f[2 * part + t][4 * c + e] = pr[0]; f[2 * part + t][4 * c + e + 1] = pr[1];
+          }
+      } else {
+        f[2 * part + t] = r[t][0];
+      }
+    }
+  };
 
-  const int nk = p.K >> 5;
+  const int nk = p.K >> 5, nmac = nk / KSUB;  // the launcher guarantees K % (32 KSUB) == 0
+  // Issue schedule (the same instruction counts in every step, so every wait is a constant):
+  //   W wave: the NWI instructions of stage kt + NSW go out in the second half of step kt (its slot was
+  //           read for the last time before this step's barrier);
+  //   A wave: macro stage mac - 1 + NSA (the slot of macro stage mac - 1, free for the whole of macro
+  //           stage mac) goes out NAS = NAI / KSUB instructions per step over the steps of macro stage mac.
+  // Past the end of K the stage index is clamped: the last stage is simply fetched again into a slot
+  // nobody will read - no tail cases, and the vmcnt arithmetic stays exact.
+  constexpr int NAS = NAI / KSUB;
+  static_assert(NAI % KSUB == 0 && NSA >= 3, "A issue schedule");
   if (w_loader) {
 #pragma unroll 1
-    for (int s = 0; s < NSW - 1 && s < nk; ++s) stage_w(s);
+    for (int s = 0; s < NSW; ++s)
+#pragma unroll
+      for (int i = 0; i < NWI; ++i) dma_w(min(s, nk - 1), s, i);
+    ln2_wait_vm<(NSW - 1) * NWI>();
   } else {
 #pragma unroll 1
-    for (int s = 0; s < NSA - 1 && s < nk; ++s) stage_a(s);
+    for (int s = 0; s < NSA - 1; ++s)   // macro stages 0 .. NSA - 2; NSA - 1 follows during macro stage 0
+#pragma unroll
+      for (int i = 0; i < NAI; ++i) dma_a(min(s, nmac - 1), s, i);
+    ln2_wait_vm<(NSA - 2) * NAI>();
   }
+  __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
-#pragma unroll 1
-  for (int kt = 0; kt < nk; ++kt) {
-    // my stream's stage kt must have landed; the younger stages of my stream stay in flight
-    if (w_loader) ln2_wait_stages<NWI, NSW - 2>(min(NSW - 2, nk - 1 - kt));
-    else ln2_wait_stages<NAI, NSA - 2>(min(NSA - 2, nk - 1 - kt));
-    __builtin_amdgcn_s_barrier();
+  // Two fragment sets in ping-pong (the K loop is unrolled by two: no register copies at the loop edge).
+  bf16x8 faA[4], fbA[4], faB[4], fbB[4];   // step kt: all A tiles, B half 0
+  {
+    araw_t r0[2][AF32 ? 2 : 1], r1[2][AF32 ? 2 : 1];
+    read_a(0, 0, r0); read_a(0, 1, r1); read_b(0, 0, fbA);
+    cvt_a(r0, faA, 0); cvt_a(r1, faA, 1);
+  }
+  // One K step: fa / fb0 hold its fragments, fan / fbn receive the next step's.
+  auto kstep = [&](int kt, bf16x8 (&fa)[4], bf16x8 (&fb0)[4], bf16x8 (&fan)[4], bf16x8 (&fbn)[4]) {
+    const bool more = kt + 1 < nk;                       // a next step exists
+    const int mac = kt / KSUB, sub = kt % KSUB;
+    bf16x8 fb1[4];
+    araw_t ra[2][AF32 ? 2 : 1], rb[2][AF32 ? 2 : 1];
     __builtin_amdgcn_sched_barrier(0);
-    // the slot every wave finished reading in the previous iteration takes the next stage
-    if (w_loader) { if (kt + NSW - 1 < nk) stage_w(kt + NSW - 1); }
-    else { if (kt + NSA - 1 < nk) stage_a(kt + NSA - 1); }
+    read_b(kt, 1, fb1);
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned char* sw = smem + (kt % NSW) * W_BYTES + w_off0;
-    const unsigned char* sa = smem + A_BASE + (kt % NSA) * A_BYTES;
-    bf16x8 fa[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (CARE_LN_DBG & 1) asm volatile("" :: "v"(fb0[q]), "v"(fa[mt]));
+        else acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[q], fa[mt], acc[mt][q], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      // my stream's stage kt + 1 has landed (its younger instructions stay in flight); my reads of stage kt are done
+      if (w_loader) ln2_wait_vm<(NSW - 2) * NWI>();
+      else if (sub == KSUB - 1) ln2_wait_vm<(NSA - 3) * NAI + (KSUB - 1) * NAS>();  // step kt + 1 opens macro stage mac + 1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(kt + 1, 0, ra);
+      read_b(kt + 1, 0, fbn);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // second half of the MFMAs with this step's DMA instructions woven in one at a time; the A tiles of
+    // the next step arrive in two parts
+    const int wst = min(kt + NSW, nk - 1), wslot = kt + NSW;           // W stage and the slot it takes
+    const int ast = min(mac - 1 + NSA, nmac - 1), aslot = mac - 1 + NSA;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      if constexpr (AF32) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(sa + a_off[mt][0]);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(sa + a_off[mt][1]);
-        fa[mt][0] = (bf16_t)lo[0]; fa[mt][1] = (bf16_t)lo[1]; fa[mt][2] = (bf16_t)lo[2]; fa[mt][3] = (bf16_t)lo[3];
-        fa[mt][4] = (bf16_t)hi[0]; fa[mt][5] = (bf16_t)hi[1]; fa[mt][6] = (bf16_t)hi[2]; fa[mt][7] = (bf16_t)hi[3];
-      } else {
-        fa[mt] = *reinterpret_cast<const bf16x8*>(sa + a_off[mt][0]);
-      }
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      bf16x8 fb[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int nt = half * 4 + q;
-        fb[q] = *reinterpret_cast<const bf16x8*>(sw + ((nt >> 1) * 32 + (nt & 1) * 4) * 64);
+        if (CARE_LN_DBG & 1) asm volatile("" :: "v"(fb1[q]), "v"(fa[mt]));
+        else acc[mt][4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[q], fa[mt], acc[mt][4 + q], 0, 0, 0);
+        const int m = mt * 4 + q;  // 0..15
+        if ((m + 1) % (16 / NWI) == 0 || (m + 1) % (16 / NAS) == 0) {
+          if (w_loader) { if ((m + 1) % (16 / NWI) == 0) dma_w(wst, wslot, m / (16 / NWI)); }
+          else { if ((m + 1) % (16 / NAS) == 0) dma_a(ast, aslot, sub * NAS + m / (16 / NAS)); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc[mt][half * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[q], fa[mt], acc[mt][half * 4 + q], 0, 0, 0);
+      if (mt == 1 && more) {  // first A part has had 8 MFMAs to arrive: convert it, fetch the second part
+        cvt_a(ra, fan, 0);
+        read_a(kt + 1, 1, rb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    if (more) cvt_a(rb, fan, 1);
+  };
+
+#pragma unroll 1
+  for (int kt = 0; kt < nk; kt += 2) {  // nk is even (K % 64 == 0)
+    kstep(kt, faA, fbA, faB, fbB);
+    kstep(kt + 1, faB, fbB, faA, fbA);
   }
 
   // ------------------------------------------------------------------ epilogue (in registers)
   // acc[mt][2p + e][j] = C[row 64 rg + 16 mt + fr][col 128 cg + 32 p + 8 fg + 4 e + j]
-  __builtin_amdgcn_s_barrier();  // the rings are dead: their first 4 KB become the statistics exchange
-  float* stat = reinterpret_cast<float*>(smem);            // [2 passes][128 rows][4 column groups]
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // the rings are dead: their first bytes become the statistics exchange
+  float* stat = reinterpret_cast<float*>(smem);            // [2 passes][BM rows][4 column groups]
   const int col0 = cg * 128 + 8 * fg;
+  int m0e = m0;
+  asm volatile("" : "+s"(m0e));  // everything below depends on it: no epilogue address arithmetic is hoisted into the K loop's register budget
   int grow[4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) grow[mt] = m0 + rg * 64 + mt * 16 + fr;
+  for (int mt = 0; mt < 4; ++mt) grow[mt] = m0e + rg * 64 + mt * 16 + fr;
 
+  // pass 1: v = acc + bias (+ residual) (+ position), row sums
   float rsum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int pq = 0; pq < 4; ++pq) {
-    const int c = col0 + 32 * pq;
-    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-    if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + c); b1 = *reinterpret_cast<const float4*>(p.bias + c + 4); }
+  {
+    int64_t roff[4], poff[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int gc = min(grow[mt], p.M - 1);
-      f32x4& v0 = acc[mt][2 * pq];
-      f32x4& v1 = acc[mt][2 * pq + 1];
-      v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
-      v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
-      if (p.res) {
-        const float4 r0 = *reinterpret_cast<const float4*>(p.res + (int64_t)gc * p.ldres + c);
-        const float4 r1 = *reinterpret_cast<const float4*>(p.res + (int64_t)gc * p.ldres + c + 4);
-        v0[0] += r0.x; v0[1] += r0.y; v0[2] += r0.z; v0[3] += r0.w;
-        v1[0] += r1.x; v1[1] += r1.y; v1[2] += r1.z; v1[3] += r1.w;
+      roff[mt] = (int64_t)gc * p.ldres;
+      poff[mt] = (int64_t)(gc % p.grp) * LN_N;
+    }
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+      const int c = col0 + 32 * pq;
+      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+      if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + c); b1 = *reinterpret_cast<const float4*>(p.bias + c + 4); }
+      float4 r[4][2], q[4][2];
+#pragma unroll
+      for (int mth = 0; mth < 2; ++mth) {
+#pragma unroll
+      for (int mt = 2 * mth; mt < 2 * mth + 2; ++mt) {
+        if constexpr (EPI == 1) {
+          r[mt][0] = *reinterpret_cast<const float4*>(p.res + roff[mt] + c);
+          r[mt][1] = *reinterpret_cast<const float4*>(p.res + roff[mt] + c + 4);
+        }
+        if constexpr (EPI == 2) {
+          q[mt][0] = *reinterpret_cast<const float4*>(p.pos + poff[mt] + c);
+          q[mt][1] = *reinterpret_cast<const float4*>(p.pos + poff[mt] + c + 4);
+        }
       }
-      if (p.pos) {
-        const float* pp = p.pos + (int64_t)(gc % p.grp) * LN_N + c;
-        const float4 r0 = *reinterpret_cast<const float4*>(pp), r1 = *reinterpret_cast<const float4*>(pp + 4);
-        v0[0] += r0.x; v0[1] += r0.y; v0[2] += r0.z; v0[3] += r0.w;
-        v1[0] += r1.x; v1[1] += r1.y; v1[2] += r1.z; v1[3] += r1.w;
+#pragma unroll
+      for (int mt = 2 * mth; mt < 2 * mth + 2; ++mt) {
+        f32x4& v0 = acc[mt][2 * pq];
+        f32x4& v1 = acc[mt][2 * pq + 1];
+        v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
+        v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
+        if constexpr (EPI == 1) {
+          v0[0] += r[mt][0].x; v0[1] += r[mt][0].y; v0[2] += r[mt][0].z; v0[3] += r[mt][0].w;
+          v1[0] += r[mt][1].x; v1[1] += r[mt][1].y; v1[2] += r[mt][1].z; v1[3] += r[mt][1].w;
+        }
+        if constexpr (EPI == 2) {
+          v0[0] += q[mt][0].x; v0[1] += q[mt][0].y; v0[2] += q[mt][0].z; v0[3] += q[mt][0].w;
+          v1[0] += q[mt][1].x; v1[1] += q[mt][1].y; v1[2] += q[mt][1].z; v1[3] += q[mt][1].w;
+        }
+        rsum[mt] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
       }
-      rsum[mt] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+      __builtin_amdgcn_sched_barrier(0);  // two rows x one column group of loads in flight at a time (registers)
+      }
     }
   }
   float mean[4], rstd[4];
@@ -511,13 +619,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ln2_kernel(LnArgs p) {
     }
     q += __shfl_xor(q, 16, 64);
     q += __shfl_xor(q, 32, 64);
-    if (fg == 0) stat[512 + (rg * 64 + mt * 16 + fr) * 4 + cg] = q;
+    if (fg == 0) stat[BM * 4 + (rg * 64 + mt * 16 + fr) * 4 + cg] = q;
   }
   __syncthreads();
   int64_t orow[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const float4 t = *reinterpret_cast<const float4*>(stat + 512 + (rg * 64 + mt * 16 + fr) * 4);
+    const float4 t = *reinterpret_cast<const float4*>(stat + BM * 4 + (rg * 64 + mt * 16 + fr) * 4);
     rstd[mt] = 1.0f / sqrtf(((t.x + t.y) + (t.z + t.w)) * (1.0f / LN_N) + p.eps);
     orow[mt] = (int64_t)(grow[mt] / p.grp) * p.out_grp_rows + p.out_row_off + (grow[mt] % p.grp);
   }
@@ -550,22 +658,29 @@ __global__ __launch_bounds__(512, 2) void gemm_ln2_kernel(LnArgs p) {
   }
 }
 
-template <bool AF32, int NSW, int NSA>
-int launch_ln2(const LnArgs& p, hipStream_t st) {
-  constexpr int LDS = NSW * LN_N * 64 + NSA * 128 * (AF32 ? 128 : 64);
+template <bool AF32, int RG, int NSW, int NSA, int EPI>
+int launch_ln2e(const LnArgs& p, hipStream_t st) {
+  constexpr int BM = 64 * RG;
+  constexpr int LDS = NSW * LN_N * 64 + NSA * BM * 256;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static std::atomic<unsigned long long> lds_ok{0};
-  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_ln2_kernel<AF32, NSW, NSA>), LDS, lds_ok)) return e;
-  hipLaunchKernelGGL((gemm_ln2_kernel<AF32, NSW, NSA>), dim3((p.M + 127) / 128), dim3(512), LDS, st, p);
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_ln2_kernel<AF32, RG, NSW, NSA, EPI>), LDS, lds_ok)) return e;
+  hipLaunchKernelGGL((gemm_ln2_kernel<AF32, RG, NSW, NSA, EPI>), dim3((p.M + BM - 1) / BM), dim3(256 * RG), LDS, st, p);
   return care_launch_status();
+}
+
+template <bool AF32, int RG, int NSW, int NSA>
+int launch_ln2(const LnArgs& p, hipStream_t st) {
+  if (p.res) return launch_ln2e<AF32, RG, NSW, NSA, 1>(p, st);
+  return launch_ln2e<AF32, RG, NSW, NSA, 0>(p, st);
 }
 
 }  // namespace
 
-extern "C" int care_gemm_ln(const void* A, int64_t lda, int a_dtype, const void* W, const float* bias,
-                            const float* res, int64_t ldres, const float* pos, const float* gamma, const float* beta,
-                            float eps, float* out, void* out_bf16, int64_t ldo, int M, int N, int K, int grp,
-                            int out_grp_rows, int out_row_off, void* stream) {
+static int gemm_ln_impl(const void* A, int64_t lda, int a_dtype, const void* W, int w_packed, const float* bias,
+                        const float* res, int64_t ldres, const float* pos, const float* gamma, const float* beta,
+                        float eps, float* out, void* out_bf16, int64_t ldo, int M, int N, int K, int grp,
+                        int out_grp_rows, int out_row_off, void* stream) {
   if (!A || !W || !gamma || !beta || (!out && !out_bf16) || M <= 0 || K <= 0 || grp <= 0) return CARE_EINVAL;
   if (a_dtype != CARE_F32 && a_dtype != CARE_BF16) return CARE_EDTYPE;
   if (N != LN_N || K % 32 != 0) return CARE_ESHAPE;
@@ -577,6 +692,7 @@ extern "C" int care_gemm_ln(const void* A, int64_t lda, int a_dtype, const void*
   p.A = A; p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.bias = bias; p.res = res; p.ldres = ldres;
   p.pos = pos; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out = out; p.outb = reinterpret_cast<bf16_t*>(out_bf16);
   p.ldo = ldo; p.M = M; p.K = K; p.grp = grp; p.out_grp_rows = out_grp_rows; p.out_row_off = out_row_off;
+  p.w_packed = w_packed;
   hipStream_t st = (hipStream_t)stream;
   // 64-row blocks (RG = 1) or 128-row blocks (RG = 2, one launch round of them takes ~1.3x as long):
   // whichever needs less time in whole rounds over the 256 CUs.  *Measured* K = 512: M = 16384
@@ -585,16 +701,55 @@ extern "C" int care_gemm_ln(const void* A, int64_t lda, int a_dtype, const void*
   const long rounds1 = ((M + 63) / 64 + 255) / 256, rounds2 = ((M + 127) / 128 + 255) / 256;
   bool big = 10 * rounds1 > 13 * rounds2;
   if (const char* e = getenv("CARE_LN_RG")) big = atoi(e) >= 2;  // tuning override
-  static const int v2 = [] { const char* e = getenv("CARE_LN_V2"); return e ? atoi(e) : 1; }();  // A/B switch
-  if (big && v2) {
-    if (a_dtype == CARE_F32) {
-      if (v2 == 2) return launch_ln2<true, 3, 4>(p, st);
-      return launch_ln2<true, 2, 6>(p, st);
-    }
-    if (v2 == 2) return launch_ln2<false, 2, 6>(p, st);
-    if (v2 == 3) return launch_ln2<false, 3, 8>(p, st);
-    return launch_ln2<false, 3, 4>(p, st);
+  static const int v2 = [] { const char* e = getenv("CARE_LN_V2"); return e ? atoi(e) : 1; }();  // A/B switch: 0 = round-1 kernel
+  // version 2 moves A in 256-byte pieces of a row: K must be a whole number of them
+  const bool v2_ok = !pos && K % (a_dtype == CARE_F32 ? 64 : 128) == 0;
+  if (w_packed && !(v2 && v2_ok)) return CARE_ESHAPE;  // only the version-2 kernels read the packed order
+  if (v2 && v2_ok) {
+    if (a_dtype == CARE_F32) return big ? launch_ln2<true, 2, 2, 3>(p, st) : launch_ln2<true, 1, 3, 4>(p, st);
+    return big ? launch_ln2<false, 2, 2, 3>(p, st) : launch_ln2<false, 1, 3, 4>(p, st);
   }
   if (a_dtype == CARE_F32) return big ? launch_ln<true, 2>(p, st) : launch_ln<true, 1>(p, st);
   return big ? launch_ln<false, 2>(p, st) : launch_ln<false, 1>(p, st);
+}
+
+extern "C" int care_gemm_ln(const void* A, int64_t lda, int a_dtype, const void* W, const float* bias,
+                            const float* res, int64_t ldres, const float* pos, const float* gamma, const float* beta,
+                            float eps, float* out, void* out_bf16, int64_t ldo, int M, int N, int K, int grp,
+                            int out_grp_rows, int out_row_off, void* stream) {
+  return gemm_ln_impl(A, lda, a_dtype, W, 0, bias, res, ldres, pos, gamma, beta, eps, out, out_bf16, ldo, M, N, K, grp,
+                      out_grp_rows, out_row_off, stream);
+}
+
+extern "C" int care_gemm_ln_packed(const void* A, int64_t lda, int a_dtype, const void* W_packed, const float* bias,
+                                   const float* res, int64_t ldres, const float* gamma, const float* beta, float eps,
+                                   float* out, void* out_bf16, int64_t ldo, int M, int N, int K, int grp,
+                                   int out_grp_rows, int out_row_off, void* stream) {
+  return gemm_ln_impl(A, lda, a_dtype, W_packed, 1, bias, res, ldres, nullptr, gamma, beta, eps, out, out_bf16, ldo, M, N,
+                      K, grp, out_grp_rows, out_row_off, stream);
+}
+
+namespace {
+// W [512, K] bf16 (nn.Linear layout) -> the K-step-major order the version-2 kernels stream: for every K
+// step of 32 the 32-KB LDS image of that step, rows in order, the four 16-byte chunks of a row at their
+// swizzled positions (position c of row n holds chunk c ^ ((n & 8) >> 2)).
+__global__ void pack_ln_weight_kernel(const bf16_t* W, bf16_t* Wp, int K) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk per thread
+  const int64_t total = (int64_t)LN_N * K / 8;
+  if (slot >= total) return;
+  const int c = (int)(slot & 3), n = (int)((slot >> 2) % LN_N);
+  const int kt = (int)(slot / (4 * LN_N));
+  const int src_chunk = c ^ ((n & 8) >> 2);
+  reinterpret_cast<bf16x8*>(Wp)[slot] = *reinterpret_cast<const bf16x8*>(W + (int64_t)n * K + kt * 32 + src_chunk * 8);
+}
+}  // namespace
+
+extern "C" int care_pack_ln_weight(const void* W, void* W_packed, int N, int K, void* stream) {
+  if (!W || !W_packed || W == W_packed) return CARE_EINVAL;
+  if (N != LN_N || K <= 0 || K % 32 != 0) return CARE_ESHAPE;
+  if (!care_aligned16(W) || !care_aligned16(W_packed)) return CARE_EALIGN;
+  const int64_t total = (int64_t)LN_N * K / 8;
+  hipLaunchKernelGGL(pack_ln_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const bf16_t*>(W), reinterpret_cast<bf16_t*>(W_packed), K);
+  return care_launch_status();
 }

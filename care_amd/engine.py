@@ -179,6 +179,15 @@ class HipEngine:
                 self._pack_attn(w, sd, lp + ".attr_attention", "d{}_aa".format(li), False, wt, f32)
             self._pack_ffn(w, sd, lp + ".ffn", "d{}_ffn".format(li), wt, f32)
         w["vocab"] = wt(sd["cls_head.tgt_word_prj.weight"])
+        if self.as_ok and d == 512:
+            # weights of the fused Linear -> LayerNorm GEMMs also in the K-step-major order the kernel
+            # streams (csrc/gemm_ln.hip, care_pack_ln_weight): 1 KB of full cache lines per DMA instruction
+            for name in [k for k in w if k.startswith("enc_w_") or k.endswith("_o_w") or k.endswith("_ffn_w2")]:
+                W = w[name]
+                if W is not None and W.dtype == torch.bfloat16 and W.shape[0] == 512 and W.shape[1] % 128 == 0:
+                    Wp = torch.empty_like(W)
+                    call("care_pack_ln_weight", ptr(W), ptr(Wp), 512, W.shape[1])
+                    w[name + "#packed"] = Wp
         self.w = w
         self._graphs.clear()
 
@@ -290,10 +299,17 @@ class HipEngine:
         # 440 K vs 446-451 K
         return self.as_ok and self.d == 512 and rows >= int(os.environ.get("CARE_LN_MIN_ROWS", "10240"))
 
-    def gemm_ln(self, A, W, bias, res, g, be, out, outb, grp=None, out_grp_rows=None, out_row_off=0, pos=None, tag=None):
+    def gemm_ln(self, A, W, bias, res, g, be, out, outb, grp=None, out_grp_rows=None, out_row_off=0, pos=None, tag=None,
+                Wp=None):
+        """out = LN(A W^T + bias + res [+ pos]); Wp: the same weight in care_pack_ln_weight order (preferred)."""
         rows, K = A.shape
         grp = rows if grp is None else grp
         out_grp_rows = grp if out_grp_rows is None else out_grp_rows
+        if Wp is not None and pos is None and os.environ.get("CARE_LN_PACKED", "1") != "0":
+            call("care_gemm_ln_packed", ptr(A), A.stride(0), _code(A), ptr(Wp), ptr(bias), ptr(res),
+                 res.stride(0) if res is not None else 0, ptr(g), ptr(be), self.eps, ptr(out), ptr(outb),
+                 (out if out is not None else outb).stride(-2), rows, self.d, K, grp, out_grp_rows, out_row_off, tag=tag)
+            return out
         call("care_gemm_ln", ptr(A), A.stride(0), _code(A), ptr(W), ptr(bias), ptr(res),
              res.stride(0) if res is not None else 0, ptr(pos), ptr(g), ptr(be), self.eps, ptr(out), ptr(outb),
              (out if out is not None else outb).stride(-2), rows, self.d, K, grp, out_grp_rows, out_row_off, tag=tag)
@@ -337,7 +353,7 @@ class HipEngine:
         if split and self.ln_fusable(rows) and not ln_kw.get("pos"):
             # dense2 + bias + residual + LayerNorm in one kernel: no split-K slabs at all
             return self.gemm_ln(h, w2, w[name + "_b2"], x, w[name + "_g"], w[name + "_be"], out, outb,
-                                tag=(gemm_tag + "_ln") if gemm_tag else None, **ln_kw)
+                                tag=(gemm_tag + "_ln") if gemm_tag else None, Wp=w.get(name + "_w2#packed"), **ln_kw)
         if split:
             # K = ff > 512: split K over blocks into fp32 slabs; the LayerNorm kernel sums them
             ns = self.ff // 512
@@ -389,7 +405,7 @@ class HipEngine:
             ln_kw = dict(grp=n, out_grp_rows=grp_rows, out_row_off=off)
             if fused:  # Linear + bias + LayerNorm in one kernel, raw fp32 features streamed by LDS-DMA
                 self.gemm_ln(x2, w["enc_w_" + ch], w["enc_b_" + ch], None, w["enc_g_" + ch], w["enc_be_" + ch],
-                             dst, dstb, tag="enc_gemm", **ln_kw)
+                             dst, dstb, tag="enc_gemm", Wp=w.get("enc_w_" + ch + "#packed"), **ln_kw)
             elif opt["encoder"] == "Embedder":
                 self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], dst, dstb, **ln_kw)
             else:  # MultiTransformerEncoder
@@ -624,7 +640,7 @@ class HipEngine:
             x1, x1b = self.ws(tag + "x1", (N, d)), self.wsb(tag + "x1", (N, d))
             if self.ln_fusable(N):
                 self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x, w[nm + "_g"], w[nm + "_be"], x1, x1b,
-                             tag="step_dxd_ln")
+                             tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
             else:
                 o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
                 self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b)
@@ -651,7 +667,7 @@ class HipEngine:
             x2, x2b = self.ws(tag + "x2", (N, d)), self.wsb(tag + "x2", (N, d))
             if self.ln_fusable(N):
                 self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x1, w[nm + "_g"], w[nm + "_be"], x2, x2b,
-                             tag="step_dxd_ln")
+                             tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
             else:
                 o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
                 self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 8
+#define CARE_ABI_VERSION 9
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -184,6 +184,21 @@ int care_gemm_ln(const void* A, int64_t lda, int a_dtype, const void* W, const f
                  const float* res, int64_t ldres, const float* pos, const float* gamma,
                  const float* beta, float eps, float* out, void* out_bf16, int64_t ldo, int M,
                  int N, int K, int grp, int out_grp_rows, int out_row_off, void* stream);
+
+/*
+ * care_pack_ln_weight / care_gemm_ln_packed: the same fused Linear -> (+residual) -> LayerNorm with
+ *   the [512, K] bf16 weight re-laid-out ONCE (at weight-load time) into the order the kernel streams
+ *   it: for every K step of 32 the 32-KB LDS image of that step (rows in order, 16-byte chunks at
+ *   their bank-swizzled positions), so every DMA instruction reads 1 KB of full cache lines instead
+ *   of sixteen 64-byte row pieces.  Same arithmetic, bit for bit, as care_gemm_ln on the plain
+ *   weight.  K % 64 (fp32 A) / K % 128 (bf16 A) == 0; no position table.  W_packed: K * 1024 bytes.
+ */
+int care_pack_ln_weight(const void* W, void* W_packed, int N, int K, void* stream);
+int care_gemm_ln_packed(const void* A, int64_t lda, int a_dtype, const void* W_packed,
+                        const float* bias, const float* res, int64_t ldres, const float* gamma,
+                        const float* beta, float eps, float* out, void* out_bf16, int64_t ldo,
+                        int M, int N, int K, int grp, int out_grp_rows, int out_row_off,
+                        void* stream);
 
 /*
  * care_group_mean: out[g, col_off + c] = mean over the grp rows of group g of x[., c].

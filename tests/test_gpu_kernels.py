@@ -304,7 +304,7 @@ def test_fused_label_scoring(M):
     assert torch.equal(pred[safe].long(), logits.argmax(1)[safe]) and torch.equal(pred2.long(), logits.argmax(1))
 
 
-@pytest.mark.parametrize("form", ["auto", "128-row blocks"])
+@pytest.mark.parametrize("form", ["auto", "128-row blocks", "packed W", "packed W, 128-row blocks"])
 @pytest.mark.parametrize("a_f32", [True, False])
 @pytest.mark.parametrize("M,K", [(7, 128), (64, 512), (200, 2048), (28 * 300, 512), (128 * 300 + 5, 128), (40000, 2048),
                                  (28 * 1171, 32), (1000, 96), (129, 64)])
@@ -312,21 +312,34 @@ def test_gemm_ln_fused(a_f32, M, K, form, monkeypatch):
     """form: the library picks 64- or 128-row blocks by launch rounds; CARE_LN_RG=2 forces the 128-row
     kernel (wave-specialised loaders, LayerNorm in the accumulator registers) onto every shape, ragged
     last blocks and K shorter than its ring depth included."""
-    if form != "auto":
+    if "128-row" in form:
         monkeypatch.setenv("CARE_LN_RG", "2")
+    packed = "packed" in form
+    if packed and K % (64 if a_f32 else 128):
+        pytest.skip("the packed-weight kernels move A in 256-byte row pieces")
     d, grp = 512, 28 if M % 28 == 0 else M
     A = _rand(M, K, seed=50)
     W = _rand(d, K, seed=51, scale=1 / math.sqrt(K))
     bias, g, b = _rand(d, seed=52), _rand(d, seed=53), _rand(d, seed=54)
     res = _rand(M, d, seed=55)
-    pos = _rand(grp, d, seed=56) if grp == 28 else None
+    pos = _rand(grp, d, seed=56) if (grp == 28 and not packed) else None
     Ain = A if a_f32 else A.to(torch.bfloat16).contiguous()
     Wb = W.to(torch.bfloat16).contiguous()
     ngrp = M // grp
     out = torch.zeros(ngrp, grp + 9, d, device=DEV)
     outb = torch.zeros(ngrp, grp + 9, d, device=DEV, dtype=torch.bfloat16)
-    _call("care_gemm_ln", _p(Ain), K, 0 if a_f32 else 1, _p(Wb), _p(bias), _p(res), d, _p(pos), _p(g), _p(b), 1e-12,
-          _p(out), _p(outb), d, M, d, K, grp, grp + 9, 4)
+    if packed:  # same arithmetic on the re-laid-out weight: bit-identical to the plain-weight call
+        Wp = torch.empty_like(Wb)
+        _call("care_pack_ln_weight", _p(Wb), _p(Wp), d, K)
+        _call("care_gemm_ln_packed", _p(Ain), K, 0 if a_f32 else 1, _p(Wp), _p(bias), _p(res), d, _p(g), _p(b), 1e-12,
+              _p(out), _p(outb), d, M, d, K, grp, grp + 9, 4)
+        out2 = torch.zeros_like(out)
+        _call("care_gemm_ln", _p(Ain), K, 0 if a_f32 else 1, _p(Wb), _p(bias), _p(res), d, None, _p(g), _p(b), 1e-12,
+              _p(out2), None, d, M, d, K, grp, grp + 9, 4)
+        assert torch.equal(out, out2)
+    else:
+        _call("care_gemm_ln", _p(Ain), K, 0 if a_f32 else 1, _p(Wb), _p(bias), _p(res), d, _p(pos), _p(g), _p(b), 1e-12,
+              _p(out), _p(outb), d, M, d, K, grp, grp + 9, 4)
     y = (_bf(A).double() @ _bf(W).double().t()).float() + bias + res
     if pos is not None:
         y = (y.view(ngrp, grp, d) + pos.unsqueeze(0)).view(M, d)

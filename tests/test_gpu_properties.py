@@ -216,7 +216,7 @@ def test_benchmarked_operating_point_against_oracle_sample(config, B):
     spread over the batch: a clip whose every reference step is decided by >= 0.1 must be bit-exact,
     any other divergence must start at a near-tie; replay == eager bit for bit."""
     from oracle import care_cpu
-    from test_gpu_parity import BF16_LSE_PEAKED, CLEAR_MARGIN, GREEDY_TIE_TOL, _audit_greedy
+    from test_gpu_parity import BF16_LSE_PEAKED, CLEAR_MARGIN, _audit_greedy
 
     opt, P, model, feats = _setup(config, B, "bf16", seed=189, boost=PEAKED_ROWS)
     eng = model.engine()
@@ -249,7 +249,9 @@ def test_benchmarked_operating_point_against_oracle_sample(config, B):
             exact += 1
             assert abs(float(score[i]) / n - scores[j][0]) < BF16_LSE_PEAKED  # peaked rows: logits up to +-30
         else:
-            _audit_greedy(P, opt, {k: v[j:j + 1] for k, v in inputs.items()}, h, r, GREEDY_TIE_TOL)
+            # peaked rows scale the logit noise with them (measured logsumexp error up to 2.6e-2 on the
+            # peaked fixtures): a step decided by less than 5e-2 may flip, one decided by >= 0.1 may not
+            _audit_greedy(P, opt, {k: v[j:j + 1] for k, v in inputs.items()}, h, r, 5e-2)
     print("operating point {} B={}: {}/64 sampled captions bit-exact, {} with clear margins".format(config, B, exact, clear))
     assert exact >= 48 and len(set(length[idx].tolist())) > 3
 

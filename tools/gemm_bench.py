@@ -67,8 +67,15 @@ def ln_main():
         outb = torch.empty(M, 512, device=DEV, dtype=torch.bfloat16)
         p = lambda t: t.data_ptr()
         resp = None if f32 else p(res)  # the embedder (raw fp32 features) has no residual
-        t = time_call(lambda: _lib.call("care_gemm_ln", p(Ain), K, 0 if f32 else 1, p(W), p(bias), resp, 512, None,
-                                        p(g), p(b), 1e-12, p(out), p(outb), 512, M, 512, K, M, M, 0), iters=5)
+        outp = None if os.environ.get("LN_LEAN") else p(out)  # LN_LEAN=1: bf16 output only (the lean encode)
+        if os.environ.get("LN_PACKED", "1") != "0":
+            Wp = torch.empty_like(W)
+            _lib.call("care_pack_ln_weight", p(W), p(Wp), 512, K)
+            t = time_call(lambda: _lib.call("care_gemm_ln_packed", p(Ain), K, 0 if f32 else 1, p(Wp), p(bias), resp, 512,
+                                            p(g), p(b), 1e-12, outp, p(outb), 512, M, 512, K, M, M, 0), iters=5)
+        else:
+            t = time_call(lambda: _lib.call("care_gemm_ln", p(Ain), K, 0 if f32 else 1, p(W), p(bias), resp, 512, None,
+                                            p(g), p(b), 1e-12, outp, p(outb), 512, M, 512, K, M, M, 0), iters=5)
         nbytes = M * K * (4 if f32 else 2) + M * 512 * (6 if f32 else 10)  # A in; fp32 + bf16 out; (+ fp32 residual in)
         print("gemm_ln M=%6d K=%4d A=%s: %8.1f us (%6.1f TF, %5.2f TB/s)" % (M, K, "f32" if f32 else "bf16", t, 2.0 * M * 512 * K / t / 1e6,
                                                                           nbytes / t / 1e6), flush=True)

@@ -1,7 +1,8 @@
-mkdir -p gpurun_out/r2a
-python -m pytest tests/test_gpu_kernels.py -q -k "gemm_ln" > gpurun_out/r2a/t_ln.log 2>&1; echo "ln tests rc=$?"
-for v in 0 1 2 3; do CARE_LN_V2=$v timeout 300 python tools/gemm_bench.py ln > gpurun_out/r2a/ln_v$v.log 2>&1; done
-CARE_LN_RG=2 CARE_LN_V2=1 timeout 300 python tools/gemm_bench.py ln > gpurun_out/r2a/ln_v1_forced.log 2>&1
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_properties.py -q --maxfail=12 > gpurun_out/r2a/t_par.log 2>&1; echo "parity rc=$?"
-timeout 600 python bench.py > gpurun_out/r2a/bench.log 2>&1; echo "bench rc=$?"
-tail -3 gpurun_out/r2a/t_ln.log; tail -5 gpurun_out/r2a/t_par.log; cat gpurun_out/r2a/ln_v1.log
+mkdir -p gpurun_out/r2e
+python -m pytest tests/test_gpu_kernels.py -q -k "gemm_ln" > gpurun_out/r2e/t_ln.log 2>&1; echo "ln tests rc=$?"; tail -3 gpurun_out/r2e/t_ln.log
+timeout 300 python tools/gemm_bench.py ln > gpurun_out/r2e/ln_packed.log 2>&1
+LN_LEAN=1 timeout 300 python tools/gemm_bench.py ln > gpurun_out/r2e/ln_packed_lean.log 2>&1
+for d in 6 15; do CARE_HIP_LIB=care_amd/dbg/libcare_hip_dbg$d.so timeout 300 python tools/gemm_bench.py ln > gpurun_out/r2e/ln_dbg$d.log 2>&1; done
+for f in ln_packed ln_packed_lean ln_dbg6 ln_dbg15; do echo "== $f"; grep gemm_ln gpurun_out/r2e/$f.log | head -14; done
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_properties.py -q --maxfail=12 > gpurun_out/r2e/t_par.log 2>&1; echo "parity rc=$?"; tail -5 gpurun_out/r2e/t_par.log
+timeout 600 python bench.py > gpurun_out/r2e/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/r2e/bench.log | cut -c1-200
