@@ -1,0 +1,106 @@
+// compact.hip - active-set compaction of the decode loop (early termination).
+//
+// The reference stops a batch when every instance is done and physically removes finished instances
+// from every cached tensor at each step (models/Translator.py:77-81,194-209 `collect_active_part`).
+// Here the decode runs in segments of a few steps; between two segments the host reads ONE counter
+// (rows still active) and, when enough rows have finished, the active rows are gathered to the front
+// of a second set of buffers - three small kernels:
+//   care_active_slots : stable partition of the slot indices, unfinished first (one workgroup);
+//   care_gather_rows  : dst[i] = src[idx[i]]   (the per-slot state: K/V caches, memory, inputs ...);
+//   care_scatter_rows : dst[idx[i]] = src[i]   (per-slot results -> per-clip outputs; idx < 0 skips).
+#include "care_common.h"
+
+namespace {
+
+// One workgroup of 1024 threads: idx[0 .. cnt) = slots with finished == 0 in ascending order,
+// idx[cnt .. n) = the finished ones in ascending order; count[0] = cnt.
+__global__ __launch_bounds__(1024) void active_slots_kernel(const int32_t* finished, int n, int32_t* idx, int32_t* count) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_act, total_act;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // pass 1: number of active slots (needed for the offset of the finished part)
+  int local = 0;
+  for (int i = tid; i < n; i += 1024) local += finished[i] == 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+  if (lane == 0) wave_tot[wv] = local;
+  __syncthreads();
+  if (tid == 0) {
+    int s = 0;
+    for (int w = 0; w < 16; ++w) s += wave_tot[w];
+    total_act = s; base_act = 0;
+    count[0] = s;
+  }
+  __syncthreads();
+  // pass 2: chunks of 1024 slots in order; within a chunk a ballot-based exclusive scan
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + tid;
+    const bool in = i < n;
+    const bool act = in && finished[i] == 0;
+    const unsigned long long m = __ballot(act);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wv; ++w) woff += wave_tot[w];
+    int chunk_tot = 0;
+    for (int w = 0; w < 16; ++w) chunk_tot += wave_tot[w];
+    const int a0 = base_act;
+    if (in) {
+      const int na = a0 + woff + before;              // active slots before i
+      if (act) idx[na] = i;
+      else idx[total_act + (i - na)] = i;             // finished slots before i = i - na
+    }
+    __syncthreads();
+    if (tid == 0) base_act = a0 + chunk_tot;
+    __syncthreads();
+  }
+}
+
+// row_bytes % 4 == 0; 16-byte vectors when everything is 16-byte aligned, dwords otherwise
+template <bool SCATTER, typename V>
+__global__ __launch_bounds__(256) void move_rows_kernel(const unsigned char* src, int64_t src_stride, unsigned char* dst,
+                                                        int64_t dst_stride, const int32_t* idx, int n, int row_vecs) {
+  const int per_blk = 256 / 64;  // one wave per row
+  const int i = blockIdx.x * per_blk + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int j = idx[i];
+  if (SCATTER && j < 0) return;
+  const V* s = reinterpret_cast<const V*>(src + (int64_t)(SCATTER ? i : j) * src_stride);
+  V* d = reinterpret_cast<V*>(dst + (int64_t)(SCATTER ? j : i) * dst_stride);
+  for (int v = (threadIdx.x & 63) + blockIdx.y * 64; v < row_vecs; v += 64 * gridDim.y) d[v] = s[v];
+}
+
+template <bool SCATTER>
+int move_rows(const void* src, int64_t src_stride, void* dst, int64_t dst_stride, const int32_t* idx, int n,
+              int64_t row_bytes, hipStream_t st) {
+  if (!src || !dst || !idx || n <= 0 || row_bytes <= 0) return CARE_EINVAL;
+  if ((row_bytes % 4) || (src_stride % 4) || (dst_stride % 4) || (((uintptr_t)src | (uintptr_t)dst) & 3)) return CARE_EALIGN;
+  const bool v16 = !(row_bytes % 16) && !(src_stride % 16) && !(dst_stride % 16) && care_aligned16(src) && care_aligned16(dst);
+  const int vecs = (int)(row_bytes / (v16 ? 16 : 4));
+  const int gy = vecs > 4096 ? 8 : (vecs > 512 ? 2 : 1);  // long rows: several workgroups per row
+  dim3 grid((n + 3) / 4, gy);
+  if (v16) hipLaunchKernelGGL((move_rows_kernel<SCATTER, uint4>), grid, dim3(256), 0, st, (const unsigned char*)src,
+                              src_stride, (unsigned char*)dst, dst_stride, idx, n, vecs);
+  else hipLaunchKernelGGL((move_rows_kernel<SCATTER, uint32_t>), grid, dim3(256), 0, st, (const unsigned char*)src,
+                          src_stride, (unsigned char*)dst, dst_stride, idx, n, vecs);
+  return care_launch_status();
+}
+
+}  // namespace
+
+extern "C" int care_active_slots(const int32_t* finished, int n, int32_t* idx, int32_t* count, void* stream) {
+  if (!finished || !idx || !count || n <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(active_slots_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, finished, n, idx, count);
+  return care_launch_status();
+}
+
+extern "C" int care_gather_rows(const void* src, int64_t src_stride_bytes, void* dst, int64_t dst_stride_bytes,
+                                const int32_t* idx, int n, int64_t row_bytes, void* stream) {
+  return move_rows<false>(src, src_stride_bytes, dst, dst_stride_bytes, idx, n, row_bytes, (hipStream_t)stream);
+}
+
+extern "C" int care_scatter_rows(const void* src, int64_t src_stride_bytes, void* dst, int64_t dst_stride_bytes,
+                                 const int32_t* idx, int n, int64_t row_bytes, void* stream) {
+  return move_rows<true>(src, src_stride_bytes, dst, dst_stride_bytes, idx, n, row_bytes, (hipStream_t)stream);
+}

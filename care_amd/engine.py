@@ -110,6 +110,11 @@ class HipEngine:
         self._lane = 0
         self.lanes = 1  # batch lanes of a graph-replayed greedy pass (lanes_for)
         self.latent = os.environ.get("CARE_LATENT", "1") != "0"
+        self._ws_cap = None
+        # early termination + active-set compaction of the greedy loop (greedy_early_exit); the fixed
+        # 29-step pass remains available (`early_exit=False`, CARE_EARLY_EXIT=0)
+        self.early_exit = os.environ.get("CARE_EARLY_EXIT", "1") != "0"
+        self.segment_steps = int(os.environ.get("CARE_SEGMENT_STEPS", "4"))
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, sd: Dict[str, torch.Tensor], device) -> None:
@@ -225,6 +230,15 @@ class HipEngine:
     def ws(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         """Named, cached workspace (allocated on first use, reused afterwards); one namespace per
         batch lane (lanes_for), so concurrent lanes never share a buffer."""
+        cap = self._ws_cap
+        if cap is not None and len(shape) >= 1 and shape[0] == cap[0] and cap[0] != cap[1]:
+            # compacted decode (greedy_early_exit): `n` active slots of `cap` use the first n rows of ONE
+            # full-size buffer instead of a workspace of their own for every row count
+            shape = (cap[1],) + tuple(shape[1:])
+            return self._ws_get(name, shape, dtype)[: cap[0]]
+        return self._ws_get(name, shape, dtype)
+
+    def _ws_get(self, name, shape, dtype):
         key = (self._lane, name, tuple(shape), dtype)
         t = self._ws.get(key)
         if t is None:
@@ -376,17 +390,21 @@ class HipEngine:
         return (self.as_ok and self.d == 512 and not self.has_concepts and self.opt["encoder"] == "Embedder" and
                 all(ch in self.dec_mod and int(self.opt["dim_" + ch]) % 32 == 0 for ch in self.modality))
 
-    def encode(self, feats: List[torch.Tensor], lean: bool = False) -> Dict[str, torch.Tensor]:
+    def encode(self, feats: List[torch.Tensor], lean: bool = False, static: bool = False) -> Dict[str, torch.Tensor]:
         """`Seq2SeqBase.encoding_phase` (models/Framework.py:150-187); outputs are fresh tensors.
-        lean (translate path only, see lean_ok): returns just {"encoder_hidden_states": bf16 memory}."""
+        lean (translate path only, see lean_ok): returns just {"encoder_hidden_states": bf16 memory}.
+        static (translate path only): the memory lives in engine-owned buffers that the next call
+        overwrites - so that decode segments captured as hipGraphs keep reading valid addresses."""
         w, d, opt = self.w, self.d, self.opt
         if len(feats) < len(self.modality):
             raise ValueError("expected {} feature tensors, got {}".format(len(self.modality), len(feats)))
         B = feats[0].shape[0]
         lean = lean and self.lean_ok
-        mem = None if lean else torch.empty(B, self.Lk, d, device=self.device)
-        memb = torch.empty(B, self.Lk, d, device=self.device, dtype=torch.bfloat16) if self.as_ok else None
-        means = None if lean else torch.empty(B, len(self.modality) * d, device=self.device)
+        new = (lambda name, shape, dt=torch.float32: self.ws("enc_out_" + name, shape, dt)) if static else \
+              (lambda name, shape, dt=torch.float32: torch.empty(shape, device=self.device, dtype=dt))
+        mem = None if lean else new("mem", (B, self.Lk, d))
+        memb = new("memb", (B, self.Lk, d), torch.bfloat16) if self.as_ok else None
+        means = None if lean else new("means", (B, len(self.modality) * d))
         for mi, ch in enumerate(self.modality):
             x = feats[mi].to(self.device, torch.float32).contiguous()
             n = x.shape[1]
@@ -435,25 +453,24 @@ class HipEngine:
                                 if ch in self.pred_mod], dim=1).contiguous()
             kp = self._kpad()
             scores = self.gemm(pm, w["attr_w"], w["attr_b"], self.ws("attr_scores", (B, kp)))
-            preds = torch.empty(B, kp, device=self.device)
-            avg = torch.empty(B, device=self.device)
+            preds = new("preds", (B, kp))
+            avg = new("avg", (B,))
             call("care_concept_finish", ptr(scores), kp, ptr(preds), kp, ptr(avg), B, self.k_attr)
             out["preds_attr"] = preds[:, : self.k_attr]
             out["avg_prob_attr"] = avg
             if self.has_container:
-                labels = torch.empty(B, self.topk, device=self.device, dtype=torch.int64)
+                labels = new("labels", (B, self.topk), torch.int64)
                 if self.concat:
                     dst, dstb, grp_rows, off = mem, memb, self.Lk, self.concept_off
                 else:
-                    dst, dstb, grp_rows, off = torch.empty(B, self.topk, d, device=self.device), None, self.topk, 0
+                    dst, dstb, grp_rows, off = new("sem_embs", (B, self.topk, d)), None, self.topk, 0
                 call("care_concept_topk_embed", ptr(preds), kp, self.k_attr, self.topk, ptr(w["attr_word"]),
                      ptr(w["attr_pos"]), ptr(w["attr_g"]), ptr(w["attr_be"]), self.eps, ptr(labels), ptr(dst),
                      ptr(dstb), d, grp_rows, off, B, d)
                 out["semantic_labels"] = labels
                 out["semantic_embs"] = dst[:, off: off + self.topk]
                 if self.sem:
-                    out["semantic_hidden_states"] = self.gemm(preds, w["s2h_w"], w["s2h_b"],
-                                                              torch.empty(B, d, device=self.device))
+                    out["semantic_hidden_states"] = self.gemm(preds, w["s2h_w"], w["s2h_b"], new("sem_hidden", (B, d)))
                 else:
                     out["semantic_hidden_states"] = None
         # bf16 mirror of the memory: the A operand of the cross-K/V projection (internal).  Matched by
@@ -721,7 +738,188 @@ class HipEngine:
                      ptr(length), ptr(fin), t, T, EOS, B)
         return fed, length, score
 
-    def translate_greedy(self, feats: List[torch.Tensor], use_graph: bool = True, lean: bool = False):
+    # ------------------------------------------------------------------ greedy with early exit + compaction
+    def _call_rows(self, fn, src, dst, idx, n):
+        """care_gather_rows / care_scatter_rows on tensors whose first dim is the row."""
+        rb = src[0].numel() * src.element_size()
+        call(fn, ptr(src), src.stride(0) * src.element_size(), ptr(dst), dst.stride(0) * dst.element_size(), ptr(idx), n, rb)
+
+    def _slot_bucket(self, active: int, cap: int) -> int:
+        """Row count a compacted decode runs on: `active` rounded up to a granule of cap / 32 (>= 64), so
+        that the captured segments of different batches meet the same few shapes."""
+        g = max(64, cap // 32)
+        return min(cap, (active + g - 1) // g * g)
+
+    def greedy_early_exit(self, feats: List[torch.Tensor], lean: bool = False, use_graph: bool = True):
+        """encode + greedy decode that STOPS when every clip has ended and drops ended clips from the
+        batch on the way (the reference: models/Translator.py:77-81 `if not active_inst_idx_list: break`,
+        :194-209 `collect_active_part`; per step and on the host there).
+
+        The 29 steps run in segments of `segment_steps`; after a segment one counter comes back to the
+        host - the rows still active.  None: done.  At most 3/4 of the slots in use: the active rows are
+        gathered to the front of a second set of buffers (K/V caches, memory, next-step inputs, tokens:
+        csrc/compact.hip) and the following segments run on that many rows (rounded up to a bucket;
+        the padding rows are ended clips that ride along).  Rows are independent end to end, so every
+        clip decodes exactly as in the fixed-length pass.  A segment is captured into a hipGraph the
+        second time its (first step, row count, buffer set) comes up.  Results are per CLIP:
+        fed int32 [B, T + 1] (column 0 = BOS), length int32 [B], score fp32 [B]."""
+        feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        B, T, d = feats[0].shape[0], self.T, self.d
+        S = max(1, self.segment_steps)
+        out_fed = self.ws("ge_out_fed", (B, T + 1), torch.int32)
+        out_len = self.ws("ge_out_len", (B,), torch.int32)
+        out_score = self.ws("ge_out_score", (B,))
+        idx = self.ws("ge_idx", (B,), torch.int32)
+        cnt = self.ws("ge_cnt", (1,), torch.int32)
+        fkey = (tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        st = {}
+
+        def state(par, n):
+            """Views of buffer set `par` for n slots (allocated at full size once)."""
+            self._ws_cap = (n, B)
+            tag = "g%d_" % par
+            v = dict(tag=tag, n=n,
+                     fed=self.ws(tag + "fed", (n, T + 1), torch.int32), score=self.ws(tag + "score", (n,)),
+                     length=self.ws(tag + "len", (n,), torch.int32), fin=self.ws(tag + "fin", (n,), torch.int32),
+                     clip=self.ws(tag + "clip", (n,), torch.int32),
+                     x0=self.ws(tag + "x0", (n, d)), x0b=self.wsb(tag + "x0", (n, d)),
+                     skv=[self.ws(tag + "skv%d" % li, (n, T, 2 * d), self.wt) for li in range(self.n_layers)])
+            return v
+
+        def run_steps(v, t0, t1, enc=None):
+            n = v["n"]
+            self._ws_cap = (n, B)
+            bf = self.as_ok
+            parts = _lib.argmax_parts(self.V, n, bf)
+            pmax, psum = self.ws(v["tag"] + "pmax", (n, parts)), self.ws(v["tag"] + "psum", (n, parts))
+            pidx = self.ws(v["tag"] + "pidx", (n, parts), torch.int32)
+            for t in range(t0, t1 + 1):
+                x, xb = self._decode_step(t, n, 1, v["fed"], None, v["sem"], v["ckv"], v["skv"], self.Lk, v["tag"],
+                                          akv=v["akv"], embedded=t > 1)
+                if bf:
+                    call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(pmax), ptr(pidx),
+                         ptr(psum), None, None, n, self.V, d, tag="step_vocab_argmax")
+                else:
+                    call("care_gemm_argmax", ptr(x), d, ptr(self.w["vocab"]), _code(self.w["vocab"]), ptr(pmax),
+                         ptr(pidx), ptr(psum), n, self.V, d, tag="step_vocab_argmax")
+                if t < T:
+                    call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
+                         ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n, ptr(self.w["word"]),
+                         ptr(self.w["pos"]), ptr(v["sem"]), 1, ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps,
+                         ptr(v["x0"]), ptr(v["x0b"]), d, d)
+                else:
+                    call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
+                         ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n)
+            call("care_active_slots", ptr(v["fin"]), n, ptr(idx), ptr(cnt))
+
+        def first_segment():
+            """encode, state initialisation and steps 1 .. S on all B slots of buffer set 0."""
+            self._ws_cap = None
+            enc = self.encode(feats, lean, static=True)
+            mem = enc["encoder_hidden_states"]
+            sem = enc.get("semantic_hidden_states")
+            v = state(0, B)
+            v["fed"].zero_(); v["fed"][:, 0] = BOS
+            v["score"].zero_(); v["length"].zero_(); v["fin"].zero_()
+            v["clip"].copy_(self._arange(B))
+            v["sem"] = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
+            self._ws_cap = None  # cross_src / attr_kv work on all B clips
+            v["ckv"] = self.cross_src(mem, B)
+            v["akv"] = self.attr_kv(enc.get("semantic_embs")) if self.attr_att else None
+            run_steps(v, 1, min(S, T))
+            return enc, v
+
+        def replayable(key, fn):
+            """Eager the first time a key is seen, captured the second, replayed afterwards."""
+            if not use_graph:
+                return fn()
+            entry = self._graphs.get(key)
+            if entry is None:
+                self._graphs[key] = "seen"
+                return fn()
+            if entry == "seen":
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = fn()
+                entry = (graph, out)
+                self._graphs[key] = entry
+            entry[0].replay()
+            return entry[1]
+
+        try:
+            enc, v = replayable(("gseg0", self.latent_ok, bool(lean), S) + fkey, first_segment)
+            par, t = 0, min(S, T) + 1
+            stats = dict(clips=B, steps=t - 1, row_steps=B * (t - 1), compactions=0)
+            self.last_decode = stats  # what the last pass actually ran (tests, bench)
+            while True:
+                active = int(cnt.item())  # the one host round trip per segment
+                if active == 0 or t > T:
+                    break
+                n_new = self._slot_bucket(active, B)
+                if n_new * 4 <= v["n"] * 3:
+                    v = self._compact(v, state(par ^ 1, n_new), idx, active, out_fed, out_len, out_score)
+                    par ^= 1
+                    stats["compactions"] += 1
+                t1 = min(t + S - 1, T)
+                vv = v
+                replayable(("gseg", par, t, t1, v["n"], B, self.latent_ok), lambda: run_steps(vv, t, t1))
+                stats["steps"] = t1
+                stats["row_steps"] += v["n"] * (t1 - t + 1)
+                t = t1 + 1
+            n = v["n"]
+            self._call_rows("care_scatter_rows", v["fed"], out_fed, v["clip"], n)
+            self._call_rows("care_scatter_rows", v["length"].view(n, 1), out_len.view(B, 1), v["clip"], n)
+            self._call_rows("care_scatter_rows", v["score"].view(n, 1), out_score.view(B, 1), v["clip"], n)
+        finally:
+            self._ws_cap = None
+        return enc, out_fed, out_len, out_score
+
+    def _arange(self, n):
+        t = self._ws.get(("arange", n))
+        if t is None:
+            t = torch.arange(n, device=self.device, dtype=torch.int32)
+            self._ws[("arange", n)] = t
+        return t
+
+    def _compact(self, v, w, idx, active, out_fed, out_len, out_score):
+        """Results of every slot of `v` -> the per-clip outputs; then the first w['n'] slots of the
+        partition `idx` (active ones first, ended ones as padding) -> buffer set `w`."""
+        n, m = v["n"], w["n"]
+        B = out_fed.shape[0]
+        self._call_rows("care_scatter_rows", v["fed"], out_fed, v["clip"], n)
+        self._call_rows("care_scatter_rows", v["length"].view(n, 1), out_len.view(B, 1), v["clip"], n)
+        self._call_rows("care_scatter_rows", v["score"].view(n, 1), out_score.view(B, 1), v["clip"], n)
+        for k in ("fed", "x0", "x0b"):
+            if v[k] is not None:
+                self._call_rows("care_gather_rows", v[k], w[k], idx, m)
+        for k in ("score", "length", "fin", "clip"):
+            self._call_rows("care_gather_rows", v[k].view(n, 1), w[k].view(m, 1), idx, m)
+        for a, b in zip(v["skv"], w["skv"]):
+            self._call_rows("care_gather_rows", a, b, idx, m)
+        tag = w["tag"]
+        self._ws_cap = (m, B)
+
+        def moved(name, src, per=1):
+            """Per-clip tensor with `per` rows per clip ([n * per, ...] or, per = 1, [n, ...]) -> m clips."""
+            if src is None:
+                return None
+            s2 = src.view(n, -1)
+            dst = self.ws(tag + name, (m, s2.shape[1]), src.dtype)
+            self._call_rows("care_gather_rows", s2, dst, idx, m)
+            return dst.view((m * per,) + tuple(src.shape[1:])) if per > 1 else dst.view((m,) + tuple(src.shape[1:]))
+
+        w["sem"] = moved("sem", v["sem"])
+        if isinstance(v["ckv"], tuple):  # absorbed form: one bf16 memory [n, Lk, d] shared by the layers
+            w["ckv"] = (moved("mem", v["ckv"][0]),) * len(v["ckv"])
+        else:                            # projected K/V: [n * Lk, 2d] per layer
+            w["ckv"] = [moved("ckv%d" % i, kv, self.Lk) for i, kv in enumerate(v["ckv"])]
+        w["akv"] = [moved("akv%d" % i, kv, self.topk) for i, kv in enumerate(v["akv"])] if v["akv"] is not None else None
+        w["clip"][active:].fill_(-1)     # padding slots: ended clips whose results are already out
+        return w
+
+    def translate_greedy(self, feats: List[torch.Tensor], use_graph: bool = True, lean: bool = False,
+                         early_exit: Optional[bool] = None):
         """encode + greedy decode of one batch; replayed from a hipGraph when possible.
 
         One pass issues ~360-440 kernel launches (12-15 per step); driven from Python that is
@@ -736,6 +934,9 @@ class HipEngine:
         lanes = self.lanes_for(feats[0].shape[0]) if use_graph else 1
         if lanes > 1:
             return self._translate_greedy_lanes(feats, lanes, lean)
+        if self.early_exit if early_exit is None else early_exit:
+            # stop when every clip has ended, drop ended clips on the way (greedy_early_exit)
+            return self.greedy_early_exit(feats, lean, use_graph)
         if not use_graph:
             enc = self.encode(feats, lean)
             return (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
@@ -749,8 +950,8 @@ class HipEngine:
             self._graphs[key] = "seen"
             return out
         if entry == "seen":
-            if len(self._graphs) > 8:
-                self._graphs = {k: v for k, v in self._graphs.items() if k == key}
+            if sum(1 for k in self._graphs if k[0] == key[0]) > 8:
+                self._graphs = {k: v for k, v in self._graphs.items() if k == key or k[0] != key[0]}
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -816,8 +1017,8 @@ class HipEngine:
             self._graphs[key] = "seen"
             return run()  # eager: allocates every lane's workspaces
         if entry == "seen":
-            if len(self._graphs) > 8:
-                self._graphs = {k: v for k, v in self._graphs.items() if k == key}
+            if sum(1 for k in self._graphs if k[0] == key[0]) > 8:
+                self._graphs = {k: v for k, v in self._graphs.items() if k == key or k[0] != key[0]}
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -846,8 +1047,8 @@ class HipEngine:
             self._graphs[key] = "seen"
             return run()
         if entry == "seen":
-            if len(self._graphs) > 8:
-                self._graphs = {k: v for k, v in self._graphs.items() if k == key}
+            if sum(1 for k in self._graphs if k[0] == key[0]) > 8:
+                self._graphs = {k: v for k, v in self._graphs.items() if k == key or k[0] != key[0]}
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):

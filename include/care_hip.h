@@ -362,6 +362,22 @@ int care_beam_advance(const float* cand_val, const int32_t* cand_idx, float* sco
                       int32_t* fin_len, int32_t* fin_hyp, int t, int max_steps, int need,
                       int eos_id, int V, int stride, int B, void* stream);
 
+/*
+ * Active-set compaction of the decode loop (csrc/compact.hip).  The reference ends a batch when every
+ * instance is done and removes finished instances from every cached tensor at each step
+ * (models/Translator.py:77-81,194-209); here the loop runs in segments and compacts between them.
+ *   care_active_slots: idx[0 .. cnt) = the slots with finished == 0 in ascending order, idx[cnt .. n)
+ *     = the finished ones in ascending order (a stable partition), count[0] = cnt.  n <= 2^30.
+ *   care_gather_rows:  dst row i = src row idx[i], i < n.
+ *   care_scatter_rows: dst row idx[i] = src row i, i < n; rows with idx[i] < 0 are skipped.
+ *   row_bytes and the strides are multiples of 4 (16-byte vectors are used when everything allows).
+ */
+int care_active_slots(const int32_t* finished, int n, int32_t* idx, int32_t* count, void* stream);
+int care_gather_rows(const void* src, int64_t src_stride_bytes, void* dst, int64_t dst_stride_bytes,
+                     const int32_t* idx, int n, int64_t row_bytes, void* stream);
+int care_scatter_rows(const void* src, int64_t src_stride_bytes, void* dst, int64_t dst_stride_bytes,
+                      const int32_t* idx, int n, int64_t row_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -226,7 +226,7 @@ def test_benchmarked_operating_point_against_oracle_sample(config, B):
     for it in range(4):  # eager, first sight (eager), capture, replay
         _, fed, length, score = eng.translate_greedy(feats, use_graph=it > 0, lean=True)
         runs.append((fed.clone(), length.clone(), score.clone()))
-    assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] == "greedy"), "pass was not captured"
+    assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] in ("greedy", "gseg0")), "pass was not captured"
     for other in runs[1:]:
         for a, b in zip(runs[0], other):
             assert torch.equal(a, b)
@@ -281,3 +281,69 @@ def test_beam_graph_replay_equals_eager(config, dtype, B):
     flipped = run(True)
     assert torch.equal(flipped[0], eager[0].flip(0)) and torch.equal(flipped[2], eager[2].flip(0))
     assert torch.equal(flipped[3], eager[3].flip(0))
+
+
+@pytest.mark.parametrize("config,dtype,B", [("msrvtt_base_ami", "bf16", 4096), ("msrvtt_care", "bf16", 1536),
+                                            ("msrvtt_base_ami", "fp32", 700), ("msrvtt_cabase", "fp32", 300),
+                                            ("msvd_base_i", "bf16", 64)])
+def test_early_exit_and_compaction_equal_the_fixed_length_pass(config, dtype, B):
+    """models/Translator.py:77-81,194-209: the reference stops when every instance is done and removes
+    finished instances at every step.  engine.greedy_early_exit does it per segment; clips are
+    independent, so every clip's tokens, length and score must be BIT-identical to the pass that
+    runs all 29 steps over all rows - eager and replayed from the captured segments - while the
+    work shrinks with the number of clips still active."""
+    boost = {"cls_head.tgt_word_prj.weight": {3: 5.0, 0: 3.0}}  # early EOS at mixed times, generated PADs
+    opt, P, model, feats = _setup(config, B, dtype, boost=boost)
+    eng = model.engine()
+    _, fed0, len0, sc0 = eng.translate_greedy(feats, use_graph=False, early_exit=False)
+    fed0, len0, sc0 = fed0.clone(), len0.clone(), sc0.clone()
+    assert len(set(len0.tolist())) > 4 and int(len0.max()) <= 29
+    for it in range(4):  # eager, first sight, capture, replay
+        _, fed1, len1, sc1 = eng.translate_greedy(feats, use_graph=it > 0, early_exit=True)
+        st = dict(eng.last_decode)
+        # scores: the vocabulary GEMM splits its columns by row count, so the log-sum-exp partials of a
+        # compacted batch are merged in another order (1e-7 relative); tokens and lengths are exact
+        assert torch.equal(len1, len0) and (sc1 - sc0).abs().max().item() < 1e-4
+        keep = torch.arange(30, device="cuda:0").unsqueeze(0) <= len0.unsqueeze(1)   # BOS + the caption
+        assert torch.equal(fed1 * keep, fed0 * keep)
+        if B >= 256:
+            assert st["compactions"] >= 1 and st["row_steps"] < 0.8 * B * 29, st
+        assert st["steps"] <= 29 and (st["steps"] == 29 or int(len0.max()) <= st["steps"])
+    if B >= 256:
+        assert any(k[0] == "gseg" and isinstance(g, tuple) for k, g in eng._graphs.items()), "no segment was captured"
+    # new inputs in the same buffers: the captured segments must follow them (and a different finish pattern)
+    for f in feats:
+        f.copy_(f.flip(0))
+    _, fed2, len2, sc2 = eng.translate_greedy(feats, use_graph=True, early_exit=True)
+    assert torch.equal(len2, len0.flip(0)) and (sc2 - sc0.flip(0)).abs().max().item() < 1e-4
+
+
+def test_active_slots_gather_scatter_kernels():
+    """csrc/compact.hip against torch: stable partition of the slot indices, row gather, row scatter."""
+    from care_amd import _lib
+
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    for n in (1, 63, 64, 1000, 1024, 1025, 40000):
+        fin = (torch.rand(n, generator=g, device="cuda:0") < 0.6).to(torch.int32)
+        idx = torch.empty(n, device="cuda:0", dtype=torch.int32)
+        cnt = torch.zeros(1, device="cuda:0", dtype=torch.int32)
+        _lib.call("care_active_slots", fin.data_ptr(), n, idx.data_ptr(), cnt.data_ptr())
+        act = torch.nonzero(fin == 0).flatten().to(torch.int32)
+        done = torch.nonzero(fin != 0).flatten().to(torch.int32)
+        assert int(cnt) == act.numel() and torch.equal(idx, torch.cat([act, done]))
+    for rows, cols, dt in ((1000, 29 * 1024, torch.bfloat16), (777, 30, torch.int32), (513, 1, torch.float32),
+                           (300, 84 * 512, torch.bfloat16)):
+        src = (torch.randn(rows, cols, generator=g, device="cuda:0") * 100).to(dt)
+        m = rows // 2 + 1
+        idx = torch.randperm(rows, generator=g, device="cuda:0")[:m].to(torch.int32)
+        dst = torch.zeros(m, cols, device="cuda:0", dtype=dt)
+        es = src.element_size()
+        _lib.call("care_gather_rows", src.data_ptr(), cols * es, dst.data_ptr(), cols * es, idx.data_ptr(), m, cols * es)
+        assert torch.equal(dst, src[idx.long()])
+        back = torch.zeros_like(src)
+        idx2 = idx.clone()
+        idx2[0] = -1                     # skipped
+        _lib.call("care_scatter_rows", dst.data_ptr(), cols * es, back.data_ptr(), cols * es, idx2.data_ptr(), m, cols * es)
+        ref = torch.zeros_like(src)
+        ref[idx[1:].long()] = dst[1:]
+        assert torch.equal(back, ref)
