@@ -46,6 +46,9 @@ def parse():
                          "+5-8%% at B >= 4096; the default 1 keeps every kernel alone on the chip so that the "
                          "per-kernel roofline and profiles/ describe the timed pass exactly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the extra legs (other BASELINE configs, beam 5, fp32, B = 128, crafted-EOS early exit, "
+                         "bf16 error) that rank 0 reports in `legs` beside the headline measurement at N = 1")
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads for the CPU oracle (16 was the fastest of 8..128 on the 2x64-core host)")
@@ -80,6 +83,108 @@ def kernel_model(tag, eng, B, dtype):
     if tag == "cross_kv_gemm":
         return dict(bytes=B * Lk * (d * 4 + 2 * d * es) + 2 * d * d * es, flops=2.0 * B * Lk * d * 2 * d, bound="mfma")
     return None
+
+
+def _timed(fn, iters):
+    """Seconds per call of fn (already warmed up)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def extra_legs(dev, main_dtype):
+    """The other operating points of BASELINE.json / VERDICT, measured in the same process after the
+    headline run (rank 0, N = 1 only): each is `captions/s` of whole passes over synthetic clips
+    resident in HBM, hipGraph replay, measured over >= 5 passes after 3 warm-up calls."""
+    from care_amd import get_framework
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_state_dict
+
+    legs = {}
+
+    def build(config, dtype, row_scale=None, **over):
+        opt = make_opt(config, **over)
+        model = get_framework(opt).eval()
+        P = synth_state_dict(0, [(k, tuple(v.shape)) for k, v in model.state_dict().items()], row_scale=row_scale or {})
+        model.load_state_dict(P, strict=True)
+        model.set_compute_dtype(dtype)
+        model.to(dev)
+        return opt, model.engine()
+
+    def feats_for(opt, B, seed=2000):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        return [torch.randn(shape, generator=gen, device=dev, dtype=torch.float32) for shape in feat_shapes(opt, B)]
+
+    def greedy_leg(config, dtype, B, iters=5, **kw):
+        opt, eng = build(config, dtype, **kw)
+        feats = feats_for(opt, B)
+        run = lambda: eng.translate_greedy(feats, use_graph=True, lean=True)
+        for _ in range(3):
+            run()
+        dt = _timed(run, iters)
+        return dict(config=config, dtype=dtype, clips_per_step=B, captions_per_s=round(B / dt, 1),
+                    ms_per_pass=round(dt * 1e3, 3), decoder_step_us=round(dt * 1e6 / eng.T, 2)), eng, feats, opt
+
+    # BASELINE configs[2]: the concept-guided (CARE) path
+    legs["msrvtt_care_greedy"] = greedy_leg("msrvtt_care", main_dtype, 16384)[0]
+    # fp32 parity mode (the only mode inside north_star's 1e-5 tolerance)
+    legs["msrvtt_base_ami_fp32"] = greedy_leg("msrvtt_base_ami", "fp32", 4096)[0]
+    # the reference's own operating point: translate.py batch 128 (translate.py:137); a step here is a latency
+    legs["msrvtt_base_ami_B128"] = greedy_leg("msrvtt_base_ami", main_dtype, 128, iters=20)[0]
+    legs["msrvtt_base_ami_B1"] = greedy_leg("msrvtt_base_ami", main_dtype, 1, iters=20)[0]
+    # BASELINE configs[3]: d_model = 1024
+    legs["vatex_care_large"] = greedy_leg("vatex_care_large", main_dtype, 4096)[0]
+    # BASELINE configs[4]: CARE, beam 5 (opts.py beam_size 5), and at the reference's batch of 128
+    for B in (4096, 128):
+        opt, eng = build("msrvtt_care_beam5", main_dtype)
+        feats = feats_for(opt, B)
+        run = lambda: eng.translate_beam(feats, 5, 5, use_graph=True, lean=True)
+        for _ in range(3):
+            run()
+        dt = _timed(run, 5 if B > 128 else 20)
+        legs["msrvtt_care_beam5_B%d" % B] = dict(config="msrvtt_care_beam5", dtype=main_dtype, clips_per_step=B, beam_size=5,
+                                                  rows_per_decoder_step=5 * B, captions_per_s=round(B / dt, 1),
+                                                  ms_per_pass=round(dt * 1e3, 3), decoder_step_us=round(dt * 1e6 / eng.T, 2))
+    # a model that ENDS its captions (EOS row of the vocabulary projection x 5: mixed lengths, mean ~8 like trained
+    # captions; random-init weights never emit EOS): early termination + compaction against the fixed 29 steps
+    boost = {"cls_head.tgt_word_prj.weight": {3: 5.0}}
+    leg, eng, feats, opt = greedy_leg("msrvtt_base_ami", main_dtype, 32768, row_scale=boost)
+    _, fed, length, _ = eng.translate_greedy(feats, use_graph=True, lean=True)
+    mean_len = float(length.float().mean())
+    stats = dict(eng.last_decode)
+    fixed = lambda: eng.translate_greedy(feats, use_graph=True, lean=True, early_exit=False)
+    for _ in range(3):
+        fixed()
+    dt_fixed = _timed(fixed, 5)
+    leg.update(mean_caption_length=round(mean_len, 2), steps_run=stats["steps"], compactions=stats["compactions"],
+               row_steps=stats["row_steps"], row_steps_fixed=32768 * eng.T,
+               fixed_29_steps_captions_per_s=round(32768 / dt_fixed, 1),
+               speedup_vs_fixed_29=round(dt_fixed / (leg["ms_per_pass"] * 1e-3), 2))
+    legs["early_exit_eos_model"] = leg
+    # the error of the throughput mode: teacher-forced hidden states, bf16 mode against fp32 mode of this
+    # same engine (fp32 mode is within 1e-5 of the reference, tests/test_gpu_parity.py) on the benchmarked model
+    if main_dtype == "bf16":
+        from care_amd.synth import synth_feats, synth_input_ids
+
+        opt = make_opt("msrvtt_base_ami")
+        model = get_framework(opt).eval()
+        model.load_state_dict(synth_state_dict(0, [(k, tuple(v.shape)) for k, v in model.state_dict().items()]), strict=True)
+        model.to(dev)
+        f = [x.to(dev) for x in synth_feats(3, feat_shapes(opt, 64))]
+        ids = synth_input_ids(3, 64, opt["max_len"] - 1, opt["vocab_size"]).to(dev)
+        hid = {}
+        for dt_ in ("fp32", "bf16"):
+            model.set_compute_dtype(dt_)
+            hid[dt_] = model.feedforward_step({"feats": f, "input_ids": ids})["hidden_states"].float().clone()
+        diff = (hid["bf16"] - hid["fp32"]).abs()
+        legs["bf16_hidden_state_error"] = dict(max_abs=round(float(diff.max()), 5), mean_abs=round(float(diff.mean()), 6),
+                                               against="fp32 mode of the same engine (itself within 1e-5 of the reference)",
+                                               sample="teacher-forced hidden states, 64 clips x 29 positions x 512")
+    return legs
 
 
 def main():
@@ -259,6 +364,10 @@ def main():
         gflop_per_caption=round(total_fl / 1e9, 4),
         pass_tflops=round(total_fl * value / 1e12, 2),
         roofline=roofline, kernels=per_kernel, cpu_baseline=cpu)
+    if world == 1 and not args.no_legs and args.beam == 1:
+        del model, eng, feats
+        torch.cuda.empty_cache()
+        line["legs"] = extra_legs(dev, args.dtype)
     print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

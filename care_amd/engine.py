@@ -765,7 +765,9 @@ class HipEngine:
         fed int32 [B, T + 1] (column 0 = BOS), length int32 [B], score fp32 [B]."""
         feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
         B, T, d = feats[0].shape[0], self.T, self.d
-        S = max(1, self.segment_steps)
+        # small batches are launch-bound: a segment boundary (one host round trip + one more graph launch,
+        # ~40 us) costs as much as several of their steps, so they check twice as rarely and never compact
+        S = max(1, self.segment_steps) * (1 if B >= 2048 else 2)
         out_fed = self.ws("ge_out_fed", (B, T + 1), torch.int32)
         out_len = self.ws("ge_out_len", (B,), torch.int32)
         out_score = self.ws("ge_out_score", (B,))
@@ -857,7 +859,7 @@ class HipEngine:
                 if active == 0 or t > T:
                     break
                 n_new = self._slot_bucket(active, B)
-                if n_new * 4 <= v["n"] * 3:
+                if n_new * 4 <= v["n"] * 3 and v["n"] >= 2048:
                     v = self._compact(v, state(par ^ 1, n_new), idx, active, out_fed, out_len, out_score)
                     par ^= 1
                     stats["compactions"] += 1

@@ -83,10 +83,10 @@ def test_translate_batch_fp32(golden):
 # two numbers for the benchmarked model in its JSON line); concept outputs exact (they stay fp32);
 # logsumexp of the logits <= 1e-3; greedy ids identical wherever the reference's own
 # top-1/top-2 margin exceeds the bf16 noise (audited against the oracle's margins).
-BF16_MAX, BF16_MEAN = 4e-2, 5e-3
+BF16_MAX, BF16_MEAN = 1.9e-2, 3.0e-3  # measured over the 18 fixtures: 1.48e-2 / 2.35e-3 (gpurun_out/bf16_err.jsonl)
 # logsumexp of the logits: bf16 noise of a logit scales with the norm of its vocabulary row, so the
 # `peaked` fixtures (rows scaled by 12 / 20, logits up to +-30) get a bar of their own
-BF16_LSE, BF16_LSE_PEAKED = 1e-3, 3.5e-2
+BF16_LSE, BF16_LSE_PEAKED = 1e-4, 3.5e-2  # measured 5.5e-5; 2.2e-2 .. 2.6e-2 on the peaked fixtures
 
 
 def _record(name, **values):
@@ -295,7 +295,7 @@ def test_bench_under_torchrun_with_rccl():
     env = dict(os.environ, CARE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
-           "--warmup", "2", "--batch", "256", "--no-cpu-baseline"]
+           "--warmup", "2", "--batch", "256", "--no-cpu-baseline", "--no-legs"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

@@ -283,7 +283,7 @@ def test_beam_graph_replay_equals_eager(config, dtype, B):
     assert torch.equal(flipped[3], eager[3].flip(0))
 
 
-@pytest.mark.parametrize("config,dtype,B", [("msrvtt_base_ami", "bf16", 4096), ("msrvtt_care", "bf16", 1536),
+@pytest.mark.parametrize("config,dtype,B", [("msrvtt_base_ami", "bf16", 4096), ("msrvtt_care", "bf16", 2560),
                                             ("msrvtt_base_ami", "fp32", 700), ("msrvtt_cabase", "fp32", 300),
                                             ("msvd_base_i", "bf16", 64)])
 def test_early_exit_and_compaction_equal_the_fixed_length_pass(config, dtype, B):
@@ -306,11 +306,13 @@ def test_early_exit_and_compaction_equal_the_fixed_length_pass(config, dtype, B)
         assert torch.equal(len1, len0) and (sc1 - sc0).abs().max().item() < 1e-4
         keep = torch.arange(30, device="cuda:0").unsqueeze(0) <= len0.unsqueeze(1)   # BOS + the caption
         assert torch.equal(fed1 * keep, fed0 * keep)
-        if B >= 256:
+        if B >= 2048:  # smaller batches only stop early, they do not compact (launch-bound)
             assert st["compactions"] >= 1 and st["row_steps"] < 0.8 * B * 29, st
         assert st["steps"] <= 29 and (st["steps"] == 29 or int(len0.max()) <= st["steps"])
     if B >= 256:
         assert any(k[0] == "gseg" and isinstance(g, tuple) for k, g in eng._graphs.items()), "no segment was captured"
+    if B >= 2048:
+        assert any(k[0] == "gseg" and k[4] < B for k in eng._graphs), "no compacted segment ran"
     # new inputs in the same buffers: the captured segments must follow them (and a different finish pattern)
     for f in feats:
         f.copy_(f.flip(0))
