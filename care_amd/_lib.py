@@ -50,6 +50,7 @@ SIGNATURES = {
     "care_gemm_collect_bf16": [_P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "care_beam_pick": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _L, _I, _P, _I, _I, _P, _P, _I, _P],
     "care_beam_select": [_P, _L, _I, _I, _P, _P, _I, _P],
+    "care_attention_probs": [_P, _L, _P, _I, _L, _L, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     "care_active_slots": [_P, _I, _P, _P, _P],
     "care_gather_rows": [_P, _L, _P, _L, _P, _I, _L, _P],
     "care_scatter_rows": [_P, _L, _P, _L, _P, _I, _L, _P],

@@ -370,3 +370,67 @@ extern "C" int care_attention(const float* Q, int64_t ldq, const void* K, const 
     return anc ? launch_attention_row<true>(p, st) : launch_attention_row<false>(p, st);
   return kv_dtype == CARE_BF16 ? launch_attention<bf16_t>(p, st) : launch_attention<float>(p, st);
 }
+
+// ---------------------------------------------------------------------------------------------
+// care_attention_probs: the softmax probabilities themselves, [rows, heads, nkeys] fp32 - the
+// `attention_probs` the reference's decoder returns next to its hidden states
+// (models/Decoder/Transformer.py:239-252: all_intra_attentions / all_inter_attentions /
+// attention_probs; read by regularisers and notebooks, never by decoding).  The fused kernels above
+// keep them in registers; this one is the off-path companion for the teacher-forced forward: one wave
+// per (row, head), lane j owns keys j and j + 64, same score arithmetic (scale, -1e9 mask, bias after
+// the mask).
+namespace {
+template <typename KT>
+__global__ __launch_bounds__(256) void attention_probs_kernel(AttnArgs p, float* probs) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= p.rows * p.heads) return;
+  const int r = item / p.heads, h = item % p.heads;
+  int nk = p.nkeys;
+  if (p.causal) nk = min(nk, (r % p.seq) + 1 + p.causal_off);
+  const int kvb = r / p.rows_per_kv;
+  const float* q = p.Q + (int64_t)r * p.ldq + h * 64;
+  const KT* Kb = reinterpret_cast<const KT*>(p.K) + (int64_t)kvb * p.kv_batch_stride + h * 64;
+  float s[2];
+  float m = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = lane + 64 * u;
+    s[u] = -INFINITY;
+    if (j < nk) {
+      const KT* kr = Kb + (int64_t)j * p.kv_row_stride;
+      float d = 0.f;
+      for (int i = 0; i < 64; ++i) d = fmaf(q[i], (float)kr[i], d);
+      d *= 0.125f;
+      if (p.pad_tok && p.pad_tok[(int64_t)kvb * p.pad_stride + j] == p.pad_id) d = -1e9f;
+      if (p.bias) d += p.bias[h * p.bias_ld + j];
+      s[u] = d;
+    }
+    m = fmaxf(m, s[u]);
+  }
+  m = care_wave_max(m);
+  float e0 = s[0] == -INFINITY ? 0.f : expf(s[0] - m), e1 = s[1] == -INFINITY ? 0.f : expf(s[1] - m);
+  const float inv = 1.0f / care_wave_sum(e0 + e1);
+  float* o = probs + ((int64_t)r * p.heads + h) * p.nkeys;
+  if (lane < p.nkeys) o[lane] = e0 * inv;        // keys past the causal bound get exactly 0, like the reference's
+  if (lane + 64 < p.nkeys) o[lane + 64] = e1 * inv;  // softmax of -1e9-masked scores would in fp32
+}
+}  // namespace
+
+extern "C" int care_attention_probs(const float* Q, int64_t ldq, const void* K, int kv_dtype, int64_t kv_batch_stride,
+                                    int64_t kv_row_stride, int rows_per_kv, int nkeys, int causal, int seq,
+                                    const int32_t* pad_tok, int pad_stride, int pad_id, const float* bias, int bias_ld,
+                                    float* probs, int rows, int heads, void* stream) {
+  if (!Q || !K || !probs || rows <= 0 || heads <= 0 || nkeys <= 0 || nkeys > 128 || rows_per_kv <= 0) return CARE_EINVAL;
+  if (kv_dtype != CARE_F32 && kv_dtype != CARE_BF16) return CARE_EDTYPE;
+  if (causal && seq <= 0) return CARE_EINVAL;
+  AttnArgs p{};
+  p.Q = Q; p.ldq = ldq; p.K = K; p.kv_batch_stride = kv_batch_stride; p.kv_row_stride = kv_row_stride;
+  p.rows_per_kv = rows_per_kv; p.nkeys = nkeys; p.causal = causal; p.seq = seq; p.causal_off = 0;
+  p.pad_tok = pad_tok; p.pad_stride = pad_stride; p.pad_id = pad_id; p.bias = bias; p.bias_ld = bias_ld;
+  p.rows = rows; p.heads = heads;
+  const dim3 grid((rows * heads + 3) / 4), block(256);
+  if (kv_dtype == CARE_BF16) hipLaunchKernelGGL(attention_probs_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p, probs);
+  else hipLaunchKernelGGL(attention_probs_kernel<float>, grid, block, 0, (hipStream_t)stream, p, probs);
+  return care_launch_status();
+}

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void beam_advance_wave_kernel(
         // a lane without a candidate (-1) never wins; among candidates: value desc, flat index asc
         if (ol >= 0 && (bl < 0 || ov > bv || (ov == bv && of < bf))) { bv = ov; bf = of; bl = ol; }
       }
-      if (bl >= 0) {  // (fewer live candidates than beams cannot happen while topk <= beam_size)
+      if (bl >= 0) {  // no candidate left: every beam has ended (possible once topk > beam_size), see below
         sc[k] = bv; parent[k] = bl / bm; tok[k] = __shfl(col, bl, 64);
         if (lane == bl) live = false;
       }
@@ -367,9 +367,14 @@ __global__ __launch_bounds__(256) void beam_advance_wave_kernel(
     }
     ++nf;
   };
+  // topk > beam_size (need > bm): a clip can run out of live beams before `need` hypotheses have ended.
+  // The reference then keeps extending the ended beams from -1e20 rows, i.e. from a topk over exact
+  // ties whose order torch leaves unspecified (parity unpinned); here the clip simply ends with the
+  // hypotheses it has - such -1e20 continuations are never reported.
+  if (sc[0] <= -1e19f) is_done = true;
 #pragma unroll
   for (int i = 0; i < MAXBM; ++i)
-    if (i < bm && !is_done && tok[i] == eos_id) {
+    if (i < bm && !is_done && tok[i] == eos_id && sc[i] > -1e19f) {
       record(anew[i], tok[i], sc[i]);
       if (nf >= need) is_done = true;
     }

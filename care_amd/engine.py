@@ -338,13 +338,25 @@ class HipEngine:
              bias.stride(0) if bias is not None else 0, ptr(ctx), ctx.stride(0), _code(ctx), rows, self.H, tag=tag)
         return ctx
 
+    def attention_probs(self, Q, K, kv_batch_stride, kv_row_stride, rows_per_kv, nkeys, causal=False, seq=1,
+                        pad_tok=None, bias=None):
+        """[rows, H, nkeys] fp32 probabilities of one attention (auxiliary outputs of the teacher-forced
+        forward; the fused attention kernels never materialise them)."""
+        rows = Q.shape[0]
+        probs = torch.empty(rows, self.H, nkeys, device=self.device)
+        call("care_attention_probs", ptr(Q), Q.stride(0), ptr(K), _code(K), kv_batch_stride, kv_row_stride, rows_per_kv,
+             nkeys, 1 if causal else 0, seq, ptr(pad_tok), pad_tok.stride(0) if pad_tok is not None else 0, PAD,
+             ptr(bias), bias.stride(0) if bias is not None else 0, ptr(probs), rows, self.H)
+        return probs
+
     def _ctx(self, tag, rows):
         """Attention context buffer: only ever read by the output projection GEMM."""
         return self.ws(tag + "ctx", (rows, self.d), self.act_dtype)
 
-    def _mha_self_full(self, name, x, xb, seq, pad_tok, causal, tag):
+    def _mha_self_full(self, name, x, xb, seq, pad_tok, causal, tag, aux=None):
         """Self-attention sub-block over whole sequences (teacher forcing / encoder).
-        x fp32 (residual), xb its bf16 mirror or None.  Returns (x1, x1b)."""
+        x fp32 (residual), xb its bf16 mirror or None.  Returns (x1, x1b).
+        aux (dict): also the attention probabilities and the pre-residual projection (`text_context`)."""
         rows, d = x.shape
         w = self.w
         qkv = self.gemm(xb if xb is not None else x, w[name + "_qkv_w"], w[name + "_qkv_b"],
@@ -354,6 +366,10 @@ class HipEngine:
         o = self.gemm(ctx, w[name + "_o_w"], w[name + "_o_b"], self.ws(tag + "o", (rows, d)))
         x1, x1b = self.ws(tag + "x1", (rows, d)), self.wsb(tag + "x1", (rows, d))
         self.add_ln(o, x, w[name + "_g"], w[name + "_be"], x1, x1b)
+        if aux is not None:
+            aux["probs"] = self.attention_probs(qkv, qkv[:, d:], seq * 3 * d, 3 * d, seq, seq, causal=causal, seq=seq,
+                                                pad_tok=pad_tok)
+            aux["context"], aux["embs"] = o.clone(), x1.clone()
         return x1, x1b
 
     def _ffn(self, name, x, xb, out, outb, tag, gemm_tag=None, **ln_kw):
@@ -497,12 +513,18 @@ class HipEngine:
             out.append(self.gemm(src2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv, tag="cross_kv_gemm"))
         return out
 
-    LATENT_MIN_ROWS = 2048
+    LATENT_MIN_ROWS = 1
 
     def latent_for(self, rows: int) -> bool:
-        """Absorbed cross-attention for a decode over `rows` rows?  It halves the dominant HBM traffic
-        but adds two launches per step (head expand / reduce): *measured* (Base `ami`, bf16) +5% at
-        2048 rows, +13% at 16384, but -1% at 1024, -10% at 256, -15% at 32 (launch-bound)."""
+        """Absorbed cross-attention for a decode over `rows` rows?  The FORM OF THE ARITHMETIC is a
+        property of the model and its compute mode (bf16, d_model = 512: absorbed; otherwise projected
+        K/V), NOT of the batch a clip happens to be in: the two forms are two bf16 roundings of the same
+        algebra, and switching between them by row count (round 1: from 2048 rows) made a clip's
+        caption depend on the size of its batch wherever two tokens were nearly tied.  The price: the
+        absorbed form has two more launches per step, which small, launch-bound batches feel
+        (*measured* round 1: -15% at 32 rows, -1% at 1024; +5% at 2048, +13% at 16384).
+        `engine.latent = False` (CARE_LATENT=0) selects projected K/V for every size instead;
+        LATENT_MIN_ROWS > 1 restores a row threshold (tuning only)."""
         return self.latent_ok and rows >= self.LATENT_MIN_ROWS
 
     def cross_src(self, mem: torch.Tensor, rows: int):
@@ -537,7 +559,7 @@ class HipEngine:
             out.append(self.gemm(src, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv))
         return out
 
-    def _attr_block(self, li, x, xb, akv, rows_per_clip, tag):
+    def _attr_block(self, li, x, xb, akv, rows_per_clip, tag, aux=None):
         """Third post-LN attention block over the concept rows (Layers.py:139-154,218-225)."""
         w, d = self.w, self.d
         rows = x.shape[0]
@@ -549,11 +571,14 @@ class HipEngine:
         o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (rows, d)))
         y, yb = self.ws(tag + "x2a", (rows, d)), self.wsb(tag + "x2a", (rows, d))
         self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], y, yb)
+        if aux is not None:
+            aux["probs"] = self.attention_probs(q, kv, self.topk * 2 * d, 2 * d, rows_per_clip, self.topk)
         return y, yb
 
     # ------------------------------------------------------------------ teacher-forced decoder
     def decode_full(self, input_ids: torch.Tensor, mem: torch.Tensor, sem: Optional[torch.Tensor],
-                    want_logits: str = "all", sem_embs: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                    want_logits: str = "all", sem_embs: Optional[torch.Tensor] = None,
+                    want_aux: bool = False) -> Dict[str, torch.Tensor]:
         """`TransformerDecoder.forward` + `NaiveHead` on whole sequences (Lq = t).
 
         Used by feedforward_step (Framework.py:215-234) and by the stateless
@@ -580,8 +605,13 @@ class HipEngine:
         if self.attr_att and sem_embs is None:
             raise KeyError("this model attends to `semantic_embs` (use_attr_type={!r})".format(self.use_attr_type))
         akv = self.attr_kv(sem_embs, tag="tf_akv") if self.attr_att else None
+        # auxiliary outputs of TransformerDecoder.forward (Decoder/Transformer.py:239-252), on request
+        A = None
+        if want_aux:
+            A = dict(all_hidden_states=[x.clone().view(N, t, d)], intra=[], inter=[], attr=[])
         for li in range(self.n_layers):
-            x1, x1b = self._mha_self_full("d{}_sa".format(li), x, xb, t, ids32, True, "tf_")
+            a_sa = {} if want_aux else None
+            x1, x1b = self._mha_self_full("d{}_sa".format(li), x, xb, t, ids32, True, "tf_", aux=a_sa)
             nm = "d{}_ca".format(li)
             q = self.gemm(x1b if x1b is not None else x1, w[nm + "_q_w"], w[nm + "_q_b"], self.ws("tf_q", (rows, d)))
             kv = ckv[li]
@@ -590,15 +620,37 @@ class HipEngine:
             o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws("tf_o", (rows, d)))
             x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
             self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
+            if want_aux:
+                A["intra"].append(a_sa["probs"].view(N, t, self.H, t).permute(0, 2, 1, 3))
+                A["inter"].append(self.attention_probs(q, kv, Lk * 2 * d, 2 * d, per_clip * t, Lk,
+                                                       bias=w["d{}_hb".format(li)]).view(N, t, self.H, Lk).permute(0, 2, 1, 3))
+                A["text_context"], A["self_embs"] = a_sa["context"].view(N, t, d), a_sa["embs"].view(N, t, d)
+                A["context"], A["cross_embs"] = o.clone().view(N, t, d), x2.clone().view(N, t, d)
             if self.attr_att:
-                x2, x2b = self._attr_block(li, x2, x2b, akv, per_clip * t, "tf_")
+                a_at = {} if want_aux else None
+                x2, x2b = self._attr_block(li, x2, x2b, akv, per_clip * t, "tf_", aux=a_at)
+                if want_aux:
+                    A["attr"].append(a_at["probs"].view(N, t, self.H, self.topk).permute(0, 2, 1, 3))
             last = li == self.n_layers - 1
             x = torch.empty(rows, d, device=self.device) if last else self.ws("tf_x3", (rows, d))
             xb = self.wsb("tf_x3", (rows, d))
             self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, "tf_")
+            if want_aux:
+                A["all_hidden_states"].append(x.view(N, t, d) if last else x.clone().view(N, t, d))
         hidden = x.view(N, t, d)
         self._last_tf_bf16 = xb
         out = {"hidden_states": hidden}
+        if want_aux:
+            # word embeddings of the input ids, without position / LayerNorm (get_sentence_embeddings, :107-116)
+            sent = torch.empty(rows, d, device=self.device)
+            self._call_rows("care_gather_rows", w["word"], sent, ids32.view(rows), rows)
+            out.update(all_hidden_states=A["all_hidden_states"], all_intra_attentions=tuple(A["intra"]),
+                       all_inter_attentions=tuple(A["inter"]), attention_probs=A["inter"][-1].mean(1),
+                       context=A["context"], text_context=A["text_context"], self_embs=A["self_embs"],
+                       cross_embs=A["cross_embs"], input_embs=A["all_hidden_states"][0],
+                       input_embs_exclude_bos=A["all_hidden_states"][0][:, 1:, :], sentence_embs=sent.view(N, t, d))
+            if self.opt.get("use_attr"):
+                out.update(attr_attention_probs=tuple(A["attr"]), gate_probs=())
         if want_logits == "all":
             out["logits"] = self.gemm(xb if xb is not None else x, w["vocab"], None,
                                       torch.empty(rows, self.V, device=self.device)).view(N, t, self.V)

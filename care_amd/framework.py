@@ -348,10 +348,15 @@ class TransformerSeq2Seq(nn.Module):
         if isinstance(mem, list):
             assert len(mem) == 1
             mem = mem[0]
+        # The auxiliary entries of the reference's decoder dict (attention probabilities, contexts,
+        # intermediate embeddings: Decoder/Transformer.py:239-252; read by regularisers and notebooks,
+        # never by decoding) come with every full-sequence call, like there; the per-step calls of a
+        # decode loop (last_time_step_logits) skip them unless asked (`output_auxiliary=True`).
+        aux = kwargs.get("output_auxiliary", not last_time_step_logits)
         with torch.no_grad():
             return self.engine().decode_full(input_ids, mem, inputs_for_decoder.get("semantic_hidden_states"),
                                              want_logits="last" if last_time_step_logits else "all",
-                                             sem_embs=inputs_for_decoder.get("semantic_embs"))
+                                             sem_embs=inputs_for_decoder.get("semantic_embs"), want_aux=bool(aux))
 
     def feedforward_step(self, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
         enc = self.encoding_phase(batch["feats"], **kwargs)

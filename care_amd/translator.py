@@ -62,8 +62,8 @@ class Translator_ARFormer(object):
         return hyps, scores
 
     def _beam(self, engine, feats, use_graph=True):
-        if self.topk > self.beam_size:
-            raise ValueError("topk > beam_size is not supported")
+        # Beam.specific_nums_of_sents = max(size, topk) (Beam.py:10): with topk > beam_size a clip keeps
+        # decoding until topk hypotheses have ended (or max_len)
         need = max(self.beam_size, self.topk)
         _, nfin, fscore, flen, fhyp = engine.translate_beam(list(feats), self.beam_size, need, use_graph=use_graph,
                                                              lean=True)

@@ -363,6 +363,20 @@ int care_beam_advance(const float* cand_val, const int32_t* cand_idx, float* sco
                       int eos_id, int V, int stride, int B, void* stream);
 
 /*
+ * care_attention_probs: the attention probabilities [rows, heads, nkeys] fp32 of one attention
+ *   (scale 1/8, key-padding mask -> -1e9, then the optional per-head/per-key bias, softmax) - the
+ *   `attention_probs` entries of the dict TransformerDecoder.forward returns
+ *   (models/Decoder/Transformer.py:239-252, Attention.py:104-118).  Off the decode path: the fused
+ *   kernels never materialise them; this is for the teacher-forced forward's auxiliary outputs.
+ *   Q fp32 [rows, heads * 64]; K as in care_attention (no ancestor table); causal as there.
+ */
+int care_attention_probs(const float* Q, int64_t ldq, const void* K, int kv_dtype,
+                         int64_t kv_batch_stride, int64_t kv_row_stride, int rows_per_kv, int nkeys,
+                         int causal, int seq, const int32_t* pad_tok, int pad_stride, int pad_id,
+                         const float* bias, int bias_ld, float* probs, int rows, int heads,
+                         void* stream);
+
+/*
  * Active-set compaction of the decode loop (csrc/compact.hip).  The reference ends a batch when every
  * instance is done and removes finished instances from every cached tensor at each step
  * (models/Translator.py:77-81,194-209); here the loop runs in segments and compacts between them.

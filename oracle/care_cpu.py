@@ -56,7 +56,7 @@ def _split_heads(x: torch.Tensor, n_heads: int) -> torch.Tensor:
 
 
 def attention_block(P, prefix: str, opt: dict, x: torch.Tensor, memory: Optional[torch.Tensor],
-                    mask: Optional[torch.Tensor]) -> torch.Tensor:
+                    mask: Optional[torch.Tensor], aux: Optional[dict] = None) -> torch.Tensor:
     """Post-LN multi-head attention sub-block.
 
     `MultiHeadAttention.forward` (models/components/SubLayers.py:40-81) around
@@ -79,8 +79,11 @@ def attention_block(P, prefix: str, opt: dict, x: torch.Tensor, memory: Optional
     probs = torch.softmax(scores, dim=-1)
     ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).contiguous()
     ctx = ctx.view(ctx.shape[0], ctx.shape[1], -1)
-    out = _linear(P, prefix + ".dense", ctx) + x
-    return _layer_norm(P, prefix + ".LayerNorm", out, opt["layer_norm_eps"])
+    context = _linear(P, prefix + ".dense", ctx)  # SubLayers.py:69-70 `context` (dropout is identity)
+    out = _layer_norm(P, prefix + ".LayerNorm", context + x, opt["layer_norm_eps"])
+    if aux is not None:
+        aux.update(probs=probs, context=context, embs=out)
+    return out
 
 
 def ffn_block(P, prefix: str, opt: dict, x: torch.Tensor) -> torch.Tensor:
@@ -193,7 +196,8 @@ def decoder_embeddings(P, opt: dict, input_ids: torch.Tensor,
     return _layer_norm(P, "decoder.embedding.LayerNorm", e, opt["layer_norm_eps"])
 
 
-def decoder_forward(P, opt: dict, input_ids: torch.Tensor, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
+def decoder_forward(P, opt: dict, input_ids: torch.Tensor, inputs: Dict[str, torch.Tensor],
+                    aux: Optional[dict] = None) -> torch.Tensor:
     """`TransformerDecoder.forward` (models/Decoder/Transformer.py:161-268), ARFormer branch.
 
     Self-attention mask = key is PAD OR strictly-future (:169-174); cross mask all-False
@@ -206,26 +210,42 @@ def decoder_forward(P, opt: dict, input_ids: torch.Tensor, inputs: Dict[str, tor
     self_mask = key_pad | causal
     h = decoder_embeddings(P, opt, input_ids, inputs.get("semantic_hidden_states"))
     memory = inputs["encoder_hidden_states"]
+    if aux is not None:  # the other entries of the dict at Decoder/Transformer.py:239-252
+        aux.update(all_hidden_states=[h], all_intra_attentions=(), all_inter_attentions=(), attr_attention_probs=(),
+                   input_embs=h, input_embs_exclude_bos=h[:, 1:, :],
+                   sentence_embs=P["decoder.embedding.word_embeddings.weight"][input_ids])
     for li in range(opt["num_hidden_layers_decoder"]):
         lp = "decoder.layers.{}".format(li)
-        h = attention_block(P, lp + ".intra_attention", opt, h, None, self_mask)
-        h = attention_block(P, lp + ".inter_attention", opt, h, memory, None)
+        a1, a2, a3 = ({}, {}, {}) if aux is not None else (None, None, None)
+        h = attention_block(P, lp + ".intra_attention", opt, h, None, self_mask, a1)
+        h = attention_block(P, lp + ".inter_attention", opt, h, memory, None, a2)
         if (lp + ".attr_attention.dense.weight") in P:
             # CABase, attr_layer_pos = 'cross2attr' (Layers.py:139-154,218-225): a third post-LN
             # attention block whose keys/values are the concept embeddings, no mask
             assert opt.get("attr_layer_pos", "cross2attr") == "cross2attr"
-            h = attention_block(P, lp + ".attr_attention", opt, h, inputs["semantic_embs"], None)
+            h = attention_block(P, lp + ".attr_attention", opt, h, inputs["semantic_embs"], None, a3)
         h = ffn_block(P, lp + ".ffn", opt, h)
+        if aux is not None:
+            aux["all_hidden_states"].append(h)
+            aux["all_intra_attentions"] += (a1["probs"],)
+            aux["all_inter_attentions"] += (a2["probs"],)
+            aux.update(text_context=a1["context"], self_embs=a1["embs"], context=a2["context"], cross_embs=a2["embs"])
+            if a3:
+                aux["attr_attention_probs"] += (a3["probs"],)
+    if aux is not None:
+        aux["attention_probs"] = aux["all_inter_attentions"][-1].mean(1)
     return h
 
 
 def decoding_phase(P, opt: dict, input_ids: torch.Tensor, inputs: Dict[str, torch.Tensor],
-                   last_time_step_logits: bool = False) -> Dict[str, torch.Tensor]:
-    """`TransformerSeq2Seq.decoding_phase` (Framework.py:240-269) + `NaiveHead` (Head.py:26-32)."""
-    hidden = decoder_forward(P, opt, input_ids, inputs)
+                   last_time_step_logits: bool = False, auxiliary: bool = False) -> Dict[str, torch.Tensor]:
+    """`TransformerSeq2Seq.decoding_phase` (Framework.py:240-269) + `NaiveHead` (Head.py:26-32).
+    auxiliary: also the decoder's other dict entries (Decoder/Transformer.py:239-252)."""
+    aux = {} if auxiliary else None
+    hidden = decoder_forward(P, opt, input_ids, inputs, aux)
     w = P["cls_head.tgt_word_prj.weight"]
     logits = F.linear(hidden[:, -1, :], w) if last_time_step_logits else F.linear(hidden, w)
-    return {"hidden_states": hidden, "logits": logits}
+    return {**(aux or {}), "hidden_states": hidden, "logits": logits}
 
 
 def inputs_for_decoder(opt: dict, enc: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -238,10 +258,11 @@ def inputs_for_decoder(opt: dict, enc: Dict[str, torch.Tensor]) -> Dict[str, tor
     return {k: enc[k] for k in keys}
 
 
-def feedforward_step(P, opt: dict, feats: List[torch.Tensor], input_ids: torch.Tensor) -> Dict[str, torch.Tensor]:
+def feedforward_step(P, opt: dict, feats: List[torch.Tensor], input_ids: torch.Tensor,
+                     auxiliary: bool = False) -> Dict[str, torch.Tensor]:
     """Teacher-forced forward, `Seq2SeqBase.feedforward_step` (Framework.py:215-234)."""
     enc = encoding_phase(P, opt, feats)
-    dec = decoding_phase(P, opt, input_ids, inputs_for_decoder(opt, enc), last_time_step_logits=False)
+    dec = decoding_phase(P, opt, input_ids, inputs_for_decoder(opt, enc), last_time_step_logits=False, auxiliary=auxiliary)
     return {**enc, **dec}
 
 

@@ -24,6 +24,7 @@ from oracle.ref_import import import_reference
 OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 EOS_ROW, PAD_ROW = 3, 0
+AUX_POS = [0, 5, 28]  # positions of clip 0 whose auxiliary decoder outputs are stored
 VOCAB_W = "cls_head.tgt_word_prj.weight"
 
 # "Peaked" cases: 40 frequent-word rows of the vocabulary projection are scaled by 12 and the EOS
@@ -51,6 +52,7 @@ CASES = [
     ("base_ami_mte_b2", "base_ami_mte", 2, 22, {}, {}),
     ("msrvtt_cabase_b3", "msrvtt_cabase", 3, 23, {}, {VOCAB_W: {EOS_ROW: 4.0}}),
     ("msrvtt_cabase_beam5_b2", "msrvtt_cabase", 2, 24, {"beam_size": 5}, {VOCAB_W: {EOS_ROW: 3.5}}),
+    ("msrvtt_care_beam5_topk8_b4", "msrvtt_care_beam5", 4, 15, {"topk": 8}, {VOCAB_W: {EOS_ROW: 4.0, PAD_ROW: 3.0}}),
     ("msrvtt_base_ami_peaked_b4", "msrvtt_base_ami", 4, 189, {}, PEAKED),
     ("msrvtt_care_peaked_b3", "msrvtt_care", 3, 373, {}, PEAKED),
     ("msrvtt_care_peaked_beam5_b3", "msrvtt_care_beam5", 3, 373, {}, PEAKED),
@@ -105,6 +107,16 @@ def run_case(get_framework, get_translator, name, cfg, B, seed, overrides, row_s
         top = logits.topk(8, dim=-1)
         rec["tf_logits_top8_val"] = top[0].numpy()
         rec["tf_logits_top8_idx"] = top[1].numpy().astype(np.int32)
+        # the decoder's auxiliary dict entries (Decoder/Transformer.py:239-252), clip 0, a few positions
+        pos = AUX_POS
+        rec["aux_attention_probs"] = out["attention_probs"][0].numpy()                    # [t, Lk] (mean over heads)
+        rec["aux_intra_attention"] = out["all_intra_attentions"][-1][0].numpy()           # [H, t, t]
+        rec["aux_inter_attention"] = out["all_inter_attentions"][-1][0][:, pos].numpy()   # [H, 3, Lk]
+        for k in ("context", "text_context", "self_embs", "cross_embs", "input_embs", "sentence_embs"):
+            rec["aux_" + k] = out[k][0][pos].numpy()                                      # [3, d]
+        rec["aux_n_hidden_states"] = np.int64(len(out["all_hidden_states"]))
+        if opt.get("use_attr") and len(out.get("attr_attention_probs", ())):
+            rec["aux_attr_attention"] = out["attr_attention_probs"][-1][0][:, pos].numpy()
 
         # metrics step with the reference's OWN criteria (misc/Crit/crit_lang.py, crit_attribute.py)
         from misc.Crit.crit_attribute import NoisyOrMIL

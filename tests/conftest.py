@@ -29,7 +29,17 @@ class GoldenCase:
         self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
         self.meta = json.loads(str(self.z["meta_json"]))
 
+    _built = {}
+
     def build(self):
+        """(opt, state dict, feats, input_ids) regenerated from the seeds - memoised per fixture: the
+        portable generator costs seconds per model and a dozen tests ask for the same one."""
+        if self.name not in GoldenCase._built:
+            GoldenCase._built[self.name] = self._build()
+        opt, P, feats, ids = GoldenCase._built[self.name]
+        return dict(opt), dict(P), list(feats), ids
+
+    def _build(self):
         import torch  # noqa: F401
         from care_amd.configs import feat_shapes, make_opt
         from care_amd.synth import synth_feats, synth_input_ids, synth_state_dict, tensor_sha256

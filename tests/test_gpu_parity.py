@@ -62,6 +62,24 @@ def test_teacher_forced_fp32(golden):
     assert np.array_equal(top[1].cpu().numpy(), z["tf_logits_top8_idx"])
 
 
+def test_decoder_auxiliary_outputs_fp32(golden):
+    """feedforward_step returns the reference decoder's whole dict (Decoder/Transformer.py:239-252):
+    attention probabilities of every block, pre-residual contexts, intermediate embeddings."""
+    from test_oracle_golden import check_auxiliary
+
+    opt, P, feats, ids = golden.build()
+    out = _model(opt, P).feedforward_step({"feats": _dev(feats), "input_ids": ids.to("cuda:0")})
+    check_auxiliary(out, golden.z, lambda a, b: np.testing.assert_allclose(a.detach().float().cpu().numpy(), b, rtol=0, atol=2e-5))
+    pr = out["all_inter_attentions"][-1]
+    assert pr.shape == (ids.shape[0], opt["num_attention_heads"], ids.shape[1], out["attention_probs"].shape[2])
+    assert float((pr.sum(-1) - 1).abs().max()) < 1e-5
+    # a decode-loop style call skips them unless asked
+    model = _model(opt, P)
+    enc = model.encoding_phase(_dev(feats))
+    step = model.decoding_phase(ids[:, :3].to("cuda:0"), model.prepare_inputs_for_decoder(enc, {}), last_time_step_logits=True)
+    assert "attention_probs" not in step and step["logits"].shape == (ids.shape[0], opt["vocab_size"])
+
+
 def test_translate_batch_fp32(golden):
     from care_amd import get_translator
 
@@ -148,8 +166,8 @@ def test_greedy_bf16_matches_up_to_near_ties(golden, absorbed):
     CLEAR_MARGIN (fixture `gap_select`) must come out bit-exact - that is every clip of the `peaked`
     fixtures; any other divergence must start at a step where the oracle's own top-1/top-2 log-prob
     margin is below GREEDY_TIE_TOL (random-init logits are nearly flat).  Both forms of the
-    cross-attention: projected K/V (what these small batches use by default) and the absorbed form
-    (engine.latent_for, forced here by dropping its row threshold)."""
+    cross-attention: the absorbed form (the default wherever the model allows it) and projected K/V
+    (`engine.latent = False`)."""
     from care_amd import get_translator
     from oracle import care_cpu
 
@@ -158,10 +176,9 @@ def test_greedy_bf16_matches_up_to_near_ties(golden, absorbed):
         pytest.skip("greedy audit")
     model = _model(opt, P, "bf16")
     eng = model.engine()
-    if absorbed:
-        if not eng.latent_capable:
-            pytest.skip("absorbed cross-attention covers d_model = 512 only")
-        eng.LATENT_MIN_ROWS = 1
+    if absorbed and not eng.latent_capable:
+        pytest.skip("absorbed cross-attention covers d_model = 512 only")
+    eng.latent = absorbed  # the default is the absorbed form wherever the model allows it, at every batch size
     assert eng.latent_for(feats[0].shape[0]) == absorbed
     hyps, scores = get_translator(opt).translate_batch([model], {"feats": _dev(feats)})
     ref_hyps, ref_scores = golden.hyps()
@@ -203,10 +220,9 @@ def test_beam_bf16_vs_oracle(golden, absorbed, use_graph):
         pytest.skip("beam audit")
     model = _model(opt, P, "bf16")
     eng = model.engine()
-    if absorbed:
-        if not eng.latent_capable:
-            pytest.skip("absorbed cross-attention covers d_model = 512 only")
-        eng.LATENT_MIN_ROWS = 1
+    if absorbed and not eng.latent_capable:
+        pytest.skip("absorbed cross-attention covers d_model = 512 only")
+    eng.latent = absorbed
     dev = _dev(feats)
     tr = get_translator(opt)
     for _ in range(3 if use_graph else 1):  # first sight (eager), capture, replay
@@ -291,10 +307,15 @@ def test_bench_under_torchrun_with_rccl():
     import subprocess
     import sys
 
+    import socket
+
+    with socket.socket() as sk:  # a free port: two test runs may share a host
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CARE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
            "--warmup", "2", "--batch", "256", "--no-cpu-baseline", "--no-legs"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -10,6 +10,16 @@ import torch
 from oracle import care_cpu
 
 ATOL = 1e-6
+_FF = {}
+
+
+def _feedforward(golden):
+    """The oracle's teacher-forced forward with every auxiliary output, once per fixture."""
+    if golden.name not in _FF:
+        opt, P, feats, ids = golden.build()
+        with torch.no_grad():
+            _FF[golden.name] = care_cpu.feedforward_step(P, opt, feats, ids, auxiliary=True)
+    return _FF[golden.name]
 
 
 def _close(a, b, atol=ATOL):
@@ -41,8 +51,7 @@ def test_encoding_phase_matches_reference(golden):
 def test_teacher_forced_forward_matches_reference(golden):
     opt, P, feats, ids = golden.build()
     z = golden.z
-    with torch.no_grad():
-        out = care_cpu.feedforward_step(P, opt, feats, ids)
+    out = _feedforward(golden)
     assert np.array_equal(ids.numpy(), z["tf_input_ids"])
     n = z["tf_hidden_states"].shape[0]
     _close(out["hidden_states"][:n], z["tf_hidden_states"])
@@ -103,3 +112,30 @@ def test_score_hypothesis_reproduces_the_beam_scores(golden):
     for i in range(min(2, len(ref_hyps))):
         one = {k: v[i:i + 1] for k, v in inputs.items()}
         assert abs(care_cpu.score_hypothesis(P, opt, one, ref_hyps[i][0]) - ref_scores[i][0]) < 2e-5
+
+
+AUX_POS = [0, 5, 28]
+
+
+def check_auxiliary(out, z, close):
+    """The auxiliary entries of the decoder dict (models/Decoder/Transformer.py:239-252) against the
+    fixture: attention probabilities, pre-residual contexts, intermediate embeddings (clip 0)."""
+    for k in ("hidden_states", "all_hidden_states", "all_intra_attentions", "all_inter_attentions", "attention_probs",
+              "context", "text_context", "self_embs", "cross_embs", "input_embs", "input_embs_exclude_bos", "sentence_embs"):
+        assert k in out, k
+    assert len(out["all_hidden_states"]) == int(z["aux_n_hidden_states"])
+    t = z["aux_attention_probs"].shape[0]
+    assert tuple(out["attention_probs"].shape[1:]) == z["aux_attention_probs"].shape
+    assert tuple(out["input_embs_exclude_bos"].shape[1:]) == (t - 1, out["input_embs"].shape[2])
+    close(out["attention_probs"][0], z["aux_attention_probs"])
+    close(out["all_intra_attentions"][-1][0], z["aux_intra_attention"])
+    close(out["all_inter_attentions"][-1][0][:, AUX_POS], z["aux_inter_attention"])
+    for k in ("context", "text_context", "self_embs", "cross_embs", "input_embs", "sentence_embs"):
+        close(out[k][0][AUX_POS], z["aux_" + k])
+    if "aux_attr_attention" in z:
+        close(out["attr_attention_probs"][-1][0][:, AUX_POS], z["aux_attr_attention"])
+        assert out["gate_probs"] == () if "gate_probs" in out else True
+
+
+def test_decoder_auxiliary_outputs_match_reference(golden):
+    check_auxiliary(_feedforward(golden), golden.z, lambda a, b: _close(a, b, atol=2e-6))

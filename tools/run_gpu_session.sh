@@ -1,5 +1,2 @@
-mkdir -p gpurun_out/r2g
-timeout 900 python bench.py > gpurun_out/r2g/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/r2g/bench.log | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step']); print(json.dumps(d.get('legs'), indent=1))"
-tail -5 gpurun_out/r2g/bench.log | cut -c1-400
+mkdir -p gpurun_out/r2h
+timeout 2400 python -m pytest tests -m gpu -q --maxfail=15 > gpurun_out/r2h/t_all.log 2>&1; echo "all gpu tests rc=$?"; tail -25 gpurun_out/r2h/t_all.log
