@@ -34,7 +34,7 @@
 
 #include "care_common.h"
 
-// Ablation builds only (tools/gemm_bench.py): -DCARE_AS_DBG=<bits> 1 no stores, 2 no MFMA, 4 no W DMA,
+// Ablation builds only (tools/gemm_bench.py): -DCARE_AS_DBG=<bits> 1 no stores, 2 no MFMA, 4 no W DMA, 16 no argmax statistics, 32 no B-fragment LDS reads,
 // 8 no A loads.  Compile-time so that the shipped kernel carries no debug branches.
 #ifndef CARE_AS_DBG
 #define CARE_AS_DBG 0
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   // B fragments are read BDEPTH k-steps ahead of the MFMAs that use them: one ds_read_b128 has
   // ~130+ cycles of latency but feeds only 32 cycles of MFMA, so a shallow prefetch leaves the
   // loop LDS-latency-bound (measured: ~2600 cycles per tile instead of ~600).
-  constexpr int BDEPTH = IS_ARGMAX ? 6 : 8;  // the argmax modes need the 8 registers (they would spill)
+  constexpr int BDEPTH = IS_ARGMAX ? 4 : 8;  // the argmax modes need the registers (running max, index, sum, reference: they would spill)
   // chunk (ks*4 + fg) ^ fr  ==  (ks & ~3)*4 + ((ks & 3) ^ (fr >> 2))*4 + (fg ^ (fr & 3)): per lane
   // only FOUR distinct byte offsets (r = ks & 3) plus the compile-time 256 * (ks >> 2).
   int boff[4];
@@ -277,13 +277,13 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
   };
 
   // running (max, argmax, sum-exp) of the 8 rows this lane sees, over its column residue
-  float rm[8], rs[8], rl[HAS_LAB ? 8 : 1];
+  float rm[8], rs[8], rref[IS_ARGMAX ? 8 : 1], rl[HAS_LAB ? 8 : 1];
   int ri[8], lab[HAS_LAB ? 8 : 1];
   if constexpr (IS_ARGMAX) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       // finite sentinel, not -inf: an update with a masked (-inf) logit then gives exp(-inf) = 0, not NaN
-      rm[i] = -1e30f; rs[i] = 0.f; ri[i] = 0x7fffffff;
+      rm[i] = -1e30f; rs[i] = 0.f; ri[i] = 0x7fffffff; rref[i] = -1e30f;
       const int row = min(m0 + (i >> 2) * 16 + fg * 4 + (i & 3), p.M - 1);
       if constexpr (HAS_LAB) { rl[i] = -INFINITY; lab[i] = p.labels ? p.labels[row] : -1; }
     }
@@ -357,17 +357,43 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
 
   // online (max, sum-exp) of logit i (= m-tile i>>2, register i&3) of a finished tile, with ONE exp
   // per logit: e = exp(-|m - v|) is the rescale factor when v is the new max and the new term otherwise
+  // Per logit: the exact running maximum and its column (compare, select, max), and the sum of
+  // exponentials against a LAZY reference rref (subtract, exp, add): 5 vector instructions and one exp,
+  // no branch, instead of the 13 + 1 of the textbook online softmax (select-heavy: its new maximum
+  // rescales the sum every time).  The statistics cost more issue cycles than the 32 MFMAs of a tile,
+  // so this is what sets the kernel's matrix-pipe occupancy.  rref is looked after ONCE PER TILE
+  // (argmax_ref): set from the first tile's logits, moved - with the sum rescaled - when the running
+  // maximum has got more than 20 ahead of it (e^20 per term is far from fp32 overflow; a row whose
+  // logits jump by more than 88 inside one tile would overflow the sum: the final merge then falls
+  // back to max-only, which is what such a sum equals in fp32 anyway).
   auto argmax_one = [&](const f32x4 (&av)[2], int c0, int i) {
     const float v0 = c0 < p.N ? av[i >> 2][i & 3] : -INFINITY;
-    const bool up = v0 > rm[i];
-    const float mn = up ? v0 : rm[i];
-    const float e = __expf((up ? rm[i] : v0) - mn);
-    rs[i] = up ? fmaf(rs[i], e, 1.0f) : rs[i] + e;
-    ri[i] = up ? c0 : ri[i];
-    rm[i] = mn;
+    ri[i] = v0 > rm[i] ? c0 : ri[i];
+    rm[i] = fmaxf(rm[i], v0);
+    rs[i] += __expf(v0 - rref[i]);  // a masked (-inf) logit adds exp(-inf) = 0
     if constexpr (HAS_LAB) rl[HAS_LAB ? i : 0] = c0 == lab[HAS_LAB ? i : 0] ? v0 : rl[HAS_LAB ? i : 0];
   };
-  auto argmax_update = [&](const f32x4 (&av)[2], int tile) {
+  // before the statistics of a tile: first tile -> the reference is the tile's own logit; later ->
+  // wave-uniform test whether any running maximum has left its reference behind (rare)
+  auto argmax_ref = [&](const f32x4 (&av)[2], bool first) {
+    if (first) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rref[i] = fmaxf(av[i >> 2][i & 3], -1e30f);
+      return;
+    }
+    float far = rm[0] - rref[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) far = fmaxf(far, rm[i] - rref[i]);
+    if (__builtin_amdgcn_ballot_w64(far > 20.0f) != 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        rs[i] *= __expf(rref[i] - rm[i]);
+        rref[i] = rm[i];
+      }
+    }
+  };
+  auto argmax_update = [&](const f32x4 (&av)[2], int tile, bool first) {
+    argmax_ref(av, first);
     const int c0 = tile * TILE_N + fr;
 #pragma unroll
     for (int i = 0; i < 8; ++i) argmax_one(av, c0, i);
@@ -385,19 +411,25 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
     bf16x8 fb[BDEPTH];
 #pragma unroll
     for (int ks = 0; ks < BDEPTH; ++ks)
-      if (FULL || ks < ksn) fb[ks] = *reinterpret_cast<const bf16x8*>(sb + boff[ks & 3] + (ks >> 2) * 256);
+      if (FULL || ks < ksn) {
+        if (CARE_AS_DBG & 32) { fb[ks] = bf16x8{}; asm volatile("" : "+v"(fb[ks])); }
+        else fb[ks] = *reinterpret_cast<const bf16x8*>(sb + boff[ks & 3] + (ks >> 2) * 256);
+      }
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       if (FULL || ks < ksn) {
         const bf16x8 b = fb[ks % BDEPTH];
-        if (ks + BDEPTH < 16 && (FULL || ks + BDEPTH < ksn))
+        if (ks + BDEPTH < 16 && (FULL || ks + BDEPTH < ksn) && !(CARE_AS_DBG & 32))
           fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff[(ks + BDEPTH) & 3] + ((ks + BDEPTH) >> 2) * 256);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], b, acc[1], 0, 0, 0);
+        if (CARE_AS_DBG & 2) asm volatile("" :: "v"(b));
+        else {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], b, acc[1], 0, 0, 0);
+        }
       }
-      if (ks & 1) argmax_one(accp, c0, ks >> 1);
+      if ((ks & 1) && !(CARE_AS_DBG & 16)) argmax_one(accp, c0, ks >> 1);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -480,13 +512,14 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
       n_st = store_tile(t, bv);
     } else if constexpr (HAS_LAB) {  // 16 more live registers: no room for a second accumulator pair
       compute(slot);
-      argmax_update(acc, t);
+      argmax_update(acc, t, t == t0);
     } else if constexpr (IS_COLLECT) {
       // appends are rare extra VM operations: the counted waits then over-wait (never under-wait)
       compute(slot);
       collect(acc, t);
     } else {
       // iteration 0 has no previous tile: a column index past N masks the dummy statistics (no branch)
+      if (it > 0) argmax_ref(accp, it == 1);
       compute_woven(slot, it > 0 ? t - 1 : (1 << 26));
       accp[0] = acc[0]; accp[1] = acc[1];
     }
@@ -498,10 +531,13 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
 
   if constexpr (IS_COLLECT) collect_flush();
   if constexpr (IS_ARGMAX) {
-    if constexpr (!HAS_LAB) argmax_update(accp, t1 - 1);  // the last tile's statistics
+    if constexpr (!HAS_LAB) argmax_update(accp, t1 - 1, t1 - t0 == 1);  // the last tile's statistics
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      float m = rm[i], s = rs[i], lv = HAS_LAB ? rl[HAS_LAB ? i : 0] : 0.f;
+      // the sum relative to the true maximum (rows that saw no logit: rm = rref = -1e30, s = 0)
+      float m = rm[i], lv = HAS_LAB ? rl[HAS_LAB ? i : 0] : 0.f;
+      float s = rs[i] > 0.f ? rs[i] * __expf(rref[IS_ARGMAX ? i : 0] - rm[i]) : 0.f;
+      if (!(s < 3.0e38f)) s = 1.0f;  // the sum overflowed (a > 88 jump inside one tile): it is its largest term
       int id = ri[i];
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) {
@@ -617,6 +653,11 @@ extern "C" int care_argmax_parts_bf16_min(int M, int N, int min_parts) {
   return pick_ns_min((M + 127) / 128, (N + TILE_N - 1) / TILE_N, min_parts);
 }
 
+// the 256-row-panel kernel for large row counts (csrc/gemm_vocab.hip)
+extern "C" int care_vocab32_applies(int M, int N, int K, int a_dtype, int has_labels);
+extern "C" int care_vocab32_launch(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
+                                   int M, int N, int ns, void* stream);
+
 static int gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax, int32_t* pidx,
                            float* psum, const int32_t* labels, float* plab, int M, int N, int K, int min_parts,
                            void* stream) {
@@ -630,6 +671,9 @@ static int gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void*
   p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.labels = labels; p.plab = plab;
   p.panels = (M + 127) / 128;
   p.ns = pick_ns_min(p.panels, (N + TILE_N - 1) / TILE_N, min_parts);
+  // same number of column ranges (care_argmax_parts_bf16*), 256-row panels: half the W streaming
+  if (care_vocab32_applies(M, N, K, a_dtype, labels != nullptr))
+    return care_vocab32_launch(A, lda, W, pmax, pidx, psum, M, N, p.ns, stream);
   const int blocks = plan_stream(p, false);
   hipStream_t st = (hipStream_t)stream;
   if (labels && plab)

@@ -1,0 +1,230 @@
+// gemm_vocab.hip - the greedy vocabulary projection at large row counts:
+//     per row  (max, argmax, sum-exp)  of  hidden [M, 512] bf16  x  W^T [512, V] bf16   (Head.py:26-32 +
+//     log_softmax + top-1: Translator.py:127, Beam.py:58-70), the [M, V] logits never stored.
+//
+// Why a second kernel beside gemm_as.hip's STREAM_ARGMAX mode.  Ablation of that kernel at M = 32768
+// (tools/as_ablate.sh, round 2): 381 us in all; with the MFMAs, the statistics AND the B-fragment reads
+// removed it still takes 177 us - the time to stream W from L2 into LDS: every 128-row panel sweeps
+// the whole 10.8 MB, 2.76 GB per launch at the ~16 TB/s the L2 -> LDS path gives (65 GB/s per CU),
+// i.e. 128 flop per streamed byte caps the kernel at 2 PFLOP/s before any arithmetic happens.  MFMA
+// issue (32 x 16x16x32 per 16-column tile), 13-instruction-per-logit statistics over 8 rows per lane
+// and the fragment reads then ADD to that instead of hiding in it (114 + 62 + 76 us).  Here:
+//   * a workgroup is 8 waves x 32 rows = a 256-row panel: W is streamed half as often (256 flop/B);
+//   * W tiles are 32 columns x 512 k (32 KiB) through a 4-slot LDS ring, three in flight, one barrier
+//     per tile = per 1024 MFMA cycles of every wave;
+//   * v_mfma_f32_32x32x16_bf16 with the operands swapped (D = (X W^T)^T): half the MFMA instructions
+//     per flop, and a lane ends up with 16 columns of ONE row, so the running statistics of a row are
+//     four registers in one lane (maximum, its column, sum of exponentials, the sum's lazy reference)
+//     instead of 8 rows x 3 registers per lane: maximum by v_max3 over the tile, ONE compare per tile
+//     for "new maximum?" (the column search sits in a rarely taken branch), sub / exp / add per logit;
+//   * the statistics of tile t are woven between the MFMAs of tile t + 1 (order pinned per k-step);
+//   * the last tile of a range is simply fetched again past the end (constant vmcnt arithmetic).
+// Used by care_gemm_argmax_bf16 for bf16 A, K = 512, M >= 8192 without label logits; everything else
+// (and the beam-search / scoring variants) stays on gemm_as.hip.
+#include <cstdlib>
+#include <type_traits>
+
+#include "care_common.h"
+
+namespace {
+
+constexpr int VT_N = 32;                 // columns per W tile
+constexpr int VT_BYTES = VT_N * 1024;    // K = 512 bf16
+constexpr int V_RING = 4, V_AHEAD = 3;
+constexpr int V_LDS = V_RING * VT_BYTES;
+constexpr int V_ROWS = 256;              // rows per workgroup (8 waves x 32)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct VArgs {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* W;
+  float* pmax; int32_t* pidx; float* psum;
+  int M, N, ns, panels, total_items;
+};
+
+#ifndef CARE_V32_DBG
+#define CARE_V32_DBG 0  // ablation: 2 no MFMA, 16 no statistics, 32 no fragment reads
+#endif
+
+template <int BDEPTH>
+__global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_total = (p.N + VT_N - 1) / VT_N;
+  const int tpb = (tiles_total + p.ns - 1) / p.ns;
+
+  for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+    const int range = item % p.ns, panel = item / p.ns;
+    const int t0 = range * tpb, t1 = min(t0 + tpb, tiles_total);
+    const int m0 = panel * V_ROWS + wave * 32;
+    const int row = m0 + r;
+    if (t0 >= t1) {  // empty range (ns does not divide the tile count evenly)
+      if (h == 0 && row < p.M) {
+        const int64_t o = (int64_t)row * p.ns + range;
+        p.pmax[o] = -INFINITY; p.pidx[o] = 0x7fffffff; p.psum[o] = 0.f;
+      }
+      continue;
+    }
+    // every wave is done reading the ring of the previous item
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- W tile -> ring slot: wave w copies rows 4w .. 4w + 3 of the 32 (one 1-KiB row per DMA
+    // instruction); lane = chunk slot, source chunk = slot ^ (row & 15): conflict-free ds_read_b128
+    const unsigned char* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wrow[i] = reinterpret_cast<const unsigned char*>(p.W) + ((lane ^ ((wave * 4 + i) & 15)) << 4);
+    auto stage = [&](int tile, int slot) {
+      tile = min(tile, t1 - 1);  // past the end: the last tile again, into a slot nobody will read
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = min(tile * VT_N + wave * 4 + i, p.N - 1);  // ragged last tile: clamp to the last W row
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + (int64_t)n * 1024),
+                                         (__attribute__((address_space(3))) void*)(smem + slot * VT_BYTES + (wave * 4 + i) * 1024),
+                                         16, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < V_AHEAD; ++i) stage(t0 + i, i);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- activations of this wave's 32 rows, whole K, resident: fragment ks = X[row][16 ks + 8 h + (0..7)]
+    bf16x8 a[32];
+    const bf16_t* arow = p.A + (int64_t)min(row, p.M - 1) * p.lda + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // per-lane W fragment offset: row r of the tile, chunk (2 ks + h) ^ (r & 15); the ks part is an
+    // XOR of the low four chunk bits with (2 ks & 15) and an add of 256 per 8 k-steps
+    const int bswz = r * 1024;
+    auto boff = [&](int ks) { return bswz + ((((2 * ks + h) ^ (r & 15)) & 15) << 4) + ((2 * ks) >> 4) * 256; };
+
+    float rm = -1e30f, rs = 0.f, rref = -1e30f;
+    int ri = 0x7fffffff;
+    f32x16 acc, accp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; accp[i] = 0.f; }
+
+    // column of accumulator register i of this lane inside a tile
+    auto col_in_tile = [&](int i) { return (i & 3) + 8 * (i >> 2) + 4 * h; };
+    // statistics of one finished tile held in accp: pieces woven between the MFMAs of the next tile
+    float tmax = -INFINITY;
+    auto stat_piece = [&](int i) {  // logit i of 16
+      tmax = fmaxf(tmax, accp[i]);
+      rs += __expf(accp[i] - rref);
+    };
+    auto stat_open = [&](int tile, bool first) {
+      if (tile * VT_N + VT_N > p.N) {  // ragged last tile of the vocabulary: columns past N never win nor count
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (tile * VT_N + col_in_tile(i) >= p.N) accp[i] = -INFINITY;
+      }
+      if (first) rref = fmaxf(accp[0], -1e30f);
+      tmax = -INFINITY;
+    };
+    auto stat_close = [&](int tile) {
+      if (tmax > rm) {  // a new maximum of this row: rare after the first tiles -> divergent branch
+        int c = 0;
+#pragma unroll
+        for (int i = 15; i >= 0; --i) c = accp[i] == tmax ? col_in_tile(i) : c;  // lowest column among equals
+        ri = tile * VT_N + c;
+        rm = tmax;
+      }
+      if (rm - rref > 20.0f) {  // keep the sum's reference within e^20 of the maximum
+        rs *= __expf(rref - rm);
+        rref = rm;
+      }
+    };
+
+    // one tile: wait + barrier, refill the freed slot, 32 MFMAs with (STATS) the previous tile's statistics
+    // woven in; the first tile of a range has no predecessor - a compile-time variant, not a flag tested
+    // at every weaving point
+    auto tile_body = [&](int t, auto with_stats) {
+      constexpr bool STATS = decltype(with_stats)::value && !(CARE_V32_DBG & 16);
+      const int it = t - t0;
+      // tile t has landed; the two younger tiles (4 DMA instructions each) stay in flight.  Iteration 0
+      // drains everything: the A fragments were issued behind the prologue DMAs.
+      if constexpr (!decltype(with_stats)::value) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      stage(t + V_AHEAD, (it + V_AHEAD) % V_RING);  // the slot every wave finished reading last iteration
+      __builtin_amdgcn_sched_barrier(0);
+
+      const unsigned char* sb = smem + (it % V_RING) * VT_BYTES;
+      if constexpr (STATS) stat_open(t - 1, it == 1);
+      bf16x8 fb[BDEPTH];
+#pragma unroll
+      for (int ks = 0; ks < BDEPTH; ++ks) {
+        if (CARE_V32_DBG & 32) { fb[ks] = bf16x8{}; asm volatile("" : "+v"(fb[ks])); }
+        else fb[ks] = *reinterpret_cast<const bf16x8*>(sb + boff(ks));
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) {
+        const bf16x8 b = fb[ks % BDEPTH];
+        if (ks + BDEPTH < 32 && !(CARE_V32_DBG & 32)) fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff(ks + BDEPTH));
+        if (CARE_V32_DBG & 2) asm volatile("" :: "v"(b));
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[ks], acc, 0, 0, 0);  // D[n][m]: lane = row m, 16 columns n
+        if constexpr (STATS) { if (ks & 1) stat_piece(ks >> 1); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (STATS) stat_close(t - 1);
+      accp = acc;
+    };
+    tile_body(t0, std::false_type{});
+#pragma unroll 1
+    for (int t = t0 + 1; t < t1; ++t) tile_body(t, std::true_type{});
+    // the last tile's statistics
+    if (!(CARE_V32_DBG & 16)) {
+      stat_open(t1 - 1, t1 - t0 == 1);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) stat_piece(i);
+      stat_close(t1 - 1);
+    }
+
+    // ---- merge the two lanes of a row (columns 4 h + ...), write (max, argmax, sum relative to the max)
+    float m = rm, s = rs > 0.f ? rs * __expf(rref - rm) : 0.f;
+    if (!(s < 3.0e38f)) s = 1.0f;  // the sum overflowed (a > 88 jump inside one tile): it is its largest term
+    int id = ri;
+    {
+      const float om = __shfl_xor(m, 32, 64), os = __shfl_xor(s, 32, 64);
+      const int oi = __shfl_xor(id, 32, 64);
+      const float mn = fmaxf(m, om);
+      s = s * __expf(m - mn) + os * __expf(om - mn);
+      if (om > m || (om == m && oi < id)) id = oi;
+      m = mn;
+    }
+    if (h == 0 && row < p.M) {
+      const int64_t o = (int64_t)row * p.ns + range;
+      p.pmax[o] = m; p.pidx[o] = id; p.psum[o] = s;
+    }
+  }
+}
+
+}  // namespace
+
+// Row count from which the 256-row kernel is used (below it the 128-row panels of gemm_as.hip fill the chip better).
+extern "C" int care_vocab32_applies(int M, int N, int K, int a_dtype, int has_labels) {
+  static const int min_rows = [] { const char* e = getenv("CARE_V32_MIN_ROWS"); return e ? atoi(e) : 8192; }();
+  return K == 512 && a_dtype == CARE_BF16 && !has_labels && M >= min_rows && N >= 4 * VT_N;
+}
+
+extern "C" int care_vocab32_launch(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
+                                   int M, int N, int ns, void* stream) {
+  VArgs p{};
+  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W);
+  p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.M = M; p.N = N; p.ns = ns;
+  p.panels = (M + V_ROWS - 1) / V_ROWS;
+  p.total_items = p.panels * ns;
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&vocab_argmax32_kernel<6>), V_LDS, lds_ok)) return e;
+  const int blocks = p.total_items < 256 ? p.total_items : 256;  // one workgroup per CU (128 KiB of LDS), persistent
+  hipLaunchKernelGGL((vocab_argmax32_kernel<6>), dim3(blocks), dim3(512), V_LDS, (hipStream_t)stream, p);
+  return care_launch_status();
+}
