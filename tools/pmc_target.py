@@ -1,12 +1,13 @@
 """A few launches of the decode-step kernels at the bench shape, for `rocprofv3 --pmc ... -- python3 tools/pmc_target.py`."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from care_amd import _lib
 
 DEV = "cuda:0"
 p = lambda t: t.data_ptr() if t is not None else None
-rows, Lk, H, d, V = 16384, 84, 8, 512, 10547
+rows, Lk, H, d, V = (int(sys.argv[1]) if len(sys.argv) > 1 else 32768), 84, 8, 512, 10547
 xb = torch.randn(rows, d, device=DEV).to(torch.bfloat16)
 W = (torch.randn(V, d, device=DEV) * 0.05).to(torch.bfloat16)
 parts = _lib.argmax_parts(V, rows, True)
