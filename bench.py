@@ -165,6 +165,23 @@ def extra_legs(dev, main_dtype):
                fixed_29_steps_captions_per_s=round(32768 / dt_fixed, 1),
                speedup_vs_fixed_29=round(dt_fixed / (leg["ms_per_pass"] * 1e-3), 2))
     legs["early_exit_eos_model"] = leg
+    # the same for beam 5 (configs[4] on a model that ends its captions): finished clips leave between segments
+    opt, eng = build("msrvtt_care_beam5", main_dtype, row_scale=boost)
+    feats = feats_for(opt, 4096)
+    runs = {}
+    for name, ee in (("early_exit", True), ("fixed_29_steps", False)):
+        run = lambda: eng.translate_beam(feats, 5, 5, use_graph=True, lean=True, early_exit=ee)
+        for _ in range(3):
+            run()
+        runs[name] = _timed(run, 5)
+        if ee:
+            st = dict(eng.last_decode)
+    legs["early_exit_eos_model_beam5"] = dict(config="msrvtt_care_beam5", dtype=main_dtype, clips_per_step=4096, beam_size=5,
+                                              captions_per_s=round(4096 / runs["early_exit"], 1),
+                                              fixed_29_steps_captions_per_s=round(4096 / runs["fixed_29_steps"], 1),
+                                              speedup_vs_fixed_29=round(runs["fixed_29_steps"] / runs["early_exit"], 2),
+                                              steps_run=st["steps"], compactions=st["compactions"], row_steps=st["row_steps"],
+                                              row_steps_fixed=4096 * 5 * eng.T)
     # the error of the throughput mode: teacher-forced hidden states, bf16 mode against fp32 mode of this
     # same engine (fp32 mode is within 1e-5 of the reference, tests/test_gpu_parity.py) on the benchmarked model
     if main_dtype == "bf16":

@@ -54,6 +54,8 @@ SIGNATURES = {
     "care_active_slots": [_P, _I, _P, _P, _P],
     "care_gather_rows": [_P, _L, _P, _L, _P, _I, _L, _P],
     "care_scatter_rows": [_P, _L, _P, _L, _P, _I, _L, _P],
+    "care_expand_index": [_P, _I, _I, _P, _P],
+    "care_remap_rows": [_P, _L, _P, _I, _P],
     "care_beam_advance": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_argmax_parts": (c_int, [c_int]),

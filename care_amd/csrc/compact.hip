@@ -89,6 +89,34 @@ int move_rows(const void* src, int64_t src_stride, void* dst, int64_t dst_stride
 
 }  // namespace
 
+namespace {
+// beam search: slot list of clips -> slot list of their rows (bm consecutive rows per clip)
+__global__ __launch_bounds__(256) void expand_index_kernel(const int32_t* idx_c, int m, int bm, int32_t* idx_r) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m * bm) idx_r[i] = idx_c[i / bm] * bm + i % bm;
+}
+// beam search: ancestor tables name physical rows; after the rows of clip c moved to clip cmap[c]
+__global__ __launch_bounds__(256) void remap_rows_kernel(int32_t* anc, int64_t n, const int32_t* cmap, int bm) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int r = anc[i];
+    anc[i] = cmap[r / bm] * bm + r % bm;
+  }
+}
+}  // namespace
+
+extern "C" int care_expand_index(const int32_t* idx_c, int m, int bm, int32_t* idx_r, void* stream) {
+  if (!idx_c || !idx_r || m <= 0 || bm <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(expand_index_kernel, dim3((m * bm + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx_c, m, bm, idx_r);
+  return care_launch_status();
+}
+
+extern "C" int care_remap_rows(int32_t* anc, int64_t n, const int32_t* cmap, int bm, void* stream) {
+  if (!anc || !cmap || n <= 0 || bm <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(remap_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, anc, n, cmap, bm);
+  return care_launch_status();
+}
+
 extern "C" int care_active_slots(const int32_t* finished, int n, int32_t* idx, int32_t* count, void* stream) {
   if (!finished || !idx || !count || n <= 0) return CARE_EINVAL;
   hipLaunchKernelGGL(active_slots_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, finished, n, idx, count);

@@ -230,12 +230,13 @@ class HipEngine:
     def ws(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         """Named, cached workspace (allocated on first use, reused afterwards); one namespace per
         batch lane (lanes_for), so concurrent lanes never share a buffer."""
-        cap = self._ws_cap
-        if cap is not None and len(shape) >= 1 and shape[0] == cap[0] and cap[0] != cap[1]:
-            # compacted decode (greedy_early_exit): `n` active slots of `cap` use the first n rows of ONE
-            # full-size buffer instead of a workspace of their own for every row count
-            shape = (cap[1],) + tuple(shape[1:])
-            return self._ws_get(name, shape, dtype)[: cap[0]]
+        caps = self._ws_cap
+        if caps is not None and len(shape) >= 1:
+            # compacted decode (greedy_early_exit / beam_early_exit): `n` active slots of `cap` use the first
+            # n rows of ONE full-size buffer instead of a workspace of their own for every row count
+            for cur, cap in (caps if isinstance(caps, list) else [caps]):
+                if shape[0] == cur and cur != cap:
+                    return self._ws_get(name, (cap,) + tuple(shape[1:]), dtype)[:cur]
         return self._ws_get(name, shape, dtype)
 
     def _ws_get(self, name, shape, dtype):
@@ -1083,10 +1084,199 @@ class HipEngine:
         graph.replay()
         return out
 
-    def translate_beam(self, feats: List[torch.Tensor], bm: int, need: int, use_graph: bool = True, lean: bool = False):
+    # ------------------------------------------------------------------ beam search with early exit + compaction
+    def _beam_steps(self, v, t0, t1, bm, need):
+        """Steps t0 .. t1 of the beam search on the n clips (n * bm rows) of state `v`; ends with the
+        partition of the clip slots (care_active_slots on `done`)."""
+        n, T, d = v["n"], self.T, self.d
+        N, cap = n * bm, need + bm
+        B = v["B"]
+        self._ws_cap = [(n, B), (N, B * bm)]
+        tag = v["tag"]
+        cval, cidx = self.ws(tag + "cval", (N, bm)), self.ws(tag + "cidx", (N, bm), torch.int32)
+        fused_sel = self.as_ok and os.environ.get("CARE_BEAM_FUSED", "1") != "0"
+        if fused_sel:
+            s_parts = _lib.load().care_argmax_parts_bf16_min(N, self.V, 8)
+            s_cap = 64
+            s_pmax, s_psum = self.ws(tag + "spmax", (N, s_parts)), self.ws(tag + "spsum", (N, s_parts))
+            s_pidx = self.ws(tag + "spidx", (N, s_parts), torch.int32)
+            s_thr, s_cnt = self.ws(tag + "sthr", (N,)), self.ws(tag + "scnt", (N,), torch.int32)
+            s_cval, s_cidx = self.ws(tag + "scval", (N, s_cap)), self.ws(tag + "scidx", (N, s_cap), torch.int32)
+        else:
+            vpad = (self.V + 63) // 64 * 64
+            logits = self.ws(tag + "logits", (N, vpad))[:, : self.V]
+        for t in range(t0, t1 + 1):
+            a_old, a_new = v["anc"][(t - 1) & 1], v["anc"][t & 1]
+            x, xb = self._decode_step(t, N, bm, v["tok"], a_old, v["sem"], v["ckv"], v["skv"], self.Lk, tag, akv=v["akv"])
+            if fused_sel:
+                call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax), ptr(s_pidx),
+                     ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
+                call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
+                call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
+                     ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
+                call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
+                     bm, ptr(xb), d, _code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
+            else:
+                src = xb if xb is not None else x
+                chunk = int(os.environ.get("CARE_BEAM_CHUNK", "0")) or max(128, (176 << 20) // (logits.stride(0) * 4) // 128 * 128)
+                for lo in range(0, N, chunk):
+                    hi = min(N, lo + chunk)
+                    self.gemm(src[lo:hi], self.w["vocab"], None, logits[lo:hi])
+                    call("care_beam_select", ptr(logits[lo:hi]), logits.stride(0), self.V, bm, ptr(cval[lo:hi]),
+                         ptr(cidx[lo:hi]), hi - lo)
+            call("care_beam_advance", ptr(cval), ptr(cidx), ptr(v["scores"]), bm, ptr(v["tok"]), ptr(a_old), ptr(a_new),
+                 ptr(v["done"]), ptr(v["nfin"]), cap, ptr(v["fscore"]), ptr(v["flen"]), ptr(v["fhyp"]), t, T, need, EOS,
+                 self.V, T + 1, n)
+        call("care_active_slots", ptr(v["done"]), n, ptr(v["idx"]), ptr(v["cnt"]))
+
+    def beam_early_exit(self, feats: List[torch.Tensor], bm: int, need: int, lean: bool = False, use_graph: bool = True):
+        """encode + beam search that stops when every clip is done and drops finished clips between
+        segments (models/Translator.py:77-81,194-209), like greedy_early_exit: the clip-level state
+        (memory, finished lists ...) and the bm rows of every surviving clip (tokens, scores, K/V cache,
+        ancestor tables - whose entries are physical row numbers and are renumbered) move to the front of
+        a second buffer set.  Results per CLIP: nfin [B], fscore / flen [B, need + bm], fhyp [B, need + bm, T + 1]."""
+        feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        B, T, d = feats[0].shape[0], self.T, self.d
+        cap = need + bm
+        S = max(1, self.segment_steps) * (1 if B * bm >= 2048 else 2)
+        out = dict(nfin=self.ws("be_out_nfin", (B,), torch.int32), fscore=self.ws("be_out_fscore", (B, cap)),
+                   flen=self.ws("be_out_flen", (B, cap), torch.int32), fhyp=self.ws("be_out_fhyp", (B, cap, T + 1), torch.int32))
+        idx, cnt = self.ws("be_idx", (B,), torch.int32), self.ws("be_cnt", (1,), torch.int32)
+        fkey = (tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+
+        def state(par, n):
+            N = n * bm
+            self._ws_cap = [(n, B), (N, B * bm)]
+            tag = "b%d_" % par
+            return dict(tag=tag, n=n, B=B, idx=idx, cnt=cnt,
+                        tok=self.ws(tag + "tok", (N, T + 1), torch.int32),
+                        anc=[self.ws(tag + "anc%d" % i, (N, T + 1), torch.int32) for i in range(2)],
+                        scores=self.ws(tag + "scores", (N,)),
+                        skv=[self.ws(tag + "skv%d" % li, (N, T, 2 * d), self.wt) for li in range(self.n_layers)],
+                        done=self.ws(tag + "done", (n,), torch.int32), nfin=self.ws(tag + "nfin", (n,), torch.int32),
+                        fscore=self.ws(tag + "fscore", (n, cap)), flen=self.ws(tag + "flen", (n, cap), torch.int32),
+                        fhyp=self.ws(tag + "fhyp", (n, cap, T + 1), torch.int32), clip=self.ws(tag + "clip", (n,), torch.int32))
+
+        def first_segment():
+            self._ws_cap = None
+            enc = self.encode(feats, lean, static=True)
+            mem, sem = enc["encoder_hidden_states"], enc.get("semantic_hidden_states")
+            v = state(0, B)
+            N = B * bm
+            v["tok"].fill_(EOS); v["tok"][:, 0] = BOS
+            rows = self._arange(N)
+            for a in v["anc"]:
+                a.copy_(rows.unsqueeze(1).expand(N, T + 1))
+            for k in ("scores", "done", "nfin", "fscore", "flen", "fhyp"):
+                v[k].zero_()
+            v["clip"].copy_(self._arange(B))
+            v["sem"] = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
+            self._ws_cap = None
+            v["ckv"] = self.cross_src(mem, N)
+            v["akv"] = self.attr_kv(enc.get("semantic_embs")) if self.attr_att else None
+            self._beam_steps(v, 1, min(S, T), bm, need)
+            return enc, v
+
+        def replayable(key, fn):
+            if not use_graph:
+                return fn()
+            entry = self._graphs.get(key)
+            if entry is None:
+                self._graphs[key] = "seen"
+                return fn()
+            if entry == "seen":
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    res = fn()
+                entry = (graph, res)
+                self._graphs[key] = entry
+            entry[0].replay()
+            return entry[1]
+
+        def flush(v):
+            """finished lists of every slot of v -> the per-clip outputs"""
+            n = v["n"]
+            self._call_rows("care_scatter_rows", v["nfin"].view(n, 1), out["nfin"].view(B, 1), v["clip"], n)
+            for k in ("fscore", "flen"):
+                self._call_rows("care_scatter_rows", v[k], out[k], v["clip"], n)
+            self._call_rows("care_scatter_rows", v["fhyp"].view(n, -1), out["fhyp"].view(B, -1), v["clip"], n)
+
+        try:
+            enc, v = replayable(("bseg0", bm, need, self.latent_ok, bool(lean), S) + fkey, first_segment)
+            par, t = 0, min(S, T) + 1
+            stats = dict(clips=B, steps=t - 1, row_steps=B * bm * (t - 1), compactions=0)
+            self.last_decode = stats
+            while True:
+                active = int(cnt.item())
+                if active == 0 or t > T:
+                    break
+                m = self._slot_bucket(active, B)
+                if m * 4 <= v["n"] * 3 and v["n"] * bm >= 2048:
+                    flush(v)
+                    v = self._compact_beam(v, state(par ^ 1, m), idx, active, bm)
+                    par ^= 1
+                    stats["compactions"] += 1
+                t1 = min(t + S - 1, T)
+                vv = v
+                replayable(("bseg", par, t, t1, v["n"], B, bm, need, self.latent_ok), lambda: self._beam_steps(vv, t, t1, bm, need))
+                stats["steps"] = t1
+                stats["row_steps"] += v["n"] * bm * (t1 - t + 1)
+                t = t1 + 1
+            flush(v)
+        finally:
+            self._ws_cap = None
+        return enc, out["nfin"], out["fscore"], out["flen"], out["fhyp"]
+
+    def _compact_beam(self, v, w, idx, active, bm):
+        """The first w['n'] clips of the partition `idx` (unfinished first, finished ones as padding) and their rows
+        -> buffer set `w`; ancestor entries are renumbered to the rows' new places."""
+        n, m, B = v["n"], w["n"], v["B"]
+        N, M = n * bm, m * bm
+        self._ws_cap = [(m, B), (M, B * bm), (n, B), (N, B * bm)]
+        tag = w["tag"]
+        idx_r = self.ws(tag + "idx_r", (M,), torch.int32)
+        call("care_expand_index", ptr(idx), m, bm, ptr(idx_r))
+        cmap = self.ws(tag + "cmap", (n,), torch.int32)
+        cmap.zero_()  # clips that are dropped map to clip 0: nothing references their rows any more
+        self._call_rows("care_scatter_rows", self._arange(m).view(m, 1), cmap.view(n, 1), idx, m)
+        for k in ("done", "nfin", "clip"):
+            self._call_rows("care_gather_rows", v[k].view(n, 1), w[k].view(m, 1), idx, m)
+        for k in ("fscore", "flen"):
+            self._call_rows("care_gather_rows", v[k], w[k], idx, m)
+        self._call_rows("care_gather_rows", v["fhyp"].view(n, -1), w["fhyp"].view(m, -1), idx, m)
+        self._call_rows("care_gather_rows", v["tok"], w["tok"], idx_r, M)
+        self._call_rows("care_gather_rows", v["scores"].view(N, 1), w["scores"].view(M, 1), idx_r, M)
+        for a, b in zip(v["anc"], w["anc"]):
+            self._call_rows("care_gather_rows", a, b, idx_r, M)
+            call("care_remap_rows", ptr(b), b.numel(), ptr(cmap), bm)
+        for a, b in zip(v["skv"], w["skv"]):
+            self._call_rows("care_gather_rows", a, b, idx_r, M)
+
+        def moved(name, src, per=1):
+            if src is None:
+                return None
+            s2 = src.view(n, -1)
+            dst = self.ws(tag + name, (m, s2.shape[1]), src.dtype)
+            self._call_rows("care_gather_rows", s2, dst, idx, m)
+            return dst.view((m * per,) + tuple(src.shape[1:])) if per > 1 else dst.view((m,) + tuple(src.shape[1:]))
+
+        w["sem"] = moved("sem", v["sem"])
+        if isinstance(v["ckv"], tuple):
+            w["ckv"] = (moved("mem", v["ckv"][0]),) * len(v["ckv"])
+        else:
+            w["ckv"] = [moved("ckv%d" % i, kv, self.Lk) for i, kv in enumerate(v["ckv"])]
+        w["akv"] = [moved("akv%d" % i, kv, self.topk) for i, kv in enumerate(v["akv"])] if v["akv"] is not None else None
+        w["clip"][active:].fill_(-1)
+        return w
+
+    def translate_beam(self, feats: List[torch.Tensor], bm: int, need: int, use_graph: bool = True, lean: bool = False,
+                       early_exit: Optional[bool] = None):
         """encode + beam search of one batch, replayed from a hipGraph when the input buffers repeat
         (same policy as translate_greedy).  Returns (enc_outputs, nfin, fscore, flen, fhyp)."""
         feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        if self.early_exit if early_exit is None else early_exit:
+            return self.beam_early_exit(feats, bm, need, lean, use_graph)
 
         def run():
             enc = self.encode(feats, lean)

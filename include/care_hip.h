@@ -391,6 +391,12 @@ int care_gather_rows(const void* src, int64_t src_stride_bytes, void* dst, int64
                      const int32_t* idx, int n, int64_t row_bytes, void* stream);
 int care_scatter_rows(const void* src, int64_t src_stride_bytes, void* dst, int64_t dst_stride_bytes,
                       const int32_t* idx, int n, int64_t row_bytes, void* stream);
+/* Beam search keeps bm consecutive rows per clip and ancestor tables that name physical rows:
+ *   care_expand_index: idx_r[k * bm + j] = idx_c[k] * bm + j  (clip slots -> row slots), k < m;
+ *   care_remap_rows:   anc[i] = cmap[anc[i] / bm] * bm + anc[i] % bm for the n entries of a table, after
+ *     the rows of clip c have moved to clip cmap[c]. */
+int care_expand_index(const int32_t* idx_c, int m, int bm, int32_t* idx_r, void* stream);
+int care_remap_rows(int32_t* anc, int64_t n, const int32_t* cmap, int bm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -228,7 +228,7 @@ def test_beam_bf16_vs_oracle(golden, absorbed, use_graph):
     for _ in range(3 if use_graph else 1):  # first sight (eager), capture, replay
         hyps, scores = tr.translate_batch([model], {"feats": dev}, use_graph=use_graph)
     if use_graph:
-        assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] == "beam"), "beam pass was not captured"
+        assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] in ("beam", "bseg0")), "beam pass was not captured"
     ref_hyps, ref_scores = golden.hyps()
     z = golden.z
     enc = care_cpu.encoding_phase(P, opt, feats)

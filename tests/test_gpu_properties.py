@@ -290,7 +290,7 @@ def test_beam_graph_replay_equals_eager(config, dtype, B):
         again = run(True)
         for a, b in zip(eager, again):
             assert torch.equal(a, b)
-    assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] == "beam"), "beam pass was not captured"
+    assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] in ("beam", "bseg0")), "beam pass was not captured"
     for f in feats:
         f.copy_(f.flip(0))
     flipped = run(True)
@@ -364,3 +364,31 @@ def test_active_slots_gather_scatter_kernels():
         ref = torch.zeros_like(src)
         ref[idx[1:].long()] = dst[1:]
         assert torch.equal(back, ref)
+
+
+@pytest.mark.parametrize("config,dtype,B,bm,need", [("msrvtt_care_beam5", "bf16", 1024, 5, 5), ("msrvtt_base_ami", "fp32", 200, 5, 7),
+                                                    ("msrvtt_cabase", "bf16", 640, 3, 3)])
+def test_beam_early_exit_and_compaction_equal_the_fixed_length_pass(config, dtype, B, bm, need):
+    """Beam search with early termination and clip compaction (engine.beam_early_exit: the clip-level
+    state and the bm rows of every surviving clip move, ancestor tables are renumbered) returns the
+    finished lists of the pass that runs all 29 steps over all rows: counts, lengths and tokens
+    exactly, scores up to the merge order of the log-sum-exp partials."""
+    boost = {"cls_head.tgt_word_prj.weight": {3: 5.0, 0: 3.0}}
+    opt, P, model, feats = _setup(config, B, dtype, boost=boost)
+    eng = model.engine()
+    _, nfin0, fsc0, flen0, fhyp0 = eng.translate_beam(feats, bm, need, use_graph=False, early_exit=False)
+    nfin0, fsc0, flen0, fhyp0 = nfin0.clone(), fsc0.clone(), flen0.clone(), fhyp0.clone()
+    assert int(nfin0.min()) >= 1 and len(set(flen0[:, 0].tolist())) > 3
+    for it in range(4):  # eager, first sight, capture, replay
+        _, nfin1, fsc1, flen1, fhyp1 = eng.translate_beam(feats, bm, need, use_graph=it > 0, early_exit=True)
+        st = dict(eng.last_decode)
+        assert torch.equal(nfin1, nfin0)
+        cap = flen0.shape[1]
+        live = torch.arange(cap, device="cuda:0").unsqueeze(0) < nfin0.clamp(max=cap).unsqueeze(1)   # recorded entries
+        assert torch.equal(flen1 * live, flen0 * live)
+        assert ((fsc1 - fsc0) * live).abs().max().item() < 1e-3
+        pos = torch.arange(fhyp0.shape[2], device="cuda:0").view(1, 1, -1) < (flen0 * live).unsqueeze(2)
+        assert torch.equal(fhyp1 * pos, fhyp0 * pos)
+        if B * bm >= 2048:
+            assert st["compactions"] >= 1 and st["row_steps"] < 0.8 * B * bm * 29, st
+    assert any(k[0] == "bseg0" and isinstance(g, tuple) for k, g in eng._graphs.items())
