@@ -614,6 +614,12 @@ int plan_stream(AsArgs& p, bool has_bias) {
 
 }  // namespace
 
+// the 256-row-panel store kernel for large row counts (csrc/gemm_store32.hip)
+extern "C" int care_store32_applies(int M, int N, int K, int a_dtype, int n_split, int has_bias_cols);
+extern "C" int care_store32_launch(const void* A, int64_t lda, const void* W, const float* bias, void* C0, int64_t ldc0,
+                                   int c0_bf16, void* C1, int64_t ldc1, int c1_bf16, int n_split, int M, int N, int act,
+                                   void* stream);
+
 extern "C" int care_gemm_bf16(const void* A, int64_t lda, int a_dtype, const void* W, const float* bias, void* C0,
                               int64_t ldc0, int c0_dtype, void* C1, int64_t ldc1, int c1_dtype, int n_split, int M,
                               int N, int K, int act, void* stream) {
@@ -623,6 +629,11 @@ extern "C" int care_gemm_bf16(const void* A, int64_t lda, int a_dtype, const voi
   if (!C0 || n_split <= 0 || n_split > N || (n_split < N && !C1)) return CARE_EINVAL;
   if (n_split % 16 != 0 && n_split != N) return CARE_ESHAPE;
   if (act < CARE_ACT_NONE || act > CARE_ACT_GELU) return CARE_EDTYPE;
+  if (care_store32_applies(M, N, K, a_dtype, n_split, 0)) {
+    const int rc32 = care_store32_launch(A, lda, W, bias, C0, ldc0, c0_dtype == CARE_BF16, C1, ldc1, c1_dtype == CARE_BF16,
+                                         n_split, M, N, act, stream);
+    if (rc32 != CARE_ESHAPE && rc32 != CARE_EALIGN) return rc32;  // shapes / alignments it does not take: the 128-row kernel
+  }
   AsArgs p{};
   p.A = A; p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.bias = bias;
   p.C0 = C0; p.ldc0 = ldc0; p.c0_bf16 = c0_dtype == CARE_BF16;

@@ -1,0 +1,254 @@
+// gemm_store32.hip - C = act(A W^T + bias) for bf16 A [M, 512], bf16 W [N, 512] at large row counts:
+// the QKV, Wq and FFN1 projections of a decode step (Attention.py:53-67, SubLayers.py:129-141).
+//
+// Same structure as csrc/gemm_vocab.hip (see there for the ablation that motivates it: with 128-row
+// panels the L2 -> LDS stream of W bounds the A-stationary kernel before any arithmetic):
+//   * a workgroup is 8 waves x 32 rows = a 256-row panel with its A fragments resident in registers;
+//   * W tiles of 32 output columns x 512 k through a 4-slot LDS ring (LDS-DMA, three in flight), one
+//     barrier per tile; the bias slice of the block's column range is staged in LDS once;
+//   * v_mfma_f32_32x32x16_bf16 with swapped operands; the W rows of a tile are permuted over the MFMA
+//     rows when the tile is STAGED (LDS row n takes column 16 ((n >> 2) & 1) + 4 (n >> 3) + (n & 3)), so
+//     a lane ends up with 16 CONSECUTIVE output columns of one row: two 16-byte bf16 stores (or four
+//     fp32 ones) per tile, 64 (128) contiguous bytes per row from the two lanes of a row - the
+//     16x16 form stores 8 bytes per lane, 32-byte row pieces;
+//   * the epilogue of tile t (bias, activation, convert, store) is woven between the MFMAs of tile
+//     t + 1; its stores are counted in the vmcnt arithmetic of the ring.
+// Two destinations like care_gemm_bf16 (columns < n_split -> C0, the rest -> C1; each fp32 or bf16,
+// own leading dimension): the QKV projection writes q and, straight into the cache, k | v.
+#include <cstdlib>
+#include <type_traits>
+
+#include "care_common.h"
+
+namespace {
+
+constexpr int ST_N = 32;
+constexpr int ST_BYTES = ST_N * 1024;
+constexpr int S_RING = 4, S_AHEAD = 3;
+constexpr int S_BIAS_OFF = S_RING * ST_BYTES;
+constexpr int S_BIAS_MAX = 4096;         // bias columns a block can stage
+constexpr int S_LDS = S_BIAS_OFF + S_BIAS_MAX * 4;
+constexpr int S_ROWS = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct SArgs {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* W;
+  const float* bias;
+  void* C0; int64_t ldc0; int c0_bf16;
+  void* C1; int64_t ldc1; int c1_bf16;
+  int n_split, M, N, act, ns, panels, total_items;
+};
+
+__device__ __forceinline__ float s_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+template <int BDEPTH>
+__global__ __launch_bounds__(512, 2) void gemm_store32_kernel(SArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_total = p.N / ST_N;  // the launcher guarantees N % 32 == 0 and n_split % 32 == 0
+  const int tpb = (tiles_total + p.ns - 1) / p.ns;
+
+  for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+    const int range = item % p.ns, panel = item / p.ns;
+    const int t0 = range * tpb, t1 = min(t0 + tpb, tiles_total);
+    if (t0 >= t1) continue;
+    const int m0 = panel * S_ROWS + wave * 32;
+    const int row = m0 + r;
+    // every wave is done with the ring and the bias slice of the previous item
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- W tile -> ring slot: wave w copies LDS rows 4w .. 4w + 3; LDS row n holds output column
+    // perm(n) of the tile, lane = chunk slot, source chunk = slot ^ (n & 15)
+    unsigned wlane[4];
+    int wcol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = wave * 4 + i;
+      wlane[i] = (unsigned)((lane ^ (n & 15)) << 4);
+      wcol[i] = 16 * ((n >> 2) & 1) + 4 * (n >> 3) + (n & 3);
+    }
+    auto stage = [&](int tile, int slot) {
+      tile = min(tile, t1 - 1);  // past the end: the last tile again, into a slot nobody will read
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(p.W) +
+                                                            (int64_t)(tile * ST_N + wcol[i]) * 1024 + wlane[i]),
+            (__attribute__((address_space(3))) void*)(smem + slot * ST_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < S_AHEAD; ++i) stage(t0 + i, i);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- activations of this wave's 32 rows, whole K, resident
+    bf16x8 a[32];
+    const bf16_t* arow = p.A + (int64_t)min(row, p.M - 1) * p.lda + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- bias slice of the range -> LDS (behind the DMAs and the A loads: one combined latency)
+    const int col0 = t0 * ST_N;
+    if (p.bias) {
+      float* sb = reinterpret_cast<float*>(smem + S_BIAS_OFF);
+      const int nb = (t1 - t0) * ST_N;
+      for (int i = tid; i < nb; i += 512) sb[i] = p.bias[col0 + i];
+    }
+
+    // The destination is a property of the TILE (wave-uniform): a range may straddle n_split, a 32-column
+    // tile cannot (n_split % 32 == 0).  VM store instructions per tile: 2 (bf16) or 4 (fp32), none for a
+    // wave whose rows are all past M - the last three iterations' counts enter the vmcnt arithmetic.
+    const bool wave_rows = m0 < p.M;
+    int st_hist0 = 0, st_hist1 = 0, st_hist2 = 0;  // stores issued in the iterations it - 1, it - 2, it - 3
+
+    const int bswz = r * 1024;
+    auto boff = [&](int ks) { return bswz + ((((2 * ks + h) ^ (r & 15)) & 15) << 4) + ((2 * ks) >> 4) * 256; };
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    f32x16 accA, accB;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accA[i] = 0.f; accB[i] = 0.f; }
+
+    // epilogue piece g (0..3) of a finished tile: columns 16 h + 4 g .. + 3 of this lane's row
+    // (accumulator registers 4 g .. 4 g + 3 hold output columns 16 h + 4 g + (0..3) after the staging permutation)
+    auto out_piece = [&](const f32x16& ap, int tile, int g, float (&v)[16]) {
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) {  // asm read: hipcc would drain the in-flight DMAs in front of a C++ LDS read here
+        const unsigned addr = lds0 + (unsigned)(S_BIAS_OFF + ((tile * ST_N - col0) + 16 * h + 4 * g) * 4);
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(bv) : "v"(addr) : "memory");
+      }
+      v[4 * g + 0] = ap[4 * g + 0] + bv.x; v[4 * g + 1] = ap[4 * g + 1] + bv.y;
+      v[4 * g + 2] = ap[4 * g + 2] + bv.z; v[4 * g + 3] = ap[4 * g + 3] + bv.w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p.act == CARE_ACT_RELU) v[4 * g + j] = fmaxf(v[4 * g + j], 0.0f);
+        else if (p.act == CARE_ACT_GELU) v[4 * g + j] = s_gelu(v[4 * g + j]);
+      }
+    };
+    auto out_store = [&](int tile, const float (&v)[16]) -> int {
+      const bool second = tile * ST_N >= p.n_split;
+      unsigned char* C = reinterpret_cast<unsigned char*>(second ? p.C1 : p.C0);
+      const int64_t ld = second ? p.ldc1 : p.ldc0;
+      const bool isb = (second ? p.c1_bf16 : p.c0_bf16) != 0;
+      const int cshift = second ? p.n_split : 0;
+      if (row < p.M) {
+        const int64_t o = (int64_t)row * ld + (tile * ST_N - cshift) + 16 * h;
+        if (isb) {
+          bf16x8 o0, o1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { o0[j] = (bf16_t)v[j]; o1[j] = (bf16_t)v[8 + j]; }
+          bf16_t* dst = reinterpret_cast<bf16_t*>(C) + o;
+          *reinterpret_cast<bf16x8*>(dst) = o0;
+          *reinterpret_cast<bf16x8*>(dst + 8) = o1;
+        } else {
+          float* dst = reinterpret_cast<float*>(C) + o;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dst + 4 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        }
+      }
+      return wave_rows ? (isb ? 2 : 4) : 0;
+    };
+
+    auto wait_tile = [&]() {
+      // the tile has landed when at most the DMAs of the two younger tiles (8) and the stores issued since
+      // its own DMA are outstanding: its DMA went out three iterations ago (or in the prologue) AHEAD of
+      // that iteration's stores
+      switch (8 + st_hist0 + st_hist1 + st_hist2) {
+        case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory"); break;
+      }
+    };
+
+    auto tile_body = [&](int t, auto with_prev, f32x16& ac, f32x16& ap) {
+      constexpr bool PREV = decltype(with_prev)::value;
+      const int it = t - t0;
+      if constexpr (!PREV) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // also the A fragments and the bias slice
+      else wait_tile();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      stage(t + S_AHEAD, (it + S_AHEAD) % S_RING);
+      __builtin_amdgcn_sched_barrier(0);
+
+      const unsigned char* sb = smem + (it % S_RING) * ST_BYTES;
+      bf16x8 fb[BDEPTH];
+#pragma unroll
+      for (int ks = 0; ks < BDEPTH; ++ks) fb[ks] = *reinterpret_cast<const bf16x8*>(sb + boff(ks));
+      float v[16];
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) {
+        const bf16x8 b = fb[ks % BDEPTH];
+        if (ks + BDEPTH < 32) fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff(ks + BDEPTH));
+        if (ks == 0) ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[ks], ac, 0, 0, 0);
+        if constexpr (PREV) {
+          if (ks % 6 == 5 && ks / 6 < 4) out_piece(ap, t - 1, ks / 6, v);   // pieces after k-steps 5, 11, 17, 23
+          if (ks == 27) { st_hist2 = st_hist1; st_hist1 = st_hist0; st_hist0 = out_store(t - 1, v); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (!PREV) { st_hist2 = st_hist1; st_hist1 = st_hist0; st_hist0 = 0; }
+    };
+    tile_body(t0, std::false_type{}, accA, accB);
+    int t = t0 + 1;
+#pragma unroll 1
+    for (; t + 1 < t1; t += 2) {
+      tile_body(t, std::true_type{}, accB, accA);
+      tile_body(t + 1, std::true_type{}, accA, accB);
+    }
+    auto last_out = [&](const f32x16& al) {
+      float v[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) out_piece(al, t1 - 1, g, v);
+      out_store(t1 - 1, v);
+    };
+    if (t < t1) {
+      tile_body(t, std::true_type{}, accB, accA);
+      last_out(accB);
+    } else {
+      last_out(accA);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int care_store32_applies(int M, int N, int K, int a_dtype, int n_split, int has_bias_cols) {
+  static const int min_rows = [] { const char* e = getenv("CARE_S32_MIN_ROWS"); return e ? atoi(e) : 8192; }();
+  return K == 512 && a_dtype == CARE_BF16 && M >= min_rows && N % ST_N == 0 && n_split % ST_N == 0 && N >= 4 * ST_N;
+}
+
+extern "C" int care_store32_launch(const void* A, int64_t lda, const void* W, const float* bias, void* C0, int64_t ldc0,
+                                   int c0_bf16, void* C1, int64_t ldc1, int c1_bf16, int n_split, int M, int N, int act,
+                                   void* stream) {
+  SArgs p{};
+  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.bias = bias;
+  p.C0 = C0; p.ldc0 = ldc0; p.c0_bf16 = c0_bf16; p.C1 = C1; p.ldc1 = ldc1; p.c1_bf16 = c1_bf16;
+  p.n_split = n_split; p.M = M; p.N = N; p.act = act;
+  p.panels = (M + S_ROWS - 1) / S_ROWS;
+  // column ranges per panel: enough work items for one workgroup per CU (256), whole tiles per range; the
+  // bias slice of a range must fit its LDS staging area
+  const int tiles = N / ST_N;
+  int ns = 1;
+  while ((p.panels * ns < 256 && ns * 2 <= tiles) || ((tiles + ns - 1) / ns) * ST_N > S_BIAS_MAX) ns *= 2;
+  if (((tiles + ns - 1) / ns) * ST_N > S_BIAS_MAX) return CARE_ESHAPE;
+  p.ns = ns;
+  p.total_items = p.panels * ns;
+  // 16-byte stores: destinations and leading dimensions must allow them
+  const int e0 = c0_bf16 ? 8 : 4, e1 = c1_bf16 ? 8 : 4;
+  if ((ldc0 % e0) || !care_aligned16(C0) || (n_split < N && ((ldc1 % e1) || !care_aligned16(C1)))) return CARE_EALIGN;
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_store32_kernel<4>), S_LDS, lds_ok)) return e;
+  const int blocks = p.total_items < 256 ? p.total_items : 256;
+  hipLaunchKernelGGL((gemm_store32_kernel<4>), dim3(blocks), dim3(512), S_LDS, (hipStream_t)stream, p);
+  return care_launch_status();
+}

@@ -97,6 +97,44 @@ def test_gemm_split_destinations_and_bf16_out(kernel):
     assert cache[:, 6, :].abs().max().item() == 0 and cache[:, 8, :].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("M,N,act,out_bf16", [(8192, 2048, 1, True), (8192 + 100, 512, 0, False), (12000, 2048, 2, True),
+                                              (33000, 512, 0, True), (8192, 4096, 1, True)])
+def test_gemm_store_256_row_panels(M, N, act, out_bf16):
+    """csrc/gemm_store32.hip (bf16 activations, K = 512, M >= 8192): bias + activation + 16-byte stores of
+    16 consecutive columns per lane, against torch on the bf16-rounded operands; a ragged last panel."""
+    K = 512
+    A = _rand(M, K, seed=61).to(torch.bfloat16).contiguous()
+    W = _rand(N, K, seed=62, scale=0.05)
+    bias = _rand(N, seed=63)
+    Wb = W.to(torch.bfloat16).contiguous()
+    out = torch.full((M + 3, N + 8), 7.0, device=DEV, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    dst = out[:M, :N]
+    _call("care_gemm_bf16", _p(A), K, 1, _p(Wb), _p(bias), _p(dst), dst.stride(0), 1 if out_bf16 else 0, None, 0, 0, N, M, N, K, act)
+    ref = A.float() @ Wb.float().t() + bias
+    ref = torch.relu(ref) if act == 1 else (torch.nn.functional.gelu(ref) if act == 2 else ref)
+    torch.cuda.synchronize()
+    assert (dst.float() - ref).abs().max().item() < (3e-2 if out_bf16 else 3e-3)
+    assert float(out[M:].float().min()) == 7.0 and float(out[:, N:].float().min()) == 7.0   # nothing written outside
+
+
+def test_gemm_store_256_row_panels_split_destinations():
+    """The QKV projection of a decode step at 16384 rows: q fp32 [M, 512] and k | v bf16 straight into
+    position 7 of the [M, 29, 1024] cache (columns >= n_split, own leading dimension)."""
+    M, K, d = 16384 + 5, 512, 512
+    A = _rand(M, K, seed=64).to(torch.bfloat16).contiguous()
+    W, bias = _rand(3 * d, K, seed=65, scale=0.05), _rand(3 * d, seed=66)
+    Wb = W.to(torch.bfloat16).contiguous()
+    q = torch.zeros(M, d, device=DEV)
+    cache = torch.zeros(M, 29, 2 * d, device=DEV, dtype=torch.bfloat16)
+    dst = cache[:, 7, :]
+    _call("care_gemm_bf16", _p(A), K, 1, _p(Wb), _p(bias), _p(q), d, 0, _p(dst), dst.stride(0), 1, d, M, 3 * d, K, 0)
+    ref = A.float() @ Wb.float().t() + bias
+    torch.cuda.synchronize()
+    assert (q - ref[:, :d]).abs().max().item() < 3e-3
+    assert (cache[:, 7, :].float() - ref[:, d:]).abs().max().item() < 3e-2
+    assert cache[:, 6, :].abs().max().item() == 0 and cache[:, 8, :].abs().max().item() == 0
+
+
 @pytest.mark.parametrize("M", [1, 3, 64, 129, 1000])
 @pytest.mark.parametrize("mode", ["f32", "bf16_generic", "bf16_as"])
 def test_gemm_argmax(M, mode):
