@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -35,6 +35,8 @@ SIGNATURES = {
     "care_gemm_ln": [_P, _L, _I, _P, _P, _P, _L, _P, _P, _P, _F, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_gemm_ln_packed": [_P, _L, _I, _P, _P, _P, _L, _P, _P, _F, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_pack_ln_weight": [_P, _P, _I, _I, _P],
+    "care_pack_ln_weight_split": [_P, _P, _I, _I, _P],
+    "care_gemm_ln_split": [_P, _L, _P, _P, _P, _P, _F, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_gemm_bf16_splitk": [_P, _L, _I, _P, _P, _P, _L, _L, _I, _I, _I, _P],
     "care_group_mean": [_P, _L, _I, _I, _I, _P, _L, _I, _I, _I, _P],
     "care_concept_finish": [_P, _L, _P, _L, _P, _I, _I, _P],

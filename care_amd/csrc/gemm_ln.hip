@@ -328,8 +328,15 @@ __device__ __forceinline__ void ln2_wait_stages(int younger) {
 // A template parameter because a run-time condition per load makes hipcc branch around every load and
 // wait for it on the spot, and duplicating the epilogue behind ONE run-time branch made it spill the
 // 128 accumulators (700 B of scratch per lane).
-template <bool AF32, int RG, int NSW, int NSA, int EPI>
+// REP = 3 (fp32 A, packed split weight only): the "split-bf16" product a_hi w_hi + a_hi w_lo + a_lo w_hi
+// with a = a_hi + a_lo, w = w_hi + w_lo in bf16 pieces - three bf16 MFMA passes instead of the 16x
+// slower exact-f32 MFMA, error ~2^-17 per operand (concept models: the embedder feeds a discrete
+// top-30 choice, see engine.load_weights).  Every REAL K step is three consecutive virtual steps that
+// share the A stage (converted as hi, hi, lo) and take the W stages w_hi, w_lo, w_hi of
+// care_pack_ln_weight_split.
+template <bool AF32, int RG, int NSW, int NSA, int EPI, int REP = 1>
 __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
+  static_assert(REP == 1 || (REP == 3 && AF32), "split products need the fp32 operand");
   constexpr int BM = 64 * RG, NW = 4 * RG, NLD = NW / 2;  // NLD loader waves per operand
   // A moves in MACRO stages of 256 contiguous bytes per row (2 K steps of fp32, 4 of bf16): with 128
   // (64) bytes per row and step every DRAM page was visited for one cache line at a time and the raw
@@ -413,16 +420,18 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
   using araw_t = typename std::conditional<AF32, f32x4, bf16x8>::type;  // [tile][AF32 ? lo/hi : 1]
   auto read_a = [&](int kt, int part, araw_t (&r)[2][AF32 ? 2 : 1]) {
     if (CARE_LN_DBG & 8) { for (int t = 0; t < 2; ++t) for (int c = 0; c < (AF32 ? 2 : 1); ++c) { r[t][c] = araw_t{}; asm volatile("" : "+v"(r[t][c])); } return; }
-    const int jx = (kt % KSUB) * (AF32 ? 128 : 64);
-    const unsigned char* sa = smem + ((kt / KSUB) % NSA) * A_BYTES + (a_lane ^ jx);
-    const unsigned char* sx = smem + ((kt / KSUB) % NSA) * A_BYTES + (a_lane ^ jx ^ 16);
+    const int kr = kt / REP;  // real K step of virtual step kt
+    const int jx = (kr % KSUB) * (AF32 ? 128 : 64);
+    const unsigned char* sa = smem + ((kr / KSUB) % NSA) * A_BYTES + (a_lane ^ jx);
+    const unsigned char* sx = smem + ((kr / KSUB) % NSA) * A_BYTES + (a_lane ^ jx ^ 16);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       r[t][0] = *reinterpret_cast<const araw_t*>(sa + (2 * part + t) * 16 * A_ROWB);
       if constexpr (AF32) r[t][1] = *reinterpret_cast<const araw_t*>(sx + (2 * part + t) * 16 * A_ROWB);
     }
   };
-  auto cvt_a = [&](const araw_t (&r)[2][AF32 ? 2 : 1], bf16x8 (&f)[4], int part) {
+  auto cvt_a = [&](const araw_t (&r)[2][AF32 ? 2 : 1], bf16x8 (&f)[4], int part, int kt) {
+    const bool lo = REP == 3 && kt % REP == 2;  // third pass of a real step: the low piece a - bf16(a)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if constexpr (AF32) {  // pairs -> one v_cvt_pk_bf16_f32 each
@@ -432,7 +441,8 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
-            const bf16x2 pr = __builtin_convertvector(f32x2{r[t][c][e], r[t][c][e + 1]}, bf16x2);
+            bf16x2 pr = __builtin_convertvector(f32x2{r[t][c][e], r[t][c][e + 1]}, bf16x2);
+            if (lo) pr = __builtin_convertvector(f32x2{r[t][c][e] - (float)pr[0], r[t][c][e + 1] - (float)pr[1]}, bf16x2);
             f[2 * part + t][4 * c + e] = pr[0]; f[2 * part + t][4 * c + e + 1] = pr[1];
           }
       } else {
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
     }
   };
 
-  const int nk = p.K >> 5, nmac = nk / KSUB;  // the launcher guarantees K % (32 KSUB) == 0
+  const int nk = (p.K >> 5) * REP, nmac = (p.K >> 5) / KSUB;  // the launcher guarantees K % (32 KSUB) == 0; nk: virtual steps
   // Issue schedule (the same instruction counts in every step, so every wait is a constant):
   //   W wave: the NWI instructions of stage kt + NSW go out in the second half of step kt (its slot was
   //           read for the last time before this step's barrier);
@@ -472,12 +482,15 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
   {
     araw_t r0[2][AF32 ? 2 : 1], r1[2][AF32 ? 2 : 1];
     read_a(0, 0, r0); read_a(0, 1, r1); read_b(0, 0, fbA);
-    cvt_a(r0, faA, 0); cvt_a(r1, faA, 1);
+    cvt_a(r0, faA, 0, 0); cvt_a(r1, faA, 1, 0);
   }
   // One K step: fa / fb0 hold its fragments, fan / fbn receive the next step's.
   auto kstep = [&](int kt, bf16x8 (&fa)[4], bf16x8 (&fb0)[4], bf16x8 (&fan)[4], bf16x8 (&fbn)[4]) {
     const bool more = kt + 1 < nk;                       // a next step exists
-    const int mac = kt / KSUB, sub = kt % KSUB;
+    const int kr = kt / REP, mode = kt % REP;            // real step; 0 .. REP - 1: which product of the split
+    const int mac = kr / KSUB, sub = kr % KSUB;
+    const bool a_issue = mode == 0;                      // the A stream moves once per real step
+    const bool a_edge = sub == KSUB - 1 && mode == REP - 1;  // step kt + 1 opens macro stage mac + 1
     bf16x8 fb1[4];
     araw_t ra[2][AF32 ? 2 : 1], rb[2][AF32 ? 2 : 1];
     __builtin_amdgcn_sched_barrier(0);
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
     if (more) {
       // my stream's stage kt + 1 has landed (its younger instructions stay in flight); my reads of stage kt are done
       if (w_loader) ln2_wait_vm<(NSW - 2) * NWI>();
-      else if (sub == KSUB - 1) ln2_wait_vm<(NSA - 3) * NAI + (KSUB - 1) * NAS>();  // step kt + 1 opens macro stage mac + 1
+      else if (a_edge) ln2_wait_vm<REP == 1 ? (NSA - 3) * NAI + (KSUB - 1) * NAS : (NSA - 2) * NAI>();  // all of macro stage mac - 1 + NSA is out by now when REP > 1
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -514,17 +527,17 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
         const int m = mt * 4 + q;  // 0..15
         if ((m + 1) % (16 / NWI) == 0 || (m + 1) % (16 / NAS) == 0) {
           if (w_loader) { if ((m + 1) % (16 / NWI) == 0) dma_w(wst, wslot, m / (16 / NWI)); }
-          else { if ((m + 1) % (16 / NAS) == 0) dma_a(ast, aslot, sub * NAS + m / (16 / NAS)); }
+          else { if (a_issue && (m + 1) % (16 / NAS) == 0) dma_a(ast, aslot, sub * NAS + m / (16 / NAS)); }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (mt == 1 && more) {  // first A part has had 8 MFMAs to arrive: convert it, fetch the second part
-        cvt_a(ra, fan, 0);
+        cvt_a(ra, fan, 0, kt + 1);
         read_a(kt + 1, 1, rb);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (more) cvt_a(rb, fan, 1);
+    if (more) cvt_a(rb, fan, 1, kt + 1);
   };
 
 #pragma unroll 1
@@ -658,14 +671,14 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
   }
 }
 
-template <bool AF32, int RG, int NSW, int NSA, int EPI>
+template <bool AF32, int RG, int NSW, int NSA, int EPI, int REP = 1>
 int launch_ln2e(const LnArgs& p, hipStream_t st) {
   constexpr int BM = 64 * RG;
   constexpr int LDS = NSW * LN_N * 64 + NSA * BM * 256;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static std::atomic<unsigned long long> lds_ok{0};
-  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_ln2_kernel<AF32, RG, NSW, NSA, EPI>), LDS, lds_ok)) return e;
-  hipLaunchKernelGGL((gemm_ln2_kernel<AF32, RG, NSW, NSA, EPI>), dim3((p.M + BM - 1) / BM), dim3(256 * RG), LDS, st, p);
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_ln2_kernel<AF32, RG, NSW, NSA, EPI, REP>), LDS, lds_ok)) return e;
+  hipLaunchKernelGGL((gemm_ln2_kernel<AF32, RG, NSW, NSA, EPI, REP>), dim3((p.M + BM - 1) / BM), dim3(256 * RG), LDS, st, p);
   return care_launch_status();
 }
 
@@ -705,6 +718,10 @@ static int gemm_ln_impl(const void* A, int64_t lda, int a_dtype, const void* W, 
   // version 2 moves A in 256-byte pieces of a row: K must be a whole number of them
   const bool v2_ok = !pos && K % (a_dtype == CARE_F32 ? 64 : 128) == 0;
   if (w_packed && !(v2 && v2_ok)) return CARE_ESHAPE;  // only the version-2 kernels read the packed order
+  if (w_packed == 2) {  // split-bf16 products (care_pack_ln_weight_split): fp32 A, no residual
+    if (a_dtype != CARE_F32 || res) return CARE_ESHAPE;
+    return big ? launch_ln2e<true, 2, 2, 3, 0, 3>(p, st) : launch_ln2e<true, 1, 3, 4, 0, 3>(p, st);
+  }
   if (v2 && v2_ok) {
     if (a_dtype == CARE_F32) return big ? launch_ln2<true, 2, 2, 3>(p, st) : launch_ln2<true, 1, 3, 4>(p, st);
     return big ? launch_ln2<false, 2, 2, 3>(p, st) : launch_ln2<false, 1, 3, 4>(p, st);
@@ -727,6 +744,45 @@ extern "C" int care_gemm_ln_packed(const void* A, int64_t lda, int a_dtype, cons
                                    int out_grp_rows, int out_row_off, void* stream) {
   return gemm_ln_impl(A, lda, a_dtype, W_packed, 1, bias, res, ldres, nullptr, gamma, beta, eps, out, out_bf16, ldo, M, N,
                       K, grp, out_grp_rows, out_row_off, stream);
+}
+
+extern "C" int care_gemm_ln_split(const void* A, int64_t lda, const void* W_split, const float* bias, const float* gamma,
+                                  const float* beta, float eps, float* out, void* out_bf16, int64_t ldo, int M, int N,
+                                  int K, int grp, int out_grp_rows, int out_row_off, void* stream) {
+  return gemm_ln_impl(A, lda, CARE_F32, W_split, 2, bias, nullptr, 0, nullptr, gamma, beta, eps, out, out_bf16, ldo, M, N, K,
+                      grp, out_grp_rows, out_row_off, stream);
+}
+
+namespace {
+// W [512, K] fp32 -> the stream of the split-bf16 kernels: per real K step the three 32-KB LDS images
+// w_hi, w_lo, w_hi (w_hi = bf16(w), w_lo = bf16(w - w_hi)), rows and swizzled chunks as in pack_ln_weight_kernel
+__global__ void pack_ln_weight_split_kernel(const float* W, bf16_t* Wp, int K) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk of one of the three images
+  const int64_t total = (int64_t)LN_N * K / 8 * 3;
+  if (slot >= total) return;
+  const int c = (int)(slot & 3), n = (int)((slot >> 2) % LN_N);
+  const int64_t img = slot / (4 * LN_N);     // 3 kt + j
+  const int kt = (int)(img / 3), j = (int)(img % 3);
+  const int src_chunk = c ^ ((n & 8) >> 2);
+  const float* src = W + (int64_t)n * K + kt * 32 + src_chunk * 8;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bf16_t hi = (bf16_t)src[e];
+    o[e] = j == 1 ? (bf16_t)(src[e] - (float)hi) : hi;
+  }
+  reinterpret_cast<bf16x8*>(Wp)[slot] = o;
+}
+}  // namespace
+
+extern "C" int care_pack_ln_weight_split(const float* W, void* W_split, int N, int K, void* stream) {
+  if (!W || !W_split) return CARE_EINVAL;
+  if (N != LN_N || K <= 0 || K % 64 != 0) return CARE_ESHAPE;
+  if (!care_aligned16(W) || !care_aligned16(W_split)) return CARE_EALIGN;
+  const int64_t total = (int64_t)LN_N * K / 8 * 3;
+  hipLaunchKernelGGL(pack_ln_weight_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+                     reinterpret_cast<bf16_t*>(W_split), K);
+  return care_launch_status();
 }
 
 namespace {

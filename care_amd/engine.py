@@ -129,8 +129,10 @@ class HipEngine:
         opt, d = self.opt, self.d
         # Concept detection ends in a DISCRETE choice (top-30 of 500, pred_attribute.py:264) whose
         # neighbouring probabilities differ by ~1e-4, below bf16 operand noise (~1.5e-3 measured).
-        # So with a concept head the feature-embedding GEMMs stay in exact f32 MFMA even in bf16
-        # mode (once per clip, 12% of the FLOPs); everything downstream of the choice is bf16.
+        # So with a concept head the feature-embedding GEMMs keep fp32 operands even in bf16 mode:
+        # as three bf16 MFMA passes over hi/lo pieces (care_gemm_ln_split, memory within ~3e-5 of
+        # fp32, concept probabilities ~3e-6) where the fused kernel applies, in exact f32 MFMA
+        # otherwise (or with CARE_ENC_SPLIT=0); everything downstream of the choice is bf16.
         enc_wt = f32 if (self.has_concepts and opt["encoder"] == "Embedder") else wt
         for ch in self.modality:
             p = "encoder.Encoder_{}".format(ch.upper())
@@ -193,6 +195,11 @@ class HipEngine:
                     Wp = torch.empty_like(W)
                     call("care_pack_ln_weight", ptr(W), ptr(Wp), 512, W.shape[1])
                     w[name + "#packed"] = Wp
+                elif (W is not None and name.startswith("enc_w_") and W.dtype == torch.float32 and W.shape[0] == 512 and
+                      W.shape[1] % 64 == 0 and opt["encoder"] == "Embedder" and os.environ.get("CARE_ENC_SPLIT", "1") != "0"):
+                    Ws = torch.empty(3 * W.shape[1] * 512, device=self.device, dtype=torch.bfloat16)
+                    call("care_pack_ln_weight_split", ptr(W), ptr(Ws), 512, W.shape[1])
+                    w[name + "#split"] = Ws
         self.w = w
         self._graphs.clear()
 
@@ -428,8 +435,9 @@ class HipEngine:
             if n != self.rows_of[ch]:
                 raise ValueError("modality `{}`: {} rows, expected {}".format(ch, n, self.rows_of[ch]))
             x2 = x.view(B * n, x.shape[2])
+            Ws = w.get("enc_w_" + ch + "#split")
             fused = (opt["encoder"] == "Embedder" and self.as_ok and d == 512 and
-                     w["enc_w_" + ch].dtype == torch.bfloat16 and x2.shape[1] % 32 == 0)
+                     (w["enc_w_" + ch].dtype == torch.bfloat16 or Ws is not None) and x2.shape[1] % 32 == 0)
             lin = None if fused else self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch],
                                                self.ws("enc_lin", (B * n, d)), tag="enc_gemm")
             in_mem = ch in self.dec_mod
@@ -438,7 +446,11 @@ class HipEngine:
             else:
                 dst, dstb, grp_rows, off = self.ws("enc_side_" + ch, (B, n, d)), None, n, 0
             ln_kw = dict(grp=n, out_grp_rows=grp_rows, out_row_off=off)
-            if fused:  # Linear + bias + LayerNorm in one kernel, raw fp32 features streamed by LDS-DMA
+            if fused and Ws is not None:  # the same, fp32 operands as hi/lo bf16 pieces (concept models)
+                call("care_gemm_ln_split", ptr(x2), x2.stride(0), ptr(Ws), ptr(w["enc_b_" + ch]), ptr(w["enc_g_" + ch]),
+                     ptr(w["enc_be_" + ch]), self.eps, ptr(dst), ptr(dstb), dst.stride(-2), B * n, d, x2.shape[1], n,
+                     grp_rows, off, tag="enc_gemm")
+            elif fused:  # Linear + bias + LayerNorm in one kernel, raw fp32 features streamed by LDS-DMA
                 self.gemm_ln(x2, w["enc_w_" + ch], w["enc_b_" + ch], None, w["enc_g_" + ch], w["enc_be_" + ch],
                              dst, dstb, tag="enc_gemm", Wp=w.get("enc_w_" + ch + "#packed"), **ln_kw)
             elif opt["encoder"] == "Embedder":

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 9
+#define CARE_ABI_VERSION 10
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -199,6 +199,21 @@ int care_gemm_ln_packed(const void* A, int64_t lda, int a_dtype, const void* W_p
                         const float* beta, float eps, float* out, void* out_bf16, int64_t ldo,
                         int M, int N, int K, int grp, int out_grp_rows, int out_row_off,
                         void* stream);
+
+/*
+ * care_pack_ln_weight_split / care_gemm_ln_split: the Embedder's Linear -> LayerNorm
+ *   (models/Encoder.py:167) for models whose memory feeds the DISCRETE concept choice
+ *   (pred_attribute.py:88-125,262-264): fp32 A and an fp32 [512, K] weight, multiplied as
+ *   a_hi w_hi + a_hi w_lo + a_lo w_hi with x_hi = bf16(x), x_lo = bf16(x - x_hi) - three bf16 MFMA
+ *   passes accumulated in fp32 (operand error ~2^-17 instead of bf16's 2^-9; the a_lo w_lo term,
+ *   ~2^-18 relative, is dropped).  W_split: 3 * K * 1024 bytes (per K step of 32 the LDS images of
+ *   w_hi, w_lo, w_hi).  K % 64 == 0; no residual, no position table.
+ */
+int care_pack_ln_weight_split(const float* W, void* W_split, int N, int K, void* stream);
+int care_gemm_ln_split(const void* A, int64_t lda, const void* W_split, const float* bias,
+                       const float* gamma, const float* beta, float eps, float* out,
+                       void* out_bf16, int64_t ldo, int M, int N, int K, int grp,
+                       int out_grp_rows, int out_row_off, void* stream);
 
 /*
  * care_group_mean: out[g, col_off + c] = mean over the grp rows of group g of x[., c].

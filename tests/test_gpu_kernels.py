@@ -433,6 +433,38 @@ def test_gemm_ln_fused(a_f32, M, K, form, monkeypatch):
     assert torch.equal(outb, out.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("M,K", [(56, 64), (28 * 37, 2048), (28 * 9 + 5, 4096), (300, 1024), (28 * 400, 2048)])
+def test_gemm_ln_split_products(M, K):
+    """care_gemm_ln_split: fp32 operands as hi/lo bf16 pieces, three MFMA passes.  Against the SAME three
+    products in float64 (what the kernel computes, up to fp32 accumulation order) and against the plain
+    fp32 Linear -> LayerNorm (what it stands in for: ~6e-6 typical error on O(1) outputs)."""
+    d, grp = 512, 28 if M % 28 == 0 else M
+    A = _rand(M, K, seed=60)
+    W = _rand(d, K, seed=61, scale=1 / math.sqrt(K))
+    bias, g, b = _rand(d, seed=62), _rand(d, seed=63), _rand(d, seed=64)
+    ngrp = M // grp
+    out = torch.zeros(ngrp, grp + 3, d, device=DEV)
+    outb = torch.zeros(ngrp, grp + 3, d, device=DEV, dtype=torch.bfloat16)
+    Ws = torch.empty(3 * K * d, device=DEV, dtype=torch.bfloat16)
+    _call("care_pack_ln_weight_split", _p(W), _p(Ws), d, K)
+    _call("care_gemm_ln_split", _p(A), K, _p(Ws), _p(bias), _p(g), _p(b), 1e-12, _p(out), _p(outb), d, M, d, K, grp, grp + 3, 2)
+    hi = lambda x: x.to(torch.bfloat16).float()
+    lo = lambda x: (x - hi(x)).to(torch.bfloat16).float()
+    y3 = (hi(A).double() @ hi(W).double().t() + hi(A).double() @ lo(W).double().t() + lo(A).double() @ hi(W).double().t())
+    ln = lambda y: torch.nn.functional.layer_norm(y.float() + bias, (d,), g, b, 1e-12).view(ngrp, grp, d)
+    torch.cuda.synchronize()
+    got = out[:, 2:2 + grp]
+    assert (got - ln(y3)).abs().max().item() < 3e-6 * math.sqrt(K / 64)  # fp32 accumulation only
+    err = (got - ln(A.double() @ W.double().t())).abs()  # ~6e-6 per output (2^-17.5 per product), gamma up to ~4
+    assert err.mean().item() < 1e-5 and err.max().item() < 1.2e-4
+    assert out[:, :2].abs().max().item() == 0 and out[:, 2 + grp:].abs().max().item() == 0
+    assert torch.equal(outb, out.to(torch.bfloat16))
+    # a bf16 weight image, a residual or an unpacked K are refused, not silently mishandled
+    from care_amd._lib import CareHipError
+    with pytest.raises(CareHipError):
+        _call("care_gemm_ln_split", _p(A), K + 32, _p(Ws), _p(bias), _p(g), _p(b), 1e-12, _p(out), None, d, M, d, K + 32, grp, grp + 3, 2)
+
+
 # --------------------------------------------------------------------------------------------
 # absorbed cross-attention (attention_latent.hip, heads.hip)
 @pytest.mark.parametrize("rows,heads", [(1, 8), (7, 8), (16, 8), (250, 8), (1029, 8), (33, 4)])

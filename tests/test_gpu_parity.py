@@ -107,6 +107,11 @@ BF16_MAX, BF16_MEAN = 1.9e-2, 3.0e-3  # measured over the 18 fixtures: 1.48e-2 /
 BF16_LSE, BF16_LSE_PEAKED = 1e-4, 3.5e-2  # measured 5.5e-5; 2.2e-2 .. 2.6e-2 on the peaked fixtures
 
 
+# concept models, bf16 mode: the embedder multiplies fp32 operands as three bf16 passes (a_hi w_hi + a_hi w_lo
+# + a_lo w_hi); what is dropped is ~2^-17 per product
+SPLIT_MEM, SPLIT_PREDS = 4e-5, 1e-5  # CPU emulation over the CARE fixtures: 2.2e-5 / 2.9e-6
+
+
 def _record(name, **values):
     """Measured errors -> gpurun_out/bf16_err.jsonl (scratch; the bars above are set from it)."""
     import json
@@ -124,10 +129,11 @@ def test_encoding_and_teacher_forced_bf16(golden):
     model = _model(opt, P, "bf16")
     enc = model.encoding_phase(_dev(feats))
     if "preds_attr" in z and opt["encoder"] == "Embedder":
-        # concept path is exact even in bf16 mode: same labels, same probabilities
-        assert _maxdiff(enc["preds_attr"], z["preds_attr"]) < ATOL_FP32
+        # the concept path keeps fp32 operands in bf16 mode (hi/lo split products, care_gemm_ln_split):
+        # same labels; probabilities and memory within the split's error of the reference
+        assert _maxdiff(enc["preds_attr"], z["preds_attr"]) < SPLIT_PREDS
         assert np.array_equal(enc["semantic_labels"].cpu().numpy(), z["semantic_labels"])
-        assert _maxdiff(enc["encoder_hidden_states"][0], z["encoder_hidden_states_clip0"]) < ATOL_FP32
+        assert _maxdiff(enc["encoder_hidden_states"][0], z["encoder_hidden_states_clip0"]) < SPLIT_MEM
     else:
         assert _maxdiff(enc["encoder_hidden_states"][0], z["encoder_hidden_states_clip0"]) < BF16_MAX
     out = model.feedforward_step({"feats": _dev(feats), "input_ids": ids.to("cuda:0")})
