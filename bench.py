@@ -253,8 +253,15 @@ def main():
             eng.translate_beam(feats, args.beam, args.beam, use_graph=not args.no_graph, lean=True)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
+        _lib.TIMING = {}   # instrumented pass (untimed): HIP events around every tagged launch
+        eng.translate_beam(feats, args.beam, args.beam, use_graph=False, lean=True)
+        torch.cuda.synchronize()
+        timing, _lib.TIMING = _lib.TIMING, None
+        kernels = {t: dict(launches=len(ev), avg_us=round(1e3 * sum(s.elapsed_time(e) for s, e in ev) / len(ev), 2),
+                           total_ms=round(sum(s.elapsed_time(e) for s, e in ev), 3)) for t, ev in timing.items()}
+        kernels = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"]))
         print(json.dumps(dict(metric="captions/sec (beam %d)" % args.beam, value=round(B / dt, 1), unit="captions/s",
-                              n_gpus=1, steps=args.steps, ms_per_step=round(dt * 1e3, 3), dtype=args.dtype,
+                              n_gpus=1, steps=args.steps, ms_per_step=round(dt * 1e3, 3), dtype=args.dtype, kernels=kernels,
                               config=dict(config_name=args.config, clips_per_gpu_per_step=B, beam_size=args.beam,
                                           rows_per_decoder_step=B * args.beam))), flush=True)
         return

@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -62,7 +62,7 @@ SIGNATURES = {
 }
 PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_argmax_parts": (c_int, [c_int]),
          "care_argmax_parts_bf16": (c_int, [c_int, c_int]),
-         "care_argmax_parts_bf16_min": (c_int, [c_int, c_int, c_int])}
+         "care_argmax_parts_bf16_min": (c_int, [c_int, c_int, c_int, c_int, c_int])}
 
 _lib = None
 

@@ -36,7 +36,21 @@
 #include "care_common.h"
 
 #ifndef CARE_LAT_DBG
-#define CARE_LAT_DBG 0  // ablation builds (tools/latent_probe.py): 1 no ct stores, 2 no qt loads, 4 no arithmetic
+#define CARE_LAT_DBG 0  // ablation builds (tools/lat_ablate.sh): 1 no ct stores, 2 no qt loads, 4 no arithmetic, 8 direct 8-byte stores
+#endif
+
+// Cache policy of the streams (ablation: -DCARE_LAT_LD_AUX=0 -DCARE_LAT_ST_NT=0).  The clips' memory, q~ and c~ are
+// each touched once per launch: marked non-temporal they stop evicting one another (and the next kernels' weights)
+// from L2 / the memory-side cache.  *Measured* 32768 rows x 84 keys, same box: 673 us plain, 658 nt stores only,
+// 629 nt loads only, 574 both; a later box: 622-670 plain, 571-608 all three nt, 535-568 with plain q~ loads.
+#ifndef CARE_LAT_LD_AUX
+#define CARE_LAT_LD_AUX 2  // cache-policy immediate of the LDS-DMA loads: 1 sc0, 2 nt, 16 sc1
+#endif
+#ifndef CARE_LAT_Q_AUX
+#define CARE_LAT_Q_AUX CARE_LAT_LD_AUX  // q~ too (whole pass, B = 32768: 57.4 ms plain, 55.0 with plain q~ loads, 54.7 all nt)
+#endif
+#ifndef CARE_LAT_ST_NT
+#define CARE_LAT_ST_NT 1
 #endif
 
 namespace {
@@ -54,9 +68,22 @@ struct LatArgs {
   const float* bias; int bias_ld;     // [heads][nkeys] or null
   bf16_t* ct; int64_t ldc;            // [rows][heads][512]
   int rows, heads;
+  int paired;                         // two rows of a clip per wave (see the kernel)
 };
 
 __device__ __forceinline__ int lat_swz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
+
+// s_waitcnt vmcnt(n) for a wave-uniform n in 16..32 (or 48); anything else waits for more (always safe)
+__device__ __forceinline__ void lat_wait_vm(int n) {
+  switch (n) {
+#define LAT_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    LAT_VM_CASE(17) LAT_VM_CASE(18) LAT_VM_CASE(19) LAT_VM_CASE(20) LAT_VM_CASE(21) LAT_VM_CASE(22) LAT_VM_CASE(23)
+    LAT_VM_CASE(24) LAT_VM_CASE(25) LAT_VM_CASE(26) LAT_VM_CASE(27) LAT_VM_CASE(28) LAT_VM_CASE(29) LAT_VM_CASE(30)
+    LAT_VM_CASE(31) LAT_VM_CASE(32) LAT_VM_CASE(48)
+#undef LAT_VM_CASE
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+  }
+}
 
 template <int WAVES, int NSLOT>
 __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs p) {
@@ -80,7 +107,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
                                ((lane ^ lat_swz(i)) << 4);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(ring + slot * CH_BYTES + i * 1024),
-                                       16, 0, 0);
+                                       16, 0, CARE_LAT_LD_AUX);
     }
   };
 
@@ -97,7 +124,51 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
   for (int m = 0; m < 8; ++m)
     toff[m] = trow * 1024 + ((((m * 2 + (tp >> 1)) ^ lat_swz(trow)) & 15) << 4) + 8 * (tp & 1);
 
-  const int headc = min(fr, p.heads - 1);
+  // MFMA column fr = (sub-row, head).  With <= 8 heads and rows that share a clip's memory (beam search:
+  // rows_per_kv consecutive rows per clip) a wave takes TWO rows of the clip at once - columns 0..7 the
+  // first, 8..15 the second - so the memory streams once per pair instead of once per row, at the same
+  // MFMA cost (the N axis is 16 wide either way).  Work items: `ipc` per clip, the last one of a clip
+  // with an odd row count is half empty.
+  const bool paired = p.paired != 0;
+  const int ipc = paired ? (p.rows_per_kv + 1) / 2 : 1;
+  const int items = paired ? (p.rows / p.rows_per_kv) * ipc : p.rows;
+  const int ncols = paired ? 2 * p.heads : p.heads;  // columns in use
+  const int nq = ncols <= 8 ? 8 : 16;                // DMA instructions of a query stage
+  auto col_sub = [&](int i) { return paired && i >= p.heads ? 1 : 0; };
+  auto col_head = [&](int i) { return paired ? (i >= p.heads ? i - p.heads : i) : min(i, p.heads - 1); };
+  const int csub = col_sub(fr), headc = fr < ncols ? col_head(fr) : 0;
+  auto first_row = [&](int item) { return paired ? (item / ipc) * p.rows_per_kv + 2 * (item % ipc) : item; };
+  // output staging (see the store phase): my 8-byte piece of global chunk 2 m + (fg >> 1) of column fr
+  int woff[8];
+#pragma unroll
+  for (int mm = 0; mm < 8; ++mm) woff[mm] = fr * 1024 + ((((2 * mm + (fg >> 1)) ^ lat_swz(fr)) & 15) << 4) + 8 * (fg & 1);
+  // a query stage of 8 rows: the idle columns 8..15 read rows 0..7 again (defined values, never stored)
+  const int frq = fr < nq ? fr : fr - 8;
+  int qoff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) qoff[r] = frq * 1024 + ((((r * 4 + fg) ^ lat_swz(frq)) & 15) << 4);
+
+  // The expanded query of an item travels through the SAME ring as one more stage in front of the
+  // item's memory chunks: LDS row i = the 1 KB of column i (same swizzle, so the B fragments are read
+  // exactly like a chunk's A fragments).  A plain global load at the row start would be waited for
+  // with vmcnt(0) - the wave's whole DMA queue drained once per row (measured: 597 -> 465 us of the
+  // 658 us launch at 32768 rows x 84 keys were the q~ loads and c~ stores).
+  auto stage_q = [&](int item, int slot) {
+    const int row = first_row(item);
+    const bool second = paired && (row % p.rows_per_kv) + 1 < p.rows_per_kv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i >= nq) break;
+      const int ci = i < ncols ? i : 0;
+      const int r = row + (col_sub(ci) && second ? 1 : 0);
+      const unsigned char* g = reinterpret_cast<const unsigned char*>(p.qt + (int64_t)r * p.ldq + col_head(ci) * LAT_D) +
+                               ((lane ^ lat_swz(i)) << 4);
+      if (CARE_LAT_DBG & 2) continue;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(ring + slot * CH_BYTES + i * 1024),
+                                       16, 0, CARE_LAT_Q_AUX);
+    }
+  };
 
   // additive per-(head, key) term, the same for every row: hybrid bias (0 without one) for valid
   // keys, -inf for the padding keys of the last chunk.  Staged in LDS once per block - a global
@@ -108,17 +179,31 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
     sbias[i] = key < p.nkeys ? (p.bias ? p.bias[h * p.bias_ld + key] : 0.f) : -INFINITY;
   }
   __syncthreads();
-  int t = 0;  // chunks consumed so far by this wave -> ring slot
-  if (gw < p.rows) stage(gw, 0, 0);
+  int t = 0;  // stages consumed so far by this wave -> ring slot
+  if (gw < items) stage_q(gw, 0);
+  int n_stored = 0;  // store instructions of the previous item: younger than the stage being waited for
 
-  for (int row = gw; row < p.rows; row += total_waves) {
-    // expanded query of this row: B operand of the S MFMAs, resident for all chunks
+  for (int item = gw; item < items; item += total_waves) {
+    const int row = first_row(item);
+    // is my column a real (row, head)?  The second row of a pair must belong to the same clip.
+    const bool col_ok = fr < ncols && (csub == 0 || (row % p.rows_per_kv) + 1 < p.rows_per_kv);
+    const int myrow = row + (col_ok ? csub : 0);
+    // ---- query stage: B operand of the S MFMAs, resident for all chunks
     bf16x8 qf[16];
-    const bf16_t* qrow = p.qt + (int64_t)row * p.ldq + headc * LAT_D + fg * 8;
+    {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stage(row, 0, (t + 1) % NSLOT);
+      // the query has landed; younger: chunk 0 (16) and, in program order before it, the previous item's stores
+      // (loads and stores retire in issue order on gfx9-family vmcnt, which is what hipcc itself assumes)
+      lat_wait_vm(16 + n_stored);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* sq = ring + (t % NSLOT) * CH_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      if (CARE_LAT_DBG & 2) { qf[ks] = bf16x8{}; asm volatile("" : "+v"(qf[ks])); }
-      else qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32);
+      for (int ks = 0; ks < 16; ++ks) {
+        if (CARE_LAT_DBG & 2) { qf[ks] = bf16x8{}; asm volatile("" : "+v"(qf[ks])); }
+        else qf[ks] = *reinterpret_cast<const bf16x8*>(sq + qoff[ks & 3] + (ks >> 2) * 256);
+      }
+      ++t;
     }
 
     f32x4 acc[32];
@@ -130,12 +215,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
       const int slot = t % NSLOT;
       // next chunk (of this row or of the wave's next row) into the slot consumed one iteration ago
       const bool more_here = c + 1 < nch;
-      const int nrow = more_here ? row : row + total_waves;
-      const bool have_next = nrow < p.rows;
+      const bool have_next = more_here || item + total_waves < items;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS reads of that slot are done
-      if (have_next) {
-        stage(nrow, more_here ? c + 1 : 0, (t + 1) % NSLOT);
+      if (more_here) {
+        stage(row, c + 1, (t + 1) % NSLOT);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // everything but the 16 newest DMAs
+      } else if (have_next) {
+        stage_q(item + total_waves, (t + 1) % NSLOT);
+        if ((CARE_LAT_DBG & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nq == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -151,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s, 0, 0, 0);
       }
       // lane (head fr, group fg) holds keys c*16 + fg*4 + r
-      s += *reinterpret_cast<const f32x4*>(sbias + fr * 128 + c * CH_KEYS + fg * 4);
+      s += *reinterpret_cast<const f32x4*>(sbias + headc * 128 + c * CH_KEYS + fg * 4);
 
       // ---- online softmax over the keys of each head, with a LAZY reference maximum: the
       // exponentials are taken against m_ref, which only moves (and only then are the 128
@@ -216,14 +305,63 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    if (fr < p.heads && !(CARE_LAT_DBG & 1)) {
-      bf16_t* out = p.ct + (int64_t)row * p.ldc + fr * LAT_D + fg * 4;
+    // Through the ring slot of the item's last chunk (consumed, not restaged before the next query turn): every
+    // lane writes its 8-byte pieces at the swizzled chunk positions, then each column's 1 KB goes out as ONE store
+    // instruction of full lines (the direct form was 32 instructions of 32-byte pieces per column: 86 us of the
+    // 599 us launch at 32768 rows x 84 keys).
+    n_stored = 0;
+    if (CARE_LAT_DBG & 8) {  // ablation: the direct form
+      if (col_ok) {
+        bf16_t* out = p.ct + (int64_t)myrow * p.ldc + headc * LAT_D + fg * 4;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[m][r] * inv);
+          *reinterpret_cast<bf16x4*>(out + m * 16) = o;
+        }
+      }
+      n_stored = 32;
+    } else if (!(CARE_LAT_DBG & 1)) {
+      const unsigned ob = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(ring + ((t - 1) % NSLOT) * CH_BYTES);
 #pragma unroll
       for (int m = 0; m < 32; ++m) {
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[m][r] * inv);
-        *reinterpret_cast<bf16x4*>(out + m * 16) = o;
+        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ob + woff[m & 7]), "v"(o), "n"((m >> 3) * 256) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const bool second = paired && (row % p.rows_per_kv) + 1 < p.rows_per_kv;
+      const unsigned rb = ob + lane * 16;
+#pragma unroll
+      for (int i0 = 0; i0 < 16; i0 += 8) {
+        if (i0 >= ncols) break;
+        f32x4 v[8];
+        asm volatile(
+            "ds_read_b128 %0, %8 offset:%9\n\t"
+            "ds_read_b128 %1, %8 offset:%9+1024\n\t"
+            "ds_read_b128 %2, %8 offset:%9+2048\n\t"
+            "ds_read_b128 %3, %8 offset:%9+3072\n\t"
+            "ds_read_b128 %4, %8 offset:%9+4096\n\t"
+            "ds_read_b128 %5, %8 offset:%9+5120\n\t"
+            "ds_read_b128 %6, %8 offset:%9+6144\n\t"
+            "ds_read_b128 %7, %8 offset:%9+7168\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+            : "v"(rb), "n"(i0 * 1024)
+            : "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = i0 + k;
+          if (i < ncols && (col_sub(i) == 0 || second)) {
+            unsigned char* dst = reinterpret_cast<unsigned char*>(p.ct + (int64_t)(row + col_sub(i)) * p.ldc + col_head(i) * LAT_D) +
+                                 ((lane ^ lat_swz(i)) << 4);
+            if (CARE_LAT_ST_NT) __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(dst));
+            else *reinterpret_cast<f32x4*>(dst) = v[k];
+            ++n_stored;
+          }
+        }
       }
     }
   }
@@ -235,7 +373,9 @@ int launch_latent(const LatArgs& p, hipStream_t st) {
   static std::atomic<unsigned long long> lds_ok{0};  // per device (care_common.h)
   if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&attention_latent_kernel<WAVES, NSLOT>), LDS, lds_ok))
     return e;
-  const int blocks = min((p.rows + WAVES - 1) / WAVES, 256);
+  const bool paired = p.paired != 0;
+  const int items = paired ? (p.rows / p.rows_per_kv) * ((p.rows_per_kv + 1) / 2) : p.rows;
+  const int blocks = min((items + WAVES - 1) / WAVES, 256);
   hipLaunchKernelGGL((attention_latent_kernel<WAVES, NSLOT>), dim3(blocks), dim3(WAVES * 64), LDS, st, p);
   return care_launch_status();
 }
@@ -255,6 +395,8 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
   p.mem = reinterpret_cast<const bf16_t*>(mem); p.mem_bs = mem_batch_stride; p.mem_rs = mem_row_stride;
   p.rows_per_kv = rows_per_kv; p.nkeys = nkeys; p.bias = bias; p.bias_ld = bias_ld;
   p.ct = reinterpret_cast<bf16_t*>(ct); p.ldc = ldc; p.rows = rows; p.heads = heads;
+  static const int pair_ok = [] { const char* e = getenv("CARE_LAT_PAIR"); return e ? atoi(e) : 1; }();  // A/B switch
+  p.paired = pair_ok && heads <= 8 && rows_per_kv > 1 && rows % rows_per_kv == 0;
   hipStream_t st = (hipStream_t)stream;
   // tuning: 0 = 4 waves x 2 slots, 1 = 3 waves x 3 slots (read once; initialisation is thread-safe)
   static const int cfg = [] { const char* e = getenv("CARE_LAT_CFG"); return e ? atoi(e) : 0; }();

@@ -659,19 +659,27 @@ extern "C" int care_argmax_parts_bf16(int M, int N) {
   return pick_ns((M + 127) / 128, (N + TILE_N - 1) / TILE_N);
 }
 
-extern "C" int care_argmax_parts_bf16_min(int M, int N, int min_parts) {
-  if (M <= 0 || N <= 0 || min_parts <= 0) return CARE_EINVAL;
-  return pick_ns_min((M + 127) / 128, (N + TILE_N - 1) / TILE_N, min_parts);
-}
-
-// the 256-row-panel kernel for large row counts (csrc/gemm_vocab.hip)
+// the 256-row-panel kernels for large row counts (csrc/gemm_vocab.hip)
 extern "C" int care_vocab32_applies(int M, int N, int K, int a_dtype, int has_labels);
 extern "C" int care_vocab32_launch(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
                                    int M, int N, int ns, void* stream);
+extern "C" int care_collect32_launch(const void* A, int64_t lda, const void* W, const float* thr, int32_t* cnt, float* cval,
+                                     int32_t* cidx, int cap, int M, int N, int ns, void* stream);
+extern "C" int care_vocab32_ranges(int M, int N, int min_parts);
+
+// column ranges of the `_min` statistics pass (beam search): on the 256-row kernel its own rule (whole launch rounds)
+static bool min_uses_v32(int M, int N, int K, int a_dtype, int min_parts) {
+  return min_parts <= 32 && care_vocab32_applies(M, N, K, a_dtype, 0);
+}
+extern "C" int care_argmax_parts_bf16_min(int M, int N, int K, int a_dtype, int min_parts) {
+  if (M <= 0 || N <= 0 || K <= 0 || min_parts <= 0) return CARE_EINVAL;
+  if (min_uses_v32(M, N, K, a_dtype, min_parts)) return care_vocab32_ranges(M, N, min_parts);
+  return pick_ns_min((M + 127) / 128, (N + TILE_N - 1) / TILE_N, min_parts);
+}
 
 static int gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax, int32_t* pidx,
                            float* psum, const int32_t* labels, float* plab, int M, int N, int K, int min_parts,
-                           void* stream) {
+                           bool min_entry, void* stream) {
   int rc = as_check(A, lda, a_dtype, W, M, N, K);
   if (rc) return rc;
   if (!pmax || !pidx || !psum || ((labels != nullptr) != (plab != nullptr))) return CARE_EINVAL;
@@ -682,9 +690,12 @@ static int gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void*
   p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.labels = labels; p.plab = plab;
   p.panels = (M + 127) / 128;
   p.ns = pick_ns_min(p.panels, (N + TILE_N - 1) / TILE_N, min_parts);
-  // same number of column ranges (care_argmax_parts_bf16*), 256-row panels: half the W streaming
-  if (care_vocab32_applies(M, N, K, a_dtype, labels != nullptr))
+  // 256-row panels: half the W streaming.  The greedy entry keeps the range count of care_argmax_parts_bf16, the
+  // `_min` entry the one of care_argmax_parts_bf16_min.
+  if (care_vocab32_applies(M, N, K, a_dtype, labels != nullptr)) {
+    if (min_entry && min_uses_v32(M, N, K, a_dtype, min_parts)) p.ns = care_vocab32_ranges(M, N, min_parts);
     return care_vocab32_launch(A, lda, W, pmax, pidx, psum, M, N, p.ns, stream);
+  }
   const int blocks = plan_stream(p, false);
   hipStream_t st = (hipStream_t)stream;
   if (labels && plab)
@@ -697,14 +708,14 @@ static int gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void*
 extern "C" int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
                                      int32_t* pidx, float* psum, const int32_t* labels, float* plab, int M, int N,
                                      int K, void* stream) {
-  return gemm_argmax_bf16(A, lda, a_dtype, W, pmax, pidx, psum, labels, plab, M, N, K, 1, stream);
+  return gemm_argmax_bf16(A, lda, a_dtype, W, pmax, pidx, psum, labels, plab, M, N, K, 1, false, stream);
 }
 
 extern "C" int care_gemm_argmax_bf16_min(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
                                          int32_t* pidx, float* psum, int M, int N, int K, int min_parts,
                                          void* stream) {
   if (min_parts <= 0) return CARE_EINVAL;
-  return gemm_argmax_bf16(A, lda, a_dtype, W, pmax, pidx, psum, nullptr, nullptr, M, N, K, min_parts, stream);
+  return gemm_argmax_bf16(A, lda, a_dtype, W, pmax, pidx, psum, nullptr, nullptr, M, N, K, min_parts, true, stream);
 }
 
 extern "C" int care_gemm_collect_bf16(const void* A, int64_t lda, int a_dtype, const void* W, const float* thr,
@@ -714,6 +725,8 @@ extern "C" int care_gemm_collect_bf16(const void* A, int64_t lda, int a_dtype, c
   if (rc) return rc;
   if (!thr || !cnt || !cval || !cidx || cap <= 0) return CARE_EINVAL;
   if (K > 512 || a_dtype != CARE_BF16 || N >= (1 << 24)) return CARE_ESHAPE;  // columns are staged in 24 bits
+  if (care_vocab32_applies(M, N, K, a_dtype, 0))  // the range count only balances the launch here (lists are per row)
+    return care_collect32_launch(A, lda, W, thr, cnt, cval, cidx, cap, M, N, care_vocab32_ranges(M, N, 1), stream);
   AsArgs p{};
   p.A = A; p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.M = M; p.N = N; p.K = K; p.n_split = N;
   p.kslices = 1; p.ldw = K;

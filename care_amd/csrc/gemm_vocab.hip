@@ -41,14 +41,21 @@ struct VArgs {
   const bf16_t* W;
   float* pmax; int32_t* pidx; float* psum;
   int M, N, ns, panels, total_items;
+  // collect mode (beam search, second pass): logits >= thr[row] are appended to the row's candidate list
+  const float* thr; int32_t* cnt; float* cval; int32_t* cidx; int cap;
 };
+
+enum { V_ARGMAX = 0, V_COLLECT = 1 };
+constexpr int V_STAGE = 8192;                  // collect: LDS staging of the candidates of one work item
+constexpr int V_LCAP = (V_STAGE - 8) / 8;
 
 #ifndef CARE_V32_DBG
 #define CARE_V32_DBG 0  // ablation: 2 no MFMA, 16 no statistics, 32 no fragment reads
 #endif
 
-template <int BDEPTH>
+template <int BDEPTH, int MODE>
 __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
+  constexpr bool COLLECT = MODE == V_COLLECT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,21 +63,37 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
   const int tiles_total = (p.N + VT_N - 1) / VT_N;
   const int tpb = (tiles_total + p.ns - 1) / p.ns;
 
-  for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
-    const int range = item % p.ns, panel = item / p.ns;
-    const int t0 = range * tpb, t1 = min(t0 + tpb, tiles_total);
+  // Work distribution: the panels x ns (panel, range) items in panel-major order, cut into gridDim.x contiguous
+  // spans - a block's consecutive items are consecutive column ranges of the SAME panel, so a RUN of them keeps the
+  // activations in registers and the W ring streaming straight through the range boundaries (only the statistics are
+  // closed and written there).  Any item count balances: 4096 clips x beam 5 = 80 panels x 16 ranges = 5 per block.
+  const int i_lo = (int)((long)blockIdx.x * p.total_items / gridDim.x), i_hi = (int)((long)(blockIdx.x + 1) * p.total_items / gridDim.x);
+  for (int item = i_lo; item < i_hi;) {
+    const int panel = item / p.ns, ra = item % p.ns;
+    const int rb = min(p.ns, ra + (i_hi - item));  // ranges ra .. rb - 1 of this panel
+    item += rb - ra;
+    const int t0 = ra * tpb, t1 = min(rb * tpb, tiles_total);
     const int m0 = panel * V_ROWS + wave * 32;
     const int row = m0 + r;
-    if (t0 >= t1) {  // empty range (ns does not divide the tile count evenly)
-      if (h == 0 && row < p.M) {
+    // ranges past the last tile (ns does not divide the tile count evenly) hold nothing
+    if (!COLLECT && h == 0 && row < p.M)
+      for (int range = max(ra, (tiles_total + tpb - 1) / tpb); range < rb; ++range) {
         const int64_t o = (int64_t)row * p.ns + range;
         p.pmax[o] = -INFINITY; p.pidx[o] = 0x7fffffff; p.psum[o] = 0.f;
       }
-      continue;
-    }
-    // every wave is done reading the ring of the previous item
+    if (t0 >= t1) continue;
+    // every wave is done reading the ring of the previous run
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // collect: candidates are staged in LDS behind the ring - [0] = count, then (value, row-in-panel << 24 | column)
+    // pairs - and flushed to the global lists once per run (a global atomic with return inside the tile loop
+    // is a memory round trip that also drains the W tiles in flight); LDS atomics via asm (no vmcnt involvement)
+    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + V_LDS;
+    if (COLLECT && tid == 0) {  // ordered before the first append by the first tile's barrier
+      const int zero = 0;
+      asm volatile("ds_write_b32 %0, %1" ::"v"(lbase), "v"(zero) : "memory");
+    }
+    const float thr = COLLECT ? (row < p.M ? p.thr[row] : INFINITY) : 0.f;
 
     // ---- W tile -> ring slot: wave w copies rows 4w .. 4w + 3 of the 32 (one 1-KiB row per DMA
     // instruction); lane = chunk slot, source chunk = slot ^ (row & 15): conflict-free ds_read_b128
@@ -115,7 +138,14 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
     float tmax = -INFINITY;
     auto stat_piece = [&](int i) {  // logit i of 16
       tmax = fmaxf(tmax, accp[i]);
-      rs += __expf(accp[i] - rref);
+      if (!COLLECT) rs += __expf(accp[i] - rref);
+    };
+    auto append_global = [&](int grow, float v, int c) {
+      const int pos = atomicAdd(&p.cnt[grow], 1);
+      if (pos < p.cap) {
+        p.cval[(int64_t)grow * p.cap + pos] = v;
+        p.cidx[(int64_t)grow * p.cap + pos] = c;
+      }
     };
     auto stat_open = [&](int tile, bool first) {
       if (tile * VT_N + VT_N > p.N) {  // ragged last tile of the vocabulary: columns past N never win nor count
@@ -123,10 +153,33 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
         for (int i = 0; i < 16; ++i)
           if (tile * VT_N + col_in_tile(i) >= p.N) accp[i] = -INFINITY;
       }
-      if (first) rref = fmaxf(accp[0], -1e30f);
+      if (first && !COLLECT) rref = fmaxf(accp[0], -1e30f);
       tmax = -INFINITY;
     };
     auto stat_close = [&](int tile) {
+      if constexpr (COLLECT) {
+        // ONE wave-uniform test per tile (about every second tile of a wave holds a candidate of one of its rows)
+        if (__builtin_expect(__any(tmax >= thr), 0)) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float v = accp[i];
+            const int c = tile * VT_N + col_in_tile(i);
+            if (v >= thr && c < p.N) {
+              int pos;
+              const int one = 1;
+              asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(lbase), "v"(one) : "memory");
+              if (pos < V_LCAP) {
+                const unsigned a = lbase + 8 + (unsigned)pos * 8;
+                const int packed = ((wave * 32 + r) << 24) | c;
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(a), "v"(v), "v"(packed) : "memory");
+              } else {
+                append_global(row, v, c);  // staging area full
+              }
+            }
+          }
+        }
+        return;
+      }
       if (tmax > rm) {  // a new maximum of this row: rare after the first tiles -> divergent branch
         int c = 0;
 #pragma unroll
@@ -156,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
       __builtin_amdgcn_sched_barrier(0);
 
       const unsigned char* sb = smem + (it % V_RING) * VT_BYTES;
-      if constexpr (STATS) stat_open(t - 1, it == 1);
+      if constexpr (STATS) stat_open(t - 1, (t - 1) % tpb == 0);
       bf16x8 fb[BDEPTH];
 #pragma unroll
       for (int ks = 0; ks < BDEPTH; ++ks) {
@@ -177,32 +230,51 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
       if constexpr (STATS) stat_close(t - 1);
       accp = acc;
     };
+    // the statistics of a finished range: merge the two lanes of a row (columns 4 h + ...), write (max, argmax,
+    // sum relative to the max), start over
+    auto close_range = [&](int range) {
+      float m = rm, sx = rs > 0.f ? rs * __expf(rref - rm) : 0.f;
+      if (!(sx < 3.0e38f)) sx = 1.0f;  // the sum overflowed (a > 88 jump inside one tile): it is its largest term
+      int id = ri;
+      const float om = __shfl_xor(m, 32, 64), os = __shfl_xor(sx, 32, 64);
+      const int oi = __shfl_xor(id, 32, 64);
+      const float mn = fmaxf(m, om);
+      sx = sx * __expf(m - mn) + os * __expf(om - mn);
+      if (om > m || (om == m && oi < id)) id = oi;
+      if (h == 0 && row < p.M) {
+        const int64_t o = (int64_t)row * p.ns + range;
+        p.pmax[o] = mn; p.pidx[o] = id; p.psum[o] = sx;
+      }
+      rm = -1e30f; rs = 0.f; rref = -1e30f; ri = 0x7fffffff;
+    };
     tile_body(t0, std::false_type{});
 #pragma unroll 1
-    for (int t = t0 + 1; t < t1; ++t) tile_body(t, std::true_type{});
+    for (int t = t0 + 1; t < t1; ++t) {
+      tile_body(t, std::true_type{});                       // ... with the statistics of tile t - 1
+      if (!COLLECT && t % tpb == 0) close_range(t / tpb - 1);  // which was the last one of its range
+    }
     // the last tile's statistics
     if (!(CARE_V32_DBG & 16)) {
-      stat_open(t1 - 1, t1 - t0 == 1);
+      stat_open(t1 - 1, (t1 - 1) % tpb == 0);
 #pragma unroll
       for (int i = 0; i < 16; ++i) stat_piece(i);
       stat_close(t1 - 1);
     }
-
-    // ---- merge the two lanes of a row (columns 4 h + ...), write (max, argmax, sum relative to the max)
-    float m = rm, s = rs > 0.f ? rs * __expf(rref - rm) : 0.f;
-    if (!(s < 3.0e38f)) s = 1.0f;  // the sum overflowed (a > 88 jump inside one tile): it is its largest term
-    int id = ri;
-    {
-      const float om = __shfl_xor(m, 32, 64), os = __shfl_xor(s, 32, 64);
-      const int oi = __shfl_xor(id, 32, 64);
-      const float mn = fmaxf(m, om);
-      s = s * __expf(m - mn) + os * __expf(om - mn);
-      if (om > m || (om == m && oi < id)) id = oi;
-      m = mn;
-    }
-    if (h == 0 && row < p.M) {
-      const int64_t o = (int64_t)row * p.ns + range;
-      p.pmax[o] = m; p.pidx[o] = id; p.psum[o] = s;
+    if constexpr (COLLECT) {  // flush the staged candidates: all 512 threads
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      typedef int i32x2 __attribute__((ext_vector_type(2)));
+      int n;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(n) : "v"(lbase) : "memory");
+      n = min(n, V_LCAP);
+      for (int e = tid; e < n; e += 512) {
+        i32x2 pr;
+        const unsigned a = lbase + 8 + (unsigned)e * 8;
+        asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pr) : "v"(a) : "memory");
+        append_global(panel * V_ROWS + (int)((unsigned)pr[1] >> 24), __builtin_bit_cast(float, pr[0]), pr[1] & 0xffffff);
+      }
+    } else {
+      close_range((t1 - 1) / tpb);
     }
   }
 }
@@ -223,8 +295,40 @@ extern "C" int care_vocab32_launch(const void* A, int64_t lda, const void* W, fl
   p.panels = (M + V_ROWS - 1) / V_ROWS;
   p.total_items = p.panels * ns;
   static std::atomic<unsigned long long> lds_ok{0};
-  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&vocab_argmax32_kernel<6>), V_LDS, lds_ok)) return e;
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&vocab_argmax32_kernel<6, V_ARGMAX>), V_LDS, lds_ok)) return e;
   const int blocks = p.total_items < 256 ? p.total_items : 256;  // one workgroup per CU (128 KiB of LDS), persistent
-  hipLaunchKernelGGL((vocab_argmax32_kernel<6>), dim3(blocks), dim3(512), V_LDS, (hipStream_t)stream, p);
+  hipLaunchKernelGGL((vocab_argmax32_kernel<6, V_ARGMAX>), dim3(blocks), dim3(512), V_LDS, (hipStream_t)stream, p);
   return care_launch_status();
+}
+
+// Second pass of the fused beam selection (care_gemm_collect_bf16) on the same 256-row panels.
+extern "C" int care_collect32_launch(const void* A, int64_t lda, const void* W, const float* thr, int32_t* cnt, float* cval,
+                                     int32_t* cidx, int cap, int M, int N, int ns, void* stream) {
+  VArgs p{};
+  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W);
+  p.thr = thr; p.cnt = cnt; p.cval = cval; p.cidx = cidx; p.cap = cap; p.M = M; p.N = N; p.ns = ns;
+  p.panels = (M + V_ROWS - 1) / V_ROWS;
+  p.total_items = p.panels * ns;
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&vocab_argmax32_kernel<6, V_COLLECT>), V_LDS + V_STAGE, lds_ok))
+    return e;
+  const int blocks = p.total_items < 256 ? p.total_items : 256;
+  hipLaunchKernelGGL((vocab_argmax32_kernel<6, V_COLLECT>), dim3(blocks), dim3(512), V_LDS + V_STAGE, (hipStream_t)stream, p);
+  return care_launch_status();
+}
+
+// Column ranges for the 256-row panels: whole launch rounds over the 256 CUs, each work item paying ~3 tile times of
+// prologue (A fragments, ring fill).  32768 rows -> 8 (4 rounds of 42 tiles), 20480 rows (4096 clips x beam 5) -> 16
+// (5 rounds of 21 tiles instead of 3 of 42: 640 items over 256 CUs leave half the chip idle in the third round).
+extern "C" int care_vocab32_ranges(int M, int N, int min_parts) {
+  const int panels = (M + V_ROWS - 1) / V_ROWS, tiles = (N + VT_N - 1) / VT_N;
+  int best = 0;
+  long best_cost = 0;
+  for (int ns = 8; ns <= 32; ns += 8) {
+    if (ns < min_parts && ns < 32) continue;
+    const long rounds = ((long)panels * ns + 255) / 256;
+    const long cost = rounds * ((tiles + ns - 1) / ns + 3);
+    if (!best || cost < best_cost) { best = ns; best_cost = cost; }
+  }
+  return best;
 }

@@ -8,6 +8,14 @@
 //   care_head_reduce:  ctx[r][h*64+e] = sum_c ct[r][h][c] * wv[h*64+e][c] + bv   (K = 512, N = 64 per head)
 #include "care_common.h"
 
+// cache policy of the two big streams (q~ out of the expansion, c~ into the reduction): see attention_latent.hip
+#ifndef CARE_HEADS_ST_NT
+#define CARE_HEADS_ST_NT 0
+#endif
+#ifndef CARE_HEADS_LD_AUX
+#define CARE_HEADS_LD_AUX 0
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -57,7 +65,8 @@ __global__ __launch_bounds__(256) void head_expand_kernel(const bf16_t* q, int64
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[half * 4 + j] = (bf16_t)acc[j];
       }
-      *reinterpret_cast<bf16x8*>(out + k * 32) = o;
+      if (CARE_HEADS_ST_NT) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(out + k * 32));
+      else *reinterpret_cast<bf16x8*>(out + k * 32) = o;
     }
     af[0] = an[0]; af[1] = an[1];
   }
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const bf16_t* ct, int6
                                                                       h * 512) + ((lane ^ i) << 4);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(smem + slot * RED_TILE + i * 1024),
-                                       16, 0, 0);
+                                       16, 0, CARE_HEADS_LD_AUX);
     }
   };
   int roff[4];

@@ -1108,7 +1108,7 @@ class HipEngine:
         cval, cidx = self.ws(tag + "cval", (N, bm)), self.ws(tag + "cidx", (N, bm), torch.int32)
         fused_sel = self.as_ok and os.environ.get("CARE_BEAM_FUSED", "1") != "0"
         if fused_sel:
-            s_parts = _lib.load().care_argmax_parts_bf16_min(N, self.V, 8)
+            s_parts = _lib.load().care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
             s_cap = 64
             s_pmax, s_psum = self.ws(tag + "spmax", (N, s_parts)), self.ws(tag + "spsum", (N, s_parts))
             s_pidx = self.ws(tag + "spidx", (N, s_parts), torch.int32)
@@ -1340,7 +1340,7 @@ class HipEngine:
         vpad = (self.V + 63) // 64 * 64  # 16-byte aligned row stride -> the GEMM's vector store path
         fused_sel = self.as_ok and os.environ.get("CARE_BEAM_FUSED", "1") != "0"
         if fused_sel:
-            s_parts = _lib.load().care_argmax_parts_bf16_min(N, self.V, 8)
+            s_parts = _lib.load().care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
             s_cap = 64
             s_pmax, s_psum = self.ws("b_spmax", (N, s_parts)), self.ws("b_spsum", (N, s_parts))
             s_pidx = self.ws("b_spidx", (N, s_parts), torch.int32)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 10
+#define CARE_ABI_VERSION 11
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -333,7 +333,9 @@ int care_beam_select(const float* logits, int64_t ldl, int V, int bm, float* can
  *   [rows, V] logits in memory.  Replaces torch.log_softmax (models/Translator.py:127) + the per-row
  *   part of Beam.advance's top-k (misc/Decoding/Beam.py:60) exactly like care_beam_select does:
  *     1. care_gemm_argmax_bf16_min : care_gemm_argmax_bf16 with at least `min_parts` column ranges
- *        (care_argmax_parts_bf16_min gives the count) -> pmax / pidx / psum [M, parts];
+ *        (care_argmax_parts_bf16_min, called with the same M, N, K, a_dtype and min_parts, gives the
+ *        count: at large row counts the kernel balances its column ranges over whole launch rounds)
+ *        -> pmax / pidx / psum [M, parts];
  *     2. care_beam_threshold      : thr[r] = bm-th largest range maximum of row r (a lower bound of
  *        the row's bm-th best logit); cnt[r] = 0;
  *     3. care_gemm_collect_bf16   : the same product; every logit >= thr[r] is appended to row r's
@@ -342,7 +344,7 @@ int care_beam_select(const float* logits, int64_t ldl, int V, int bm, float* can
  *        desc, column asc) as log-probabilities; a row with cnt > cap is recomputed exactly from
  *        A and W inside the kernel.
  */
-int care_argmax_parts_bf16_min(int M, int N, int min_parts);
+int care_argmax_parts_bf16_min(int M, int N, int K, int a_dtype, int min_parts);
 int care_gemm_argmax_bf16_min(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
                               int32_t* pidx, float* psum, int M, int N, int K, int min_parts,
                               void* stream);

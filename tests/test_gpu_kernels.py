@@ -174,7 +174,7 @@ def test_gemm_argmax(M, mode):
 
 
 @pytest.mark.parametrize("M,N,min_parts", [(8192, 10547, 1), (8192 + 77, 10547, 1), (12288, 5000, 8), (33000, 10547, 1),
-                                           (8192, 130, 1)])
+                                           (8192, 130, 1), (20480, 10547, 8), (9000, 10547, 24)])
 def test_vocab_argmax_256_row_panels(M, N, min_parts, monkeypatch):
     """csrc/gemm_vocab.hip (bf16 activations, K = 512, M >= 8192): per column range (max, lowest argmax,
     sum-exp) of the logits - against the bf16-rounded product in fp64, against the 128-row kernel of
@@ -190,7 +190,8 @@ def test_vocab_argmax_256_row_panels(M, N, min_parts, monkeypatch):
     A[5] = (W[11] * 40).to(torch.bfloat16)   # rows whose maximum IS the tied column
     A[M - 1] = (W[N - 2] * 40).to(torch.bfloat16)
     Wb = W.to(torch.bfloat16).contiguous()
-    parts = _lib.load().care_argmax_parts_bf16_min(M, N, min_parts)
+    parts = (_lib.load().care_argmax_parts_bf16_min(M, N, K, 1, min_parts) if min_parts > 1 else
+             _lib.load().care_argmax_parts_bf16(M, N))
 
     def run():
         pm, ps = torch.full((M, parts), float("nan"), device=DEV), torch.full((M, parts), float("nan"), device=DEV)
@@ -494,11 +495,14 @@ def test_head_expand_and_reduce(rows, heads):
 
 @pytest.mark.parametrize("rows,nkeys,rows_per_kv,use_bias", [(1, 84, 1, True), (5, 7, 1, False), (37, 16, 1, True),
                                                              (130, 114, 1, True), (100, 84, 5, True),
-                                                             (1030, 128, 1, False), (64, 33, 2, True)])
+                                                             (1030, 128, 1, False), (64, 33, 2, True),
+                                                             (35, 57, 5, True), (9, 20, 3, False), (7, 20, 2, True),
+                                                             (5 * 1100, 84, 5, False), (12, 40, 3, "H4")])
 def test_attention_latent(rows, nkeys, rows_per_kv, use_bias):
     """ct[r][h] = softmax_j(qt[r][h] . mem[clip][j] + bias[h][j]) . mem[clip] against torch on the same
-    bf16 operands (the kernel rounds the probabilities and the output to bf16)."""
-    H, d = 8, 512
+    bf16 operands (the kernel rounds the probabilities and the output to bf16).  Rows that share a clip
+    (rows_per_kv > 1, whole clips) are taken two per wave - pairs, the odd row out, clip edges."""
+    H, d = (4 if use_bias == "H4" else 8), 512
     clips = (rows + rows_per_kv - 1) // rows_per_kv
     mem = _rand(clips, nkeys, d, seed=11).to(torch.bfloat16)
     qt = _rand(rows, H, d, seed=12, scale=0.12).to(torch.bfloat16)
@@ -614,11 +618,13 @@ def test_greedy_update_embed_equals_the_two_kernels(rows, parts, d, with_sem):
     assert torch.equal(x1, x2) and torch.equal(x1b, x2b)
 
 
-@pytest.mark.parametrize("M,V,bm", [(5, 10547, 5), (300, 10547, 5), (130, 700, 8), (64, 10547, 1)])
+@pytest.mark.parametrize("M,V,bm", [(5, 10547, 5), (300, 10547, 5), (130, 700, 8), (64, 10547, 1), (8192 + 40, 10547, 5),
+                                    (12288, 3000, 8)])
 def test_fused_beam_selection_equals_logits_plus_beam_select(M, V, bm):
     """statistics GEMM -> threshold -> candidate GEMM -> pick  ==  store-mode GEMM + care_beam_select,
     including rows with tied logits (duplicated vocabulary rows) and a plateau of > 64 ties at the
-    top, which overflows the candidate list and takes the exact in-kernel recomputation."""
+    top, which overflows the candidate list and takes the exact in-kernel recomputation.  From 8192 rows
+    both GEMM passes run on the 256-row panels of csrc/gemm_vocab.hip (statistics / collect modes)."""
     from care_amd import _lib
 
     K = 512
@@ -634,7 +640,7 @@ def test_fused_beam_selection_equals_logits_plus_beam_select(M, V, bm):
     ref_v = torch.zeros(M, bm, device=DEV); ref_i = torch.zeros(M, bm, device=DEV, dtype=torch.int32)
     _call("care_beam_select", _p(logits), ld, V, bm, _p(ref_v), _p(ref_i), M)
 
-    parts = _lib.load().care_argmax_parts_bf16_min(M, V, 8)
+    parts = _lib.load().care_argmax_parts_bf16_min(M, V, K, 1, 8)
     assert parts >= 8
     pmax = torch.empty(M, parts, device=DEV); psum = torch.empty(M, parts, device=DEV)
     pidx = torch.empty(M, parts, device=DEV, dtype=torch.int32)

@@ -112,7 +112,11 @@ def test_abi_library_exports_every_declared_symbol():
     # the column split of the A-stationary GEMM (csrc/gemm_as.hip: pick_ns), at its measured optima
     for rows, parts in [(1, 512), (4096, 16), (8192, 8), (16384, 4), (20480, 8), (32768, 2), (65536, 1)]:
         assert loaded.care_argmax_parts_bf16(rows, 10547) == parts, rows
-    assert loaded.care_argmax_parts_bf16_min(32768, 10547, 8) == 8
+    assert loaded.care_argmax_parts_bf16_min(4096, 10547, 512, 1, 8) == 16   # 128-row panels: the greedy split
+    # from 8192 bf16 rows the 256-row kernel: whole launch rounds over the 256 CUs (csrc/gemm_vocab.hip)
+    for rows, parts in [(8192, 8), (12288, 16), (20480, 16), (32768, 8)]:
+        assert loaded.care_argmax_parts_bf16_min(rows, 10547, 512, 1, 8) == parts, rows
+    assert loaded.care_argmax_parts_bf16_min(32768, 10547, 512, 0, 8) == 8    # fp32 rows stay on the 128-row kernel
 
 
 def test_synth_generator_is_deterministic_and_portable():
