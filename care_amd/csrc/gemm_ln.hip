@@ -298,6 +298,9 @@ int launch_ln(const LnArgs& p, hipStream_t st) {
 //     with 16-byte loads and every store is 16 bytes per lane (64 or 128 contiguous bytes per row).
 //     The per-row arithmetic does not depend on RG: a row's result is bit-identical whatever block
 //     size the launch rule picks (batch-composition invariance, tests/test_gpu_properties.py).
+#ifndef CARE_LN_ST_NT
+#define CARE_LN_ST_NT 0  // bf16 output stores non-temporal (ablation)
+#endif
 #ifndef CARE_LN_A_AUX
 #define CARE_LN_A_AUX 0  // cache policy of the A stream's DMA (2 = nt: every A byte is read once)
 #endif
@@ -346,7 +349,12 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
   constexpr int A_BASE = NSW * W_BYTES;
   constexpr int NWI = W_BYTES / 1024 / NLD;          // DMA instructions per stage per W wave: 16 / 8
   constexpr int NAI = A_BYTES / 1024 / NLD;          // per macro stage per A wave: 8
-  static_assert(NSW >= 2 && NSA >= 3, "ring depths");
+  static_assert(NSW >= 2 && NSA >= 2, "ring depths");
+  // NSA == 2 (bf16 A: a macro stage is 4 K steps): the whole of macro stage mac + 1 goes out in the FIRST step of
+  // macro stage mac (three steps of lookahead) - the LDS this saves buys a third W stage: with two, the weight
+  // tile of step kt + 1 was requested from L2 only one step (~1000 MFMA cycles) ahead and every step waited for it.
+  constexpr bool AE = NSA == 2;
+  static_assert(!AE || (!AF32 && REP == 1), "early A issue: bf16 A only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
   // Past the end of K the stage index is clamped: the last stage is simply fetched again into a slot
   // nobody will read - no tail cases, and the vmcnt arithmetic stays exact.
   constexpr int NAS = NAI / KSUB;
-  static_assert(NAI % KSUB == 0 && NSA >= 3, "A issue schedule");
+  static_assert(NAI % KSUB == 0 && 16 % NAI == 0, "A issue schedule");
   if (w_loader) {
 #pragma unroll 1
     for (int s = 0; s < NSW; ++s)
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
     if (more) {
       // my stream's stage kt + 1 has landed (its younger instructions stay in flight); my reads of stage kt are done
       if (w_loader) ln2_wait_vm<(NSW - 2) * NWI>();
-      else if (a_edge) ln2_wait_vm<REP == 1 ? (NSA - 3) * NAI + (KSUB - 1) * NAS : (NSA - 2) * NAI>();  // all of macro stage mac - 1 + NSA is out by now when REP > 1
+      else if (a_edge) ln2_wait_vm<AE ? 0 : REP == 1 ? (NSA - 3) * NAI + (KSUB - 1) * NAS : (NSA - 2) * NAI>();  // all of macro stage mac - 1 + NSA is out by now when REP > 1
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -525,8 +533,9 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
         if (CARE_LN_DBG & 1) asm volatile("" :: "v"(fb1[q]), "v"(fa[mt]));
         else acc[mt][4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[q], fa[mt], acc[mt][4 + q], 0, 0, 0);
         const int m = mt * 4 + q;  // 0..15
-        if ((m + 1) % (16 / NWI) == 0 || (m + 1) % (16 / NAS) == 0) {
+        if ((m + 1) % (16 / NWI) == 0 || (m + 1) % (16 / (AE ? NAI : NAS)) == 0) {
           if (w_loader) { if ((m + 1) % (16 / NWI) == 0) dma_w(wst, wslot, m / (16 / NWI)); }
+          else if (AE) { if (sub == 0 && (m + 1) % (16 / NAI) == 0) dma_a(ast, aslot, m / (16 / NAI)); }
           else { if (a_issue && (m + 1) % (16 / NAS) == 0) dma_a(ast, aslot, sub * NAS + m / (16 / NAS)); }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -665,7 +674,8 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
         bf16x8 ob;
         ob[0] = (bf16_t)o0.x; ob[1] = (bf16_t)o0.y; ob[2] = (bf16_t)o0.z; ob[3] = (bf16_t)o0.w;
         ob[4] = (bf16_t)o1.x; ob[5] = (bf16_t)o1.y; ob[6] = (bf16_t)o1.z; ob[7] = (bf16_t)o1.w;
-        *reinterpret_cast<bf16x8*>(p.outb + orow[mt] * p.ldo + c) = ob;
+        if (CARE_LN_ST_NT) __builtin_nontemporal_store(ob, reinterpret_cast<bf16x8*>(p.outb + orow[mt] * p.ldo + c));
+        else *reinterpret_cast<bf16x8*>(p.outb + orow[mt] * p.ldo + c) = ob;
       }
     }
   }
@@ -724,6 +734,8 @@ static int gemm_ln_impl(const void* A, int64_t lda, int a_dtype, const void* W, 
   }
   if (v2 && v2_ok) {
     if (a_dtype == CARE_F32) return big ? launch_ln2<true, 2, 2, 3>(p, st) : launch_ln2<true, 1, 3, 4>(p, st);
+    static const int ae = [] { const char* e = getenv("CARE_LN_AE"); return e ? atoi(e) : 1; }();  // A/B switch
+    if (big && ae) return launch_ln2<false, 2, 3, 2>(p, st);
     return big ? launch_ln2<false, 2, 2, 3>(p, st) : launch_ln2<false, 1, 3, 4>(p, st);
   }
   if (a_dtype == CARE_F32) return big ? launch_ln<true, 2>(p, st) : launch_ln<true, 1>(p, st);
