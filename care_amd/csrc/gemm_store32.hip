@@ -32,6 +32,13 @@ constexpr int S_ROWS = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef CARE_S32_ST_NT
+#define CARE_S32_ST_NT 0  // non-temporal output stores (ablation)
+#endif
+#ifndef CARE_S32_DBG
+#define CARE_S32_DBG 0  // ablation builds: 1 no stores, 2 no bias reads, 4 no activation / conversion either
+#endif
+
 struct SArgs {
   const bf16_t* A; int64_t lda;
   const bf16_t* W;
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void gemm_store32_kernel(SArgs p) {
     // (accumulator registers 4 g .. 4 g + 3 hold output columns 16 h + 4 g + (0..3) after the staging permutation)
     auto out_piece = [&](const f32x16& ap, int tile, int g, float (&v)[16]) {
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) {  // asm read: hipcc would drain the in-flight DMAs in front of a C++ LDS read here
+      if (p.bias && !(CARE_S32_DBG & 2)) {  // asm read: hipcc would drain the in-flight DMAs in front of a C++ LDS read here
         const unsigned addr = lds0 + (unsigned)(S_BIAS_OFF + ((tile * ST_N - col0) + 16 * h + 4 * g) * 4);
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(bv) : "v"(addr) : "memory");
       }
@@ -136,21 +143,45 @@ __global__ __launch_bounds__(512, 2) void gemm_store32_kernel(SArgs p) {
       const int64_t ld = second ? p.ldc1 : p.ldc0;
       const bool isb = (second ? p.c1_bf16 : p.c0_bf16) != 0;
       const int cshift = second ? p.n_split : 0;
-      if (row < p.M) {
-        const int64_t o = (int64_t)row * ld + (tile * ST_N - cshift) + 16 * h;
-        if (isb) {
+      if (row < p.M && !(CARE_S32_DBG & 1)) {
+        int64_t o = (int64_t)row * ld + (tile * ST_N - cshift) + 16 * h;
+        if (CARE_S32_DBG & 8) {  // ablation: the same bytes to lane-linear (wrong) addresses - fully coalesced instructions
+          const int64_t ob = (int64_t)min(m0, p.M - 40) * ld + (tile * ST_N - cshift);
+          if (isb) {
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o0[j] = (bf16_t)v[j]; o1[j] = (bf16_t)v[8 + j]; }
+            bf16_t* dst = reinterpret_cast<bf16_t*>(C) + ob + lane * 8;
+            *reinterpret_cast<bf16x8*>(dst) = o0;
+            *reinterpret_cast<bf16x8*>(dst + 512) = o1;
+          } else {
+            float* dst = reinterpret_cast<float*>(C) + ob + lane * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(dst + 256 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+          }
+        } else if (isb) {
           bf16x8 o0, o1;
 #pragma unroll
           for (int j = 0; j < 8; ++j) { o0[j] = (bf16_t)v[j]; o1[j] = (bf16_t)v[8 + j]; }
           bf16_t* dst = reinterpret_cast<bf16_t*>(C) + o;
-          *reinterpret_cast<bf16x8*>(dst) = o0;
-          *reinterpret_cast<bf16x8*>(dst + 8) = o1;
+          if (CARE_S32_ST_NT) {
+            __builtin_nontemporal_store(o0, reinterpret_cast<bf16x8*>(dst));
+            __builtin_nontemporal_store(o1, reinterpret_cast<bf16x8*>(dst + 8));
+          } else {
+            *reinterpret_cast<bf16x8*>(dst) = o0;
+            *reinterpret_cast<bf16x8*>(dst + 8) = o1;
+          }
         } else {
           float* dst = reinterpret_cast<float*>(C) + o;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dst + 4 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 o = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            if (CARE_S32_ST_NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst + 4 * g));
+            else *reinterpret_cast<f32x4*>(dst + 4 * g) = o;
+          }
         }
       }
+      if (CARE_S32_DBG & 1) { asm volatile("" :: "v"(v[0]), "v"(v[5]), "v"(v[10]), "v"(v[15])); return 0; }
       return wave_rows ? (isb ? 2 : 4) : 0;
     };
 

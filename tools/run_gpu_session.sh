@@ -1,10 +1,1 @@
-mkdir -p gpurun_out/r2y
-timeout 900 python -m pytest tests/test_gpu_kernels.py -q -x -m gpu -k "gemm_ln" 2>&1 | tail -3
-timeout 900 python -m pytest tests/test_gpu_properties.py -q -x -m gpu 2>&1 | tail -3
-run() { timeout 600 python bench.py --no-legs --no-cpu-baseline > gpurun_out/r2y/$1.log 2>&1; tail -1 gpurun_out/r2y/$1.log | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); k=d['kernels']; print('$1', d['value'], d['ms_per_step'], ' '.join('%s %.1f' % (t.replace('step_',''), k[t]['avg_us']) for t in k))"; }
-CARE_LN_AE=1 run ae1
-CARE_LN_AE=0 run ae0
-CARE_LN_AE=1 run ae1
-CARE_LN_AE=0 run ae0
+python tools/beam_eos_probe.py 5 8 12 20 2>&1 | tail -6
