@@ -271,6 +271,51 @@ def test_benchmarked_operating_point_against_oracle_sample(config, B):
     assert exact >= 48 and len(set(length[idx].tolist())) > 3
 
 
+def test_benchmarked_beam_operating_point_against_oracle_sample():
+    """BASELINE configs[4] at bench scale: 2048 clips x beam 5 = 10240 rows - the 256-row vocabulary kernels in
+    both passes (statistics over the balanced ranges, collect), two rows per wave in the absorbed cross-attention,
+    fused dense+LayerNorm, segments replayed from hipGraphs - on the peaked model, audited against the CPU oracle
+    on a 24-clip sample: the reported score is the winner's exact score, a clip with clear reference margins is
+    bit-exact, any other difference is a near-tie; replay == eager."""
+    from oracle import care_cpu
+    from test_gpu_parity import BEAM_TIE_TOL, BF16_LSE_PEAKED, CLEAR_MARGIN
+
+    B, bm = 2048, 5
+    opt, P, model, feats = _setup("msrvtt_care_beam5", B, "bf16", seed=373, boost=PEAKED_ROWS)
+    eng = model.engine()
+    from care_amd import _lib
+    assert _lib.load().care_argmax_parts_bf16_min(B * bm, eng.V, eng.d, 1, 8) >= 8
+    from care_amd import get_translator
+    tr = get_translator(opt)
+    runs = [tr.translate_batch([model], {"feats": feats}, use_graph=it > 0) for it in range(3)]  # eager, capture, replay
+    assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] in ("beam", "bseg0")), "beam pass was not captured"
+    assert runs[1] == runs[0] and runs[2] == runs[0]
+    ghyps, gscores = runs[0]
+    idx = [int(i) for i in torch.linspace(0, B - 1, 24).round().tolist()]
+    sample = [f[idx].cpu() for f in feats]
+    torch.set_num_threads(16)
+    hyps, scores, gaps = care_cpu.translate_batch(P, opt, sample, return_gaps=True)
+    enc = care_cpu.encoding_phase(P, opt, sample)
+    inputs = care_cpu.inputs_for_decoder(opt, enc)
+    exact = clear_n = 0
+    for j, i in enumerate(idx):
+        h, r = ghyps[i][0], hyps[j][0]
+        one = {kk: v[j:j + 1] for kk, v in inputs.items()}
+        exact_h = care_cpu.score_hypothesis(P, opt, one, h)
+        assert abs(gscores[i][0] - exact_h) < BF16_LSE_PEAKED, (i, gscores[i][0], exact_h)
+        clear = gaps[j]["best_slack"] >= CLEAR_MARGIN and gaps[j]["rank"] >= 0.05
+        clear_n += clear
+        if clear:
+            assert h == r, "clip {}: clear reference margins but the bf16 beam winner differs".format(i)
+        if h == r:
+            exact += 1
+        else:
+            assert (abs(exact_h - scores[j][0]) < BEAM_TIE_TOL or gaps[j]["best_slack"] < BEAM_TIE_TOL or
+                    gaps[j]["rank"] < BEAM_TIE_TOL), (i, h, r)
+    print("beam operating point: {}/24 winners bit-exact, {} with clear margins".format(exact, clear_n))
+    assert exact >= 18
+
+
 @pytest.mark.parametrize("config,dtype,B", [("msrvtt_care_beam5", "bf16", 512), ("msrvtt_care_beam5", "fp32", 96),
                                             ("msrvtt_base_ami", "bf16", 2048)])
 def test_beam_graph_replay_equals_eager(config, dtype, B):

@@ -1,2 +1,1 @@
-python tools/argmax_bench.py 32768
-for v in x16 x48; do CARE_HIP_LIB=care_amd/dbg/libcare_hip_$v.so python tools/argmax_bench.py 32768; done
+timeout 1200 python -m pytest tests/test_gpu_properties.py -q -x -m gpu -k "beam_operating" -s 2>&1 | tail -8
