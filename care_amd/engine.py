@@ -756,7 +756,13 @@ class HipEngine:
             if self.attr_att:
                 x2, x2b = self._attr_block(li, x2, x2b, akv, rows_per_clip, tag)
             x, xb = self.ws(tag + "x3_%d" % (li & 1), (N, d)), self.wsb(tag + "x3_%d" % (li & 1), (N, d))
-            self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, tag, gemm_tag="step_ffn_gemm")
+            # the last layer's hidden state feeds the vocabulary projection only, which reads the bf16 mirror:
+            # the fused kernel then skips the fp32 copy (67 MB of stores per step at 32768 rows)
+            bf16_only = (li == self.n_layers - 1 and xb is not None and self.ln_fusable(N) and self.as_ok and
+                         self.ff % 512 == 0 and self.ff >= 1024)
+            self._ffn("d{}_ffn".format(li), x2, x2b, None if bf16_only else x, xb, tag, gemm_tag="step_ffn_gemm")
+            if bf16_only:
+                x = None
         return x, xb
 
     def greedy(self, mem: torch.Tensor, sem: Optional[torch.Tensor], steps: Optional[int] = None,
