@@ -281,6 +281,19 @@ class HipEngine:
         """dtype of activations that are ONLY GEMM inputs (attention context, FFN hidden)."""
         return torch.bfloat16 if self.as_ok else torch.float32
 
+    # Rows (clips x beam) from which the per-row top-k of beam search runs as two passes of the vocabulary GEMM
+    # (no [rows, V] logits in memory).  Below it the logits are written (a few MB, cache resident) and
+    # care_beam_select reads them: two launches per step instead of four.  Both forms pick the same columns in
+    # the same order (tests/test_gpu_kernels.py::test_fused_beam_selection_...), log-probabilities within 2e-5.
+    # *Measured* beam 5: 128 clips 6.35 vs 7.59 ms per pass (unfused vs fused), 512 clips 10.7 vs 10.9,
+    # 1024 clips 16.6 vs 15.8.  The form is fixed for a pass by its INITIAL row count.
+    BEAM_FUSED_MIN_ROWS = 4096
+
+    def beam_fused_for(self, rows: int) -> bool:
+        if os.environ.get("CARE_BEAM_FUSED", "1") == "0":
+            return False
+        return self.as_ok and rows >= self.BEAM_FUSED_MIN_ROWS
+
     def wsb(self, name: str, shape) -> Optional[torch.Tensor]:
         """bf16 mirror workspace of a GEMM-input activation (None unless as_ok)."""
         return self.ws(name + "#bf", shape, torch.bfloat16) if self.as_ok else None
@@ -1112,7 +1125,7 @@ class HipEngine:
         self._ws_cap = [(n, B), (N, B * bm)]
         tag = v["tag"]
         cval, cidx = self.ws(tag + "cval", (N, bm)), self.ws(tag + "cidx", (N, bm), torch.int32)
-        fused_sel = self.as_ok and os.environ.get("CARE_BEAM_FUSED", "1") != "0"
+        fused_sel = self.beam_fused_for(B * bm)  # one form for the whole pass, whatever the compaction leaves
         if fused_sel:
             s_parts = _lib.load().care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
             s_cap = 64
@@ -1344,7 +1357,7 @@ class HipEngine:
         cval = self.ws("b_cval", (N, bm))
         cidx = self.ws("b_cidx", (N, bm), torch.int32)
         vpad = (self.V + 63) // 64 * 64  # 16-byte aligned row stride -> the GEMM's vector store path
-        fused_sel = self.as_ok and os.environ.get("CARE_BEAM_FUSED", "1") != "0"
+        fused_sel = self.beam_fused_for(B * bm)
         if fused_sel:
             s_parts = _lib.load().care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
             s_cap = 64

@@ -284,7 +284,7 @@ def test_benchmarked_beam_operating_point_against_oracle_sample():
     opt, P, model, feats = _setup("msrvtt_care_beam5", B, "bf16", seed=373, boost=PEAKED_ROWS)
     eng = model.engine()
     from care_amd import _lib
-    assert _lib.load().care_argmax_parts_bf16_min(B * bm, eng.V, eng.d, 1, 8) >= 8
+    assert eng.beam_fused_for(B * bm) and _lib.load().care_argmax_parts_bf16_min(B * bm, eng.V, eng.d, 1, 8) >= 8
     from care_amd import get_translator
     tr = get_translator(opt)
     runs = [tr.translate_batch([model], {"feats": feats}, use_graph=it > 0) for it in range(3)]  # eager, capture, replay
