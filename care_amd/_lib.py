@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -49,6 +49,8 @@ SIGNATURES = {
     "care_head_reduce": [_P, _L, _P, _P, _P, _L, _I, _I, _P],
     "care_gemm_argmax_bf16_min": [_P, _L, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "care_beam_threshold": [_P, _I, _I, _P, _P, _I, _P],
+    "care_gemm_argmax_bf16_tiles": [_P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "care_beam_sparse_collect": [_P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "care_gemm_collect_bf16": [_P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "care_beam_pick": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _L, _I, _P, _I, _I, _P, _P, _I, _P],
     "care_beam_select": [_P, _L, _I, _I, _P, _P, _I, _P],
@@ -62,7 +64,8 @@ SIGNATURES = {
 }
 PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_argmax_parts": (c_int, [c_int]),
          "care_argmax_parts_bf16": (c_int, [c_int, c_int]),
-         "care_argmax_parts_bf16_min": (c_int, [c_int, c_int, c_int, c_int, c_int])}
+         "care_argmax_parts_bf16_min": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+         "care_beam_sparse_applies": (c_int, [c_int, c_int, c_int, c_int])}
 
 _lib = None
 

@@ -666,6 +666,8 @@ extern "C" int care_vocab32_launch(const void* A, int64_t lda, const void* W, fl
 extern "C" int care_collect32_launch(const void* A, int64_t lda, const void* W, const float* thr, int32_t* cnt, float* cval,
                                      int32_t* cidx, int cap, int M, int N, int ns, void* stream);
 extern "C" int care_vocab32_ranges(int M, int N, int min_parts);
+extern "C" int care_vocab32_launch_tiles(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
+                                         float* tile_max, int M, int N, int ns, void* stream);
 
 // column ranges of the `_min` statistics pass (beam search): on the 256-row kernel its own rule (whole launch rounds)
 static bool min_uses_v32(int M, int N, int K, int a_dtype, int min_parts) {
@@ -716,6 +718,19 @@ extern "C" int care_gemm_argmax_bf16_min(const void* A, int64_t lda, int a_dtype
                                          void* stream) {
   if (min_parts <= 0) return CARE_EINVAL;
   return gemm_argmax_bf16(A, lda, a_dtype, W, pmax, pidx, psum, nullptr, nullptr, M, N, K, min_parts, true, stream);
+}
+
+// The `_min` statistics pass that also writes the maximum of every (32-column tile, row): tile_max [ceil(N / 32), M]
+// fp32 - the map the sparse second pass (care_beam_sparse_collect) works from.  Shapes of the 256-row kernel only
+// (care_beam_sparse_applies); the partials are exactly those of care_gemm_argmax_bf16_min.
+extern "C" int care_gemm_argmax_bf16_tiles(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
+                                           int32_t* pidx, float* psum, float* tile_max, int M, int N, int K,
+                                           int min_parts, void* stream) {
+  int rc = as_check(A, lda, a_dtype, W, M, N, K);
+  if (rc) return rc;
+  if (!pmax || !pidx || !psum || !tile_max || min_parts <= 0) return CARE_EINVAL;
+  if (!min_uses_v32(M, N, K, a_dtype, min_parts)) return CARE_ESHAPE;
+  return care_vocab32_launch_tiles(A, lda, W, pmax, pidx, psum, tile_max, M, N, care_vocab32_ranges(M, N, min_parts), stream);
 }
 
 extern "C" int care_gemm_collect_bf16(const void* A, int64_t lda, int a_dtype, const void* W, const float* thr,

@@ -43,6 +43,9 @@ struct VArgs {
   int M, N, ns, panels, total_items;
   // collect mode (beam search, second pass): logits >= thr[row] are appended to the row's candidate list
   const float* thr; int32_t* cnt; float* cval; int32_t* cidx; int cap;
+  // statistics mode, optional: the maximum of every (tile, row) -> tile_max[tile * M + row]: the map from which the
+  // SPARSE second pass of the beam selection (csrc/beam_sparse.hip) recomputes only the tiles that hold a candidate
+  float* tile_max;
 };
 
 enum { V_ARGMAX = 0, V_COLLECT = 1 };
@@ -180,6 +183,10 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
         }
         return;
       }
+      if (p.tile_max) {  // one 128-byte store per wave and tile (rows past M repeat row M - 1: the same value)
+        const float tm = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        if (h == 0) p.tile_max[(int64_t)tile * p.M + min(row, p.M - 1)] = tm;
+      }
       if (tmax > rm) {  // a new maximum of this row: rare after the first tiles -> divergent branch
         int c = 0;
 #pragma unroll
@@ -202,7 +209,15 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
       // tile t has landed; the two younger tiles (4 DMA instructions each) stay in flight.  Iteration 0
       // drains everything: the A fragments were issued behind the prologue DMAs.
       if constexpr (!decltype(with_stats)::value) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else if (COLLECT || !p.tile_max) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else {  // + the tile_max stores issued since this tile's DMA went out (iterations it - 3 .. it - 1 that had statistics)
+        switch (min(it - 1, 3)) {
+          case 0: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory"); break;
+        }
+      }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       stage(t + V_AHEAD, (it + V_AHEAD) % V_RING);  // the slot every wave finished reading last iteration
@@ -287,11 +302,17 @@ extern "C" int care_vocab32_applies(int M, int N, int K, int a_dtype, int has_la
   return K == 512 && a_dtype == CARE_BF16 && !has_labels && M >= min_rows && N >= 4 * VT_N;
 }
 
+extern "C" int care_vocab32_launch_tiles(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
+                                         float* tile_max, int M, int N, int ns, void* stream);
 extern "C" int care_vocab32_launch(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
                                    int M, int N, int ns, void* stream) {
+  return care_vocab32_launch_tiles(A, lda, W, pmax, pidx, psum, nullptr, M, N, ns, stream);
+}
+extern "C" int care_vocab32_launch_tiles(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
+                                         float* tile_max, int M, int N, int ns, void* stream) {
   VArgs p{};
   p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W);
-  p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.M = M; p.N = N; p.ns = ns;
+  p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.M = M; p.N = N; p.ns = ns; p.tile_max = tile_max;
   p.panels = (M + V_ROWS - 1) / V_ROWS;
   p.total_items = p.panels * ns;
   static std::atomic<unsigned long long> lds_ok{0};

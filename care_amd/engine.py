@@ -289,6 +289,15 @@ class HipEngine:
     # 1024 clips 16.6 vs 15.8.  The form is fixed for a pass by its INITIAL row count.
     BEAM_FUSED_MIN_ROWS = 4096
 
+    def _beam_sparse_ws(self, tag: str, rows: int):
+        """Workspaces of the sparse second pass (csrc/beam_sparse.hip) - (tile maxima [tiles, rows] fp32, per-tile
+        row counts, per-tile row lists [tiles, rows]) - or None where the 256-row statistics kernel does not apply."""
+        if os.environ.get("CARE_BEAM_SPARSE", "1") == "0" or not _lib.load().care_beam_sparse_applies(rows, self.V, self.d, 1):
+            return None
+        tiles = (self.V + 31) // 32
+        return (self.ws(tag + "stmax", (tiles, rows)), self.ws(tag + "stcount", (tiles,), torch.int32),
+                self.ws(tag + "stlist", (tiles, rows), torch.int32))
+
     def beam_fused_for(self, rows: int) -> bool:
         if os.environ.get("CARE_BEAM_FUSED", "1") == "0":
             return False
@@ -1133,6 +1142,7 @@ class HipEngine:
             s_pidx = self.ws(tag + "spidx", (N, s_parts), torch.int32)
             s_thr, s_cnt = self.ws(tag + "sthr", (N,)), self.ws(tag + "scnt", (N,), torch.int32)
             s_cval, s_cidx = self.ws(tag + "scval", (N, s_cap)), self.ws(tag + "scidx", (N, s_cap), torch.int32)
+            sparse = self._beam_sparse_ws(tag, N)
         else:
             vpad = (self.V + 63) // 64 * 64
             logits = self.ws(tag + "logits", (N, vpad))[:, : self.V]
@@ -1140,11 +1150,20 @@ class HipEngine:
             a_old, a_new = v["anc"][(t - 1) & 1], v["anc"][t & 1]
             x, xb = self._decode_step(t, N, bm, v["tok"], a_old, v["sem"], v["ckv"], v["skv"], self.Lk, tag, akv=v["akv"])
             if fused_sel:
-                call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax), ptr(s_pidx),
-                     ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
-                call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
-                     ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
+                if sparse is not None:
+                    # second pass only over the (tile, row) products whose tile maximum reaches the row's threshold
+                    call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                         ptr(s_pidx), ptr(s_psum), ptr(sparse[0]), N, self.V, d, 8, tag="beam_vocab_stats")
+                    call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
+                    call("care_beam_sparse_collect", ptr(xb), d, ptr(self.w["vocab"]), ptr(sparse[0]), ptr(s_thr),
+                         ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap, ptr(sparse[1]), ptr(sparse[2]), N, self.V, d,
+                         tag="beam_vocab_collect")
+                else:
+                    call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                         ptr(s_pidx), ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
+                    call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
+                    call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
+                         ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
                 call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
                      bm, ptr(xb), d, _code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
             else:
@@ -1365,6 +1384,7 @@ class HipEngine:
             s_pidx = self.ws("b_spidx", (N, s_parts), torch.int32)
             s_thr, s_cnt = self.ws("b_sthr", (N,)), self.ws("b_scnt", (N,), torch.int32)
             s_cval, s_cidx = self.ws("b_scval", (N, s_cap)), self.ws("b_scidx", (N, s_cap), torch.int32)
+            sparse = self._beam_sparse_ws("b_", N)
             logits = None
         else:
             logits = self.ws("b_logits", (N, vpad))[:, : self.V]
@@ -1375,13 +1395,21 @@ class HipEngine:
             a_old, a_new = anc[(t - 1) & 1], anc[t & 1]
             x, xb = self._decode_step(t, N, bm, tok, a_old, sem, ckv, skv, Lk, "b_", akv=akv)
             if fused_sel:
-                # fused selection (csrc/beam.hip): statistics GEMM -> threshold -> candidate GEMM -> pick;
+                # fused selection (csrc/beam.hip): statistics GEMM -> threshold -> candidate pass -> pick;
                 # the [N, V] logits never exist
-                call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax), ptr(s_pidx),
-                     ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
-                call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
-                     ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
+                if sparse is not None:
+                    call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                         ptr(s_pidx), ptr(s_psum), ptr(sparse[0]), N, self.V, d, 8, tag="beam_vocab_stats")
+                    call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
+                    call("care_beam_sparse_collect", ptr(xb), d, ptr(self.w["vocab"]), ptr(sparse[0]), ptr(s_thr),
+                         ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap, ptr(sparse[1]), ptr(sparse[2]), N, self.V, d,
+                         tag="beam_vocab_collect")
+                else:
+                    call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                         ptr(s_pidx), ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
+                    call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
+                    call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
+                         ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
                 call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
                      bm, ptr(xb), d, _code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
                 call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),

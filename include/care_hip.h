@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 11
+#define CARE_ABI_VERSION 12
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -353,6 +353,21 @@ int care_beam_threshold(const float* pmax, int parts, int bm, float* thr, int32_
 int care_gemm_collect_bf16(const void* A, int64_t lda, int a_dtype, const void* W, const float* thr,
                            int32_t* cnt, float* cval, int32_t* cidx, int cap, int M, int N, int K,
                            void* stream);
+/*
+ * The SPARSE second pass (large row counts, K = 512, bf16 rows: care_beam_sparse_applies): step 1 as
+ *   care_gemm_argmax_bf16_tiles, which also writes tile_max [ceil(N / 32), M] fp32 - the maximum of every
+ *   (32-column tile, row); step 3 as care_beam_sparse_collect, which lists per tile the rows whose tile
+ *   maximum reaches thr[row] (tcount [tiles], tlist [tiles, M] int32 scratch) and recomputes ONLY those
+ *   (tile, row) products - the same MFMA chain as the first pass, bit-identical logits - appending the
+ *   logits >= thr[row] to cval / cidx exactly like care_gemm_collect_bf16 (~2 % of its arithmetic).
+ */
+int care_beam_sparse_applies(int M, int N, int K, int a_dtype);
+int care_gemm_argmax_bf16_tiles(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
+                                int32_t* pidx, float* psum, float* tile_max, int M, int N, int K,
+                                int min_parts, void* stream);
+int care_beam_sparse_collect(const void* A, int64_t lda, const void* W, const float* tile_max,
+                             const float* thr, int32_t* cnt, float* cval, int32_t* cidx, int cap,
+                             int32_t* tcount, int32_t* tlist, int M, int N, int K, void* stream);
 int care_beam_pick(const float* pmax, const float* psum, int parts, const int32_t* cnt,
                    const float* cval, const int32_t* cidx, int cap, int bm, const void* A, int64_t lda,
                    int a_dtype, const void* W, int V, int K, float* cand_val, int32_t* cand_idx,

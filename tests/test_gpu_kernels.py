@@ -654,6 +654,29 @@ def test_fused_beam_selection_equals_logits_plus_beam_select(M, V, bm):
     _call("care_beam_pick", _p(pmax), _p(psum), parts, _p(cnt), _p(cval), _p(cidx), cap, bm, _p(A), K, 1, _p(W), V, K,
           _p(got_v), _p(got_i), M)
     torch.cuda.synchronize()
+    if _lib.load().care_beam_sparse_applies(M, V, K, 1):
+        # the sparse second pass (csrc/beam_sparse.hip): the same statistics + the maxima of every (tile, row), then
+        # only the (tile, row) products that can hold a candidate - the same candidate SETS, hence the same picks
+        tiles = (V + 31) // 32
+        tmx = torch.full((tiles, M), float("nan"), device=DEV)
+        pm2, ps2, pi2 = torch.empty_like(pmax), torch.empty_like(psum), torch.empty_like(pidx)
+        thr2 = torch.empty_like(thr); cnt2 = torch.full_like(cnt, -1)
+        cval2, cidx2 = torch.empty_like(cval), torch.empty_like(cidx)
+        tcount = torch.full((tiles,), -3, device=DEV, dtype=torch.int32)
+        tlist = torch.empty(tiles, M, device=DEV, dtype=torch.int32)
+        sp_v, sp_i = torch.zeros_like(got_v), torch.zeros_like(got_i)
+        _call("care_gemm_argmax_bf16_tiles", _p(A), K, 1, _p(W), _p(pm2), _p(pi2), _p(ps2), _p(tmx), M, V, K, 8)
+        _call("care_beam_threshold", _p(pm2), parts, bm, _p(thr2), _p(cnt2), M)
+        _call("care_beam_sparse_collect", _p(A), K, _p(W), _p(tmx), _p(thr2), _p(cnt2), _p(cval2), _p(cidx2), cap,
+              _p(tcount), _p(tlist), M, V, K)
+        _call("care_beam_pick", _p(pm2), _p(ps2), parts, _p(cnt2), _p(cval2), _p(cidx2), cap, bm, _p(A), K, 1, _p(W), V, K,
+              _p(sp_v), _p(sp_i), M)
+        torch.cuda.synchronize()
+        assert torch.equal(pm2, pmax) and torch.equal(pi2, pidx) and torch.equal(ps2, psum)
+        assert torch.equal(tmx.max(0).values, pmax.max(1).values)      # the map's row maxima are the rows' maxima
+        assert torch.equal(cnt2, cnt)                                   # the same number of candidates per row ...
+        assert torch.equal(sp_i, got_i) and torch.equal(sp_v, got_v)    # ... and the same picks, bit for bit
+        assert int(tcount.sum()) >= M and int(tcount.max()) <= M
     assert int(cnt.min()) >= bm                      # at least bm candidates reach every threshold
     if V > 5000:
         assert int(cnt[1]) > cap                     # the plateau row did overflow

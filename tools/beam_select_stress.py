@@ -50,6 +50,18 @@ def main():
         over = cnt > cap
         assert torch.equal(got_i[~over], ref_i[~over]), (it, M, V, bm, parts)
         assert (got_v[~over] - ref_v[~over]).abs().max().item() < 2e-5
+        if _lib.load().care_beam_sparse_applies(M, V, K, 1):  # the sparse second pass: same candidate sets, same picks
+            tiles = (V + 31) // 32
+            tmx = torch.empty(tiles, M, device=DEV)
+            cnt2 = torch.full_like(cnt, -1); cval2, cidx2 = torch.empty_like(cval), torch.empty_like(cidx)
+            tcount = torch.empty(tiles, device=DEV, dtype=torch.int32); tlist = torch.empty(tiles, M, device=DEV, dtype=torch.int32)
+            sp_v, sp_i = torch.zeros_like(got_v), torch.zeros_like(got_i)
+            call("care_gemm_argmax_bf16_tiles", p(A), K, 1, p(W), p(pmax), p(pidx), p(psum), p(tmx), M, V, K, 8)
+            call("care_beam_threshold", p(pmax), parts, bm, p(thr), p(cnt2), M)
+            call("care_beam_sparse_collect", p(A), K, p(W), p(tmx), p(thr), p(cnt2), p(cval2), p(cidx2), cap, p(tcount), p(tlist), M, V, K)
+            call("care_beam_pick", p(pmax), p(psum), parts, p(cnt2), p(cval2), p(cidx2), cap, bm, p(A), K, 1, p(W), V, K, p(sp_v), p(sp_i), M)
+            torch.cuda.synchronize()
+            assert torch.equal(cnt2, cnt) and torch.equal(sp_i, got_i) and torch.equal(sp_v, got_v), ("sparse pass", it, M, V, bm)
         print("case %d: M=%d V=%d bm=%d parts=%d ok (%d rows overflowed)" % (it, M, V, bm, parts, int(over.sum())), flush=True)
 
 
