@@ -105,7 +105,12 @@ def extra_legs(dev, main_dtype):
 
     legs = {}
 
+    import gc
+
     def build(config, dtype, row_scale=None, **over):
+        # engines of finished legs (GBs of workspaces, captured graphs, model <-> engine cycles) go before the next one
+        gc.collect()
+        torch.cuda.empty_cache()
         opt = make_opt(config, **over)
         model = get_framework(opt).eval()
         P = synth_state_dict(0, [(k, tuple(v.shape)) for k, v in model.state_dict().items()], row_scale=row_scale or {})
@@ -140,6 +145,7 @@ def extra_legs(dev, main_dtype):
     legs["vatex_care_large"] = greedy_leg("vatex_care_large", main_dtype, 4096)[0]
     # BASELINE configs[4]: CARE, beam 5 (opts.py beam_size 5), and at the reference's batch of 128
     for B in (4096, 128):
+        eng = None
         opt, eng = build("msrvtt_care_beam5", main_dtype)
         feats = feats_for(opt, B)
         run = lambda: eng.translate_beam(feats, 5, 5, use_graph=True, lean=True)
