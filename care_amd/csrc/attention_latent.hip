@@ -401,5 +401,7 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
   // tuning: 0 = 4 waves x 2 slots, 1 = 3 waves x 3 slots (read once; initialisation is thread-safe)
   static const int cfg = [] { const char* e = getenv("CARE_LAT_CFG"); return e ? atoi(e) : 0; }();
   if (cfg == 1) return launch_latent<3, 3>(p, st);
+  if (cfg == 2) return launch_latent<3, 2>(p, st);
+  if (cfg == 3) return launch_latent<2, 4>(p, st);
   return launch_latent<4, 2>(p, st);
 }
