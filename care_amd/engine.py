@@ -291,11 +291,11 @@ class HipEngine:
 
     def _beam_sparse_ws(self, tag: str, rows: int):
         """Workspaces of the sparse second pass (csrc/beam_sparse.hip) - (tile maxima [tiles, rows] fp32, per-tile
-        row counts, per-tile row lists [tiles, rows]) - or None where the 256-row statistics kernel does not apply."""
+        row counts + work-unit prefix sums [2 tiles + 1], per-tile row lists [tiles, rows]) - or None where the 256-row statistics kernel does not apply."""
         if os.environ.get("CARE_BEAM_SPARSE", "1") == "0" or not _lib.load().care_beam_sparse_applies(rows, self.V, self.d, 1):
             return None
         tiles = (self.V + 31) // 32
-        return (self.ws(tag + "stmax", (tiles, rows)), self.ws(tag + "stcount", (tiles,), torch.int32),
+        return (self.ws(tag + "stmax", (tiles, rows)), self.ws(tag + "stcount", (2 * tiles + 1,), torch.int32),
                 self.ws(tag + "stlist", (tiles, rows), torch.int32))
 
     def beam_fused_for(self, rows: int) -> bool:

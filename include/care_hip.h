@@ -357,7 +357,8 @@ int care_gemm_collect_bf16(const void* A, int64_t lda, int a_dtype, const void* 
  * The SPARSE second pass (large row counts, K = 512, bf16 rows: care_beam_sparse_applies): step 1 as
  *   care_gemm_argmax_bf16_tiles, which also writes tile_max [ceil(N / 32), M] fp32 - the maximum of every
  *   (32-column tile, row); step 3 as care_beam_sparse_collect, which lists per tile the rows whose tile
- *   maximum reaches thr[row] (tcount [tiles], tlist [tiles, M] int32 scratch) and recomputes ONLY those
+ *   maximum reaches thr[row] (tcount [2 tiles + 1], tlist [tiles, M] int32 scratch: counts, then the
+ *   prefix sums of the 128-entry work units) and recomputes ONLY those
  *   (tile, row) products - the same MFMA chain as the first pass, bit-identical logits - appending the
  *   logits >= thr[row] to cval / cidx exactly like care_gemm_collect_bf16 (~2 % of its arithmetic).
  */

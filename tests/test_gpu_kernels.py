@@ -662,7 +662,7 @@ def test_fused_beam_selection_equals_logits_plus_beam_select(M, V, bm):
         pm2, ps2, pi2 = torch.empty_like(pmax), torch.empty_like(psum), torch.empty_like(pidx)
         thr2 = torch.empty_like(thr); cnt2 = torch.full_like(cnt, -1)
         cval2, cidx2 = torch.empty_like(cval), torch.empty_like(cidx)
-        tcount = torch.full((tiles,), -3, device=DEV, dtype=torch.int32)
+        tcount = torch.full((2 * tiles + 1,), -3, device=DEV, dtype=torch.int32)  # counts, then work-unit prefix sums
         tlist = torch.empty(tiles, M, device=DEV, dtype=torch.int32)
         sp_v, sp_i = torch.zeros_like(got_v), torch.zeros_like(got_i)
         _call("care_gemm_argmax_bf16_tiles", _p(A), K, 1, _p(W), _p(pm2), _p(pi2), _p(ps2), _p(tmx), M, V, K, 8)
@@ -676,7 +676,8 @@ def test_fused_beam_selection_equals_logits_plus_beam_select(M, V, bm):
         assert torch.equal(tmx.max(0).values, pmax.max(1).values)      # the map's row maxima are the rows' maxima
         assert torch.equal(cnt2, cnt)                                   # the same number of candidates per row ...
         assert torch.equal(sp_i, got_i) and torch.equal(sp_v, got_v)    # ... and the same picks, bit for bit
-        assert int(tcount.sum()) >= M and int(tcount.max()) <= M
+        assert int(tcount[:tiles].sum()) >= M and int(tcount[:tiles].max()) <= M
+        assert int(tcount[2 * tiles]) == int(((tcount[:tiles] + 127) // 128).sum())
     assert int(cnt.min()) >= bm                      # at least bm candidates reach every threshold
     if V > 5000:
         assert int(cnt[1]) > cap                     # the plateau row did overflow

@@ -54,7 +54,7 @@ def main():
             tiles = (V + 31) // 32
             tmx = torch.empty(tiles, M, device=DEV)
             cnt2 = torch.full_like(cnt, -1); cval2, cidx2 = torch.empty_like(cval), torch.empty_like(cidx)
-            tcount = torch.empty(tiles, device=DEV, dtype=torch.int32); tlist = torch.empty(tiles, M, device=DEV, dtype=torch.int32)
+            tcount = torch.empty(2 * tiles + 1, device=DEV, dtype=torch.int32); tlist = torch.empty(tiles, M, device=DEV, dtype=torch.int32)
             sp_v, sp_i = torch.zeros_like(got_v), torch.zeros_like(got_i)
             call("care_gemm_argmax_bf16_tiles", p(A), K, 1, p(W), p(pmax), p(pidx), p(psum), p(tmx), M, V, K, 8)
             call("care_beam_threshold", p(pmax), parts, bm, p(thr), p(cnt2), M)

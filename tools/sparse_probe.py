@@ -19,13 +19,13 @@ tmx = torch.empty(tiles, M, device=DEV)
 thr = torch.empty(M, device=DEV); cnt = torch.zeros(M, device=DEV, dtype=torch.int32)
 cap = 64
 cval = torch.empty(M, cap, device=DEV); cidx = torch.empty(M, cap, device=DEV, dtype=torch.int32)
-tcount = torch.zeros(tiles, device=DEV, dtype=torch.int32); tlist = torch.empty(tiles, M, device=DEV, dtype=torch.int32)
+tcount = torch.zeros(2 * tiles + 1, device=DEV, dtype=torch.int32); tlist = torch.empty(tiles, M, device=DEV, dtype=torch.int32)
 call("care_gemm_argmax_bf16_tiles", p(A), K, 1, p(W), p(pm), p(pi), p(ps), p(tmx), M, V, K, 8)
 call("care_beam_threshold", p(pm), parts, bm, p(thr), p(cnt), M)
 call("care_beam_sparse_collect", p(A), K, p(W), p(tmx), p(thr), p(cnt), p(cval), p(cidx), cap, p(tcount), p(tlist), M, V, K)
 torch.cuda.synchronize()
 print("parts %d; (tile,row) pairs %d = %.2f per row; per tile mean %.0f max %d; candidates per row mean %.2f max %d" % (
-    parts, int(tcount.sum()), float(tcount.sum()) / M, float(tcount.float().mean()), int(tcount.max()), float(cnt.float().mean()), int(cnt.max())))
+    parts, int(tcount[:tiles].sum()), float(tcount[:tiles].sum()) / M, float(tcount[:tiles].float().mean()), int(tcount[:tiles].max()), float(cnt.float().mean()), int(cnt.max())))
 def sparse():
     call("care_beam_threshold", p(pm), parts, bm, p(thr), p(cnt), M)
     call("care_beam_sparse_collect", p(A), K, p(W), p(tmx), p(thr), p(cnt), p(cval), p(cidx), cap, p(tcount), p(tlist), M, V, K)
