@@ -307,6 +307,17 @@ int launch_ln(const LnArgs& p, hipStream_t st) {
 #ifndef CARE_LN_DBG
 #define CARE_LN_DBG 0  // ablation builds (tools/ln_ablate.sh): 1 no MFMA, 2 no W DMA, 4 no A DMA, 8 no fragment reads
 #endif
+// the step's MFMA: bf16 operands, or - split products - the same registers holding fp16 pieces
+template <bool F16>
+__device__ __forceinline__ f32x4 ln2_mfma(const bf16x8& b, const bf16x8& a, const f32x4& c) {
+  if constexpr (F16) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void ln2_wait_vm() {
   static_assert(N >= 0 && N <= 63, "vmcnt immediate");
@@ -331,10 +342,11 @@ __device__ __forceinline__ void ln2_wait_stages(int younger) {
 // A template parameter because a run-time condition per load makes hipcc branch around every load and
 // wait for it on the spot, and duplicating the epilogue behind ONE run-time branch made it spill the
 // 128 accumulators (700 B of scratch per lane).
-// REP = 3 (fp32 A, packed split weight only): the "split-bf16" product a_hi w_hi + a_hi w_lo + a_lo w_hi
-// with a = a_hi + a_lo, w = w_hi + w_lo in bf16 pieces - three bf16 MFMA passes instead of the 16x
-// slower exact-f32 MFMA, error ~2^-17 per operand (concept models: the embedder feeds a discrete
-// top-30 choice, see engine.load_weights).  Every REAL K step is three consecutive virtual steps that
+// REP = 3 (fp32 A, packed split weight only): the split product a_hi w_hi + a_hi w_lo + a_lo w_hi with
+// a = a_hi + a_lo, w = w_hi + w_lo in FP16 pieces (11 significant bits each: what is dropped, a_lo w_lo, is
+// ~2^-22 of a product - fp32-grade; bf16 pieces would leave 2^-17) - three fp16 MFMA passes, the same rate as
+// bf16, instead of the 16x slower exact-f32 MFMA (concept models: the embedder feeds a discrete top-30 choice,
+// see engine.load_weights).  Feature magnitudes must stay below fp16's 65504 (ViT / ResNet / VGGish features are O(1..100)).  Every REAL K step is three consecutive virtual steps that
 // share the A stage (converted as hi, hi, lo) and take the W stages w_hi, w_lo, w_hi of
 // care_pack_ln_weight_split.
 template <bool AF32, int RG, int NSW, int NSA, int EPI, int REP = 1>
@@ -445,14 +457,29 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
       if constexpr (AF32) {  // pairs -> one v_cvt_pk_bf16_f32 each
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        if constexpr (REP == 3) {  // split products: fp16 pieces (11 bits each) in the bf16-typed fragment registers
+          // (whole 32-bit pairs are moved: an element-wise bit_cast of the halves made hipcc drop the odd ones)
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+          u32x4v packed;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+          for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            bf16x2 pr = __builtin_convertvector(f32x2{r[t][c][e], r[t][c][e + 1]}, bf16x2);
-            if (lo) pr = __builtin_convertvector(f32x2{r[t][c][e] - (float)pr[0], r[t][c][e + 1] - (float)pr[1]}, bf16x2);
-            f[2 * part + t][4 * c + e] = pr[0]; f[2 * part + t][4 * c + e + 1] = pr[1];
-          }
+            for (int e = 0; e < 4; e += 2) {
+              f16x2 pr = __builtin_convertvector(f32x2{r[t][c][e], r[t][c][e + 1]}, f16x2);
+              if (lo) pr = __builtin_convertvector(f32x2{r[t][c][e] - (float)pr[0], r[t][c][e + 1] - (float)pr[1]}, f16x2);
+              packed[2 * c + (e >> 1)] = __builtin_bit_cast(unsigned, pr);
+            }
+          f[2 * part + t] = __builtin_bit_cast(bf16x8, packed);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              bf16x2 pr = __builtin_convertvector(f32x2{r[t][c][e], r[t][c][e + 1]}, bf16x2);
+              f[2 * part + t][4 * c + e] = pr[0]; f[2 * part + t][4 * c + e + 1] = pr[1];
+            }
+        }
       } else {
         f[2 * part + t] = r[t][0];
       }
@@ -509,7 +536,7 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (CARE_LN_DBG & 1) asm volatile("" :: "v"(fb0[q]), "v"(fa[mt]));
-        else acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[q], fa[mt], acc[mt][q], 0, 0, 0);
+        else acc[mt][q] = ln2_mfma<REP == 3>(fb0[q], fa[mt], acc[mt][q]);
     __builtin_amdgcn_sched_barrier(0);
     if (more) {
       // my stream's stage kt + 1 has landed (its younger instructions stay in flight); my reads of stage kt are done
@@ -531,7 +558,7 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (CARE_LN_DBG & 1) asm volatile("" :: "v"(fb1[q]), "v"(fa[mt]));
-        else acc[mt][4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[q], fa[mt], acc[mt][4 + q], 0, 0, 0);
+        else acc[mt][4 + q] = ln2_mfma<REP == 3>(fb1[q], fa[mt], acc[mt][4 + q]);
         const int m = mt * 4 + q;  // 0..15
         if ((m + 1) % (16 / NWI) == 0 || (m + 1) % (16 / (AE ? NAI : NAS)) == 0) {
           if (w_loader) { if ((m + 1) % (16 / NWI) == 0) dma_w(wst, wslot, m / (16 / NWI)); }
@@ -728,7 +755,7 @@ static int gemm_ln_impl(const void* A, int64_t lda, int a_dtype, const void* W, 
   // version 2 moves A in 256-byte pieces of a row: K must be a whole number of them
   const bool v2_ok = !pos && K % (a_dtype == CARE_F32 ? 64 : 128) == 0;
   if (w_packed && !(v2 && v2_ok)) return CARE_ESHAPE;  // only the version-2 kernels read the packed order
-  if (w_packed == 2) {  // split-bf16 products (care_pack_ln_weight_split): fp32 A, no residual
+  if (w_packed == 2) {  // split products (care_pack_ln_weight_split): fp32 A, no residual
     if (a_dtype != CARE_F32 || res) return CARE_ESHAPE;
     return big ? launch_ln2e<true, 2, 2, 3, 0, 3>(p, st) : launch_ln2e<true, 1, 3, 4, 0, 3>(p, st);
   }
@@ -766,8 +793,8 @@ extern "C" int care_gemm_ln_split(const void* A, int64_t lda, const void* W_spli
 }
 
 namespace {
-// W [512, K] fp32 -> the stream of the split-bf16 kernels: per real K step the three 32-KB LDS images
-// w_hi, w_lo, w_hi (w_hi = bf16(w), w_lo = bf16(w - w_hi)), rows and swizzled chunks as in pack_ln_weight_kernel
+// W [512, K] fp32 -> the stream of the split-product kernels: per real K step the three 32-KB LDS images
+// w_hi, w_lo, w_hi (w_hi = fp16(w), w_lo = fp16(w - w_hi)), rows and swizzled chunks as in pack_ln_weight_kernel
 __global__ void pack_ln_weight_split_kernel(const float* W, bf16_t* Wp, int K) {
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk of one of the three images
   const int64_t total = (int64_t)LN_N * K / 8 * 3;
@@ -778,11 +805,14 @@ __global__ void pack_ln_weight_split_kernel(const float* W, bf16_t* Wp, int K) {
   const int src_chunk = c ^ ((n & 8) >> 2);
   const float* src = W + (int64_t)n * K + kt * 32 + src_chunk * 8;
   bf16x8 o;
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  f16x8 oh;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const bf16_t hi = (bf16_t)src[e];
-    o[e] = j == 1 ? (bf16_t)(src[e] - (float)hi) : hi;
+  for (int e = 0; e < 8; ++e) {  // fp16 pieces in the 16-bit slots
+    const _Float16 hi = (_Float16)src[e];
+    oh[e] = j == 1 ? (_Float16)(src[e] - (float)hi) : hi;
   }
+  o = __builtin_bit_cast(bf16x8, oh);
   reinterpret_cast<bf16x8*>(Wp)[slot] = o;
 }
 }  // namespace

@@ -130,8 +130,8 @@ class HipEngine:
         # Concept detection ends in a DISCRETE choice (top-30 of 500, pred_attribute.py:264) whose
         # neighbouring probabilities differ by ~1e-4, below bf16 operand noise (~1.5e-3 measured).
         # So with a concept head the feature-embedding GEMMs keep fp32 operands even in bf16 mode:
-        # as three bf16 MFMA passes over hi/lo pieces (care_gemm_ln_split, memory within ~3e-5 of
-        # fp32, concept probabilities ~3e-6) where the fused kernel applies, in exact f32 MFMA
+        # as three fp16 MFMA passes over hi/lo pieces (care_gemm_ln_split: fp32-grade, memory within
+        # ~5e-6 of the reference) where the fused kernel applies, in exact f32 MFMA
         # otherwise (or with CARE_ENC_SPLIT=0); everything downstream of the choice is bf16.
         enc_wt = f32 if (self.has_concepts and opt["encoder"] == "Embedder") else wt
         for ch in self.modality:
@@ -468,7 +468,7 @@ class HipEngine:
             else:
                 dst, dstb, grp_rows, off = self.ws("enc_side_" + ch, (B, n, d)), None, n, 0
             ln_kw = dict(grp=n, out_grp_rows=grp_rows, out_row_off=off)
-            if fused and Ws is not None:  # the same, fp32 operands as hi/lo bf16 pieces (concept models)
+            if fused and Ws is not None:  # the same, fp32 operands as hi/lo fp16 pieces (concept models)
                 call("care_gemm_ln_split", ptr(x2), x2.stride(0), ptr(Ws), ptr(w["enc_b_" + ch]), ptr(w["enc_g_" + ch]),
                      ptr(w["enc_be_" + ch]), self.eps, ptr(dst), ptr(dstb), dst.stride(-2), B * n, d, x2.shape[1], n,
                      grp_rows, off, tag="enc_gemm")

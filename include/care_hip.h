@@ -204,10 +204,10 @@ int care_gemm_ln_packed(const void* A, int64_t lda, int a_dtype, const void* W_p
  * care_pack_ln_weight_split / care_gemm_ln_split: the Embedder's Linear -> LayerNorm
  *   (models/Encoder.py:167) for models whose memory feeds the DISCRETE concept choice
  *   (pred_attribute.py:88-125,262-264): fp32 A and an fp32 [512, K] weight, multiplied as
- *   a_hi w_hi + a_hi w_lo + a_lo w_hi with x_hi = bf16(x), x_lo = bf16(x - x_hi) - three bf16 MFMA
- *   passes accumulated in fp32 (operand error ~2^-17 instead of bf16's 2^-9; the a_lo w_lo term,
- *   ~2^-18 relative, is dropped).  W_split: 3 * K * 1024 bytes (per K step of 32 the LDS images of
- *   w_hi, w_lo, w_hi).  K % 64 == 0; no residual, no position table.
+ *   a_hi w_hi + a_hi w_lo + a_lo w_hi with x_hi = fp16(x), x_lo = fp16(x - x_hi) - three fp16 MFMA
+ *   passes accumulated in fp32 (11 bits per piece: the dropped a_lo w_lo term is ~2^-22 of a product,
+ *   fp32-grade, against bf16's 2^-9 per operand).  |x| < 65504.  W_split: 3 * K * 1024 bytes (per K
+ *   step of 32 the LDS images of w_hi, w_lo, w_hi).  K % 64 == 0; no residual, no position table.
  */
 int care_pack_ln_weight_split(const float* W, void* W_split, int N, int K, void* stream);
 int care_gemm_ln_split(const void* A, int64_t lda, const void* W_split, const float* bias,
