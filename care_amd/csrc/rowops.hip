@@ -123,17 +123,21 @@ __global__ __launch_bounds__(256) void concept_topk_embed_kernel(const float* pr
                                                                  int d) {
   // one workgroup per clip.  Rank by counting: rank(i) = #{j : v[j] > v[i] or (v[j] == v[i] and j < i)};
   // the element of rank r < topk is label r (value desc, index asc) - no iterative selection.
-  __shared__ float sv[1024];
+  __shared__ __attribute__((aligned(16))) float sv[1024];
   __shared__ int slab[64];
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < k; i += 256) sv[i] = preds[(int64_t)b * ldp + i];
+  const int k4 = (k + 3) & ~3;
+  for (int i = tid; i < k4; i += 256) sv[i] = i < k ? preds[(int64_t)b * ldp + i] : -INFINITY;  // pads never outrank
   __syncthreads();
   for (int i = tid; i < k; i += 256) {
     const float vi = sv[i];
     int rank = 0;
-    for (int j = 0; j < k; ++j) {
-      const float vj = sv[j];
-      rank += (vj > vi) || (vj == vi && j < i);
+    for (int j = 0; j < k4; j += 4) {  // four comparands per LDS read
+      const float4 vj = *reinterpret_cast<const float4*>(sv + j);
+      rank += (vj.x > vi) || (vj.x == vi && j < i);
+      rank += (vj.y > vi) || (vj.y == vi && j + 1 < i);
+      rank += (vj.z > vi) || (vj.z == vi && j + 2 < i);
+      rank += (vj.w > vi) || (vj.w == vi && j + 3 < i);
     }
     if (rank < topk) slab[rank] = i;
   }
