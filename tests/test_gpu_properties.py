@@ -223,13 +223,14 @@ def test_lean_encode_gives_identical_captions(config, B):
 PEAKED_ROWS = {"cls_head.tgt_word_prj.weight": {**{r: 12.0 for r in range(6, 46)}, 3: 20.0}}  # gen_golden.PEAKED
 
 
-@pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 16384), ("msrvtt_care", 4096)])
+@pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 16384), ("msrvtt_care", 4096), ("msrvtt_base_ami", 12345)])
 def test_benchmarked_operating_point_against_oracle_sample(config, B):
     """The code path bench.py times, end to end: bf16, lean encode, absorbed cross-attention, >= 10240
     rows (fused dense+LayerNorm in 128-row blocks, the 8-range vocabulary split), hipGraph replay - on
     a model with peaked (trained-like) logits, audited against the CPU oracle on a 64-clip sample
     spread over the batch: a clip whose every reference step is decided by >= 0.1 must be bit-exact,
-    any other divergence must start at a near-tie; replay == eager bit for bit."""
+    any other divergence must start at a near-tie; replay == eager bit for bit.  B = 12345: ragged last
+    panels in every 64- / 128- / 256-row kernel."""
     from oracle import care_cpu
     from test_gpu_parity import BF16_LSE_PEAKED, CLEAR_MARGIN, _audit_greedy
 
