@@ -14,6 +14,7 @@
 // the MFMA N axis.  One WAVE owns a row at a time (no workgroup barrier anywhere):
 //   * the row's memory streams through a wave-private LDS ring in chunks of 16 keys (16 KiB), one
 //     LDS-DMA instruction per key row (1 KiB, full lines), one chunk ahead of the arithmetic;
+//   * the row's expanded query is one more stage of the same ring in front of its chunks (round 2; see stage_q);
 //   * S^T[key][head]  = mem_chunk [16 x 512] . qt^T [512 x 16]: 16 MFMA 16x16x32, A fragments read
 //     row-wise from LDS (ds_read_b128), B = qt fragments resident in 64 VGPRs for the whole row;
 //   * online softmax per head: a lane holds 4 keys of one head, max / sum by two xor-shuffles;
@@ -25,14 +26,13 @@
 //     and leaves the row reads 2-way.
 // bf16 mode only (the fp32 parity mode keeps projected K/V and csrc/attention.hip).
 //
-// What bounds it (measured, 16384 rows, Lk = 84, 1.68 GB per launch): the DMA ring alone (no
-// arithmetic, no stores) streams the memory at 6.2 TB/s; with q~ loads and c~ stores 296 us; the
-// full kernel 316-334 us = 5.0-5.3 TB/s.  Removing the per-chunk accumulator copies (fixed softmax
-// reference, slow-path redo) and coalescing the stores through LDS changed NOTHING on the same box:
-// the arithmetic sits in slack.  The limit is bytes in flight - the 128 KiB of LDS ring per CU is
-// ~27 MB chip-wide, which at the ~5 us loaded latency is ~5 TB/s (the K/V kernel buffers 264 KiB
-// per CU in registers and reaches 6.1).  3 waves x 3 slots is slower (fewer waves), a fifth wave
-// does not fit the 160 KiB.
+// What bounds it.  Round 1 read the kernel as limited by bytes in flight (DMA ring alone 6.2 TB/s, full kernel
+// 5.0-5.3).  Round 2's ablation builds (tools/lat_ablate.sh, 32768 rows x 84 keys) found the actual costs: the
+// query load at the row start was waited for with vmcnt(0) - the wave's DMA queue drained once per row (658 us;
+// without q~ loads and c~ stores 465) - fixed by sending the query through the ring; the stream's cache policy
+// (673 -> 574 us with non-temporal loads and stores); and the c~ stores, whose cost is their bytes (no stores:
+// 513 us).  Arithmetic is hidden completely, and the ring depth no longer matters (3 waves x 2 slots within 1 %
+// of 4 x 2 and 3 x 3): 545-615 us per launch = 5.4-6.2 TB/s, the memory system's rate for this read/write mix.
 #include "care_common.h"
 
 #ifndef CARE_LAT_DBG
