@@ -24,6 +24,10 @@ def main():
         W = (torch.randn(V, K, device=DEV) * 0.05).to(torch.bfloat16)
         if V > 600:
             W[17] = W[400]  # exact ties
+        if it % 2 == 1:  # a frequent token: one column near the top of EVERY row (its tile is hot for all rows)
+            u = torch.randn(K, device=DEV)
+            A = (A.float() + 0.5 * u).to(torch.bfloat16)
+            W[min(V - 1, 777)] = (0.02 * u).to(torch.bfloat16)
         ld = (V + 63) // 64 * 64
         ref_v = torch.zeros(M, bm, device=DEV); ref_i = torch.zeros(M, bm, device=DEV, dtype=torch.int32)
         chunk = 4096
