@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -23,6 +23,8 @@ LIB_PATH = os.environ.get("CARE_HIP_LIB") or os.path.join(os.path.dirname(os.pat
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "care_gemm": [_P, _L, _P, _I, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "care_split3_weight": [_P, _P, _I, _I, _P],
+    "care_gemm_split3": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _P],
     "care_gemm_argmax": [_P, _L, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "care_gemm_bf16": [_P, _L, _I, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_gemm_argmax_bf16": [_P, _L, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -48,10 +48,17 @@ __device__ __forceinline__ void store_out(void* C, int64_t ld, int is_bf16, int 
   else reinterpret_cast<float*>(C)[(int64_t)row * ld + col] = v;
 }
 
-template <typename WT, int BM, int BN, bool ARGMAX>
+// SPLIT (16-bit W only): the split product of fp32 operands, A = A_hi + A_lo, W = W_hi + W_lo in FP16 pieces,
+//   C = A_hi W_hi^T + A_hi W_lo^T + A_lo W_hi^T  as ONE product over 3K: W is the [N, 3K] concatenation W_hi | W_lo | W_hi
+//   (care_split3_weight), the A tile of virtual column block k0 comes from real columns k0 % K, converted to its
+//   high piece in the first two thirds and to its low piece in the last; v_mfma_f32_16x16x32_f16.  What is dropped
+//   (A_lo W_lo) is ~2^-22 of a product: fp32-grade, at a third of the bf16 rate instead of the exact-f32 MFMA's 1/16.
+template <typename WT, int BM, int BN, bool ARGMAX, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   constexpr int BK = KTraits<WT>::BK;
   constexpr bool BF = sizeof(WT) == 2;
+  static_assert(!SPLIT || BF, "split products take 16-bit weight pieces");
+  const int KW = SPLIT ? 3 * p.K : p.K;  // columns of W (and of the virtual product)
   constexpr int MT = BM / 32, NT = BN / 32;
   // A staging: f32 mode 8 16-byte chunks per row, bf16 mode 16 float4 per row (-> 8 bytes each)
   constexpr int A_CH = BF ? 16 : 8;
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       // rows past M are clamped, not branched around: their products are never stored, and a
       // branch per unrolled load would serialise the loads behind vmcnt(0) waits
       const int gr = min(m0 + row, p.M - 1);
-      ra[i] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)gr * p.lda + k0 + ch * 4);
+      ra[i] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)gr * p.lda + (SPLIT ? k0 % p.K : k0) + ch * 4);
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
@@ -89,17 +96,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       int row = c >> 3, ch = c & 7;
       const int gn = min(n0 + row, p.N - 1);
       rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.W) +
-                                              ((int64_t)gn * p.K + k0) * sizeof(WT) + ch * 16);
+                                              ((int64_t)gn * KW + k0) * sizeof(WT) + ch * 16);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int k0) {
+    const bool lo_piece = SPLIT && k0 >= 2 * p.K;
     unsigned char* a = sA + buf * BM * 128;
     unsigned char* b = sB + buf * BN * 128;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int c = i * 256 + tid;
       int row = c / A_CH, ch = c % A_CH;
-      if constexpr (BF) {
+      if constexpr (SPLIT) {  // fp16 pieces, moved as whole 32-bit pairs
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 v;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          f16x2 pr = __builtin_convertvector(f32x2{ra[i][e], ra[i][e + 1]}, f16x2);
+          if (lo_piece) pr = __builtin_convertvector(f32x2{ra[i][e] - (float)pr[0], ra[i][e + 1] - (float)pr[1]}, f16x2);
+          v[e >> 1] = __builtin_bit_cast(unsigned, pr);
+        }
+        *reinterpret_cast<u32x2*>(a + row * 128 + ((((ch >> 1) ^ (row & 7))) << 4) + (ch & 1) * 8) = v;
+      } else if constexpr (BF) {
         bf16x4 v;
         v[0] = (bf16_t)ra[i][0]; v[1] = (bf16_t)ra[i][1]; v[2] = (bf16_t)ra[i][2]; v[3] = (bf16_t)ra[i][3];
         *reinterpret_cast<bf16x4*>(a + row * 128 + ((((ch >> 1) ^ (row & 7))) << 4) + (ch & 1) * 8) = v;
@@ -121,9 +141,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
+  const int nk = KW / BK;
   load_tile(0);
-  store_tile(0);
+  store_tile(0, 0);
   __syncthreads();
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -147,7 +167,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+            if constexpr (SPLIT) {
+              typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[m]), __builtin_bit_cast(f16x8, fb[n]),
+                                                                 acc[m][n], 0, 0, 0);
+            } else {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+            }
       } else {
         f32x4 fa[MT], fb[NT];
 #pragma unroll
@@ -163,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
               acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][j], fb[n][j], acc[m][n], 0, 0, 0);
       }
     }
-    store_tile(buf ^ 1);
+    store_tile(buf ^ 1, min(kt + 1, nk - 1) * BK);
     __syncthreads();
   }
 
@@ -226,12 +252,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
-template <typename WT, int BM, int BN, bool ARGMAX>
+template <typename WT, int BM, int BN, bool ARGMAX, bool SPLIT = false>
 int launch(const GemmArgs& p, hipStream_t st) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const size_t lds = 2 * (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<WT, BM, BN, ARGMAX>), dim3(tiles), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<WT, BM, BN, ARGMAX, SPLIT>), dim3(tiles), dim3(256), lds, st, p);
   return care_launch_status();
+}
+
+// W [N, K] fp32 -> [N, 3K] fp16 pieces  W_hi | W_lo | W_hi  (the operand of care_gemm_split3)
+__global__ void split3_weight_kernel(const float* W, unsigned short* out, int N, int K) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)N * K) return;
+  const int n = (int)(i / K), k = (int)(i % K);
+  const _Float16 hi = (_Float16)W[i];
+  const _Float16 lo = (_Float16)(W[i] - (float)hi);
+  unsigned short* row = out + (int64_t)n * 3 * K;
+  row[k] = __builtin_bit_cast(unsigned short, hi);
+  row[K + k] = __builtin_bit_cast(unsigned short, lo);
+  row[2 * K + k] = __builtin_bit_cast(unsigned short, hi);
 }
 
 int check_common(const float* A, int64_t lda, const void* W, int wdtype, int M, int N, int K) {
@@ -271,6 +310,29 @@ extern "C" int care_gemm(const float* A, int64_t lda, const void* W, int wdtype,
   if (wdtype == CARE_BF16)
     return big ? launch<bf16_t, 128, 128, false>(p, st) : launch<bf16_t, 64, 64, false>(p, st);
   return big ? launch<float, 128, 128, false>(p, st) : launch<float, 64, 64, false>(p, st);
+}
+
+extern "C" int care_split3_weight(const float* W, void* W3, int N, int K, void* stream) {
+  if (!W || !W3 || N <= 0 || K <= 0) return CARE_EINVAL;
+  const int64_t total = (int64_t)N * K;
+  hipLaunchKernelGGL(split3_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+                     reinterpret_cast<unsigned short*>(W3), N, K);
+  return care_launch_status();
+}
+
+// C = A W^T + bias with fp32-grade products at a third of the bf16 rate (see gemm_kernel, SPLIT): A [M, K] fp32,
+// W3 = care_split3_weight(W) [N, 3K] fp16 pieces, C fp32 [M, ldc].  K % 64 == 0.
+extern "C" int care_gemm_split3(const float* A, int64_t lda, const void* W3, const float* bias, float* C, int64_t ldc,
+                                int M, int N, int K, void* stream) {
+  int rc = check_common(A, lda, W3, CARE_BF16, M, N, K);
+  if (rc) return rc;
+  if (!C) return CARE_EINVAL;
+  GemmArgs p{};
+  p.A = A; p.lda = lda; p.W = W3; p.bias = bias;
+  p.C0 = C; p.ldc0 = ldc; p.c0_bf16 = 0; p.C1 = nullptr; p.n_split = N; p.M = M; p.N = N; p.K = K; p.act = CARE_ACT_NONE;
+  hipStream_t st = (hipStream_t)stream;
+  const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  return big_tiles >= 512 ? launch<bf16_t, 128, 128, false, true>(p, st) : launch<bf16_t, 64, 64, false, true>(p, st);
 }
 
 extern "C" int care_argmax_parts(int N) { return N > 0 ? 2 * ((N + 127) / 128) : CARE_EINVAL; }

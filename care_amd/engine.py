@@ -200,6 +200,15 @@ class HipEngine:
                     Ws = torch.empty(3 * W.shape[1] * 512, device=self.device, dtype=torch.bfloat16)
                     call("care_pack_ln_weight_split", ptr(W), ptr(Ws), 512, W.shape[1])
                     w[name + "#split"] = Ws
+        if self.bf and self.has_concepts and opt["encoder"] == "Embedder" and os.environ.get("CARE_ENC_SPLIT", "1") != "0":
+            # concept models the fused kernel does not cover (d_model != 512): the embedder GEMM with split products
+            # through the generic kernel (care_gemm_split3) instead of its exact-f32 MFMA
+            for ch in self.modality:
+                W = w["enc_w_" + ch]
+                if ("enc_w_" + ch + "#split") not in w and W.dtype == torch.float32 and W.shape[1] % 64 == 0:
+                    W3 = torch.empty(W.shape[0], 3 * W.shape[1], device=self.device, dtype=torch.float16)
+                    call("care_split3_weight", ptr(W), ptr(W3), W.shape[0], W.shape[1])
+                    w["enc_w_" + ch + "#split3"] = W3
         self.w = w
         self._graphs.clear()
 
@@ -460,8 +469,15 @@ class HipEngine:
             Ws = w.get("enc_w_" + ch + "#split")
             fused = (opt["encoder"] == "Embedder" and self.as_ok and d == 512 and
                      (w["enc_w_" + ch].dtype == torch.bfloat16 or Ws is not None) and x2.shape[1] % 32 == 0)
-            lin = None if fused else self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch],
-                                               self.ws("enc_lin", (B * n, d)), tag="enc_gemm")
+            W3 = w.get("enc_w_" + ch + "#split3")
+            if fused:
+                lin = None
+            elif W3 is not None:
+                lin = self.ws("enc_lin", (B * n, d))
+                call("care_gemm_split3", ptr(x2), x2.stride(0), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
+                     B * n, d, x2.shape[1], tag="enc_gemm")
+            else:
+                lin = self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch], self.ws("enc_lin", (B * n, d)), tag="enc_gemm")
             in_mem = ch in self.dec_mod
             if in_mem:
                 dst, dstb, grp_rows, off = mem, memb, self.Lk, self.mem_off[ch]

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 12
+#define CARE_ABI_VERSION 13
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -75,6 +75,17 @@ int care_gemm(const float* A, int64_t lda, const void* W, int wdtype, const floa
 int care_argmax_parts(int N);
 int care_gemm_argmax(const float* A, int64_t lda, const void* W, int wdtype,
                      float* pmax, int32_t* pidx, float* psum, int M, int N, int K, void* stream);
+
+/*
+ * care_split3_weight / care_gemm_split3: C = A W^T + bias for fp32 A and an fp32 weight with fp32-GRADE products at a
+ *   third of the 16-bit MFMA rate (the exact-f32 MFMA of care_gemm runs at 1/16): operands split into fp16 pieces,
+ *   A_hi W_hi + A_hi W_lo + A_lo W_hi as one product over 3K (the dropped term is ~2^-22 of a product).  The
+ *   feature embedder (models/Encoder.py:167) of concept models whose d_model the fused care_gemm_ln_split does not
+ *   cover.  W3: [N, 3K] 16-bit (W_hi | W_lo | W_hi), made once by care_split3_weight; C fp32; K % 64 == 0; |A| < 65504.
+ */
+int care_split3_weight(const float* W, void* W3, int N, int K, void* stream);
+int care_gemm_split3(const float* A, int64_t lda, const void* W3, const float* bias, float* C,
+                     int64_t ldc, int M, int N, int K, void* stream);
 
 /*
  * care_gemm_bf16 / care_gemm_argmax_bf16: the same contracts as care_gemm /

@@ -434,6 +434,28 @@ def test_gemm_ln_fused(a_f32, M, K, form, monkeypatch):
     assert torch.equal(outb, out.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("M,N,K", [(70, 1024, 64), (28 * 41, 1024, 2048), (4500, 768, 512), (28 * 1200, 1024, 128)])
+def test_gemm_split3_products(M, N, K):
+    """care_gemm_split3: the generic GEMM with fp32 operands as fp16 hi/lo pieces (one product over 3K) - against the
+    same three products in float64 and against the exact product (what it stands in for)."""
+    A = _rand(M, K, seed=70)
+    W = _rand(N, K, seed=71, scale=1 / math.sqrt(K))
+    bias = _rand(N, seed=72)
+    W3 = torch.empty(N, 3 * K, device=DEV, dtype=torch.float16)
+    C = torch.full((M, N + 8), float("nan"), device=DEV)
+    _call("care_split3_weight", _p(W), _p(W3), N, K)
+    _call("care_gemm_split3", _p(A), K, _p(W3), _p(bias), _p(C), N + 8, M, N, K)
+    torch.cuda.synchronize()
+    hi = lambda x: x.to(torch.float16).float()
+    lo = lambda x: (x - hi(x)).to(torch.float16).float()
+    assert torch.equal(W3[:, :K].float(), hi(W)) and torch.equal(W3[:, K:2 * K].float(), lo(W)) and torch.equal(W3[:, 2 * K:], W3[:, :K])
+    y3 = hi(A).double() @ hi(W).double().t() + hi(A).double() @ lo(W).double().t() + lo(A).double() @ hi(W).double().t() + bias
+    got = C[:, :N]
+    assert (got - y3).abs().max().item() < 3e-6 * math.sqrt(K / 64)
+    assert (got - (A.double() @ W.double().t() + bias)).abs().max().item() < 4e-6 * math.sqrt(K / 64)
+    assert torch.isnan(C[:, N:]).all()
+
+
 @pytest.mark.parametrize("M,K", [(56, 64), (28 * 37, 2048), (28 * 9 + 5, 4096), (300, 1024), (28 * 400, 2048)])
 def test_gemm_ln_split_products(M, K):
     """care_gemm_ln_split: fp32 operands as hi/lo FP16 pieces, three MFMA passes.  Against the SAME three
