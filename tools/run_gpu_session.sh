@@ -1,8 +1,2 @@
-R=$PWD; O=$R/gpurun_out/r2k; mkdir -p $O
-timeout -k 5 900 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/tests.log; cat $O/tests.log
-timeout -k 5 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout -k 5 600 python bench.py > $O/bench_full.log 2>&1; tail -1 $O/bench_full.log | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_us'])
-for k,v in d.get('legs',{}).items(): print(' ', k, {a:b for a,b in v.items() if a in ('captions_per_s','ms_per_pass','speedup_vs_fixed_29')})"
+timeout -k 5 400 python -m pytest tests/test_gpu_kernels.py -q -x -m gpu -k "gemm_store or gemm_bf16 or test_gemm" 2>&1 | tail -2
+timeout -k 5 600 python -m pytest tests/test_gpu_properties.py -q -x -m gpu 2>&1 | tail -2
