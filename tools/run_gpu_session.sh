@@ -1,2 +1,6 @@
-timeout -k 5 400 python -m pytest tests/test_gpu_kernels.py -q -x -m gpu -k "gemm_store or gemm_bf16 or test_gemm" 2>&1 | tail -2
-timeout -k 5 600 python -m pytest tests/test_gpu_properties.py -q -x -m gpu 2>&1 | tail -2
+for v in "" ln16 "" ln16; do
+lib=""; [ -n "$v" ] && lib=care_amd/dbg/libcare_hip_$v.so
+CARE_HIP_LIB=$lib timeout -k 5 200 python bench.py --no-legs --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); k=d['kernels']; print('variant [$v]', d['value'], d['ms_per_step'], 'dxd_ln %.1f ffn_ln %.1f enc %.1f' % (k['step_dxd_ln']['avg_us'], k['step_ffn_gemm_ln']['avg_us'], k['enc_gemm']['avg_us']))"
+done
