@@ -33,6 +33,7 @@ constexpr int VT_BYTES = VT_N * 1024;    // K = 512 bf16
 constexpr int V_RING = 4, V_AHEAD = 3;
 constexpr int V_LDS = V_RING * VT_BYTES;
 constexpr int V_ROWS = 256;              // rows per workgroup (8 waves x 32)
+constexpr float V_LOG2E = 1.4426950408889634f;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -52,6 +53,9 @@ enum { V_ARGMAX = 0, V_COLLECT = 1 };
 constexpr int V_STAGE = 8192;                  // collect: LDS staging of the candidates of one work item
 constexpr int V_LCAP = (V_STAGE - 8) / 8;
 
+#ifndef V32_STAGGER
+#define V32_STAGGER 1  // the two waves of a SIMD take MFMAs / statistics in opposite order (0: both multiply first)
+#endif
 #ifndef CARE_V32_DBG
 #define CARE_V32_DBG 0  // ablation: 2 no MFMA, 16 no statistics, 32 no fragment reads
 #endif
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
     auto boff = [&](int ks) { return bswz + ((((2 * ks + h) ^ (r & 15)) & 15) << 4) + ((2 * ks) >> 4) * 256; };
 
     float rm = -1e30f, rs = 0.f, rref = -1e30f;
+    float rref2 = -1e30f * V_LOG2E;  // rref * log2(e): one fma + one exp2 per logit (MFMA and VALU time ADD on a SIMD, §4.1c)
     int ri = 0x7fffffff;
     f32x16 acc, accp;
 #pragma unroll
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
     float tmax = -INFINITY;
     auto stat_piece = [&](int i) {  // logit i of 16
       tmax = fmaxf(tmax, accp[i]);
-      if (!COLLECT) rs += __expf(accp[i] - rref);
+      if (!COLLECT) rs += __builtin_amdgcn_exp2f(fmaf(accp[i], V_LOG2E, -rref2));
     };
     auto append_global = [&](int grow, float v, int c) {
       const int pos = atomicAdd(&p.cnt[grow], 1);
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
         for (int i = 0; i < 16; ++i)
           if (tile * VT_N + col_in_tile(i) >= p.N) accp[i] = -INFINITY;
       }
-      if (first && !COLLECT) rref = fmaxf(accp[0], -1e30f);
+      if (first && !COLLECT) { rref = fmaxf(accp[0], -1e30f); rref2 = rref * V_LOG2E; }
       tmax = -INFINITY;
     };
     auto stat_close = [&](int tile) {
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
       }
       if (rm - rref > 20.0f) {  // keep the sum's reference within e^20 of the maximum
         rs *= __expf(rref - rm);
-        rref = rm;
+        rref = rm; rref2 = rref * V_LOG2E;
       }
     };
 
@@ -224,7 +229,25 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
       __builtin_amdgcn_sched_barrier(0);
 
       const unsigned char* sb = smem + (it % V_RING) * VT_BYTES;
-      if constexpr (STATS) stat_open(t - 1, (t - 1) % tpb == 0);
+      // A wave cannot issue VALU work in the shadow of its OWN MFMAs (tools/micro/mfma_valu_overlap.hip: they add), so
+      // the statistics of tile t - 1 (~180 VALU instructions) only overlap the matrix pipe if the OTHER wave of the SIMD
+      // is multiplying meanwhile.  The per-tile barrier starts all eight waves together: left alone both waves of a SIMD
+      // queue for the matrix pipe and then for the VALU.  So the two waves of a SIMD (w and w + 4) take the two halves
+      // of a tile step in opposite order: waves 0-3 multiply first, waves 4-7 do their statistics first.
+      const bool stats_first = (V32_STAGGER == 1 && wave >= 4) || (V32_STAGGER == 2 && (wave & 1)) || (V32_STAGGER == 3 && (wave & 2));
+      auto stats_prev = [&]() {
+        stat_open(t - 1, (t - 1) % tpb == 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) stat_piece(i);
+        stat_close(t - 1);
+      };
+      if constexpr (STATS) {
+        if (stats_first) {
+          stats_prev();
+          asm volatile("" : "+v"(rs), "+v"(rm), "+v"(rref), "+v"(rref2));  // done before the first MFMA, not sunk behind the chain
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
       bf16x8 fb[BDEPTH];
 #pragma unroll
       for (int ks = 0; ks < BDEPTH; ++ks) {
@@ -239,10 +262,11 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
         if (ks + BDEPTH < 32 && !(CARE_V32_DBG & 32)) fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff(ks + BDEPTH));
         if (CARE_V32_DBG & 2) asm volatile("" :: "v"(b));
         else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[ks], acc, 0, 0, 0);  // D[n][m]: lane = row m, 16 columns n
-        if constexpr (STATS) { if (ks & 1) stat_piece(ks >> 1); }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (STATS) stat_close(t - 1);
+      if constexpr (STATS) {
+        if (!stats_first) stats_prev();
+      }
       accp = acc;
     };
     // the statistics of a finished range: merge the two lanes of a row (columns 4 h + ...), write (max, argmax,
@@ -260,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
         const int64_t o = (int64_t)row * p.ns + range;
         p.pmax[o] = mn; p.pidx[o] = id; p.psum[o] = sx;
       }
-      rm = -1e30f; rs = 0.f; rref = -1e30f; ri = 0x7fffffff;
+      rm = -1e30f; rs = 0.f; rref = -1e30f; rref2 = -1e30f * V_LOG2E; ri = 0x7fffffff;
     };
     tile_body(t0, std::false_type{});
 #pragma unroll 1
