@@ -1,14 +1,7 @@
-R=$PWD; O=$R/gpurun_out/r2m; mkdir -p $O
-timeout -k 5 900 python -m pytest tests -q -m gpu 2>&1 | tail -2 > $O/tests.log; cat $O/tests.log
-timeout -k 5 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout -k 5 600 python bench.py > $O/bench_full.log 2>&1; tail -1 $O/bench_full.log | python -c "
+timeout -k 5 400 python -m pytest tests/test_gpu_kernels.py -q -x -m gpu -k "vocab_argmax or fused_beam or greedy" 2>&1 | tail -2
+for v in "" prev "" prev "" prev; do
+lib=""; [ -n "$v" ] && lib=care_amd/dbg/libcare_hip_$v.so
+CARE_HIP_LIB=$lib timeout -k 5 200 python bench.py --no-legs --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read())
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_us'])
-for k,v in d['kernels'].items(): print('  %-20s %4d x %8.1f' % (k, v['launches'], v['avg_us']))
-for k,v in d.get('legs',{}).items(): print(' ', k, {a:b for a,b in v.items() if a in ('captions_per_s','ms_per_pass','speedup_vs_fixed_29')})"
-cd /tmp; export TMPDIR=/tmp
-timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-legs > $O/prof_stats.log 2>&1
-cd $R
-f=$(find $O/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv && head -3 $O/kernel_stats.csv | cut -c1-150
-find $O -name "*kernel_trace.csv" -delete
+d=json.loads(sys.stdin.read()); k=d['kernels']; print('variant [$v]', d['value'], d['ms_per_step'], 'vocab %.1f cross %.1f' % (k['step_vocab_argmax']['avg_us'], k['step_cross_attn']['avg_us']))"
+done
