@@ -7,8 +7,9 @@ sit beside them) and `hyper_parameters = {'opt': {...}, 'new_opt_used_to_overrid
 merges `{**opt, **new_opt_used_to_override}` (`Wrapper.py:29,402-403`) and rewrites the
 dataset paths stored in `opt`.  Lightning is not needed for any of that; this module reads
 the same file with an ALLOW-LIST unpickler - checkpoints are the "pre-trained models released by
-others" case, so nothing outside tensors, plain containers and numpy scalars is ever imported or
-called (Lightning's `AttributeDict` becomes a dict; any other global raises UnpicklingError) -
+others" case, so nothing outside tensors, plain containers, numpy scalars / arrays and `_codecs.encode`
+(a bytes literal under pickle protocol 2) is ever imported or called (Lightning's `AttributeDict` becomes a
+dict; any other global - `torch.storage._load_from_bytes`, a nested unrestricted load, included - raises) -
 and returns a `CaptionRunner` that owns the care_amd captioner and translator.
 """
 import os
@@ -35,7 +36,8 @@ class _AttrDict(dict):
 # Globals a reference checkpoint can legitimately name.  Everything else is refused: a pickle GLOBAL
 # opcode is an import + attribute lookup and REDUCE calls the result, i.e. arbitrary code.
 _ALLOWED_GLOBALS = {
-    "collections": {"OrderedDict", "defaultdict"},
+    "collections": {"OrderedDict", "defaultdict", "Counter"},   # Counter: MultiStepLR milestones in lr_schedulers
+    "_codecs": {"encode"},   # how pickle protocol 2 (torch.save's default) spells the bytes of a numpy scalar / array
     "builtins": {"dict", "list", "tuple", "set", "frozenset", "int", "float", "str", "bool", "bytes", "complex",
                  "slice", "range", "bytearray"},
     "argparse": {"Namespace"},
@@ -43,7 +45,9 @@ _ALLOWED_GLOBALS = {
               "int8", "uint8", "bool", "FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage",
               "LongStorage", "IntStorage", "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "Tensor"},
     "torch._utils": {"_rebuild_tensor_v2", "_rebuild_tensor", "_rebuild_parameter", "_rebuild_parameter_with_state"},
-    "torch.storage": {"UntypedStorage", "TypedStorage", "_load_from_bytes"},
+    # NOT `torch.storage._load_from_bytes`: it is torch.load(BytesIO(b), weights_only=False) - an unrestricted
+    # nested unpickle of attacker bytes; zip-format checkpoints never name it
+    "torch.storage": {"UntypedStorage", "TypedStorage"},
     "torch.nn.parameter": {"Parameter"},
     "numpy": {"dtype", "ndarray", "float32", "float64", "int64", "int32", "bool_"},
     "numpy.core.multiarray": {"scalar", "_reconstruct"},

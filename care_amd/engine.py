@@ -15,6 +15,7 @@ Compared with the reference the engine
 These are numerically equivalent re-orderings of the same math (decoder is causal and
 post-LN, eval-mode dropout is identity).
 """
+import collections
 import os
 import weakref
 from typing import Dict, List, Optional
@@ -106,7 +107,15 @@ class HipEngine:
         self.w: Dict[str, torch.Tensor] = {}
         self.device = None
         self._ws: Dict[tuple, torch.Tensor] = {}
-        self._graphs: Dict[tuple, object] = {}
+        self._ws_used: Dict[tuple, int] = {}     # workspace key -> number of the last pass that asked for it
+        self._ws_bytes = 0
+        self._gen = 0                            # pass counter (_begin_pass)
+        # rows (clips x beam) the running pass STARTED with: what the row-count switches of a decode step look at
+        # (ln_fusable) - compaction shrinks the row count mid-pass, and a clip's arithmetic must not change with it
+        self._form_rows: Optional[int] = None
+        # byte budget of the cached workspaces (None: 60 % of the device's memory, CARE_WS_BUDGET_GB overrides)
+        self.ws_budget_bytes: Optional[int] = None
+        self._graphs: "collections.OrderedDict[tuple, object]" = collections.OrderedDict()
         self._lane = 0
         self.lanes = 1  # batch lanes of a graph-replayed greedy pass (lanes_for)
         self.latent = os.environ.get("CARE_LATENT", "1") != "0"
@@ -261,7 +270,52 @@ class HipEngine:
         if t is None:
             t = torch.empty(shape, device=self.device, dtype=dtype)
             self._ws[key] = t
+            self._ws_bytes += t.numel() * t.element_size()
+        self._ws_used[key] = self._gen
         return t
+
+    # Captured graphs per kind (first element of the key).  The whole-pass kinds are keyed on the caller's feature
+    # buffers, the segment kinds on (buffer set, first step, rows): a loader with ragged last batches, or a caller
+    # that allocates fresh feature tensors for every batch, must not grow them without limit.
+    GRAPH_CAPS = {"greedy": 8, "beam": 8, "gseg0": 8, "bseg0": 8, "gseg": 96, "bseg": 96, "tf": 8}
+
+    def _graph_get(self, key):
+        entry = self._graphs.get(key)
+        if entry is not None:
+            self._graphs.move_to_end(key)
+        return entry
+
+    def _graph_put(self, key, entry):
+        """Insert / update a graph entry; the least recently used entries of the same kind beyond its cap go
+        (a captured graph releases its private memory pool with its last reference; 'seen' markers go too)."""
+        self._graphs[key] = entry
+        self._graphs.move_to_end(key)
+        cap = self.GRAPH_CAPS.get(key[0], 8)
+        same = [k for k in self._graphs if k[0] == key[0]]
+        for k in same[: max(0, len(same) - cap)]:
+            del self._graphs[k]
+
+    def _begin_pass(self):
+        """Top of every public pass (never inside one): count it, and when the cached workspaces exceed their byte
+        budget drop the least recently used ones - all but those of the previous pass, so a loop over one batch shape
+        stays warm.  Captured graphs hold raw workspace addresses, so every graph goes with them (the next passes
+        run eagerly once and re-capture)."""
+        self._gen += 1
+        self._form_rows = None
+        budget = self.ws_budget_bytes
+        if budget is None:
+            env = os.environ.get("CARE_WS_BUDGET_GB")
+            budget = int(float(env) * (1 << 30)) if env else int(0.6 * torch.cuda.get_device_properties(self.device).total_memory)
+            self.ws_budget_bytes = budget
+        if self._ws_bytes <= budget:
+            return
+        for key in sorted(self._ws, key=lambda k: self._ws_used.get(k, 0)):
+            if self._ws_bytes <= budget // 2 or self._ws_used.get(key, 0) >= self._gen - 1:
+                break
+            t = self._ws.pop(key)
+            self._ws_used.pop(key, None)
+            self._ws_bytes -= t.numel() * t.element_size()
+        self._graphs.clear()
 
     @property
     def bf(self) -> bool:
@@ -411,15 +465,16 @@ class HipEngine:
             aux["context"], aux["embs"] = o.clone(), x1.clone()
         return x1, x1b
 
-    def _ffn(self, name, x, xb, out, outb, tag, gemm_tag=None, **ln_kw):
+    def _ffn(self, name, x, xb, out, outb, tag, gemm_tag=None, fuse=None, **ln_kw):
         rows, d = x.shape
         w = self.w
+        fuse = self.ln_fusable(rows) if fuse is None else fuse
         split = self.as_ok and self.ff % 512 == 0 and self.ff >= 1024
         h = self.gemm(xb if xb is not None else x, w[name + "_w1"], w[name + "_b1"],
                       self.ws(tag + "h", (rows, self.ff), torch.bfloat16 if split else torch.float32),
                       act=self.act, tag=gemm_tag)
         w2 = w[name + "_w2"]
-        if split and self.ln_fusable(rows) and not ln_kw.get("pos"):
+        if split and fuse and not ln_kw.get("pos"):
             # dense2 + bias + residual + LayerNorm in one kernel: no split-K slabs at all
             return self.gemm_ln(h, w2, w[name + "_b2"], x, w[name + "_g"], w[name + "_be"], out, outb,
                                 tag=(gemm_tag + "_ln") if gemm_tag else None, Wp=w.get(name + "_w2#packed"), **ln_kw)
@@ -748,6 +803,7 @@ class HipEngine:
                  ptr(w["word"]), ptr(w["pos"]), t - 1, ptr(sem), rows_per_clip, ptr(w["emb_g"]), ptr(w["emb_be"]),
                  self.eps, ptr(x), ptr(xb), d, N, 1, d)
         g = lambda f32, b16: b16 if b16 is not None else f32  # GEMM input: the bf16 mirror when it exists
+        fuse_ln = self.ln_fusable(self._form_rows or N)  # by the pass's INITIAL row count, not what compaction left
         for li in range(self.n_layers):
             nm = "d{}_sa".format(li)
             cache = skv[li]  # [N, T, 2d]
@@ -758,7 +814,7 @@ class HipEngine:
             ctx = self.attention(q, flat, flat[:, d:], self._ctx(tag, N), T * 2 * d, 2 * d, 1, t, anc=anc,
                                  pad_tok=tok, tag="step_self_attn")
             x1, x1b = self.ws(tag + "x1", (N, d)), self.wsb(tag + "x1", (N, d))
-            if self.ln_fusable(N):
+            if fuse_ln:
                 self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x, w[nm + "_g"], w[nm + "_be"], x1, x1b,
                              tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
             else:
@@ -785,7 +841,7 @@ class HipEngine:
                 ctx = self.attention(q2, kv, kv[:, d:], self._ctx(tag, N), Lk * 2 * d, 2 * d, rows_per_clip, Lk,
                                      bias=hb, tag="step_cross_attn")
             x2, x2b = self.ws(tag + "x2", (N, d)), self.wsb(tag + "x2", (N, d))
-            if self.ln_fusable(N):
+            if fuse_ln:
                 self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x1, w[nm + "_g"], w[nm + "_be"], x2, x2b,
                              tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
             else:
@@ -796,9 +852,10 @@ class HipEngine:
             x, xb = self.ws(tag + "x3_%d" % (li & 1), (N, d)), self.wsb(tag + "x3_%d" % (li & 1), (N, d))
             # the last layer's hidden state feeds the vocabulary projection only, which reads the bf16 mirror:
             # the fused kernel then skips the fp32 copy (67 MB of stores per step at 32768 rows)
-            bf16_only = (li == self.n_layers - 1 and xb is not None and self.ln_fusable(N) and self.as_ok and
+            bf16_only = (li == self.n_layers - 1 and xb is not None and fuse_ln and self.as_ok and
                          self.ff % 512 == 0 and self.ff >= 1024)
-            self._ffn("d{}_ffn".format(li), x2, x2b, None if bf16_only else x, xb, tag, gemm_tag="step_ffn_gemm")
+            self._ffn("d{}_ffn".format(li), x2, x2b, None if bf16_only else x, xb, tag, gemm_tag="step_ffn_gemm",
+                      fuse=fuse_ln)
             if bf16_only:
                 x = None
         return x, xb
@@ -868,8 +925,12 @@ class HipEngine:
         host - the rows still active.  None: done.  At most 3/4 of the slots in use: the active rows are
         gathered to the front of a second set of buffers (K/V caches, memory, next-step inputs, tokens:
         csrc/compact.hip) and the following segments run on that many rows (rounded up to a bucket;
-        the padding rows are ended clips that ride along).  Rows are independent end to end, so every
-        clip decodes exactly as in the fixed-length pass.  A segment is captured into a hipGraph the
+        the padding rows are ended clips that ride along).  Rows are independent end to end and the row-count
+        switches of the ENGINE (fused dense+LayerNorm, beam selection form, cross-attention form) are taken from the
+        pass's initial row count (`_form_rows`), so a clip meets the same kernel forms as in the fixed-length pass;
+        what still follows the current row count are two tilings INSIDE the library (QKV / FFN1 and the vocabulary
+        arg-max move from 256-row to 128-row panels below 8192 rows): the same bf16 products and the same arg-max
+        columns, fp32 sums in another order (scores within 1e-4).  A segment is captured into a hipGraph the
         second time its (first step, row count, buffer set) comes up.  Results are per CLIP:
         fed int32 [B, T + 1] (column 0 = BOS), length int32 [B], score fp32 [B]."""
         feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
@@ -940,25 +1001,10 @@ class HipEngine:
             run_steps(v, 1, min(S, T))
             return enc, v
 
-        def replayable(key, fn):
-            """Eager the first time a key is seen, captured the second, replayed afterwards."""
-            if not use_graph:
-                return fn()
-            entry = self._graphs.get(key)
-            if entry is None:
-                self._graphs[key] = "seen"
-                return fn()
-            if entry == "seen":
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    out = fn()
-                entry = (graph, out)
-                self._graphs[key] = entry
-            entry[0].replay()
-            return entry[1]
+        replayable = lambda key, fn: self._replay(key, fn, use_graph)
 
         try:
+            self._form_rows = B
             enc, v = replayable(("gseg0", self.latent_ok, bool(lean), S) + fkey, first_segment)
             par, t = 0, min(S, T) + 1
             stats = dict(clips=B, steps=t - 1, row_steps=B * (t - 1), compactions=0)
@@ -986,11 +1032,28 @@ class HipEngine:
             self._ws_cap = None
         return enc, out_fed, out_len, out_score
 
+    def _replay(self, key, fn, use_graph=True):
+        """fn() eagerly the first time `key` is seen (allocates every workspace), captured into a hipGraph the
+        second time, replayed afterwards.  Returns fn's result (static tensors once captured)."""
+        if not use_graph:
+            return fn()
+        entry = self._graph_get(key)
+        if entry is None:
+            self._graph_put(key, "seen")
+            return fn()
+        if entry == "seen":
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = fn()
+            entry = (graph, out)
+            self._graph_put(key, entry)
+        entry[0].replay()
+        return entry[1]
+
     def _arange(self, n):
-        t = self._ws.get(("arange", n))
-        if t is None:
-            t = torch.arange(n, device=self.device, dtype=torch.int32)
-            self._ws[("arange", n)] = t
+        t = self._ws_get("arange", (n,), torch.int32)
+        torch.arange(n, device=self.device, dtype=torch.int32, out=t)  # refilled: an evicted buffer comes back empty
         return t
 
     def _compact(self, v, w, idx, active, out_fed, out_len, out_score):
@@ -1042,38 +1105,22 @@ class HipEngine:
         lean: the caller reads nothing of enc_outputs (the Translator): encode(..., lean=True).
         """
         feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        self._begin_pass()
         lanes = self.lanes_for(feats[0].shape[0]) if use_graph else 1
         if lanes > 1:
             return self._translate_greedy_lanes(feats, lanes, lean)
         if self.early_exit if early_exit is None else early_exit:
             # stop when every clip has ended, drop ended clips on the way (greedy_early_exit)
             return self.greedy_early_exit(feats, lean, use_graph)
-        if not use_graph:
+
+        def run():
+            self._form_rows = feats[0].shape[0]
             enc = self.encode(feats, lean)
             return (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
                                               sem_embs=enc.get("semantic_embs")))
+
         key = ("greedy", self.latent_ok, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-        entry = self._graphs.get(key)
-        if entry is None:
-            enc = self.encode(feats, lean)  # eager pass: allocates every workspace
-            out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
-                                             sem_embs=enc.get("semantic_embs")))
-            self._graphs[key] = "seen"
-            return out
-        if entry == "seen":
-            if sum(1 for k in self._graphs if k[0] == key[0]) > 8:
-                self._graphs = {k: v for k, v in self._graphs.items() if k == key or k[0] != key[0]}
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                enc = self.encode(feats, lean)
-                out = (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
-                                                 sem_embs=enc.get("semantic_embs")))
-            entry = (graph, out)
-            self._graphs[key] = entry
-        graph, out = entry
-        graph.replay()
-        return out
+        return self._replay(key, run, use_graph)
 
     def lanes_for(self, B: int) -> int:
         """Batch lanes of a graph-replayed greedy pass.
@@ -1123,22 +1170,7 @@ class HipEngine:
                                                                      for k in (1, 2, 3))
 
         key = ("greedy", lanes, self.latent_ok, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-        entry = self._graphs.get(key)
-        if entry is None:
-            self._graphs[key] = "seen"
-            return run()  # eager: allocates every lane's workspaces
-        if entry == "seen":
-            if sum(1 for k in self._graphs if k[0] == key[0]) > 8:
-                self._graphs = {k: v for k, v in self._graphs.items() if k == key or k[0] != key[0]}
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = run()
-            entry = (graph, out)
-            self._graphs[key] = entry
-        graph, out = entry
-        graph.replay()
-        return out
+        return self._replay(key, run, True)
 
     # ------------------------------------------------------------------ beam search with early exit + compaction
     def _beam_steps(self, v, t0, t1, bm, need):
@@ -1243,22 +1275,7 @@ class HipEngine:
             self._beam_steps(v, 1, min(S, T), bm, need)
             return enc, v
 
-        def replayable(key, fn):
-            if not use_graph:
-                return fn()
-            entry = self._graphs.get(key)
-            if entry is None:
-                self._graphs[key] = "seen"
-                return fn()
-            if entry == "seen":
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    res = fn()
-                entry = (graph, res)
-                self._graphs[key] = entry
-            entry[0].replay()
-            return entry[1]
+        replayable = lambda key, fn: self._replay(key, fn, use_graph)
 
         def flush(v):
             """finished lists of every slot of v -> the per-clip outputs"""
@@ -1269,6 +1286,7 @@ class HipEngine:
             self._call_rows("care_scatter_rows", v["fhyp"].view(n, -1), out["fhyp"].view(B, -1), v["clip"], n)
 
         try:
+            self._form_rows = B * bm
             enc, v = replayable(("bseg0", bm, need, self.latent_ok, bool(lean), S) + fkey, first_segment)
             par, t = 0, min(S, T) + 1
             stats = dict(clips=B, steps=t - 1, row_steps=B * bm * (t - 1), compactions=0)
@@ -1341,33 +1359,18 @@ class HipEngine:
         """encode + beam search of one batch, replayed from a hipGraph when the input buffers repeat
         (same policy as translate_greedy).  Returns (enc_outputs, nfin, fscore, flen, fhyp)."""
         feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        self._begin_pass()
         if self.early_exit if early_exit is None else early_exit:
             return self.beam_early_exit(feats, bm, need, lean, use_graph)
 
         def run():
+            self._form_rows = feats[0].shape[0] * bm
             enc = self.encode(feats, lean)
             return (enc,) + tuple(self.beam(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need,
                                             sem_embs=enc.get("semantic_embs")))
 
-        if not use_graph:
-            return run()
         key = ("beam", bm, need, self.latent_ok, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-        entry = self._graphs.get(key)
-        if entry is None:
-            self._graphs[key] = "seen"
-            return run()
-        if entry == "seen":
-            if sum(1 for k in self._graphs if k[0] == key[0]) > 8:
-                self._graphs = {k: v for k, v in self._graphs.items() if k == key or k[0] != key[0]}
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = run()
-            entry = (graph, out)
-            self._graphs[key] = entry
-        graph, out = entry
-        graph.replay()
-        return out
+        return self._replay(key, run, use_graph)
 
     def beam(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int,
              sem_embs: Optional[torch.Tensor] = None):

@@ -327,7 +327,9 @@ class TransformerSeq2Seq(nn.Module):
     def encoding_phase(self, feats: List[torch.Tensor], **kwargs) -> Dict[str, torch.Tensor]:
         n_mod = len(self.opt["modality"])
         with torch.no_grad():
-            out = self.engine().encode(list(feats[:n_mod]))
+            eng = self.engine()
+            eng._begin_pass()
+            out = eng.encode(list(feats[:n_mod]))
         if self.predictor is not None:
             out["attribute_prediction_prj"] = self.predictor.nets[0].prj
         return out
@@ -354,7 +356,9 @@ class TransformerSeq2Seq(nn.Module):
         # decode loop (last_time_step_logits) skip them unless asked (`output_auxiliary=True`).
         aux = kwargs.get("output_auxiliary", not last_time_step_logits)
         with torch.no_grad():
-            return self.engine().decode_full(input_ids, mem, inputs_for_decoder.get("semantic_hidden_states"),
+            eng = self.engine()
+            eng._begin_pass()
+            return eng.decode_full(input_ids, mem, inputs_for_decoder.get("semantic_hidden_states"),
                                              want_logits="last" if last_time_step_logits else "all",
                                              sem_embs=inputs_for_decoder.get("semantic_embs"), want_aux=bool(aux))
 

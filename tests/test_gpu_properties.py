@@ -438,3 +438,35 @@ def test_beam_early_exit_and_compaction_equal_the_fixed_length_pass(config, dtyp
         if B * bm >= 2048:
             assert st["compactions"] >= 1 and st["row_steps"] < 0.8 * B * bm * 29, st
     assert any(k[0] == "bseg0" and isinstance(g, tuple) for k, g in eng._graphs.items())
+
+
+def test_caches_stay_bounded_over_many_batch_shapes():
+    """A loader with ragged batches (or fresh feature tensors per batch) must not grow the engine without limit:
+    workspaces are evicted least-recently-used against a byte budget at pass boundaries (with every captured graph,
+    which holds their addresses), graph entries are capped per kind - and the captions stay what they were."""
+    boost = {"cls_head.tgt_word_prj.weight": {3: 4.0}}
+    opt, P, model, feats = _setup("msrvtt_base_ami", 1400, "bf16", boost=boost)
+    eng = model.engine()
+    ref = _greedy(model, [f[:300].contiguous() for f in feats], use_graph=True)
+    torch.cuda.synchronize()
+    eng.ws_budget_bytes = 192 << 20
+    peak_ws, peak_alloc = 0, 0
+    base = torch.cuda.memory_allocated()
+    sizes = [300 + 27 * i for i in range(40)]
+    for B in sizes:
+        sub = [f[:B].contiguous() for f in feats]      # fresh tensors: new graph keys every time
+        for _ in range(2):
+            fed, length, score = _greedy(model, sub, use_graph=True)
+        torch.cuda.synchronize()
+        peak_ws = max(peak_ws, eng._ws_bytes)
+        peak_alloc = max(peak_alloc, torch.cuda.memory_allocated() - base)
+        del sub
+    biggest = max(sizes)
+    # one pass's set at the largest shape may exceed the budget by itself; what must not happen is accumulation
+    one_set = eng._ws_bytes
+    assert peak_ws <= eng.ws_budget_bytes + 2 * one_set, (peak_ws, one_set)
+    assert peak_alloc <= 3 * (eng.ws_budget_bytes + 2 * one_set), peak_alloc
+    assert sum(1 for k in eng._graphs if k[0] in ("gseg0", "greedy")) <= 8
+    assert sum(1 for k in eng._graphs if k[0] == "gseg") <= eng.GRAPH_CAPS["gseg"]
+    again = _greedy(model, [f[:300].contiguous() for f in feats], use_graph=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref, again))

@@ -101,6 +101,37 @@ def test_checkpoint_overrides_default_like_the_reference_and_hostile_pickles_are
         read_checkpoint(evil)
     assert not os.path.exists(tmp_path / "pwned")
 
+    # the nested-load bypass: an outer pickle at protocol 4 that REDUCEs
+    # torch.storage._load_from_bytes over an inner, unrestricted pickle
+    class Nested:
+        def __reduce__(self):
+            import torch.storage
+            return (torch.storage._load_from_bytes, (pickle.dumps(Hostile()),))
+
+    evil2 = str(tmp_path / "evil2.ckpt")
+    torch.save({"state_dict": {}, "hyper_parameters": {"opt": opt, "payload": Nested()}}, evil2, pickle_protocol=4)
+    with pytest.raises(pickle.UnpicklingError, match="refusing to import"):
+        read_checkpoint(evil2)
+    assert not os.path.exists(tmp_path / "pwned")
+
+
+def test_checkpoint_with_numpy_values_and_scheduler_state_loads(tmp_path):
+    """What Lightning checkpoints legitimately hold beside tensors: numpy scalars / arrays (protocol 2 spells
+    their bytes through `_codecs.encode`) and a `collections.Counter` (MultiStepLR milestones)."""
+    import collections
+
+    from care_amd.checkpoint import read_checkpoint
+    from care_amd.configs import make_opt
+
+    opt = make_opt("msvd_base_i")
+    path = str(tmp_path / "np.ckpt")
+    torch.save({"state_dict": {"captioner.x": torch.ones(2)},
+                "hyper_parameters": {"opt": opt, "new_opt_used_to_override": {}},
+                "callbacks": {"best": np.float64(0.5), "hist": np.arange(4, dtype=np.int64)},
+                "lr_schedulers": [{"milestones": collections.Counter({10: 1, 20: 1})}]}, path)
+    ck = read_checkpoint(path)
+    assert torch.equal(ck["state_dict"]["x"], torch.ones(2)) and ck["opt"]["dim_hidden"] == opt["dim_hidden"]
+
 
 def test_frame_sampling_and_detokenisation_match_reference():
     from care_amd.data import get_uniform_ids_from_k_snippets, resampling
