@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -28,6 +28,8 @@ SIGNATURES = {
     "care_gemm_argmax": [_P, _L, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "care_gemm_bf16": [_P, _L, _I, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_gemm_argmax_bf16": [_P, _L, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "care_gemm_tile": [_P, _L, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "care_gemm_tile_argmax": [_P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "care_score_partials": [_P, _P, _P, _P, _I, _P, _P, _I, _P],
     "care_score_logits": [_P, _L, _I, _P, _P, _P, _I, _P],
     "care_greedy_update": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -66,6 +68,7 @@ SIGNATURES = {
 }
 PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_argmax_parts": (c_int, [c_int]),
          "care_argmax_parts_bf16": (c_int, [c_int, c_int]),
+         "care_argmax_parts_tile": (c_int, [c_int]),
          "care_argmax_parts_bf16_min": (c_int, [c_int, c_int, c_int, c_int, c_int]),
          "care_beam_sparse_applies": (c_int, [c_int, c_int, c_int, c_int])}
 

@@ -1,0 +1,325 @@
+// gemm_tile.hip - C = act(A W^T + bias) for bf16 A [M, K] and bf16 W [N, K] with ANY K % 64 == 0:
+// the nn.Linear layers of the d_model = 768 / 1024 architectures (config/archs.yaml:15-26: K = 768, 1024,
+// 3072, 4096), where the A-stationary kernels (csrc/gemm_as.hip, gemm_store32.hip, gemm_vocab.hip: the
+// activations of a row panel resident in registers for the WHOLE K) run out of registers at K > 512.
+//
+// Classic output-tile decomposition, built for gfx950:
+//   * a workgroup of WGM x WGN waves owns a (64 WGM) x (64 WGN) output tile, a wave 64 x 64 of it
+//     (16 accumulator tiles of v_mfma_f32_16x16x32_bf16 = 64 VGPRs);
+//   * BOTH operands stream through an LDS ring in K steps of 64 (rows of 128 bytes) by LDS-DMA
+//     (global_load_lds, 16 B per lane: one wave instruction = 8 rows x 128 B, full cache lines), STAGES - 1
+//     steps in flight; the LDS image is lane-linear, so the bank swizzle (16-byte chunk ^= row & 7, the
+//     conflict-free pattern of ds_read_b128's 16-lane groups) is applied to the per-lane SOURCE address
+//     and again on the fragment read;
+//   * one raw s_barrier per K step: [counted s_waitcnt vmcnt -> barrier -> issue step t + STAGES - 1 ->
+//     multiply step t]; the wait precedes the barrier that precedes the read (LDS-DMA data is ordered for a
+//     ds_read only by the issuing wave's vmcnt + a barrier), the re-staged slot was read one barrier ago;
+//   * MFMA operands are swapped (D = W_tile A_tile^T) and the W rows of a wave's 64 columns are permuted
+//     over the MFMA rows WHEN STAGED (LDS row 16 nt + 4 g + r holds column 16 g + 4 nt + r), so a lane ends
+//     up with 16 CONSECUTIVE output columns of one row: 16-byte stores, and the row statistics of the
+//     arg-max epilogue are a 16-value chain in one lane + two cross-lane steps;
+//   * epilogues: bias + activation + (split) store in bf16 / fp32 - or per-row (max, first arg-max,
+//     sum exp) of the 64 columns of every wave, the vocabulary projection of greedy decoding
+//     (models/Head.py:26-32, Translator.py:127), optionally with the label logit (teacher-forced scoring);
+//   * blocks are numbered XCD-aware: the blocks of one XCD (blockIdx % 8) walk a contiguous run of tiles,
+//     row tiles fastest, so an XCD's L2 keeps the W column tile it is multiplying.
+#include <cstdlib>
+
+#include "care_common.h"
+
+namespace {
+
+struct TArgs {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* W; int64_t ldw;
+  const float* bias;
+  void* C0; int64_t ldc0; int c0_bf16;
+  void* C1; int64_t ldc1; int c1_bf16;
+  int n_split, M, N, K, act;
+  float* pmax; int32_t* pidx; float* psum; int parts;
+  const int32_t* labels; float* plab;
+  int tiles_m, tiles_n;
+};
+
+enum { EPI_STORE = 0, EPI_ARGMAX = 1, EPI_ARGMAX_LAB = 2 };
+
+__device__ __forceinline__ float t_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+template <int N_>
+__device__ __forceinline__ void t_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory");
+}
+
+template <int WGM, int WGN, int STAGES, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
+  constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
+  constexpr int PIECES = (BM + BN) / 8;   // 1-KB DMA pieces (8 rows x 128 B) of one K step
+  constexpr int P = PIECES / NW;          // pieces per wave and K step
+  static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // XCD-aware tile number (bijective for any grid size)
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int m0 = (t % p.tiles_m) * BM, n0 = (t / p.tiles_m) * BN;
+
+  // ---- staging: piece q = wave * P + i covers LDS rows 8 q .. 8 q + 7 of the stage image (A rows first)
+  const int prow = lane >> 3;
+  const int sc = ((lane & 7) ^ prow) << 4;  // source chunk of this lane's LDS slot (row & 7 == prow)
+  const unsigned char* src[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int R = (wave * P + i) * 8 + prow;
+    if ((wave * P + i) * 8 < BM) {
+      const int row = min(m0 + R, p.M - 1);  // clamped, never branched around: rows past M are not stored
+      src[i] = reinterpret_cast<const unsigned char*>(p.A) + (int64_t)row * p.lda * 2 + sc;
+    } else {
+      const int Rb = R - BM;  // LDS row 16 nt + 4 g + r of a wave's 64 columns holds column 16 g + 4 nt + r
+      const int col = (Rb & ~63) + 16 * ((Rb >> 2) & 3) + 4 * ((Rb >> 4) & 3) + (Rb & 3);
+      const int row = min(n0 + col, p.N - 1);
+      src[i] = reinterpret_cast<const unsigned char*>(p.W) + (int64_t)row * p.ldw * 2 + sc;
+    }
+  }
+  auto issue = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(smem + slot * STAGE_BYTES +
+                                                                                 (wave * P + i) * 1024),
+                                       16, 0, 0);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K >> 6;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s, s);
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int a_row = (wm * 64 + fr) * 128, b_row = (BM + wn * 64 + fr) * 128;
+  const int sw0 = ((fg ^ (fr & 7)) << 4), sw1 = (((4 + fg) ^ (fr & 7)) << 4);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_sched_barrier(0);  // the MFMAs of step kt - 1 (and the waits on their fragments) stay above the barrier
+    // step kt has landed when at most the STAGES - 2 younger steps of this wave are outstanding
+    if (kt + STAGES - 2 < nk) t_wait_vm<(STAGES - 2) * P>();
+    else t_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int sw = kk ? sw1 : sw0;
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const bf16x8*>(st + a_row + m * 2048 + sw);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(st + b_row + n * 2048 + sw);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[n], fa[m], acc[m][n], 0, 0, 0);
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // acc[m][n][j] = out[row m0 + 64 wm + 16 m + fr][column n0 + 64 wn + 16 fg + 4 n + j]
+  const int colw = n0 + wn * 64;          // first column of the wave
+  const int col0 = colw + fg * 16;        // first of this lane's 16 consecutive columns
+  if constexpr (EPI == EPI_STORE) {
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = (p.bias && col0 + j < p.N) ? p.bias[col0 + j] : 0.0f;
+    const bool second = col0 >= p.n_split;  // n_split % 16 == 0: a lane's 16 columns never straddle it
+    unsigned char* C = reinterpret_cast<unsigned char*>(second ? p.C1 : p.C0);
+    const int64_t ld = second ? p.ldc1 : p.ldc0;
+    const bool isb = (second ? p.c1_bf16 : p.c0_bf16) != 0;
+    const int cc = col0 - (second ? p.n_split : 0);
+    const int nvalid = min(16, (second ? p.N : min(p.N, p.n_split)) - col0);  // columns of this lane inside the destination
+    const bool vec = nvalid == 16 && ((ld & 7) == 0) && ((cc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = m0 + wm * 64 + m * 16 + fr;
+      float v[16];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = acc[m][n][j] + bv[4 * n + j];
+          if (p.act == CARE_ACT_RELU) x = fmaxf(x, 0.0f);
+          else if (p.act == CARE_ACT_GELU) x = t_gelu(x);
+          v[4 * n + j] = x;
+        }
+      if (row >= p.M || nvalid <= 0) continue;
+      if (isb) {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (int64_t)row * ld + cc;
+        if (vec) {
+          bf16x8 o0, o1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { o0[j] = (bf16_t)v[j]; o1[j] = (bf16_t)v[8 + j]; }
+          *reinterpret_cast<bf16x8*>(dst) = o0;
+          *reinterpret_cast<bf16x8*>(dst + 8) = o1;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j < nvalid) dst[j] = (bf16_t)v[j];
+        }
+      } else {
+        float* dst = reinterpret_cast<float*>(C) + (int64_t)row * ld + cc;
+        if (vec) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(dst + 4 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j < nvalid) dst[j] = v[j];
+        }
+      }
+    }
+  } else {
+    // per row of this wave's 64 columns: max, FIRST arg-max, sum exp(x - max) [, the logit of the label column]
+    const int part = (n0 / BN) * WGN + wn;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = m0 + wm * 64 + m * 16 + fr;
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = col0 + 4 * n + j;
+          const float x = col < p.N ? acc[m][n][j] : -INFINITY;
+          if (x > best) { best = x; bi = col; }  // columns ascend: the first maximum is kept
+        }
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      float s = 0.0f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col0 + 4 * n + j < p.N) s += __expf(acc[m][n][j] - best);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      float lv = -INFINITY;
+      if constexpr (EPI == EPI_ARGMAX_LAB) {
+        const int lab = p.labels[min(row, p.M - 1)];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (col0 + 4 * n + j == lab) lv = acc[m][n][j];
+        lv = fmaxf(lv, __shfl_xor(lv, 16, 64));
+        lv = fmaxf(lv, __shfl_xor(lv, 32, 64));
+      }
+      if (fg == 0 && row < p.M) {
+        const int64_t o = (int64_t)row * p.parts + part;
+        p.pmax[o] = best; p.pidx[o] = bi; p.psum[o] = s;
+        if constexpr (EPI == EPI_ARGMAX_LAB) p.plab[o] = lv;
+      }
+    }
+  }
+}
+
+template <int WGM, int WGN, int STAGES, int EPI>
+int launch_tile(TArgs& p, hipStream_t st) {
+  constexpr int BM = 64 * WGM, BN = 64 * WGN;
+  constexpr int lds = STAGES * (BM + BN) * 128;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  if (lds > 64 * 1024) {
+    static std::atomic<unsigned long long> done{0};
+    const int rc = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_tile_kernel<WGM, WGN, STAGES, EPI>), lds, done);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL((gemm_tile_kernel<WGM, WGN, STAGES, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), lds, st, p);
+  return care_launch_status();
+}
+
+// Tile shape: the biggest one whose tiles still fill the 256 CUs about twice over (a 256-row x 128-column tile
+// reads a third less of A and W per flop than 128 x 128), CARE_TILE_CFG overrides (tuning).
+int pick_cfg(int M, int N) {
+  if (const char* e = getenv("CARE_TILE_CFG")) return atoi(e);
+  const long t22 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const long t42 = (long)((M + 255) / 256) * ((N + 127) / 128);
+  if (t42 >= 448) return 42;
+  (void)t22;
+  return 22;
+}
+
+template <int EPI>
+int dispatch(TArgs& p, hipStream_t st) {
+  switch (pick_cfg(p.M, p.N)) {
+    case 42: return launch_tile<4, 2, 3, EPI>(p, st);
+    case 423: return launch_tile<4, 2, 3, EPI>(p, st);
+    case 422: return launch_tile<4, 2, 2, EPI>(p, st);
+    case 223: return launch_tile<2, 2, 3, EPI>(p, st);
+    case 224: return launch_tile<2, 2, 4, EPI>(p, st);
+    default: return launch_tile<2, 2, 2, EPI>(p, st);
+  }
+}
+
+int tile_check(const void* A, int64_t lda, const void* W, int M, int N, int K) {
+  if (!A || !W || M <= 0 || N <= 0 || K <= 0) return CARE_EINVAL;
+  if (K % 64 != 0) return CARE_ESHAPE;
+  if (!care_aligned16(A) || !care_aligned16(W) || (lda % 8) != 0) return CARE_EALIGN;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int care_gemm_tile(const void* A, int64_t lda, const void* W, const float* bias, void* C0, int64_t ldc0,
+                              int c0_dtype, void* C1, int64_t ldc1, int c1_dtype, int n_split, int M, int N, int K,
+                              int act, void* stream) {
+  int rc = tile_check(A, lda, W, M, N, K);
+  if (rc) return rc;
+  if (!C0 || n_split <= 0 || n_split > N || (n_split < N && !C1)) return CARE_EINVAL;
+  if (n_split % 16 != 0 && n_split != N) return CARE_ESHAPE;
+  if (act < CARE_ACT_NONE || act > CARE_ACT_GELU) return CARE_EDTYPE;
+  if ((c0_dtype != CARE_F32 && c0_dtype != CARE_BF16) || (C1 && c1_dtype != CARE_F32 && c1_dtype != CARE_BF16))
+    return CARE_EDTYPE;
+  TArgs p{};
+  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.ldw = K; p.bias = bias;
+  p.C0 = C0; p.ldc0 = ldc0; p.c0_bf16 = c0_dtype == CARE_BF16;
+  p.C1 = C1; p.ldc1 = ldc1; p.c1_bf16 = c1_dtype == CARE_BF16;
+  p.n_split = n_split; p.M = M; p.N = N; p.K = K; p.act = act;
+  return dispatch<EPI_STORE>(p, (hipStream_t)stream);
+}
+
+extern "C" int care_argmax_parts_tile(int N) { return N > 0 ? 2 * ((N + 127) / 128) : CARE_EINVAL; }
+
+extern "C" int care_gemm_tile_argmax(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
+                                     const int32_t* labels, float* plab, int M, int N, int K, void* stream) {
+  int rc = tile_check(A, lda, W, M, N, K);
+  if (rc) return rc;
+  if (!pmax || !pidx || !psum || ((labels != nullptr) != (plab != nullptr))) return CARE_EINVAL;
+  TArgs p{};
+  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.ldw = K;
+  p.n_split = N; p.M = M; p.N = N; p.K = K;
+  p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.parts = care_argmax_parts_tile(N);
+  p.labels = labels; p.plab = plab;
+  return labels ? dispatch<EPI_ARGMAX_LAB>(p, (hipStream_t)stream) : dispatch<EPI_ARGMAX>(p, (hipStream_t)stream);
+}

@@ -329,6 +329,13 @@ class HipEngine:
         return self.bf and self.d <= 512 and self.d % 128 == 0
 
     @property
+    def bf_act(self) -> bool:
+        """bf16 mode with bf16 MIRRORS of the GEMM-input activations (any d_model % 64 == 0): K = d <= 512 goes to
+        the A-stationary kernels (as_ok), larger K (d_model 768 / 1024, their FFNs) to the LDS-tiled bf16 kernel
+        (csrc/gemm_tile.hip)."""
+        return self.bf and self.d % 64 == 0 and self.ff % 64 == 0
+
+    @property
     def latent_capable(self) -> bool:
         """Shapes / dtype the absorbed cross-attention kernels cover: bf16 mode, d_model = 512, head dim 64."""
         return self.as_ok and self.d == 512 and self.H * 64 == self.d and self.H <= 16
@@ -342,7 +349,7 @@ class HipEngine:
     @property
     def act_dtype(self):
         """dtype of activations that are ONLY GEMM inputs (attention context, FFN hidden)."""
-        return torch.bfloat16 if self.as_ok else torch.float32
+        return torch.bfloat16 if self.bf_act else torch.float32
 
     # Rows (clips x beam) from which the per-row top-k of beam search runs as two passes of the vocabulary GEMM
     # (no [rows, V] logits in memory).  Below it the logits are written (a few MB, cache resident) and
@@ -368,25 +375,53 @@ class HipEngine:
 
     def wsb(self, name: str, shape) -> Optional[torch.Tensor]:
         """bf16 mirror workspace of a GEMM-input activation (None unless as_ok)."""
-        return self.ws(name + "#bf", shape, torch.bfloat16) if self.as_ok else None
+        return self.ws(name + "#bf", shape, torch.bfloat16) if self.bf_act else None
 
     def gemm(self, A, W, bias, out, act=0, out2=None, n_split=None, tag=None):
-        """out = act(A @ W^T + bias).  bf16 weights + bf16 A -> A-stationary kernel
-        (csrc/gemm_as.hip); anything else -> the generic LDS-tiled kernel (csrc/gemm.hip)."""
+        """out = act(A @ W^T + bias).  bf16 weights + bf16 A -> A-stationary kernel (csrc/gemm_as.hip) for
+        K <= 512, the LDS-tiled bf16 kernel (csrc/gemm_tile.hip) for larger K; anything else -> the generic
+        fp32-activation kernel (csrc/gemm.hip)."""
         M, K = A.shape
         N = W.shape[0]
         assert W.shape[1] == K and A.stride(1) == 1 and out.stride(-1) == 1
         tail = (ptr(bias), ptr(out), out.stride(0), _code(out), ptr(out2),
                 out2.stride(0) if out2 is not None else 0, _code(out2), N if n_split is None else n_split, M, N, K, act)
         if W.dtype == torch.bfloat16 and A.dtype == torch.bfloat16:
-            if K > 512 or K % 128 or A.stride(0) % 8:
-                raise ValueError("bf16 A operand needs K <= 512, K % 128 == 0 (got K = {})".format(K))
-            call("care_gemm_bf16", ptr(A), A.stride(0), _code(A), ptr(W), *tail, tag=tag)
+            if K % 64 or A.stride(0) % 8:
+                raise ValueError("bf16 A operand needs K % 64 == 0 and a 16-byte aligned row stride (got K = {})".format(K))
+            if K <= 512 and K % 128 == 0 and os.environ.get("CARE_FORCE_TILE", "0") == "0":
+                call("care_gemm_bf16", ptr(A), A.stride(0), _code(A), ptr(W), *tail, tag=tag)
+            else:
+                call("care_gemm_tile", ptr(A), A.stride(0), ptr(W), *tail, tag=tag)
         else:
             if A.dtype != torch.float32:
                 raise ValueError("generic GEMM takes fp32 activations")
             call("care_gemm", ptr(A), A.stride(0), ptr(W), _code(W), *tail, tag=tag)
         return out
+
+    def vocab_parts(self, rows: int) -> int:
+        """Column groups per row of the fused vocabulary arg-max for `rows` rows (the kernel vocab_argmax picks)."""
+        if self.as_ok:
+            return _lib.load().care_argmax_parts_bf16(rows, self.V)
+        if self.bf_act:
+            return _lib.load().care_argmax_parts_tile(self.V)
+        return _lib.load().care_argmax_parts(self.V)
+
+    def vocab_argmax(self, x, xb, rows, pmax, pidx, psum, labels=None, plab=None, tag="step_vocab_argmax"):
+        """Per-row (max, arg-max, sum exp) partials of the vocabulary projection of the last hidden state
+        (NaiveHead + log_softmax + top-1, Head.py:26-32 / Translator.py:127); the [rows, V] logits never exist.
+        bf16, d <= 512: A-stationary kernels; bf16, larger d: the LDS-tiled kernel; fp32 mode: exact-f32 MFMA."""
+        d, W = self.d, self.w["vocab"]
+        if self.as_ok:
+            call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels),
+                 ptr(plab), rows, self.V, d, tag=tag)
+        elif self.bf_act:
+            call("care_gemm_tile_argmax", ptr(xb), d, ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels), ptr(plab),
+                 rows, self.V, d, tag=tag)
+        else:
+            if labels is not None:
+                raise ValueError("label logits come from the bf16 kernels only (fp32 mode scores materialised logits)")
+            call("care_gemm_argmax", ptr(x), d, ptr(W), _code(W), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
 
     def add_ln(self, x, res, g, be, out, outb=None, grp=None, out_grp_rows=None, out_row_off=0, pos=None, nslab=1):
         """out = LN(sum of the nslab slabs of x + res); x is [rows, d] or [nslab, rows, d]."""
@@ -471,7 +506,7 @@ class HipEngine:
         fuse = self.ln_fusable(rows) if fuse is None else fuse
         split = self.as_ok and self.ff % 512 == 0 and self.ff >= 1024
         h = self.gemm(xb if xb is not None else x, w[name + "_w1"], w[name + "_b1"],
-                      self.ws(tag + "h", (rows, self.ff), torch.bfloat16 if split else torch.float32),
+                      self.ws(tag + "h", (rows, self.ff), torch.bfloat16 if (split or self.bf_act) else torch.float32),
                       act=self.act, tag=gemm_tag)
         w2 = w[name + "_w2"]
         if split and fuse and not ln_kw.get("pos"):
@@ -513,7 +548,7 @@ class HipEngine:
         new = (lambda name, shape, dt=torch.float32: self.ws("enc_out_" + name, shape, dt)) if static else \
               (lambda name, shape, dt=torch.float32: torch.empty(shape, device=self.device, dtype=dt))
         mem = None if lean else new("mem", (B, self.Lk, d))
-        memb = new("memb", (B, self.Lk, d), torch.bfloat16) if self.as_ok else None
+        memb = new("memb", (B, self.Lk, d), torch.bfloat16) if self.bf_act else None
         means = None if lean else new("means", (B, len(self.modality) * d))
         for mi, ch in enumerate(self.modality):
             x = feats[mi].to(self.device, torch.float32).contiguous()
@@ -610,7 +645,7 @@ class HipEngine:
         B, Lk, d = mem.shape
         mem = mem.contiguous()
         ref, memb = getattr(self, "_mem_mirror", (None, None))
-        src = memb if (self.as_ok and memb is not None and ref is not None and ref() is mem) else mem
+        src = memb if (self.bf_act and memb is not None and ref is not None and ref() is mem) else mem
         src2 = src.view(B * Lk, d)
         out = []
         for li in range(self.n_layers):
@@ -654,7 +689,7 @@ class HipEngine:
             return None
         B, n, d = sem_embs.shape
         src = sem_embs.to(self.device, torch.float32).contiguous().view(B * n, d)
-        if self.as_ok:  # the A-stationary kernel wants a bf16 operand
+        if self.bf_act:  # the bf16 kernels want a bf16 operand
             srcb = self.ws(tag + "_srcb", (B * n, d), torch.bfloat16)
             srcb.copy_(src)
             src = srcb
@@ -777,14 +812,13 @@ class HipEngine:
         lab32 = labels.to(self.device, torch.int32).contiguous().view(rows)
         logp = torch.empty(rows, device=self.device)
         pred = torch.empty(rows, device=self.device, dtype=torch.int32)
-        if self.as_ok:
+        if self.bf_act:
             out = self.decode_full(input_ids, mem, sem, want_logits="none", sem_embs=sem_embs)
             xb = self._last_tf_bf16
-            parts = _lib.argmax_parts(self.V, rows, True)
+            parts = self.vocab_parts(rows)
             pm, pi = self.ws("sc_pmax", (rows, parts)), self.ws("sc_pidx", (rows, parts), torch.int32)
             ps, pl = self.ws("sc_psum", (rows, parts)), self.ws("sc_plab", (rows, parts))
-            call("care_gemm_argmax_bf16", ptr(xb), self.d, _code(xb), ptr(self.w["vocab"]), ptr(pm), ptr(pi), ptr(ps),
-                 ptr(lab32), ptr(pl), rows, self.V, self.d)
+            self.vocab_argmax(None, xb, rows, pm, pi, ps, lab32, pl, tag="tf_vocab_score")
             call("care_score_partials", ptr(pm), ptr(pi), ptr(ps), ptr(pl), parts, ptr(logp), ptr(pred), rows)
         else:
             out = self.decode_full(input_ids, mem, sem, want_logits="all", sem_embs=sem_embs)
@@ -881,20 +915,14 @@ class HipEngine:
         ckv = self.cross_src(mem, B)
         akv = self.attr_kv(sem_embs) if self.attr_att else None
         skv = [self.ws("g_skv%d" % li, (B, T, 2 * d), self.wt) for li in range(self.n_layers)]
-        bf = self.as_ok
-        parts = _lib.argmax_parts(self.V, B, bf)
+        parts = self.vocab_parts(B)
         pmax = self.ws("g_pmax", (B, parts))
         pidx = self.ws("g_pidx", (B, parts), torch.int32)
         psum = self.ws("g_psum", (B, parts))
         x0, x0b = self.ws("g_x0", (B, d)), self.wsb("g_x0", (B, d))  # the workspaces _decode_step embeds into
         for t in range(1, steps + 1):
             x, xb = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_", akv=akv, embedded=t > 1)
-            if bf:
-                call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(pmax), ptr(pidx),
-                     ptr(psum), None, None, B, self.V, d, tag="step_vocab_argmax")
-            else:
-                call("care_gemm_argmax", ptr(x), d, ptr(self.w["vocab"]), _code(self.w["vocab"]), ptr(pmax),
-                     ptr(pidx), ptr(psum), B, self.V, d, tag="step_vocab_argmax")
+            self.vocab_argmax(x, xb, B, pmax, pidx, psum)
             if t < steps:  # the token choice and, in the same launch, its embedding = the input of step t + 1
                 call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
                      ptr(length), ptr(fin), t, T, EOS, B, ptr(self.w["word"]), ptr(self.w["pos"]), ptr(sem), 1,
@@ -961,19 +989,13 @@ class HipEngine:
         def run_steps(v, t0, t1, enc=None):
             n = v["n"]
             self._ws_cap = (n, B)
-            bf = self.as_ok
-            parts = _lib.argmax_parts(self.V, n, bf)
+            parts = self.vocab_parts(n)
             pmax, psum = self.ws(v["tag"] + "pmax", (n, parts)), self.ws(v["tag"] + "psum", (n, parts))
             pidx = self.ws(v["tag"] + "pidx", (n, parts), torch.int32)
             for t in range(t0, t1 + 1):
                 x, xb = self._decode_step(t, n, 1, v["fed"], None, v["sem"], v["ckv"], v["skv"], self.Lk, v["tag"],
                                           akv=v["akv"], embedded=t > 1)
-                if bf:
-                    call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(pmax), ptr(pidx),
-                         ptr(psum), None, None, n, self.V, d, tag="step_vocab_argmax")
-                else:
-                    call("care_gemm_argmax", ptr(x), d, ptr(self.w["vocab"]), _code(self.w["vocab"]), ptr(pmax),
-                         ptr(pidx), ptr(psum), n, self.V, d, tag="step_vocab_argmax")
+                self.vocab_argmax(x, xb, n, pmax, pidx, psum)
                 if t < T:
                     call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
                          ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n, ptr(self.w["word"]),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 13
+#define CARE_ABI_VERSION 14
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -112,6 +112,23 @@ int care_gemm_bf16_splitk(const void* A, int64_t lda, int a_dtype, const void* W
 int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W, float* pmax,
                           int32_t* pidx, float* psum, const int32_t* labels, float* plab,
                           int M, int N, int K, void* stream);
+
+/*
+ * care_gemm_tile / care_gemm_tile_argmax: the contracts of care_gemm_bf16 / care_gemm_argmax_bf16 for bf16 A
+ *   and ANY K % 64 == 0 (csrc/gemm_tile.hip: both operands streamed through an LDS ring by LDS-DMA in K steps of
+ *   64, 64 x 64 output tiles per wave) - the nn.Linear layers of the d_model = 768 / 1024 architectures
+ *   (config/archs.yaml:15-26: K = 768, 1024, 3072, 4096; the same reference lines as care_gemm), and the
+ *   vocabulary projection of greedy decoding / teacher-forced scoring there (models/Head.py:26-32,
+ *   Translator.py:127, misc/Crit/crit_lang.py:75-103).  A bf16 [M, lda], W bf16 [N, K], lda % 8 == 0.
+ *   care_gemm_tile_argmax writes care_argmax_parts_tile(N) partials per row (one per 64 columns); labels / plab
+ *   (optional, both or neither) as in care_gemm_argmax_bf16.
+ */
+int care_gemm_tile(const void* A, int64_t lda, const void* W, const float* bias, void* C0, int64_t ldc0,
+                   int c0_dtype, void* C1, int64_t ldc1, int c1_dtype, int n_split, int M, int N, int K,
+                   int act, void* stream);
+int care_argmax_parts_tile(int N);
+int care_gemm_tile_argmax(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
+                          const int32_t* labels, float* plab, int M, int N, int K, void* stream);
 
 /*
  * Teacher-forced scoring (the metrics step): log-probability of the label token and the arg-max

@@ -711,3 +711,98 @@ def test_fused_beam_selection_equals_logits_plus_beam_select(M, V, bm):
     if bool(over.any()):
         assert torch.equal(got_i[over], ref_i[over])
         assert (got_v[over] - ref_v[over]).abs().max().item() < 1e-3
+
+
+TILE_SHAPES = [(1, 1024, 1024), (5, 10547, 1024), (64, 768, 768), (100, 3072, 1024), (257, 4096, 1024), (300, 1024, 4096),
+               (130, 640, 640), (200, 768, 3072), (1000, 48, 512), (4096, 1024, 1024), (513, 10547, 768), (777, 2304, 768),
+               (4096 + 19, 3072, 1024), (2048, 512, 2048)]
+
+
+@pytest.mark.parametrize("M,N,K", TILE_SHAPES)
+@pytest.mark.parametrize("act,out_bf16", [(0, False), (1, True), (2, False)])
+@pytest.mark.parametrize("cfg", ["", "223", "42", "422"])
+def test_gemm_tile(M, N, K, act, out_bf16, cfg, monkeypatch):
+    """csrc/gemm_tile.hip (bf16 A, bf16 W, any K % 64 == 0: the d_model 768 / 1024 layers) in every tile shape / ring
+    depth, against torch on the same bf16 operands; ragged edges in M and N; nothing written outside the destination."""
+    if cfg and (act == 2 or M < 64) and cfg != "42":
+        pytest.skip("tile shapes covered on the other combinations")
+    if cfg:
+        monkeypatch.setenv("CARE_TILE_CFG", cfg)
+    A = _rand(M, K, seed=71).to(torch.bfloat16).contiguous()
+    W = _rand(N, K, seed=72, scale=1 / math.sqrt(K))
+    bias = _rand(N, seed=73)
+    Wb = W.to(torch.bfloat16).contiguous()
+    ld = (N + 15) // 8 * 8
+    out = torch.full((M + 2, ld), 7.0, device=DEV, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    dst = out[:M, :N]
+    _call("care_gemm_tile", _p(A), K, _p(Wb), _p(bias), _p(dst), dst.stride(0), 1 if out_bf16 else 0, None, 0, 0, N, M, N, K, act)
+    ref = A.double() @ Wb.double().t() + bias.double()
+    ref = torch.relu(ref) if act == 1 else (torch.nn.functional.gelu(ref) if act == 2 else ref)
+    torch.cuda.synchronize()
+    assert (dst.double() - ref).abs().max().item() < (4e-2 if out_bf16 else 3e-3)
+    assert float(out[M:].float().min()) == 7.0 and float(out[:, N:].float().min()) == 7.0
+
+
+def test_gemm_tile_split_destinations_and_odd_leading_dimension():
+    """QKV of a d_model = 1024 decode step: q fp32 and k | v bf16 straight into position 7 of the cache; and the
+    vocabulary logits with an odd leading dimension (scalar store path)."""
+    M, K, d = 300, 1024, 1024
+    A = _rand(M, K, seed=74).to(torch.bfloat16).contiguous()
+    W, bias = _rand(3 * d, K, seed=75, scale=0.03), _rand(3 * d, seed=76)
+    Wb = W.to(torch.bfloat16).contiguous()
+    q = torch.zeros(M, d, device=DEV)
+    cache = torch.zeros(M, 29, 2 * d, device=DEV, dtype=torch.bfloat16)
+    dst = cache[:, 7, :]
+    _call("care_gemm_tile", _p(A), K, _p(Wb), _p(bias), _p(q), d, 0, _p(dst), dst.stride(0), 1, d, M, 3 * d, K, 0)
+    ref = A.float() @ Wb.float().t() + bias
+    torch.cuda.synchronize()
+    assert (q - ref[:, :d]).abs().max().item() < 3e-3
+    assert (cache[:, 7, :].float() - ref[:, d:]).abs().max().item() < 4e-2
+    assert cache[:, 6, :].abs().max().item() == 0 and cache[:, 8, :].abs().max().item() == 0
+    N = 10547
+    Wv = _rand(N, K, seed=77, scale=0.03).to(torch.bfloat16).contiguous()
+    logits = torch.full((M, N), float("nan"), device=DEV)
+    _call("care_gemm_tile", _p(A), K, _p(Wv), None, _p(logits), N, 0, None, 0, 0, N, M, N, K, 0)
+    torch.cuda.synchronize()
+    assert (logits - A.float() @ Wv.float().t()).abs().max().item() < 3e-3
+
+
+@pytest.mark.parametrize("M,K", [(1, 1024), (3, 768), (129, 1024), (1000, 1024), (4096 + 7, 1024), (300, 512)])
+@pytest.mark.parametrize("cfg", ["", "42"])
+def test_gemm_tile_argmax(M, K, cfg, monkeypatch):
+    """The fused vocabulary arg-max of the LDS-tiled kernel: per 64-column group (max, lowest arg-max, sum exp) and the
+    label logit, reduced by care_greedy_update / care_score_partials, against the bf16 product in fp64; exact ties
+    between far-apart columns and inside the ragged last tile go to the lower column."""
+    from care_amd import _lib
+
+    if cfg:
+        monkeypatch.setenv("CARE_TILE_CFG", cfg)
+    N = 10547
+    A = _rand(M, K, seed=81).to(torch.bfloat16).contiguous()
+    W = _rand(N, K, seed=82, scale=0.05)
+    W[N // 2 + 5] = W[11]
+    W[N - 1] = W[N - 2]
+    A[0] = (W[11] * 40).to(torch.bfloat16)
+    A[M - 1] = (W[N - 2] * 40).to(torch.bfloat16)
+    Wb = W.to(torch.bfloat16).contiguous()
+    parts = _lib.load().care_argmax_parts_tile(N)
+    ref = A.double() @ Wb.double().t()
+    labels = torch.randint(0, N, (M,), device=DEV, dtype=torch.int32)
+    pm, ps = torch.full((M, parts), float("nan"), device=DEV), torch.full((M, parts), float("nan"), device=DEV)
+    pl = torch.full((M, parts), float("nan"), device=DEV)
+    pi = torch.full((M, parts), -7, device=DEV, dtype=torch.int32)
+    _call("care_gemm_tile_argmax", _p(A), K, _p(Wb), _p(pm), _p(pi), _p(ps), _p(labels), _p(pl), M, N, K)
+    logp, pred = torch.empty(M, device=DEV), torch.empty(M, device=DEV, dtype=torch.int32)
+    _call("care_score_partials", _p(pm), _p(pi), _p(ps), _p(pl), parts, _p(logp), _p(pred), M)
+    pm2, ps2 = torch.full((M, parts), float("nan"), device=DEV), torch.full((M, parts), float("nan"), device=DEV)
+    pi2 = torch.full((M, parts), -7, device=DEV, dtype=torch.int32)
+    _call("care_gemm_tile_argmax", _p(A), K, _p(Wb), _p(pm2), _p(pi2), _p(ps2), None, None, M, N, K)
+    torch.cuda.synchronize()
+    assert torch.equal(pm, pm2) and torch.equal(pi, pi2) and torch.equal(ps, ps2)
+    top2 = ref.topk(2, dim=1)
+    safe = (top2[0][:, 0] - top2[0][:, 1]) > 1e-3
+    assert torch.equal(pred[safe].long(), top2[1][:, 0][safe])
+    if M > 1:
+        assert int(pred[0]) == 11 and int(pred[M - 1]) == N - 2      # ties: the lower column
+    want = torch.log_softmax(ref, dim=1).gather(1, labels.long().unsqueeze(1)).squeeze(1)
+    assert (logp.double() - want).abs().max().item() < 2e-3
