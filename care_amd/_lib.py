@@ -29,6 +29,8 @@ SIGNATURES = {
     "care_gemm_bf16": [_P, _L, _I, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_gemm_argmax_bf16": [_P, _L, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "care_gemm_tile": [_P, _L, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "care_split2_act": [_P, _L, _P, _I, _I, _P],
+    "care_gemm_tile_split3": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     "care_gemm_tile_argmax": [_P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "care_score_partials": [_P, _P, _P, _P, _I, _P, _P, _I, _P],
     "care_score_logits": [_P, _L, _I, _P, _P, _P, _I, _P],
@@ -48,6 +50,7 @@ SIGNATURES = {
     "care_embed_ln": [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _F, _P, _P, _L, _I, _I, _I, _P],
     "care_attention": [_P, _L, _P, _P, _I, _L, _L, _I, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _L,
                        _I, _I, _I, _P],
+    "care_attention_seq": [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _L, _I, _I, _P],
     "care_attention_latent": [_P, _L, _P, _L, _L, _I, _I, _P, _I, _P, _L, _I, _I, _I, _P],
     "care_head_expand": [_P, _L, _P, _P, _L, _I, _I, _P],
     "care_head_reduce": [_P, _L, _P, _P, _P, _L, _I, _I, _P],

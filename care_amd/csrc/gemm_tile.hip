@@ -39,6 +39,7 @@ struct TArgs {
   float* pmax; int32_t* pidx; float* psum; int parts;
   const int32_t* labels; float* plab;
   int tiles_m, tiles_n;
+  int a_wrap;  // K steps (of 64) after which the A columns start over: see care_gemm_tile_split3 (INT_MAX otherwise)
 };
 
 enum { EPI_STORE = 0, EPI_ARGMAX = 1, EPI_ARGMAX_LAB = 2 };
@@ -50,9 +51,10 @@ __device__ __forceinline__ void t_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory");
 }
 
-template <int WGM, int WGN, int STAGES, int EPI>
+template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
-  constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
+  constexpr int NW = WGM * WGN, BM = 64 * WTM * WGM, BN = 64 * WGN;
+  constexpr int MT = 4 * WTM;             // 16-row accumulator tiles of a wave (its (64 WTM) x 64 outputs)
   constexpr int PIECES = (BM + BN) / 8;   // 1-KB DMA pieces (8 rows x 128 B) of one K step
   constexpr int P = PIECES / NW;          // pieces per wave and K step
   static_assert(PIECES % NW == 0, "pieces must divide over the waves");
@@ -77,8 +79,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
   const int prow = lane >> 3;
   const int sc = ((lane & 7) ^ prow) << 4;  // source chunk of this lane's LDS slot (row & 7 == prow)
   const unsigned char* src[P];
+  bool is_a[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) {
+    is_a[i] = (wave * P + i) * 8 < BM;
     const int R = (wave * P + i) * 8 + prow;
     if ((wave * P + i) * 8 < BM) {
       const int row = min(m0 + R, p.M - 1);  // clamped, never branched around: rows past M are not stored
@@ -91,17 +95,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
     }
   }
   auto issue = [&](int kt, int slot) {
+    const int kta = F16 ? kt - (kt >= p.a_wrap ? p.a_wrap : 0) : kt;  // split products: the A columns start over
 #pragma unroll
     for (int i = 0; i < P; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * 128),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)((F16 && is_a[i]) ? kta : kt) * 128),
                                        (__attribute__((address_space(3))) void*)(smem + slot * STAGE_BYTES +
                                                                                  (wave * P + i) * 1024),
                                        16, 0, 0);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
     if (s < nk) issue(s, s);
 
   const int fr = lane & 15, fg = lane >> 4;
-  const int a_row = (wm * 64 + fr) * 128, b_row = (BM + wn * 64 + fr) * 128;
+  const int a_row = (wm * 64 * WTM + fr) * 128, b_row = (BM + wn * 64 + fr) * 128;
   const int sw0 = ((fg ^ (fr & 7)) << 4), sw1 = (((4 + fg) ^ (fr & 7)) << 4);
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -127,21 +132,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int sw = kk ? sw1 : sw0;
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const bf16x8*>(st + a_row + m * 2048 + sw);
+      bf16x8 fa[MT], fb[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(st + b_row + n * 2048 + sw);
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const bf16x8*>(st + a_row + m * 2048 + sw);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[n], fa[m], acc[m][n], 0, 0, 0);
+          if constexpr (F16) {
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fb[n]), __builtin_bit_cast(f16x8, fa[m]),
+                                                               acc[m][n], 0, 0, 0);
+          } else {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[n], fa[m], acc[m][n], 0, 0, 0);
+          }
     }
   }
 
   // ------------------------------------------------------------------ epilogue
-  // acc[m][n][j] = out[row m0 + 64 wm + 16 m + fr][column n0 + 64 wn + 16 fg + 4 n + j]
+  // acc[m][n][j] = out[row m0 + 64 WTM wm + 16 m + fr][column n0 + 64 wn + 16 fg + 4 n + j]
   const int colw = n0 + wn * 64;          // first column of the wave
   const int col0 = colw + fg * 16;        // first of this lane's 16 consecutive columns
   if constexpr (EPI == EPI_STORE) {
@@ -156,8 +167,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
     const int nvalid = min(16, (second ? p.N : min(p.N, p.n_split)) - col0);  // columns of this lane inside the destination
     const bool vec = nvalid == 16 && ((ld & 7) == 0) && ((cc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int row = m0 + wm * 64 + m * 16 + fr;
+    for (int m = 0; m < MT; ++m) {
+      const int row = m0 + wm * 64 * WTM + m * 16 + fr;
       float v[16];
 #pragma unroll
       for (int n = 0; n < 4; ++n)
@@ -196,10 +207,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
     }
   } else {
     // per row of this wave's 64 columns: max, FIRST arg-max, sum exp(x - max) [, the logit of the label column]
-    const int part = (n0 / BN) * WGN + wn;
+    const int part = (n0 >> 6) + wn;  // one partial per 64 columns, whatever the tile shape
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int row = m0 + wm * 64 + m * 16 + fr;
+    for (int m = 0; m < MT; ++m) {
+      const int row = m0 + wm * 64 * WTM + m * 16 + fr;
       float best = -INFINITY;
       int bi = 0x7fffffff;
 #pragma unroll
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
         lv = fmaxf(lv, __shfl_xor(lv, 16, 64));
         lv = fmaxf(lv, __shfl_xor(lv, 32, 64));
       }
-      if (fg == 0 && row < p.M) {
+      if (fg == 0 && row < p.M && part < p.parts) {
         const int64_t o = (int64_t)row * p.parts + part;
         p.pmax[o] = best; p.pidx[o] = bi; p.psum[o] = s;
         if constexpr (EPI == EPI_ARGMAX_LAB) p.plab[o] = lv;
@@ -244,41 +255,44 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
   }
 }
 
-template <int WGM, int WGN, int STAGES, int EPI>
+template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false>
 int launch_tile(TArgs& p, hipStream_t st) {
-  constexpr int BM = 64 * WGM, BN = 64 * WGN;
+  constexpr int BM = 64 * WTM * WGM, BN = 64 * WGN;
   constexpr int lds = STAGES * (BM + BN) * 128;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   if (lds > 64 * 1024) {
     static std::atomic<unsigned long long> done{0};
-    const int rc = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_tile_kernel<WGM, WGN, STAGES, EPI>), lds, done);
+    const int rc = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16>), lds, done);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL((gemm_tile_kernel<WGM, WGN, STAGES, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), lds, st, p);
   return care_launch_status();
 }
 
-// Tile shape: the biggest one whose tiles still fill the 256 CUs about twice over (a 256-row x 128-column tile
-// reads a third less of A and W per flop than 128 x 128), CARE_TILE_CFG overrides (tuning).
+// Tile shape (CARE_TILE_CFG overrides, tuning): 256 x 256 tiles of 16 waves (half the L2 -> LDS bytes per flop of
+// 128 x 128, four waves per SIMD) as soon as they occupy half the 256 CUs, 128 x 128 tiles of 4 waves (two workgroups
+// per CU) below.  *Measured* (tools/tile_bench.py, one MI355X, bf16 out): M = 4096, K = 1024: N = 4096 952 vs 701
+// TFLOP/s, N = 3072 (192 big tiles) 843 vs 580, N = 2304 / K = 768 (144) 576 vs 484, N = 1024 (64) 314 vs 483;
+// M = 466944, N = 2048 929 vs 682; 8 waves of 128 x 64 (2422) and 256 x 128 tiles (422, 2222) lie in between.
 int pick_cfg(int M, int N) {
   if (const char* e = getenv("CARE_TILE_CFG")) return atoi(e);
-  const long t22 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  const long t42 = (long)((M + 255) / 256) * ((N + 127) / 128);
-  if (t42 >= 448) return 42;
-  (void)t22;
-  return 22;
+  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  return t256 >= 128 ? 4412 : 222;
 }
 
 template <int EPI>
 int dispatch(TArgs& p, hipStream_t st) {
   switch (pick_cfg(p.M, p.N)) {
-    case 42: return launch_tile<4, 2, 3, EPI>(p, st);
-    case 423: return launch_tile<4, 2, 3, EPI>(p, st);
-    case 422: return launch_tile<4, 2, 2, EPI>(p, st);
-    case 223: return launch_tile<2, 2, 3, EPI>(p, st);
-    case 224: return launch_tile<2, 2, 4, EPI>(p, st);
-    default: return launch_tile<2, 2, 2, EPI>(p, st);
+    case 42: return launch_tile<4, 2, 1, 3, EPI>(p, st);
+    case 423: return launch_tile<4, 2, 1, 3, EPI>(p, st);
+    case 422: return launch_tile<4, 2, 1, 2, EPI>(p, st);
+    case 223: return launch_tile<2, 2, 1, 3, EPI>(p, st);
+    case 2222: return launch_tile<2, 2, 2, 2, EPI>(p, st);   // 256 x 128, 4 waves of 128 x 64
+    case 2422: return launch_tile<2, 4, 2, 2, EPI>(p, st);   // 256 x 256, 8 waves of 128 x 64
+    case 4412: return launch_tile<4, 4, 1, 2, EPI>(p, st);   // 256 x 256, 16 waves of 64 x 64
+    case 2223: return launch_tile<2, 2, 2, 3, EPI>(p, st);
+    default: return launch_tile<2, 2, 1, 2, EPI>(p, st);
   }
 }
 
@@ -309,7 +323,49 @@ extern "C" int care_gemm_tile(const void* A, int64_t lda, const void* W, const f
   return dispatch<EPI_STORE>(p, (hipStream_t)stream);
 }
 
-extern "C" int care_argmax_parts_tile(int N) { return N > 0 ? 2 * ((N + 127) / 128) : CARE_EINVAL; }
+// fp32 [M, K] -> fp16 pieces [M, 2K]: x_hi = fp16(x) | x_lo = fp16(x - x_hi)
+__global__ void split2_act_kernel(const float* A, int64_t lda, _Float16* out, int M, int K) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 each
+  const int kq = K >> 2;
+  if (i >= (int64_t)M * kq) return;
+  const int r = (int)(i / kq), c = (int)(i % kq) * 4;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(A + (int64_t)r * lda + c);
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { hi[j] = (_Float16)v[j]; lo[j] = (_Float16)(v[j] - (float)hi[j]); }
+  _Float16* row = out + (int64_t)r * 2 * K;
+  *reinterpret_cast<f16x4*>(row + c) = hi;
+  *reinterpret_cast<f16x4*>(row + K + c) = lo;
+}
+
+extern "C" int care_split2_act(const float* A, int64_t lda, void* A2, int M, int K, void* stream) {
+  if (!A || !A2 || M <= 0 || K <= 0) return CARE_EINVAL;
+  if (K % 4 != 0 || lda % 4 != 0 || !care_aligned16(A) || !care_aligned16(A2)) return CARE_EALIGN;
+  const int64_t total = (int64_t)M * (K >> 2);
+  hipLaunchKernelGGL(split2_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, lda,
+                     reinterpret_cast<_Float16*>(A2), M, K);
+  return care_launch_status();
+}
+
+// C = A W^T + bias with fp32-GRADE products on the LDS-tiled kernel: A2 = care_split2_act(A) [M, 2K] (hi | lo),
+// W3 = care_split3_weight(W) [N, 3K] (hi | lo | hi); one product over the virtual 3K columns
+// a_hi w_hi + a_hi w_lo + a_lo w_hi (the A columns start over after the first K: a_hi, a_hi again, then a_lo),
+// v_mfma_f32_16x16x32_f16.  The contract of care_gemm_split3 (csrc/gemm.hip) at about twice its rate.
+extern "C" int care_gemm_tile_split3(const void* A2, const void* W3, const float* bias, float* C, int64_t ldc, int M,
+                                     int N, int K, void* stream) {
+  int rc = tile_check(A2, 2 * (int64_t)K, W3, M, N, K);
+  if (rc) return rc;
+  if (!C) return CARE_EINVAL;
+  TArgs p{};
+  p.A = reinterpret_cast<const bf16_t*>(A2); p.lda = 2 * (int64_t)K; p.W = reinterpret_cast<const bf16_t*>(W3); p.ldw = 3 * (int64_t)K;
+  p.bias = bias; p.C0 = C; p.ldc0 = ldc; p.c0_bf16 = 0; p.C1 = nullptr; p.n_split = N; p.M = M; p.N = N; p.K = 3 * K;
+  p.act = CARE_ACT_NONE; p.a_wrap = K >> 6;
+  hipStream_t st = (hipStream_t)stream;
+  return pick_cfg(M, N) == 4412 ? launch_tile<4, 4, 1, 2, EPI_STORE, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_STORE, true>(p, st);
+}
+
+extern "C" int care_argmax_parts_tile(int N) { return N > 0 ? (N + 63) / 64 : CARE_EINVAL; }
 
 extern "C" int care_gemm_tile_argmax(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
                                      const int32_t* labels, float* plab, int M, int N, int K, void* stream) {

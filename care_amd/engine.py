@@ -423,14 +423,14 @@ class HipEngine:
                 raise ValueError("label logits come from the bf16 kernels only (fp32 mode scores materialised logits)")
             call("care_gemm_argmax", ptr(x), d, ptr(W), _code(W), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
 
-    def add_ln(self, x, res, g, be, out, outb=None, grp=None, out_grp_rows=None, out_row_off=0, pos=None, nslab=1):
+    def add_ln(self, x, res, g, be, out, outb=None, grp=None, out_grp_rows=None, out_row_off=0, pos=None, nslab=1, tag=None):
         """out = LN(sum of the nslab slabs of x + res); x is [rows, d] or [nslab, rows, d]."""
         rows, d = x.shape[-2], x.shape[-1]
         grp = rows if grp is None else grp
         out_grp_rows = grp if out_grp_rows is None else out_grp_rows
         call("care_add_ln", ptr(x), x.stride(-2), ptr(res), res.stride(0) if res is not None else 0, ptr(pos), ptr(g),
              ptr(be), self.eps, ptr(out), ptr(outb), out.stride(-2), rows, d, grp, out_grp_rows, out_row_off,
-             nslab, x.stride(0) if nslab > 1 else 0)
+             nslab, x.stride(0) if nslab > 1 else 0, tag=tag)
         return out
 
     def ln_fusable(self, rows: int) -> bool:
@@ -519,9 +519,10 @@ class HipEngine:
             f = self.ws(tag + "fslab", (ns, rows, d))
             call("care_gemm_bf16_splitk", ptr(h), h.stride(0), _code(h), ptr(w2), ptr(w[name + "_b2"]), ptr(f), d,
                  f.stride(0), rows, d, self.ff, tag=gemm_tag)
-            return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, nslab=ns, **ln_kw)
+            return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, nslab=ns,
+                               tag="step_add_ln" if gemm_tag else None, **ln_kw)
         f = self.gemm(h, w2, w[name + "_b2"], self.ws(tag + "f", (rows, d)), tag=gemm_tag)
-        return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, **ln_kw)
+        return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, tag="step_add_ln" if gemm_tag else None, **ln_kw)
 
     # ------------------------------------------------------------------ encoder + concept head
     @property
@@ -564,8 +565,14 @@ class HipEngine:
                 lin = None
             elif W3 is not None:
                 lin = self.ws("enc_lin", (B * n, d))
-                call("care_gemm_split3", ptr(x2), x2.stride(0), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
-                     B * n, d, x2.shape[1], tag="enc_gemm")
+                if os.environ.get("CARE_ENC_TILE", "1") != "0":  # fp16 pieces of the features once, then the LDS-tiled kernel
+                    a2 = self.ws("enc_a2", (B * n, 2 * x2.shape[1]), torch.float16)
+                    call("care_split2_act", ptr(x2), x2.stride(0), ptr(a2), B * n, x2.shape[1], tag="enc_split")
+                    call("care_gemm_tile_split3", ptr(a2), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
+                         B * n, d, x2.shape[1], tag="enc_gemm")
+                else:
+                    call("care_gemm_split3", ptr(x2), x2.stride(0), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
+                         B * n, d, x2.shape[1], tag="enc_gemm")
             else:
                 lin = self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch], self.ws("enc_lin", (B * n, d)), tag="enc_gemm")
             in_mem = ch in self.dec_mod
@@ -717,9 +724,76 @@ class HipEngine:
         return y, yb
 
     # ------------------------------------------------------------------ teacher-forced decoder
+    def tf_fast_ok(self, t: int, want_aux: bool) -> bool:
+        """Teacher-forced forward on the fast kernels (_decode_full_fast): bf16 mode, d_model = 512, no auxiliary
+        dict entries (attention probabilities etc. are not materialised by the fused kernels)."""
+        return (self.as_ok and self.d == 512 and not want_aux and t <= 32 and
+                os.environ.get("CARE_TF_FAST", "1") != "0")
+
+    def _dense_ln(self, ctx, name, res, out, outb, rows, tag):
+        """dense -> (+ residual) -> LayerNorm of an attention block (SubLayers.py:69-79): one fused kernel from
+        ~10 K rows (ln_fusable), the A-stationary GEMM + LayerNorm pair below."""
+        w = self.w
+        if self.ln_fusable(rows):
+            return self.gemm_ln(ctx, w[name + "_o_w"], w[name + "_o_b"], res, w[name + "_g"], w[name + "_be"], out, outb,
+                                tag=tag + "_ln", Wp=w.get(name + "_o_w#packed"))
+        o = self.gemm(ctx, w[name + "_o_w"], w[name + "_o_b"], self.ws("tf_o", (rows, self.d)), tag=tag + "_gemm")
+        return self.add_ln(o, res, w[name + "_g"], w[name + "_be"], out, outb)
+
+    def _decode_full_fast(self, x, xb, ids32, N, t, B, Lk, per_clip, ckv, akv, want_logits, hidden_fp32=True):
+        """The teacher-forced decoder (Decoder/Transformer.py:161-268 with Lq = t) on the kernels of the decode path:
+        bf16 QKV / Wq / FFN1 through the store GEMMs, dense + residual + LayerNorm and FFN2 fused (gemm_ln), and both
+        attentions through care_attention_seq - one wave per (sequence, head), the keys and values of a sequence read
+        once for its t query positions, QK^T and PV on the matrix cores.  Same operand roundings as a decode step
+        (bf16 GEMM inputs, fp32 residual stream and statistics)."""
+        w, d, H = self.w, self.d, self.H
+        rows = N * t
+        bfw = lambda name, shape: self.ws(name, shape, torch.bfloat16)
+        ctx = bfw("tf_ctxb", (rows, d))
+        for li in range(self.n_layers):
+            nm = "d{}_sa".format(li)
+            qkv = self.gemm(xb, w[nm + "_qkv_w"], w[nm + "_qkv_b"], bfw("tf_qkvb", (rows, 3 * d)), tag="tf_qkv_gemm")
+            call("care_attention_seq", ptr(qkv), 3 * d, ptr(qkv[:, d:]), ptr(qkv[:, 2 * d:]), t * 3 * d, 3 * d, 1, t, 1, t,
+                 ptr(ids32), t, PAD, None, 0, ptr(ctx), d, N, H, tag="tf_self_attn")
+            x1, x1b = self.ws("tf_x1", (rows, d)), self.wsb("tf_x1", (rows, d))
+            self._dense_ln(ctx, nm, x, x1, x1b, rows, "tf_dxd")
+            nm = "d{}_ca".format(li)
+            hb = w["d{}_hb".format(li)]
+            q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm")
+            kv = ckv[li]
+            call("care_attention_seq", ptr(q2), d, ptr(kv), ptr(kv[:, d:]), Lk * 2 * d, 2 * d, per_clip, Lk, 0, t,
+                 None, 0, PAD, ptr(hb), hb.stride(0) if hb is not None else 0, ptr(ctx), d, N, H, tag="tf_cross_attn")
+            x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
+            self._dense_ln(ctx, nm, x1, x2, x2b, rows, "tf_dxd")
+            if self.attr_att:
+                nm = "d{}_aa".format(li)
+                q3 = self.gemm(x2b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm")
+                kv = akv[li]
+                call("care_attention_seq", ptr(q3), d, ptr(kv), ptr(kv[:, d:]), self.topk * 2 * d, 2 * d, per_clip,
+                     self.topk, 0, t, None, 0, PAD, None, 0, ptr(ctx), d, N, H, tag="tf_attr_attn")
+                y, yb = self.ws("tf_x2a", (rows, d)), self.wsb("tf_x2a", (rows, d))
+                self._dense_ln(ctx, nm, x2, y, yb, rows, "tf_dxd")
+                x2, x2b = y, yb
+            last = li == self.n_layers - 1
+            xb = self.wsb("tf_x3", (rows, d))
+            if last and not hidden_fp32 and self.ln_fusable(rows) and self.ff % 512 == 0 and self.ff >= 1024:
+                x = None  # scoring only reads the bf16 mirror
+            else:
+                x = torch.empty(rows, d, device=self.device) if last else self.ws("tf_x3", (rows, d))
+            self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, "tf_", gemm_tag="tf_ffn_gemm")
+        self._last_tf_bf16 = xb
+        out = {"hidden_states": x.view(N, t, d) if x is not None else None}
+        if want_logits == "all":
+            out["logits"] = self.gemm(xb, w["vocab"], None, torch.empty(rows, self.V, device=self.device),
+                                      tag="tf_vocab_logits").view(N, t, self.V)
+        elif want_logits == "last":
+            src = xb.view(N, t, d)[:, -1, :]
+            out["logits"] = self.gemm(src, w["vocab"], None, torch.empty(N, self.V, device=self.device))
+        return out
+
     def decode_full(self, input_ids: torch.Tensor, mem: torch.Tensor, sem: Optional[torch.Tensor],
                     want_logits: str = "all", sem_embs: Optional[torch.Tensor] = None,
-                    want_aux: bool = False) -> Dict[str, torch.Tensor]:
+                    want_aux: bool = False, hidden_fp32: bool = True) -> Dict[str, torch.Tensor]:
         """`TransformerDecoder.forward` + `NaiveHead` on whole sequences (Lq = t).
 
         Used by feedforward_step (Framework.py:215-234) and by the stateless
@@ -741,11 +815,13 @@ class HipEngine:
             sem_div = t * (per_clip if sem.shape[0] == B else 1)
         x, xb = self.ws("tf_x0", (rows, d)), self.wsb("tf_x0", (rows, d))
         call("care_embed_ln", ptr(ids32), t, 0, None, 0, ptr(w["word"]), ptr(w["pos"]), 0, ptr(sem), sem_div,
-             ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(x), ptr(xb), d, rows, t, d)
+             ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(x), ptr(xb), d, rows, t, d, tag="tf_embed")
         ckv = self.cross_kv(mem, tag="tf_ckv")
         if self.attr_att and sem_embs is None:
             raise KeyError("this model attends to `semantic_embs` (use_attr_type={!r})".format(self.use_attr_type))
         akv = self.attr_kv(sem_embs, tag="tf_akv") if self.attr_att else None
+        if self.tf_fast_ok(t, want_aux):
+            return self._decode_full_fast(x, xb, ids32, N, t, B, Lk, per_clip, ckv, akv, want_logits, hidden_fp32)
         # auxiliary outputs of TransformerDecoder.forward (Decoder/Transformer.py:239-252), on request
         A = None
         if want_aux:
@@ -813,7 +889,7 @@ class HipEngine:
         logp = torch.empty(rows, device=self.device)
         pred = torch.empty(rows, device=self.device, dtype=torch.int32)
         if self.bf_act:
-            out = self.decode_full(input_ids, mem, sem, want_logits="none", sem_embs=sem_embs)
+            out = self.decode_full(input_ids, mem, sem, want_logits="none", sem_embs=sem_embs, hidden_fp32=False)
             xb = self._last_tf_bf16
             parts = self.vocab_parts(rows)
             pm, pi = self.ws("sc_pmax", (rows, parts)), self.ws("sc_pidx", (rows, parts), torch.int32)
@@ -853,7 +929,7 @@ class HipEngine:
                              tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
             else:
                 o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
-                self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b)
+                self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b, tag="step_add_ln")
             nm = "d{}_ca".format(li)
             hb = w["d{}_hb".format(li)]
             if isinstance(ckv, tuple):  # absorbed form (cross_src)
@@ -880,7 +956,7 @@ class HipEngine:
                              tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
             else:
                 o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
-                self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
+                self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b, tag="step_add_ln")
             if self.attr_att:
                 x2, x2b = self._attr_block(li, x2, x2b, akv, rows_per_clip, tag)
             x, xb = self.ws(tag + "x3_%d" % (li & 1), (N, d)), self.wsb(tag + "x3_%d" % (li & 1), (N, d))
@@ -926,7 +1002,7 @@ class HipEngine:
             if t < steps:  # the token choice and, in the same launch, its embedding = the input of step t + 1
                 call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
                      ptr(length), ptr(fin), t, T, EOS, B, ptr(self.w["word"]), ptr(self.w["pos"]), ptr(sem), 1,
-                     ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps, ptr(x0), ptr(x0b), d, d)
+                     ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps, ptr(x0), ptr(x0b), d, d, tag="step_update_embed")
             else:
                 call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
                      ptr(length), ptr(fin), t, T, EOS, B)
@@ -1000,7 +1076,7 @@ class HipEngine:
                     call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
                          ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n, ptr(self.w["word"]),
                          ptr(self.w["pos"]), ptr(v["sem"]), 1, ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps,
-                         ptr(v["x0"]), ptr(v["x0b"]), d, d)
+                         ptr(v["x0"]), ptr(v["x0b"]), d, d, tag="step_update_embed")
                 else:
                     call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
                          ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n)

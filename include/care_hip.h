@@ -123,6 +123,13 @@ int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W
  *   care_gemm_tile_argmax writes care_argmax_parts_tile(N) partials per row (one per 64 columns); labels / plab
  *   (optional, both or neither) as in care_gemm_argmax_bf16.
  */
+/* care_split2_act / care_gemm_tile_split3: the contract of care_gemm_split3 (fp32 A, fp32-GRADE products
+ *   a_hi w_hi + a_hi w_lo + a_lo w_hi in fp16 pieces: the feature embedder of concept models, models/Encoder.py:167)
+ *   on the LDS-tiled kernel: A2 = care_split2_act(A) fp16 [M, 2K] (hi | lo), W3 = care_split3_weight(W) [N, 3K];
+ *   C fp32 [M, ldc].  K % 64 == 0, |A| < 65504. */
+int care_split2_act(const float* A, int64_t lda, void* A2, int M, int K, void* stream);
+int care_gemm_tile_split3(const void* A2, const void* W3, const float* bias, float* C, int64_t ldc, int M, int N,
+                          int K, void* stream);
 int care_gemm_tile(const void* A, int64_t lda, const void* W, const float* bias, void* C0, int64_t ldc0,
                    int c0_dtype, void* C1, int64_t ldc1, int c1_dtype, int n_split, int M, int N, int K,
                    int act, void* stream);
@@ -314,6 +321,22 @@ int care_attention(const float* Q, int64_t ldq, const void* K, const void* V, in
                    int causal_off, const int32_t* pad_tok, int pad_stride, int pad_id,
                    const float* bias, int bias_ld, void* ctx, int64_t ldctx, int ctx_dtype,
                    int rows, int heads, void* stream);
+
+/*
+ * care_attention_seq: the same attention (models/components/Attention.py:83-131) for WHOLE query sequences of
+ *   seq <= 32 positions with bf16 operands - the teacher-forced forward (models/Framework.py:215-237,
+ *   Decoder/Transformer.py:161-268) - one wave per (sequence, head), K and V read once for all positions,
+ *   QK^T and PV on the matrix cores (csrc/attention_seq.hip).
+ *   Q bf16 [nseq * seq, ldq] (head h at columns h*64..); key j of sequence s at
+ *   base + (s / seqs_per_kv) * kv_batch_stride + j * kv_row_stride + h * 64 (elements, bf16) for K and V.
+ *   causal: query position i sees keys j <= i.  pad_tok (int32, optional): key j is masked (-1e9, before the
+ *   bias) when pad_tok[(s / seqs_per_kv) * pad_stride + j] == pad_id.  bias fp32 [heads, bias_ld] or NULL.
+ *   ctx bf16 [nseq * seq, ldctx].  nkeys <= 128.
+ */
+int care_attention_seq(const void* Q, int64_t ldq, const void* K, const void* V, int64_t kv_batch_stride,
+                       int64_t kv_row_stride, int seqs_per_kv, int nkeys, int causal, int seq,
+                       const int32_t* pad_tok, int pad_stride, int pad_id, const float* bias, int bias_ld,
+                       void* ctx, int64_t ldctx, int nseq, int heads, void* stream);
 
 /*
  * care_attention_latent: the cross-attention of a decoder step with W_k / W_v absorbed into

@@ -720,7 +720,7 @@ TILE_SHAPES = [(1, 1024, 1024), (5, 10547, 1024), (64, 768, 768), (100, 3072, 10
 
 @pytest.mark.parametrize("M,N,K", TILE_SHAPES)
 @pytest.mark.parametrize("act,out_bf16", [(0, False), (1, True), (2, False)])
-@pytest.mark.parametrize("cfg", ["", "223", "42", "422"])
+@pytest.mark.parametrize("cfg", ["", "223", "42", "2222", "2422", "4412"])
 def test_gemm_tile(M, N, K, act, out_bf16, cfg, monkeypatch):
     """csrc/gemm_tile.hip (bf16 A, bf16 W, any K % 64 == 0: the d_model 768 / 1024 layers) in every tile shape / ring
     depth, against torch on the same bf16 operands; ragged edges in M and N; nothing written outside the destination."""
@@ -768,7 +768,7 @@ def test_gemm_tile_split_destinations_and_odd_leading_dimension():
 
 
 @pytest.mark.parametrize("M,K", [(1, 1024), (3, 768), (129, 1024), (1000, 1024), (4096 + 7, 1024), (300, 512)])
-@pytest.mark.parametrize("cfg", ["", "42"])
+@pytest.mark.parametrize("cfg", ["", "42", "2422", "2223"])
 def test_gemm_tile_argmax(M, K, cfg, monkeypatch):
     """The fused vocabulary arg-max of the LDS-tiled kernel: per 64-column group (max, lowest arg-max, sum exp) and the
     label logit, reduced by care_greedy_update / care_score_partials, against the bf16 product in fp64; exact ties
@@ -806,3 +806,78 @@ def test_gemm_tile_argmax(M, K, cfg, monkeypatch):
         assert int(pred[0]) == 11 and int(pred[M - 1]) == N - 2      # ties: the lower column
     want = torch.log_softmax(ref, dim=1).gather(1, labels.long().unsqueeze(1)).squeeze(1)
     assert (logp.double() - want).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 1024, 2048), (4096 + 33, 1024, 512), (28 * 64, 768, 128), (70000, 1024, 128)])
+def test_gemm_tile_split3(M, N, K):
+    """fp32-grade products on the LDS-tiled kernel (fp16 pieces, three MFMA passes as one product over 3K with the A
+    columns wrapping): against the exact product in fp64, and against the generic kernel's care_gemm_split3."""
+    A = _rand(M, K, seed=91)
+    W = _rand(N, K, seed=92, scale=1 / math.sqrt(K))
+    bias = _rand(N, seed=93)
+    W3 = torch.empty(N, 3 * K, device=DEV, dtype=torch.float16)
+    _call("care_split3_weight", _p(W), _p(W3), N, K)
+    A2 = torch.empty(M, 2 * K, device=DEV, dtype=torch.float16)
+    _call("care_split2_act", _p(A), K, _p(A2), M, K)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    _call("care_gemm_tile_split3", _p(A2), _p(W3), _p(bias), _p(out), N, M, N, K)
+    old = torch.full((M, N), float("nan"), device=DEV)
+    _call("care_gemm_split3", _p(A), K, _p(W3), _p(bias), _p(old), N, M, N, K)
+    ref = A.double() @ W.double().t() + bias.double()
+    torch.cuda.synchronize()
+    assert (out.double() - ref).abs().max().item() < 2e-5
+    assert (out - old).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("nseq,seq,nkeys,per_kv,kind", [(7, 29, 29, 1, "self"), (5, 30, 30, 1, "self"), (3, 12, 12, 1, "self"),
+                                                        (9, 29, 84, 3, "cross"), (4, 29, 114, 1, "cross_bias"),
+                                                        (6, 17, 28, 2, "cross"), (2, 29, 128, 1, "cross_bias"),
+                                                        (3000, 29, 114, 5, "cross_bias"), (2048, 29, 29, 1, "self")])
+def test_attention_seq(nseq, seq, nkeys, per_kv, kind):
+    """csrc/attention_seq.hip (one wave per (sequence, head), K / V read once for all query positions) against torch
+    on the same bf16 operands: causal + key-padding mask (-1e9 before the bias) for self-attention; per-(head, key)
+    bias and key/value blocks shared by `per_kv` consecutive sequences for cross-attention."""
+    H, d = 8, 512
+    rows = nseq * seq
+    g = torch.Generator().manual_seed(nseq * 131 + nkeys)
+    if kind == "self":
+        qkv = (torch.randn(rows, 3 * d, generator=g) * 1.5).to(DEV).to(torch.bfloat16)
+        Q, K, V = qkv, qkv[:, d:], qkv[:, 2 * d:]
+        ldq, kbs, krs = 3 * d, seq * 3 * d, 3 * d
+        tok = torch.randint(1, 50, (nseq, seq), generator=g).to(DEV).to(torch.int32)
+        tok[:, 0] = 1
+        tok[0, 3] = 0
+        tok[nseq - 1, seq - 2:] = 0       # PAD keys (id 0), also at a row's own position
+        bias = None
+        Kf = qkv[:, d:2 * d].float().view(nseq, seq, H, 64)
+        Vf = qkv[:, 2 * d:].float().view(nseq, seq, H, 64)
+        Qf = qkv[:, :d].float().view(nseq, seq, H, 64)
+    else:
+        nkv = (nseq + per_kv - 1) // per_kv
+        assert nseq % per_kv == 0
+        q = (torch.randn(rows, d, generator=g) * 1.5).to(DEV).to(torch.bfloat16)
+        kv = (torch.randn(nkv * nkeys, 2 * d, generator=g)).to(DEV).to(torch.bfloat16)
+        Q, K, V = q, kv, kv[:, d:]
+        ldq, kbs, krs = d, nkeys * 2 * d, 2 * d
+        tok = None
+        bias = (torch.randn(H, nkeys, generator=g) * 0.5).to(DEV) if kind == "cross_bias" else None
+        idx = torch.arange(nseq, device=DEV) // per_kv
+        Kf = kv[:, :d].float().view(nkv, nkeys, H, 64)[idx]
+        Vf = kv[:, d:].float().view(nkv, nkeys, H, 64)[idx]
+        Qf = q.float().view(nseq, seq, H, 64)
+    ctx = torch.full((rows, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _call("care_attention_seq", _p(Q), ldq, _p(K), _p(V), kbs, krs, per_kv, nkeys, 1 if kind == "self" else 0, seq,
+          _p(tok), seq if tok is not None else 0, 0, _p(bias), nkeys if bias is not None else 0, _p(ctx), d, nseq, H)
+    sc = torch.einsum("sqhe,skhe->shqk", Qf, Kf) / 8.0
+    if kind == "self":
+        mask = (tok == 0)[:, None, None, :] | torch.triu(torch.ones(seq, seq, device=DEV, dtype=torch.bool), 1)[None, None]
+        sc = sc.masked_fill(mask, -1e9)
+    if bias is not None:
+        sc = sc + bias[None, :, None, :]
+    pr = torch.softmax(sc, dim=-1)
+    ref = torch.einsum("shqk,skhe->sqhe", pr, Vf).reshape(rows, d)
+    torch.cuda.synchronize()
+    got = ctx.float()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 4e-2      # bf16 probabilities and bf16 output
+    assert (got - ref).abs().mean().item() < 3e-3

@@ -330,3 +330,28 @@ def test_bench_under_torchrun_with_rccl():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_teacher_forced_fast_path_bf16(golden):
+    """The teacher-forced forward on the decode path's kernels (engine._decode_full_fast: store GEMMs, fused dense +
+    LayerNorm, one-wave-per-(sequence, head) attention): hidden states against the fp32 reference at the bf16 bars,
+    and against the unfused sequence of the same mode; the fused scoring (no logits in memory) against the reference's
+    own word accuracy / perplexity inputs."""
+    opt, P, feats, ids = golden.build()
+    z = golden.z
+    model = _model(opt, P, "bf16")
+    eng = model.engine()
+    if not eng.tf_fast_ok(ids.shape[1], False):
+        pytest.skip("fast teacher-forced path: bf16, d_model = 512")
+    batch = {"feats": _dev(feats), "input_ids": ids.to("cuda:0")}
+    fast = model.feedforward_step(batch, output_auxiliary=False)
+    assert "attention_probs" not in fast
+    slow = model.feedforward_step(batch)          # with the auxiliary dict: the unfused sequence
+    n = z["tf_hidden_states"].shape[0]
+    err = (fast["hidden_states"][:n].float().cpu() - torch.from_numpy(z["tf_hidden_states"])).abs()
+    assert err.max().item() < BF16_MAX and err.mean().item() < BF16_MEAN, (err.max().item(), err.mean().item())
+    d2 = (fast["hidden_states"].float() - slow["hidden_states"].float()).abs()
+    assert d2.max().item() < BF16_MAX and d2.mean().item() < BF16_MEAN
+    lse = _maxdiff(torch.logsumexp(fast["logits"], -1), z["tf_logits_lse"])
+    assert lse < (BF16_LSE_PEAKED if "peaked" in golden.name else 2 * BF16_LSE), lse
+    _record(golden.name + "#tf_fast", hid_max=err.max().item(), hid_mean=err.mean().item())
