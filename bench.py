@@ -117,7 +117,10 @@ def extra_legs(dev, main_dtype):
         model.load_state_dict(P, strict=True)
         model.set_compute_dtype(dtype)
         model.to(dev)
+        eng_model[0] = model
         return opt, model.engine()
+
+    eng_model = [None]
 
     def feats_for(opt, B, seed=2000):
         gen = torch.Generator(device=dev)
@@ -190,6 +193,88 @@ def extra_legs(dev, main_dtype):
                                               speedup_vs_fixed_29=round(runs["fixed_29_steps"] / runs["early_exit"], 2),
                                               steps_run=st["steps"], compactions=st["compactions"], row_steps=st["row_steps"],
                                               row_steps_fixed=4096 * 5 * eng.T)
+    # ---- teacher-forced forward (models/Framework.py:215-237; the eval metrics step of Wrapper.py:182-184), B = 4096:
+    # encode + the decoder over all 29 positions + fused scoring (word accuracy / perplexity inputs; the [B*29, V]
+    # logits never exist), and the same through the module API with the fp32 logits materialised (5 GB)
+    opt, eng = build("msrvtt_base_ami", main_dtype)
+    Btf = 4096
+    feats = feats_for(opt, Btf)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    ids = torch.randint(4, opt["vocab_size"], (Btf, eng.T), generator=gen, device=dev)
+    ids[:, 0] = 1
+    labels = torch.randint(4, opt["vocab_size"], (Btf, eng.T), generator=gen, device=dev)
+
+    def tf_score():
+        eng._begin_pass()
+        enc = eng.encode(feats)
+        return eng.score_teacher_forced(ids, labels, enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
+                                        sem_embs=enc.get("semantic_embs"))
+
+    for _ in range(3):
+        tf_score()
+    dt = _timed(tf_score, 10)
+    d_, ff_, V_, Lk_, T_ = eng.d, eng.ff, eng.V, eng.Lk, eng.T
+    fl = (sum(2 * eng.rows_of[ch] * d_ * opt["dim_" + ch] for ch in eng.modality) + 4 * Lk_ * d_ * d_ +
+          sum(2 * d_ * d_ * 6 + 4 * d_ * ff_ + 2 * d_ * V_ + 4 * Lk_ * d_ + 4 * t * d_ for t in range(1, T_ + 1)))
+    _lib_mod = __import__("care_amd")._lib
+    _lib_mod.TIMING = {}
+    tf_score()
+    torch.cuda.synchronize()
+    timing, _lib_mod.TIMING = _lib_mod.TIMING, None
+    tfk = {t: round(sum(s.elapsed_time(e) for s, e in ev), 3) for t, ev in timing.items()}
+    legs["feedforward_step"] = dict(config="msrvtt_base_ami", dtype=main_dtype, clips_per_step=Btf, positions=T_,
+                                    what="encode + teacher-forced decoder over all positions + fused scoring (no logits in memory)",
+                                    clips_per_s=round(Btf / dt, 1), ms_per_pass=round(dt * 1e3, 3),
+                                    gflop_per_clip=round(fl / 1e9, 4), tflops=round(fl * Btf / dt / 1e12, 1),
+                                    frac_of_bf16_mfma_peak=round(fl * Btf / dt / 1e12 / MFMA_PEAK_TF["bf16"], 4),
+                                    fast_path=bool(eng.tf_fast_ok(T_, False)),
+                                    kernel_ms=dict(sorted(tfk.items(), key=lambda kv: -kv[1])))
+    model_tf = eng_model[0]
+    batch = {"feats": feats, "input_ids": ids}
+    api = lambda: model_tf.feedforward_step(batch, output_auxiliary=False)
+    for _ in range(2):
+        api()
+    dt_api = _timed(api, 5)
+    legs["feedforward_step"]["module_api_with_fp32_logits"] = dict(
+        ms_per_pass=round(dt_api * 1e3, 3), clips_per_s=round(Btf / dt_api, 1), tflops=round(fl * Btf / dt_api / 1e12, 1),
+        logits_bytes=Btf * T_ * V_ * 4)
+    del model_tf, batch, api
+
+    # ---- host-fed: the reference moves `feats` host -> device per batch (translate.py:34-38); here pinned host batches
+    # (what DataLoader(pin_memory=True) yields) through FeaturePrefetcher - H2D on a side stream, overlapped with the
+    # previous batch's decode.  fp32 features, and bf16 ones a loader rounded on the host (bit-identical products for a
+    # model without a concept head: its embedder multiplies bf16-rounded features anyway).
+    from care_amd.data import FeaturePrefetcher
+
+    for Bh in (4096, 16384):
+        opt, eng = build("msrvtt_base_ami", main_dtype)
+        shapes = feat_shapes(opt, Bh)
+        for name, hdt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            host = [[torch.randn(sh, device=dev).to(hdt).cpu().pin_memory() for sh in shapes] for _ in range(2)]
+            nb = 8 if Bh <= 4096 else 5
+            def run_host():
+                for f in FeaturePrefetcher((host[i % 2] for i in range(nb)), dev):
+                    eng.translate_greedy(f, use_graph=True, lean=True)
+            run_host()
+            run_host()
+            dt = _timed(run_host, 2) / nb
+            nbytes = sum(t.numel() * t.element_size() for t in host[0])
+            res = feats_for(opt, Bh)
+            if hdt == torch.bfloat16:
+                res = [t.to(hdt) for t in res]
+            runr = lambda: eng.translate_greedy(res, use_graph=True, lean=True)
+            for _ in range(3):
+                runr()
+            dtr = _timed(runr, 5)
+            legs["host_fed_B%d_%s" % (Bh, name)] = dict(
+                config="msrvtt_base_ami", dtype=main_dtype, clips_per_step=Bh, feature_transport=name,
+                captions_per_s=round(Bh / dt, 1), ms_per_batch=round(dt * 1e3, 3), h2d_bytes_per_batch=nbytes,
+                pcie_GBps_achieved=round(nbytes / dt / 1e9, 1), hbm_resident_captions_per_s=round(Bh / dtr, 1),
+                bound="PCIe H2D" if nbytes / dt / 1e9 > 35 and dt > 1.1 * dtr else "decode",
+                sample="%d batches from 2 pinned host buffers, double-buffered device slots" % nb)
+            del host, res
+
     # the error of the throughput mode: teacher-forced hidden states, bf16 mode against fp32 mode of this
     # same engine (fp32 mode is within 1e-5 of the reference, tests/test_gpu_parity.py) on the benchmarked model
     if main_dtype == "bf16":
@@ -325,6 +410,43 @@ def main():
     # trace, profiles/).  The back-to-back re-launch (same arguments, 50x between two events) is
     # reported beside it; it is faster because consecutive launches re-read a warm L2/MALL.
     dom_b2b_us = _lib.relaunch_avg_us(dom, 50)
+
+    # The same kernel INSIDE the timed configuration (hipGraph replay): its launches are bracketed by one-thread
+    # timestamp kernels (device wall clock, 100 MHz) in a freshly captured copy of the pass - HIP events do not record
+    # in a replayed graph.  A bracket also spans two kernel boundaries; their cost is measured the same way around an
+    # empty bracket and reported beside the raw figure.
+    def stamped_us(tag, cap=64):
+        buf = torch.zeros(2 * cap + 64, dtype=torch.int64, device=dev)
+        eng._graphs.clear()
+        _lib.STAMP = dict(tag=tag, buf=buf, n=0)
+        try:
+            step()                      # eager: keys seen
+            _lib.STAMP["n"] = 0
+            step()                      # captured (+ replayed)
+            n = _lib.STAMP["n"]
+            step()                      # replay: the stamps of this pass are read
+            torch.cuda.synchronize()
+        finally:
+            _lib.STAMP = None
+            eng._graphs.clear()
+        t = buf[: 2 * n].view(n, 2).cpu()
+        raw = float((t[:, 1] - t[:, 0]).double().mean()) / 100.0   # 100 MHz ticks -> us
+        # empty brackets in a small graph: stamp, stamp
+        lib, base = _lib.load(), buf.data_ptr() + 16 * cap
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            for i in range(16):
+                lib.care_timestamp(base + 16 * i, _lib.stream_ptr())
+                lib.care_timestamp(base + 16 * i + 8, _lib.stream_ptr())
+        g.replay()
+        torch.cuda.synchronize()
+        e = buf[2 * cap: 2 * cap + 32].view(16, 2).cpu()
+        return raw, float((e[:, 1] - e[:, 0]).double().mean()) / 100.0, n
+
+    graph_us = graph_ovh = None
+    if not args.no_graph and args.lanes == 1:
+        graph_us, graph_ovh, _n = stamped_us(dom)
     dur_s = kernels[dom]["avg_us"] * 1e-6
     if km["bound"] == "hbm":
         achieved, peak, unit = km["bytes"] / dur_s / 1e9, HBM_PEAK_GBS, "GB/s"
@@ -341,6 +463,14 @@ def main():
     roofline = dict(kernel=dom, bound=km["bound"], achieved=round(achieved, 2), peak=peak, unit=unit,
                     frac=round(achieved / peak, 4), traffic=traffic,
                     avg_launch_us=round(kernels[dom]["avg_us"], 2), avg_launch_us_back_to_back=round(dom_b2b_us, 2),
+                    avg_launch_us_in_graph_replay=None if graph_us is None else round(graph_us - graph_ovh, 2),
+                    in_graph_bracket_raw_us=None if graph_us is None else round(graph_us, 2),
+                    in_graph_bracket_overhead_us=None if graph_ovh is None else round(graph_ovh, 2),
+                    frac_in_graph_replay=None if graph_us is None else round(
+                        (km["bytes"] / 1e9 if km["bound"] == "hbm" else km["flops"] / 1e12) / ((graph_us - graph_ovh) * 1e-6) / peak, 4),
+                    duration_sources="avg_launch_us: HIP events around every launch of an eager pass (agrees with "
+                                     "rocprofv3's trace of an eager run); avg_launch_us_in_graph_replay: device "
+                                     "timestamps inside the replayed hipGraph = the timed configuration",
                     launches=kernels[dom]["launches"],
                     algorithmic_bytes_per_launch=int(km["bytes"]), algorithmic_flops_per_launch=int(km["flops"]))
     per_kernel = {}

@@ -33,6 +33,8 @@ SIGNATURES = {
     "care_gemm_tile_split3": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     "care_gemm_tile_argmax": [_P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "care_score_partials": [_P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "care_label_logits": [_P, _L, _P, _P, _P, _I, _I, _I, _P],
+    "care_score_partials_lab": [_P, _P, _P, _I, _P, _P, _P, _I, _P],
     "care_score_logits": [_P, _L, _I, _P, _P, _P, _I, _P],
     "care_greedy_update": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "care_greedy_update_embed": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _F,
@@ -62,6 +64,7 @@ SIGNATURES = {
     "care_beam_pick": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _L, _I, _P, _I, _I, _P, _P, _I, _P],
     "care_beam_select": [_P, _L, _I, _I, _P, _P, _I, _P],
     "care_attention_probs": [_P, _L, _P, _I, _L, _L, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P],
+    "care_timestamp": [_P, _P],
     "care_active_slots": [_P, _I, _P, _P, _P],
     "care_gather_rows": [_P, _L, _P, _L, _P, _I, _L, _P],
     "care_scatter_rows": [_P, _L, _P, _L, _P, _I, _L, _P],
@@ -121,13 +124,24 @@ def stream_ptr():
 # launch stream (torch's current stream): TIMING[tag] = [(start_event, end_event), ...].
 # bench.py uses it to measure per-kernel durations live; it is None in normal operation.
 TIMING = None
+# When set to {"tag": name, "buf": int64 device tensor [2 * cap], "n": 0}, every launch tagged `name` is bracketed by
+# two care_timestamp kernels (device wall clock, 100 MHz) - also under hipGraph capture, where events cannot be
+# used: slot 2 i / 2 i + 1 = before / after the i-th such launch of a pass.  bench.py only.
+STAMP = None
 LAST_CALL = {}  # tag -> (function name, args): lets bench.py re-launch one kernel back to back
 
 
 def call(name: str, *args, tag: str = None):
     """Invoke an ABI function on torch's current stream; raise on any non-zero status."""
     fn = getattr(load(), name)
-    if TIMING is not None and tag is not None:
+    if STAMP is not None and tag == STAMP["tag"] and 2 * STAMP["n"] + 2 <= STAMP["buf"].numel():
+        base, i = STAMP["buf"].data_ptr(), STAMP["n"]
+        STAMP["n"] = i + 1
+        lib = load()
+        lib.care_timestamp(base + 16 * i, stream_ptr())
+        rc = fn(*args, stream_ptr())
+        lib.care_timestamp(base + 16 * i + 8, stream_ptr())
+    elif TIMING is not None and tag is not None:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
         rc = fn(*args, stream_ptr())

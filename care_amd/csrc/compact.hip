@@ -132,3 +132,17 @@ extern "C" int care_scatter_rows(const void* src, int64_t src_stride_bytes, void
                                  const int32_t* idx, int n, int64_t row_bytes, void* stream) {
   return move_rows<true>(src, src_stride_bytes, dst, dst_stride_bytes, idx, n, row_bytes, (hipStream_t)stream);
 }
+
+// care_timestamp: the device's constant-rate wall clock (s_memrealtime, 100 MHz) written by a one-thread kernel -
+// bench.py brackets the launches of one kernel INSIDE a captured hipGraph with these (HIP events do not record
+// inside a replayed graph), so the roofline line carries the kernel's duration in the timed configuration.
+__global__ void timestamp_kernel(unsigned long long* out) {
+  if (threadIdx.x == 0) *out = wall_clock64();
+}
+
+extern "C" int care_timestamp(void* out, void* stream) {
+  if (!out) return CARE_EINVAL;
+  hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(out));
+  return care_launch_status();
+}
+

@@ -280,9 +280,11 @@ __global__ __launch_bounds__(256) void greedy_update_embed_kernel(
 
 // teacher-forced scoring from the fused vocabulary partials: per row the arg-max column and the
 // log-probability of the label column, log_softmax(x)[label] = x[label] - max - log(sum exp(x - max))
+// lab_parts: column groups of plab per row (== parts: the fused label logits of care_gemm_argmax_bf16; 1: the logit of
+// the label column computed on its own by care_label_logits)
 __global__ __launch_bounds__(256) void score_partials_kernel(const float* pmax, const int32_t* pidx, const float* psum,
                                                              const float* plab, int parts, float* logp, int32_t* pred,
-                                                             int rows) {
+                                                             int rows, int lab_parts) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256) void score_partials_kernel(const float* pmax, 
     const float v = pmax[(int64_t)r * parts + c];
     const int id = pidx[(int64_t)r * parts + c];
     if (v > best || (v == best && id < bi)) { best = v; bi = id; }
-    lv = fmaxf(lv, plab[(int64_t)r * parts + c]);
+    if (c < lab_parts) lv = fmaxf(lv, plab[(int64_t)r * lab_parts + c]);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -436,7 +438,44 @@ extern "C" int care_score_partials(const float* pmax, const int32_t* pidx, const
                                    int parts, float* logp, int32_t* pred, int rows, void* stream) {
   if (!pmax || !pidx || !psum || !plab || !logp || !pred || rows <= 0 || parts <= 0) return CARE_EINVAL;
   hipLaunchKernelGGL(score_partials_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, pmax, pidx, psum, plab, parts,
-                     logp, pred, rows);
+                     logp, pred, rows, parts);
+  return care_launch_status();
+}
+
+// logit of ONE column per row: out[r] = A[r, :] . W[col[r], :] (bf16 operands, fp32 accumulation) - one wave per row
+__global__ __launch_bounds__(256) void label_logits_kernel(const bf16_t* A, int64_t lda, const bf16_t* W, const int32_t* col,
+                                                           float* out, int rows, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int c = min(max(col[r], 0), N - 1);
+  const bf16_t* a = A + (int64_t)r * lda;
+  const bf16_t* w = W + (int64_t)c * K;
+  float s = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const bf16x8 av = *reinterpret_cast<const bf16x8*>(a + k);
+    const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = fmaf((float)av[j], (float)wv[j], s);
+  }
+  s = care_wave_sum(s);
+  if (lane == 0) out[r] = s;
+}
+
+extern "C" int care_label_logits(const void* A, int64_t lda, const void* W, const int32_t* col, float* out, int rows,
+                                 int N, int K, void* stream) {
+  if (!A || !W || !col || !out || rows <= 0 || N <= 0 || K <= 0) return CARE_EINVAL;
+  if (K % 8 != 0 || lda % 8 != 0 || !care_aligned16(A) || !care_aligned16(W)) return CARE_EALIGN;
+  hipLaunchKernelGGL(label_logits_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, reinterpret_cast<const bf16_t*>(A), lda,
+                     reinterpret_cast<const bf16_t*>(W), col, out, rows, N, K);
+  return care_launch_status();
+}
+
+extern "C" int care_score_partials_lab(const float* pmax, const int32_t* pidx, const float* psum, int parts,
+                                       const float* lab_logit, float* logp, int32_t* pred, int rows, void* stream) {
+  if (!pmax || !pidx || !psum || !lab_logit || !logp || !pred || rows <= 0 || parts <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(score_partials_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, pmax, pidx, psum, lab_logit, parts,
+                     logp, pred, rows, 1);
   return care_launch_status();
 }
 

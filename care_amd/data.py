@@ -89,14 +89,17 @@ class FeaturePrefetcher:
         while len(self.slots) <= i:
             self.slots.append(None)
         slot = self.slots[i]
-        if slot is None or any(a.shape != b.shape for a, (b, _) in zip(like, slot["bufs"])):
+        if slot is None or any(a.shape != d.shape or a.dtype != d.dtype or (p is None) != a.is_pinned()
+                               for a, (p, d) in zip(like, slot["bufs"])):
             if slot is not None:  # both users of the old buffers must be done before they are dropped
                 for ev in (slot["staged"], slot["consumed"]):
                     if ev is not None:
                         ev.synchronize()
-            slot = {"bufs": [(torch.empty(t.shape, dtype=torch.float32).pin_memory(),
-                              torch.empty(t.shape, dtype=torch.float32, device=self.device)) for t in like],
-                    "staged": None, "consumed": None}
+            # dtype follows the batch: fp32 features, or bf16 ones a loader rounded for a model whose embedder
+            # multiplies bf16 operands anyway (engine.feats_dtype_ok: half the bytes over PCIe, the same products)
+            slot = {"bufs": [(None if t.is_pinned() else torch.empty(t.shape, dtype=t.dtype).pin_memory(),
+                              torch.empty(t.shape, dtype=t.dtype, device=self.device)) for t in like],
+                    "staged": None, "consumed": None, "src": None}
             self.slots[i] = slot
         return slot
 
@@ -107,8 +110,12 @@ class FeaturePrefetcher:
             if slot["consumed"] is not None:
                 self.stream.wait_event(slot["consumed"])  # the consumer's reads of the device tensors
             for src, (pin, dev) in zip(batch, slot["bufs"]):
-                pin.copy_(src)
-                dev.copy_(pin, non_blocking=True)
+                if pin is None:     # the loader already pins (DataLoader(pin_memory=True)): no second host copy
+                    dev.copy_(src, non_blocking=True)
+                else:
+                    pin.copy_(src)
+                    dev.copy_(pin, non_blocking=True)
+            slot["src"] = list(batch)  # pinned sources stay alive until their copy has been waited for
             slot["staged"] = torch.cuda.Event()
             slot["staged"].record(self.stream)
 

@@ -536,6 +536,22 @@ class HipEngine:
         return (self.as_ok and self.d == 512 and not self.has_concepts and self.opt["encoder"] == "Embedder" and
                 all(ch in self.dec_mod and int(self.opt["dim_" + ch]) % 32 == 0 for ch in self.modality))
 
+    @property
+    def feats_bf16_ok(self) -> bool:
+        """bf16 feature tensors are taken as they are (no widening copy): the fused embedder of a model without a
+        concept head multiplies bf16-rounded features anyway, so features a loader rounded on the host (the same
+        round-to-nearest-even) give bit-identical products at half the PCIe / HBM bytes."""
+        return (self.as_ok and self.d == 512 and not self.has_concepts and self.opt["encoder"] == "Embedder" and
+                all(int(self.opt["dim_" + ch]) % 128 == 0 for ch in self.modality))
+
+    def _prep_one(self, f):
+        if f.dtype == torch.bfloat16 and self.feats_bf16_ok:
+            return f.to(self.device).contiguous()
+        return f.to(self.device, torch.float32).contiguous()
+
+    def _prep_feats(self, feats):
+        return [self._prep_one(f) for f in feats[: len(self.modality)]]
+
     def encode(self, feats: List[torch.Tensor], lean: bool = False, static: bool = False) -> Dict[str, torch.Tensor]:
         """`Seq2SeqBase.encoding_phase` (models/Framework.py:150-187); outputs are fresh tensors.
         lean (translate path only, see lean_ok): returns just {"encoder_hidden_states": bf16 memory}.
@@ -552,7 +568,7 @@ class HipEngine:
         memb = new("memb", (B, self.Lk, d), torch.bfloat16) if self.bf_act else None
         means = None if lean else new("means", (B, len(self.modality) * d))
         for mi, ch in enumerate(self.modality):
-            x = feats[mi].to(self.device, torch.float32).contiguous()
+            x = self._prep_one(feats[mi])
             n = x.shape[1]
             if n != self.rows_of[ch]:
                 raise ValueError("modality `{}`: {} rows, expected {}".format(ch, n, self.rows_of[ch]))
@@ -893,9 +909,14 @@ class HipEngine:
             xb = self._last_tf_bf16
             parts = self.vocab_parts(rows)
             pm, pi = self.ws("sc_pmax", (rows, parts)), self.ws("sc_pidx", (rows, parts), torch.int32)
-            ps, pl = self.ws("sc_psum", (rows, parts)), self.ws("sc_plab", (rows, parts))
-            self.vocab_argmax(None, xb, rows, pm, pi, ps, lab32, pl, tag="tf_vocab_score")
-            call("care_score_partials", ptr(pm), ptr(pi), ptr(ps), ptr(pl), parts, ptr(logp), ptr(pred), rows)
+            ps = self.ws("sc_psum", (rows, parts))
+            # the label logit as a dot product of its own (rows x d MACs): the statistics then come from the kernel
+            # without label bookkeeping - from 8192 rows the 256-row panels of csrc/gemm_vocab.hip
+            pl = self.ws("sc_lab", (rows,))
+            self.vocab_argmax(None, xb, rows, pm, pi, ps, tag="tf_vocab_score")
+            call("care_label_logits", ptr(xb), xb.stride(0), ptr(self.w["vocab"]), ptr(lab32), ptr(pl), rows, self.V, self.d,
+                 tag="tf_label_logits")
+            call("care_score_partials_lab", ptr(pm), ptr(pi), ptr(ps), parts, ptr(pl), ptr(logp), ptr(pred), rows)
         else:
             out = self.decode_full(input_ids, mem, sem, want_logits="all", sem_embs=sem_embs)
             lg = out["logits"].view(rows, self.V)
@@ -1037,7 +1058,7 @@ class HipEngine:
         columns, fp32 sums in another order (scores within 1e-4).  A segment is captured into a hipGraph the
         second time its (first step, row count, buffer set) comes up.  Results are per CLIP:
         fed int32 [B, T + 1] (column 0 = BOS), length int32 [B], score fp32 [B]."""
-        feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        feats = self._prep_feats(feats)
         B, T, d = feats[0].shape[0], self.T, self.d
         # small batches are launch-bound: a segment boundary (one host round trip + one more graph launch,
         # ~40 us) costs as much as several of their steps, so they check twice as rarely and never compact
@@ -1202,7 +1223,7 @@ class HipEngine:
         Returns (enc_outputs, fed, length, score) - static tensors when replayed.
         lean: the caller reads nothing of enc_outputs (the Translator): encode(..., lean=True).
         """
-        feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        feats = self._prep_feats(feats)
         self._begin_pass()
         lanes = self.lanes_for(feats[0].shape[0]) if use_graph else 1
         if lanes > 1:
@@ -1331,7 +1352,7 @@ class HipEngine:
         (memory, finished lists ...) and the bm rows of every surviving clip (tokens, scores, K/V cache,
         ancestor tables - whose entries are physical row numbers and are renumbered) move to the front of
         a second buffer set.  Results per CLIP: nfin [B], fscore / flen [B, need + bm], fhyp [B, need + bm, T + 1]."""
-        feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        feats = self._prep_feats(feats)
         B, T, d = feats[0].shape[0], self.T, self.d
         cap = need + bm
         S = max(1, self.segment_steps) * (1 if B * bm >= 2048 else 2)
@@ -1456,7 +1477,7 @@ class HipEngine:
                        early_exit: Optional[bool] = None):
         """encode + beam search of one batch, replayed from a hipGraph when the input buffers repeat
         (same policy as translate_greedy).  Returns (enc_outputs, nfin, fscore, flen, fhyp)."""
-        feats = [f.to(self.device, torch.float32).contiguous() for f in feats[: len(self.modality)]]
+        feats = self._prep_feats(feats)
         self._begin_pass()
         if self.early_exit if early_exit is None else early_exit:
             return self.beam_early_exit(feats, bm, need, lean, use_graph)

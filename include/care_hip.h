@@ -151,6 +151,13 @@ int care_gemm_tile_argmax(const void* A, int64_t lda, const void* W, float* pmax
 int care_score_partials(const float* pmax, const int32_t* pidx, const float* psum,
                         const float* plab, int parts, float* logp, int32_t* pred, int rows,
                         void* stream);
+/* The label logit on its own (so that the arg-max statistics can come from the fastest kernel, which keeps none):
+ *   care_label_logits: out[r] = A[r, :] . W[col[r], :], bf16 A [rows, lda] and W [N, K], fp32 accumulation;
+ *   care_score_partials_lab: care_score_partials with that one logit per row instead of per-group label partials. */
+int care_label_logits(const void* A, int64_t lda, const void* W, const int32_t* col, float* out, int rows, int N,
+                      int K, void* stream);
+int care_score_partials_lab(const float* pmax, const int32_t* pidx, const float* psum, int parts,
+                            const float* lab_logit, float* logp, int32_t* pred, int rows, void* stream);
 int care_score_logits(const float* logits, int64_t ld, int V, const int32_t* labels, float* logp,
                       int32_t* pred, int rows, void* stream);
 
@@ -481,6 +488,10 @@ int care_scatter_rows(const void* src, int64_t src_stride_bytes, void* dst, int6
  *     the rows of clip c have moved to clip cmap[c]. */
 int care_expand_index(const int32_t* idx_c, int m, int bm, int32_t* idx_r, void* stream);
 int care_remap_rows(int32_t* anc, int64_t n, const int32_t* cmap, int bm, void* stream);
+
+/* care_timestamp: out[0] (uint64) = the device wall clock (constant 100 MHz) when the one-thread kernel runs.
+ *   Measurement only (bench.py: the duration of a kernel inside a replayed hipGraph); no reference counterpart. */
+int care_timestamp(void* out, void* stream);
 
 #ifdef __cplusplus
 }

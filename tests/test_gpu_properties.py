@@ -223,10 +223,23 @@ def test_lean_encode_gives_identical_captions(config, B):
 PEAKED_ROWS = {"cls_head.tgt_word_prj.weight": {**{r: 12.0 for r in range(6, 46)}, 3: 20.0}}  # gen_golden.PEAKED
 
 
-@pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 16384), ("msrvtt_care", 4096), ("msrvtt_base_ami", 12345)])
+def _audit_record(**kw):
+    import json
+    import os
+
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "audit.jsonl"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+
+
+@pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 32768), ("msrvtt_base_ami", 16384), ("msrvtt_care", 4096),
+                                      ("msrvtt_base_ami", 12345), ("vatex_care_large", 4096), ("care_median_gelu", 2048)])
 def test_benchmarked_operating_point_against_oracle_sample(config, B):
     """The code path bench.py times, end to end: bf16, lean encode, absorbed cross-attention, >= 10240
-    rows (fused dense+LayerNorm in 128-row blocks, the 8-range vocabulary split), hipGraph replay - on
+    rows (fused dense+LayerNorm in 128-row blocks, the 8-range vocabulary split), hipGraph replay - B = 32768 is
+    bench.py's default batch; `vatex_care_large` / `care_median_gelu` (d_model 1024 / 768) run the LDS-tiled bf16
+    GEMMs of csrc/gemm_tile.hip with projected K/V - on
     a model with peaked (trained-like) logits, audited against the CPU oracle on a 64-clip sample
     spread over the batch: a clip whose every reference step is decided by >= 0.1 must be bit-exact,
     any other divergence must start at a near-tie; replay == eager bit for bit.  B = 12345: ragged last
@@ -237,7 +250,10 @@ def test_benchmarked_operating_point_against_oracle_sample(config, B):
     opt, P, model, feats = _setup(config, B, "bf16", seed=189, boost=PEAKED_ROWS)
     eng = model.engine()
     eng.LATENT_MIN_ROWS = type(eng).LATENT_MIN_ROWS  # the engine's own switch points, as in bench.py
-    assert eng.latent_for(B) and eng.ln_fusable(B) == (B >= 10240)
+    if eng.d == 512:
+        assert eng.latent_for(B) and eng.ln_fusable(B) == (B >= 10240)
+    else:
+        assert eng.bf_act and not eng.as_ok and not eng.latent_for(B)
     runs = []
     for it in range(4):  # eager, first sight (eager), capture, replay
         _, fed, length, score = eng.translate_greedy(feats, use_graph=it > 0, lean=True)
@@ -268,8 +284,11 @@ def test_benchmarked_operating_point_against_oracle_sample(config, B):
             # peaked rows scale the logit noise with them (measured logsumexp error up to 2.6e-2 on the
             # peaked fixtures): a step decided by less than 5e-2 may flip, one decided by >= 0.1 may not
             _audit_greedy(P, opt, {k: v[j:j + 1] for k, v in inputs.items()}, h, r, 5e-2)
-    print("operating point {} B={}: {}/64 sampled captions bit-exact, {} with clear margins".format(config, B, exact, clear))
-    assert exact >= 48 and len(set(length[idx].tolist())) > 3
+    _audit_record(test="greedy_operating_point", config=config, B=B, sampled=64, exact=exact, clear=clear)
+    # measured on the MI355X: 64/64 at every operating point; a clear-margin clip that differs fails above, so what
+    # the count adds is a cap on near-tie flips
+    assert exact >= clear and exact >= 62, "operating point {} B={}: {}/64 sampled captions bit-exact, {} with clear margins".format(config, B, exact, clear)
+    assert len(set(length[idx].tolist())) > 3
 
 
 def test_benchmarked_beam_operating_point_against_oracle_sample():
@@ -313,8 +332,8 @@ def test_benchmarked_beam_operating_point_against_oracle_sample():
         else:
             assert (abs(exact_h - scores[j][0]) < BEAM_TIE_TOL or gaps[j]["best_slack"] < BEAM_TIE_TOL or
                     gaps[j]["rank"] < BEAM_TIE_TOL), (i, h, r)
-    print("beam operating point: {}/24 winners bit-exact, {} with clear margins".format(exact, clear_n))
-    assert exact >= 18
+    _audit_record(test="beam_operating_point", config="msrvtt_care_beam5", B=B, sampled=24, exact=exact, clear=clear_n)
+    assert exact >= clear_n and exact >= 21, "beam operating point: {}/24 winners bit-exact, {} with clear margins".format(exact, clear_n)
 
 
 @pytest.mark.parametrize("config,dtype,B", [("msrvtt_care_beam5", "bf16", 512), ("msrvtt_care_beam5", "fp32", 96),
