@@ -348,23 +348,46 @@ extern "C" int care_split2_act(const float* A, int64_t lda, void* A2, int M, int
   return care_launch_status();
 }
 
-// C = A W^T + bias with fp32-GRADE products on the LDS-tiled kernel: A2 = care_split2_act(A) [M, 2K] (hi | lo),
+// C = act(A W^T + bias) with fp32-GRADE products on the LDS-tiled kernel: A2 = care_split2_act(A) [M, 2K] (hi | lo),
 // W3 = care_split3_weight(W) [N, 3K] (hi | lo | hi); one product over the virtual 3K columns
 // a_hi w_hi + a_hi w_lo + a_lo w_hi (the A columns start over after the first K: a_hi, a_hi again, then a_lo),
-// v_mfma_f32_16x16x32_f16.  The contract of care_gemm_split3 (csrc/gemm.hip) at about twice its rate.
-extern "C" int care_gemm_tile_split3(const void* A2, const void* W3, const float* bias, float* C, int64_t ldc, int M,
-                                     int N, int K, void* stream) {
+// v_mfma_f32_16x16x32_f16.  The contract of care_gemm_split3 (csrc/gemm.hip) at about twice its rate, with the
+// destinations / activation of care_gemm.
+static void split3_args(TArgs& p, const void* A2, const void* W3, int M, int N, int K) {
+  p.A = reinterpret_cast<const bf16_t*>(A2); p.lda = 2 * (int64_t)K; p.W = reinterpret_cast<const bf16_t*>(W3); p.ldw = 3 * (int64_t)K;
+  p.M = M; p.N = N; p.K = 3 * K; p.a_wrap = K >> 6; p.n_split = N;
+}
+
+extern "C" int care_gemm_tile_split3(const void* A2, const void* W3, const float* bias, void* C0, int64_t ldc0, int c0_dtype,
+                                     void* C1, int64_t ldc1, int c1_dtype, int n_split, int M, int N, int K, int act,
+                                     void* stream) {
   int rc = tile_check(A2, 2 * (int64_t)K, W3, M, N, K);
   if (rc) return rc;
-  if (!C) return CARE_EINVAL;
+  if (!C0 || n_split <= 0 || n_split > N || (n_split < N && !C1)) return CARE_EINVAL;
+  if (n_split % 16 != 0 && n_split != N) return CARE_ESHAPE;
+  if (act < CARE_ACT_NONE || act > CARE_ACT_GELU) return CARE_EDTYPE;
+  if ((c0_dtype != CARE_F32 && c0_dtype != CARE_BF16) || (C1 && c1_dtype != CARE_F32 && c1_dtype != CARE_BF16))
+    return CARE_EDTYPE;
   TArgs p{};
-  p.A = reinterpret_cast<const bf16_t*>(A2); p.lda = 2 * (int64_t)K; p.W = reinterpret_cast<const bf16_t*>(W3); p.ldw = 3 * (int64_t)K;
-  p.bias = bias; p.C0 = C; p.ldc0 = ldc; p.c0_bf16 = 0; p.C1 = nullptr; p.n_split = N; p.M = M; p.N = N; p.K = 3 * K;
-  p.act = CARE_ACT_NONE; p.a_wrap = K >> 6;
+  split3_args(p, A2, W3, M, N, K);
+  p.bias = bias; p.C0 = C0; p.ldc0 = ldc0; p.c0_bf16 = c0_dtype == CARE_BF16;
+  p.C1 = C1; p.ldc1 = ldc1; p.c1_bf16 = c1_dtype == CARE_BF16; p.n_split = n_split; p.act = act;
   hipStream_t st = (hipStream_t)stream;
   return pick_cfg(M, N) == 4412 ? launch_tile<4, 4, 1, 2, EPI_STORE, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_STORE, true>(p, st);
 }
 
+// the fused vocabulary arg-max (care_gemm_tile_argmax) on split products: fp32-grade logits, never written
+extern "C" int care_gemm_tile_split3_argmax(const void* A2, const void* W3, float* pmax, int32_t* pidx, float* psum, int M,
+                                            int N, int K, void* stream) {
+  int rc = tile_check(A2, 2 * (int64_t)K, W3, M, N, K);
+  if (rc) return rc;
+  if (!pmax || !pidx || !psum) return CARE_EINVAL;
+  TArgs p{};
+  split3_args(p, A2, W3, M, N, K);
+  p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.parts = care_argmax_parts_tile(N);
+  hipStream_t st = (hipStream_t)stream;
+  return pick_cfg(M, N) == 4412 ? launch_tile<4, 4, 1, 2, EPI_ARGMAX, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_ARGMAX, true>(p, st);
+}
 extern "C" int care_argmax_parts_tile(int N) { return N > 0 ? (N + 63) / 64 : CARE_EINVAL; }
 
 extern "C" int care_gemm_tile_argmax(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,

@@ -67,11 +67,18 @@ class _LaneOutputs(dict):
 
 class HipEngine:
     def __init__(self, opt: dict, dtype: str = "fp32"):
-        if dtype not in ("fp32", "bf16"):
-            raise ValueError("compute dtype must be 'fp32' or 'bf16', got {!r}".format(dtype))
+        if dtype not in ("fp32", "bf16", "fp16x3"):
+            raise ValueError("compute dtype must be 'fp32', 'bf16' or 'fp16x3', got {!r}".format(dtype))
         self.opt = opt
         self.dtype = dtype
         self.wt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        # 'fp16x3': fp32 storage everywhere (activations, K/V caches, weights' masters) like 'fp32', but every GEMM
+        # multiplies hi/lo fp16 pieces of both operands - a_hi w_hi + a_hi w_lo + a_lo w_hi, three fp16 MFMA passes,
+        # what is dropped is ~2^-22 of a product - on the LDS-tiled kernel instead of the exact-f32 MFMA (1/16 of
+        # the 16-bit rate): fp32-GRADE results (the reference's 1e-5 bars, token ids as in fp32 mode) at about
+        # twice fp32 mode's throughput.  The mode between bf16 (1.5e-2) and exact fp32.
+        self.split3 = dtype == "fp16x3"
+        self._w3: Dict[int, torch.Tensor] = {}
         self.d = int(opt["dim_hidden"])
         self.H = int(opt["num_attention_heads"])
         if self.d != self.H * 64:
@@ -218,6 +225,14 @@ class HipEngine:
                     W3 = torch.empty(W.shape[0], 3 * W.shape[1], device=self.device, dtype=torch.float16)
                     call("care_split3_weight", ptr(W), ptr(W3), W.shape[0], W.shape[1])
                     w["enc_w_" + ch + "#split3"] = W3
+        self._w3 = {}
+        if self.split3:
+            for name, W in w.items():
+                if (isinstance(W, torch.Tensor) and W.dim() == 2 and W.dtype == torch.float32 and W.shape[1] % 64 == 0 and
+                        "#" not in name and not name.startswith(("word", "pos", "attr_word", "attr_pos", "enc_pos_"))):
+                    W3 = torch.empty(W.shape[0], 3 * W.shape[1], device=self.device, dtype=torch.float16)
+                    call("care_split3_weight", ptr(W), ptr(W3), W.shape[0], W.shape[1])
+                    self._w3[W.data_ptr()] = W3
         self.w = w
         self._graphs.clear()
 
@@ -396,14 +411,20 @@ class HipEngine:
         else:
             if A.dtype != torch.float32:
                 raise ValueError("generic GEMM takes fp32 activations")
-            call("care_gemm", ptr(A), A.stride(0), ptr(W), _code(W), *tail, tag=tag)
+            W3 = self._w3.get(W.data_ptr()) if self.split3 else None
+            if W3 is not None and A.stride(0) % 4 == 0:
+                a2 = self.ws("split_a2", (M, 2 * K), torch.float16)
+                call("care_split2_act", ptr(A), A.stride(0), ptr(a2), M, K)
+                call("care_gemm_tile_split3", ptr(a2), ptr(W3), *tail, tag=tag)
+            else:
+                call("care_gemm", ptr(A), A.stride(0), ptr(W), _code(W), *tail, tag=tag)
         return out
 
     def vocab_parts(self, rows: int) -> int:
         """Column groups per row of the fused vocabulary arg-max for `rows` rows (the kernel vocab_argmax picks)."""
         if self.as_ok:
             return _lib.load().care_argmax_parts_bf16(rows, self.V)
-        if self.bf_act:
+        if self.bf_act or (self.split3 and self.w["vocab"].data_ptr() in self._w3):
             return _lib.load().care_argmax_parts_tile(self.V)
         return _lib.load().care_argmax_parts(self.V)
 
@@ -421,7 +442,13 @@ class HipEngine:
         else:
             if labels is not None:
                 raise ValueError("label logits come from the bf16 kernels only (fp32 mode scores materialised logits)")
-            call("care_gemm_argmax", ptr(x), d, ptr(W), _code(W), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
+            W3 = self._w3.get(W.data_ptr()) if self.split3 else None
+            if W3 is not None:
+                a2 = self.ws("split_a2v", (rows, 2 * d), torch.float16)
+                call("care_split2_act", ptr(x), x.stride(0), ptr(a2), rows, d)
+                call("care_gemm_tile_split3_argmax", ptr(a2), ptr(W3), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
+            else:
+                call("care_gemm_argmax", ptr(x), d, ptr(W), _code(W), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
 
     def add_ln(self, x, res, g, be, out, outb=None, grp=None, out_grp_rows=None, out_row_off=0, pos=None, nslab=1, tag=None):
         """out = LN(sum of the nslab slabs of x + res); x is [rows, d] or [nslab, rows, d]."""
@@ -584,8 +611,8 @@ class HipEngine:
                 if os.environ.get("CARE_ENC_TILE", "1") != "0":  # fp16 pieces of the features once, then the LDS-tiled kernel
                     a2 = self.ws("enc_a2", (B * n, 2 * x2.shape[1]), torch.float16)
                     call("care_split2_act", ptr(x2), x2.stride(0), ptr(a2), B * n, x2.shape[1], tag="enc_split")
-                    call("care_gemm_tile_split3", ptr(a2), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
-                         B * n, d, x2.shape[1], tag="enc_gemm")
+                    call("care_gemm_tile_split3", ptr(a2), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0), CARE_F32,
+                         None, 0, 0, d, B * n, d, x2.shape[1], 0, tag="enc_gemm")
                 else:
                     call("care_gemm_split3", ptr(x2), x2.stride(0), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
                          B * n, d, x2.shape[1], tag="enc_gemm")

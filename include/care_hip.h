@@ -126,10 +126,15 @@ int care_gemm_argmax_bf16(const void* A, int64_t lda, int a_dtype, const void* W
 /* care_split2_act / care_gemm_tile_split3: the contract of care_gemm_split3 (fp32 A, fp32-GRADE products
  *   a_hi w_hi + a_hi w_lo + a_lo w_hi in fp16 pieces: the feature embedder of concept models, models/Encoder.py:167)
  *   on the LDS-tiled kernel: A2 = care_split2_act(A) fp16 [M, 2K] (hi | lo), W3 = care_split3_weight(W) [N, 3K];
- *   C fp32 [M, ldc].  K % 64 == 0, |A| < 65504. */
+ *   destinations, split and activation as care_gemm.  K % 64 == 0, |A| < 65504. */
 int care_split2_act(const float* A, int64_t lda, void* A2, int M, int K, void* stream);
-int care_gemm_tile_split3(const void* A2, const void* W3, const float* bias, float* C, int64_t ldc, int M, int N,
-                          int K, void* stream);
+int care_gemm_tile_split3(const void* A2, const void* W3, const float* bias, void* C0, int64_t ldc0, int c0_dtype,
+                          void* C1, int64_t ldc1, int c1_dtype, int n_split, int M, int N, int K, int act,
+                          void* stream);
+/* ... and the fused vocabulary arg-max (care_gemm_tile_argmax's partials) on the same split products: the `fp16x3`
+ *   compute mode (fp32 storage, every GEMM as three fp16 MFMA passes) of care_amd/engine.py. */
+int care_gemm_tile_split3_argmax(const void* A2, const void* W3, float* pmax, int32_t* pidx, float* psum, int M,
+                                 int N, int K, void* stream);
 int care_gemm_tile(const void* A, int64_t lda, const void* W, const float* bias, void* C0, int64_t ldc0,
                    int c0_dtype, void* C1, int64_t ldc1, int c1_dtype, int n_split, int M, int N, int K,
                    int act, void* stream);

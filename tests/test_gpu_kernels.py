@@ -820,7 +820,7 @@ def test_gemm_tile_split3(M, N, K):
     A2 = torch.empty(M, 2 * K, device=DEV, dtype=torch.float16)
     _call("care_split2_act", _p(A), K, _p(A2), M, K)
     out = torch.full((M, N), float("nan"), device=DEV)
-    _call("care_gemm_tile_split3", _p(A2), _p(W3), _p(bias), _p(out), N, M, N, K)
+    _call("care_gemm_tile_split3", _p(A2), _p(W3), _p(bias), _p(out), N, 0, None, 0, 0, N, M, N, K, 0)
     old = torch.full((M, N), float("nan"), device=DEV)
     _call("care_gemm_split3", _p(A), K, _p(W3), _p(bias), _p(old), N, M, N, K)
     ref = A.double() @ W.double().t() + bias.double()
