@@ -5,7 +5,7 @@ product path raises.  Nothing here imports `oracle/`.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 import torch
 
@@ -20,7 +20,7 @@ _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignm
 LIB_PATH = os.environ.get("CARE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcare_hip.so")
 
 # name -> argtypes, in the exact order of include/care_hip.h
-_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+_P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
 SIGNATURES = {
     "care_gemm": [_P, _L, _P, _I, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_split3_weight": [_P, _P, _I, _I, _P],
@@ -66,6 +66,16 @@ SIGNATURES = {
     "care_beam_select": [_P, _L, _I, _I, _P, _P, _I, _P],
     "care_attention_probs": [_P, _L, _P, _I, _L, _L, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     "care_timestamp": [_P, _P],
+    "care_ln_bwd": [_P, _L, _P, _L, _P, _P, _L, _F, _P, _L, _P, _P, _I, _I, _P],
+    "care_act": [_P, _P, _P, _L, _I, _P],
+    "care_dropout": [_P, _P, _L, _F, _U, _P],
+    "care_strided_sum": [_P, _L, _P, _L, _I, _I, _I, _L, _L, _F, _P],
+    "care_bcast_rows": [_P, _L, _P, _L, _I, _I, _I, _F, _P],
+    "care_add_pos_sem": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "care_scatter_add_rows": [_P, _L, _P, _P, _L, _I, _I, _I, _P],
+    "care_concept_bwd": [_P, _L, _P, _L, _P, _P, _L, _I, _I, _P],
+    "care_attn_pv": [_P, _P, _L, _L, _P, _L, _I, _I, _I, _I, _F, _U, _P],
+    "care_attn_bwd": [_P, _L, _P, _P, _L, _L, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _F, _U, _P],
     "care_active_slots": [_P, _I, _P, _P, _P],
     "care_gather_rows": [_P, _L, _P, _L, _P, _I, _L, _P],
     "care_scatter_rows": [_P, _L, _P, _L, _P, _I, _L, _P],

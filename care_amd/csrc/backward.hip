@@ -1,0 +1,349 @@
+// backward.hip - the kernels the TRAINING-mode forward / backward needs beside the forward path's own
+// (care_amd/training.py: torch.autograd.Functions over this ABI; models/Wrapper.py:423-435 -> Framework.py:215-237
+// under autograd in the reference).  fp32 throughout; the matrix products of a backward pass re-use care_gemm on
+// transposed operands, what is here is everything that is not a GEMM: LayerNorm / activation / softmax-attention /
+// concept-head backward, dropout, the scatter-add of embedding gradients and the reductions of broadcasts.
+// These are correctness-first row kernels (one wave per row or per (sequence, head)); training throughput is not the
+// benchmarked path.
+#include "care_common.h"
+
+namespace {
+
+#define BST ((hipStream_t)stream)
+
+// ------------------------------------------------------------------ LayerNorm backward
+// s = x (+ res); y = (s - mean) * rstd * gamma + beta.  ds = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
+// dgamma += dy * xhat, dbeta += dy (atomics into zero-initialised [d] buffers).  One wave per row, d <= 2048.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, int64_t ldx, const float* res, int64_t ldres,
+                                                     const float* gamma, const float* dy, int64_t lddy, float eps, float* ds,
+                                                     int64_t ldds, float* dgamma, float* dbeta, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  constexpr int MAXC = 32;  // columns per lane: d <= 2048
+  float s[MAXC], g[MAXC];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    s[i] = 0.f;
+    if (c < d) {
+      s[i] = x[(int64_t)r * ldx + c] + (res ? res[(int64_t)r * ldres + c] : 0.f);
+      sum += s[i];
+    }
+  }
+  const float mean = care_wave_sum(sum) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < d) { const float a = s[i] - mean; q += a * a; }
+  const float rstd = 1.0f / sqrtf(care_wave_sum(q) / (float)d + eps);
+  float mg = 0.f, mgx = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    g[i] = 0.f;
+    if (c < d) {
+      const float xh = (s[i] - mean) * rstd;
+      const float dyv = dy[(int64_t)r * lddy + c];
+      g[i] = dyv * gamma[c];
+      mg += g[i];
+      mgx += g[i] * xh;
+      atomicAdd(dgamma + c, dyv * xh);
+      atomicAdd(dbeta + c, dyv);
+      s[i] = xh;
+    }
+  }
+  mg = care_wave_sum(mg) / (float)d;
+  mgx = care_wave_sum(mgx) / (float)d;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d) ds[(int64_t)r * ldds + c] = rstd * (g[i] - mg - s[i] * mgx);
+  }
+}
+
+// ------------------------------------------------------------------ activation, dropout
+__device__ __forceinline__ float b_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float b_gelu_grad(float v) {
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+// dy == nullptr: out = act(z); else out = dy * act'(z)
+__global__ void act_kernel(const float* z, const float* dy, float* out, int64_t n, int act) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = z[i];
+  if (!dy) out[i] = act == CARE_ACT_RELU ? fmaxf(v, 0.f) : (act == CARE_ACT_GELU ? b_gelu(v) : v);
+  else out[i] = dy[i] * (act == CARE_ACT_RELU ? (v > 0.f ? 1.f : 0.f) : (act == CARE_ACT_GELU ? b_gelu_grad(v) : 1.f));
+}
+
+// counter-based uniform in [0, 1): a 64-bit mix (splitmix64 finaliser) of (seed, element index) - stateless, so the
+// backward pass re-creates the forward's mask from the same (seed, index)
+__device__ __forceinline__ float b_uniform(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// out = x * keep / (1 - p), keep = uniform(seed, i) >= p  (nn.Dropout in training mode; the same call is its backward)
+__global__ void dropout_kernel(const float* x, float* out, int64_t n, float p, unsigned long long seed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = b_uniform(seed, (unsigned long long)i) >= p ? x[i] * (1.0f / (1.0f - p)) : 0.f;
+}
+
+// ------------------------------------------------------------------ reductions of broadcasts, scatter-add
+// out[r][c] = scale * sum_{k < terms} x[(r * row_stride + k * term_stride)][c]
+__global__ void strided_sum_kernel(const float* x, int64_t ldx, float* out, int64_t ldo, int rows, int d, int terms,
+                                   int64_t row_stride, int64_t term_stride, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * d) return;
+  const int r = (int)(i / d), c = (int)(i % d);
+  float s = 0.f;
+  for (int k = 0; k < terms; ++k) s += x[((int64_t)r * row_stride + (int64_t)k * term_stride) * ldx + c];
+  out[(int64_t)r * ldo + c] = s * scale;
+}
+
+// dst[i][c] = scale * src[i / grp][c]  (backward of a mean / sum over groups of `grp` consecutive rows; also a broadcast add's forward operand)
+__global__ void bcast_rows_kernel(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int d, int grp, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * d) return;
+  const int r = (int)(i / d), c = (int)(i % d);
+  dst[(int64_t)r * ldd + c] = scale * src[(int64_t)(r / grp) * lds_ + c];
+}
+
+// out[r] = x[r] + pos[r % seq] + sem[r / sem_div]  (Embeddings.forward before its LayerNorm; pos / sem optional)
+__global__ void add_pos_sem_kernel(const float* x, const float* pos, const float* sem, float* out, int rows, int d, int seq,
+                                   int sem_div) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * d) return;
+  const int r = (int)(i / d), c = (int)(i % d);
+  float v = x[i];
+  if (pos) v += pos[(int64_t)(r % seq) * d + c];
+  if (sem) v += sem[(int64_t)(r / sem_div) * d + c];
+  out[i] = v;
+}
+
+// table[idx[i]][c] += src[i][c]  (embedding backward); rows with idx < 0 or == skip_idx are skipped (padding_idx)
+__global__ void scatter_add_rows_kernel(const float* src, int64_t lds_, const int32_t* idx, float* table, int64_t ldt, int rows,
+                                        int d, int skip_idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * d) return;
+  const int r = (int)(i / d), c = (int)(i % d);
+  const int t = idx[r];
+  if (t < 0 || t == skip_idx) return;
+  atomicAdd(table + (int64_t)t * ldt + c, src[(int64_t)r * lds_ + c]);
+}
+
+// ------------------------------------------------------------------ concept head backward
+// p = sigmoid(s); preds = 1 - exp(log(clamp(1 - p, 1e-12, 1))) (= p while 1 - p >= 1e-12), avg = mean_k p
+// (pred_attribute.py:17-46 at seq_len 1).  ds = (dpreds [1 - p >= 1e-12] + davg / k) * p (1 - p)
+__global__ void concept_bwd_kernel(const float* scores, int64_t lds_, const float* dpreds, int64_t ldp, const float* davg,
+                                   float* ds, int64_t ldo, int B, int k) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * k) return;
+  const int b = (int)(i / k), c = (int)(i % k);
+  const float p = 1.0f / (1.0f + expf(-scores[(int64_t)b * lds_ + c]));
+  float g = davg ? davg[b] / (float)k : 0.f;
+  if (dpreds && (1.0f - p) >= 1e-12f) g += dpreds[(int64_t)b * ldp + c];
+  ds[(int64_t)b * ldo + c] = g * p * (1.0f - p);
+}
+
+// ------------------------------------------------------------------ attention: P V and the backward of softmax(QK^T / 8 + ...) V
+struct AttnBArgs {
+  const float* Q; int64_t ldq;           // [nseq * seq, ldq], head h at columns 64 h
+  const float* K; const float* V; int64_t kv_bs, kv_rs;  // key j of sequence s at base + s * kv_bs + j * kv_rs + 64 h
+  const float* P;                        // probabilities AFTER softmax, BEFORE dropout: [nseq * seq, heads, nkeys]
+  const float* dctx; int64_t ldd;        // [nseq * seq, ldd]
+  float* ctx; int64_t ldc;               // forward output
+  float* dQ; int64_t lddq; float* dK; float* dV; int64_t dkv_bs, dkv_rs;
+  float* dbias; int bias_ld;             // [heads, bias_ld] (atomics) or null
+  int nseq, seq, nkeys, heads;
+  float p_drop; unsigned long long seed;
+};
+
+__device__ __forceinline__ float attn_keep(const AttnBArgs& a, int64_t pidx) {
+  if (a.p_drop <= 0.f) return 1.0f;
+  return b_uniform(a.seed, (unsigned long long)pidx) >= a.p_drop ? 1.0f / (1.0f - a.p_drop) : 0.f;
+}
+
+// ctx[s, i, 64 h + e] = sum_j keep(i, j) P[s, i, h, j] V[s, j, 64 h + e]: one wave per (sequence, head), lane = e
+__global__ __launch_bounds__(64) void attn_pv_kernel(AttnBArgs a) {
+  const int s = blockIdx.x / a.heads, h = blockIdx.x % a.heads, e = threadIdx.x;
+  const float* Vb = a.V + (int64_t)s * a.kv_bs + h * 64 + e;
+  for (int i = 0; i < a.seq; ++i) {
+    const int64_t prow = ((int64_t)(s * a.seq + i) * a.heads + h) * a.nkeys;
+    float acc = 0.f;
+    for (int j = 0; j < a.nkeys; ++j) {
+      const float pd = a.P[prow + j] * attn_keep(a, prow + j);
+      acc = fmaf(pd, Vb[(int64_t)j * a.kv_rs], acc);
+    }
+    a.ctx[(int64_t)(s * a.seq + i) * a.ldc + h * 64 + e] = acc;
+  }
+}
+
+// One wave per (sequence, head).  LDS: dS row [nkeys], dK / dV accumulators [nkeys][64].
+//   dPd[j] = dctx_i . V_j ; dP = dPd * keep ; dS = P (dP - sum_j dP P) ; dQ_i = dS K / 8 ; dK_j += dS_j Q_i / 8 ;
+//   dV_j += (P keep)_ij dctx_i ; dbias[h][j] += dS_j
+__global__ __launch_bounds__(64) void attn_bwd_kernel(AttnBArgs a) {
+  extern __shared__ float sh[];
+  float* sdS = sh;                    // [nkeys]
+  float* sPd = sh + 128;              // [nkeys]
+  float* sdc = sh + 256;              // [64] dctx row
+  float* sq = sh + 320;               // [64] Q row
+  float* sdK = sh + 384;              // [nkeys][64]
+  float* sdV = sdK + a.nkeys * 64;    // [nkeys][64]
+  const int s = blockIdx.x / a.heads, h = blockIdx.x % a.heads, lane = threadIdx.x;
+  const float* Kb = a.K + (int64_t)s * a.kv_bs + h * 64;
+  const float* Vb = a.V + (int64_t)s * a.kv_bs + h * 64;
+  for (int j = 0; j < a.nkeys; ++j) { sdK[j * 64 + lane] = 0.f; sdV[j * 64 + lane] = 0.f; }
+  __syncthreads();
+  for (int i = 0; i < a.seq; ++i) {
+    const int64_t row = (int64_t)s * a.seq + i;
+    const int64_t prow = (row * a.heads + h) * a.nkeys;
+    sdc[lane] = a.dctx[row * a.ldd + h * 64 + lane];
+    sq[lane] = a.Q[row * a.ldq + h * 64 + lane];
+    __syncthreads();
+    // lanes over keys
+    float dot = 0.f;
+    float dP[2], Pv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = lane + 64 * t;
+      dP[t] = 0.f; Pv[t] = 0.f;
+      if (j < a.nkeys) {
+        float acc = 0.f;
+        const float* vj = Vb + (int64_t)j * a.kv_rs;
+        for (int e = 0; e < 64; ++e) acc = fmaf(sdc[e], vj[e], acc);
+        const float keep = attn_keep(a, prow + j);
+        Pv[t] = a.P[prow + j];
+        dP[t] = acc * keep;
+        sPd[j] = Pv[t] * keep;
+        dot += dP[t] * Pv[t];
+      }
+    }
+    dot = care_wave_sum(dot);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = lane + 64 * t;
+      if (j < a.nkeys) {
+        const float dS = Pv[t] * (dP[t] - dot);
+        sdS[j] = dS;
+        if (a.dbias) atomicAdd(a.dbias + (int64_t)h * a.bias_ld + j, dS);
+      }
+    }
+    __syncthreads();
+    // lanes over the 64 dims
+    float dq = 0.f;
+    const float qe = sq[lane], de = sdc[lane];
+    for (int j = 0; j < a.nkeys; ++j) {
+      const float dS = sdS[j];
+      dq = fmaf(dS, Kb[(int64_t)j * a.kv_rs + lane], dq);
+      sdK[j * 64 + lane] = fmaf(dS, qe, sdK[j * 64 + lane]);
+      sdV[j * 64 + lane] = fmaf(sPd[j], de, sdV[j * 64 + lane]);
+    }
+    a.dQ[row * a.lddq + h * 64 + lane] = dq * 0.125f;
+    __syncthreads();
+  }
+  for (int j = 0; j < a.nkeys; ++j) {
+    a.dK[(int64_t)s * a.dkv_bs + (int64_t)j * a.dkv_rs + h * 64 + lane] = sdK[j * 64 + lane] * 0.125f;
+    a.dV[(int64_t)s * a.dkv_bs + (int64_t)j * a.dkv_rs + h * 64 + lane] = sdV[j * 64 + lane];
+  }
+}
+
+inline unsigned grid1d(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int care_ln_bwd(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* gamma, const float* dy,
+                           int64_t lddy, float eps, float* ds, int64_t ldds, float* dgamma, float* dbeta, int rows, int d,
+                           void* stream) {
+  if (!x || !gamma || !dy || !ds || !dgamma || !dbeta || rows <= 0 || d <= 0) return CARE_EINVAL;
+  if (d > 2048) return CARE_ESHAPE;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, BST, x, ldx, res, ldres, gamma, dy, lddy, eps, ds, ldds,
+                     dgamma, dbeta, rows, d);
+  return care_launch_status();
+}
+
+extern "C" int care_act(const float* z, const float* dy, float* out, int64_t n, int act, void* stream) {
+  if (!z || !out || n <= 0) return CARE_EINVAL;
+  if (act < CARE_ACT_NONE || act > CARE_ACT_GELU) return CARE_EDTYPE;
+  hipLaunchKernelGGL(act_kernel, dim3(grid1d(n)), dim3(256), 0, BST, z, dy, out, n, act);
+  return care_launch_status();
+}
+
+extern "C" int care_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream) {
+  if (!x || !out || n <= 0 || !(p >= 0.f && p < 1.f)) return CARE_EINVAL;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid1d(n)), dim3(256), 0, BST, x, out, n, p, (unsigned long long)seed);
+  return care_launch_status();
+}
+
+extern "C" int care_strided_sum(const float* x, int64_t ldx, float* out, int64_t ldo, int rows, int d, int terms,
+                                int64_t row_stride, int64_t term_stride, float scale, void* stream) {
+  if (!x || !out || rows <= 0 || d <= 0 || terms <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(strided_sum_kernel, dim3(grid1d((int64_t)rows * d)), dim3(256), 0, BST, x, ldx, out, ldo, rows, d, terms,
+                     row_stride, term_stride, scale);
+  return care_launch_status();
+}
+
+extern "C" int care_bcast_rows(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int d, int grp, float scale,
+                               void* stream) {
+  if (!src || !dst || rows <= 0 || d <= 0 || grp <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3(grid1d((int64_t)rows * d)), dim3(256), 0, BST, src, lds_, dst, ldd, rows, d, grp, scale);
+  return care_launch_status();
+}
+
+extern "C" int care_add_pos_sem(const float* x, const float* pos, const float* sem, float* out, int rows, int d, int seq,
+                                int sem_div, void* stream) {
+  if (!x || !out || rows <= 0 || d <= 0 || seq <= 0 || sem_div <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(add_pos_sem_kernel, dim3(grid1d((int64_t)rows * d)), dim3(256), 0, BST, x, pos, sem, out, rows, d, seq, sem_div);
+  return care_launch_status();
+}
+
+extern "C" int care_scatter_add_rows(const float* src, int64_t lds_, const int32_t* idx, float* table, int64_t ldt, int rows,
+                                     int d, int skip_idx, void* stream) {
+  if (!src || !idx || !table || rows <= 0 || d <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid1d((int64_t)rows * d)), dim3(256), 0, BST, src, lds_, idx, table, ldt, rows,
+                     d, skip_idx);
+  return care_launch_status();
+}
+
+extern "C" int care_concept_bwd(const float* scores, int64_t lds_, const float* dpreds, int64_t ldp, const float* davg, float* ds,
+                                int64_t ldo, int B, int k, void* stream) {
+  if (!scores || !ds || B <= 0 || k <= 0) return CARE_EINVAL;
+  hipLaunchKernelGGL(concept_bwd_kernel, dim3(grid1d((int64_t)B * k)), dim3(256), 0, BST, scores, lds_, dpreds, ldp, davg, ds, ldo, B, k);
+  return care_launch_status();
+}
+
+extern "C" int care_attn_pv(const float* P, const float* V, int64_t kv_bs, int64_t kv_rs, float* ctx, int64_t ldc, int nseq,
+                            int seq, int nkeys, int heads, float p_drop, uint64_t seed, void* stream) {
+  if (!P || !V || !ctx || nseq <= 0 || seq <= 0 || nkeys <= 0 || heads <= 0) return CARE_EINVAL;
+  AttnBArgs a{};
+  a.P = P; a.V = V; a.kv_bs = kv_bs; a.kv_rs = kv_rs; a.ctx = ctx; a.ldc = ldc;
+  a.nseq = nseq; a.seq = seq; a.nkeys = nkeys; a.heads = heads; a.p_drop = p_drop; a.seed = seed;
+  hipLaunchKernelGGL(attn_pv_kernel, dim3(nseq * heads), dim3(64), 0, BST, a);
+  return care_launch_status();
+}
+
+extern "C" int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, int64_t kv_bs, int64_t kv_rs,
+                             const float* P, const float* dctx, int64_t ldd, float* dQ, int64_t lddq, float* dK, float* dV,
+                             int64_t dkv_bs, int64_t dkv_rs, float* dbias, int bias_ld, int nseq, int seq, int nkeys, int heads,
+                             float p_drop, uint64_t seed, void* stream) {
+  if (!Q || !K || !V || !P || !dctx || !dQ || !dK || !dV || nseq <= 0 || seq <= 0 || nkeys <= 0 || heads <= 0) return CARE_EINVAL;
+  if (nkeys > 128) return CARE_ESHAPE;
+  AttnBArgs a{};
+  a.Q = Q; a.ldq = ldq; a.K = K; a.V = V; a.kv_bs = kv_bs; a.kv_rs = kv_rs; a.P = P; a.dctx = dctx; a.ldd = ldd;
+  a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.dV = dV; a.dkv_bs = dkv_bs; a.dkv_rs = dkv_rs; a.dbias = dbias; a.bias_ld = bias_ld;
+  a.nseq = nseq; a.seq = seq; a.nkeys = nkeys; a.heads = heads; a.p_drop = p_drop; a.seed = seed;
+  const int lds = (384 + 2 * nkeys * 64) * 4;
+  static std::atomic<unsigned long long> ok{0};
+  if (lds > 64 * 1024)
+    if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel), lds, ok)) return e;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nseq * heads), dim3(64), lds, BST, a);
+  return care_launch_status();
+}

@@ -303,8 +303,8 @@ class TransformerSeq2Seq(nn.Module):
     def engine(self) -> HipEngine:
         if self.training:
             raise NotImplementedError(
-                "care_amd kernels are forward-only in this round: call .eval() "
-                "(training needs autograd and is not routed to a different implementation)")
+                "the inference engine (encoding_phase / decoding_phase / translate) runs in eval mode: call .eval(); "
+                "in training mode use forward() / feedforward_step(), which run under autograd (care_amd/training.py)")
         params = list(self.parameters())
         device = params[0].device
         stamp = (device, self._compute_dtype, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
@@ -365,6 +365,11 @@ class TransformerSeq2Seq(nn.Module):
                                              sem_embs=inputs_for_decoder.get("semantic_embs"), want_aux=bool(aux))
 
     def feedforward_step(self, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
+        if self.training:
+            # models/Wrapper.py:423-435 -> Framework.py:215-237 with dropout active, under autograd: every op's
+            # forward and backward is a HIP kernel behind the C ABI (care_amd/training.py)
+            from .training import training_forward
+            return training_forward(self, batch, **kwargs)
         enc = self.encoding_phase(batch["feats"], **kwargs)
         inputs = self.prepare_inputs_for_decoder(enc, batch)
         dec = self.decoding_phase(batch["input_ids"], inputs, **kwargs)

@@ -494,6 +494,47 @@ int care_scatter_rows(const void* src, int64_t src_stride_bytes, void* dst, int6
 int care_expand_index(const int32_t* idx_c, int m, int bm, int32_t* idx_r, void* stream);
 int care_remap_rows(int32_t* anc, int64_t n, const int32_t* cmap, int bm, void* stream);
 
+/*
+ * Training mode (models/Wrapper.py:423-435 -> models/Framework.py:215-237 under autograd; care_amd/training.py):
+ *   everything of a backward pass that is not a GEMM (those re-use care_gemm on transposed operands).  fp32.
+ *   care_ln_bwd: backward of care_add_ln (y = LN(x + res) gamma + beta): ds = dx = dres; dgamma / dbeta are
+ *     ACCUMULATED (atomics) into zero-initialised [d] buffers.  d <= 2048.  (nn.LayerNorm of Encoder.py:167,
+ *     SubLayers.py:73-79,147-150, Embeddings.py:84,185.)
+ *   care_act: dy == NULL: out = act(z); else out = dy * act'(z)  (activations.py:3-16; exact-erf GELU).
+ *   care_dropout: out = x * keep / (1 - p), keep = [u(seed, i) >= p] from a counter-based generator - the same call
+ *     with the same seed is nn.Dropout's backward (RNG parity with torch is not a goal).
+ *   care_strided_sum: out[r] = scale * sum_{k < terms} x[r * row_stride + k * term_stride]  (bias gradients, the
+ *     backward of broadcast adds);  care_bcast_rows: dst[i] = scale * src[i / grp]  (backward of mean(1), Encoder.py:106).
+ *   care_add_pos_sem: out[r] = x[r] + pos[r % seq] + sem[r / sem_div]  (Embeddings.py:170-176 before its LayerNorm).
+ *   care_scatter_add_rows: table[idx[i]] += src[i]  (nn.Embedding backward; rows idx == skip_idx (padding_idx) skipped).
+ *   care_concept_bwd: backward of care_concept_finish (pred_attribute.py:17-46) to the concept scores.
+ *   care_attn_pv: ctx = dropout(P) V per (sequence, head); P [nseq * seq, heads, nkeys] from care_attention_probs.
+ *   care_attn_bwd: backward of softmax(Q K^T / 8 + mask + bias) -> dropout -> . V  (Attention.py:83-131): dQ, dK, dV
+ *     (written) and dbias [heads, bias_ld] (accumulated, optional).  nkeys <= 128, head dim 64; key / value block s of
+ *     sequence s (no sharing between sequences: rows_per_kv = seq).
+ */
+int care_ln_bwd(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* gamma, const float* dy,
+                int64_t lddy, float eps, float* ds, int64_t ldds, float* dgamma, float* dbeta, int rows, int d,
+                void* stream);
+int care_act(const float* z, const float* dy, float* out, int64_t n, int act, void* stream);
+int care_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream);
+int care_strided_sum(const float* x, int64_t ldx, float* out, int64_t ldo, int rows, int d, int terms,
+                     int64_t row_stride, int64_t term_stride, float scale, void* stream);
+int care_bcast_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int d, int grp, float scale,
+                    void* stream);
+int care_add_pos_sem(const float* x, const float* pos, const float* sem, float* out, int rows, int d, int seq,
+                     int sem_div, void* stream);
+int care_scatter_add_rows(const float* src, int64_t lds, const int32_t* idx, float* table, int64_t ldt, int rows,
+                          int d, int skip_idx, void* stream);
+int care_concept_bwd(const float* scores, int64_t lds, const float* dpreds, int64_t ldp, const float* davg, float* ds,
+                     int64_t ldo, int B, int k, void* stream);
+int care_attn_pv(const float* P, const float* V, int64_t kv_bs, int64_t kv_rs, float* ctx, int64_t ldc, int nseq,
+                 int seq, int nkeys, int heads, float p_drop, uint64_t seed, void* stream);
+int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, int64_t kv_bs, int64_t kv_rs,
+                  const float* P, const float* dctx, int64_t ldd, float* dQ, int64_t lddq, float* dK, float* dV,
+                  int64_t dkv_bs, int64_t dkv_rs, float* dbias, int bias_ld, int nseq, int seq, int nkeys, int heads,
+                  float p_drop, uint64_t seed, void* stream);
+
 /* care_timestamp: out[0] (uint64) = the device wall clock (constant 100 MHz) when the one-thread kernel runs.
  *   Measurement only (bench.py: the duration of a kernel inside a replayed hipGraph); no reference counterpart. */
 int care_timestamp(void* out, void* stream);

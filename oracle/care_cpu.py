@@ -172,8 +172,10 @@ def encoding_phase(P, opt: dict, feats: List[torch.Tensor]) -> Dict[str, torch.T
             out["semantic_embs"] = _layer_norm(P, sp + ".attr_embs.LayerNorm", emb, opt["layer_norm_eps"])
             out["semantic_labels"] = labels
             if "emb" in opt.get("use_attr_type", ""):
+                # pred_attribute.py:279: detached unless `global_semantic_guidance_not_detach` (same forward values)
+                src = preds_attr if opt.get("global_semantic_guidance_not_detach") else preds_attr.detach()
                 out["semantic_hidden_states"] = F.linear(
-                    preds_attr, P[sp + ".semantic2hidden.weight"], P.get(sp + ".semantic2hidden.bias"))
+                    src, P[sp + ".semantic2hidden.weight"], P.get(sp + ".semantic2hidden.bias"))
             if "concat" in opt.get("use_attr_type", ""):
                 out["encoder_hidden_states"] = torch.cat(
                     (out["encoder_hidden_states"], out["semantic_embs"]), dim=1)

@@ -1,0 +1,131 @@
+"""GPU: training mode (models/Wrapper.py:423-435 -> Framework.py:215-237 under autograd).
+
+`model.train()(batch)` runs care_amd/training.py: torch.autograd.Functions whose forward and backward are HIP kernels.
+With every dropout probability at 0 the forward is the eval forward and `loss.backward()` must give the gradients of
+the oracle (the reference's math in torch, differentiated by torch's own autograd on the CPU) for every parameter."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NO_DROP = dict(encoder_dropout_prob=0.0, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+
+def _build(golden, **over):
+    from care_amd import get_framework
+
+    opt, P, feats, ids = golden.build()
+    opt.update(over)
+    model = get_framework(opt)
+    model.load_state_dict(P, strict=True)
+    return opt, P, feats, ids, model.to("cuda:0")
+
+
+def _loss(out, gen_dev, seeds=(11, 12)):
+    """A fixed random linear functional of everything the reference's criteria read."""
+    g = torch.Generator().manual_seed(seeds[0])
+    lg = out["logits"]
+    w = torch.randn(lg.shape, generator=g).to(lg.device)
+    loss = (lg * w).sum() / lg.shape[0]
+    if "preds_attr" in out:
+        g2 = torch.Generator().manual_seed(seeds[1])
+        pa = out["preds_attr"].reshape(lg.shape[0], -1)
+        loss = loss + (pa * torch.randn(pa.shape, generator=g2).to(lg.device)).sum() + 3.0 * out["avg_prob_attr"].reshape(-1).sum()
+    return loss
+
+
+@pytest.mark.parametrize("name", ["msrvtt_base_ami_b2", "msrvtt_care_b2", "msrvtt_cabase_b3", "msrvtt_base_ami_eos_b4",
+                                  "care_median_gelu_b2"])
+def test_training_forward_and_gradients_match_the_oracle_autograd(name):
+    from conftest import GoldenCase
+    from oracle import care_cpu
+
+    opt, P, feats, ids, model = _build(GoldenCase(name), **NO_DROP)
+    model.train()
+    batch = {"feats": [f.to("cuda:0") for f in feats], "input_ids": ids.to("cuda:0")}
+    out = model(batch)
+    assert out["logits"].requires_grad and out["schedule_sampling_prob"] == 0
+    loss = _loss(out, "cuda:0")
+    loss.backward()
+    # oracle: the same math in torch on the CPU, differentiated by torch
+    Pc = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in P.items()}
+    ref = care_cpu.feedforward_step(Pc, opt, feats, ids)
+    assert (out["logits"].detach().cpu() - ref["logits"].detach()).abs().max().item() < 2e-4
+    assert (out["hidden_states"].detach().cpu() - ref["hidden_states"].detach()).abs().max().item() < 2e-5
+    if "preds_attr" in ref:
+        assert (out["preds_attr"].detach().cpu().reshape(-1) - ref["preds_attr"].detach().reshape(-1)).abs().max().item() < 1e-5
+    rloss = _loss(ref, "cpu")
+    assert abs(float(loss) - float(rloss)) < 1e-3 * max(1.0, abs(float(rloss)))
+    rloss.backward()
+    checked = 0
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        gref = Pc[k].grad
+        if gref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, "no gradient for " + k
+        scale = max(float(gref.abs().max()), 1e-6)
+        err = float((p.grad.cpu() - gref).abs().max()) / scale
+        worst = max(worst, (k, err), key=lambda kv: kv[1])
+        assert err < 1e-4, (k, err, scale)
+        checked += 1
+    assert checked >= 20, checked
+    # padding_idx: the PAD row of the word embedding gets no gradient (nn.Embedding(padding_idx=0))
+    assert float(model.decoder.embedding.word_embeddings.weight.grad[0].abs().max()) == 0.0
+    print("worst relative gradient error", worst)
+
+
+def test_dropout_is_active_seeded_and_differentiable():
+    from conftest import GoldenCase
+
+    opt, P, feats, ids, model = _build(GoldenCase("msrvtt_care_b2"))   # reference defaults: 0.5 / 0.5 / 0.1
+    batch = {"feats": [f.to("cuda:0") for f in feats], "input_ids": ids.to("cuda:0")}
+    model.train()
+    torch.manual_seed(5)
+    a = model(batch)["logits"].detach().clone()
+    torch.manual_seed(5)
+    b = model(batch)["logits"].detach().clone()
+    torch.manual_seed(6)
+    c = model(batch)["logits"].detach().clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    model.eval()
+    e = model.feedforward_step(batch, output_auxiliary=False)["logits"]
+    assert not torch.allclose(a, e, atol=1e-3)            # dropout changed the forward
+    model.train()
+    out = model(batch)
+    _loss(out, "cuda:0").backward()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) >= 20 and all(torch.isfinite(g).all() for g in grads)
+    # the kernel's keep rate
+    from care_amd import _lib
+    x = torch.ones(1 << 20, device="cuda:0")
+    y = torch.empty_like(x)
+    _lib.call("care_dropout", x.data_ptr(), y.data_ptr(), x.numel(), 0.3, 12345)
+    torch.cuda.synchronize()
+    keep = float((y > 0).float().mean())
+    assert abs(keep - 0.7) < 5e-3 and abs(float(y.max()) - 1 / 0.7) < 1e-5
+
+
+def test_a_few_optimizer_steps_reduce_the_loss():
+    """train.py's loop in miniature: cross-entropy on the teacher-forced logits, torch's own optimiser on the module's
+    parameters, gradients from the HIP backward."""
+    from conftest import GoldenCase
+
+    opt, P, feats, ids, model = _build(GoldenCase("msrvtt_base_ami_b2"), **NO_DROP)
+    model.train()
+    batch = {"feats": [f.to("cuda:0") for f in feats], "input_ids": ids.to("cuda:0")}
+    labels = torch.roll(ids, -1, dims=1).to("cuda:0")
+    optim = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(6):
+        optim.zero_grad()
+        lg = model(batch)["logits"]
+        loss = torch.nn.functional.cross_entropy(lg.reshape(-1, lg.shape[-1]), labels.reshape(-1))
+        loss.backward()
+        optim.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] - 0.5, losses
+    model.eval()    # the engine re-packs the updated weights
+    out = model.feedforward_step(batch, output_auxiliary=False)
+    assert torch.isfinite(out["logits"]).all()

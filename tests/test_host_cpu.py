@@ -76,8 +76,10 @@ def test_no_silent_fallback_on_cpu_or_in_training():
         model.encoding_phase(feats)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         get_translator(opt).translate_batch([model], {"feats": feats})
-    with pytest.raises(NotImplementedError, match="forward-only"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):   # training mode too: autograd over the HIP kernels
         model.train().feedforward_step({"feats": feats, "input_ids": torch.zeros(2, 29, dtype=torch.long)})
+    with pytest.raises(NotImplementedError, match="eval mode"):
+        model.train().encoding_phase(feats)
     with pytest.raises(TypeError):
         get_translator(opt).translate_batch([torch.nn.Linear(2, 2)], {"feats": feats})
 
