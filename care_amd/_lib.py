@@ -32,6 +32,7 @@ SIGNATURES = {
     "care_split2_act": [_P, _L, _P, _I, _I, _P],
     "care_gemm_tile_split3": [_P, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_gemm_tile_split3_argmax": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "care_gemm_tile_batched": [_P, _L, _L, _P, _L, _L, _P, _I, _P, _L, _L, _I, _I, _I, _I, _I, _P],
     "care_gemm_tile_argmax": [_P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "care_score_partials": [_P, _P, _P, _P, _I, _P, _P, _I, _P],
     "care_label_logits": [_P, _L, _P, _P, _P, _I, _I, _I, _P],

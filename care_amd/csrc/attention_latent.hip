@@ -367,6 +367,245 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
   }
 }
 
+
+// ------------------------------------------------------------------ d_model = 1024 (16 heads): two waves per row
+// The same algorithm with the row's 1024 dims cut in two halves of 512: a workgroup of TWO waves owns a row, wave w
+// streams and multiplies dims [512 w, 512 w + 512) - its own ring, its own 64 query-fragment registers and 128
+// accumulators, exactly the single-wave kernel's footprint.  What the halves share is the score: each wave has the
+// partial dot products over its dims, they swap them through 2 x 1 KB of LDS (double-buffered by chunk parity, one raw
+// s_barrier per chunk - the DMAs in flight are not drained) and both add them (a + b == b + a in IEEE arithmetic), so
+// both take identical softmax decisions; the 16 heads fill the MFMA N axis.  Per row and step 114 x 2 KB of memory +
+// 2 x 32 KB of q~ / c~ instead of 2 x 114 x 2 KB of projected K and V.
+template <int NSLOT>
+__global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int D2 = 1024;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = which half of the dims
+  unsigned char* ring = smem + wave * (NSLOT * CH_BYTES);
+  float* sbias = reinterpret_cast<float*>(smem + 2 * NSLOT * CH_BYTES);              // [16][128]
+  float* xch = reinterpret_cast<float*>(smem + 2 * NSLOT * CH_BYTES + 16 * 128 * 4);  // [2 parities][2 waves][64 lanes][4]
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nch = (p.nkeys + CH_KEYS - 1) / CH_KEYS;
+  const int items = p.rows;
+  const int ncols = p.heads;                // <= 16
+  const int nq = ncols <= 8 ? 8 : 16;
+
+  auto stage = [&](int row, int c, int slot) {
+    const bf16_t* base = p.mem + (int64_t)(row / p.rows_per_kv) * p.mem_bs + wave * LAT_D;
+#pragma unroll
+    for (int i = 0; i < CH_KEYS; ++i) {
+      const int key = min(c * CH_KEYS + i, p.nkeys - 1);
+      const unsigned char* g = reinterpret_cast<const unsigned char*>(base + (int64_t)key * p.mem_rs) + ((lane ^ lat_swz(i)) << 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(ring + slot * CH_BYTES + i * 1024), 16, 0,
+                                       CARE_LAT_LD_AUX);
+    }
+  };
+  auto stage_q = [&](int row, int slot) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i >= nq) break;
+      const int hcol = min(i, ncols - 1);
+      const unsigned char* g = reinterpret_cast<const unsigned char*>(p.qt + (int64_t)row * p.ldq + hcol * D2 + wave * LAT_D) +
+                               ((lane ^ lat_swz(i)) << 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(ring + slot * CH_BYTES + i * 1024), 16, 0,
+                                       CARE_LAT_Q_AUX);
+    }
+  };
+
+  int roff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) roff[r] = fr * 1024 + ((((r * 4 + fg) ^ lat_swz(fr)) & 15) << 4);
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  const int trow = fg * 4 + tq;
+  int toff[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) toff[m] = trow * 1024 + ((((m * 2 + (tp >> 1)) ^ lat_swz(trow)) & 15) << 4) + 8 * (tp & 1);
+  int woff[8];
+#pragma unroll
+  for (int mm = 0; mm < 8; ++mm) woff[mm] = fr * 1024 + ((((2 * mm + (fg >> 1)) ^ lat_swz(fr)) & 15) << 4) + 8 * (fg & 1);
+  const int frq = fr < nq ? fr : fr - 8;
+  int qoff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) qoff[r] = frq * 1024 + ((((r * 4 + fg) ^ lat_swz(frq)) & 15) << 4);
+  const int headc = fr < ncols ? fr : 0;
+  const bool col_ok = fr < ncols;
+
+  for (int i = threadIdx.x; i < 16 * 128; i += 128) {
+    const int h = min(i >> 7, p.heads - 1), key = i & 127;
+    sbias[i] = key < p.nkeys ? (p.bias ? p.bias[h * p.bias_ld + key] : 0.f) : -INFINITY;
+  }
+  __syncthreads();
+  int t = 0, par = 0;
+  if ((int)blockIdx.x < items) stage_q(blockIdx.x, 0);
+  int n_stored = 0;
+
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int row = item;
+    bf16x8 qf[16];
+    {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stage(row, 0, (t + 1) % NSLOT);
+      lat_wait_vm(16 + n_stored);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* sq = ring + (t % NSLOT) * CH_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(sq + qoff[ks & 3] + (ks >> 2) * 256);
+      ++t;
+    }
+    f32x4 acc[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_ref = -INFINITY, l_part = 0.f;
+
+    for (int c = 0; c < nch; ++c, ++t, par ^= 1) {
+      const int slot = t % NSLOT;
+      const bool more_here = c + 1 < nch;
+      const bool have_next = more_here || item + (int)gridDim.x < items;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (more_here) {
+        stage(row, c + 1, (t + 1) % NSLOT);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else if (have_next) {
+        stage_q(item + gridDim.x, (t + 1) % NSLOT);
+        if (nq == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* sb = ring + slot * CH_BYTES;
+
+      // ---- partial S^T over this wave's 512 dims, swapped with the other half's
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + roff[ks & 3] + (ks >> 2) * 256);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s, 0, 0, 0);
+      }
+      {
+        const unsigned xb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)xch;
+        const unsigned mine = xb + (unsigned)(((par * 2 + wave) * 64 + lane) * 16);
+        const unsigned other = xb + (unsigned)(((par * 2 + (wave ^ 1)) * 64 + lane) * 16);
+        f32x4 o;
+        asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(mine), "v"(s) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(other) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        s += o;
+      }
+      s += *reinterpret_cast<const f32x4*>(sbias + headc * 128 + c * CH_KEYS + fg * 4);
+
+      float cm = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+      cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+      cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+      if (__any(cm > m_ref + 16.0f)) {
+        const float m_new = fmaxf(m_ref, cm);
+        const float alpha = __expf(m_ref - m_new);
+        m_ref = m_new;
+        l_part *= alpha;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) acc[m] *= alpha;
+      }
+      s16x4 pb;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = __expf(s[r] - m_ref);
+        psum += pr;
+        const bf16_t h = (bf16_t)pr;
+        pb[r] = __builtin_bit_cast(short, h);
+      }
+      l_part += psum;
+
+      const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sb;
+      unsigned tad[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) tad[m] = sbase + toff[m];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        s16x4 a[8];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8 offset:%16\n\t"
+            "ds_read_b64_tr_b16 %1, %9 offset:%16\n\t"
+            "ds_read_b64_tr_b16 %2, %10 offset:%16\n\t"
+            "ds_read_b64_tr_b16 %3, %11 offset:%16\n\t"
+            "ds_read_b64_tr_b16 %4, %12 offset:%16\n\t"
+            "ds_read_b64_tr_b16 %5, %13 offset:%16\n\t"
+            "ds_read_b64_tr_b16 %6, %14 offset:%16\n\t"
+            "ds_read_b64_tr_b16 %7, %15 offset:%16\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+            : "v"(tad[0]), "v"(tad[1]), "v"(tad[2]), "v"(tad[3]), "v"(tad[4]), "v"(tad[5]), "v"(tad[6]), "v"(tad[7]),
+              "n"(g * 256)
+            : "memory");
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+          acc[g * 8 + m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[m], pb, acc[g * 8 + m], 0, 0, 0);
+      }
+    }
+
+    // ---- normalise and store this wave's 512 dims of every head
+    float l = l_part;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    n_stored = 0;
+    const unsigned ob = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(ring + ((t - 1) % NSLOT) * CH_BYTES);
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[m][r] * inv);
+      asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ob + woff[m & 7]), "v"(o), "n"((m >> 3) * 256) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned rb = ob + lane * 16;
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += 8) {
+      if (i0 >= ncols) break;
+      f32x4 v[8];
+      asm volatile(
+          "ds_read_b128 %0, %8 offset:%9\n\t"
+          "ds_read_b128 %1, %8 offset:%9+1024\n\t"
+          "ds_read_b128 %2, %8 offset:%9+2048\n\t"
+          "ds_read_b128 %3, %8 offset:%9+3072\n\t"
+          "ds_read_b128 %4, %8 offset:%9+4096\n\t"
+          "ds_read_b128 %5, %8 offset:%9+5120\n\t"
+          "ds_read_b128 %6, %8 offset:%9+6144\n\t"
+          "ds_read_b128 %7, %8 offset:%9+7168\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+          : "v"(rb), "n"(i0 * 1024)
+          : "memory");
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = i0 + k;
+        if (i < ncols) {
+          unsigned char* dst = reinterpret_cast<unsigned char*>(p.ct + (int64_t)row * p.ldc + i * D2 + wave * LAT_D) +
+                               ((lane ^ lat_swz(i)) << 4);
+          if (CARE_LAT_ST_NT) __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(dst));
+          else *reinterpret_cast<f32x4*>(dst) = v[k];
+          ++n_stored;
+        }
+      }
+    }
+    (void)col_ok;
+  }
+}
+
+template <int NSLOT>
+int launch_latent2(const LatArgs& p, hipStream_t st) {
+  constexpr int LDS = 2 * NSLOT * CH_BYTES + 16 * 128 * 4 + 2 * 2 * 64 * 16;
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&attention_latent2_kernel<NSLOT>), LDS, lds_ok)) return e;
+  const int blocks = min(p.rows, 512);  // two 2-wave workgroups per CU
+  hipLaunchKernelGGL((attention_latent2_kernel<NSLOT>), dim3(blocks), dim3(128), LDS, st, p);
+  return care_launch_status();
+}
+
 template <int WAVES, int NSLOT>
 int launch_latent(const LatArgs& p, hipStream_t st) {
   constexpr int LDS = WAVES * NSLOT * CH_BYTES + 16 * 128 * 4;
@@ -386,7 +625,7 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
                                      int64_t mem_row_stride, int rows_per_kv, int nkeys, const float* bias,
                                      int bias_ld, void* ct, int64_t ldc, int rows, int heads, int d, void* stream) {
   if (!qt || !mem || !ct || rows <= 0 || heads <= 0 || nkeys <= 0 || rows_per_kv <= 0) return CARE_EINVAL;
-  if (d != LAT_D || heads > 16 || nkeys > 128) return CARE_ESHAPE;
+  if ((d != LAT_D && d != 2 * LAT_D) || heads > 16 || nkeys > 128) return CARE_ESHAPE;
   if ((ldq % 8) || (ldc % 4) || (mem_batch_stride % 8) || (mem_row_stride % 8) || !care_aligned16(qt) ||
       !care_aligned16(mem) || !care_aligned16(ct) || mem_row_stride < LAT_D)
     return CARE_EALIGN;
@@ -398,6 +637,11 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
   static const int pair_ok = [] { const char* e = getenv("CARE_LAT_PAIR"); return e ? atoi(e) : 1; }();  // A/B switch
   p.paired = pair_ok && heads <= 8 && rows_per_kv > 1 && rows % rows_per_kv == 0;
   hipStream_t st = (hipStream_t)stream;
+  if (d == 2 * LAT_D) {  // d_model = 1024: two waves per row (attention_latent2_kernel)
+    p.paired = 0;
+    static const int slots2 = [] { const char* e = getenv("CARE_LAT2_SLOTS"); return e ? atoi(e) : 2; }();
+    return slots2 == 3 ? launch_latent2<3>(p, st) : launch_latent2<2>(p, st);
+  }
   // tuning: 0 = 4 waves x 2 slots, 1 = 3 waves x 3 slots (read once; initialisation is thread-safe)
   static const int cfg = [] { const char* e = getenv("CARE_LAT_CFG"); return e ? atoi(e) : 0; }();
   if (cfg == 1) return launch_latent<3, 3>(p, st);

@@ -40,6 +40,7 @@ struct TArgs {
   const int32_t* labels; float* plab;
   int tiles_m, tiles_n;
   int a_wrap;  // K steps (of 64) after which the A columns start over: see care_gemm_tile_split3 (INT_MAX otherwise)
+  int64_t a_bs, w_bs, c_bs; int bias_bs;  // batched launches (blockIdx.y): element offsets per batch of A, W, C0, bias
 };
 
 enum { EPI_STORE = 0, EPI_ARGMAX = 1, EPI_ARGMAX_LAB = 2 };
@@ -74,6 +75,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
     t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
   const int m0 = (t % p.tiles_m) * BM, n0 = (t / p.tiles_m) * BN;
+  if (gridDim.y > 1) {  // batched: one independent product per blockIdx.y (the per-head projections of the absorbed attention)
+    const int b = blockIdx.y;
+    p.A += (int64_t)b * p.a_bs;
+    p.W += (int64_t)b * p.w_bs;
+    p.C0 = reinterpret_cast<unsigned char*>(p.C0) + (int64_t)b * p.c_bs * (p.c0_bf16 ? 2 : 4);
+    if (p.bias) p.bias += (int64_t)b * p.bias_bs;
+  }
 
   // ---- staging: piece q = wave * P + i covers LDS rows 8 q .. 8 q + 7 of the stage image (A rows first)
   const int prow = lane >> 3;
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
 }
 
 template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false>
-int launch_tile(TArgs& p, hipStream_t st) {
+int launch_tile(TArgs& p, hipStream_t st, int batch = 1) {
   constexpr int BM = 64 * WTM * WGM, BN = 64 * WGN;
   constexpr int lds = STAGES * (BM + BN) * 128;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -266,7 +274,7 @@ int launch_tile(TArgs& p, hipStream_t st) {
     const int rc = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16>), lds, done);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL((gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16>), dim3(p.tiles_m * p.tiles_n, batch), dim3(64 * WGM * WGN), lds, st, p);
   return care_launch_status();
 }
 
@@ -321,6 +329,36 @@ extern "C" int care_gemm_tile(const void* A, int64_t lda, const void* W, const f
   p.C1 = C1; p.ldc1 = ldc1; p.c1_bf16 = c1_dtype == CARE_BF16;
   p.n_split = n_split; p.M = M; p.N = N; p.K = K; p.act = act;
   return dispatch<EPI_STORE>(p, (hipStream_t)stream);
+}
+
+// `batch` independent products in one launch: product b multiplies A + b a_bs ([M, lda]) by W + b w_bs ([N, K] rows of
+// length K... leading dimension ldw) into C + b c_bs, bias + b bias_bs.  The per-head projections on either side of the
+// absorbed cross-attention for d_model = 1024 (the roles of care_head_expand / care_head_reduce, csrc/heads.hip):
+//   expand: A = q + 64 h (K = 64), W = wkt[h] [d, 64], C = qt + d h   -> [rows, heads, d]
+//   reduce: A = ct + d h (K = d),  W = W_v rows 64 h .. (ldw = d), C = ctx + 64 h (N = 64), bias = b_v + 64 h
+extern "C" int care_gemm_tile_batched(const void* A, int64_t lda, int64_t a_bs, const void* W, int64_t ldw, int64_t w_bs,
+                                      const float* bias, int bias_bs, void* C, int64_t ldc, int64_t c_bs, int c_dtype,
+                                      int batch, int M, int N, int K, void* stream) {
+  int rc = tile_check(A, lda, W, M, N, K);
+  if (rc) return rc;
+  if (!C || batch <= 0 || batch > 65535) return CARE_EINVAL;
+  if (c_dtype != CARE_F32 && c_dtype != CARE_BF16) return CARE_EDTYPE;
+  if ((a_bs % 8) || (w_bs % 8) || (ldw % 8) || (c_bs % 8)) return CARE_EALIGN;
+  TArgs p{};
+  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.ldw = ldw; p.bias = bias;
+  p.C0 = C; p.ldc0 = ldc; p.c0_bf16 = c_dtype == CARE_BF16; p.n_split = N; p.M = M; p.N = N; p.K = K; p.act = CARE_ACT_NONE;
+  p.a_bs = a_bs; p.w_bs = w_bs; p.c_bs = c_bs; p.bias_bs = bias_bs;
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 64) {  // 64-column tiles: the A stream is read once
+    // *measured* (head reduce, 4096 rows x 16 heads, K = 1024): 128-row tiles / 3 stages 38.9 us, 256 / 3 39.8,
+    // 256 / 2 41.5, 128 / 4 56.0
+    static const int cfg64 = [] { const char* e = getenv("CARE_TILE_CFG64"); return e ? atoi(e) : 213; }();
+    if (cfg64 == 412) return launch_tile<4, 1, 1, 2, EPI_STORE>(p, st, batch);
+    if (cfg64 == 413) return launch_tile<4, 1, 1, 3, EPI_STORE>(p, st, batch);
+    return launch_tile<2, 1, 1, 3, EPI_STORE>(p, st, batch);
+  }
+  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * batch;
+  return t256 >= 128 ? launch_tile<4, 4, 1, 2, EPI_STORE>(p, st, batch) : launch_tile<2, 2, 1, 2, EPI_STORE>(p, st, batch);
 }
 
 // fp32 [M, K] -> fp16 pieces [M, 2K]: x_hi = fp16(x) | x_lo = fp16(x - x_hi)

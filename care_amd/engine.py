@@ -352,8 +352,14 @@ class HipEngine:
 
     @property
     def latent_capable(self) -> bool:
-        """Shapes / dtype the absorbed cross-attention kernels cover: bf16 mode, d_model = 512, head dim 64."""
-        return self.as_ok and self.d == 512 and self.H * 64 == self.d and self.H <= 16
+        """Shapes / dtype the absorbed cross-attention kernels cover: bf16 mode, head dim 64, d_model = 512 (one wave
+        per row; per-head projections in csrc/heads.hip) or 1024 (two waves per row, 16 heads; per-head projections as
+        one batched launch of the LDS-tiled GEMM)."""
+        if self.H * 64 != self.d or self.H > 16:
+            return False
+        if os.environ.get("CARE_LATENT_1024", "1") == "0" and self.d == 1024:
+            return False
+        return (self.as_ok and self.d == 512) or (self.bf_act and self.d == 1024)
 
     @property
     def latent_ok(self) -> bool:
@@ -985,13 +991,21 @@ class HipEngine:
                 q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2b", (N, d), torch.bfloat16),
                                tag="step_dxd_gemm")
                 qt = self.ws(tag + "qt", (N, H * d), torch.bfloat16)
-                call("care_head_expand", ptr(q2), d, ptr(w[nm + "_wkt"]), ptr(qt), H * d, N, H, tag="step_head_expand")
+                if d == 512:
+                    call("care_head_expand", ptr(q2), d, ptr(w[nm + "_wkt"]), ptr(qt), H * d, N, H, tag="step_head_expand")
+                else:  # one batched launch: head h multiplies q[:, 64 h : 64 h + 64] by wkt[h] [d, 64]
+                    call("care_gemm_tile_batched", ptr(q2), d, 64, ptr(w[nm + "_wkt"]), 64, d * 64, None, 0, ptr(qt), H * d, d,
+                         CARE_BF16, H, N, d, 64, tag="step_head_expand")
                 ct = self.ws(tag + "ct", (N, H * d), torch.bfloat16)
                 call("care_attention_latent", ptr(qt), H * d, ptr(ckv[li]), Lk * d, d, rows_per_clip, Lk, ptr(hb),
                      hb.stride(0) if hb is not None else 0, ptr(ct), H * d, N, H, d, tag="step_cross_attn")
                 ctx = self._ctx(tag, N)
-                call("care_head_reduce", ptr(ct), H * d, ptr(w[nm + "_v_w"]), ptr(w[nm + "_v_b"]), ptr(ctx), d, N, H,
-                     tag="step_head_reduce")
+                if d == 512:
+                    call("care_head_reduce", ptr(ct), H * d, ptr(w[nm + "_v_w"]), ptr(w[nm + "_v_b"]), ptr(ctx), d, N, H,
+                         tag="step_head_reduce")
+                else:  # head h: ctx[:, 64 h : 64 h + 64] = ct[:, h] W_v[64 h : 64 h + 64, :]^T + b_v
+                    call("care_gemm_tile_batched", ptr(ct), H * d, d, ptr(w[nm + "_v_w"]), d, 64 * d, ptr(w[nm + "_v_b"]), 64,
+                         ptr(ctx), d, 64, CARE_BF16, H, N, 64, d, tag="step_head_reduce")
             else:
                 q2 = self.gemm(g(x1, x1b), w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)),
                                tag="step_dxd_gemm")

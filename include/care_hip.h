@@ -139,6 +139,13 @@ int care_gemm_tile(const void* A, int64_t lda, const void* W, const float* bias,
                    int c0_dtype, void* C1, int64_t ldc1, int c1_dtype, int n_split, int M, int N, int K,
                    int act, void* stream);
 int care_argmax_parts_tile(int N);
+/* care_gemm_tile_batched: `batch` independent products C_b = A_b W_b^T + bias_b in one launch (element offsets a_bs,
+ *   w_bs, c_bs, bias_bs per batch; W rows of leading dimension ldw): the per-head projections on either side of the
+ *   absorbed cross-attention for d_model = 1024 - the roles of care_head_expand / care_head_reduce
+ *   (models/components/Attention.py:63-67 moved to the query / context side). */
+int care_gemm_tile_batched(const void* A, int64_t lda, int64_t a_bs, const void* W, int64_t ldw, int64_t w_bs,
+                           const float* bias, int bias_bs, void* C, int64_t ldc, int64_t c_bs, int c_dtype, int batch,
+                           int M, int N, int K, void* stream);
 int care_gemm_tile_argmax(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
                           const int32_t* labels, float* plab, int M, int N, int K, void* stream);
 
@@ -357,10 +364,11 @@ int care_attention_seq(const void* Q, int64_t ldq, const void* K, const void* V,
  *     scores[h][j] = (W_k,h^T q_h / 8) . mem_j   (+ a per-head constant the softmax cancels)
  *     ct[h]        = sum_j softmax_j(scores[h][j] + bias[h][j]) mem_j
  *   so every step reads ONE bf16 copy of the memory row instead of projected K and V.
- *   qt  bf16 [rows, heads, 512] (row stride ldq): the expanded, pre-scaled queries.
+ *   qt  bf16 [rows, heads, d] (row stride ldq): the expanded, pre-scaled queries.
  *   mem bf16: key j of row r at  mem + (r / rows_per_kv) * mem_batch_stride + j * mem_row_stride.
- *   bias fp32 [heads, bias_ld] or NULL.  ct bf16 [rows, heads, 512] (row stride ldc); the caller
- *   finishes ctx_h = W_v,h ct[h] + b_v,h.  nkeys <= 128, heads <= 16, d == 512.
+ *   bias fp32 [heads, bias_ld] or NULL.  ct bf16 [rows, heads, d] (row stride ldc); the caller
+ *   finishes ctx_h = W_v,h ct[h] + b_v,h.  nkeys <= 128, heads <= 16, d == 512 (one wave per row) or d == 1024
+ *   (two waves per row, each owning 512 dims; the partial scores cross through LDS).
  */
 int care_attention_latent(const void* qt, int64_t ldq, const void* mem, int64_t mem_batch_stride,
                           int64_t mem_row_stride, int rows_per_kv, int nkeys, const float* bias,

@@ -550,7 +550,7 @@ def test_attention_latent_rejects_bad_arguments():
     mem = _rand(2, 20, d).to(torch.bfloat16)
     qt = _rand(2, H, d).to(torch.bfloat16)
     ct = torch.empty(2, H, d, device=DEV, dtype=torch.bfloat16)
-    with pytest.raises(_lib.CareHipError):  # d_model other than 512
+    with pytest.raises(_lib.CareHipError):  # d_model other than 512 / 1024
         _call("care_attention_latent", _p(qt), H * d, _p(mem), 20 * d, d, 1, 20, None, 0, _p(ct), H * d, 2, H, 768)
     with pytest.raises(_lib.CareHipError):  # more than 128 keys
         _call("care_attention_latent", _p(qt), H * d, _p(mem), 20 * d, d, 1, 129, None, 0, _p(ct), H * d, 2, H, d)
@@ -881,3 +881,51 @@ def test_attention_seq(nseq, seq, nkeys, per_kv, kind):
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() < 4e-2      # bf16 probabilities and bf16 output
     assert (got - ref).abs().mean().item() < 3e-3
+
+
+@pytest.mark.parametrize("rows,nkeys,rows_per_kv,H,use_bias", [(1, 114, 1, 16, True), (300, 114, 1, 16, True), (77, 84, 1, 16, False),
+                                                                (4096 + 5, 114, 1, 16, True), (35, 57, 5, 16, True),
+                                                                (12, 40, 3, 12, False), (640, 114, 5, 16, True)])
+def test_attention_latent_d1024(rows, nkeys, rows_per_kv, H, use_bias):
+    """The two-waves-per-row form of the absorbed cross-attention (d_model = 1024: each wave owns 512 dims, the
+    partial scores cross through LDS) against torch on the same bf16 operands."""
+    d = 1024
+    clips = (rows + rows_per_kv - 1) // rows_per_kv
+    mem = _rand(clips, nkeys, d, seed=11).to(torch.bfloat16)
+    qt = _rand(rows, H, d, seed=12, scale=0.09).to(torch.bfloat16)
+    bias = _rand(H, nkeys, seed=13, scale=0.7) if use_bias else None
+    ct = torch.full((rows, H, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _call("care_attention_latent", _p(qt), H * d, _p(mem), nkeys * d, d, rows_per_kv, nkeys, _p(bias), nkeys, _p(ct),
+          H * d, rows, H, d)
+    clip_of = torch.arange(rows, device=DEV) // rows_per_kv
+    m = mem.float()[clip_of]
+    s = torch.einsum("rhc,rjc->rhj", qt.float(), m)
+    if use_bias:
+        s = s + bias[None]
+    ref = torch.einsum("rhj,rjc->rhc", torch.softmax(s, -1), m)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ct.float()).all()
+    err = (ct.float() - ref).abs()
+    assert err.max().item() < 1.2e-2 * max(1.0, ref.abs().max().item()) and err.mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("rows", [1, 130, 4096 + 9])
+def test_gemm_tile_batched_head_projections(rows):
+    """care_gemm_tile_batched in its two uses (d_model = 1024, 16 heads): qt[r][h] = wkt[h] q[r, 64 h : 64 h + 64] and
+    ctx[r, 64 h : 64 h + 64] = W_v[64 h : 64 h + 64, :] ct[r][h] + b_v - against torch on the same bf16 operands."""
+    H, d = 16, 1024
+    q = _rand(rows, d, seed=21).to(torch.bfloat16)
+    wkt = _rand(H, d, 64, seed=22, scale=0.05).to(torch.bfloat16)
+    qt = torch.full((rows, H, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _call("care_gemm_tile_batched", _p(q), d, 64, _p(wkt), 64, d * 64, None, 0, _p(qt), H * d, d, 1, H, rows, d, 64)
+    ref = torch.einsum("rhe,hce->rhc", q.float().view(rows, H, 64), wkt.float())
+    torch.cuda.synchronize()
+    assert (qt.float() - ref).abs().max().item() < 2e-2
+    ct = _rand(rows, H, d, seed=23, scale=0.5).to(torch.bfloat16)
+    wv = _rand(d, d, seed=24, scale=0.03).to(torch.bfloat16)
+    bv = _rand(d, seed=25)
+    ctx = torch.full((rows, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _call("care_gemm_tile_batched", _p(ct), H * d, d, _p(wv), d, 64 * d, _p(bv), 64, _p(ctx), d, 64, 1, H, rows, 64, d)
+    ref2 = torch.einsum("rhc,hec->rhe", ct.float(), wv.float().view(H, 64, d)).reshape(rows, d) + bv
+    torch.cuda.synchronize()
+    assert (ctx.float() - ref2).abs().max().item() < 3e-2
