@@ -80,6 +80,10 @@ def kernel_model(tag, eng, B, dtype):
         return dict(bytes=B * (ff * es + 3 * d * 4) + d * ff * es, flops=2.0 * B * d * ff, bound="mfma")
     if tag == "step_qkv_gemm":
         return dict(bytes=B * (d * 4 + d * 4 + 2 * d * es) + 3 * d * d * es, flops=2.0 * B * d * 3 * d, bound="mfma")
+    if tag == "step_add_ln":       # fp32 GEMM output + fp32 residual in, fp32 + bf16 mirror out
+        return dict(bytes=B * d * (4 + 4 + 4 + 2), flops=8.0 * B * d, bound="hbm")
+    if tag == "step_update_embed":  # word row + position row in, fp32 + bf16 activations out (+ the arg-max partials)
+        return dict(bytes=B * d * (4 + 4 + 4 + 2), flops=8.0 * B * d, bound="hbm")
     if tag == "cross_kv_gemm":
         return dict(bytes=B * Lk * (d * 4 + 2 * d * es) + 2 * d * d * es, flops=2.0 * B * Lk * d * 2 * d, bound="mfma")
     return None
@@ -95,15 +99,13 @@ def _timed(fn, iters):
     return (time.perf_counter() - t0) / iters
 
 
-def extra_legs(dev, main_dtype):
+def extra_legs(dev, main_dtype, legs):
     """The other operating points of BASELINE.json / VERDICT, measured in the same process after the
     headline run (rank 0, N = 1 only): each is `captions/s` of whole passes over synthetic clips
     resident in HBM, hipGraph replay, measured over >= 5 passes after 3 warm-up calls."""
     from care_amd import get_framework
     from care_amd.configs import feat_shapes, make_opt
     from care_amd.synth import synth_state_dict
-
-    legs = {}
 
     import gc
 
@@ -405,6 +407,7 @@ def main():
     tagged_ms = sum(k["total_ms"] for k in kernels.values())
     # decoder-step time: the 29 steps' tagged kernels (event-measured) per step
     step_tags = [t for t in kernels if t.startswith("step_")]
+    step_tags = [t for t in step_tags if kernel_model(t, eng, B, args.dtype) is not None]
     dom = max(step_tags, key=lambda t: kernels[t]["total_ms"])
     km = kernel_model(dom, eng, B, args.dtype)
     # `achieved` uses the IN-SITU duration: the average over the kernel's launches inside the
@@ -531,7 +534,14 @@ def main():
     if world == 1 and not args.no_legs and args.beam == 1:
         del model, eng, feats
         torch.cuda.empty_cache()
-        line["legs"] = extra_legs(dev, args.dtype)
+        legs = {}
+        try:   # a leg that fails (e.g. no pinned host memory on the box) must not take the headline line with it
+            extra_legs(dev, args.dtype, legs)
+        except Exception as exc:  # noqa: BLE001 - reported in the line
+            import traceback
+            legs["error"] = "{}: {}".format(type(exc).__name__, exc)
+            legs["error_where"] = traceback.format_exc().strip().splitlines()[-3:]
+        line["legs"] = legs
     print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

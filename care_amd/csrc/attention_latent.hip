@@ -606,6 +606,181 @@ int launch_latent2(const LatArgs& p, hipStream_t st) {
   return care_launch_status();
 }
 
+
+// ------------------------------------------------------------------ few rows (a launch-latency-bound decode step)
+// With one row per wave and at most one wave per row-slot of the chip, the single-wave kernel above is a latency chain:
+// six or eight chunks, each requested one chunk ahead (*measured* by rocprofv3 inside the replayed graph: 17 us at 1
+// row, 20 us at 128 rows - the longest kernel of a small-batch decode step).  This variant is the SAME arithmetic in
+// the SAME order (chunk after chunk, the same lazy-reference softmax: bit-identical outputs) with the row's query
+// stage and its first PF = 3 chunks in flight at once (64 LDS-DMA instructions, the 6-bit vmcnt's reach) and every
+// later chunk requested three ahead: one wave per workgroup, a ring of PF + 1 chunk slots + the query slot.  Single
+// items per wave only (rows <= workgroups): no cross-row prefetch, no store accounting.
+template <int PF>
+__global__ __launch_bounds__(64, 1) void attention_latent_few_kernel(LatArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NCS = PF + 1;                 // chunk slots
+  const int lane = threadIdx.x & 63;
+  unsigned char* ring = smem;                 // [NCS chunk slots][query slot]
+  float* sbias = reinterpret_cast<float*>(smem + (NCS + 1) * CH_BYTES);  // [16][128]
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nch = (p.nkeys + CH_KEYS - 1) / CH_KEYS;
+  const int row = blockIdx.x;
+  const int ncols = p.heads;
+  const int nq = ncols <= 8 ? 8 : 16;
+
+  auto stage = [&](int c, int slot) {
+    const bf16_t* base = p.mem + (int64_t)(row / p.rows_per_kv) * p.mem_bs;
+#pragma unroll
+    for (int i = 0; i < CH_KEYS; ++i) {
+      const int key = min(c * CH_KEYS + i, p.nkeys - 1);
+      const unsigned char* g = reinterpret_cast<const unsigned char*>(base + (int64_t)key * p.mem_rs) + ((lane ^ lat_swz(i)) << 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(ring + slot * CH_BYTES + i * 1024), 16, 0, 0);
+    }
+  };
+  // query stage first (it is needed first), then the first PF chunks
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i >= nq) break;
+    const int hcol = min(i, ncols - 1);
+    const unsigned char* g = reinterpret_cast<const unsigned char*>(p.qt + (int64_t)row * p.ldq + hcol * LAT_D) + ((lane ^ lat_swz(i)) << 4);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(ring + NCS * CH_BYTES + i * 1024), 16, 0, 0);
+  }
+#pragma unroll
+  for (int c = 0; c < PF; ++c)
+    if (c < nch) stage(c, c);
+  const int issued0 = min(PF, nch);
+
+  int roff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) roff[r] = fr * 1024 + ((((r * 4 + fg) ^ lat_swz(fr)) & 15) << 4);
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  const int trow = fg * 4 + tq;
+  int toff[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) toff[m] = trow * 1024 + ((((m * 2 + (tp >> 1)) ^ lat_swz(trow)) & 15) << 4) + 8 * (tp & 1);
+  const int frq = fr < nq ? fr : fr - 8;
+  int qoff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) qoff[r] = frq * 1024 + ((((r * 4 + fg) ^ lat_swz(frq)) & 15) << 4);
+  const int headc = fr < ncols ? fr : 0;
+
+  for (int i = lane; i < 16 * 128; i += 64) {   // ordinary loads: they retire BEHIND the DMAs issued above (in-order vmcnt)
+    const int h = min(i >> 7, p.heads - 1), key = i & 127;
+    sbias[i] = key < p.nkeys ? (p.bias ? p.bias[h * p.bias_ld + key] : 0.f) : -INFINITY;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // one wave per workgroup: no barrier needed
+  __builtin_amdgcn_sched_barrier(0);
+  (void)issued0;
+
+  bf16x8 qf[16];
+  {
+    const unsigned char* sq = ring + NCS * CH_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(sq + qoff[ks & 3] + (ks >> 2) * 256);
+  }
+  f32x4 acc[32];
+#pragma unroll
+  for (int m = 0; m < 32; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_ref = -INFINITY, l_part = 0.f;
+
+  for (int c = 0; c < nch; ++c) {
+    const int slot = c % NCS;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of chunk c - 1 (whose slot is re-staged now) are done
+    if (c >= 1 && c + PF - 1 < nch && c + PF - 1 >= PF) stage(c + PF - 1, (c + PF - 1) % NCS);
+    // chunk c has landed when only the younger chunks' DMAs are outstanding
+    {
+      const int younger = min(c + PF - 1, nch - 1) - c;   // chunks requested after chunk c (0 .. PF - 1)
+      if (c < PF) {
+        // chunks 0 .. PF - 1 were all waited for together with the bias loads above
+      } else if (younger >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* sb = ring + slot * CH_BYTES;
+
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + roff[ks & 3] + (ks >> 2) * 256);
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s, 0, 0, 0);
+    }
+    s += *reinterpret_cast<const f32x4*>(sbias + headc * 128 + c * CH_KEYS + fg * 4);
+    float cm = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+    cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+    if (__any(cm > m_ref + 16.0f)) {
+      const float m_new = fmaxf(m_ref, cm);
+      const float alpha = __expf(m_ref - m_new);
+      m_ref = m_new;
+      l_part *= alpha;
+#pragma unroll
+      for (int m = 0; m < 32; ++m) acc[m] *= alpha;
+    }
+    s16x4 pb;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pr = __expf(s[r] - m_ref);
+      psum += pr;
+      const bf16_t h = (bf16_t)pr;
+      pb[r] = __builtin_bit_cast(short, h);
+    }
+    l_part += psum;
+    const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sb;
+    unsigned tad[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) tad[m] = sbase + toff[m];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      s16x4 a[8];
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8 offset:%16\n\t"
+          "ds_read_b64_tr_b16 %1, %9 offset:%16\n\t"
+          "ds_read_b64_tr_b16 %2, %10 offset:%16\n\t"
+          "ds_read_b64_tr_b16 %3, %11 offset:%16\n\t"
+          "ds_read_b64_tr_b16 %4, %12 offset:%16\n\t"
+          "ds_read_b64_tr_b16 %5, %13 offset:%16\n\t"
+          "ds_read_b64_tr_b16 %6, %14 offset:%16\n\t"
+          "ds_read_b64_tr_b16 %7, %15 offset:%16\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+          : "v"(tad[0]), "v"(tad[1]), "v"(tad[2]), "v"(tad[3]), "v"(tad[4]), "v"(tad[5]), "v"(tad[6]), "v"(tad[7]),
+            "n"(g * 256)
+          : "memory");
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        acc[g * 8 + m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[m], pb, acc[g * 8 + m], 0, 0, 0);
+    }
+  }
+
+  float l = l_part;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  if (fr < ncols) {   // lane (head fr, group fg) holds dims m * 16 + fg * 4 + 0..3: 8-byte stores (one row: nothing to coalesce with)
+    bf16_t* out = p.ct + (int64_t)row * p.ldc + headc * LAT_D + fg * 4;
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[m][r] * inv);
+      *reinterpret_cast<bf16x4*>(out + m * 16) = o;
+    }
+  }
+}
+
+int launch_latent_few(const LatArgs& p, hipStream_t st) {
+  constexpr int PF = 3;
+  constexpr int LDS = (PF + 2) * CH_BYTES + 16 * 128 * 4;
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&attention_latent_few_kernel<PF>), LDS, lds_ok)) return e;
+  hipLaunchKernelGGL((attention_latent_few_kernel<PF>), dim3(p.rows), dim3(64), LDS, st, p);
+  return care_launch_status();
+}
+
 template <int WAVES, int NSLOT>
 int launch_latent(const LatArgs& p, hipStream_t st) {
   constexpr int LDS = WAVES * NSLOT * CH_BYTES + 16 * 128 * 4;
@@ -642,6 +817,9 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
     static const int slots2 = [] { const char* e = getenv("CARE_LAT2_SLOTS"); return e ? atoi(e) : 2; }();
     return slots2 == 3 ? launch_latent2<3>(p, st) : launch_latent2<2>(p, st);
   }
+  // few rows: one wave per row with the whole head of the row's stream in flight (attention_latent_few_kernel)
+  static const int few_rows = [] { const char* e = getenv("CARE_LAT_FEW_ROWS"); return e ? atoi(e) : 256; }();
+  if (rows <= few_rows && !p.paired) return launch_latent_few(p, st);
   // tuning: 0 = 4 waves x 2 slots, 1 = 3 waves x 3 slots (read once; initialisation is thread-safe)
   static const int cfg = [] { const char* e = getenv("CARE_LAT_CFG"); return e ? atoi(e) : 0; }();
   if (cfg == 1) return launch_latent<3, 3>(p, st);

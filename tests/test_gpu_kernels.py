@@ -929,3 +929,29 @@ def test_gemm_tile_batched_head_projections(rows):
     ref2 = torch.einsum("rhc,hec->rhe", ct.float(), wv.float().view(H, 64, d)).reshape(rows, d) + bv
     torch.cuda.synchronize()
     assert (ctx.float() - ref2).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("rows,nkeys,H,use_bias", [(1, 84, 8, True), (128, 114, 8, True), (200, 28, 8, False), (256, 128, 8, True),
+                                                   (3, 16, 8, False), (77, 17, 4, True)])
+def test_attention_latent_few_rows_is_bit_identical_to_the_streaming_kernel(rows, nkeys, H, use_bias):
+    """Up to 256 rows the absorbed cross-attention runs one wave per row with the head of the row's stream in flight
+    (attention_latent_few_kernel): the same arithmetic in the same order as the streaming kernel - so a launch of
+    these rows alone equals, bit for bit, their slice of a 300-row launch (which takes the streaming kernel)."""
+    d = 512
+    big = 300
+    mem = _rand(big, nkeys, d, seed=11).to(torch.bfloat16)
+    qt = _rand(big, H, d, seed=12, scale=0.12).to(torch.bfloat16)
+    bias = _rand(H, nkeys, seed=13, scale=0.7) if use_bias else None
+    out_big = torch.full((big, H, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    out_few = torch.full((rows, H, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    args = lambda o, n: (_p(qt), H * d, _p(mem), nkeys * d, d, 1, nkeys, _p(bias), nkeys, _p(o), H * d, n, H, d)
+    _call("care_attention_latent", *args(out_big, big))
+    _call("care_attention_latent", *args(out_few, rows))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out_few.float()).all()
+    assert torch.equal(out_few, out_big[:rows])
+    s = torch.einsum("rhc,rjc->rhj", qt.float(), mem.float())
+    if use_bias:
+        s = s + bias[None]
+    ref = torch.einsum("rhj,rjc->rhc", torch.softmax(s, -1), mem.float())
+    assert (out_big.float() - ref).abs().max().item() < 1.2e-2 * max(1.0, ref.abs().max().item())
