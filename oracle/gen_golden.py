@@ -52,6 +52,9 @@ CASES = [
     ("base_ami_mte_b2", "base_ami_mte", 2, 22, {}, {}),
     ("msrvtt_cabase_b3", "msrvtt_cabase", 3, 23, {}, {VOCAB_W: {EOS_ROW: 4.0}}),
     ("msrvtt_cabase_beam5_b2", "msrvtt_cabase", 2, 24, {"beam_size": 5}, {VOCAB_W: {EOS_ROW: 3.5}}),
+    # CABase under beam search with captions that run on (EOS x 2.5: winners of 11, 8 and 26 tokens): the third attention
+    # block over the concept rows across many beam re-orderings (the _b2 case above ends after 3 tokens)
+    ("msrvtt_cabase_beam5_long_b3", "msrvtt_cabase", 3, 41, {"beam_size": 5, "topk": 2}, {VOCAB_W: {EOS_ROW: 2.5}}),
     ("msrvtt_care_beam5_topk8_b4", "msrvtt_care_beam5", 4, 15, {"topk": 8}, {VOCAB_W: {EOS_ROW: 4.0, PAD_ROW: 3.0}}),
     ("msrvtt_base_ami_peaked_b4", "msrvtt_base_ami", 4, 189, {}, PEAKED),
     ("msrvtt_care_peaked_b3", "msrvtt_care", 3, 373, {}, PEAKED),
