@@ -466,6 +466,10 @@ class HipEngine:
              nslab, x.stride(0) if nslab > 1 else 0, tag=tag)
         return out
 
+    # Unfused FFN2 (K = ff) from this many rows on the LDS-tiled kernel (one product over the whole K, no slabs) instead of
+    # the split-K slabs of the A-stationary kernel
+    FFN2_TILE_MIN_ROWS = 1 << 30
+
     def ln_fusable(self, rows: int) -> bool:
         """Whether dense -> (+res) -> LayerNorm runs as ONE kernel (csrc/gemm_ln.hip): bf16 mode,
         d_model = 512, and enough 64-row panels to occupy the chip (below ~10 K rows the A-stationary
@@ -546,7 +550,7 @@ class HipEngine:
             # dense2 + bias + residual + LayerNorm in one kernel: no split-K slabs at all
             return self.gemm_ln(h, w2, w[name + "_b2"], x, w[name + "_g"], w[name + "_be"], out, outb,
                                 tag=(gemm_tag + "_ln") if gemm_tag else None, Wp=w.get(name + "_w2#packed"), **ln_kw)
-        if split:
+        if split and rows < int(os.environ.get("CARE_FFN2_TILE_ROWS", str(self.FFN2_TILE_MIN_ROWS))):
             # K = ff > 512: split K over blocks into fp32 slabs; the LayerNorm kernel sums them
             ns = self.ff // 512
             f = self.ws(tag + "fslab", (ns, rows, d))

@@ -172,3 +172,41 @@ def test_sharding_bounds_and_records():
     assert rec.shape == (3, 33) and rec[2].abs().sum() == 0
     f, l, s = unpack_records(rec)
     assert torch.equal(f, fed) and l.tolist() == [5, 7] and s.tolist() == [-1.5, -2.25]
+
+
+def test_graph_cache_is_lru_capped_per_kind():
+    """engine._graph_put / _graph_get (no GPU needed): per-kind caps, least recently used entries go first, "seen"
+    markers count like graphs, other kinds are untouched."""
+    from care_amd.configs import make_opt
+    from care_amd.engine import HipEngine
+
+    eng = HipEngine(make_opt("msrvtt_base_ami"), "bf16")
+    cap = eng.GRAPH_CAPS["gseg0"]
+    for i in range(cap + 5):
+        eng._graph_put(("gseg0", i), "seen")
+    assert [k[1] for k in eng._graphs if k[0] == "gseg0"] == list(range(5, cap + 5))
+    assert eng._graph_get(("gseg0", 5)) == "seen"            # touched: now the most recent
+    eng._graph_put(("gseg0", 999), ("graph", "out"))
+    kept = [k[1] for k in eng._graphs if k[0] == "gseg0"]
+    assert 5 in kept and 6 not in kept and kept[-1] == 999 and len(kept) == cap
+    for i in range(200):
+        eng._graph_put(("gseg", 0, i), "seen")
+    assert sum(1 for k in eng._graphs if k[0] == "gseg") == eng.GRAPH_CAPS["gseg"]
+    assert sum(1 for k in eng._graphs if k[0] == "gseg0") == cap
+    assert eng._graph_get(("nope",)) is None
+
+
+def test_compute_modes_and_shape_routing_flags():
+    from care_amd.configs import make_opt
+    from care_amd.engine import HipEngine
+
+    base = HipEngine(make_opt("msrvtt_base_ami"), "bf16")
+    assert base.as_ok and base.bf_act and base.latent_capable and not base.split3
+    large = HipEngine(make_opt("vatex_care_large"), "bf16")
+    assert not large.as_ok and large.bf_act and large.latent_capable          # tile GEMMs, two-wave absorbed attention
+    median = HipEngine(make_opt("care_median_gelu"), "bf16")
+    assert not median.as_ok and median.bf_act and not median.latent_capable   # 12 heads: projected K/V
+    x3 = HipEngine(make_opt("msrvtt_care"), "fp16x3")
+    assert x3.split3 and not x3.bf and x3.wt == torch.float32 and not x3.bf_act
+    with pytest.raises(ValueError):
+        HipEngine(make_opt("msrvtt_care"), "fp8")
