@@ -52,15 +52,23 @@ __device__ __forceinline__ void t_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory");
 }
 
-template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false>
+// BK = K elements per ring stage: 64 (128-byte LDS rows, two MFMA k-steps per stage) or 32 (64-byte rows, one k-step:
+// twice the stages in the same LDS, i.e. more K steps of prefetch for the same bytes in use).  Swizzle of a 64-byte
+// row's four 16-byte chunks: chunk ^= G[(row >> 2) & 3], G = {0, 3, 2, 1} - the 16 lanes of every ds_read_b128 lane
+// group ({0-3, 12-15, 20-27}, ...) then fall on 16 different 16-byte slots of the 256-byte bank row.
+template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false, int BK = 64>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
   constexpr int NW = WGM * WGN, BM = 64 * WTM * WGM, BN = 64 * WGN;
   constexpr int MT = 4 * WTM;             // 16-row accumulator tiles of a wave (its (64 WTM) x 64 outputs)
-  constexpr int PIECES = (BM + BN) / 8;   // 1-KB DMA pieces (8 rows x 128 B) of one K step
+  constexpr int ROWB = BK * 2;            // bytes of an LDS row
+  constexpr int RPP = 1024 / ROWB;        // rows per 1-KB DMA piece (one wave instruction)
+  constexpr int CPR = ROWB / 16;          // 16-byte chunks per row
+  constexpr int PIECES = (BM + BN) / RPP; // DMA pieces of one K step
   constexpr int P = PIECES / NW;          // pieces per wave and K step
+  static_assert(BK == 64 || BK == 32, "K step");
   static_assert(PIECES % NW == 0, "pieces must divide over the waves");
-  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
-  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  static_assert(STAGES >= 2 && STAGES <= 6, "ring depth");
+  constexpr int STAGE_BYTES = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -84,15 +92,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
   }
 
   // ---- staging: piece q = wave * P + i covers LDS rows 8 q .. 8 q + 7 of the stage image (A rows first)
-  const int prow = lane >> 3;
-  const int sc = ((lane & 7) ^ prow) << 4;  // source chunk of this lane's LDS slot (row & 7 == prow)
+  const int prow = lane / CPR;
+  // source chunk of this lane's LDS slot (the piece starts at a multiple of RPP rows: row & 7 == prow, (row >> 2) & 3 == (prow >> 2) & 3)
+  const int sc = (BK == 64 ? ((lane & 7) ^ prow) : ((lane & 3) ^ ((0x1230 >> (4 * ((prow >> 2) & 3))) & 3))) << 4;
   const unsigned char* src[P];
   bool is_a[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) {
-    is_a[i] = (wave * P + i) * 8 < BM;
-    const int R = (wave * P + i) * 8 + prow;
-    if ((wave * P + i) * 8 < BM) {
+    is_a[i] = (wave * P + i) * RPP < BM;
+    const int R = (wave * P + i) * RPP + prow;
+    if ((wave * P + i) * RPP < BM) {
       const int row = min(m0 + R, p.M - 1);  // clamped, never branched around: rows past M are not stored
       src[i] = reinterpret_cast<const unsigned char*>(p.A) + (int64_t)row * p.lda * 2 + sc;
     } else {
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
     const int kta = F16 ? kt - (kt >= p.a_wrap ? p.a_wrap : 0) : kt;  // split products: the A columns start over
 #pragma unroll
     for (int i = 0; i < P; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)((F16 && is_a[i]) ? kta : kt) * 128),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)((F16 && is_a[i]) ? kta : kt) * ROWB),
                                        (__attribute__((address_space(3))) void*)(smem + slot * STAGE_BYTES +
                                                                                  (wave * P + i) * 1024),
                                        16, 0, 0);
@@ -118,14 +127,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K >> 6;
+  const int nk = p.K / BK;
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue(s, s);
 
   const int fr = lane & 15, fg = lane >> 4;
-  const int a_row = (wm * 64 * WTM + fr) * 128, b_row = (BM + wn * 64 + fr) * 128;
-  const int sw0 = ((fg ^ (fr & 7)) << 4), sw1 = (((4 + fg) ^ (fr & 7)) << 4);
+  const int a_row = (wm * 64 * WTM + fr) * ROWB, b_row = (BM + wn * 64 + fr) * ROWB;
+  const int sw0 = BK == 64 ? ((fg ^ (fr & 7)) << 4) : ((fg ^ ((0x1230 >> (4 * ((fr >> 2) & 3))) & 3)) << 4);
+  const int sw1 = (((4 + fg) ^ (fr & 7)) << 4);
 
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_sched_barrier(0);  // the MFMAs of step kt - 1 (and the waits on their fragments) stay above the barrier
@@ -138,13 +148,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BK / 32; ++kk) {
       const int sw = kk ? sw1 : sw0;
       bf16x8 fa[MT], fb[4];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(st + b_row + n * 2048 + sw);
+      for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(st + b_row + n * 16 * ROWB + sw);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const bf16x8*>(st + a_row + m * 2048 + sw);
+      for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const bf16x8*>(st + a_row + m * 16 * ROWB + sw);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -263,18 +273,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
   }
 }
 
-template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false>
+template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false, int BK = 64>
 int launch_tile(TArgs& p, hipStream_t st, int batch = 1) {
   constexpr int BM = 64 * WTM * WGM, BN = 64 * WGN;
-  constexpr int lds = STAGES * (BM + BN) * 128;
+  constexpr int lds = STAGES * (BM + BN) * BK * 2;
+  if (BK == 32 && F16) p.a_wrap *= 2;  // a_wrap is handed over in K steps of 64
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   if (lds > 64 * 1024) {
     static std::atomic<unsigned long long> done{0};
-    const int rc = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16>), lds, done);
+    const int rc = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16, BK>), lds, done);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL((gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16>), dim3(p.tiles_m * p.tiles_n, batch), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16, BK>), dim3(p.tiles_m * p.tiles_n, batch), dim3(64 * WGM * WGN), lds, st, p);
   return care_launch_status();
 }
 
@@ -299,6 +310,10 @@ int dispatch(TArgs& p, hipStream_t st) {
     case 2222: return launch_tile<2, 2, 2, 2, EPI>(p, st);   // 256 x 128, 4 waves of 128 x 64
     case 2422: return launch_tile<2, 4, 2, 2, EPI>(p, st);   // 256 x 256, 8 waves of 128 x 64
     case 4412: return launch_tile<4, 4, 1, 2, EPI>(p, st);   // 256 x 256, 16 waves of 64 x 64
+    case 4414: return launch_tile<4, 4, 1, 4, EPI, false, 32>(p, st);   // ... K steps of 32, four stages
+    case 4413: return launch_tile<4, 4, 1, 3, EPI, false, 32>(p, st);
+    case 2224: return launch_tile<2, 2, 1, 4, EPI, false, 32>(p, st);   // 128 x 128, K steps of 32, four stages (64 KB)
+    case 2226: return launch_tile<2, 2, 1, 6, EPI, false, 32>(p, st);
     case 2223: return launch_tile<2, 2, 2, 3, EPI>(p, st);
     default: return launch_tile<2, 2, 1, 2, EPI>(p, st);
   }

@@ -720,7 +720,7 @@ TILE_SHAPES = [(1, 1024, 1024), (5, 10547, 1024), (64, 768, 768), (100, 3072, 10
 
 @pytest.mark.parametrize("M,N,K", TILE_SHAPES)
 @pytest.mark.parametrize("act,out_bf16", [(0, False), (1, True), (2, False)])
-@pytest.mark.parametrize("cfg", ["", "223", "42", "2222", "2422", "4412"])
+@pytest.mark.parametrize("cfg", ["", "223", "42", "2222", "2422", "4412", "4414", "2224"])
 def test_gemm_tile(M, N, K, act, out_bf16, cfg, monkeypatch):
     """csrc/gemm_tile.hip (bf16 A, bf16 W, any K % 64 == 0: the d_model 768 / 1024 layers) in every tile shape / ring
     depth, against torch on the same bf16 operands; ragged edges in M and N; nothing written outside the destination."""
@@ -768,7 +768,7 @@ def test_gemm_tile_split_destinations_and_odd_leading_dimension():
 
 
 @pytest.mark.parametrize("M,K", [(1, 1024), (3, 768), (129, 1024), (1000, 1024), (4096 + 7, 1024), (300, 512)])
-@pytest.mark.parametrize("cfg", ["", "42", "2422", "2223"])
+@pytest.mark.parametrize("cfg", ["", "42", "2422", "2223", "4414"])
 def test_gemm_tile_argmax(M, K, cfg, monkeypatch):
     """The fused vocabulary arg-max of the LDS-tiled kernel: per 64-column group (max, lowest arg-max, sum exp) and the
     label logit, reduced by care_greedy_update / care_score_partials, against the bf16 product in fp64; exact ties

@@ -18,7 +18,7 @@ def main():
               (4096 * 29, 1536, 512), (4096 * 29, 512, 2048), (128, 3072, 1024), (640, 4096, 1024)]
     if len(sys.argv) > 1:
         shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
-    cfgs = ["222", "422", "2222", "2223", "2422", "4412"]
+    cfgs = ["222", "4412", "4413", "4414", "2224", "2226"]
     p = lambda t: t.data_ptr()
     for M, N, K in shapes:
         A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
@@ -36,7 +36,7 @@ def main():
                                             M, N, K, 0))
             line += " %s: %7.1f us %6.1f TF |" % (cfg, t, fl / t / 1e6)
         if N > 8192:
-            for cfg in ("222", "2422"):
+            for cfg in ("4412", "4414"):
                 os.environ["CARE_TILE_CFG"] = cfg
                 t = time_call(lambda: _lib.call("care_gemm_tile_argmax", p(A), K, p(W), p(pm), p(pi), p(ps), None, None, M, N, K))
                 line += " argmax %s: %7.1f us %6.1f TF |" % (cfg, t, fl / t / 1e6)
