@@ -497,3 +497,54 @@ def test_caches_stay_bounded_over_many_batch_shapes():
     assert sum(1 for k in eng._graphs if k[0] == "gseg") <= eng.GRAPH_CAPS["gseg"]
     again = _greedy(model, [f[:300].contiguous() for f in feats], use_graph=True)
     assert all(torch.equal(a, b) for a, b in zip(ref, again))
+
+
+def test_bf16_features_and_pinned_prefetch_give_the_same_captions():
+    """A model without a concept head multiplies bf16-rounded features anyway: bf16 feature tensors (half the PCIe / HBM
+    bytes, `engine.feats_bf16_ok`) give bit-identical captions and scores to the fp32 tensors of the same values; the
+    prefetcher hands pinned batches (fp32 or bf16) straight to the device; a concept model widens bf16 features."""
+    from care_amd.data import FeaturePrefetcher
+
+    boost = {"cls_head.tgt_word_prj.weight": {3: 4.0}}
+    opt, P, model, feats = _setup("msrvtt_base_ami", 700, "bf16", boost=boost)
+    eng = model.engine()
+    assert eng.feats_bf16_ok
+    fb = [f.to(torch.bfloat16) for f in feats]
+    ref = _greedy(model, [f.float() for f in fb], use_graph=False)      # fp32 tensors holding bf16-representable values
+    got = _greedy(model, fb, use_graph=False)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    host = [[f.cpu().pin_memory() for f in fb], [f.float().cpu().pin_memory() for f in fb], [f.cpu() for f in fb]]
+    for dev_feats in FeaturePrefetcher(host * 2, "cuda:0"):
+        out = _greedy(model, dev_feats, use_graph=True)
+        assert all(torch.equal(a, b) for a, b in zip(ref, out))
+    # a concept model needs the fp32 split products: bf16 tensors are widened, not consumed as they are
+    opt2, P2, model2, feats2 = _setup("msrvtt_care", 64, "bf16", boost=boost)
+    assert not model2.engine().feats_bf16_ok
+    a = _greedy(model2, [f.to(torch.bfloat16) for f in feats2])
+    b = _greedy(model2, [f.to(torch.bfloat16).float() for f in feats2])
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 512), ("msrvtt_care", 256)])
+def test_fp16x3_batch_composition_early_exit_and_beam(config, B):
+    """The fp16x3 mode through the same machinery as the other two: graph replay == eager, chunks of a batch reproduce
+    it, early exit + compaction == the fixed 29 steps, beam size 1 == greedy."""
+    boost = {"cls_head.tgt_word_prj.weight": {3: 4.0, 0: 3.0}}
+    opt, P, model, feats = _setup(config, B, "fp16x3", boost=boost)
+    eng = model.engine()
+    assert eng.split3
+    fed, length, score = _greedy(model, feats)
+    for use_graph in (True, True, True):
+        f2, l2, s2 = _greedy(model, feats, use_graph=use_graph)
+        assert torch.equal(fed, f2) and torch.equal(length, l2) and torch.equal(score, s2)
+    _, f3, l3, s3 = eng.translate_greedy(feats, use_graph=False, early_exit=False)
+    assert torch.equal(l3, length) and (s3 - score).abs().max().item() < 1e-4
+    for i in range(B):
+        k = int(length[i]) + 1
+        assert torch.equal(f3[i, :k], fed[i, :k])
+    sub = [f[100:164].contiguous() for f in feats]
+    f_s, l_s, s_s = _greedy(model, sub)
+    assert torch.equal(l_s, length[100:164]) and (s_s - score[100:164]).abs().max().item() < 1e-4
+    _, nfin, fscore, flen, fhyp = eng.translate_beam(feats, 1, 1, use_graph=False)
+    assert torch.all(nfin == 1) and torch.equal(flen[:, 0], length)
+    assert (fscore[:, 0] - score).abs().max().item() < 1e-4
