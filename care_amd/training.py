@@ -19,7 +19,8 @@ torch itself only moves data (transposes, zero padding to the kernels' K % 32, c
 autograd engine (which also sums the gradients of a tensor with several consumers).  fp32 arithmetic; the module's
 own nn.Parameters are the operands, so `loss.backward()` fills their `.grad` and any torch optimiser steps them.
 
-Scope: the `Embedder` encoder and every decoder variant of the hot path (Base, CARE, CABase); the training-only
+Scope: the `Embedder` and `MultiTransformerEncoder` encoders and every decoder variant of the hot path (Base, CARE,
+CABase); the training-only
 sparse-sampling branch of the concept head (pred_attribute.py:100-119, off by default) and scheduled sampling (RNN
 decoders only, Framework.py:221-232) are outside it, like in eval mode.
 """
@@ -287,8 +288,8 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("the model is on `{}`: move it to the MI355X (there is no CPU fallback)".format(dev))
-    if opt["encoder"] != "Embedder":
-        raise NotImplementedError("training mode covers the `Embedder` encoder (opts.py:31 default)")
+    if opt["encoder"] not in ("Embedder", "MultiTransformerEncoder"):
+        raise NotImplementedError("training mode covers the `Embedder` and `MultiTransformerEncoder` encoders")
     d, H = int(opt["dim_hidden"]), int(opt["num_attention_heads"])
     eps = float(opt["layer_norm_eps"])
     act = ACT_CODES[opt["hidden_act"]]
@@ -297,6 +298,23 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
     p_att = float(opt.get("attention_probs_dropout_prob", 0.1))
     seeds = _Seeds()
     drop = lambda x, p: _Dropout.apply(x, p, seeds.next()) if p > 0.0 else x
+
+    def mha(pre, xq, kv2, nseq, seq, n_keys, causal, pad_tok, bias):
+        """Post-LN multi-head attention sub-block (SubLayers.py:40-81) on [nseq * seq, d] queries."""
+        sd = pre + ".SDPA."
+        q = _Linear.apply(xq, P[sd + "query.weight"], P.get(sd + "query.bias"))
+        k = _Linear.apply(kv2, P[sd + "key.weight"], P.get(sd + "key.bias"))
+        v = _Linear.apply(kv2, P[sd + "value.weight"], P.get(sd + "value.bias"))
+        ctx_ = _Attention.apply(q, k, v, bias, pad_tok, nseq, seq, n_keys, H, causal, p_att, seeds.next())
+        o = drop(_Linear.apply(ctx_, P[pre + ".dense.weight"], P[pre + ".dense.bias"]), p_hid)
+        return _AddLN.apply(o, xq, P[pre + ".LayerNorm.weight"], P[pre + ".LayerNorm.bias"], eps)
+
+    def ffn(fp, x2):
+        """PositionwiseFeedForward (SubLayers.py:137-152), post-LN."""
+        h = _Act.apply(_Linear.apply(x2, P[fp + ".dense1.weight"], P[fp + ".dense1.bias"]), act)
+        f = drop(_Linear.apply(h, P[fp + ".dense2.weight"], P[fp + ".dense2.bias"]), p_hid)
+        return _AddLN.apply(f, x2, P[fp + ".LayerNorm.weight"], P[fp + ".LayerNorm.bias"], eps)
+
     modality = opt["modality"]
     dec_mod = opt.get("modality_for_decoder") or modality
     pred_mod = opt.get("modality_for_predictor") or modality
@@ -318,7 +336,17 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
         n = x.shape[1]
         pre = "encoder.Encoder_{}".format(ch.upper())
         h = _Linear.apply(x.view(B * n, x.shape[2]), P[pre + ".0.weight"], P[pre + ".0.bias"])
-        h = drop(_AddLN.apply(h, None, P[pre + ".1.weight"], P[pre + ".1.bias"], eps), p_enc)
+        if opt["encoder"] == "Embedder":
+            h = drop(_AddLN.apply(h, None, P[pre + ".1.weight"], P[pre + ".1.bias"], eps), p_enc)
+        else:  # TransformerEncoderBase (Encoder.py:244-298): + position, LayerNorm, dropout, unmasked self-attention + FFN layers
+            q1 = pre + ".1"
+            pos_e = P[q1 + ".position_embeddings.weight"] if opt.get("trainable_pe", False) else Bf[q1 + ".position_embeddings.pe"][0]
+            h = _AddPosSem.apply(h, pos_e[:n], None, n, n)
+            h = drop(_AddLN.apply(h, None, P[q1 + ".LayerNorm.weight"], P[q1 + ".LayerNorm.bias"], eps), p_hid)
+            for li in range(int(opt["num_hidden_layers_encoder"])):
+                lp = "{}.layers.{}".format(q1, li)
+                h = mha(lp + ".intra_attention", h, h, B, n, n, False, None, None)
+                h = ffn(lp + ".ffn", h)
         streams[ch] = h.view(B, n, d)
         means[ch] = _GroupMean.apply(h, n)
     mem = torch.cat([streams[ch] for ch in modality if ch in dec_mod], dim=1)
@@ -371,27 +399,15 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
     x = _AddPosSem.apply(x, pos_table[:t], sem_hidden, t, t)
     x = drop(_AddLN.apply(x, None, P[e + ".LayerNorm.weight"], P[e + ".LayerNorm.bias"], eps), p_hid)
 
-    def mha(pre, xq, kv2, n_keys, causal, pad_tok, bias):
-        sd = pre + ".SDPA."
-        q = _Linear.apply(xq, P[sd + "query.weight"], P.get(sd + "query.bias"))
-        k = _Linear.apply(kv2, P[sd + "key.weight"], P.get(sd + "key.bias"))
-        v = _Linear.apply(kv2, P[sd + "value.weight"], P.get(sd + "value.bias"))
-        ctx_ = _Attention.apply(q, k, v, bias, pad_tok, N, t, n_keys, H, causal, p_att, seeds.next())
-        o = drop(_Linear.apply(ctx_, P[pre + ".dense.weight"], P[pre + ".dense.bias"]), p_hid)
-        return _AddLN.apply(o, xq, P[pre + ".LayerNorm.weight"], P[pre + ".LayerNorm.bias"], eps)
-
     attr_att = bool(opt.get("use_attr", False)) and "att" in use_attr_type.lower()
     for li in range(int(opt["num_hidden_layers_decoder"])):
         lp = "decoder.layers.{}".format(li)
-        x1 = mha(lp + ".intra_attention", x, x, t, True, ids32, None)
-        x2 = mha(lp + ".inter_attention", x1, mem2, Lk, False, None, P.get(lp + ".inter_attention.SDPA.hybrid_bias"))
+        x1 = mha(lp + ".intra_attention", x, x, N, t, t, True, ids32, None)
+        x2 = mha(lp + ".inter_attention", x1, mem2, N, t, Lk, False, None, P.get(lp + ".inter_attention.SDPA.hybrid_bias"))
         if attr_att:
-            x2 = mha(lp + ".attr_attention", x2, sem_embs.reshape(B * topk, d), topk, False, None,
+            x2 = mha(lp + ".attr_attention", x2, sem_embs.reshape(B * topk, d), N, t, topk, False, None,
                      P.get(lp + ".attr_attention.SDPA.hybrid_bias"))
-        fp = lp + ".ffn"
-        h = _Act.apply(_Linear.apply(x2, P[fp + ".dense1.weight"], P[fp + ".dense1.bias"]), act)
-        f = drop(_Linear.apply(h, P[fp + ".dense2.weight"], P[fp + ".dense2.bias"]), p_hid)
-        x = _AddLN.apply(f, x2, P[fp + ".LayerNorm.weight"], P[fp + ".LayerNorm.bias"], eps)
+        x = ffn(lp + ".ffn", x2)
     hidden = drop(x, p_hid)  # Decoder/Transformer.py:236-237
     logits = _Linear.apply(hidden, P["cls_head.tgt_word_prj.weight"], None)
     out["hidden_states"] = hidden.view(N, t, d)
