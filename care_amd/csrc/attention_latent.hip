@@ -431,7 +431,6 @@ __global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) qoff[r] = frq * 1024 + ((((r * 4 + fg) ^ lat_swz(frq)) & 15) << 4);
   const int headc = fr < ncols ? fr : 0;
-  const bool col_ok = fr < ncols;
 
   for (int i = threadIdx.x; i < 16 * 128; i += 128) {
     const int h = min(i >> 7, p.heads - 1), key = i & 127;
@@ -592,7 +591,6 @@ __global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
         }
       }
     }
-    (void)col_ok;
   }
 }
 
@@ -650,7 +648,6 @@ __global__ __launch_bounds__(64, 1) void attention_latent_few_kernel(LatArgs p) 
 #pragma unroll
   for (int c = 0; c < PF; ++c)
     if (c < nch) stage(c, c);
-  const int issued0 = min(PF, nch);
 
   int roff[4];
 #pragma unroll
@@ -672,7 +669,6 @@ __global__ __launch_bounds__(64, 1) void attention_latent_few_kernel(LatArgs p) 
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // one wave per workgroup: no barrier needed
   __builtin_amdgcn_sched_barrier(0);
-  (void)issued0;
 
   bf16x8 qf[16];
   {

@@ -171,8 +171,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
 
   // ------------------------------------------------------------------ epilogue
   // acc[m][n][j] = out[row m0 + 64 WTM wm + 16 m + fr][column n0 + 64 wn + 16 fg + 4 n + j]
-  const int colw = n0 + wn * 64;          // first column of the wave
-  const int col0 = colw + fg * 16;        // first of this lane's 16 consecutive columns
+  const int col0 = n0 + wn * 64 + fg * 16;  // first of this lane's 16 consecutive columns
   if constexpr (EPI == EPI_STORE) {
     float bv[16];
 #pragma unroll
@@ -314,6 +313,10 @@ int dispatch(TArgs& p, hipStream_t st) {
     case 4413: return launch_tile<4, 4, 1, 3, EPI, false, 32>(p, st);
     case 2224: return launch_tile<2, 2, 1, 4, EPI, false, 32>(p, st);   // 128 x 128, K steps of 32, four stages (64 KB)
     case 2226: return launch_tile<2, 2, 1, 6, EPI, false, 32>(p, st);
+    case 122: return launch_tile<1, 2, 1, 2, EPI>(p, st);   // 64 x 128, 2 waves
+    case 123: return launch_tile<1, 2, 1, 3, EPI>(p, st);
+    case 212: return launch_tile<2, 1, 1, 2, EPI>(p, st);   // 128 x 64, 2 waves
+    case 242: return launch_tile<2, 4, 1, 2, EPI>(p, st);   // 128 x 256, 8 waves
     case 2223: return launch_tile<2, 2, 2, 3, EPI>(p, st);
     default: return launch_tile<2, 2, 1, 2, EPI>(p, st);
   }
