@@ -210,10 +210,7 @@ def extra_legs(dev, main_dtype, legs):
     labels = torch.randint(4, opt["vocab_size"], (Btf, eng.T), generator=gen, device=dev)
 
     def tf_score():
-        eng._begin_pass()
-        enc = eng.encode(feats)
-        return eng.score_teacher_forced(ids, labels, enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
-                                        sem_embs=enc.get("semantic_embs"))
+        return eng.metrics_step(feats, ids, labels)
 
     for _ in range(3):
         tf_score()
@@ -228,7 +225,7 @@ def extra_legs(dev, main_dtype, legs):
     timing, _lib_mod.TIMING = _lib_mod.TIMING, None
     tfk = {t: round(sum(s.elapsed_time(e) for s, e in ev), 3) for t, ev in timing.items()}
     legs["feedforward_step"] = dict(config="msrvtt_base_ami", dtype=main_dtype, clips_per_step=Btf, positions=T_,
-                                    what="encode + teacher-forced decoder over all positions + fused scoring (no logits in memory)",
+                                    what="engine.metrics_step: encode (lean) + teacher-forced decoder over all positions + fused scoring (no logits in memory)",
                                     clips_per_s=round(Btf / dt, 1), ms_per_pass=round(dt * 1e3, 3),
                                     gflop_per_clip=round(fl / 1e9, 4), tflops=round(fl * Btf / dt / 1e12, 1),
                                     frac_of_bf16_mfma_peak=round(fl * Btf / dt / 1e12 / MFMA_PEAK_TF["bf16"], 4),

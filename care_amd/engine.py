@@ -855,7 +855,8 @@ class HipEngine:
         """
         w, d = self.w, self.d
         N, t = input_ids.shape
-        mem = mem.to(self.device, torch.float32)
+        # a lean encode hands over the bf16 memory alone (metrics_step): it is the cross-K/V GEMM's operand as it stands
+        mem = mem.to(self.device) if (mem.dtype == torch.bfloat16 and self.bf_act) else mem.to(self.device, torch.float32)
         B, Lk = mem.shape[0], mem.shape[1]
         assert N % B == 0 and t <= self.T + 1
         per_clip = N // B
@@ -959,6 +960,18 @@ class HipEngine:
             lg = out["logits"].view(rows, self.V)
             call("care_score_logits", ptr(lg), lg.stride(0), self.V, ptr(lab32), ptr(logp), ptr(pred), rows)
         return logp.view(N, t), pred.view(N, t)
+
+    def metrics_step(self, feats: List[torch.Tensor], input_ids: torch.Tensor, labels: torch.Tensor):
+        """The eval metrics step (models/Wrapper.py:182-184 -> Framework.py:215-237 -> misc/Crit/crit_lang.py:75-103)
+        as ONE pass: encode + teacher-forced decoder + fused scoring.  Returns (logp [N, t], pred [N, t], enc):
+        the log-probability of every label token, the arg-max token, and the encoder outputs (with `preds_attr` for
+        the concept metrics).  A model without a concept head encodes lean - nothing of the fp32 memory or the frame
+        means is read by the scoring - and no [N * t, V] logits exist at any point."""
+        self._begin_pass()
+        enc = self.encode(self._prep_feats(feats), lean=not self.has_concepts)
+        logp, pred = self.score_teacher_forced(input_ids, labels, enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
+                                               sem_embs=enc.get("semantic_embs"))
+        return logp, pred, enc
 
     # ------------------------------------------------------------------ incremental decode step
     def _decode_step(self, t, N, rows_per_clip, tok, anc, sem, ckv, skv, Lk, tag, akv=None, embedded=False):
