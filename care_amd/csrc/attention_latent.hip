@@ -73,15 +73,21 @@ struct LatArgs {
 
 __device__ __forceinline__ int lat_swz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
 
-// s_waitcnt vmcnt(n) for a wave-uniform n in 16..32 (or 48); anything else waits for more (always safe)
+// s_waitcnt vmcnt(n) for a wave-uniform n in 0..32 (or 48); anything else waits for MORE than asked (always safe)
 __device__ __forceinline__ void lat_wait_vm(int n) {
   switch (n) {
 #define LAT_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    LAT_VM_CASE(0) LAT_VM_CASE(1) LAT_VM_CASE(2) LAT_VM_CASE(3) LAT_VM_CASE(4) LAT_VM_CASE(5) LAT_VM_CASE(6) LAT_VM_CASE(7)
+    LAT_VM_CASE(8) LAT_VM_CASE(9) LAT_VM_CASE(10) LAT_VM_CASE(11) LAT_VM_CASE(12) LAT_VM_CASE(13) LAT_VM_CASE(14)
+    LAT_VM_CASE(15) LAT_VM_CASE(16)
     LAT_VM_CASE(17) LAT_VM_CASE(18) LAT_VM_CASE(19) LAT_VM_CASE(20) LAT_VM_CASE(21) LAT_VM_CASE(22) LAT_VM_CASE(23)
     LAT_VM_CASE(24) LAT_VM_CASE(25) LAT_VM_CASE(26) LAT_VM_CASE(27) LAT_VM_CASE(28) LAT_VM_CASE(29) LAT_VM_CASE(30)
     LAT_VM_CASE(31) LAT_VM_CASE(32) LAT_VM_CASE(48)
 #undef LAT_VM_CASE
-    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    default:
+      if (n > 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      break;
   }
 }
 
@@ -368,71 +374,85 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
 }
 
 
-// ------------------------------------------------------------------ d_model = 1024 (16 heads): two waves per row
-// The same algorithm with the row's 1024 dims cut in two halves of 512: a workgroup of TWO waves owns a row, wave w
-// streams and multiplies dims [512 w, 512 w + 512) - its own ring, its own 64 query-fragment registers and 128
-// accumulators, exactly the single-wave kernel's footprint.  What the halves share is the score: each wave has the
-// partial dot products over its dims, they swap them through 2 x 1 KB of LDS (double-buffered by chunk parity, one raw
-// s_barrier per chunk - the DMAs in flight are not drained) and both add them (a + b == b + a in IEEE arithmetic), so
-// both take identical softmax decisions; the 16 heads fill the MFMA N axis.  Per row and step 114 x 2 KB of memory +
-// 2 x 32 KB of q~ / c~ instead of 2 x 114 x 2 KB of projected K and V.
-template <int NSLOT>
-__global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
+// ------------------------------------------------------------------ d_model = 1024 / 768: several waves per row
+// The same algorithm with the row's dims cut into NW slices of DW: a workgroup of NW waves owns a row, wave w streams and
+// multiplies dims [DW w, DW w + DW) - its own ring, its own query fragments and accumulators (NW = 2, DW = 512 for
+// d_model 1024: exactly the single-wave kernel's footprint per wave; NW = 3, DW = 256 for d_model 768: 512-byte LDS rows,
+// two key rows per LDS-DMA instruction).  What the slices share is the score: each wave has the partial dot products over
+// its dims, they swap them through NW x 1 KB of LDS (double-buffered by chunk parity, one raw s_barrier per chunk - the
+// DMAs in flight are not drained) and every wave adds the NW partials in the SAME order, so all take identical softmax
+// decisions; 16 / 12 heads fill the MFMA N axis.  Per row and step Lk x d x 2 B of memory + 2 x H x d x 2 B of q~ / c~
+// instead of 2 x Lk x d x 2 B of projected K and V.
+template <int NW, int DW, int NSLOT>
+__global__ __launch_bounds__(64 * NW, 1) void attention_latentN_kernel(LatArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int D2 = 1024;
+  constexpr int DN = NW * DW;              // d_model
+  constexpr int ROWB = DW * 2;             // bytes of an LDS row (a key's slice)
+  constexpr int RPI = 1024 / ROWB;         // key rows per LDS-DMA instruction
+  constexpr int NDMA = CH_KEYS / RPI;      // DMA instructions per chunk (and per query stage of 16 columns)
+  constexpr int CHB = CH_KEYS * ROWB;      // bytes of a chunk image
+  constexpr int KS = DW / 32;              // MFMA k-steps of the score product
+  constexpr int NACC = DW / 16;            // 16-dim accumulator tiles of the context
+  constexpr int CMASK = ROWB / 16 - 1;     // chunk-in-row mask of a DMA lane
+  static_assert(DW == 512 || DW == 256, "slice width");
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = which half of the dims
-  unsigned char* ring = smem + wave * (NSLOT * CH_BYTES);
-  float* sbias = reinterpret_cast<float*>(smem + 2 * NSLOT * CH_BYTES);              // [16][128]
-  float* xch = reinterpret_cast<float*>(smem + 2 * NSLOT * CH_BYTES + 16 * 128 * 4);  // [2 parities][2 waves][64 lanes][4]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = which slice of the dims
+  unsigned char* ring = smem + wave * (NSLOT * CHB);
+  float* sbias = reinterpret_cast<float*>(smem + NW * NSLOT * CHB);              // [16][128]
+  float* xch = reinterpret_cast<float*>(smem + NW * NSLOT * CHB + 16 * 128 * 4);  // [2 parities][NW waves][64 lanes][4]
   const int fr = lane & 15, fg = lane >> 4;
   const int nch = (p.nkeys + CH_KEYS - 1) / CH_KEYS;
   const int items = p.rows;
   const int ncols = p.heads;                // <= 16
-  const int nq = ncols <= 8 ? 8 : 16;
+  const int nq = (RPI == 1 && ncols <= 8) ? 8 : 16;   // LDS rows of a query stage
+  const int lrow = RPI == 1 ? 0 : (lane >> 5);        // row of a DMA instruction this lane copies
+  const int lchunk = lane & CMASK;
 
   auto stage = [&](int row, int c, int slot) {
-    const bf16_t* base = p.mem + (int64_t)(row / p.rows_per_kv) * p.mem_bs + wave * LAT_D;
+    const bf16_t* base = p.mem + (int64_t)(row / p.rows_per_kv) * p.mem_bs + wave * DW;
 #pragma unroll
-    for (int i = 0; i < CH_KEYS; ++i) {
-      const int key = min(c * CH_KEYS + i, p.nkeys - 1);
-      const unsigned char* g = reinterpret_cast<const unsigned char*>(base + (int64_t)key * p.mem_rs) + ((lane ^ lat_swz(i)) << 4);
+    for (int i = 0; i < NDMA; ++i) {
+      const int r = i * RPI + lrow;
+      const int key = min(c * CH_KEYS + r, p.nkeys - 1);
+      const unsigned char* g = reinterpret_cast<const unsigned char*>(base + (int64_t)key * p.mem_rs) + ((lchunk ^ lat_swz(r)) << 4);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(ring + slot * CH_BYTES + i * 1024), 16, 0,
+                                       (__attribute__((address_space(3))) void*)(ring + slot * CHB + i * 1024), 16, 0,
                                        CARE_LAT_LD_AUX);
     }
   };
   auto stage_q = [&](int row, int slot) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (i >= nq) break;
-      const int hcol = min(i, ncols - 1);
-      const unsigned char* g = reinterpret_cast<const unsigned char*>(p.qt + (int64_t)row * p.ldq + hcol * D2 + wave * LAT_D) +
-                               ((lane ^ lat_swz(i)) << 4);
+    for (int i = 0; i < NDMA; ++i) {
+      if (i * RPI >= nq) break;
+      const int r = i * RPI + lrow;
+      const int hcol = min(r, ncols - 1);
+      const unsigned char* g = reinterpret_cast<const unsigned char*>(p.qt + (int64_t)row * p.ldq + hcol * DN + wave * DW) +
+                               ((lchunk ^ lat_swz(r)) << 4);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(ring + slot * CH_BYTES + i * 1024), 16, 0,
+                                       (__attribute__((address_space(3))) void*)(ring + slot * CHB + i * 1024), 16, 0,
                                        CARE_LAT_Q_AUX);
     }
   };
+  const int nq_dma = (nq + RPI - 1) / RPI;   // DMA instructions of a query stage
 
   int roff[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) roff[r] = fr * 1024 + ((((r * 4 + fg) ^ lat_swz(fr)) & 15) << 4);
+  for (int r = 0; r < 4; ++r) roff[r] = fr * ROWB + ((((r * 4 + fg) ^ lat_swz(fr)) & 15) << 4);
   const int tq = (lane & 15) >> 2, tp = lane & 3;
   const int trow = fg * 4 + tq;
   int toff[8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) toff[m] = trow * 1024 + ((((m * 2 + (tp >> 1)) ^ lat_swz(trow)) & 15) << 4) + 8 * (tp & 1);
+  for (int m = 0; m < 8; ++m) toff[m] = trow * ROWB + ((((m * 2 + (tp >> 1)) ^ lat_swz(trow)) & 15) << 4) + 8 * (tp & 1);
   int woff[8];
 #pragma unroll
-  for (int mm = 0; mm < 8; ++mm) woff[mm] = fr * 1024 + ((((2 * mm + (fg >> 1)) ^ lat_swz(fr)) & 15) << 4) + 8 * (fg & 1);
+  for (int mm = 0; mm < 8; ++mm) woff[mm] = fr * ROWB + ((((2 * mm + (fg >> 1)) ^ lat_swz(fr)) & 15) << 4) + 8 * (fg & 1);
   const int frq = fr < nq ? fr : fr - 8;
   int qoff[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) qoff[r] = frq * 1024 + ((((r * 4 + fg) ^ lat_swz(frq)) & 15) << 4);
+  for (int r = 0; r < 4; ++r) qoff[r] = frq * ROWB + ((((r * 4 + fg) ^ lat_swz(frq)) & 15) << 4);
   const int headc = fr < ncols ? fr : 0;
 
-  for (int i = threadIdx.x; i < 16 * 128; i += 128) {
+  for (int i = threadIdx.x; i < 16 * 128; i += 64 * NW) {
     const int h = min(i >> 7, p.heads - 1), key = i & 127;
     sbias[i] = key < p.nkeys ? (p.bias ? p.bias[h * p.bias_ld + key] : 0.f) : -INFINITY;
   }
@@ -443,20 +463,20 @@ __global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
 
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int row = item;
-    bf16x8 qf[16];
+    bf16x8 qf[KS];
     {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       stage(row, 0, (t + 1) % NSLOT);
-      lat_wait_vm(16 + n_stored);
+      lat_wait_vm(NDMA + n_stored);   // the query has landed; younger: chunk 0 and, before it, the previous item's stores
       __builtin_amdgcn_sched_barrier(0);
-      const unsigned char* sq = ring + (t % NSLOT) * CH_BYTES;
+      const unsigned char* sq = ring + (t % NSLOT) * CHB;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(sq + qoff[ks & 3] + (ks >> 2) * 256);
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(sq + qoff[ks & 3] + (ks >> 2) * 256);
       ++t;
     }
-    f32x4 acc[32];
+    f32x4 acc[NACC];
 #pragma unroll
-    for (int m = 0; m < 32; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < NACC; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_ref = -INFINITY, l_part = 0.f;
 
     for (int c = 0; c < nch; ++c, ++t, par ^= 1) {
@@ -466,34 +486,39 @@ __global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (more_here) {
         stage(row, c + 1, (t + 1) % NSLOT);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        lat_wait_vm(NDMA);
       } else if (have_next) {
         stage_q(item + gridDim.x, (t + 1) % NSLOT);
-        if (nq == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        lat_wait_vm(nq_dma);
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
-      const unsigned char* sb = ring + slot * CH_BYTES;
+      const unsigned char* sb = ring + slot * CHB;
 
-      // ---- partial S^T over this wave's 512 dims, swapped with the other half's
+      // ---- partial S^T over this wave's dims, summed with the other slices' in a fixed order
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + roff[ks & 3] + (ks >> 2) * 256);
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s, 0, 0, 0);
       }
       {
         const unsigned xb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)xch;
-        const unsigned mine = xb + (unsigned)(((par * 2 + wave) * 64 + lane) * 16);
-        const unsigned other = xb + (unsigned)(((par * 2 + (wave ^ 1)) * 64 + lane) * 16);
-        f32x4 o;
+        const unsigned mine = xb + (unsigned)(((par * NW + wave) * 64 + lane) * 16);
         asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(mine), "v"(s) : "memory");
         __builtin_amdgcn_s_barrier();
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(other) : "memory");
+        f32x4 o[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const unsigned src = xb + (unsigned)(((par * NW + w) * 64 + lane) * 16);
+          asm volatile("ds_read_b128 %0, %1" : "=v"(o[w]) : "v"(src) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        s += o;
+        s = o[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += o[w];
       }
       s += *reinterpret_cast<const f32x4*>(sbias + headc * 128 + c * CH_KEYS + fg * 4);
 
@@ -506,7 +531,7 @@ __global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
         m_ref = m_new;
         l_part *= alpha;
 #pragma unroll
-        for (int m = 0; m < 32; ++m) acc[m] *= alpha;
+        for (int m = 0; m < NACC; ++m) acc[m] *= alpha;
       }
       s16x4 pb;
       float psum = 0.f;
@@ -524,7 +549,7 @@ __global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) tad[m] = sbase + toff[m];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < NACC / 8; ++g) {
         s16x4 a[8];
         asm volatile(
             "ds_read_b64_tr_b16 %0, %8 offset:%16\n\t"
@@ -546,15 +571,15 @@ __global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
       }
     }
 
-    // ---- normalise and store this wave's 512 dims of every head
+    // ---- normalise and store this wave's DW dims of every head
     float l = l_part;
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     n_stored = 0;
-    const unsigned ob = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(ring + ((t - 1) % NSLOT) * CH_BYTES);
+    const unsigned ob = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(ring + ((t - 1) % NSLOT) * CHB);
 #pragma unroll
-    for (int m = 0; m < 32; ++m) {
+    for (int m = 0; m < NACC; ++m) {
       bf16x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[m][r] * inv);
@@ -562,9 +587,10 @@ __global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned rb = ob + lane * 16;
+    // one instruction moves 1 KB of the staged image: one column (DW = 512) or two (DW = 256), each as whole lines
 #pragma unroll
-    for (int i0 = 0; i0 < 16; i0 += 8) {
-      if (i0 >= ncols) break;
+    for (int i0 = 0; i0 < NDMA; i0 += 8) {
+      if (i0 * RPI >= ncols) break;
       f32x4 v[8];
       asm volatile(
           "ds_read_b128 %0, %8 offset:%9\n\t"
@@ -581,12 +607,14 @@ __global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
           : "memory");
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int i = i0 + k;
-        if (i < ncols) {
-          unsigned char* dst = reinterpret_cast<unsigned char*>(p.ct + (int64_t)row * p.ldc + i * D2 + wave * LAT_D) +
-                               ((lane ^ lat_swz(i)) << 4);
-          if (CARE_LAT_ST_NT) __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(dst));
-          else *reinterpret_cast<f32x4*>(dst) = v[k];
+        const int i = (i0 + k) * RPI + lrow;   // the column this lane's 16 bytes belong to
+        if ((i0 + k) * RPI < ncols) {          // wave-uniform: the instruction holds at least one real column
+          if (i < ncols) {
+            unsigned char* dst = reinterpret_cast<unsigned char*>(p.ct + (int64_t)row * p.ldc + i * DN + wave * DW) +
+                                 ((lchunk ^ lat_swz(i)) << 4);
+            if (CARE_LAT_ST_NT) __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(dst));
+            else *reinterpret_cast<f32x4*>(dst) = v[k];
+          }
           ++n_stored;
         }
       }
@@ -594,16 +622,15 @@ __global__ __launch_bounds__(128, 1) void attention_latent2_kernel(LatArgs p) {
   }
 }
 
-template <int NSLOT>
-int launch_latent2(const LatArgs& p, hipStream_t st) {
-  constexpr int LDS = 2 * NSLOT * CH_BYTES + 16 * 128 * 4 + 2 * 2 * 64 * 16;
+template <int NW, int DW, int NSLOT>
+int launch_latentN(const LatArgs& p, hipStream_t st) {
+  constexpr int LDS = NW * NSLOT * CH_KEYS * DW * 2 + 16 * 128 * 4 + 2 * NW * 64 * 16;
   static std::atomic<unsigned long long> lds_ok{0};
-  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&attention_latent2_kernel<NSLOT>), LDS, lds_ok)) return e;
-  const int blocks = min(p.rows, 512);  // two 2-wave workgroups per CU
-  hipLaunchKernelGGL((attention_latent2_kernel<NSLOT>), dim3(blocks), dim3(128), LDS, st, p);
+  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&attention_latentN_kernel<NW, DW, NSLOT>), LDS, lds_ok)) return e;
+  const int blocks = min(p.rows, 512);  // two workgroups per CU
+  hipLaunchKernelGGL((attention_latentN_kernel<NW, DW, NSLOT>), dim3(blocks), dim3(64 * NW), LDS, st, p);
   return care_launch_status();
 }
-
 
 // ------------------------------------------------------------------ few rows (a launch-latency-bound decode step)
 // With one row per wave and at most one wave per row-slot of the chip, the single-wave kernel above is a latency chain:
@@ -796,7 +823,7 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
                                      int64_t mem_row_stride, int rows_per_kv, int nkeys, const float* bias,
                                      int bias_ld, void* ct, int64_t ldc, int rows, int heads, int d, void* stream) {
   if (!qt || !mem || !ct || rows <= 0 || heads <= 0 || nkeys <= 0 || rows_per_kv <= 0) return CARE_EINVAL;
-  if ((d != LAT_D && d != 2 * LAT_D) || heads > 16 || nkeys > 128) return CARE_ESHAPE;
+  if ((d != LAT_D && d != 2 * LAT_D && d != 768) || heads > 16 || nkeys > 128) return CARE_ESHAPE;
   if ((ldq % 8) || (ldc % 4) || (mem_batch_stride % 8) || (mem_row_stride % 8) || !care_aligned16(qt) ||
       !care_aligned16(mem) || !care_aligned16(ct) || mem_row_stride < LAT_D)
     return CARE_EALIGN;
@@ -808,10 +835,13 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
   static const int pair_ok = [] { const char* e = getenv("CARE_LAT_PAIR"); return e ? atoi(e) : 1; }();  // A/B switch
   p.paired = pair_ok && heads <= 8 && rows_per_kv > 1 && rows % rows_per_kv == 0;
   hipStream_t st = (hipStream_t)stream;
-  if (d == 2 * LAT_D) {  // d_model = 1024: two waves per row (attention_latent2_kernel)
+  if (d == 2 * LAT_D) {  // d_model = 1024: two waves per row, 512 dims each (attention_latentN_kernel)
     p.paired = 0;
-    static const int slots2 = [] { const char* e = getenv("CARE_LAT2_SLOTS"); return e ? atoi(e) : 2; }();
-    return slots2 == 3 ? launch_latent2<3>(p, st) : launch_latent2<2>(p, st);
+    return launch_latentN<2, 512, 2>(p, st);
+  }
+  if (d == 768) {        // d_model = 768: three waves per row, 256 dims each
+    p.paired = 0;
+    return launch_latentN<3, 256, 2>(p, st);
   }
   // few rows: one wave per row with the whole head of the row's stream in flight (attention_latent_few_kernel)
   static const int few_rows = [] { const char* e = getenv("CARE_LAT_FEW_ROWS"); return e ? atoi(e) : 256; }();

@@ -353,13 +353,13 @@ class HipEngine:
     @property
     def latent_capable(self) -> bool:
         """Shapes / dtype the absorbed cross-attention kernels cover: bf16 mode, head dim 64, d_model = 512 (one wave
-        per row; per-head projections in csrc/heads.hip) or 1024 (two waves per row, 16 heads; per-head projections as
-        one batched launch of the LDS-tiled GEMM)."""
+        per row; per-head projections in csrc/heads.hip), 1024 (two waves per row of 512 dims each) or 768 (three waves
+        of 256; per-head projections of both as one batched launch of the LDS-tiled GEMM)."""
         if self.H * 64 != self.d or self.H > 16:
             return False
-        if os.environ.get("CARE_LATENT_1024", "1") == "0" and self.d == 1024:
+        if os.environ.get("CARE_LATENT_WIDE", "1") == "0" and self.d != 512:
             return False
-        return (self.as_ok and self.d == 512) or (self.bf_act and self.d == 1024)
+        return (self.as_ok and self.d == 512) or (self.bf_act and self.d in (768, 1024))
 
     @property
     def latent_ok(self) -> bool:

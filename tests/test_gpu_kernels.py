@@ -550,8 +550,8 @@ def test_attention_latent_rejects_bad_arguments():
     mem = _rand(2, 20, d).to(torch.bfloat16)
     qt = _rand(2, H, d).to(torch.bfloat16)
     ct = torch.empty(2, H, d, device=DEV, dtype=torch.bfloat16)
-    with pytest.raises(_lib.CareHipError):  # d_model other than 512 / 1024
-        _call("care_attention_latent", _p(qt), H * d, _p(mem), 20 * d, d, 1, 20, None, 0, _p(ct), H * d, 2, H, 768)
+    with pytest.raises(_lib.CareHipError):  # d_model other than 512 / 768 / 1024
+        _call("care_attention_latent", _p(qt), H * d, _p(mem), 20 * d, d, 1, 20, None, 0, _p(ct), H * d, 2, H, 640)
     with pytest.raises(_lib.CareHipError):  # more than 128 keys
         _call("care_attention_latent", _p(qt), H * d, _p(mem), 20 * d, d, 1, 129, None, 0, _p(ct), H * d, 2, H, d)
     with pytest.raises(_lib.CareHipError):  # misaligned query
@@ -883,13 +883,14 @@ def test_attention_seq(nseq, seq, nkeys, per_kv, kind):
     assert (got - ref).abs().mean().item() < 3e-3
 
 
+@pytest.mark.parametrize("d", [1024, 768])
 @pytest.mark.parametrize("rows,nkeys,rows_per_kv,H,use_bias", [(1, 114, 1, 16, True), (300, 114, 1, 16, True), (77, 84, 1, 16, False),
                                                                 (4096 + 5, 114, 1, 16, True), (35, 57, 5, 16, True),
                                                                 (12, 40, 3, 12, False), (640, 114, 5, 16, True)])
-def test_attention_latent_d1024(rows, nkeys, rows_per_kv, H, use_bias):
-    """The two-waves-per-row form of the absorbed cross-attention (d_model = 1024: each wave owns 512 dims, the
-    partial scores cross through LDS) against torch on the same bf16 operands."""
-    d = 1024
+def test_attention_latent_d1024(rows, nkeys, rows_per_kv, H, use_bias, d):
+    """The several-waves-per-row form of the absorbed cross-attention (d_model = 1024: two waves of 512 dims; 768:
+    three waves of 256 dims, 12 heads; the partial scores cross through LDS) against torch on the same bf16 operands."""
+    H = H if d == 1024 else 12
     clips = (rows + rows_per_kv - 1) // rows_per_kv
     mem = _rand(clips, nkeys, d, seed=11).to(torch.bfloat16)
     qt = _rand(rows, H, d, seed=12, scale=0.09).to(torch.bfloat16)

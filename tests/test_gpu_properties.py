@@ -245,7 +245,7 @@ def test_benchmarked_operating_point_against_oracle_sample(config, B):
     """The code path bench.py times, end to end: bf16, lean encode, absorbed cross-attention, >= 10240
     rows (fused dense+LayerNorm in 128-row blocks, the 8-range vocabulary split), hipGraph replay - B = 32768 is
     bench.py's default batch; `vatex_care_large` / `care_median_gelu` (d_model 1024 / 768) run the LDS-tiled bf16
-    GEMMs of csrc/gemm_tile.hip, d_model 1024 with the two-waves-per-row absorbed cross-attention, 768 with projected K/V - on
+    GEMMs of csrc/gemm_tile.hip, with the several-waves-per-row absorbed cross-attention - on
     a model with peaked (trained-like) logits, audited against the CPU oracle on a 64-clip sample
     spread over the batch: a clip whose every reference step is decided by >= 0.1 must be bit-exact,
     any other divergence must start at a near-tie; replay == eager bit for bit.  B = 12345: ragged last
@@ -259,7 +259,7 @@ def test_benchmarked_operating_point_against_oracle_sample(config, B):
     if eng.d == 512:
         assert eng.latent_for(B) and eng.ln_fusable(B) == (B >= 10240)
     else:
-        assert eng.bf_act and not eng.as_ok and eng.latent_for(B) == (eng.d == 1024)
+        assert eng.bf_act and not eng.as_ok and eng.latent_for(B)
     runs = []
     for it in range(4):  # eager, first sight (eager), capture, replay
         _, fed, length, score = eng.translate_greedy(feats, use_graph=it > 0, lean=True)

@@ -205,7 +205,7 @@ def test_compute_modes_and_shape_routing_flags():
     large = HipEngine(make_opt("vatex_care_large"), "bf16")
     assert not large.as_ok and large.bf_act and large.latent_capable          # tile GEMMs, two-wave absorbed attention
     median = HipEngine(make_opt("care_median_gelu"), "bf16")
-    assert not median.as_ok and median.bf_act and not median.latent_capable   # 12 heads: projected K/V
+    assert not median.as_ok and median.bf_act and median.latent_capable       # three-wave absorbed attention
     x3 = HipEngine(make_opt("msrvtt_care"), "fp16x3")
     assert x3.split3 and not x3.bf and x3.wt == torch.float32 and not x3.bf_act
     with pytest.raises(ValueError):
