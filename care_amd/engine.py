@@ -426,9 +426,13 @@ class HipEngine:
                 call("care_gemm", ptr(A), A.stride(0), ptr(W), _code(W), *tail, tag=tag)
         return out
 
+    # up to this many rows the vocabulary arg-max of a d_model <= 512 model runs on the LDS-tiled kernel too (measured crossover
+    # between 2048 and 4096 rows on msrvtt_base_ami: 2048 rows 246 -> 241 us / step, 4096 rows 346 -> 356)
+    VOCAB_TILE_MAX_ROWS = int(os.environ.get("CARE_VOCAB_TILE_MAX_ROWS", "2048"))
+
     def vocab_parts(self, rows: int) -> int:
         """Column groups per row of the fused vocabulary arg-max for `rows` rows (the kernel vocab_argmax picks)."""
-        if self.as_ok:
+        if self.as_ok and rows > self.VOCAB_TILE_MAX_ROWS:
             return _lib.load().care_argmax_parts_bf16(rows, self.V)
         if self.bf_act or (self.split3 and self.w["vocab"].data_ptr() in self._w3):
             return _lib.load().care_argmax_parts_tile(self.V)
@@ -439,7 +443,7 @@ class HipEngine:
         (NaiveHead + log_softmax + top-1, Head.py:26-32 / Translator.py:127); the [rows, V] logits never exist.
         bf16, d <= 512: A-stationary kernels; bf16, larger d: the LDS-tiled kernel; fp32 mode: exact-f32 MFMA."""
         d, W = self.d, self.w["vocab"]
-        if self.as_ok:
+        if self.as_ok and rows > self.VOCAB_TILE_MAX_ROWS:
             call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels),
                  ptr(plab), rows, self.V, d, tag=tag)
         elif self.bf_act:
