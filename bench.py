@@ -86,6 +86,14 @@ def kernel_model(tag, eng, B, dtype):
         return dict(bytes=B * d * (4 + 4 + 4 + 2), flops=8.0 * B * d, bound="hbm")
     if tag == "cross_kv_gemm":
         return dict(bytes=B * Lk * (d * 4 + 2 * d * es) + 2 * d * d * es, flops=2.0 * B * Lk * d * 2 * d, bound="mfma")
+    if tag == "decode_resident":
+        # the whole decode of a small batch in one launch: per step every decoder weight and the vocabulary matrix once
+        # (bf16), per row the projected cross K/V and the self-attention cache so far; a latency-bound launch (grid
+        # barriers between phases), priced against HBM like the kernels it replaces
+        nl = eng.n_layers
+        wbytes = nl * (3 * d * d + d * d + 2 * d * d + 2 * d * ff) * 2 + V * d * 2
+        row = nl * (2 * Lk * d * 2 + 2 * ((T + 1) / 2) * d * 2)
+        return dict(bytes=T * (wbytes + B * row), flops=T * B * 2.0 * (nl * (6 * d * d + 2 * d * ff) + d * V), bound="hbm")
     return None
 
 
@@ -403,7 +411,7 @@ def main():
         kernels[tag] = dict(launches=len(ms), avg_us=1e3 * sum(ms) / len(ms), total_ms=sum(ms))
     tagged_ms = sum(k["total_ms"] for k in kernels.values())
     # decoder-step time: the 29 steps' tagged kernels (event-measured) per step
-    step_tags = [t for t in kernels if t.startswith("step_")]
+    step_tags = [t for t in kernels if t.startswith("step_") or t == "decode_resident"]
     step_tags = [t for t in step_tags if kernel_model(t, eng, B, args.dtype) is not None]
     dom = max(step_tags, key=lambda t: kernels[t]["total_ms"])
     km = kernel_model(dom, eng, B, args.dtype)

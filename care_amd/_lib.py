@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -67,6 +67,8 @@ SIGNATURES = {
     "care_beam_select": [_P, _L, _I, _I, _P, _P, _I, _P],
     "care_attention_probs": [_P, _L, _P, _I, _L, _L, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     "care_timestamp": [_P, _P],
+    "care_decode_resident": [_P, _I, _P, _P, _P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P,
+                             _P, _L, _I, _I, _P],
     "care_ln_bwd": [_P, _L, _P, _L, _P, _P, _L, _F, _P, _L, _P, _P, _I, _I, _P],
     "care_act": [_P, _P, _P, _L, _I, _P],
     "care_dropout": [_P, _P, _L, _F, _U, _P],
@@ -88,7 +90,22 @@ PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_argmax_
          "care_argmax_parts_bf16": (c_int, [c_int, c_int]),
          "care_argmax_parts_tile": (c_int, [c_int]),
          "care_argmax_parts_bf16_min": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-         "care_beam_sparse_applies": (c_int, [c_int, c_int, c_int, c_int])}
+         "care_beam_sparse_applies": (c_int, [c_int, c_int, c_int, c_int]),
+         "care_decode_resident_scratch": (c_int64, [c_int, c_int, c_int, c_int])}
+
+
+class ResidentAttn(ctypes.Structure):
+    """care_resident_attn (include/care_hip.h)."""
+    _fields_ = [("q_w", c_void_p), ("q_b", c_void_p), ("o_w", c_void_p), ("o_b", c_void_p), ("ln_g", c_void_p), ("ln_b", c_void_p),
+                ("kv", c_void_p), ("kv_batch_stride", c_int64), ("nkeys", ctypes.c_int32), ("rows_per_kv", ctypes.c_int32),
+                ("bias", c_void_p), ("bias_ld", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class ResidentLayer(ctypes.Structure):
+    """care_resident_layer (include/care_hip.h)."""
+    _fields_ = [("qkv_w", c_void_p), ("qkv_b", c_void_p), ("o_w", c_void_p), ("o_b", c_void_p), ("ln_g", c_void_p), ("ln_b", c_void_p),
+                ("self_kv", c_void_p), ("att", ResidentAttn * 2), ("n_att", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("ffn_g", c_void_p), ("ffn_b", c_void_p)]
 
 _lib = None
 

@@ -1,0 +1,717 @@
+// decode_resident.hip - the WHOLE greedy decode of a small batch as one resident launch.
+//
+// A decoder step of a small batch (1 .. a few hundred caption rows) is launch-bound: ~15 dependent kernels of
+// 4-5 us each (rocprofv3, profiles/r03_small_batch_*), none of which has more than a few microseconds of work.
+// Here one grid of <= one workgroup per CU stays resident for all T steps and walks the phases of a step
+// separated by grid barriers (one atomic counter, split arrive / wait): per decoder layer
+//
+//   QKV projection (+ token choice of the previous step + embedding) | self-attention | dense + residual |
+//   { query projection | attention over the static keys | dense + residual } per cross / attribute block |
+//   FFN dense1 + activation | FFN dense2 + residual | ... | vocabulary partial arg-max
+//
+// (reference: models/Decoder.py + models/components/Layers.py:157-228 driven step by step from
+// models/Translator.py:77-143; Head.py:26-32; the early exit of Translator.py:77-81 is the device-side
+// `all rows ended` counter, read by every workgroup after the same barrier).
+//
+// Layout of a phase:
+//   * GEMM phases: item = (16-row tile, 64-column group); a wave owns one 16x16 output tile over the whole K
+//     (K = 512 or ff): its W fragments (v_mfma_f32_16x16x32_bf16 A operand, 16 B per lane straight from the
+//     [N, K] row-major weight) are loaded BEFORE the wave waits at the barrier - the weights do not depend on
+//     the previous phase - and the 16 activation rows come through LDS as bf16.
+//   * LayerNorm is applied ON LOAD: a phase stores the pre-LayerNorm sum (dense + bias + residual, fp32) and
+//     every consumer normalises the 16 rows it needs (it reads all K columns anyway); the consumer of column
+//     group 0 also stores the normalised fp32 rows, the residual of the phase after next.
+//   * attention phases: one wave per (row, head), 8 key slots x 8 dim chunks per wave-wide 16-byte load (the
+//     layout of csrc/attention.hip), scores / softmax in registers.
+//   * the token choice (max / arg-max / sum-exp over the column-group partials; score, length, end flags) is
+//     folded into the first phase of the next step; the last step's choice runs after the loop.
+// Rounding points are those of the multi-launch bf16 path with projected cross K/V (bf16 A operands, K/V
+// caches and contexts, fp32 accumulators, LayerNorm and softmax statistics); sums run in another order.
+#include <atomic>
+#include <cstdlib>
+
+#include "care_common.h"
+
+namespace {
+
+constexpr int RES_MAX_LAYERS = 4;
+constexpr int RES_MAXKB = 16;  // key blocks of 8: <= 128 keys per attention
+
+struct RAttn {
+  const bf16_t* q_w; const float* q_b; const bf16_t* o_w; const float* o_b; const float* g; const float* be;
+  const bf16_t* kv; int64_t kv_bs; int nkeys, rows_per_kv; const float* bias; int bias_ld;
+};
+struct RLayer {
+  const bf16_t* qkv_w; const float* qkv_b; const bf16_t* o_w; const float* o_b; const float* g; const float* be;
+  bf16_t* skv;
+  RAttn att[2]; int n_att;
+  const bf16_t* w1; const float* b1; const bf16_t* w2; const float* b2; const float* fg; const float* fbe;
+};
+struct RArgs {
+  RLayer L[RES_MAX_LAYERS]; int n_layers;
+  const float *word, *pos, *sem; int sem_div; const float *emb_g, *emb_be; float eps;
+  const bf16_t* vocab; int V;
+  int d, H, ff, act, R, T, steps, bos, eos, pad, early, prof_step;
+  int32_t* fed; int fed_stride; float* score; int32_t* length; int32_t* fin;
+  unsigned* sync; float* xres; float* y; float* q; bf16_t* ctx; bf16_t* h;
+  float* pmax; int32_t* pidx; float* psum; int parts;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Data that one workgroup writes and another reads INSIDE the launch moves with agent-scope (sc1) accesses: stores
+// write through to the device's coherence point, loads miss the caches that are not coherent across XCDs (a CU's L1,
+// another XCD's L2) - relaxed 4- / 8-byte atomics, which is how the compiler spells them.  No cache-wide writeback or
+// invalidate is needed then, and that is the point: *measured* (tools/micro/barrier_bench.hip, 256 workgroups) a
+// barrier with __threadfence() on either side costs 17 us (one thread fences) to 39 us (every wave does), the
+// counters alone 3.7 us, two-level counters 1.9 us.  Weights, embeddings and the cross K/V (written before the
+// launch) use plain loads and stay in the L2s for all T steps.
+__device__ __forceinline__ unsigned long long cld8(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cst8(void* p, unsigned long long v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float cld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int cld_i(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cst_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cst_i(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+struct U2 { unsigned long long a, b; };
+__device__ __forceinline__ float4 cld_f4(const float* p) {
+  U2 u{cld8(p), cld8(p + 2)};
+  return __builtin_bit_cast(float4, u);
+}
+__device__ __forceinline__ void cst_f4(float* p, float4 v) {
+  const U2 u = __builtin_bit_cast(U2, v);
+  cst8(p, u.a);
+  cst8(p + 2, u.b);
+}
+__device__ __forceinline__ bf16x8 cld_b8(const bf16_t* p) {
+  U2 u{cld8(p), cld8(p + 4)};
+  return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ void cst_b8(bf16_t* p, bf16x8 v) {
+  const U2 u = __builtin_bit_cast(U2, v);
+  cst8(p, u.a);
+  cst8(p + 4, u.b);
+}
+__device__ __forceinline__ void cst_b4(bf16_t* p, bf16x4 v) { cst8(p, __builtin_bit_cast(unsigned long long, v)); }
+
+// grid barrier: arrive() at the end of a phase, wait() after the next phase has issued the loads that do not depend
+// on it.  Two levels of monotonic counters (8 groups by blockIdx % 8, the XCD round-robin; then one), the last
+// arriver publishes the generation in a flag of its own cache line, which is all the waiters poll.
+// sync (unsigned, 128-byte lines): [0] top counter, [1] rows ended, [2] steps run, [32] flag, [64 + 32 g] group g,
+// [320 ..] phase clocks (tools).
+struct GridSync {
+  unsigned* sync; unsigned nblk; unsigned gen;
+  int slot;  // >= 0: workgroup 0 records the device clock at the phase boundaries of one step (sync + 320, 8-byte slots)
+  __device__ __forceinline__ void mark() {
+    if (slot >= 0 && slot < 96 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(sync + 320)[slot++] = wall_clock64();
+  }
+  __device__ __forceinline__ void arrive() {
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's write-through stores are acknowledged
+    __syncthreads();
+    gen += 1;
+    if (threadIdx.x == 0) {
+      const unsigned grp = blockIdx.x & 7, ngrp = (nblk + 7 - grp) >> 3, ngroups = nblk < 8 ? nblk : 8;
+      const unsigned old = __hip_atomic_fetch_add(sync + 64 + grp * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == gen * ngrp - 1) {
+        const unsigned o2 = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (o2 == gen * ngroups - 1) __hip_atomic_store(sync + 32, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  __device__ __forceinline__ void wait() {
+    if (threadIdx.x == 0)
+      while (__hip_atomic_load(sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+  }
+};
+
+__device__ __forceinline__ float res_act(float v, int act) {
+  if (act == CARE_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == CARE_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+
+__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// (max, arg-max, sum exp) merge; ties go to the lower column
+__device__ __forceinline__ void amax_merge(float& m, int& i, float& s, float om, int oi, float os) {
+  const float nm = fmaxf(m, om);
+  const float a = m == -INFINITY ? 0.f : s * expf(m - nm);
+  const float b = om == -INFINITY ? 0.f : os * expf(om - nm);
+  if (om > m || (om == m && oi < i)) i = oi;
+  m = nm;
+  s = a + b;
+}
+
+// Wave-wide sum through the DPP data path (the scan of care_wave_max_dpp with + : row_shr 1, 2, 4, 8, then
+// row_bcast15 / row_bcast31; lanes without a source add 0); every lane gets the total.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define RES_DPP_ADD(CTRL, ROWMASK) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false))
+  RES_DPP_ADD(0x111, 0xF);
+  RES_DPP_ADD(0x112, 0xF);
+  RES_DPP_ADD(0x114, 0xF);
+  RES_DPP_ADD(0x118, 0xF);
+  RES_DPP_ADD(0x142, 0xA);
+  RES_DPP_ADD(0x143, 0xC);
+#undef RES_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+constexpr int RES_NP = 4;  // column-group partials per lane: V <= 64 * 64 * RES_NP
+
+// Token choice of step `ts` for the 4 rows r0 .. r0 + 3 of a wave (all lanes get the tokens): reduce the
+// column-group partials of the vocabulary phase (ties: the lowest column); WRITER: also advance the rows' state
+// (Translator.py:91-109 / the top-1 of Beam.advance).  Every load of the 4 rows is issued before the first use.
+template <bool WRITER>
+__device__ __forceinline__ void select4(const RArgs& p, int r0, int ts, int lane, int (&tok)[4]) {
+  float pm[4][RES_NP], ps[4][RES_NP];
+  int pi[4][RES_NP], fin[4];
+  float sc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + i;
+    const bool rok = r < p.R;
+#pragma unroll
+    for (int k = 0; k < RES_NP; ++k) {
+      const int c = lane + 64 * k;
+      const bool ok = rok && c < p.parts;
+      const int64_t o = (int64_t)(rok ? r : 0) * p.parts + (c < p.parts ? c : 0);
+      pm[i][k] = cld_f(p.pmax + o);
+      pi[i][k] = cld_i(p.pidx + o);
+      if (WRITER) ps[i][k] = cld_f(p.psum + o);
+      if (!ok) { pm[i][k] = -INFINITY; pi[i][k] = 0x7fffffff; if (WRITER) ps[i][k] = 0.f; }
+    }
+    if (WRITER) { fin[i] = cld_i(p.fin + (rok ? r : 0)); sc[i] = cld_f(p.score + (rok ? r : 0)); }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < RES_NP; ++k)
+      if (pm[i][k] > best || (pm[i][k] == best && pi[i][k] < bi)) { best = pm[i][k]; bi = pi[i][k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    tok[i] = bi;
+    if (WRITER) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < RES_NP; ++k) s += pm[i][k] == -INFINITY ? 0.f : ps[i][k] * expf(pm[i][k] - best);
+      s = wave_sum_dpp(s);
+      const int r = r0 + i;
+      if (lane == 0 && r < p.R) {
+        cst_i(p.fed + (int64_t)r * p.fed_stride + ts, bi);  // ended rows keep running, frozen
+        if (!fin[i]) {
+          cst_f(p.score + r, sc[i] - logf(s));
+          cst_i(p.length + r, ts);
+          if (bi == p.eos || ts >= p.T) {
+            cst_i(p.fin + r, 1);
+            __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+  }
+}
+
+enum { A_EMBED = 0, A_LN = 1, A_BF16 = 2 };
+enum { E_QKV = 0, E_Q = 1, E_RES = 2, E_ACT = 3, E_VOCAB = 4 };
+
+// 16 rows of the A operand -> LDS (bf16 [16][lda]), d = 512.  A_EMBED / A_LN: a wave owns 4 rows, a lane 2 float4 of
+// each; the rows stay in registers between the statistics and the normalisation (rowops.hip row_layernorm), all
+// loads of the 4 rows issued together.
+template <int AMODE>
+__device__ __forceinline__ void load_a_rows(const RArgs& p, int r0, int t, bool writer, const float* ysrc,
+                                            const float* g, const float* be, bool write_x, bf16_t* sA, int lda) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int d = 512;
+  const int rb = r0 + wave * 4;
+  float4 v[4][2];
+  if constexpr (AMODE == A_EMBED) {
+    int tok[4] = {p.bos, p.bos, p.bos, p.bos};
+    if (t > 1) {
+      if (writer) select4<true>(p, rb, t - 1, lane, tok);
+      else select4<false>(p, rb, t - 1, lane, tok);
+    } else if (writer) {  // state of fresh rows
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (rb + i < p.R) {
+          const int r = rb + i;
+          for (int c = lane; c <= p.T; c += 64) cst_i(p.fed + (int64_t)r * p.fed_stride + c, c == 0 ? p.bos : 0);
+          if (lane == 0) { cst_f(p.score + r, 0.f); cst_i(p.length + r, 0); cst_i(p.fin + r, 0); }
+        }
+    }
+    const float* pp = p.pos + (int64_t)(t - 1) * d;
+    const float4 p0 = *reinterpret_cast<const float4*>(pp + lane * 4), p1 = *reinterpret_cast<const float4*>(pp + 256 + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rb + i < p.R ? rb + i : 0;
+      const float* w = p.word + (int64_t)(rb + i < p.R ? tok[i] : 0) * d;
+      v[i][0] = *reinterpret_cast<const float4*>(w + lane * 4);
+      v[i][1] = *reinterpret_cast<const float4*>(w + 256 + lane * 4);
+      add4(v[i][0], p0);
+      add4(v[i][1], p1);
+      if (p.sem) {
+        const float* sm = p.sem + (int64_t)(r / p.sem_div) * d;
+        add4(v[i][0], *reinterpret_cast<const float4*>(sm + lane * 4));
+        add4(v[i][1], *reinterpret_cast<const float4*>(sm + 256 + lane * 4));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rb + i < p.R ? rb + i : 0;
+      v[i][0] = cld_f4(ysrc + (int64_t)r * d + lane * 4);
+      v[i][1] = cld_f4(ysrc + (int64_t)r * d + 256 + lane * 4);
+    }
+  }
+  const float4 g0 = *reinterpret_cast<const float4*>(g + lane * 4), g1 = *reinterpret_cast<const float4*>(g + 256 + lane * 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(be + lane * 4), b1 = *reinterpret_cast<const float4*>(be + 256 + lane * 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = wave * 4 + i, r = r0 + rr;
+    bf16_t* dst = sA + rr * lda;
+    if (r >= p.R) {  // rows past the batch: zeros into the tile
+      *reinterpret_cast<uint2*>(dst + lane * 4) = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(dst + 256 + lane * 4) = make_uint2(0u, 0u);
+      continue;
+    }
+    const float s = ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
+    const float mean = wave_sum_dpp(s) * (1.0f / d);
+    float qq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float a = v[i][c].x - mean, b = v[i][c].y - mean, cc = v[i][c].z - mean, e = v[i][c].w - mean;
+      qq += (a * a + b * b) + (cc * cc + e * e);
+    }
+    const float var = wave_sum_dpp(qq) * (1.0f / d);
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float4 gg = c ? g1 : g0, bb = c ? b1 : b0;
+      float4 o;
+      o.x = (v[i][c].x - mean) * rstd * gg.x + bb.x;
+      o.y = (v[i][c].y - mean) * rstd * gg.y + bb.y;
+      o.z = (v[i][c].z - mean) * rstd * gg.z + bb.z;
+      o.w = (v[i][c].w - mean) * rstd * gg.w + bb.w;
+      bf16x4 ob;
+      ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
+      *reinterpret_cast<bf16x4*>(dst + c * 256 + lane * 4) = ob;
+      if (write_x) cst_f4(p.xres + (int64_t)r * d + c * 256 + lane * 4, o);
+    }
+  }
+}
+
+__device__ __forceinline__ void load_a_bf16(const RArgs& p, int r0, const bf16_t* src, int K, bf16_t* sA, int lda) {
+  const int per_row = K >> 3;
+  for (int c = threadIdx.x; c < 16 * per_row; c += blockDim.x) {
+    const int rr = c / per_row, c8 = c - rr * per_row;
+    bf16x8 v = {};
+    if (r0 + rr < p.R) v = cld_b8(src + (int64_t)(r0 + rr) * K + c8 * 8);
+    *reinterpret_cast<bf16x8*>(sA + rr * lda + c8 * 8) = v;
+  }
+}
+
+template <int NF>
+__device__ __forceinline__ void load_w(bf16x8 (&wf)[NF], const bf16_t* wp) {
+#pragma unroll
+  for (int i = 0; i < NF; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wp + i * 32);
+}
+
+// Which (row tile, column items) a workgroup takes in a GEMM phase.  Workgroups are dealt to the 8 XCDs round-robin
+// (blockIdx % 8) and each XCD has an L2 of its own, so the column items - the WEIGHT slices - follow the XCD: the
+// workgroups of XCD x take items x, x + 8, ... for every row tile, and a weight slice is read into one L2 only,
+// where it stays for all T steps (by row tile first, every XCD would stream the whole vocabulary matrix per step).
+struct PhaseMap {
+  int rt, c0, nper; bool has;
+  __device__ __forceinline__ PhaseMap(int RT, int CI) {
+    const int G = gridDim.x, b = blockIdx.x;
+    if ((G & 7) == 0 && (G >> 3) >= RT) {
+      const int x = b & 7, j = b >> 3, nsl = (G >> 3) / RT, cs = j / RT;
+      rt = j - cs * RT; c0 = x + 8 * cs; nper = 8 * nsl; has = cs < nsl && c0 < CI;
+    } else {
+      nper = G / RT; rt = b % RT; c0 = b / RT; has = c0 < nper && c0 < CI;
+    }
+  }
+};
+
+// One GEMM phase: out[R, N] = A[R, K] W[N, K]^T (+ bias, epilogue EPI), K = 512 * KC.  A workgroup loads (and
+// normalises) the 16 A rows of its row tile ONCE and walks its column items; the next item's W fragments travel
+// during the epilogue of the current one.
+//   KSPLIT = false: item = 64 columns, a wave owns a 16x16 output tile over the whole K (QKV, FFN dense1, vocabulary);
+//   KSPLIT = true : item = 16 columns, the 4 waves split K and wave 0 adds the partial tiles through LDS - 4x the
+//                   items of an N = 512 phase (the two dense layers, the cross query, FFN dense2), 1/4 the W per wave.
+template <int KC, int AMODE, int EPI, bool KSPLIT>
+__device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf16_t* sA, const bf16_t* W,
+                                           const float* bias, int N, const void* asrc, const float* g, const float* be,
+                                           bool write_x, int t, bf16_t* skv) {
+  constexpr int K = 512 * KC, NF = KSPLIT ? 4 * KC : 16 * KC;
+  constexpr int lda = K + 8;
+  static_assert(NF <= 16, "W fragments of an item: <= 64 VGPRs");
+  __shared__ float s_pm[2][4][16];
+  __shared__ int s_pi[2][4][16];
+  __shared__ float s_ps[2][4][16];
+  __shared__ f32x4 s_red[2][3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
+  const int RT = (p.R + 15) >> 4, CI = KSPLIT ? (N + 15) >> 4 : (N + 63) >> 6;
+  const PhaseMap pm(RT, CI);
+  const int r0 = pm.rt * 16;
+  // this wave's tile of column item c: columns n0(c) .. + 16; its K range starts at koff
+  const int koff = KSPLIT ? wave * (K / 4) : 0;
+  auto tile_n0 = [&](int c) { return KSPLIT ? c * 16 : (c * 4 + wave) * 16; };
+  auto w_ptr = [&](int n0) { return W + (int64_t)min(n0 + l16, N - 1) * K + koff + kg * 8; };
+  bf16x8 wf[NF];
+  if (pm.has && tile_n0(pm.c0) < N) load_w<NF>(wf, w_ptr(tile_n0(pm.c0)));
+  if (do_wait) gs.wait();
+  gs.mark();
+  if (pm.has) {
+    if constexpr (AMODE == A_BF16) load_a_bf16(p, r0, reinterpret_cast<const bf16_t*>(asrc), K, sA, lda);
+    else load_a_rows<AMODE>(p, r0, t, pm.c0 == 0, reinterpret_cast<const float*>(asrc), g, be, write_x && pm.c0 == 0, sA, lda);
+    __syncthreads();
+    int par = 0;
+    const int r = r0 + l16;  // lane: row r, columns nb .. nb + 3 of its wave's tile
+    for (int c = pm.c0; c < CI; c += pm.nper, par ^= 1) {
+      const int n0 = tile_n0(c), nb = n0 + kg * 4;
+      const bool active = n0 < N;
+      float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (EPI == E_RES)
+        if ((!KSPLIT || wave == 0) && active && r < p.R) xr = cld_f4(p.xres + (int64_t)r * 512 + nb);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      if (active) {
+        const bf16_t* ar = sA + l16 * lda + koff + kg * 8;
+#pragma unroll
+        for (int i = 0; i < NF; i += 2) {
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ar + i * 32);
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ar + (i + 1) * 32);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], b1, acc1, 0, 0, 0);
+        }
+      }
+      {  // the next item's fragments travel during the epilogue
+        const int cn = c + pm.nper;
+        if (cn < CI && tile_n0(cn) < N) load_w<NF>(wf, w_ptr(tile_n0(cn)));
+      }
+      f32x4 v = acc0 + acc1;
+      if constexpr (KSPLIT) {
+        if (wave > 0) s_red[par][wave - 1][lane] = v;
+        __syncthreads();  // one per item: the partial tiles alternate between two buffers
+        if (wave > 0) continue;
+        v += s_red[par][0][lane] + s_red[par][1][lane] + s_red[par][2][lane];
+      }
+      if constexpr (EPI == E_VOCAB) {
+        float m = -INFINITY, s = 0.f;
+        int bi = 0x7fffffff;
+        if (active) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nb + e < N && v[e] > m) { m = v[e]; bi = nb + e; }
+          if (m != -INFINITY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (nb + e < N) s += expf(v[e] - m);
+          }
+        }
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          amax_merge(m, bi, s, om, oi, os);
+        }
+        if (kg == 0) { s_pm[par][wave][l16] = m; s_pi[par][wave][l16] = bi; s_ps[par][wave][l16] = s; }
+        __syncthreads();  // one per item: the partials alternate between two buffers
+        if (wave == 0 && kg == 0 && r < p.R) {
+#pragma unroll
+          for (int w = 1; w < 4; ++w) amax_merge(m, bi, s, s_pm[par][w][l16], s_pi[par][w][l16], s_ps[par][w][l16]);
+          cst_f(p.pmax + (int64_t)r * p.parts + c, m);
+          cst_i(p.pidx + (int64_t)r * p.parts + c, bi);
+          cst_f(p.psum + (int64_t)r * p.parts + c, s);
+        }
+      } else if (active && r < p.R) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        if constexpr (EPI == E_QKV) {
+          if (nb < 512) {
+            cst_f4(p.q + (int64_t)r * 512 + nb, make_float4(v[0], v[1], v[2], v[3]));
+          } else {
+            bf16x4 ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = (bf16_t)v[e];
+            cst_b4(skv + ((int64_t)r * p.T + (t - 1)) * 1024 + (nb - 512), ob);
+          }
+        } else if constexpr (EPI == E_Q) {
+          cst_f4(p.q + (int64_t)r * 512 + nb, make_float4(v[0], v[1], v[2], v[3]));
+        } else if constexpr (EPI == E_RES) {
+          cst_f4(p.y + (int64_t)r * 512 + nb, make_float4(v[0] + xr.x, v[1] + xr.y, v[2] + xr.z, v[3] + xr.w));
+        } else {  // E_ACT
+          bf16x4 ob;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ob[e] = (bf16_t)res_act(v[e], p.act);
+          cst_b4(p.h + (int64_t)r * N + nb, ob);
+        }
+      }
+    }
+  }
+  gs.mark();
+  gs.arrive();
+}
+
+// One attention phase: ctx[r, h*64 ..] = softmax(q_h K_h^T / 8 (masked, + bias)) V_h for every (row, head); one
+// wave per item, lane = (key slot, 8-dim chunk).  Masking as the reference: masked keys get -1e9, the hybrid bias
+// is added after the mask (models/components/Attention.py:104-111).  The heads of a row go to the waves of ONE XCD
+// (row % 8), so a row's static K/V is read into one L2.
+template <bool SELF>  // SELF: the keys / values are the cache this launch writes (coherent loads), pad mask from `fed`
+__device__ __forceinline__ void attn_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
+                                           int rows_per_kv, int nk, const int32_t* pad_tok, const float* bias,
+                                           int bias_ld) {
+  if (do_wait) gs.wait();
+  gs.mark();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 3, chunk = lane & 7;
+  constexpr int d = 512;
+  const int nkb = (nk + 7) >> 3, H = p.H;
+  const bool by_xcd = (gridDim.x & 7) == 0;
+  const int x = by_xcd ? (int)(blockIdx.x & 7) : 0, xs = by_xcd ? 8 : 1;
+  const int myslot = (by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) + (by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x) * wave;
+  const int nslots = (by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x) * 4;
+  const int nrows_x = (p.R - x + xs - 1) / xs;  // rows x, x + xs, ...
+  for (int li = myslot; li < nrows_x * H; li += nslots) {
+    const int r = x + xs * (li / H), hh = li % H;
+    float q[8];
+    {
+      const float4 qa = cld_f4(p.q + (int64_t)r * d + hh * 64 + chunk * 8), qb = cld_f4(p.q + (int64_t)r * d + hh * 64 + chunk * 8 + 4);
+      q[0] = qa.x; q[1] = qa.y; q[2] = qa.z; q[3] = qa.w; q[4] = qb.x; q[5] = qb.y; q[6] = qb.z; q[7] = qb.w;
+    }
+    const bf16_t* kb0 = KV + (int64_t)(r / rows_per_kv) * kv_bs + hh * 64 + chunk * 8;
+    float add[RES_MAXKB];
+    bool padded[RES_MAXKB];
+    bf16x8 kf[RES_MAXKB], vf[RES_MAXKB];
+#pragma unroll
+    for (int kb = 0; kb < RES_MAXKB; ++kb)
+      if (kb < nkb) {
+        const int j = kb * 8 + slot, jc = j < nk ? j : 0;
+        padded[kb] = pad_tok ? cld_i(pad_tok + (int64_t)r * p.fed_stride + jc) == p.pad : false;
+        add[kb] = bias ? bias[hh * bias_ld + jc] : 0.f;
+        if constexpr (SELF) { kf[kb] = cld_b8(kb0 + (int64_t)jc * 2 * d); vf[kb] = cld_b8(kb0 + (int64_t)jc * 2 * d + d); }
+        else {
+          kf[kb] = *reinterpret_cast<const bf16x8*>(kb0 + (int64_t)jc * 2 * d);
+          vf[kb] = *reinterpret_cast<const bf16x8*>(kb0 + (int64_t)jc * 2 * d + d);
+        }
+      }
+    float s[RES_MAXKB];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < RES_MAXKB; ++kb)
+      if (kb < nkb) {
+        float dd = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dd = fmaf(q[i], (float)kf[kb][i], dd);
+        dd += care_dpp_x1(dd);
+        dd += care_dpp_x2(dd);
+        dd += care_dpp_m8(dd);
+        dd *= 0.125f;
+        if (padded[kb]) dd = -1e9f;
+        dd += add[kb];
+        s[kb] = kb * 8 + slot < nk ? dd : -INFINITY;
+        m = fmaxf(m, s[kb]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 8, 64));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < RES_MAXKB; ++kb)
+      if (kb < nkb) { s[kb] = expf(s[kb] - m); sum += s[kb]; }
+    sum += __shfl_xor(sum, 8, 64);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < RES_MAXKB; ++kb)
+      if (kb < nkb) {
+        const float pw = s[kb] * inv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(pw, (float)vf[kb][i], acc[i]);
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc[i] += __shfl_xor(acc[i], 8, 64);
+      acc[i] += __shfl_xor(acc[i], 16, 64);
+      acc[i] += __shfl_xor(acc[i], 32, 64);
+    }
+    if (slot == 0) {
+      bf16x8 ob;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ob[i] = (bf16_t)acc[i];
+      cst_b8(p.ctx + (int64_t)r * d + hh * 64 + chunk * 8, ob);
+    }
+  }
+  gs.mark();
+  gs.arrive();
+}
+
+template <int KCF>
+__global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
+  GridSync gs{p.sync, gridDim.x, 0u, -1};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = p.d;
+  bool ended = false;
+  for (int t = 1; t <= p.steps && !ended; ++t) {
+    gs.slot = (p.prof_step == t && blockIdx.x == 0) ? 0 : -1;
+    for (int l = 0; l < p.n_layers; ++l) {
+      const RLayer& L = p.L[l];
+      if (l == 0) gemm_phase<1, A_EMBED, E_QKV, false>(p, gs, t > 1, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv);
+      else gemm_phase<1, A_LN, E_QKV, false>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv);
+      if (l == 0 && t > 1) {  // every row ended with the token chosen in the phase above? (read after its barrier)
+        gs.wait();
+        if (p.early && __hip_atomic_load(p.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.R) {
+          ended = true;
+          if (blockIdx.x == 0 && threadIdx.x == 0) p.sync[2] = (unsigned)(t - 1);
+          break;
+        }
+        attn_phase<true>(p, gs, false, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0);
+      } else {
+        attn_phase<true>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0);
+      }
+      gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, L.o_w, L.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr);
+      const float* g = L.g;
+      const float* be = L.be;
+      for (int a = 0; a < L.n_att; ++a) {
+        const RAttn& A = L.att[a];
+        gemm_phase<1, A_LN, E_Q, true>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr);
+        attn_phase<false>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld);
+        gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr);
+        g = A.g; be = A.be;
+      }
+      gemm_phase<1, A_LN, E_ACT, false>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr);
+      gemm_phase<KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr);
+    }
+    if (ended) break;
+    const RLayer& LL = p.L[p.n_layers - 1];
+    gemm_phase<1, A_LN, E_VOCAB, false>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr);
+  }
+  if (!ended) {  // the token of the last step
+    gs.wait();
+    for (int rb = (blockIdx.x * 4 + wave) * 4; rb < p.R; rb += gridDim.x * 16) {
+      int tok[4];
+      select4<true>(p, rb, p.steps, lane, tok);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.sync[2] = (unsigned)p.steps;
+  }
+}
+
+std::atomic<unsigned long long> g_res_lds_done[3];
+
+}  // namespace
+
+extern "C" {
+
+int64_t care_decode_resident_scratch(int rows, int d, int ff, int V) {
+  if (rows < 1 || d < 1 || ff < 1 || V < 1) return CARE_EINVAL;
+  const int64_t R16 = (rows + 15) / 16 * 16, parts = (V + 63) / 64;
+  // sync | xres, y, q fp32 [R16, d] | ctx bf16 [R16, d] | h bf16 [R16, ff] | pmax, pidx, psum [R16, parts]
+  return 2048 + R16 * d * 4 * 3 + R16 * d * 2 + R16 * ff * 2 + R16 * parts * 12;
+}
+
+int care_decode_resident(const care_resident_layer* layers, int n_layers, const float* word, const float* pos,
+                         const float* sem, int sem_div, const float* emb_g, const float* emb_b, float eps,
+                         const void* vocab_w, int V, int d, int heads, int ff, int act, int rows, int T, int steps,
+                         int bos, int eos, int pad, int32_t* fed, int fed_stride, float* score, int32_t* length,
+                         int32_t* finished, void* scratch, int64_t scratch_bytes, int early_exit, int blocks, void* stream) {
+  if (!layers || !word || !pos || !emb_g || !emb_b || !vocab_w || !fed || !score || !length || !finished || !scratch)
+    return CARE_EINVAL;
+  if (n_layers < 1 || n_layers > RES_MAX_LAYERS || rows < 1 || T < 1 || steps < 1 || steps > T || V < 1 || fed_stride < T + 1)
+    return CARE_EINVAL;
+  if (d != 512 || heads * 64 != d || (ff != 512 && ff != 1024 && ff != 2048) || T > 8 * RES_MAXKB || V > 64 * 64 * RES_NP)
+    return CARE_ESHAPE;
+  if (act < CARE_ACT_NONE || act > CARE_ACT_GELU) return CARE_EDTYPE;
+  if (scratch_bytes < care_decode_resident_scratch(rows, d, ff, V) || !care_aligned16(scratch)) return CARE_EINVAL;
+  RArgs p;
+  for (int l = 0; l < n_layers; ++l) {
+    const care_resident_layer& s = layers[l];
+    RLayer& L = p.L[l];
+    if (!s.qkv_w || !s.qkv_b || !s.o_w || !s.o_b || !s.ln_g || !s.ln_b || !s.self_kv || !s.w1 || !s.b1 || !s.w2 || !s.b2 ||
+        !s.ffn_g || !s.ffn_b || s.n_att < 0 || s.n_att > 2)
+      return CARE_EINVAL;
+    L.qkv_w = (const bf16_t*)s.qkv_w; L.qkv_b = s.qkv_b; L.o_w = (const bf16_t*)s.o_w; L.o_b = s.o_b; L.g = s.ln_g; L.be = s.ln_b;
+    L.skv = (bf16_t*)s.self_kv;
+    L.n_att = s.n_att;
+    for (int a = 0; a < s.n_att; ++a) {
+      const care_resident_attn& sa = s.att[a];
+      if (!sa.q_w || !sa.q_b || !sa.o_w || !sa.o_b || !sa.ln_g || !sa.ln_b || !sa.kv || sa.rows_per_kv < 1) return CARE_EINVAL;
+      if (sa.nkeys < 1 || sa.nkeys > 8 * RES_MAXKB) return CARE_ESHAPE;
+      RAttn& A = L.att[a];
+      A.q_w = (const bf16_t*)sa.q_w; A.q_b = sa.q_b; A.o_w = (const bf16_t*)sa.o_w; A.o_b = sa.o_b; A.g = sa.ln_g; A.be = sa.ln_b;
+      A.kv = (const bf16_t*)sa.kv; A.kv_bs = sa.kv_batch_stride; A.nkeys = sa.nkeys; A.rows_per_kv = sa.rows_per_kv;
+      A.bias = sa.bias; A.bias_ld = sa.bias_ld;
+    }
+    L.w1 = (const bf16_t*)s.w1; L.b1 = s.b1; L.w2 = (const bf16_t*)s.w2; L.b2 = s.b2; L.fg = s.ffn_g; L.fbe = s.ffn_b;
+  }
+  p.n_layers = n_layers;
+  p.word = word; p.pos = pos; p.sem = sem; p.sem_div = sem_div > 0 ? sem_div : 1; p.emb_g = emb_g; p.emb_be = emb_b; p.eps = eps;
+  p.vocab = (const bf16_t*)vocab_w; p.V = V;
+  p.d = d; p.H = heads; p.ff = ff; p.act = act; p.R = rows; p.T = T; p.steps = steps; p.bos = bos; p.eos = eos; p.pad = pad; p.early = early_exit;
+  {
+    const char* ps = getenv("CARE_RESIDENT_PROF_STEP");  // tools only: phase clocks of that step -> scratch + 1280
+    p.prof_step = ps ? atoi(ps) : 0;
+  }
+  p.fed = fed; p.fed_stride = fed_stride; p.score = score; p.length = length; p.fin = finished;
+  const int64_t R16 = (rows + 15) / 16 * 16;
+  p.parts = (V + 63) / 64;
+  unsigned char* b = (unsigned char*)scratch;
+  p.sync = (unsigned*)b; b += 2048;
+  p.xres = (float*)b; b += R16 * d * 4;
+  p.y = (float*)b; b += R16 * d * 4;
+  p.q = (float*)b; b += R16 * d * 4;
+  p.ctx = (bf16_t*)b; b += R16 * d * 2;
+  p.h = (bf16_t*)b; b += R16 * ff * 2;
+  p.pmax = (float*)b; b += R16 * p.parts * 4;
+  p.pidx = (int32_t*)b; b += R16 * p.parts * 4;
+  p.psum = (float*)b;
+
+  int dev = 0, cus = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) return (int)e;
+  // every workgroup must be resident (they wait for one another): at most one per CU; no more than the widest phase
+  // has items (the vocabulary groups x row tiles, or a wave per (row, head))
+  const int RT = (int)(R16 / 16);
+  int want = RT * p.parts;
+  if ((rows * heads + 3) / 4 > want) want = (rows * heads + 3) / 4;
+  int grid = blocks > 0 ? blocks : want;
+  grid = (grid + 7) / 8 * 8;  // whole rounds over the 8 XCDs (PhaseMap)
+  if (grid > cus) grid = cus;
+  if (grid < RT) return CARE_ESHAPE;  // a workgroup per 16-row tile at least
+  const int kmax = ff > d ? ff : d;
+  const int lds = 16 * (kmax + 8) * 2;
+  hipStream_t st = (hipStream_t)stream;
+  e = hipMemsetAsync(p.sync, 0, 2048, st);
+  if (e != hipSuccess) return (int)e;
+  const dim3 g(grid), blk(256);
+  int rc;
+  switch (ff / 512) {
+    case 1:
+      if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<1>, lds, g_res_lds_done[0]))) return rc;
+      hipLaunchKernelGGL((decode_resident_kernel<1>), g, blk, lds, st, p);
+      break;
+    case 2:
+      if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<2>, lds, g_res_lds_done[1]))) return rc;
+      hipLaunchKernelGGL((decode_resident_kernel<2>), g, blk, lds, st, p);
+      break;
+    default:
+      if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<4>, lds, g_res_lds_done[2]))) return rc;
+      hipLaunchKernelGGL((decode_resident_kernel<4>), g, blk, lds, st, p);
+      break;
+  }
+  return care_launch_status();
+}
+
+}  // extern "C"

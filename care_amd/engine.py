@@ -16,6 +16,7 @@ These are numerically equivalent re-orderings of the same math (decoder is causa
 post-LN, eval-mode dropout is identity).
 """
 import collections
+import ctypes
 import os
 import weakref
 from typing import Dict, List, Optional
@@ -131,6 +132,8 @@ class HipEngine:
         # 29-step pass remains available (`early_exit=False`, CARE_EARLY_EXIT=0)
         self.early_exit = os.environ.get("CARE_EARLY_EXIT", "1") != "0"
         self.segment_steps = int(os.environ.get("CARE_SEGMENT_STEPS", "4"))
+        # greedy batches of up to this many clips decode as ONE resident launch (greedy_resident); 0 turns it off
+        self.resident_max_rows = int(os.environ.get("CARE_RESIDENT_MAX_ROWS", "128"))
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, sd: Dict[str, torch.Tensor], device) -> None:
@@ -292,7 +295,7 @@ class HipEngine:
     # Captured graphs per kind (first element of the key).  The whole-pass kinds are keyed on the caller's feature
     # buffers, the segment kinds on (buffer set, first step, rows): a loader with ragged last batches, or a caller
     # that allocates fresh feature tensors for every batch, must not grow them without limit.
-    GRAPH_CAPS = {"greedy": 8, "beam": 8, "gseg0": 8, "bseg0": 8, "gseg": 96, "bseg": 96, "tf": 8}
+    GRAPH_CAPS = {"greedy": 8, "beam": 8, "gseg0": 8, "bseg0": 8, "gseg": 96, "bseg": 96, "tf": 8, "gres": 8}
 
     def _graph_get(self, key):
         entry = self._graphs.get(key)
@@ -1091,6 +1094,56 @@ class HipEngine:
                      ptr(length), ptr(fin), t, T, EOS, B)
         return fed, length, score
 
+    # ------------------------------------------------------------------ resident decode of small batches
+    def resident_ok(self, rows: int) -> bool:
+        """Greedy decode of `rows` clips as one resident launch (csrc/decode_resident.hip)?  bf16 mode, d_model = 512;
+        a form of its own next to the multi-launch one: projected cross K/V, the same rounding points, sums in another
+        order - so which of two nearly tied tokens wins can differ between a batch of <= resident_max_rows clips and a
+        larger one (the audit of tests/test_gpu_properties.py counts such rows)."""
+        return (0 < rows <= self.resident_max_rows and self.as_ok and self.d == 512 and self.ff in (512, 1024, 2048) and
+                self.T <= 128 and self.n_layers <= 4 and (not self.attr_att or self.topk <= 128))
+
+    def greedy_resident(self, mem: torch.Tensor, sem: Optional[torch.Tensor], sem_embs: Optional[torch.Tensor] = None,
+                        steps: Optional[int] = None, early_exit: bool = True):
+        """Greedy decoding of B clips in ONE launch: the step loop of Translator.translate_batch with beam_size 1
+        (models/Translator.py:77-143) runs on the device, phases of a step separated by grid barriers, and stops once
+        every clip has ended (Translator.py:77-81).  Returns device tensors fed int32 [B, T + 1], length int32 [B],
+        score fp32 [B]; `self.last_decode["steps"]` is a 0-dim DEVICE tensor (no host synchronisation here)."""
+        B, Lk, d = mem.shape
+        T, w = self.T, self.w
+        steps = T if steps is None else steps
+        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
+        ckv = self.cross_kv(mem, tag="r_ckv")
+        akv = self.attr_kv(sem_embs, tag="r_akv") if self.attr_att else None
+        fed = self.ws("r_fed", (B, T + 1), torch.int32)
+        score, length, fin = self.ws("r_score", (B,)), self.ws("r_len", (B,), torch.int32), self.ws("r_fin", (B,), torch.int32)
+        layers = self._res_layers = (_lib.ResidentLayer * self.n_layers)()  # kept: bench.py re-issues the recorded call
+        for li in range(self.n_layers):
+            L, sa, ffn = layers[li], "d{}_sa".format(li), "d{}_ffn".format(li)
+            L.qkv_w, L.qkv_b, L.o_w, L.o_b = ptr(w[sa + "_qkv_w"]), ptr(w[sa + "_qkv_b"]), ptr(w[sa + "_o_w"]), ptr(w[sa + "_o_b"])
+            L.ln_g, L.ln_b = ptr(w[sa + "_g"]), ptr(w[sa + "_be"])
+            L.self_kv = ptr(self.ws("r_skv%d" % li, (B, T, 2 * d), torch.bfloat16))
+            blocks = [("d{}_ca".format(li), ckv[li], Lk, w["d{}_hb".format(li)])]
+            if self.attr_att:
+                blocks.append(("d{}_aa".format(li), akv[li], self.topk, None))
+            L.n_att = len(blocks)
+            for a, (nm, kv, nkeys, hb) in enumerate(blocks):
+                A = L.att[a]
+                A.q_w, A.q_b, A.o_w, A.o_b = ptr(w[nm + "_q_w"]), ptr(w[nm + "_q_b"]), ptr(w[nm + "_o_w"]), ptr(w[nm + "_o_b"])
+                A.ln_g, A.ln_b = ptr(w[nm + "_g"]), ptr(w[nm + "_be"])
+                A.kv, A.kv_batch_stride, A.nkeys, A.rows_per_kv = ptr(kv), nkeys * 2 * d, nkeys, 1
+                A.bias, A.bias_ld = ptr(hb), (hb.stride(0) if hb is not None else 0)
+            L.w1, L.b1, L.w2, L.b2 = ptr(w[ffn + "_w1"]), ptr(w[ffn + "_b1"]), ptr(w[ffn + "_w2"]), ptr(w[ffn + "_b2"])
+            L.ffn_g, L.ffn_b = ptr(w[ffn + "_g"]), ptr(w[ffn + "_be"])
+        nbytes = _lib.load().care_decode_resident_scratch(B, d, self.ff, self.V)
+        scratch = self.ws("r_scratch", (nbytes,), torch.uint8)
+        call("care_decode_resident", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem), 1,
+             ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(w["vocab"]), self.V, d, self.H, self.ff, self.act, B, T, steps,
+             BOS, EOS, PAD, ptr(fed), T + 1, ptr(score), ptr(length), ptr(fin), ptr(scratch), nbytes,
+             int(bool(early_exit)), int(os.environ.get("CARE_RESIDENT_BLOCKS", "0")), tag="decode_resident")
+        self.last_decode = dict(clips=B, steps=scratch[8:12].view(torch.int32)[0], compactions=0, resident=True)
+        return fed, length, score
+
     # ------------------------------------------------------------------ greedy with early exit + compaction
     def _call_rows(self, fn, src, dst, idx, n):
         """care_gather_rows / care_scatter_rows on tensors whose first dim is the row."""
@@ -1290,7 +1343,20 @@ class HipEngine:
         lanes = self.lanes_for(feats[0].shape[0]) if use_graph else 1
         if lanes > 1:
             return self._translate_greedy_lanes(feats, lanes, lean)
-        if self.early_exit if early_exit is None else early_exit:
+        ee = self.early_exit if early_exit is None else early_exit
+        if self.resident_ok(feats[0].shape[0]):  # small batch: encode + one resident launch for the whole decode
+            def run_resident():
+                self._form_rows = feats[0].shape[0]
+                enc = self.encode(feats, lean, static=True)
+                return (enc,) + tuple(self.greedy_resident(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
+                                                           sem_embs=enc.get("semantic_embs"), early_exit=ee))
+            key = ("gres", bool(lean), bool(ee), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+            out = self._replay(key, run_resident, use_graph)
+            nb = _lib.load().care_decode_resident_scratch(feats[0].shape[0], self.d, self.ff, self.V)
+            self.last_decode = dict(clips=feats[0].shape[0], steps=self.ws("r_scratch", (nb,), torch.uint8)[8:12].view(torch.int32)[0],
+                                    compactions=0, resident=True)
+            return out
+        if ee:
             # stop when every clip has ended, drop ended clips on the way (greedy_early_exit)
             return self.greedy_early_exit(feats, lean, use_graph)
 

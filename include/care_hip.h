@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 14
+#define CARE_ABI_VERSION 15
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -542,6 +542,47 @@ int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, i
                   const float* P, const float* dctx, int64_t ldd, float* dQ, int64_t lddq, float* dK, float* dV,
                   int64_t dkv_bs, int64_t dkv_rs, float* dbias, int bias_ld, int nseq, int seq, int nkeys, int heads,
                   float p_drop, uint64_t seed, void* stream);
+
+/*
+ * care_decode_resident: the whole greedy decode of a SMALL batch (1 .. a few hundred caption rows) as ONE launch.
+ *   Replaces the step loop of Translator.translate_batch with beam_size 1 (models/Translator.py:77-143: embedding,
+ *   models/Decoder.py + models/components/Layers.py:157-228 per layer, Head.py:26-32, the top-1 of Beam.advance, and
+ *   the `no active instance` exit of Translator.py:77-81) for batches whose step is bound by launch latency: a grid of
+ *   at most one workgroup per CU stays resident and walks the phases of every step separated by grid barriers
+ *   (csrc/decode_resident.hip).  bf16 weights / caches, fp32 accumulation and statistics - the rounding points of the
+ *   multi-launch path with projected cross K/V.
+ *   care_resident_attn: one post-LN attention block over STATIC keys (inter_attention / attr_attention): q_w [d, d],
+ *   o_w [d, d] bf16, biases / LayerNorm fp32, kv bf16 [batches, nkeys, 2 d] (K | V, as care_gemm writes cross K/V) with
+ *   kv_batch_stride elements between batches, row r reads batch r / rows_per_kv; bias (optional) fp32 [heads, bias_ld].
+ *   care_resident_layer: qkv_w [3 d, d], o_w [d, d], w1 [ff, d], w2 [d, ff] bf16; self_kv bf16 [rows, T, 2 d] (written).
+ *   word fp32 [V, d], pos fp32 [>= T, d], sem (optional) fp32 [rows / sem_div, d]; vocab_w bf16 [V, d].
+ *   Outputs: fed int32 [rows, fed_stride >= T + 1] (column 0 = bos; columns after a row's end: the tokens it kept
+ *   choosing while frozen, or 0 once every row had ended), score fp32 [rows] (sum of chosen log-probs), length int32
+ *   [rows], finished int32 [rows].  All four are initialised by the kernel.
+ *   early_exit != 0: stop after the step at which the last row ended (else all `steps` steps run).  The number of
+ *   steps run is left in ((int32_t*)scratch)[2].
+ *   scratch: care_decode_resident_scratch(rows, d, ff, V) bytes, 16-byte aligned.  blocks: workgroups (0 = as many as
+ *   the widest phase has items, at most one per CU; every workgroup must be resident).
+ *   Requires d == 512, heads == 8, ff in {512, 1024, 2048}, T <= 128, nkeys <= 128, n_layers <= 4, n_att <= 2.
+ *   The one entry point that issues two operations: a 2-KB memset node (barrier counters) and the kernel.
+ */
+typedef struct care_resident_attn {
+  const void* q_w; const float* q_b; const void* o_w; const float* o_b; const float* ln_g; const float* ln_b;
+  const void* kv; int64_t kv_batch_stride; int32_t nkeys; int32_t rows_per_kv; const float* bias; int32_t bias_ld;
+  int32_t reserved;
+} care_resident_attn;
+typedef struct care_resident_layer {
+  const void* qkv_w; const float* qkv_b; const void* o_w; const float* o_b; const float* ln_g; const float* ln_b;
+  void* self_kv;
+  care_resident_attn att[2]; int32_t n_att; int32_t reserved;
+  const void* w1; const float* b1; const void* w2; const float* b2; const float* ffn_g; const float* ffn_b;
+} care_resident_layer;
+int64_t care_decode_resident_scratch(int rows, int d, int ff, int V);
+int care_decode_resident(const care_resident_layer* layers, int n_layers, const float* word, const float* pos,
+                         const float* sem, int sem_div, const float* emb_g, const float* emb_b, float eps,
+                         const void* vocab_w, int V, int d, int heads, int ff, int act, int rows, int T, int steps,
+                         int bos, int eos, int pad, int32_t* fed, int fed_stride, float* score, int32_t* length,
+                         int32_t* finished, void* scratch, int64_t scratch_bytes, int early_exit, int blocks, void* stream);
 
 /* care_timestamp: out[0] (uint64) = the device wall clock (constant 100 MHz) when the one-thread kernel runs.
  *   Measurement only (bench.py: the duration of a kernel inside a replayed hipGraph); no reference counterpart. */

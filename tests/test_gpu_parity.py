@@ -166,14 +166,15 @@ GREEDY_TIE_TOL = 5e-3   # log-prob units; a step decided by less than this may f
 CLEAR_MARGIN = 0.1      # a clip whose every step is decided by more than this must be bit-exact
 
 
-@pytest.mark.parametrize("absorbed", [False, True])
-def test_greedy_bf16_matches_up_to_near_ties(golden, absorbed):
+@pytest.mark.parametrize("form", ["projected", "absorbed", "resident"])
+def test_greedy_bf16_matches_up_to_near_ties(golden, form):
     """bf16 greedy ids vs the oracle.  A clip whose reference search never saw a margin below
     CLEAR_MARGIN (fixture `gap_select`) must come out bit-exact - that is every clip of the `peaked`
     fixtures; any other divergence must start at a step where the oracle's own top-1/top-2 log-prob
     margin is below GREEDY_TIE_TOL (random-init logits are nearly flat).  Both forms of the
-    cross-attention: the absorbed form (the default wherever the model allows it) and projected K/V
-    (`engine.latent = False`)."""
+    cross-attention of the multi-launch decode: the absorbed form (the default wherever the model allows it) and
+    projected K/V (`engine.latent = False`); and the resident form (the whole decode of a small batch as one launch,
+    csrc/decode_resident.hip - what the Translator runs at these batch sizes by default)."""
     from care_amd import get_translator
     from oracle import care_cpu
 
@@ -182,11 +183,19 @@ def test_greedy_bf16_matches_up_to_near_ties(golden, absorbed):
         pytest.skip("greedy audit")
     model = _model(opt, P, "bf16")
     eng = model.engine()
+    absorbed = form == "absorbed"
     if absorbed and not eng.latent_capable:
         pytest.skip("absorbed cross-attention covers d_model = 512 only")
-    eng.latent = absorbed  # the default is the absorbed form wherever the model allows it, at every batch size
-    assert eng.latent_for(feats[0].shape[0]) == absorbed
+    if form == "resident":
+        if not eng.resident_ok(feats[0].shape[0]):
+            pytest.skip("resident decode covers d_model = 512 in bf16 mode")
+    else:
+        eng.resident_max_rows = 0
+        eng.latent = absorbed  # the default is the absorbed form wherever the model allows it, at every batch size
+        assert eng.latent_for(feats[0].shape[0]) == absorbed
     hyps, scores = get_translator(opt).translate_batch([model], {"feats": _dev(feats)})
+    if form == "resident":
+        assert eng.last_decode.get("resident") and 1 <= int(eng.last_decode["steps"]) <= eng.T
     ref_hyps, ref_scores = golden.hyps()
     gap = golden.z["gap_select"]
     enc = care_cpu.encoding_phase(P, opt, feats)

@@ -100,13 +100,27 @@ def test_abi_library_exports_every_declared_symbol():
 
     build.build()
     header = open(os.path.join(ROOT, "include", "care_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(care_\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(care_\w+)\s*\(", header, re.M))
     assert len(declared) >= 18
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.exported_symbols())
     loaded = _lib.load()
+    # the two structs of care_decode_resident: ctypes mirrors against the C compiler's layout of the header
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "sz.c")
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "care_hip.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", '
+                             'sizeof(care_resident_attn), sizeof(care_resident_layer), offsetof(care_resident_layer, n_att), '
+                             'offsetof(care_resident_attn, bias)); return 0; }\n')
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(td, "sz")], check=True)
+        sizes = [int(v) for v in subprocess.run([os.path.join(td, "sz")], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(_lib.ResidentAttn), ctypes.sizeof(_lib.ResidentLayer), _lib.ResidentLayer.n_att.offset,
+                     _lib.ResidentAttn.bias.offset]
+    assert loaded.care_decode_resident_scratch(1, 512, 2048, 10547) == 2048 + 16 * (512 * 14 + 2048 * 2 + 165 * 12)
+    assert loaded.care_decode_resident_scratch(0, 512, 2048, 10547) < 0
     assert loaded.care_version() == int(re.search(r"#define CARE_ABI_VERSION (\d+)", header).group(1))
     assert loaded.care_arch() == b"gfx950"
     assert loaded.care_argmax_parts(10547) == 166
