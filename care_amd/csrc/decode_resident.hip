@@ -188,6 +188,7 @@ __device__ __forceinline__ void select4(const RArgs& p, int r0, int ts, int lane
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    if (r0 + i >= p.R) break;  // rows past the batch (wave-uniform)
     float best = -INFINITY;
     int bi = 0x7fffffff;
 #pragma unroll
@@ -309,13 +310,20 @@ __device__ __forceinline__ void load_a_rows(const RArgs& p, int r0, int t, bool 
   }
 }
 
-__device__ __forceinline__ void load_a_bf16(const RArgs& p, int r0, const bf16_t* src, int K, bf16_t* sA, int lda) {
-  const int per_row = K >> 3;
-  for (int c = threadIdx.x; c < 16 * per_row; c += blockDim.x) {
-    const int rr = c / per_row, c8 = c - rr * per_row;
-    bf16x8 v = {};
-    if (r0 + rr < p.R) v = cld_b8(src + (int64_t)(r0 + rr) * K + c8 * 8);
-    *reinterpret_cast<bf16x8*>(sA + rr * lda + c8 * 8) = v;
+template <int K>
+__device__ __forceinline__ void load_a_bf16(const RArgs& p, int r0, const bf16_t* src, bf16_t* sA, int lda) {
+  constexpr int per_row = K / 8, NC = 16 * per_row / 256;  // 16-byte chunks per thread, all in flight together
+  bf16x8 v[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = threadIdx.x + 256 * i, rr = c / per_row, c8 = c - rr * per_row;
+    v[i] = cld_b8(src + (int64_t)(r0 + rr < p.R ? r0 + rr : 0) * K + c8 * 8);
+    if (r0 + rr >= p.R) v[i] = bf16x8{};
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = threadIdx.x + 256 * i, rr = c / per_row, c8 = c - rr * per_row;
+    *reinterpret_cast<bf16x8*>(sA + rr * lda + c8 * 8) = v[i];
   }
 }
 
@@ -343,95 +351,99 @@ struct PhaseMap {
 };
 
 // One GEMM phase: out[R, N] = A[R, K] W[N, K]^T (+ bias, epilogue EPI), K = 512 * KC.  A workgroup loads (and
-// normalises) the 16 A rows of its row tile ONCE and walks its column items; the next item's W fragments travel
-// during the epilogue of the current one.
-//   KSPLIT = false: item = 64 columns, a wave owns a 16x16 output tile over the whole K (QKV, FFN dense1, vocabulary);
+// normalises) the 16 A rows of its row tile ONCE and walks its column items with two sets of W fragments: the next
+// item's travel while the current one is multiplied.
+//   KSPLIT = false: item = 64 columns, a wave owns a 16x16 output tile over the whole K (the vocabulary phase);
 //   KSPLIT = true : item = 16 columns, the 4 waves split K and wave 0 adds the partial tiles through LDS - 4x the
-//                   items of an N = 512 phase (the two dense layers, the cross query, FFN dense2), 1/4 the W per wave.
-template <int KC, int AMODE, int EPI, bool KSPLIT>
+//                   items, 1/4 of the W bytes per wave (every other phase: what a GEMM over a few rows waits for is
+//                   its CU's read rate from L2; *measured* QKV + FFN dense1 this way: 1 row 47.1 -> 43.6 us / step,
+//                   32 rows 65.0 -> 60.7, 128 rows 77.5 -> 76.9).
+// E_VOCAB keeps a running (max, arg-max, sum exp) per lane over the workgroup's items and merges lanes and waves once,
+// after the last item: one partial per (row, workgroup of the row tile), p.parts of them per row.
+template <int KC, int AMODE, int EPI, bool KSPLIT, int RTB = 1>
 __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf16_t* sA, const bf16_t* W,
                                            const float* bias, int N, const void* asrc, const float* g, const float* be,
                                            bool write_x, int t, bf16_t* skv) {
+  // RTB: 16-row tiles a workgroup multiplies with ONE fetch of its W fragments (their A rows side by side in LDS):
+  // the weight traffic of a phase is (row tiles / RTB) x the matrix - what bounds the vocabulary phase at 128 rows.
   constexpr int K = 512 * KC, NF = KSPLIT ? 4 * KC : 16 * KC;
   constexpr int lda = K + 8;
-  static_assert(NF <= 16, "W fragments of an item: <= 64 VGPRs");
-  __shared__ float s_pm[2][4][16];
-  __shared__ int s_pi[2][4][16];
-  __shared__ float s_ps[2][4][16];
+  static_assert(NF <= 16, "two sets of W fragments: <= 128 VGPRs");
+  __shared__ float s_pm[4][16];
+  __shared__ int s_pi[4][16];
+  __shared__ float s_ps[4][16];
   __shared__ f32x4 s_red[2][3][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
-  const int RT = (p.R + 15) >> 4, CI = KSPLIT ? (N + 15) >> 4 : (N + 63) >> 6;
-  const PhaseMap pm(RT, CI);
-  const int r0 = pm.rt * 16;
+  const int RT = (p.R + 15) >> 4, RG = (RT + RTB - 1) / RTB, CI = KSPLIT ? (N + 15) >> 4 : (N + 63) >> 6;
+  const PhaseMap pm(RG, CI);
+  const int r0 = pm.rt * 16 * RTB;
   // this wave's tile of column item c: columns n0(c) .. + 16; its K range starts at koff
   const int koff = KSPLIT ? wave * (K / 4) : 0;
   auto tile_n0 = [&](int c) { return KSPLIT ? c * 16 : (c * 4 + wave) * 16; };
-  auto w_ptr = [&](int n0) { return W + (int64_t)min(n0 + l16, N - 1) * K + koff + kg * 8; };
-  bf16x8 wf[NF];
-  if (pm.has && tile_n0(pm.c0) < N) load_w<NF>(wf, w_ptr(tile_n0(pm.c0)));
-  if (do_wait) gs.wait();
-  gs.mark();
-  if (pm.has) {
-    if constexpr (AMODE == A_BF16) load_a_bf16(p, r0, reinterpret_cast<const bf16_t*>(asrc), K, sA, lda);
-    else load_a_rows<AMODE>(p, r0, t, pm.c0 == 0, reinterpret_cast<const float*>(asrc), g, be, write_x && pm.c0 == 0, sA, lda);
-    __syncthreads();
-    int par = 0;
-    const int r = r0 + l16;  // lane: row r, columns nb .. nb + 3 of its wave's tile
-    for (int c = pm.c0; c < CI; c += pm.nper, par ^= 1) {
-      const int n0 = tile_n0(c), nb = n0 + kg * 4;
-      const bool active = n0 < N;
+  auto fetch = [&](bf16x8 (&wf)[NF], int c) {
+    if (c < CI && tile_n0(c) < N) load_w<NF>(wf, W + (int64_t)min(tile_n0(c) + l16, N - 1) * K + koff + kg * 8);
+  };
+  float vm[RTB], vs[RTB];  // E_VOCAB: the lane's running partial per row tile
+  int vi[RTB];
+#pragma unroll
+  for (int u = 0; u < RTB; ++u) { vm[u] = -INFINITY; vs[u] = 0.f; vi[u] = 0x7fffffff; }
+  int par = 0;
+  auto item = [&](const bf16x8 (&wf)[NF], int c) {
+    const int n0 = tile_n0(c), nb = n0 + kg * 4;
+    const bool active = n0 < N;
+#pragma unroll
+    for (int u = 0; u < RTB; ++u) {
+      const int r = r0 + u * 16 + l16;  // lane: row r, columns nb .. nb + 3 of its wave's tile
+      if (RTB > 1 && r0 + u * 16 >= p.R) break;
       float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (EPI == E_RES)
         if ((!KSPLIT || wave == 0) && active && r < p.R) xr = cld_f4(p.xres + (int64_t)r * 512 + nb);
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      if (active) {
-        const bf16_t* ar = sA + l16 * lda + koff + kg * 8;
+      // K in quarters, each with two accumulator chains (even / odd fragments), added as q0 + ((q1 + q2) + q3): the
+      // order in which the K-split form adds its four waves' tiles, so both forms give the same bits
+      constexpr int NQ = KSPLIT ? 1 : 4, QF = NF / NQ;
+      f32x4 part[NQ];
+      {
+        const bf16_t* ar = sA + (u * 16 + l16) * lda + koff + kg * 8;
 #pragma unroll
-        for (int i = 0; i < NF; i += 2) {
-          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ar + i * 32);
-          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ar + (i + 1) * 32);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], b0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], b1, acc1, 0, 0, 0);
+        for (int qq = 0; qq < NQ; ++qq) {
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+          if (active) {
+#pragma unroll
+            for (int i = qq * QF; i < (qq + 1) * QF; i += 2) {
+              const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ar + i * 32);
+              const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ar + (i + 1) * 32);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], b0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], b1, acc1, 0, 0, 0);
+            }
+          }
+          part[qq] = acc0 + acc1;
         }
       }
-      {  // the next item's fragments travel during the epilogue
-        const int cn = c + pm.nper;
-        if (cn < CI && tile_n0(cn) < N) load_w<NF>(wf, w_ptr(tile_n0(cn)));
-      }
-      f32x4 v = acc0 + acc1;
+      f32x4 v = part[0];
+      if constexpr (!KSPLIT) v = part[0] + ((part[1] + part[2]) + part[3]);
       if constexpr (KSPLIT) {
         if (wave > 0) s_red[par][wave - 1][lane] = v;
-        __syncthreads();  // one per item: the partial tiles alternate between two buffers
+        __syncthreads();  // one per tile: the partial tiles alternate between two buffers
+        par ^= 1;
         if (wave > 0) continue;
-        v += s_red[par][0][lane] + s_red[par][1][lane] + s_red[par][2][lane];
+        v = v + ((s_red[par ^ 1][0][lane] + s_red[par ^ 1][1][lane]) + s_red[par ^ 1][2][lane]);
       }
       if constexpr (EPI == E_VOCAB) {
-        float m = -INFINITY, s = 0.f;
-        int bi = 0x7fffffff;
         if (active) {
+          float m4 = -INFINITY;
+          int i4 = 0x7fffffff;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (nb + e < N && v[e] > m) { m = v[e]; bi = nb + e; }
-          if (m != -INFINITY) {
+            if (nb + e < N && v[e] > m4) { m4 = v[e]; i4 = nb + e; }
+          if (m4 > vm[u]) {  // later items hold higher columns: a tie keeps the earlier one
+            vs[u] = vm[u] == -INFINITY ? 0.f : vs[u] * expf(vm[u] - m4);
+            vm[u] = m4; vi[u] = i4;
+          }
+          if (vm[u] != -INFINITY) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (nb + e < N) s += expf(v[e] - m);
+              if (nb + e < N) vs[u] += expf(v[e] - vm[u]);
           }
-        }
-#pragma unroll
-        for (int o = 16; o < 64; o <<= 1) {
-          const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
-          const int oi = __shfl_xor(bi, o, 64);
-          amax_merge(m, bi, s, om, oi, os);
-        }
-        if (kg == 0) { s_pm[par][wave][l16] = m; s_pi[par][wave][l16] = bi; s_ps[par][wave][l16] = s; }
-        __syncthreads();  // one per item: the partials alternate between two buffers
-        if (wave == 0 && kg == 0 && r < p.R) {
-#pragma unroll
-          for (int w = 1; w < 4; ++w) amax_merge(m, bi, s, s_pm[par][w][l16], s_pi[par][w][l16], s_ps[par][w][l16]);
-          cst_f(p.pmax + (int64_t)r * p.parts + c, m);
-          cst_i(p.pidx + (int64_t)r * p.parts + c, bi);
-          cst_f(p.psum + (int64_t)r * p.parts + c, s);
         }
       } else if (active && r < p.R) {
         const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
@@ -454,6 +466,53 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
 #pragma unroll
           for (int e = 0; e < 4; ++e) ob[e] = (bf16_t)res_act(v[e], p.act);
           cst_b4(p.h + (int64_t)r * N + nb, ob);
+        }
+      }
+    }
+  };
+
+  bf16x8 wa[NF], wb[NF];
+  if (pm.has) fetch(wa, pm.c0);
+  if (do_wait) gs.wait();
+  gs.mark();
+  if (pm.has) {
+#pragma unroll
+    for (int u = 0; u < RTB; ++u) {
+      if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;
+      if constexpr (AMODE == A_BF16) load_a_bf16<K>(p, r0 + u * 16, reinterpret_cast<const bf16_t*>(asrc), sA + u * 16 * lda, lda);
+      else load_a_rows<AMODE>(p, r0 + u * 16, t, pm.c0 == 0, reinterpret_cast<const float*>(asrc), g, be, write_x && pm.c0 == 0,
+                              sA + u * 16 * lda, lda);
+    }
+    __syncthreads();
+    if constexpr (EPI == E_VOCAB) gs.mark();
+    for (int c = pm.c0; c < CI; c += 2 * pm.nper) {
+      fetch(wb, c + pm.nper);
+      item(wa, c);
+      if (c + pm.nper >= CI) break;
+      fetch(wa, c + 2 * pm.nper);
+      item(wb, c + pm.nper);
+    }
+    if constexpr (EPI == E_VOCAB) {
+      gs.mark();
+#pragma unroll
+      for (int u = 0; u < RTB; ++u) {
+        const int r = r0 + u * 16 + l16;
+        if (RTB > 1 && r0 + u * 16 >= p.R) break;
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          const float om = __shfl_xor(vm[u], o, 64), os = __shfl_xor(vs[u], o, 64);
+          const int oi = __shfl_xor(vi[u], o, 64);
+          amax_merge(vm[u], vi[u], vs[u], om, oi, os);
+        }
+        if (u > 0) __syncthreads();  // wave 0 has read the previous tile's entries
+        if (kg == 0) { s_pm[wave][l16] = vm[u]; s_pi[wave][l16] = vi[u]; s_ps[wave][l16] = vs[u]; }
+        __syncthreads();
+        if (wave == 0 && kg == 0 && r < p.R) {
+#pragma unroll
+          for (int w = 1; w < 4; ++w) amax_merge(vm[u], vi[u], vs[u], s_pm[w][l16], s_pi[w][l16], s_ps[w][l16]);
+          cst_f(p.pmax + (int64_t)r * p.parts + pm.c0, vm[u]);
+          cst_i(p.pidx + (int64_t)r * p.parts + pm.c0, vi[u]);
+          cst_f(p.psum + (int64_t)r * p.parts + pm.c0, vs[u]);
         }
       }
     }
@@ -556,7 +615,8 @@ __device__ __forceinline__ void attn_phase(const RArgs& p, GridSync& gs, bool do
   gs.arrive();
 }
 
-template <int KCF>
+// KCF = ff / 512; RB: row tiles per workgroup in the vocabulary phase
+template <int KCF, int RB>
 __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
@@ -568,8 +628,8 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
     gs.slot = (p.prof_step == t && blockIdx.x == 0) ? 0 : -1;
     for (int l = 0; l < p.n_layers; ++l) {
       const RLayer& L = p.L[l];
-      if (l == 0) gemm_phase<1, A_EMBED, E_QKV, false>(p, gs, t > 1, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv);
-      else gemm_phase<1, A_LN, E_QKV, false>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv);
+      if (l == 0) gemm_phase<1, A_EMBED, E_QKV, true>(p, gs, t > 1, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv);
+      else gemm_phase<1, A_LN, E_QKV, true>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv);
       if (l == 0 && t > 1) {  // every row ended with the token chosen in the phase above? (read after its barrier)
         gs.wait();
         if (p.early && __hip_atomic_load(p.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.R) {
@@ -591,12 +651,12 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
         gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr);
         g = A.g; be = A.be;
       }
-      gemm_phase<1, A_LN, E_ACT, false>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr);
+      gemm_phase<1, A_LN, E_ACT, true>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr);
       gemm_phase<KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr);
     }
     if (ended) break;
     const RLayer& LL = p.L[p.n_layers - 1];
-    gemm_phase<1, A_LN, E_VOCAB, false>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr);
+    gemm_phase<1, A_LN, E_VOCAB, false, RB>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr);
   }
   if (!ended) {  // the token of the last step
     gs.wait();
@@ -608,7 +668,7 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   }
 }
 
-std::atomic<unsigned long long> g_res_lds_done[3];
+std::atomic<unsigned long long> g_res_lds_done[4];
 
 }  // namespace
 
@@ -683,34 +743,44 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   if (e != hipSuccess) return (int)e;
   // every workgroup must be resident (they wait for one another): at most one per CU; no more than the widest phase
   // has items (the vocabulary groups x row tiles, or a wave per (row, head))
-  const int RT = (int)(R16 / 16);
-  int want = RT * p.parts;
+  const int RT = (int)(R16 / 16), CIV = (V + 63) / 64;
+  // row tiles a workgroup multiplies per fetch of its vocabulary fragments: 1; 2 (CARE_RESIDENT_RB, ff = 2048 builds)
+  // halves the weight traffic of the phase and doubles the rows a workgroup normalises - *measured* 128 rows: equal
+  int rb = 1;
+  {
+    const char* e = getenv("CARE_RESIDENT_RB");  // tuning
+    if (e && ff == 2048) rb = atoi(e) >= 2 ? 2 : 1;
+  }
+  const int RG = (RT + rb - 1) / rb;
+  int want = RT * CIV;
   if ((rows * heads + 3) / 4 > want) want = (rows * heads + 3) / 4;
   int grid = blocks > 0 ? blocks : want;
   grid = (grid + 7) / 8 * 8;  // whole rounds over the 8 XCDs (PhaseMap)
   if (grid > cus) grid = cus;
   if (grid < RT) return CARE_ESHAPE;  // a workgroup per 16-row tile at least
+  {  // vocabulary partials per row = workgroups per row tile that have a column item (PhaseMap)
+    const int nper = ((grid & 7) == 0 && (grid >> 3) >= RG) ? 8 * ((grid >> 3) / RG) : grid / RG;
+    p.parts = nper < CIV ? nper : CIV;
+    if (p.parts > 64 * RES_NP) return CARE_ESHAPE;
+  }
   const int kmax = ff > d ? ff : d;
-  const int lds = 16 * (kmax + 8) * 2;
+  int lds = 16 * (kmax + 8) * 2;
+  if (rb * 16 * (512 + 8) * 2 > lds) lds = rb * 16 * (512 + 8) * 2;
   hipStream_t st = (hipStream_t)stream;
   e = hipMemsetAsync(p.sync, 0, 2048, st);
   if (e != hipSuccess) return (int)e;
   const dim3 g(grid), blk(256);
   int rc;
-  switch (ff / 512) {
-    case 1:
-      if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<1>, lds, g_res_lds_done[0]))) return rc;
-      hipLaunchKernelGGL((decode_resident_kernel<1>), g, blk, lds, st, p);
-      break;
-    case 2:
-      if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<2>, lds, g_res_lds_done[1]))) return rc;
-      hipLaunchKernelGGL((decode_resident_kernel<2>), g, blk, lds, st, p);
-      break;
-    default:
-      if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<4>, lds, g_res_lds_done[2]))) return rc;
-      hipLaunchKernelGGL((decode_resident_kernel<4>), g, blk, lds, st, p);
-      break;
-  }
+#define RES_LAUNCH(KCF, RB, SLOT)                                                                                   \
+  do {                                                                                                              \
+    if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<KCF, RB>, lds, g_res_lds_done[SLOT]))) return rc; \
+    hipLaunchKernelGGL((decode_resident_kernel<KCF, RB>), g, blk, lds, st, p);                                      \
+  } while (0)
+  if (ff == 512) RES_LAUNCH(1, 1, 0);
+  else if (ff == 1024) RES_LAUNCH(2, 1, 1);
+  else if (rb == 1) RES_LAUNCH(4, 1, 2);
+  else RES_LAUNCH(4, 2, 3);
+#undef RES_LAUNCH
   return care_launch_status();
 }
 

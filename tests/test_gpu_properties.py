@@ -29,6 +29,9 @@ def _setup(config, B, dtype, seed=77, boost=None):
     # form at 2048 rows by itself; a property that compares a big batch with small chunks of it would
     # otherwise compare two roundings)
     model.engine().LATENT_MIN_ROWS = 1
+    # ... and the multi-launch decode at every batch size: the resident decode of small batches is a form of its own
+    # (tests/test_gpu_resident.py), the properties below compare batches across its row threshold
+    model.engine().resident_max_rows = 0
     gen = torch.Generator(device="cuda:0")
     gen.manual_seed(seed)
     feats = [torch.randn(s, generator=gen, device="cuda:0") for s in feat_shapes(opt, B)]

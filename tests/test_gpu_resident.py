@@ -1,0 +1,118 @@
+"""GPU: the resident decode of small batches (csrc/decode_resident.hip, care_decode_resident) - the whole greedy step loop
+of Translator.translate_batch (models/Translator.py:77-143) as one launch - against the multi-launch decode, the CPU
+oracle, and its own invariants (rows independent of the batch they ride in, replay == eager, early exit == fixed length).
+The golden fixtures run through it in tests/test_gpu_parity.py (form `resident`)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_properties import PEAKED_ROWS, _setup  # noqa: E402
+
+
+def _run(eng, feats, **kw):
+    _, fed, length, score = eng.translate_greedy(feats, **kw)
+    return fed.clone(), length.clone(), score.clone()
+
+
+def _caption_equal(fa, la, fb, lb):
+    """Rows whose captions (BOS .. the token at `length`) agree."""
+    T1 = fa.shape[1]
+    keep = torch.arange(T1, device=fa.device).unsqueeze(0) <= la.unsqueeze(1)
+    return (la == lb) & ((fa * keep) == (fb * keep)).all(dim=1)
+
+
+@pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 1), ("msrvtt_base_ami", 17), ("msrvtt_base_ami", 128),
+                                      ("msrvtt_care", 5), ("msrvtt_care", 100), ("msrvtt_cabase", 33), ("msvd_base_i", 64)])
+def test_resident_decode_against_multi_launch_and_oracle(config, B):
+    """Peaked (trained-like) logits: the resident form and the multi-launch form (projected cross K/V: the same rounding
+    points) must give the same caption wherever the oracle's every step is decided by a clear margin, and nearly
+    always otherwise; scores within the bf16 bar; the resident path must actually have run."""
+    from oracle import care_cpu
+    from test_gpu_parity import BF16_LSE_PEAKED, CLEAR_MARGIN, _audit_greedy
+
+    opt, P, model, feats = _setup(config, B, "bf16", seed=189, boost=PEAKED_ROWS)
+    eng = model.engine()
+    eng.latent = False
+    ml = _run(eng, feats, use_graph=False)
+    assert not eng.last_decode.get("resident")
+    eng.resident_max_rows = 128
+    assert eng.resident_ok(B)
+    rs = _run(eng, feats, use_graph=False)
+    assert eng.last_decode.get("resident") and 1 <= int(eng.last_decode["steps"]) <= eng.T
+    same = _caption_equal(rs[0], rs[1], ml[0], ml[1])
+    assert int(same.sum()) >= B - max(1, B // 16), "{} of {} captions differ between the two forms".format(B - int(same.sum()), B)
+    n = rs[1].clamp(min=1).float()
+    assert ((rs[2] - ml[2]).abs() / n)[same].max().item() < 2e-2
+    idx = sorted(set(int(i) for i in torch.linspace(0, B - 1, min(B, 12)).round().tolist()))
+    sample = [f[idx].cpu() for f in feats]
+    hyps, scores, gaps = care_cpu.translate_batch(P, opt, sample, return_gaps=True)
+    inputs = care_cpu.inputs_for_decoder(opt, care_cpu.encoding_phase(P, opt, sample))
+    for j, i in enumerate(idx):
+        k = int(rs[1][i])
+        h, r = rs[0][i, 1:k + 1].tolist(), hyps[j][0]
+        if gaps[j]["select"] >= CLEAR_MARGIN:
+            assert h == r, "clip {}: clear margins ({:.3f}) but the resident ids differ".format(i, gaps[j]["select"])
+        if h == r:
+            assert abs(float(rs[2][i]) / k - scores[j][0]) < BF16_LSE_PEAKED
+        else:
+            _audit_greedy(P, opt, {kk: v[j:j + 1] for kk, v in inputs.items()}, h, r, 5e-2)
+
+
+@pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 100), ("msrvtt_care", 37)])
+def test_resident_rows_do_not_depend_on_their_batch(config, B):
+    """A clip decodes to the same tokens alone, in a chunk, or in the full batch (rows are independent in every phase;
+    only the order in which the log-sum-exp partials of the vocabulary phase merge follows the grid: scores 1e-4), run
+    after run, eager or replayed from the captured graph."""
+    boost = {"cls_head.tgt_word_prj.weight": {3: 4.0, 0: 3.0}}  # early EOS at mixed steps, generated PADs
+    opt, P, model, feats = _setup(config, B, "bf16", boost=boost)
+    eng = model.engine()
+    eng.resident_max_rows = 128
+    full = _run(eng, feats, use_graph=False)
+    assert eng.last_decode.get("resident")
+    assert len(set(full[1].tolist())) > 3 and int(full[1].max()) <= eng.T
+    for it in range(3):  # first sight, capture, replay
+        again = _run(eng, feats, use_graph=True)
+        for a, b in zip(full, again):
+            assert torch.equal(a, b)
+    assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] == "gres"), "pass was not captured"
+    for lo, n in ((0, 1), (3, 16), (B - 7, 7), (B // 2, 17)):
+        sub = [f[lo:lo + n].contiguous() for f in feats]
+        f_s, l_s, s_s = _run(eng, sub, use_graph=False)
+        assert torch.equal(l_s, full[1][lo:lo + n])
+        assert bool(_caption_equal(f_s, l_s, full[0][lo:lo + n], full[1][lo:lo + n]).all())
+        assert (s_s - full[2][lo:lo + n]).abs().max().item() < 1e-4
+
+
+def test_resident_early_exit_equals_fixed_length():
+    """The device-side `every row has ended` exit (Translator.py:77-81) stops after the step at which the last clip
+    ended; tokens / lengths / scores are those of the pass that runs all 29 steps."""
+    boost = {"cls_head.tgt_word_prj.weight": {3: 6.0}}
+    opt, P, model, feats = _setup("msrvtt_base_ami", 48, "bf16", boost=boost)
+    eng = model.engine()
+    eng.resident_max_rows = 128
+    fixed = _run(eng, feats, use_graph=False, early_exit=False)
+    assert int(eng.last_decode["steps"]) == eng.T
+    early = _run(eng, feats, use_graph=False, early_exit=True)
+    steps = int(eng.last_decode["steps"])
+    assert steps == int(fixed[1].max()) < eng.T
+    assert torch.equal(early[1], fixed[1]) and torch.equal(early[2], fixed[2])
+    assert bool(_caption_equal(early[0], early[1], fixed[0], fixed[1]).all())
+    assert int(early[0][:, steps + 1:].abs().sum()) == 0  # nothing was fed after the exit
+
+
+def test_resident_entry_point_rejects_what_it_does_not_cover():
+    from care_amd import _lib
+
+    lib = _lib.load()
+    layers = (_lib.ResidentLayer * 1)()
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda:0")
+    p = buf.data_ptr()
+    args = lambda d=512, heads=8, ff=2048, rows=4, T=29, V=10547: (
+        _lib.ctypes.addressof(layers), 1, p, p, None, 1, p, p, 1e-12, p, V, d, heads, ff, 1, rows, T, T, 2, 3, 0, p, T + 1, p, p, p, p,
+        buf.numel(), 1, 0, None)
+    assert lib.care_decode_resident(*args(d=768, heads=12)) == -3       # CARE_ESHAPE: d_model != 512
+    assert lib.care_decode_resident(*args(ff=3072)) == -3
+    assert lib.care_decode_resident(*args(T=200)) == -3
+    assert lib.care_decode_resident(*args(rows=0)) == -1                # CARE_EINVAL
+    assert lib.care_decode_resident(*args()) == -1                      # layer pointers are NULL
