@@ -353,11 +353,11 @@ struct PhaseMap {
 // One GEMM phase: out[R, N] = A[R, K] W[N, K]^T (+ bias, epilogue EPI), K = 512 * KC.  A workgroup loads (and
 // normalises) the 16 A rows of its row tile ONCE and walks its column items with two sets of W fragments: the next
 // item's travel while the current one is multiplied.
-//   KSPLIT = false: item = 64 columns, a wave owns a 16x16 output tile over the whole K (the vocabulary phase);
+//   KSPLIT = false: item = 64 columns, a wave owns a 16x16 output tile over the whole K (the vocabulary phase; QKV and
+//                   FFN dense1 above 64 rows);
 //   KSPLIT = true : item = 16 columns, the 4 waves split K and wave 0 adds the partial tiles through LDS - 4x the
-//                   items, 1/4 of the W bytes per wave (every other phase: what a GEMM over a few rows waits for is
-//                   its CU's read rate from L2; *measured* QKV + FFN dense1 this way: 1 row 47.1 -> 43.6 us / step,
-//                   32 rows 65.0 -> 60.7, 128 rows 77.5 -> 76.9).
+//                   items, 1/4 of the W bytes per wave (what a GEMM over a few rows waits for is its CU's read rate
+//                   from L2): the N = 512 phases always, QKV and FFN dense1 up to 64 rows.
 // E_VOCAB keeps a running (max, arg-max, sum exp) per lane over the workgroup's items and merges lanes and waves once,
 // after the last item: one partial per (row, workgroup of the row tile), p.parts of them per row.
 template <int KC, int AMODE, int EPI, bool KSPLIT, int RTB = 1>
@@ -400,7 +400,7 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
         if ((!KSPLIT || wave == 0) && active && r < p.R) xr = cld_f4(p.xres + (int64_t)r * 512 + nb);
       // K in quarters, each with two accumulator chains (even / odd fragments), added as q0 + ((q1 + q2) + q3): the
       // order in which the K-split form adds its four waves' tiles, so both forms give the same bits
-      constexpr int NQ = KSPLIT ? 1 : 4, QF = NF / NQ;
+      constexpr int NQ = (KSPLIT || EPI == E_VOCAB) ? 1 : 4, QF = NF / NQ;  // (the vocabulary phase has one form)
       f32x4 part[NQ];
       {
         const bf16_t* ar = sA + (u * 16 + l16) * lda + koff + kg * 8;
@@ -420,7 +420,7 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
         }
       }
       f32x4 v = part[0];
-      if constexpr (!KSPLIT) v = part[0] + ((part[1] + part[2]) + part[3]);
+      if constexpr (NQ == 4) v = part[0] + ((part[1] + part[2]) + part[3]);
       if constexpr (KSPLIT) {
         if (wave > 0) s_red[par][wave - 1][lane] = v;
         __syncthreads();  // one per tile: the partial tiles alternate between two buffers
@@ -615,8 +615,9 @@ __device__ __forceinline__ void attn_phase(const RArgs& p, GridSync& gs, bool do
   gs.arrive();
 }
 
-// KCF = ff / 512; RB: row tiles per workgroup in the vocabulary phase
-template <int KCF, int RB>
+// KCF = ff / 512; RB: row tiles per workgroup in the vocabulary phase; SM (few row tiles): QKV and FFN dense1 as
+// 16-column K-split items too (the same bits either way: gemm_phase adds K in the same order in both forms)
+template <int KCF, int RB, bool SM>
 __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
@@ -628,8 +629,8 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
     gs.slot = (p.prof_step == t && blockIdx.x == 0) ? 0 : -1;
     for (int l = 0; l < p.n_layers; ++l) {
       const RLayer& L = p.L[l];
-      if (l == 0) gemm_phase<1, A_EMBED, E_QKV, true>(p, gs, t > 1, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv);
-      else gemm_phase<1, A_LN, E_QKV, true>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv);
+      if (l == 0) gemm_phase<1, A_EMBED, E_QKV, SM>(p, gs, t > 1, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv);
+      else gemm_phase<1, A_LN, E_QKV, SM>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv);
       if (l == 0 && t > 1) {  // every row ended with the token chosen in the phase above? (read after its barrier)
         gs.wait();
         if (p.early && __hip_atomic_load(p.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.R) {
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
         gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr);
         g = A.g; be = A.be;
       }
-      gemm_phase<1, A_LN, E_ACT, true>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr);
+      gemm_phase<1, A_LN, E_ACT, SM>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr);
       gemm_phase<KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr);
     }
     if (ended) break;
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   }
 }
 
-std::atomic<unsigned long long> g_res_lds_done[4];
+std::atomic<unsigned long long> g_res_lds_done[5];
 
 }  // namespace
 
@@ -771,15 +772,20 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   if (e != hipSuccess) return (int)e;
   const dim3 g(grid), blk(256);
   int rc;
-#define RES_LAUNCH(KCF, RB, SLOT)                                                                                   \
-  do {                                                                                                              \
-    if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<KCF, RB>, lds, g_res_lds_done[SLOT]))) return rc; \
-    hipLaunchKernelGGL((decode_resident_kernel<KCF, RB>), g, blk, lds, st, p);                                      \
+#define RES_LAUNCH(KCF, RB, SM, SLOT)                                                                                   \
+  do {                                                                                                                  \
+    if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<KCF, RB, SM>, lds, g_res_lds_done[SLOT]))) return rc; \
+    hipLaunchKernelGGL((decode_resident_kernel<KCF, RB, SM>), g, blk, lds, st, p);                                      \
   } while (0)
-  if (ff == 512) RES_LAUNCH(1, 1, 0);
-  else if (ff == 1024) RES_LAUNCH(2, 1, 1);
-  else if (rb == 1) RES_LAUNCH(4, 1, 2);
-  else RES_LAUNCH(4, 2, 3);
+  // QKV / FFN dense1 in 16-column K-split items up to 64 rows (*measured* us / step with / without: 1 row 43.6 / 47.1,
+  // 32 rows 60.7 / 65.0, 64 rows 66.0 / 67.7, 128 rows 76.9 / 77.5 with 8.1 against 4.6 us in FFN dense1)
+  const char* sme = getenv("CARE_RESIDENT_SMALL");  // tuning
+  const bool small = sme ? atoi(sme) != 0 : rows <= 64;
+  if (ff == 512) RES_LAUNCH(1, 1, true, 0);
+  else if (ff == 1024) RES_LAUNCH(2, 1, true, 1);
+  else if (rb == 2) RES_LAUNCH(4, 2, false, 3);
+  else if (small) RES_LAUNCH(4, 1, true, 4);
+  else RES_LAUNCH(4, 1, false, 2);
 #undef RES_LAUNCH
   return care_launch_status();
 }

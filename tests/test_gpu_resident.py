@@ -84,6 +84,43 @@ def test_resident_rows_do_not_depend_on_their_batch(config, B):
         assert (s_s - full[2][lo:lo + n]).abs().max().item() < 1e-4
 
 
+def test_resident_two_decoder_layers_against_oracle():
+    """num_hidden_layers_decoder = 2: the second layer's QKV phase normalises the first layer's FFN sum on load."""
+    from care_amd import get_framework
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_state_dict
+    from oracle import care_cpu
+    from test_gpu_parity import CLEAR_MARGIN, _audit_greedy
+
+    opt = make_opt("msrvtt_base_ami", num_hidden_layers_decoder=2)
+    model = get_framework(opt).eval()
+    P = synth_state_dict(189, [(k, tuple(v.shape)) for k, v in model.state_dict().items()], row_scale=PEAKED_ROWS)
+    model.load_state_dict(P, strict=True)
+    model.set_compute_dtype("bf16")
+    model.to("cuda:0")
+    eng = model.engine()
+    assert eng.n_layers == 2 and eng.resident_ok(9)
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(4)
+    feats = [torch.randn(s, generator=gen, device="cuda:0") for s in feat_shapes(opt, 9)]
+    fed, length, score = _run(eng, feats, use_graph=False)
+    assert eng.last_decode.get("resident")
+    sample = [f.cpu() for f in feats]
+    hyps, scores, gaps = care_cpu.translate_batch(P, opt, sample, return_gaps=True)
+    inputs = care_cpu.inputs_for_decoder(opt, care_cpu.encoding_phase(P, opt, sample))
+    exact = 0
+    for i in range(9):
+        k = int(length[i])
+        h, r = fed[i, 1:k + 1].tolist(), hyps[i][0]
+        if gaps[i]["select"] >= CLEAR_MARGIN:
+            assert h == r
+        if h == r:
+            exact += 1
+        else:
+            _audit_greedy(P, opt, {kk: v[i:i + 1] for kk, v in inputs.items()}, h, r, 5e-2)
+    assert exact >= 7
+
+
 def test_resident_early_exit_equals_fixed_length():
     """The device-side `every row has ended` exit (Translator.py:77-81) stops after the step at which the last clip
     ended; tokens / lengths / scores are those of the pass that runs all 29 steps."""
