@@ -51,7 +51,7 @@ struct RArgs {
   RLayer L[RES_MAX_LAYERS]; int n_layers;
   const float *word, *pos, *sem; int sem_div; const float *emb_g, *emb_be; float eps;
   const bf16_t* vocab; int V;
-  int d, H, ff, act, R, T, steps, bos, eos, pad, early, prof_step;
+  int d, H, ff, act, R, T, steps, bos, eos, pad, early, prof_step, ghost;
   int32_t* fed; int fed_stride; float* score; int32_t* length; int32_t* fin;
   unsigned* sync; float* xres; float* y; float* q; bf16_t* ctx; bf16_t* h;
   float* pmax; int32_t* pidx; float* psum; int parts;
@@ -120,10 +120,35 @@ struct GridSync {
       }
     }
   }
+  // A workgroup that has spun for ~2 s without the others arriving (workgroups that never became resident: another
+  // kernel holds CUs for good, e.g. a second resident launch on another stream) raises the abort flag; every
+  // workgroup then leaves, phases turn into no-ops and length[0] = -1 tells the host (care_decode_resident).
+  bool dead;
   __device__ __forceinline__ void wait() {
-    if (threadIdx.x == 0)
-      while (__hip_atomic_load(sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(1);
+    __shared__ int s_dead;
+    if (threadIdx.x == 0) {
+      int d = 0;
+      unsigned spins = 0;
+      unsigned long long t0 = 0;
+      for (;;) {
+        const unsigned long long f = cld8(sync + 32);  // {generation, abort}
+        if ((unsigned)f >= gen) break;
+        if (f >> 32) { d = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 4095u) == 0) {
+          const unsigned long long now = wall_clock64();  // 100 MHz
+          if (!t0) t0 = now;
+          else if (now - t0 > 200000000ull) {
+            __hip_atomic_store(sync + 33, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d = 1;
+            break;
+          }
+        }
+      }
+      s_dead = d;
+    }
     __syncthreads();
+    dead = dead || s_dead != 0;
   }
 };
 
@@ -472,8 +497,10 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
   };
 
   bf16x8 wa[NF], wb[NF];
+  if (gs.dead) return;
   if (pm.has) fetch(wa, pm.c0);
   if (do_wait) gs.wait();
+  if (gs.dead) return;
   gs.mark();
   if (pm.has) {
 #pragma unroll
@@ -529,7 +556,9 @@ template <bool SELF>  // SELF: the keys / values are the cache this launch write
 __device__ __forceinline__ void attn_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
                                            int rows_per_kv, int nk, const int32_t* pad_tok, const float* bias,
                                            int bias_ld) {
+  if (gs.dead) return;
   if (do_wait) gs.wait();
+  if (gs.dead) return;
   gs.mark();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 3, chunk = lane & 7;
   constexpr int d = 512;
@@ -621,11 +650,11 @@ template <int KCF, int RB, bool SM>
 __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
-  GridSync gs{p.sync, gridDim.x, 0u, -1};
+  GridSync gs{p.sync, gridDim.x + (unsigned)p.ghost, 0u, -1, false};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = p.d;
   bool ended = false;
-  for (int t = 1; t <= p.steps && !ended; ++t) {
+  for (int t = 1; t <= p.steps && !ended && !gs.dead; ++t) {
     gs.slot = (p.prof_step == t && blockIdx.x == 0) ? 0 : -1;
     for (int l = 0; l < p.n_layers; ++l) {
       const RLayer& L = p.L[l];
@@ -659,8 +688,12 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
     const RLayer& LL = p.L[p.n_layers - 1];
     gemm_phase<1, A_LN, E_VOCAB, false, RB>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr);
   }
+  if (!ended && !gs.dead) gs.wait();
+  if (gs.dead) {  // aborted (GridSync::wait): say so where the host looks anyway
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cst_i(p.length, -1); p.sync[2] = 0xffffffffu; }
+    return;
+  }
   if (!ended) {  // the token of the last step
-    gs.wait();
     for (int rb = (blockIdx.x * 4 + wave) * 4; rb < p.R; rb += gridDim.x * 16) {
       int tok[4];
       select4<true>(p, rb, p.steps, lane, tok);
@@ -723,6 +756,7 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   {
     const char* ps = getenv("CARE_RESIDENT_PROF_STEP");  // tools only: phase clocks of that step -> scratch + 1280
     p.prof_step = ps ? atoi(ps) : 0;
+    p.ghost = getenv("CARE_RESIDENT_TEST_GHOST") ? 8 : 0;  // tests only: barriers that can never complete (watchdog)
   }
   p.fed = fed; p.fed_stride = fed_stride; p.score = score; p.length = length; p.fin = finished;
   const int64_t R16 = (rows + 15) / 16 * 16;

@@ -13,6 +13,7 @@ from typing import List
 
 import torch
 
+from . import _lib
 from .framework import TransformerSeq2Seq
 
 
@@ -53,6 +54,9 @@ class Translator_ARFormer(object):
     def _greedy(self, engine, feats, use_graph):
         _, fed, length, score = engine.translate_greedy(list(feats), use_graph=use_graph, lean=True)
         fed, length, score = fed.cpu(), length.cpu().tolist(), score.cpu()
+        if length and length[0] < 0:  # care_decode_resident gave up waiting for its workgroups (include/care_hip.h)
+            raise _lib.CareHipError("the resident decode timed out at a grid barrier: its workgroups never became resident "
+                                    "together (another long-running kernel holds CUs?); set CARE_RESIDENT_MAX_ROWS=0")
         hyps, scores = [], []
         n_best = self.topk
         for i, n in enumerate(length):

@@ -564,6 +564,8 @@ int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, i
  *   scratch: care_decode_resident_scratch(rows, d, ff, V) bytes, 16-byte aligned.  blocks: workgroups (0 = as many as
  *   the widest phase has items, at most one per CU; every workgroup must be resident).
  *   Requires d == 512, heads == 8, ff in {512, 1024, 2048}, T <= 128, nkeys <= 128, n_layers <= 4, n_att <= 2.
+ *   Every workgroup must be resident at the same time (they wait for one another): do not run two of these launches
+ *   concurrently on different streams.  A workgroup that waits ~2 s at a barrier aborts the launch: length[0] = -1.
  *   The one entry point that issues two operations: a 2-KB memset node (barrier counters) and the kernel.
  */
 typedef struct care_resident_attn {

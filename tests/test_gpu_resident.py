@@ -153,3 +153,29 @@ def test_resident_entry_point_rejects_what_it_does_not_cover():
     assert lib.care_decode_resident(*args(T=200)) == -3
     assert lib.care_decode_resident(*args(rows=0)) == -1                # CARE_EINVAL
     assert lib.care_decode_resident(*args()) == -1                      # layer pointers are NULL
+
+
+def test_resident_barrier_watchdog_aborts_instead_of_hanging():
+    """A grid that cannot meet at its barriers must give up, not hang: simulated by a counter state in which one more
+    workgroup than exists would have to arrive (the launch zeroes the counters itself, so the kernel is started
+    through the tuning knob that makes it expect workgroups that are not there)."""
+    import os
+
+    from care_amd import _lib
+    from care_amd.translator import Translator_ARFormer
+
+    boost = {"cls_head.tgt_word_prj.weight": {3: 6.0}}
+    opt, P, model, feats = _setup("msrvtt_base_ami", 2, "bf16", boost=boost)
+    eng = model.engine()
+    eng.resident_max_rows = 128
+    os.environ["CARE_RESIDENT_TEST_GHOST"] = "1"  # the kernel counts one ghost workgroup into every barrier
+    try:
+        _, fed, length, score = eng.translate_greedy(feats, use_graph=False, lean=True)
+        torch.cuda.synchronize()
+        assert int(length[0]) == -1 and int(eng.last_decode["steps"]) == -1
+        with pytest.raises(_lib.CareHipError):
+            Translator_ARFormer(opt)._greedy(eng, feats, False)
+    finally:
+        del os.environ["CARE_RESIDENT_TEST_GHOST"]
+    _, fed, length, score = eng.translate_greedy(feats, use_graph=False, lean=True)
+    assert int(length.min()) >= 1
