@@ -405,14 +405,25 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
   // this wave's tile of column item c: columns n0(c) .. + 16; its K range starts at koff
   const int koff = KSPLIT ? wave * (K / 4) : 0;
   auto tile_n0 = [&](int c) { return KSPLIT ? c * 16 : (c * 4 + wave) * 16; };
+  // (unconditional: an item past the last one re-reads the last one's rows.  A branch around the loads would make the
+  // compiler wait for ALL outstanding loads - vmcnt(0) - at its join, i.e. for the fragments just requested, before the
+  // MFMAs of the current item)
   auto fetch = [&](bf16x8 (&wf)[NF], int c) {
-    if (c < CI && tile_n0(c) < N) load_w<NF>(wf, W + (int64_t)min(tile_n0(c) + l16, N - 1) * K + koff + kg * 8);
+    load_w<NF>(wf, W + (int64_t)min(tile_n0(min(c, CI - 1)) + l16, N - 1) * K + koff + kg * 8);
   };
   float vm[RTB], vs[RTB];  // E_VOCAB: the lane's running partial per row tile
   int vi[RTB];
 #pragma unroll
   for (int u = 0; u < RTB; ++u) { vm[u] = -INFINITY; vs[u] = 0.f; vi[u] = 0x7fffffff; }
   int par = 0;
+  // the wave's A fragments (its K range of the 16 rows): read from LDS once per phase and kept in registers - every
+  // item of the workgroup multiplies the same rows (per row tile when RTB > 1)
+  bf16x8 af[NF];
+  auto load_af = [&](int u) {
+    const bf16_t* ar = sA + (u * 16 + l16) * lda + koff + kg * 8;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ar + i * 32);
+  };
   auto item = [&](const bf16x8 (&wf)[NF], int c) {
     const int n0 = tile_n0(c), nb = n0 + kg * 4;
     const bool active = n0 < N;
@@ -428,17 +439,15 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
       constexpr int NQ = (KSPLIT || EPI == E_VOCAB) ? 1 : 4, QF = NF / NQ;  // (the vocabulary phase has one form)
       f32x4 part[NQ];
       {
-        const bf16_t* ar = sA + (u * 16 + l16) * lda + koff + kg * 8;
+        if constexpr (RTB > 1) load_af(u);
 #pragma unroll
         for (int qq = 0; qq < NQ; ++qq) {
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
           if (active) {
 #pragma unroll
             for (int i = qq * QF; i < (qq + 1) * QF; i += 2) {
-              const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ar + i * 32);
-              const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ar + (i + 1) * 32);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], b0, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], b1, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[i], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], af[i + 1], acc1, 0, 0, 0);
             }
           }
           part[qq] = acc0 + acc1;
@@ -511,13 +520,18 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
                               sA + u * 16 * lda, lda);
     }
     __syncthreads();
+    if constexpr (RTB == 1) load_af(0);
     if constexpr (EPI == E_VOCAB) gs.mark();
-    for (int c = pm.c0; c < CI; c += 2 * pm.nper) {
-      fetch(wb, c + pm.nper);
-      item(wa, c);
-      if (c + pm.nper >= CI) break;
-      fetch(wa, c + 2 * pm.nper);
-      item(wb, c + pm.nper);
+    if (pm.c0 + pm.nper >= CI) {
+      item(wa, pm.c0);  // one item: nothing to prefetch (most phases at most row counts)
+    } else {
+      for (int c = pm.c0; c < CI; c += 2 * pm.nper) {
+        fetch(wb, c + pm.nper);
+        item(wa, c);
+        if (c + pm.nper >= CI) break;
+        fetch(wa, c + 2 * pm.nper);
+        item(wb, c + pm.nper);
+      }
     }
     if constexpr (EPI == E_VOCAB) {
       gs.mark();
@@ -779,9 +793,11 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   // every workgroup must be resident (they wait for one another): at most one per CU; no more than the widest phase
   // has items (the vocabulary groups x row tiles, or a wave per (row, head))
   const int RT = (int)(R16 / 16), CIV = (V + 63) / 64;
-  // row tiles a workgroup multiplies per fetch of its vocabulary fragments: 1; 2 (CARE_RESIDENT_RB, ff = 2048 builds)
-  // halves the weight traffic of the phase and doubles the rows a workgroup normalises - *measured* 128 rows: equal
-  int rb = 1;
+  // row tiles a workgroup multiplies per fetch of its vocabulary fragments: 2 from 128 rows (ff = 2048 builds) - the 8
+  // workgroups of an XCD that share a column item ask its L2 for the same 64 KB at the same time, and two row tiles per
+  // fetch halve those requests while doubling the rows a workgroup normalises (*measured*, same box, us per step:
+  // 128 rows 77.6 -> 76.5, 96 rows 73.1 -> 73.0)
+  int rb = (ff == 2048 && rows >= 128) ? 2 : 1;
   {
     const char* e = getenv("CARE_RESIDENT_RB");  // tuning
     if (e && ff == 2048) rb = atoi(e) >= 2 ? 2 : 1;
