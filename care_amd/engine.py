@@ -739,7 +739,10 @@ class HipEngine:
         absorbed form has two more launches per step, which small, launch-bound batches feel
         (*measured* round 1: -15% at 32 rows, -1% at 1024; +5% at 2048, +13% at 16384).
         `engine.latent = False` (CARE_LATENT=0) selects projected K/V for every size instead;
-        LATENT_MIN_ROWS > 1 restores a row threshold (tuning only)."""
+        LATENT_MIN_ROWS > 1 restores a row threshold (tuning only).
+        This is the MULTI-LAUNCH decode.  Greedy batches of <= resident_max_rows clips (128) take the resident decode
+        instead (resident_ok): one launch, projected K/V - a deliberate exception to the rule above, bought with
+        2 x the small-batch step rate; `resident_max_rows = 0` restores one form at every size."""
         return self.latent_ok and rows >= self.LATENT_MIN_ROWS
 
     def cross_src(self, mem: torch.Tensor, rows: int):
