@@ -16,6 +16,7 @@ These are numerically equivalent re-orderings of the same math (decoder is causa
 post-LN, eval-mode dropout is identity).
 """
 import collections
+import contextlib
 import ctypes
 import os
 import weakref
@@ -614,63 +615,78 @@ class HipEngine:
         mem = None if lean else new("mem", (B, self.Lk, d))
         memb = new("memb", (B, self.Lk, d), torch.bfloat16) if self.bf_act else None
         means = None if lean else new("means", (B, len(self.modality) * d))
+        # small batches, Embedder: the modalities' launches are a few microseconds of latency-bound work each - they run
+        # side by side on streams of their own (forked from / joined to the caller's stream; also inside a capture)
+        cur = torch.cuda.current_stream()
+        side = []
+        if small and opt["encoder"] == "Embedder" and len(self.modality) > 1:
+            if len(getattr(self, "_enc_streams", ())) < len(self.modality) - 1:
+                self._enc_streams = [torch.cuda.Stream(device=self.device) for _ in range(len(self.modality) - 1)]
+            side = self._enc_streams[: len(self.modality) - 1]
         for mi, ch in enumerate(self.modality):
-            x = self._prep_one(feats[mi])
-            n = x.shape[1]
-            if n != self.rows_of[ch]:
-                raise ValueError("modality `{}`: {} rows, expected {}".format(ch, n, self.rows_of[ch]))
-            x2 = x.view(B * n, x.shape[2])
-            Ws = w.get("enc_w_" + ch + "#split")
-            fused = (opt["encoder"] == "Embedder" and self.as_ok and d == 512 and
-                     (w["enc_w_" + ch].dtype == torch.bfloat16 or Ws is not None) and x2.shape[1] % 32 == 0)
-            if small and fused and Ws is None:
-                fused = False
-            W3 = w.get("enc_w_" + ch + "#split3")
-            if fused:
-                lin = None
-            elif W3 is not None:
-                lin = self.ws("enc_lin", (B * n, d))
-                if os.environ.get("CARE_ENC_TILE", "1") != "0":  # fp16 pieces of the features once, then the LDS-tiled kernel
-                    a2 = self.ws("enc_a2", (B * n, 2 * x2.shape[1]), torch.float16)
-                    call("care_split2_act", ptr(x2), x2.stride(0), ptr(a2), B * n, x2.shape[1], tag="enc_split")
-                    call("care_gemm_tile_split3", ptr(a2), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0), CARE_F32,
-                         None, 0, 0, d, B * n, d, x2.shape[1], 0, tag="enc_gemm")
-                else:
-                    call("care_gemm_split3", ptr(x2), x2.stride(0), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
-                         B * n, d, x2.shape[1], tag="enc_gemm")
-            else:
-                lin = self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch], self.ws("enc_lin", (B * n, d)), tag="enc_gemm")
-            in_mem = ch in self.dec_mod
-            if in_mem:
-                dst, dstb, grp_rows, off = mem, memb, self.Lk, self.mem_off[ch]
-                if dst is None and not fused:  # lean + unfused: the LayerNorm kernel writes an fp32 row too
-                    dst = self.ws("enc_mem_f32", (B, self.Lk, d))
-            else:
-                dst, dstb, grp_rows, off = self.ws("enc_side_" + ch, (B, n, d)), None, n, 0
-            ln_kw = dict(grp=n, out_grp_rows=grp_rows, out_row_off=off)
-            if fused and Ws is not None:  # the same, fp32 operands as hi/lo fp16 pieces (concept models)
-                call("care_gemm_ln_split", ptr(x2), x2.stride(0), ptr(Ws), ptr(w["enc_b_" + ch]), ptr(w["enc_g_" + ch]),
-                     ptr(w["enc_be_" + ch]), self.eps, ptr(dst), ptr(dstb), dst.stride(-2), B * n, d, x2.shape[1], n,
-                     grp_rows, off, tag="enc_gemm")
-            elif fused:  # Linear + bias + LayerNorm in one kernel, raw fp32 features streamed by LDS-DMA
-                self.gemm_ln(x2, w["enc_w_" + ch], w["enc_b_" + ch], None, w["enc_g_" + ch], w["enc_be_" + ch],
-                             dst, dstb, tag="enc_gemm", Wp=w.get("enc_w_" + ch + "#packed"), **ln_kw)
-            elif opt["encoder"] == "Embedder":
-                self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], dst, dstb, **ln_kw)
-            else:  # MultiTransformerEncoder
-                h, hb = self.ws("enc_h0", (B * n, d)), self.wsb("enc_h0", (B * n, d))
-                self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], h, hb, grp=n, pos=w["enc_pos_" + ch])
-                n_enc = int(opt["num_hidden_layers_encoder"])
-                for li in range(n_enc):
-                    nm = "enc{}{}".format(ch, li)
-                    h1, h1b = self._mha_self_full(nm + "_sa", h, hb, n, None, False, "enc_")
-                    if li == n_enc - 1:
-                        self._ffn(nm + "_ffn", h1, h1b, dst, dstb, "enc_", **ln_kw)
+            st = side[mi - 1] if side and mi > 0 else None
+            sfx = "_" + ch if side else ""
+            if st is not None:
+                st.wait_stream(cur)
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                x = self._prep_one(feats[mi])
+                n = x.shape[1]
+                if n != self.rows_of[ch]:
+                    raise ValueError("modality `{}`: {} rows, expected {}".format(ch, n, self.rows_of[ch]))
+                x2 = x.view(B * n, x.shape[2])
+                Ws = w.get("enc_w_" + ch + "#split")
+                fused = (opt["encoder"] == "Embedder" and self.as_ok and d == 512 and
+                         (w["enc_w_" + ch].dtype == torch.bfloat16 or Ws is not None) and x2.shape[1] % 32 == 0)
+                if small and fused and Ws is None:
+                    fused = False
+                W3 = w.get("enc_w_" + ch + "#split3")
+                if fused:
+                    lin = None
+                elif W3 is not None:
+                    lin = self.ws("enc_lin" + sfx, (B * n, d))
+                    if os.environ.get("CARE_ENC_TILE", "1") != "0":  # fp16 pieces of the features once, then the LDS-tiled kernel
+                        a2 = self.ws("enc_a2" + sfx, (B * n, 2 * x2.shape[1]), torch.float16)
+                        call("care_split2_act", ptr(x2), x2.stride(0), ptr(a2), B * n, x2.shape[1], tag="enc_split")
+                        call("care_gemm_tile_split3", ptr(a2), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0), CARE_F32,
+                             None, 0, 0, d, B * n, d, x2.shape[1], 0, tag="enc_gemm")
                     else:
-                        h, hb = self.ws("enc_h%d" % (li + 1), (B * n, d)), self.wsb("enc_h%d" % (li + 1), (B * n, d))
-                        self._ffn(nm + "_ffn", h1, h1b, h, hb, "enc_")
-            if not lean:
-                call("care_group_mean", ptr(dst), d, grp_rows, off, n, ptr(means), means.stride(0), mi * d, B, d)
+                        call("care_gemm_split3", ptr(x2), x2.stride(0), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
+                             B * n, d, x2.shape[1], tag="enc_gemm")
+                else:
+                    lin = self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch], self.ws("enc_lin" + sfx, (B * n, d)), tag="enc_gemm")
+                in_mem = ch in self.dec_mod
+                if in_mem:
+                    dst, dstb, grp_rows, off = mem, memb, self.Lk, self.mem_off[ch]
+                    if dst is None and not fused:  # lean + unfused: the LayerNorm kernel writes an fp32 row too
+                        dst = self.ws("enc_mem_f32", (B, self.Lk, d))
+                else:
+                    dst, dstb, grp_rows, off = self.ws("enc_side_" + ch, (B, n, d)), None, n, 0
+                ln_kw = dict(grp=n, out_grp_rows=grp_rows, out_row_off=off)
+                if fused and Ws is not None:  # the same, fp32 operands as hi/lo fp16 pieces (concept models)
+                    call("care_gemm_ln_split", ptr(x2), x2.stride(0), ptr(Ws), ptr(w["enc_b_" + ch]), ptr(w["enc_g_" + ch]),
+                         ptr(w["enc_be_" + ch]), self.eps, ptr(dst), ptr(dstb), dst.stride(-2), B * n, d, x2.shape[1], n,
+                         grp_rows, off, tag="enc_gemm")
+                elif fused:  # Linear + bias + LayerNorm in one kernel, raw fp32 features streamed by LDS-DMA
+                    self.gemm_ln(x2, w["enc_w_" + ch], w["enc_b_" + ch], None, w["enc_g_" + ch], w["enc_be_" + ch],
+                                 dst, dstb, tag="enc_gemm", Wp=w.get("enc_w_" + ch + "#packed"), **ln_kw)
+                elif opt["encoder"] == "Embedder":
+                    self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], dst, dstb, **ln_kw)
+                else:  # MultiTransformerEncoder
+                    h, hb = self.ws("enc_h0", (B * n, d)), self.wsb("enc_h0", (B * n, d))
+                    self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], h, hb, grp=n, pos=w["enc_pos_" + ch])
+                    n_enc = int(opt["num_hidden_layers_encoder"])
+                    for li in range(n_enc):
+                        nm = "enc{}{}".format(ch, li)
+                        h1, h1b = self._mha_self_full(nm + "_sa", h, hb, n, None, False, "enc_")
+                        if li == n_enc - 1:
+                            self._ffn(nm + "_ffn", h1, h1b, dst, dstb, "enc_", **ln_kw)
+                        else:
+                            h, hb = self.ws("enc_h%d" % (li + 1), (B * n, d)), self.wsb("enc_h%d" % (li + 1), (B * n, d))
+                            self._ffn(nm + "_ffn", h1, h1b, h, hb, "enc_")
+                if not lean:
+                    call("care_group_mean", ptr(dst), d, grp_rows, off, n, ptr(means), means.stride(0), mi * d, B, d)
+        for st in side:
+            cur.wait_stream(st)
         if lean:
             return {"encoder_hidden_states": memb}
         out: Dict[str, torch.Tensor] = {"encoder_hidden_states": mem}
