@@ -1,9 +1,9 @@
 // decode_resident.hip - the WHOLE greedy decode of a small batch as one resident launch.
 //
 // A decoder step of a small batch (1 .. a few hundred caption rows) is launch-bound: ~15 dependent kernels of
-// 4-5 us each (rocprofv3, profiles/r03_small_batch_*), none of which has more than a few microseconds of work.
-// Here one grid of <= one workgroup per CU stays resident for all T steps and walks the phases of a step
-// separated by grid barriers (one atomic counter, split arrive / wait): per decoder layer
+// 4-5 us each (rocprofv3, profiles/r03_small_batch_multilaunch_*), none of which has more than a few microseconds of
+// work.  Here one grid of <= one workgroup per CU stays resident for all T steps and walks the phases of a step
+// separated by grid barriers (split arrive / wait, no fences - see GridSync): per decoder layer
 //
 //   QKV projection (+ token choice of the previous step + embedding) | self-attention | dense + residual |
 //   { query projection | attention over the static keys | dense + residual } per cross / attribute block |
@@ -13,20 +13,24 @@
 // models/Translator.py:77-143; Head.py:26-32; the early exit of Translator.py:77-81 is the device-side
 // `all rows ended` counter, read by every workgroup after the same barrier).
 //
-// Layout of a phase:
-//   * GEMM phases: item = (16-row tile, 64-column group); a wave owns one 16x16 output tile over the whole K
-//     (K = 512 or ff): its W fragments (v_mfma_f32_16x16x32_bf16 A operand, 16 B per lane straight from the
-//     [N, K] row-major weight) are loaded BEFORE the wave waits at the barrier - the weights do not depend on
-//     the previous phase - and the 16 activation rows come through LDS as bf16.
+// Layout of a phase (DESIGN.md 4.2d has the measurements):
+//   * GEMM phases: a workgroup owns one 16-row tile (its A rows go through LDS as bf16 once, then live in registers
+//     as MFMA fragments) and walks column items - 16 columns with the 4 waves splitting K, or 64 columns with a wave
+//     per 16 x 16 tile (gemm_phase).  The W fragments (v_mfma_f32_16x16x32_bf16 A operand, 16 B per lane straight from
+//     the [N, K] row-major weight) of the first item are requested BEFORE the workgroup waits at the barrier - weights
+//     do not depend on the previous phase - and double-buffered across items.
 //   * LayerNorm is applied ON LOAD: a phase stores the pre-LayerNorm sum (dense + bias + residual, fp32) and
 //     every consumer normalises the 16 rows it needs (it reads all K columns anyway); the consumer of column
-//     group 0 also stores the normalised fp32 rows, the residual of the phase after next.
+//     item 0 also stores the normalised fp32 rows, the residual of the phase after next.
 //   * attention phases: one wave per (row, head), 8 key slots x 8 dim chunks per wave-wide 16-byte load (the
 //     layout of csrc/attention.hip), scores / softmax in registers.
-//   * the token choice (max / arg-max / sum-exp over the column-group partials; score, length, end flags) is
-//     folded into the first phase of the next step; the last step's choice runs after the loop.
+//   * the token choice (max / arg-max / sum-exp over the vocabulary partials) is folded into the first phase of
+//     the next step; the rows' score / length / end flags are advanced there by an otherwise idle workgroup
+//     (PhaseMap::helper) or the workgroup of column item 0; the last step's choice runs after the loop.
+//   * column items follow blockIdx % 8 = the XCD a workgroup runs on, so every weight byte lives in ONE L2 (PhaseMap).
 // Rounding points are those of the multi-launch bf16 path with projected cross K/V (bf16 A operands, K/V
-// caches and contexts, fp32 accumulators, LayerNorm and softmax statistics); sums run in another order.
+// caches and contexts, fp32 accumulators, LayerNorm and softmax statistics); sums run in another order, the same
+// order at every row count.
 #include <atomic>
 #include <cstdlib>
 
@@ -247,6 +251,26 @@ __device__ __forceinline__ void select4(const RArgs& p, int r0, int ts, int lane
   }
 }
 
+// The decode state of rows rb .. rb + 3 at the top of step t: fresh rows at t = 1 (fed = BOS, zeros), else the token
+// choice of step t - 1 with its score / length / end-flag update.
+__device__ __forceinline__ void advance_state4(const RArgs& p, int rb, int t, int lane, int (&tok)[4]) {
+  if (t > 1) {
+    select4<true>(p, rb, t - 1, lane, tok);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (rb + i < p.R) {
+      const int r = rb + i;
+      for (int c = lane; c <= p.T; c += 64) cst_i(p.fed + (int64_t)r * p.fed_stride + c, c == 0 ? p.bos : 0);
+      if (lane == 0) { cst_f(p.score + r, 0.f); cst_i(p.length + r, 0); cst_i(p.fin + r, 0); }
+    }
+}
+__device__ __forceinline__ void advance_state4(const RArgs& p, int rb, int t, int lane) {
+  int tok[4];
+  advance_state4(p, rb, t, lane, tok);
+}
+
 enum { A_EMBED = 0, A_LN = 1, A_BF16 = 2 };
 enum { E_QKV = 0, E_Q = 1, E_RES = 2, E_ACT = 3, E_VOCAB = 4 };
 
@@ -262,18 +286,8 @@ __device__ __forceinline__ void load_a_rows(const RArgs& p, int r0, int t, bool 
   float4 v[4][2];
   if constexpr (AMODE == A_EMBED) {
     int tok[4] = {p.bos, p.bos, p.bos, p.bos};
-    if (t > 1) {
-      if (writer) select4<true>(p, rb, t - 1, lane, tok);
-      else select4<false>(p, rb, t - 1, lane, tok);
-    } else if (writer) {  // state of fresh rows
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (rb + i < p.R) {
-          const int r = rb + i;
-          for (int c = lane; c <= p.T; c += 64) cst_i(p.fed + (int64_t)r * p.fed_stride + c, c == 0 ? p.bos : 0);
-          if (lane == 0) { cst_f(p.score + r, 0.f); cst_i(p.length + r, 0); cst_i(p.fin + r, 0); }
-        }
-    }
+    if (writer) advance_state4(p, rb, t, lane, tok);
+    else if (t > 1) select4<false>(p, rb, t - 1, lane, tok);
     const float* pp = p.pos + (int64_t)(t - 1) * d;
     const float4 p0 = *reinterpret_cast<const float4*>(pp + lane * 4), p1 = *reinterpret_cast<const float4*>(pp + 256 + lane * 4);
 #pragma unroll
@@ -362,13 +376,20 @@ __device__ __forceinline__ void load_w(bf16x8 (&wf)[NF], const bf16_t* wp) {
 // (blockIdx % 8) and each XCD has an L2 of its own, so the column items - the WEIGHT slices - follow the XCD: the
 // workgroups of XCD x take items x, x + 8, ... for every row tile, and a weight slice is read into one L2 only,
 // where it stays for all T steps (by row tile first, every XCD would stream the whole vocabulary matrix per step).
+// helper: when the phase leaves workgroups without an item, one of them per row tile (XCD 7's first idle slot) is the
+// row tile's `helper` - it advances the rows' decode state (score, length, end flags: select4<true>) off the path of
+// the workgroups that multiply; otherwise (`helped` false) the workgroup of column item 0 does that too.
 struct PhaseMap {
-  int rt, c0, nper; bool has;
+  int rt, c0, nper; bool has, helped, helper;
   __device__ __forceinline__ PhaseMap(int RT, int CI) {
     const int G = gridDim.x, b = blockIdx.x;
+    helped = helper = false;
     if ((G & 7) == 0 && (G >> 3) >= RT) {
       const int x = b & 7, j = b >> 3, nsl = (G >> 3) / RT, cs = j / RT;
       rt = j - cs * RT; c0 = x + 8 * cs; nper = 8 * nsl; has = cs < nsl && c0 < CI;
+      const int csh = CI > 7 ? (CI - 7 + 7) >> 3 : 0;  // first slot of XCD 7 without an item: 7 + 8 csh >= CI
+      helped = csh < nsl;
+      helper = helped && x == 7 && cs == csh;
     } else {
       nper = G / RT; rt = b % RT; c0 = b / RT; has = c0 < nper && c0 < CI;
     }
@@ -511,13 +532,15 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
   if (do_wait) gs.wait();
   if (gs.dead) return;
   gs.mark();
+  if constexpr (AMODE == A_EMBED)
+    if (pm.helper) advance_state4(p, r0 + wave * 4, t, lane);
   if (pm.has) {
 #pragma unroll
     for (int u = 0; u < RTB; ++u) {
       if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;
       if constexpr (AMODE == A_BF16) load_a_bf16<K>(p, r0 + u * 16, reinterpret_cast<const bf16_t*>(asrc), sA + u * 16 * lda, lda);
-      else load_a_rows<AMODE>(p, r0 + u * 16, t, pm.c0 == 0, reinterpret_cast<const float*>(asrc), g, be, write_x && pm.c0 == 0,
-                              sA + u * 16 * lda, lda);
+      else load_a_rows<AMODE>(p, r0 + u * 16, t, pm.c0 == 0 && !pm.helped, reinterpret_cast<const float*>(asrc), g, be,
+                              write_x && pm.c0 == 0, sA + u * 16 * lda, lda);
     }
     __syncthreads();
     if constexpr (RTB == 1) load_af(0);
