@@ -225,7 +225,8 @@ class HipEngine:
             # through the generic kernel (care_gemm_split3) instead of its exact-f32 MFMA
             for ch in self.modality:
                 W = w["enc_w_" + ch]
-                if ("enc_w_" + ch + "#split") not in w and W.dtype == torch.float32 and W.shape[1] % 64 == 0:
+                # (d_model = 512 too: small batches take this form instead of the fused kernel, see encode(small=True))
+                if W.dtype == torch.float32 and W.shape[1] % 64 == 0:
                     W3 = torch.empty(W.shape[0], 3 * W.shape[1], device=self.device, dtype=torch.float16)
                     call("care_split3_weight", ptr(W), ptr(W3), W.shape[0], W.shape[1])
                     w["enc_w_" + ch + "#split3"] = W3
@@ -637,8 +638,8 @@ class HipEngine:
                 Ws = w.get("enc_w_" + ch + "#split")
                 fused = (opt["encoder"] == "Embedder" and self.as_ok and d == 512 and
                          (w["enc_w_" + ch].dtype == torch.bfloat16 or Ws is not None) and x2.shape[1] % 32 == 0)
-                if small and fused and Ws is None:
-                    fused = False
+                if small and fused and (Ws is None or w.get("enc_w_" + ch + "#split3") is not None):
+                    fused = False  # (concept models: the split products through the LDS-tiled kernel, below)
                 W3 = w.get("enc_w_" + ch + "#split3")
                 if fused:
                     lin = None
@@ -1129,6 +1130,12 @@ class HipEngine:
         return (0 < rows <= self.resident_max_rows and self.as_ok and self.d == 512 and self.ff in (512, 1024, 2048) and
                 self.T <= 128 and self.n_layers <= 4 and (not self.attr_att or self.topk <= 128))
 
+    def small_forms(self, clips: int) -> bool:
+        """Batches of <= resident_max_rows clips (bf16, d_model = 512) take the small-batch forms of the pass: the
+        embedder as GEMM + LayerNorm launches side by side per modality (encode(small=True)) and, for greedy decoding,
+        the resident decode.  `resident_max_rows = 0`: one set of forms at every batch size."""
+        return 0 < clips <= self.resident_max_rows and self.as_ok and self.d == 512
+
     def greedy_resident(self, mem: torch.Tensor, sem: Optional[torch.Tensor], sem_embs: Optional[torch.Tensor] = None,
                         steps: Optional[int] = None, early_exit: bool = True):
         """Greedy decoding of B clips in ONE launch: the step loop of Translator.translate_batch with beam_size 1
@@ -1530,7 +1537,7 @@ class HipEngine:
 
         def first_segment():
             self._ws_cap = None
-            enc = self.encode(feats, lean, static=True)
+            enc = self.encode(feats, lean, static=True, small=self.small_forms(B))
             mem, sem = enc["encoder_hidden_states"], enc.get("semantic_hidden_states")
             v = state(0, B)
             N = B * bm
@@ -1638,7 +1645,7 @@ class HipEngine:
 
         def run():
             self._form_rows = feats[0].shape[0] * bm
-            enc = self.encode(feats, lean)
+            enc = self.encode(feats, lean, small=self.small_forms(feats[0].shape[0]))
             return (enc,) + tuple(self.beam(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need,
                                             sem_embs=enc.get("semantic_embs")))
 
