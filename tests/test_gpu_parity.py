@@ -216,9 +216,9 @@ BEAM_SCORE_TOL = 2e-2   # length-normalised log-prob: bf16 noise on a hypothesis
 BEAM_TIE_TOL = 2e-2     # how close two hypotheses / a pruning decision must be to count as a tie
 
 
-@pytest.mark.parametrize("absorbed", [False, True])
+@pytest.mark.parametrize("form", ["projected", "absorbed", "small"])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_beam_bf16_vs_oracle(golden, absorbed, use_graph):
+def test_beam_bf16_vs_oracle(golden, form, use_graph):
     """bf16 beam search (fused two-pass selection, device beam state) vs the reference, per clip:
       * the score the GPU reports for its best hypothesis is that hypothesis' exact fp32 score
         (oracle teacher-forced rescoring) within bf16 noise - whatever path the search took;
@@ -226,7 +226,9 @@ def test_beam_bf16_vs_oracle(golden, absorbed, use_graph):
         scoring, or the reference's winner was within BEAM_TIE_TOL of being pruned at some step
         (fixture `gap_best_slack`), or its final lead over the runner-up was that small (`gap_rank`);
       * a clip with clear margins everywhere (the `peaked` fixture) must be bit-exact.
-    use_graph: the hipGraph-captured pass (third call on the same buffers replays) vs eager."""
+    use_graph: the hipGraph-captured pass (third call on the same buffers replays) vs eager.
+    form: the cross-attention of the large-batch pass, projected or absorbed, with its fused embedder; `small`: what
+    the engine runs by default for a batch this small (engine.small_forms: unfused embedder, projected K/V)."""
     from care_amd import get_translator
     from oracle import care_cpu
 
@@ -235,9 +237,15 @@ def test_beam_bf16_vs_oracle(golden, absorbed, use_graph):
         pytest.skip("beam audit")
     model = _model(opt, P, "bf16")
     eng = model.engine()
+    absorbed = form == "absorbed"
     if absorbed and not eng.latent_capable:
         pytest.skip("absorbed cross-attention covers d_model = 512 only")
-    eng.latent = absorbed
+    if form == "small":
+        if not eng.small_forms(feats[0].shape[0]):
+            pytest.skip("the small-batch forms cover d_model = 512 in bf16 mode")
+    else:
+        eng.resident_max_rows = 0
+        eng.latent = absorbed
     # the per-row top-k: two passes of the vocabulary GEMM (what large batches use) in the graph variant,
     # logits + care_beam_select (what the engine picks for a batch this small) in the eager one
     eng.BEAM_FUSED_MIN_ROWS = 1 if use_graph else type(eng).BEAM_FUSED_MIN_ROWS
