@@ -1500,7 +1500,7 @@ class HipEngine:
                 chunk = int(os.environ.get("CARE_BEAM_CHUNK", "0")) or max(128, (176 << 20) // (logits.stride(0) * 4) // 128 * 128)
                 for lo in range(0, N, chunk):
                     hi = min(N, lo + chunk)
-                    self.gemm(src[lo:hi], self.w["vocab"], None, logits[lo:hi])
+                    self.gemm(src[lo:hi], self.w["vocab"], None, logits[lo:hi], tag="step_vocab_logits")
                     call("care_beam_select", ptr(logits[lo:hi]), logits.stride(0), self.V, bm, ptr(cval[lo:hi]),
                          ptr(cidx[lo:hi]), hi - lo)
             call("care_beam_advance", ptr(cval), ptr(cidx), ptr(v["scores"]), bm, ptr(v["tok"]), ptr(a_old), ptr(a_new),
