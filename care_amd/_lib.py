@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -64,7 +64,7 @@ SIGNATURES = {
     "care_beam_sparse_collect": [_P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "care_gemm_collect_bf16": [_P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "care_beam_pick": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _L, _I, _P, _I, _I, _P, _P, _I, _P],
-    "care_beam_select": [_P, _L, _I, _I, _P, _P, _I, _P],
+    "care_beam_select": [_P, _L, _I, _I, _P, _P, _I, _I, _P],
     "care_attention_probs": [_P, _L, _P, _I, _L, _L, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     "care_timestamp": [_P, _P],
     "care_decode_resident": [_P, _I, _P, _P, _P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P,

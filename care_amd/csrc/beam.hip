@@ -129,14 +129,19 @@ constexpr int BS_CAP = 192;  // candidates per wave and chunk
 #define BS_EXP __expf
 #endif
 
+// SPLIT = 4 (few rows: a launch of rows / 4 workgroups leaves most CUs idle and every wave walks its 42-KB row in
+// three dependent chunks): the four waves of a workgroup share ONE row - a quarter of the 16-byte groups each - and
+// wave 0 merges the four sorted lists and (max, sum exp) pairs through LDS.  The same bm columns in the same order;
+// the log-sum-exp is added in another order (log-probabilities differ in the last bits).
+template <int SPLIT>
 __global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logits, int64_t ldl, int V, int bm,
                                                                float* cand_val, int32_t* cand_idx, int rows) {
   __shared__ float lval[4][BS_CAP];
   __shared__ int lidx[4][BS_CAP];
   __shared__ int lcnt[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = blockIdx.x * 4 + wave;
-  if (r >= rows) return;  // wave-uniform; no block-wide barrier below
+  const int r = SPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+  if (r >= rows) return;  // wave-uniform (SPLIT = 1: no block-wide barrier below; SPLIT = 4: workgroup-uniform)
   const float* x = logits + (int64_t)r * ldl;
   float tv[MAXBM];  // the wave's top-bm so far, identical in all lanes, sorted (value desc, index asc)
   int ti[MAXBM];
@@ -179,7 +184,9 @@ __global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logi
   };
 
   const int nv4 = V >> 2;  // whole 16-byte groups; the V % 4 tail is handled at the end
-  for (int base = 0; base < nv4; base += 1024) {  // 16 groups per lane: group (base + u*64 + lane)
+  const int per = SPLIT == 1 ? nv4 : (nv4 + SPLIT - 1) / SPLIT;  // this wave's groups: [g0, g1)
+  const int g0 = SPLIT == 1 ? 0 : min(nv4, wave * per), g1 = SPLIT == 1 ? nv4 : min(nv4, g0 + per);
+  for (int base = g0; base < g1; base += 1024) {  // 16 groups per lane: group (base + u*64 + lane)
     f32x4 v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (int64_t)min(base + u * 64 + lane, nv4 - 1) * 4);
@@ -189,23 +196,37 @@ __global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logi
     for (int q = 0; q < 4; ++q) qmax[q] = -INFINITY;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      if (base + u * 64 + lane >= nv4) v[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (base + u * 64 + lane >= g1) v[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float e0 = v[u][j];
         qmax[u >> 2] = fmaxf(qmax[u >> 2], e0);
         if (CARE_BS_DBG & 1) continue;
-        const bool up = e0 > m;
-        const float mn = up ? e0 : m;
-        const float e = BS_EXP((up ? m : e0) - mn);  // rescale factor if e0 is the new max, else the new term
-        s = up ? fmaf(s, e, 1.0f) : s + e;
-        m = mn;
+        if constexpr (SPLIT == 1) {  // online: one exp per logit, a serial chain through (m, s) - hidden by the other waves
+          const bool up = e0 > m;
+          const float mn = up ? e0 : m;
+          const float e = BS_EXP((up ? m : e0) - mn);  // rescale factor if e0 is the new max, else the new term
+          s = up ? fmaf(s, e, 1.0f) : s + e;
+          m = mn;
+        }
       }
     }
     const float lmax = fmaxf(fmaxf(qmax[0], qmax[1]), fmaxf(qmax[2], qmax[3]));
+    if constexpr (SPLIT > 1) {  // few rows, one wave per SIMD: the lane's maximum first, then 64 INDEPENDENT exps
+      if (!(CARE_BS_DBG & 1) && lmax > -INFINITY) {
+        float sc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sc += BS_EXP(v[u][j] - lmax);
+        const float mn = fmaxf(m, lmax);
+        s = s * BS_EXP(m - mn) + sc * BS_EXP(lmax - mn);
+        m = mn;
+      }
+    }
     // ---- B: threshold and candidate list
     float tau = tv[bm - 1];
-    if (base == 0) {  // first chunk: the list is empty; k-th largest lane maximum (ties only make it more conservative)
+    if (base == g0) {  // first chunk: the list is empty; k-th largest lane maximum (ties only make it more conservative)
       float y = lmax, kth = -INFINITY;
       for (int k = 0; k < bm; ++k) {
         kth = care_wave_max_dpp(y);
@@ -236,14 +257,14 @@ __global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logi
     if (n <= BS_CAP) {
       for (int i = 0; i < n; ++i) insert(lval[wave][i], lidx[wave][i]);
     } else {  // list overflow: the chunk again, from memory
-      const int c_end = min((base + 1024) * 4, nv4 * 4);
+      const int c_end = min((base + 1024) * 4, g1 * 4);
       for (int c0 = base * 4; c0 < c_end; c0 += 64) {
         const int c = c0 + lane;
         rounds(c < c_end ? x[c < c_end ? c : 0] : 0.f, c < c_end ? c : 0x7fffffff);
       }
     }
   }
-  {  // the V % 4 tail logits
+  if (SPLIT == 1 || wave == SPLIT - 1) {  // the V % 4 tail logits
     const int c = nv4 * 4 + lane;
     const bool in = c < V;
     const float e0 = in ? x[in ? c : 0] : -INFINITY;
@@ -261,8 +282,27 @@ __global__ __launch_bounds__(256) void beam_select_wave_kernel(const float* logi
     for (int i = 0; i < n; ++i) insert(lval[wave][i], lidx[wave][i]);
   }
 
-  const float mx = care_wave_max(m);
-  const float logsum = logf(care_wave_sum(s * BS_EXP(m - mx)));
+  float mx = care_wave_max(m);
+  float ssum = care_wave_sum(s * BS_EXP(m - mx));
+  if constexpr (SPLIT > 1) {
+    __shared__ float pv[SPLIT][MAXBM], pmx[SPLIT], psm[SPLIT];
+    __shared__ int pi[SPLIT][MAXBM];
+    if (lane == 0) {
+      pmx[wave] = mx; psm[wave] = ssum;
+#pragma unroll
+      for (int k = 0; k < MAXBM; ++k) { pv[wave][k] = tv[k]; pi[wave][k] = ti[k]; }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < SPLIT; ++w) {
+      for (int k = 0; k < bm; ++k)
+        if (pi[w][k] != 0x7fffffff) insert(pv[w][k], pi[w][k]);
+      const float om = pmx[w], nm = fmaxf(mx, om);
+      ssum = ssum * BS_EXP(mx - nm) + psm[w] * BS_EXP(om - nm);
+      mx = nm;
+    }
+  }
+  const float logsum = logf(ssum);
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < MAXBM; ++k)
@@ -499,11 +539,14 @@ __global__ __launch_bounds__(256) void beam_pick_kernel(const float* pmax, const
 }  // namespace
 
 extern "C" int care_beam_select(const float* logits, int64_t ldl, int V, int bm, float* cand_val, int32_t* cand_idx,
-                                int rows, void* stream) {
+                                int rows, int waves_per_row, void* stream) {
   if (!logits || !cand_val || !cand_idx || rows <= 0 || V <= 0) return CARE_EINVAL;
-  if (bm <= 0 || bm > MAXBM || bm > V) return CARE_ESHAPE;
-  if ((ldl % 4) == 0 && care_aligned16(logits))
-    hipLaunchKernelGGL(beam_select_wave_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl,
+  if (bm <= 0 || bm > MAXBM || bm > V || (waves_per_row != 1 && waves_per_row != 4)) return CARE_ESHAPE;
+  if ((ldl % 4) == 0 && care_aligned16(logits) && waves_per_row == 4)
+    hipLaunchKernelGGL(beam_select_wave_kernel<4>, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, bm,
+                       cand_val, cand_idx, rows);
+  else if ((ldl % 4) == 0 && care_aligned16(logits))
+    hipLaunchKernelGGL(beam_select_wave_kernel<1>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl,
                        V, bm, cand_val, cand_idx, rows);
   else
     hipLaunchKernelGGL(beam_select_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, bm, cand_val,

@@ -1502,7 +1502,7 @@ class HipEngine:
                     hi = min(N, lo + chunk)
                     self.gemm(src[lo:hi], self.w["vocab"], None, logits[lo:hi], tag="step_vocab_logits")
                     call("care_beam_select", ptr(logits[lo:hi]), logits.stride(0), self.V, bm, ptr(cval[lo:hi]),
-                         ptr(cidx[lo:hi]), hi - lo)
+                         ptr(cidx[lo:hi]), hi - lo, 4 if self._small_pass else 1, tag="step_beam_select")
             call("care_beam_advance", ptr(cval), ptr(cidx), ptr(v["scores"]), bm, ptr(v["tok"]), ptr(a_old), ptr(a_new),
                  ptr(v["done"]), ptr(v["nfin"]), cap, ptr(v["fscore"]), ptr(v["flen"]), ptr(v["fhyp"]), t, T, need, EOS,
                  self.V, T + 1, n)
@@ -1728,7 +1728,7 @@ class HipEngine:
                 hi = min(N, lo + chunk)
                 self.gemm(src[lo:hi], self.w["vocab"], None, logits[lo:hi])
                 call("care_beam_select", ptr(logits[lo:hi]), logits.stride(0), self.V, bm, ptr(cval[lo:hi]),
-                     ptr(cidx[lo:hi]), hi - lo)
+                     ptr(cidx[lo:hi]), hi - lo, 4 if self._small_pass else 1)
             call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
                  ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
         return nfin, fscore, flen, fhyp

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 15
+#define CARE_ABI_VERSION 16
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -395,9 +395,11 @@ int care_head_reduce(const void* ct, int64_t ldc, const void* wv, const float* b
  *   (models/Translator.py:127) plus the per-row part of the flattened topk of
  *   Beam.advance (misc/Decoding/Beam.py:60): cand_val[r, k] = (x - max) - log(sum exp(x - max))
  *   of the k-th best column (value desc, index asc), cand_idx[r, k] its column.  bm <= 8.
+ *   waves_per_row: 1 (a 64-lane wave walks a row), or 4 for few rows (a workgroup per row, four partial lists merged:
+ *   the same columns in the same order, the log-sum-exp added in another order).
  */
 int care_beam_select(const float* logits, int64_t ldl, int V, int bm, float* cand_val,
-                     int32_t* cand_idx, int rows, void* stream);
+                     int32_t* cand_idx, int rows, int waves_per_row, void* stream);
 
 /*
  * Fused beam selection (bf16 mode): the per-row top beam_size of log_softmax(x W^T) without the

@@ -304,11 +304,13 @@ def test_concept_kernels():
     assert mem[:, :84].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("waves", [1, 4])
 @pytest.mark.parametrize("rows,V,ld,bm", [(7, 10547, 10547, 5), (7, 10547, 10560, 5), (130, 10547, 10560, 8),
-                                          (5, 300, 320, 1), (9, 17, 20, 5), (3, 5, 8, 5), (4, 1029, 1032, 3)])
-def test_beam_select(rows, V, ld, bm):
-    """Both kernels behind care_beam_select: the wave-per-row one (16-byte aligned rows) and the
-    block-per-row fallback (ld % 4 != 0): top-bm (value desc, index asc) as log-probabilities."""
+                                          (5, 300, 320, 1), (9, 17, 20, 5), (3, 5, 8, 5), (4, 1029, 1032, 3),
+                                          (6, 20004, 20008, 5)])
+def test_beam_select(rows, V, ld, bm, waves):
+    """The kernels behind care_beam_select: a wave per row, four waves per row (few rows: 16-byte aligned rows both)
+    and the block-per-row fallback (ld % 4 != 0): top-bm (value desc, index asc) as log-probabilities."""
     buf = torch.full((rows, ld), float("nan"), device=DEV)
     logits = buf[:, :V]
     logits.copy_(_rand(rows, V, seed=24 + V, scale=2.0))
@@ -319,7 +321,7 @@ def test_beam_select(rows, V, ld, bm):
         logits[1, 3] = float("-inf")
     cv = torch.zeros(rows, bm, device=DEV)
     ci = torch.zeros(rows, bm, device=DEV, dtype=torch.int32)
-    _call("care_beam_select", _p(buf), ld, V, bm, _p(cv), _p(ci), rows)
+    _call("care_beam_select", _p(buf), ld, V, bm, _p(cv), _p(ci), rows, waves)
     lp = torch.log_softmax(logits.double(), dim=1)
     torch.cuda.synchronize()
     x = logits.cpu().numpy()
@@ -594,7 +596,7 @@ def test_beam_select_massive_ties_take_the_overflow_path():
     logits[5] = _rand(V, seed=79)
     cv = torch.zeros(rows, bm, device=DEV)
     ci = torch.zeros(rows, bm, device=DEV, dtype=torch.int32)
-    _call("care_beam_select", _p(buf), ld, V, bm, _p(cv), _p(ci), rows)
+    _call("care_beam_select", _p(buf), ld, V, bm, _p(cv), _p(ci), rows, 1)
     torch.cuda.synchronize()
     x = logits.cpu().numpy()
     lp = torch.log_softmax(logits.double(), dim=1)
@@ -660,7 +662,7 @@ def test_fused_beam_selection_equals_logits_plus_beam_select(M, V, bm):
     logits = torch.empty(M, ld, device=DEV)
     _call("care_gemm_bf16", _p(A), K, 1, _p(W), None, _p(logits), ld, 0, None, 0, 0, V, M, V, K, 0)
     ref_v = torch.zeros(M, bm, device=DEV); ref_i = torch.zeros(M, bm, device=DEV, dtype=torch.int32)
-    _call("care_beam_select", _p(logits), ld, V, bm, _p(ref_v), _p(ref_i), M)
+    _call("care_beam_select", _p(logits), ld, V, bm, _p(ref_v), _p(ref_i), M, 1)
 
     parts = _lib.load().care_argmax_parts_bf16_min(M, V, K, 1, 8)
     assert parts >= 8
