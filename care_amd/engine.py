@@ -134,7 +134,7 @@ class HipEngine:
         self.early_exit = os.environ.get("CARE_EARLY_EXIT", "1") != "0"
         self.segment_steps = int(os.environ.get("CARE_SEGMENT_STEPS", "4"))
         # greedy batches of up to this many clips decode as ONE resident launch (greedy_resident); 0 turns it off
-        self.resident_max_rows = int(os.environ.get("CARE_RESIDENT_MAX_ROWS", "128"))
+        self.resident_max_rows = int(os.environ.get("CARE_RESIDENT_MAX_ROWS", "256"))
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, sd: Dict[str, torch.Tensor], device) -> None:
@@ -758,7 +758,7 @@ class HipEngine:
         (*measured* round 1: -15% at 32 rows, -1% at 1024; +5% at 2048, +13% at 16384).
         `engine.latent = False` (CARE_LATENT=0) selects projected K/V for every size instead;
         LATENT_MIN_ROWS > 1 restores a row threshold (tuning only).
-        This is the MULTI-LAUNCH decode.  Greedy batches of <= resident_max_rows clips (128) take the resident decode
+        This is the MULTI-LAUNCH decode.  Greedy batches of <= resident_max_rows clips (256) take the resident decode
         instead (resident_ok): one launch, projected K/V - a deliberate exception to the rule above, bought with
         2 x the small-batch step rate; `resident_max_rows = 0` restores one form at every size."""
         return self.latent_ok and rows >= self.LATENT_MIN_ROWS and not getattr(self, "_small_pass", False)
