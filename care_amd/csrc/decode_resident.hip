@@ -819,7 +819,8 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   // row tiles a workgroup multiplies per fetch of its vocabulary fragments: 2 from 128 rows (ff = 2048 builds) - the 8
   // workgroups of an XCD that share a column item ask its L2 for the same 64 KB at the same time, and two row tiles per
   // fetch halve those requests while doubling the rows a workgroup normalises (*measured*, same box, us per step:
-  // 128 rows 77.6 -> 76.5, 96 rows 73.1 -> 73.0)
+  // 128 rows 77.6 -> 76.5, 96 rows 73.1 -> 73.0; ms per pass with 1 / 2 / 4 row tiles: 192 rows 3.20 / 3.04 / 3.24,
+  // 256 rows 3.38 / 3.25 / 3.44)
   int rb = (ff == 2048 && rows >= 128) ? 2 : 1;
   {
     const char* e = getenv("CARE_RESIDENT_RB");  // tuning
