@@ -224,3 +224,31 @@ def test_compute_modes_and_shape_routing_flags():
     assert x3.split3 and not x3.bf and x3.wt == torch.float32 and not x3.bf_act
     with pytest.raises(ValueError):
         HipEngine(make_opt("msrvtt_care"), "fp8")
+
+
+def test_small_batch_form_rules(monkeypatch):
+    """Which batches take the small-batch forms (resident greedy decode, unfused embedder, projected K/V under beam
+    search): bf16 mode, d_model = 512, up to `resident_max_rows` clips (256, CARE_RESIDENT_MAX_ROWS); off -> one set of
+    forms at every size, and the absorbed cross-attention again follows the model alone."""
+    from care_amd.configs import make_opt
+    from care_amd.engine import HipEngine
+
+    monkeypatch.delenv("CARE_RESIDENT_MAX_ROWS", raising=False)
+    base = HipEngine(make_opt("msrvtt_base_ami"), "bf16")
+    assert base.resident_max_rows == 256
+    assert base.resident_ok(1) and base.resident_ok(256) and not base.resident_ok(257) and not base.resident_ok(0)
+    assert base.small_forms(128) and not base.small_forms(320)
+    assert all(base.latent_for(r) for r in (1, 640, 1 << 20))          # the multi-launch form: absorbed at every size
+    base._small_pass = True                                            # ... except inside a small beam pass
+    assert not base.latent_for(640)
+    base._small_pass = False
+    base.resident_max_rows = 0
+    assert not base.resident_ok(1) and not base.small_forms(1)
+    for cfg, dtype in (("msrvtt_base_ami", "fp32"), ("msrvtt_care", "fp16x3"), ("vatex_care_large", "bf16"),
+                       ("care_median_gelu", "bf16")):
+        e = HipEngine(make_opt(cfg), dtype)
+        assert not e.resident_ok(8) and not e.small_forms(8), (cfg, dtype)   # d_model 512 + bf16 only
+    two = HipEngine(make_opt("msrvtt_base_ami", num_hidden_layers_decoder=2), "bf16")
+    assert two.resident_ok(8)
+    monkeypatch.setenv("CARE_RESIDENT_MAX_ROWS", "64")
+    assert HipEngine(make_opt("msrvtt_care"), "bf16").resident_max_rows == 64
