@@ -1128,8 +1128,15 @@ class HipEngine:
         a form of its own next to the multi-launch one: projected cross K/V, the same rounding points, sums in another
         order - so which of two nearly tied tokens wins can differ between a batch of <= resident_max_rows clips and a
         larger one (the audit of tests/test_gpu_properties.py counts such rows)."""
-        return (0 < rows <= self.resident_max_rows and self.as_ok and self.d == 512 and self.ff in (512, 1024, 2048) and
-                self.T <= 128 and self.n_layers <= 4 and (not self.attr_att or self.topk <= 128))
+        if not (0 < rows <= self.resident_max_rows and self.as_ok and self.d == 512 and self.ff in (512, 1024, 2048) and
+                self.T <= 128 and self.n_layers <= 4 and (not self.attr_att or self.topk <= 128)):
+            return False
+        # one workgroup per CU at most, and at least one per 16-row tile (a partitioned GPU has fewer CUs)
+        if self.device is not None and torch.cuda.is_available():
+            if getattr(self, "_cus", None) is None:
+                self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+            return (rows + 15) // 16 <= self._cus
+        return True
 
     def small_forms(self, clips: int) -> bool:
         """Batches of <= resident_max_rows clips (bf16, d_model = 512) take the small-batch forms of the pass: the
