@@ -276,14 +276,12 @@ enum { E_QKV = 0, E_Q = 1, E_RES = 2, E_ACT = 3, E_VOCAB = 4 };
 
 // 16 rows of the A operand -> LDS (bf16 [16][lda]), d = 512.  A_EMBED / A_LN: a wave owns 4 rows, a lane 2 float4 of
 // each; the rows stay in registers between the statistics and the normalisation (rowops.hip row_layernorm), all
-// loads of the 4 rows issued together.
+// loads of the 4 rows issued together: fetch_a_rows requests them ...
 template <int AMODE>
-__device__ __forceinline__ void load_a_rows(const RArgs& p, int r0, int t, bool writer, const float* ysrc,
-                                            const float* g, const float* be, bool write_x, bf16_t* sA, int lda) {
+__device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, bool writer, const float* ysrc, float4 (&v)[4][2]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int d = 512;
   const int rb = r0 + wave * 4;
-  float4 v[4][2];
   if constexpr (AMODE == A_EMBED) {
     int tok[4] = {p.bos, p.bos, p.bos, p.bos};
     if (writer) advance_state4(p, rb, t, lane, tok);
@@ -312,6 +310,13 @@ __device__ __forceinline__ void load_a_rows(const RArgs& p, int r0, int t, bool 
       v[i][1] = cld_f4(ysrc + (int64_t)r * d + 256 + lane * 4);
     }
   }
+}
+
+// ... and their LayerNorm into the LDS tile (+ the fp32 rows for the residual when write_x)
+__device__ __forceinline__ void finish_a_rows(const RArgs& p, int r0, const float4 (&v)[4][2], const float* g, const float* be,
+                                              bool write_x, bf16_t* sA, int lda) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int d = 512;
   const float4 g0 = *reinterpret_cast<const float4*>(g + lane * 4), g1 = *reinterpret_cast<const float4*>(g + 256 + lane * 4);
   const float4 b0 = *reinterpret_cast<const float4*>(be + lane * 4), b1 = *reinterpret_cast<const float4*>(be + 256 + lane * 4);
 #pragma unroll
@@ -535,12 +540,22 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
   if constexpr (AMODE == A_EMBED)
     if (pm.helper) advance_state4(p, r0 + wave * 4, t, lane);
   if (pm.has) {
+    if constexpr (AMODE == A_BF16) {
 #pragma unroll
-    for (int u = 0; u < RTB; ++u) {
-      if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;
-      if constexpr (AMODE == A_BF16) load_a_bf16<K>(p, r0 + u * 16, reinterpret_cast<const bf16_t*>(asrc), sA + u * 16 * lda, lda);
-      else load_a_rows<AMODE>(p, r0 + u * 16, t, pm.c0 == 0 && !pm.helped, reinterpret_cast<const float*>(asrc), g, be,
-                              write_x && pm.c0 == 0, sA + u * 16 * lda, lda);
+      for (int u = 0; u < RTB; ++u) {
+        if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;
+        load_a_bf16<K>(p, r0 + u * 16, reinterpret_cast<const bf16_t*>(asrc), sA + u * 16 * lda, lda);
+      }
+    } else {  // the rows of every tile requested before the first one is normalised
+      float4 av[RTB][4][2];
+#pragma unroll
+      for (int u = 0; u < RTB; ++u)
+        fetch_a_rows<AMODE>(p, r0 + u * 16, t, pm.c0 == 0 && !pm.helped, reinterpret_cast<const float*>(asrc), av[u]);
+#pragma unroll
+      for (int u = 0; u < RTB; ++u) {
+        if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;
+        finish_a_rows(p, r0 + u * 16, av[u], g, be, write_x && pm.c0 == 0, sA + u * 16 * lda, lda);
+      }
     }
     __syncthreads();
     if constexpr (RTB == 1) load_af(0);
