@@ -113,7 +113,7 @@ def extra_legs(dev, main_dtype, legs):
     resident in HBM, hipGraph replay, measured over >= 5 passes after 3 warm-up calls."""
     from care_amd import get_framework
     from care_amd.configs import feat_shapes, make_opt
-    from care_amd.synth import synth_state_dict
+    from care_amd.synth import synth_input_ids, synth_state_dict
 
     import gc
 
@@ -249,6 +249,39 @@ def extra_legs(dev, main_dtype, legs):
         ms_per_pass=round(dt_api * 1e3, 3), clips_per_s=round(Btf / dt_api, 1), tflops=round(fl * Btf / dt_api / 1e12, 1),
         logits_bytes=Btf * T_ * V_ * 4)
     del model_tf, batch, api
+
+    # ---- training mode (train.py's step without loss / optimiser: Wrapper.py:423-435): forward + backward of the whole
+    # path under torch.autograd, every forward and backward a HIP kernel (care_amd/training.py; fp32 storage, exact-f32
+    # MFMA), at the reference's training batch (opts.py --batch_size 64), dropout at the reference's rates
+    opt, eng = build("msrvtt_care", "fp32")
+    model_tr = eng_model[0]
+    model_tr.train()
+    Btr = 64
+    f_tr = feats_for(opt, Btr)
+    ids_tr = synth_input_ids(7, Btr, opt["max_len"] - 1, opt["vocab_size"]).to(dev)
+    batch = {"feats": f_tr, "input_ids": ids_tr}
+    g_tr = None
+
+    def train_step():
+        nonlocal g_tr
+        for prm in model_tr.parameters():
+            prm.grad = None
+        out = model_tr(batch)
+        if g_tr is None:
+            g_tr = torch.randn_like(out["logits"]) * 1e-3
+        torch.autograd.backward([out["logits"]], [g_tr])
+
+    for _ in range(2):
+        train_step()
+    dt_tr = _timed(train_step, 5)
+    fl_tr = 3.0 * fl  # forward + the two backward products of every GEMM, per clip (same shapes as the teacher-forced forward)
+    legs["training_step"] = dict(config="msrvtt_care", dtype="f32", clips_per_step=Btr,
+                                 what="model.train(); forward + backward through care_amd/training.py (autograd Functions over HIP kernels), "
+                                      "gradient of a fixed cotangent on the logits; no loss, no optimiser",
+                                 ms_per_step=round(dt_tr * 1e3, 3), clips_per_s=round(Btr / dt_tr, 1),
+                                 tflops=round(fl_tr * Btr / dt_tr / 1e12, 2))
+    model_tr.eval()
+    del model_tr, batch, f_tr, ids_tr, g_tr
 
     # ---- host-fed: the reference moves `feats` host -> device per batch (translate.py:34-38); here pinned host batches
     # (what DataLoader(pin_memory=True) yields) through FeaturePrefetcher - H2D on a side stream, overlapped with the
