@@ -57,7 +57,7 @@ struct RArgs {
   const bf16_t* vocab; int V;
   int d, H, ff, act, R, T, steps, bos, eos, pad, early, prof_step, ghost;
   int32_t* fed; int fed_stride; float* score; int32_t* length; int32_t* fin;
-  unsigned* sync; float* xres; float* y; float* q; bf16_t* ctx; bf16_t* h;
+  unsigned* sync; float* xres; float* y; float* y2; float* q; bf16_t* ctx; bf16_t* h;
   float* pmax; int32_t* pidx; float* psum; int parts;
 };
 
@@ -278,7 +278,8 @@ enum { E_QKV = 0, E_Q = 1, E_RES = 2, E_ACT = 3, E_VOCAB = 4 };
 // each; the rows stay in registers between the statistics and the normalisation (rowops.hip row_layernorm), all
 // loads of the 4 rows issued together: fetch_a_rows requests them ...
 template <int AMODE>
-__device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, bool writer, const float* ysrc, float4 (&v)[4][2]) {
+__device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, bool writer, const float* ysrc, const float* ysrc2,
+                                             float4 (&v)[4][2]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int d = 512;
   const int rb = r0 + wave * 4;
@@ -308,6 +309,14 @@ __device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, bool
       const int r = rb + i < p.R ? rb + i : 0;
       v[i][0] = cld_f4(ysrc + (int64_t)r * d + lane * 4);
       v[i][1] = cld_f4(ysrc + (int64_t)r * d + 256 + lane * 4);
+    }
+    if (ysrc2) {  // the second K half of a two-workgroup FFN dense2 (ffn2_phase<true>): y = y + y2
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = rb + i < p.R ? rb + i : 0;
+        add4(v[i][0], cld_f4(ysrc2 + (int64_t)r * d + lane * 4));
+        add4(v[i][1], cld_f4(ysrc2 + (int64_t)r * d + 256 + lane * 4));
+      }
     }
   }
 }
@@ -414,7 +423,7 @@ struct PhaseMap {
 template <int KC, int AMODE, int EPI, bool KSPLIT, int RTB = 1>
 __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf16_t* sA, const bf16_t* W,
                                            const float* bias, int N, const void* asrc, const float* g, const float* be,
-                                           bool write_x, int t, bf16_t* skv) {
+                                           bool write_x, int t, bf16_t* skv, const float* asrc2 = nullptr) {
   // RTB: 16-row tiles a workgroup multiplies with ONE fetch of its W fragments (their A rows side by side in LDS):
   // the weight traffic of a phase is (row tiles / RTB) x the matrix - what bounds the vocabulary phase at 128 rows.
   constexpr int K = 512 * KC, NF = KSPLIT ? 4 * KC : 16 * KC;
@@ -550,7 +559,7 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
       float4 av[RTB][4][2];
 #pragma unroll
       for (int u = 0; u < RTB; ++u)
-        fetch_a_rows<AMODE>(p, r0 + u * 16, t, pm.c0 == 0 && !pm.helped, reinterpret_cast<const float*>(asrc), av[u]);
+        fetch_a_rows<AMODE>(p, r0 + u * 16, t, pm.c0 == 0 && !pm.helped, reinterpret_cast<const float*>(asrc), asrc2, av[u]);
 #pragma unroll
       for (int u = 0; u < RTB; ++u) {
         if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;
@@ -592,6 +601,100 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
           cst_f(p.pmax + (int64_t)r * p.parts + pm.c0, vm[u]);
           cst_i(p.pidx + (int64_t)r * p.parts + pm.c0, vi[u]);
           cst_f(p.psum + (int64_t)r * p.parts + pm.c0, vs[u]);
+        }
+      }
+    }
+  }
+  gs.mark();
+  gs.arrive();
+}
+
+// FFN dense2 + residual for ff = 2048: out[R, 512] = h[R, 2048] W2^T + b2 + x.  K is added in EIGHTHS of 256 (two
+// accumulator chains each), as half0 = e0 + ((e1 + e2) + e3), half1 = e4 + ((e5 + e6) + e7), y = ((half0 + b) + x) + half1,
+// in both forms - a row's bits do not depend on the form its batch takes:
+//   HALF = false: item = 16 columns, wave w multiplies eighths 2 w and 2 w + 1, wave 0 adds the eight tiles from LDS;
+//   HALF = true (<= 64 rows: 32 items per row tile leave most CUs idle and each fetches 64 KB of W2 - what the phase waits for):
+//                item = (16 columns, K half), wave w multiplies eighth 4 half + w; the half-0 workgroup stores
+//                (half0 + b) + x to y, the half-1 workgroup stores half1 to y2, and the consumers add y + y2 on load.
+template <bool HALF>
+__device__ __forceinline__ void ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const bf16_t* W, const float* bias) {
+  constexpr int K = 2048, lda = K + 8, NF = HALF ? 8 : 16;
+  __shared__ f32x4 s_e[2][7][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
+  const int RT = (p.R + 15) >> 4, CI = HALF ? 64 : 32;
+  const PhaseMap pm(RT, CI);
+  const int r0 = pm.rt * 16, r = r0 + l16;
+  auto k0_of = [&](int c) { return HALF ? ((c & 1) * 4 + wave) * 256 : wave * 512; };
+  auto n0_of = [&](int c) { return (HALF ? c >> 1 : c) * 16; };
+  bf16x8 wf[NF];
+  if (gs.dead) return;
+  if (pm.has) load_w<NF>(wf, W + (int64_t)(n0_of(pm.c0) + l16) * K + k0_of(pm.c0) + kg * 8);
+  gs.wait();
+  if (gs.dead) return;
+  gs.mark();
+  if (pm.has) {
+    int par = 0;
+    bool tile_loaded = false;
+    for (int c = pm.c0; c < CI; c += pm.nper, par ^= 1) {
+      const int n0 = n0_of(c), nb = n0 + kg * 4, k0 = k0_of(c), kh = HALF ? c & 1 : 0;
+      if (c != pm.c0) load_w<NF>(wf, W + (int64_t)(n0 + l16) * K + k0 + kg * 8);
+      float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wave == 0 && kh == 0 && r < p.R) xr = cld_f4(p.xres + (int64_t)r * 512 + nb);
+      if (!tile_loaded || HALF) {  // the 16 rows of h (HALF: the K half of this item) -> LDS
+        if (tile_loaded) __syncthreads();
+        constexpr int KP = HALF ? 1024 : 2048, per_row = KP / 8, NC = 16 * per_row / 256;
+        const int kb = HALF ? kh * 1024 : 0;
+        bf16x8 v[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          const int q = threadIdx.x + 256 * i, rr = q / per_row, c8 = q - rr * per_row;
+          v[i] = cld_b8(p.h + (int64_t)(r0 + rr < p.R ? r0 + rr : 0) * K + kb + c8 * 8);
+          if (r0 + rr >= p.R) v[i] = bf16x8{};
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          const int q = threadIdx.x + 256 * i, rr = q / per_row, c8 = q - rr * per_row;
+          *reinterpret_cast<bf16x8*>(sA + rr * lda + kb + c8 * 8) = v[i];
+        }
+        __syncthreads();
+        tile_loaded = true;
+      }
+      const bf16_t* ar = sA + l16 * lda + k0 + kg * 8;
+      f32x4 e[NF / 8];
+#pragma unroll
+      for (int h8 = 0; h8 < NF / 8; ++h8) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = h8 * 8; i < h8 * 8 + 8; i += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], *reinterpret_cast<const bf16x8*>(ar + i * 32), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], *reinterpret_cast<const bf16x8*>(ar + (i + 1) * 32), acc1, 0, 0, 0);
+        }
+        e[h8] = acc0 + acc1;
+      }
+      // eighth tiles of the other waves -> LDS (slot = eighth - 1 within the item's range; wave 0 keeps its first)
+      if constexpr (HALF) {
+        if (wave > 0) s_e[par][wave - 1][lane] = e[0];
+      } else {
+        if (wave == 0) s_e[par][0][lane] = e[1];
+        else { s_e[par][2 * wave - 1][lane] = e[0]; s_e[par][2 * wave][lane] = e[1]; }
+      }
+      __syncthreads();
+      if (wave == 0 && r < p.R) {
+        if constexpr (HALF) {
+          const f32x4 half = e[0] + ((s_e[par][0][lane] + s_e[par][1][lane]) + s_e[par][2][lane]);
+          if (kh == 0) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
+            cst_f4(p.y + (int64_t)r * 512 + nb, make_float4((half[0] + bv.x) + xr.x, (half[1] + bv.y) + xr.y,
+                                                             (half[2] + bv.z) + xr.z, (half[3] + bv.w) + xr.w));
+          } else {
+            cst_f4(p.y2 + (int64_t)r * 512 + nb, make_float4(half[0], half[1], half[2], half[3]));
+          }
+        } else {
+          const f32x4 half0 = e[0] + ((s_e[par][0][lane] + s_e[par][1][lane]) + s_e[par][2][lane]);
+          const f32x4 half1 = s_e[par][3][lane] + ((s_e[par][4][lane] + s_e[par][5][lane]) + s_e[par][6][lane]);
+          const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
+          cst_f4(p.y + (int64_t)r * 512 + nb, make_float4(((half0[0] + bv.x) + xr.x) + half1[0], ((half0[1] + bv.y) + xr.y) + half1[1],
+                                                           ((half0[2] + bv.z) + xr.z) + half1[2], ((half0[3] + bv.w) + xr.w) + half1[3]));
         }
       }
     }
@@ -698,20 +801,21 @@ __device__ __forceinline__ void attn_phase(const RArgs& p, GridSync& gs, bool do
 
 // KCF = ff / 512; RB: row tiles per workgroup in the vocabulary phase; SM (few row tiles): QKV and FFN dense1 as
 // 16-column K-split items too (the same bits either way: gemm_phase adds K in the same order in both forms)
-template <int KCF, int RB, bool SM>
+template <int KCF, int RB, bool SM, bool HF>  // HF (ff = 2048, <= 64 rows): FFN dense2 over two workgroups per column tile
 __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
   GridSync gs{p.sync, gridDim.x + (unsigned)p.ghost, 0u, -1, false};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = p.d;
+  const float* y2 = (KCF == 4 && HF) ? p.y2 : nullptr;  // the second K half of FFN dense2, added by its consumers
   bool ended = false;
   for (int t = 1; t <= p.steps && !ended && !gs.dead; ++t) {
     gs.slot = (p.prof_step == t && blockIdx.x == 0) ? 0 : -1;
     for (int l = 0; l < p.n_layers; ++l) {
       const RLayer& L = p.L[l];
       if (l == 0) gemm_phase<1, A_EMBED, E_QKV, SM>(p, gs, t > 1, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv);
-      else gemm_phase<1, A_LN, E_QKV, SM>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv);
+      else gemm_phase<1, A_LN, E_QKV, SM>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2);
       if (l == 0 && t > 1) {  // every row ended with the token chosen in the phase above? (read after its barrier)
         gs.wait();
         if (p.early && __hip_atomic_load(p.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.R) {
@@ -734,11 +838,12 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
         g = A.g; be = A.be;
       }
       gemm_phase<1, A_LN, E_ACT, SM>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr);
-      gemm_phase<KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr);
+      if constexpr (KCF == 4) ffn2_phase<HF>(p, gs, sA, L.w2, L.b2);
+      else gemm_phase<KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr);
     }
     if (ended) break;
     const RLayer& LL = p.L[p.n_layers - 1];
-    gemm_phase<1, A_LN, E_VOCAB, false, RB>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr);
+    gemm_phase<1, A_LN, E_VOCAB, false, RB>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2);
   }
   if (!ended && !gs.dead) gs.wait();
   if (gs.dead) {  // aborted (GridSync::wait): say so where the host looks anyway
@@ -754,7 +859,7 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   }
 }
 
-std::atomic<unsigned long long> g_res_lds_done[5];
+std::atomic<unsigned long long> g_res_lds_done[6];
 
 }  // namespace
 
@@ -763,8 +868,8 @@ extern "C" {
 int64_t care_decode_resident_scratch(int rows, int d, int ff, int V) {
   if (rows < 1 || d < 1 || ff < 1 || V < 1) return CARE_EINVAL;
   const int64_t R16 = (rows + 15) / 16 * 16, parts = (V + 63) / 64;
-  // sync | xres, y, q fp32 [R16, d] | ctx bf16 [R16, d] | h bf16 [R16, ff] | pmax, pidx, psum [R16, parts]
-  return 2048 + R16 * d * 4 * 3 + R16 * d * 2 + R16 * ff * 2 + R16 * parts * 12;
+  // sync | xres, y, y2, q fp32 [R16, d] | ctx bf16 [R16, d] | h bf16 [R16, ff] | pmax, pidx, psum [R16, parts]
+  return 2048 + R16 * d * 4 * 4 + R16 * d * 2 + R16 * ff * 2 + R16 * parts * 12;
 }
 
 int care_decode_resident(const care_resident_layer* layers, int n_layers, const float* word, const float* pos,
@@ -817,6 +922,7 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   p.sync = (unsigned*)b; b += 2048;
   p.xres = (float*)b; b += R16 * d * 4;
   p.y = (float*)b; b += R16 * d * 4;
+  p.y2 = (float*)b; b += R16 * d * 4;
   p.q = (float*)b; b += R16 * d * 4;
   p.ctx = (bf16_t*)b; b += R16 * d * 2;
   p.h = (bf16_t*)b; b += R16 * ff * 2;
@@ -861,20 +967,25 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   if (e != hipSuccess) return (int)e;
   const dim3 g(grid), blk(256);
   int rc;
-#define RES_LAUNCH(KCF, RB, SM, SLOT)                                                                                   \
+#define RES_LAUNCH(KCF, RB, SM, HF, SLOT)                                                                               \
   do {                                                                                                                  \
-    if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<KCF, RB, SM>, lds, g_res_lds_done[SLOT]))) return rc; \
-    hipLaunchKernelGGL((decode_resident_kernel<KCF, RB, SM>), g, blk, lds, st, p);                                      \
+    if ((rc = care_allow_dynamic_lds((const void*)decode_resident_kernel<KCF, RB, SM, HF>, lds, g_res_lds_done[SLOT]))) return rc; \
+    hipLaunchKernelGGL((decode_resident_kernel<KCF, RB, SM, HF>), g, blk, lds, st, p);                                  \
   } while (0)
   // QKV / FFN dense1 in 16-column K-split items up to 64 rows (*measured* us / step with / without: 1 row 43.6 / 47.1,
-  // 32 rows 60.7 / 65.0, 64 rows 66.0 / 67.7, 128 rows 76.9 / 77.5 with 8.1 against 4.6 us in FFN dense1)
+  // 32 rows 60.7 / 65.0, 64 rows 66.0 / 67.7, 128 rows 76.9 / 77.5 with 8.1 against 4.6 us in FFN dense1); FFN dense2
+  // over two workgroups per column tile up to 64 rows (ffn2_phase; *measured* ms per pass with / without: 1 row 1.28 / 1.33,
+  // 16 rows 1.59 / 1.68, 32 rows 1.69 / 1.86, 64 rows 1.94 / 2.00)
   const char* sme = getenv("CARE_RESIDENT_SMALL");  // tuning
   const bool small = sme ? atoi(sme) != 0 : rows <= 64;
-  if (ff == 512) RES_LAUNCH(1, 1, true, 0);
-  else if (ff == 1024) RES_LAUNCH(2, 1, true, 1);
-  else if (rb == 2) RES_LAUNCH(4, 2, false, 3);
-  else if (small) RES_LAUNCH(4, 1, true, 4);
-  else RES_LAUNCH(4, 1, false, 2);
+  const char* hfe = getenv("CARE_RESIDENT_HALF_ROWS");   // tuning
+  const bool half = rows <= (hfe ? atoi(hfe) : 64);
+  if (ff == 512) RES_LAUNCH(1, 1, true, false, 0);
+  else if (ff == 1024) RES_LAUNCH(2, 1, true, false, 1);
+  else if (rb == 2) RES_LAUNCH(4, 2, false, false, 3);
+  else if (small && half) RES_LAUNCH(4, 1, true, true, 5);
+  else if (small) RES_LAUNCH(4, 1, true, false, 4);
+  else RES_LAUNCH(4, 1, false, false, 2);
 #undef RES_LAUNCH
   return care_launch_status();
 }
