@@ -3,7 +3,7 @@
 // A decoder step of a small batch (1 .. a few hundred caption rows) is launch-bound: ~15 dependent kernels of
 // 4-5 us each (rocprofv3, profiles/r03_small_batch_multilaunch_*), none of which has more than a few microseconds of
 // work.  Here one grid of <= one workgroup per CU stays resident for all T steps and walks the phases of a step
-// separated by grid barriers (split arrive / wait, no fences - see GridSync): per decoder layer
+// separated by producer-counted hand-offs (no fences, no full barriers - see GridSync): per decoder layer
 //
 //   QKV projection (+ token choice of the previous step + embedding) | self-attention | dense + residual |
 //   { query projection | attention over the static keys | dense + residual } per cross / attribute block |
@@ -100,56 +100,74 @@ __device__ __forceinline__ void cst_b8(bf16_t* p, bf16x8 v) {
 }
 __device__ __forceinline__ void cst_b4(bf16_t* p, bf16x4 v) { cst8(p, __builtin_bit_cast(unsigned long long, v)); }
 
-// grid barrier: arrive() at the end of a phase, wait() after the next phase has issued the loads that do not depend
-// on it.  Two levels of monotonic counters (8 groups by blockIdx % 8, the XCD round-robin; then one), the last
-// arriver publishes the generation in a flag of its own cache line, which is all the waiters poll.
-// sync (unsigned, 128-byte lines): [0] top counter, [1] rows ended, [2] steps run, [32] flag, [64 + 32 g] group g,
-// [320 ..] phase clocks (tools).
+// Synchronisation between phases: producer-counted hand-offs instead of full grid barriers.  Only the workgroups that
+// HAVE WORK in a phase (`participants`) count themselves in when their stores are acknowledged - one atomic add on the
+// phase's counter, sharded 8 ways by blockIdx % 8 (the XCD; 128-byte lines of their own) - and only the participants
+// of the NEXT phase wait, polling the 8 shards until their sum reaches producers x executions.  Against the two-level
+// barrier with a published generation (every workgroup: group counter -> top counter -> flag -> poll) that is one
+// memory round trip less per phase and no waiting for workgroups that have nothing to do.  Why it is enough:
+//   * a phase reads what the previous phase wrote, or older data whose writers the previous phase's producers waited
+//     for in turn (residual rows, caches, decode state): the order is transitive along the chain of phases;
+//   * a buffer is overwritten in phase k + 2 at the earliest by workgroups that waited for ALL producers of phase
+//     k + 1, and the readers of the old contents in phase k + 1 are among those producers;
+//   * every workgroup waits for the first phase of a step (the token choice): all of them read the same `rows ended`.
+// sync (unsigned): [1] rows ended, [2] steps run, [33] abort flag, [512 ..] phase clocks (tools), [1024 + (32 slot + 4
+// shard) * 8 ...]: counter of (slot, shard), slot = the phase's position within a step.
+constexpr int RES_MAX_SLOTS = 48;
+constexpr int RES_SYNC_BYTES = 4096 + RES_MAX_SLOTS * 8 * 128;
 struct GridSync {
-  unsigned* sync; unsigned nblk; unsigned gen;
-  int slot;  // >= 0: workgroup 0 records the device clock at the phase boundaries of one step (sync + 320, 8-byte slots)
+  unsigned* sync;
+  unsigned ghost;  // tests: producers that never arrive are expected too (the watchdog)
+  int slot;        // >= 0: workgroup 0 records the device clock at the phase boundaries of one step (sync + 512, 8-byte slots)
+  bool dead;
+  int cur, prev;   // position of this phase / of the phase it consumes within the step
+  unsigned want;   // what the counters of `prev` must add up to: its producers x the times it has run (0: nothing to wait for)
   __device__ __forceinline__ void mark() {
-    if (slot >= 0 && slot < 96 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(sync + 320)[slot++] = wall_clock64();
+    if (slot >= 0 && slot < 96 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(sync + 512)[slot++] = wall_clock64();
   }
-  __device__ __forceinline__ void arrive() {
+  __device__ __forceinline__ unsigned* counter(int sl, int shard) const { return sync + 1024 + (sl * 8 + shard) * 32; }
+  __device__ __forceinline__ void arrive(bool participant) {
+    if (!participant) return;       // workgroup-uniform
     __builtin_amdgcn_s_waitcnt(0);  // this wave's write-through stores are acknowledged
     __syncthreads();
-    gen += 1;
-    if (threadIdx.x == 0) {
-      const unsigned grp = blockIdx.x & 7, ngrp = (nblk + 7 - grp) >> 3, ngroups = nblk < 8 ? nblk : 8;
-      const unsigned old = __hip_atomic_fetch_add(sync + 64 + grp * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old == gen * ngrp - 1) {
-        const unsigned o2 = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (o2 == gen * ngroups - 1) __hip_atomic_store(sync + 32, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter(cur, blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // A workgroup that has spun for ~2 s without the others arriving (workgroups that never became resident: another
-  // kernel holds CUs for good, e.g. a second resident launch on another stream) raises the abort flag; every
-  // workgroup then leaves, phases turn into no-ops and length[0] = -1 tells the host (care_decode_resident).
-  bool dead;
+  // A workgroup that has spun for ~2 s (workgroups that never became resident: another kernel holds CUs for good, e.g.
+  // a second resident launch on another stream) raises the abort flag; every workgroup then leaves at its next wait,
+  // phases turn into no-ops and length[0] = -1 tells the host (care_decode_resident).
   __device__ __forceinline__ void wait() {
     __shared__ int s_dead;
-    if (threadIdx.x == 0) {
+    if (want == 0) return;  // the first phase of the launch
+    if (threadIdx.x < 64) {
+      const unsigned need = want + ghost;
+      const unsigned* c = counter(prev, threadIdx.x & 7);
       int d = 0;
       unsigned spins = 0;
       unsigned long long t0 = 0;
       for (;;) {
-        const unsigned long long f = cld8(sync + 32);  // {generation, abort}
-        if ((unsigned)f >= gen) break;
-        if (f >> 32) { d = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 4095u) == 0) {
-          const unsigned long long now = wall_clock64();  // 100 MHz
-          if (!t0) t0 = now;
-          else if (now - t0 > 200000000ull) {
-            __hip_atomic_store(sync + 33, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            d = 1;
-            break;
+        unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // lanes 0 .. 7: the 8 shards
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        if (v >= need) break;  // (the same sum in every group of 8 lanes)
+#ifndef RES_POLL_SLEEP
+#define RES_POLL_SLEEP 1
+#endif
+        __builtin_amdgcn_s_sleep(RES_POLL_SLEEP);
+        if ((++spins & 63u) == 0) {
+          if (__hip_atomic_load(sync + 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { d = 1; break; }
+          if ((spins & 4095u) == 0) {
+            const unsigned long long now = wall_clock64();  // 100 MHz
+            if (!t0) t0 = now;
+            else if (now - t0 > 200000000ull) {
+              __hip_atomic_store(sync + 33, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              d = 1;
+              break;
+            }
           }
         }
       }
-      s_dead = d;
+      if (threadIdx.x == 0) s_dead = d;
     }
     __syncthreads();
     dead = dead || s_dead != 0;
@@ -407,7 +425,10 @@ struct PhaseMap {
     } else {
       nper = G / RT; rt = b % RT; c0 = b / RT; has = c0 < nper && c0 < CI;
     }
+    np_ = (unsigned)(RT * (nper < CI ? nper : CI));
+    nh_ = helped ? (unsigned)RT : 0u;
   }
+  unsigned np_, nh_;  // workgroups with an item / helpers in this phase (the same numbers in every workgroup)
 };
 
 // One GEMM phase: out[R, N] = A[R, K] W[N, K]^T (+ bias, epilogue EPI), K = 512 * KC.  A workgroup loads (and
@@ -421,7 +442,7 @@ struct PhaseMap {
 // E_VOCAB keeps a running (max, arg-max, sum exp) per lane over the workgroup's items and merges lanes and waves once,
 // after the last item: one partial per (row, workgroup of the row tile), p.parts of them per row.
 template <int KC, int AMODE, int EPI, bool KSPLIT, int RTB = 1>
-__device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf16_t* sA, const bf16_t* W,
+__device__ __forceinline__ unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf16_t* sA, const bf16_t* W,
                                            const float* bias, int N, const void* asrc, const float* g, const float* be,
                                            bool write_x, int t, bf16_t* skv, const float* asrc2 = nullptr) {
   // RTB: 16-row tiles a workgroup multiplies with ONE fetch of its W fragments (their A rows side by side in LDS):
@@ -541,10 +562,13 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
   };
 
   bf16x8 wa[NF], wb[NF];
-  if (gs.dead) return;
+  // who hands this phase's output on: the workgroups with an item (+ the helpers that advance the decode state)
+  const bool participant = pm.has || (AMODE == A_EMBED && pm.helper);
+  const unsigned nprod = pm.np_ + (AMODE == A_EMBED ? pm.nh_ : 0u);
+  if (gs.dead) return nprod;
   if (pm.has) fetch(wa, pm.c0);
-  if (do_wait) gs.wait();
-  if (gs.dead) return;
+  if (do_wait && participant) gs.wait();
+  if (gs.dead) return nprod;
   gs.mark();
   if constexpr (AMODE == A_EMBED)
     if (pm.helper) advance_state4(p, r0 + wave * 4, t, lane);
@@ -606,7 +630,8 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
     }
   }
   gs.mark();
-  gs.arrive();
+  gs.arrive(participant);
+  return nprod;
 }
 
 // FFN dense2 + residual for ff = 2048: out[R, 512] = h[R, 2048] W2^T + b2 + x.  K is added in EIGHTHS of 256 (two
@@ -617,7 +642,7 @@ __device__ __forceinline__ void gemm_phase(const RArgs& p, GridSync& gs, bool do
 //                item = (16 columns, K half), wave w multiplies eighth 4 half + w; the half-0 workgroup stores
 //                (half0 + b) + x to y, the half-1 workgroup stores half1 to y2, and the consumers add y + y2 on load.
 template <bool HALF>
-__device__ __forceinline__ void ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const bf16_t* W, const float* bias) {
+__device__ __forceinline__ unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const bf16_t* W, const float* bias) {
   constexpr int K = 2048, lda = K + 8, NF = HALF ? 8 : 16;
   __shared__ f32x4 s_e[2][7][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
@@ -627,10 +652,11 @@ __device__ __forceinline__ void ffn2_phase(const RArgs& p, GridSync& gs, bf16_t*
   auto k0_of = [&](int c) { return HALF ? ((c & 1) * 4 + wave) * 256 : wave * 512; };
   auto n0_of = [&](int c) { return (HALF ? c >> 1 : c) * 16; };
   bf16x8 wf[NF];
-  if (gs.dead) return;
+  const unsigned nprod = pm.np_;
+  if (gs.dead) return nprod;
   if (pm.has) load_w<NF>(wf, W + (int64_t)(n0_of(pm.c0) + l16) * K + k0_of(pm.c0) + kg * 8);
-  gs.wait();
-  if (gs.dead) return;
+  if (pm.has) gs.wait();
+  if (gs.dead) return nprod;
   gs.mark();
   if (pm.has) {
     int par = 0;
@@ -700,7 +726,8 @@ __device__ __forceinline__ void ffn2_phase(const RArgs& p, GridSync& gs, bf16_t*
     }
   }
   gs.mark();
-  gs.arrive();
+  gs.arrive(pm.has);
+  return nprod;
 }
 
 // One attention phase: ctx[r, h*64 ..] = softmax(q_h K_h^T / 8 (masked, + bias)) V_h for every (row, head); one
@@ -708,21 +735,30 @@ __device__ __forceinline__ void ffn2_phase(const RArgs& p, GridSync& gs, bf16_t*
 // is added after the mask (models/components/Attention.py:104-111).  The heads of a row go to the waves of ONE XCD
 // (row % 8), so a row's static K/V is read into one L2.
 template <bool SELF>  // SELF: the keys / values are the cache this launch writes (coherent loads), pad mask from `fed`
-__device__ __forceinline__ void attn_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
+__device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
                                            int rows_per_kv, int nk, const int32_t* pad_tok, const float* bias,
                                            int bias_ld) {
-  if (gs.dead) return;
-  if (do_wait) gs.wait();
-  if (gs.dead) return;
-  gs.mark();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 3, chunk = lane & 7;
   constexpr int d = 512;
   const int nkb = (nk + 7) >> 3, H = p.H;
   const bool by_xcd = (gridDim.x & 7) == 0;
   const int x = by_xcd ? (int)(blockIdx.x & 7) : 0, xs = by_xcd ? 8 : 1;
-  const int myslot = (by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) + (by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x) * wave;
-  const int nslots = (by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x) * 4;
+  const int bpx = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;  // workgroups per XCD (or all of them)
+  const int slot0 = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int myslot = slot0 + bpx * wave;
+  const int nslots = bpx * 4;
   const int nrows_x = (p.R - x + xs - 1) / xs;  // rows x, x + xs, ...
+  // a workgroup has an item iff its wave 0 has one (the smallest slot of the four)
+  const bool participant = slot0 < nrows_x * H;
+  unsigned nprod = 0;
+  for (int xx = 0; xx < xs; ++xx) {
+    const int it = ((p.R - xx + xs - 1) / xs) * H;
+    nprod += (unsigned)(it < bpx ? it : bpx);
+  }
+  if (gs.dead) return nprod;
+  if (do_wait && participant) gs.wait();
+  if (gs.dead) return nprod;
+  gs.mark();
   for (int li = myslot; li < nrows_x * H; li += nslots) {
     const int r = x + xs * (li / H), hh = li % H;
     float q[8];
@@ -796,7 +832,8 @@ __device__ __forceinline__ void attn_phase(const RArgs& p, GridSync& gs, bool do
     }
   }
   gs.mark();
-  gs.arrive();
+  gs.arrive(participant);
+  return nprod;
 }
 
 // KCF = ff / 512; RB: row tiles per workgroup in the vocabulary phase; SM (few row tiles): QKV and FFN dense1 as
@@ -805,47 +842,69 @@ template <int KCF, int RB, bool SM, bool HF>  // HF (ff = 2048, <= 64 rows): FFN
 __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
-  GridSync gs{p.sync, gridDim.x + (unsigned)p.ghost, 0u, -1, false};
+  GridSync gs{p.sync, (unsigned)p.ghost, -1, false, 0, 0, 0u};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = p.d;
   const float* y2 = (KCF == 4 && HF) ? p.y2 : nullptr;  // the second K half of FFN dense2, added by its consumers
   bool ended = false;
+  // the phase a phase consumes: its position within the step, its producers, how many times it has run
+  int sl = 0, sl_prev = 0;
+  unsigned np_prev = 0, ex_prev = 0;
+#define RES_PHASE(CALL)                     \
+  do {                                      \
+    gs.prev = sl_prev;                      \
+    gs.want = np_prev * ex_prev;            \
+    gs.cur = sl;                            \
+    const unsigned np_this = (CALL);        \
+    sl_prev = sl;                           \
+    np_prev = np_this;                      \
+    ex_prev = (unsigned)t;                  \
+    ++sl;                                   \
+  } while (0)
   for (int t = 1; t <= p.steps && !ended && !gs.dead; ++t) {
     gs.slot = (p.prof_step == t && blockIdx.x == 0) ? 0 : -1;
+    sl = 0;
     for (int l = 0; l < p.n_layers; ++l) {
       const RLayer& L = p.L[l];
-      if (l == 0) gemm_phase<1, A_EMBED, E_QKV, SM>(p, gs, t > 1, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv);
-      else gemm_phase<1, A_LN, E_QKV, SM>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2);
-      if (l == 0 && t > 1) {  // every row ended with the token chosen in the phase above? (read after its barrier)
+      if (l == 0) RES_PHASE((gemm_phase<1, A_EMBED, E_QKV, SM>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv)));
+      else RES_PHASE((gemm_phase<1, A_LN, E_QKV, SM>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2)));
+      if (l == 0 && t > 1) {  // every row ended with the token chosen in the phase above?  EVERY workgroup waits for it
+        gs.prev = sl_prev;
+        gs.want = np_prev * ex_prev;
         gs.wait();
         if (p.early && __hip_atomic_load(p.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.R) {
           ended = true;
           if (blockIdx.x == 0 && threadIdx.x == 0) p.sync[2] = (unsigned)(t - 1);
           break;
         }
-        attn_phase<true>(p, gs, false, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0);
+        RES_PHASE((attn_phase<true>(p, gs, false, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)));
       } else {
-        attn_phase<true>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0);
+        RES_PHASE((attn_phase<true>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)));
       }
-      gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, L.o_w, L.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr);
+      RES_PHASE((gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, L.o_w, L.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
       const float* g = L.g;
       const float* be = L.be;
       for (int a = 0; a < L.n_att; ++a) {
         const RAttn& A = L.att[a];
-        gemm_phase<1, A_LN, E_Q, true>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr);
-        attn_phase<false>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld);
-        gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr);
+        RES_PHASE((gemm_phase<1, A_LN, E_Q, true>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr)));
+        RES_PHASE((attn_phase<false>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)));
+        RES_PHASE((gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
         g = A.g; be = A.be;
       }
-      gemm_phase<1, A_LN, E_ACT, SM>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr);
-      if constexpr (KCF == 4) ffn2_phase<HF>(p, gs, sA, L.w2, L.b2);
-      else gemm_phase<KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr);
+      RES_PHASE((gemm_phase<1, A_LN, E_ACT, SM>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr)));
+      if constexpr (KCF == 4) RES_PHASE((ffn2_phase<HF>(p, gs, sA, L.w2, L.b2)));
+      else RES_PHASE((gemm_phase<KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr)));
     }
     if (ended) break;
     const RLayer& LL = p.L[p.n_layers - 1];
-    gemm_phase<1, A_LN, E_VOCAB, false, RB>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2);
+    RES_PHASE((gemm_phase<1, A_LN, E_VOCAB, false, RB>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2)));
   }
-  if (!ended && !gs.dead) gs.wait();
+#undef RES_PHASE
+  if (!ended && !gs.dead) {  // every workgroup: the vocabulary partials of the last step are complete
+    gs.prev = sl_prev;
+    gs.want = np_prev * ex_prev;
+    gs.wait();
+  }
   if (gs.dead) {  // aborted (GridSync::wait): say so where the host looks anyway
     if (blockIdx.x == 0 && threadIdx.x == 0) { cst_i(p.length, -1); p.sync[2] = 0xffffffffu; }
     return;
@@ -869,7 +928,7 @@ int64_t care_decode_resident_scratch(int rows, int d, int ff, int V) {
   if (rows < 1 || d < 1 || ff < 1 || V < 1) return CARE_EINVAL;
   const int64_t R16 = (rows + 15) / 16 * 16, parts = (V + 63) / 64;
   // sync | xres, y, y2, q fp32 [R16, d] | ctx bf16 [R16, d] | h bf16 [R16, ff] | pmax, pidx, psum [R16, parts]
-  return 2048 + R16 * d * 4 * 4 + R16 * d * 2 + R16 * ff * 2 + R16 * parts * 12;
+  return RES_SYNC_BYTES + R16 * d * 4 * 4 + R16 * d * 2 + R16 * ff * 2 + R16 * parts * 12;
 }
 
 int care_decode_resident(const care_resident_layer* layers, int n_layers, const float* word, const float* pos,
@@ -911,7 +970,7 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   p.vocab = (const bf16_t*)vocab_w; p.V = V;
   p.d = d; p.H = heads; p.ff = ff; p.act = act; p.R = rows; p.T = T; p.steps = steps; p.bos = bos; p.eos = eos; p.pad = pad; p.early = early_exit;
   {
-    const char* ps = getenv("CARE_RESIDENT_PROF_STEP");  // tools only: phase clocks of that step -> scratch + 1280
+    const char* ps = getenv("CARE_RESIDENT_PROF_STEP");  // tools only: phase clocks of that step -> scratch + 2048
     p.prof_step = ps ? atoi(ps) : 0;
     p.ghost = getenv("CARE_RESIDENT_TEST_GHOST") ? 8 : 0;  // tests only: barriers that can never complete (watchdog)
   }
@@ -919,7 +978,7 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   const int64_t R16 = (rows + 15) / 16 * 16;
   p.parts = (V + 63) / 64;
   unsigned char* b = (unsigned char*)scratch;
-  p.sync = (unsigned*)b; b += 2048;
+  p.sync = (unsigned*)b; b += RES_SYNC_BYTES;
   p.xres = (float*)b; b += R16 * d * 4;
   p.y = (float*)b; b += R16 * d * 4;
   p.y2 = (float*)b; b += R16 * d * 4;
@@ -963,7 +1022,7 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   int lds = 16 * (kmax + 8) * 2;
   if (rb * 16 * (512 + 8) * 2 > lds) lds = rb * 16 * (512 + 8) * 2;
   hipStream_t st = (hipStream_t)stream;
-  e = hipMemsetAsync(p.sync, 0, 2048, st);
+  e = hipMemsetAsync(p.sync, 0, RES_SYNC_BYTES, st);
   if (e != hipSuccess) return (int)e;
   const dim3 g(grid), blk(256);
   int rc;

@@ -568,7 +568,7 @@ int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, i
  *   Requires d == 512, heads == 8, ff in {512, 1024, 2048}, T <= 128, nkeys <= 128, n_layers <= 4, n_att <= 2.
  *   Every workgroup must be resident at the same time (they wait for one another): do not run two of these launches
  *   concurrently on different streams.  A workgroup that waits ~2 s at a barrier aborts the launch: length[0] = -1.
- *   The one entry point that issues two operations: a 2-KB memset node (barrier counters) and the kernel.
+ *   The one entry point that issues two operations: a 52-KB memset node (hand-off counters) and the kernel.
  */
 typedef struct care_resident_attn {
   const void* q_w; const float* q_b; const void* o_w; const float* o_b; const float* ln_g; const float* ln_b;

@@ -119,7 +119,7 @@ def test_abi_library_exports_every_declared_symbol():
         sizes = [int(v) for v in subprocess.run([os.path.join(td, "sz")], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [ctypes.sizeof(_lib.ResidentAttn), ctypes.sizeof(_lib.ResidentLayer), _lib.ResidentLayer.n_att.offset,
                      _lib.ResidentAttn.bias.offset]
-    assert loaded.care_decode_resident_scratch(1, 512, 2048, 10547) == 2048 + 16 * (512 * 18 + 2048 * 2 + 165 * 12)
+    assert loaded.care_decode_resident_scratch(1, 512, 2048, 10547) == 53248 + 16 * (512 * 18 + 2048 * 2 + 165 * 12)
     assert loaded.care_decode_resident_scratch(0, 512, 2048, 10547) < 0
     assert loaded.care_version() == int(re.search(r"#define CARE_ABI_VERSION (\d+)", header).group(1))
     assert loaded.care_arch() == b"gfx950"

@@ -28,7 +28,7 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 128]:
     torch.cuda.synchronize()
     nb = _lib.load().care_decode_resident_scratch(B, eng.d, eng.ff, eng.V)
     sc = eng.ws("r_scratch", (nb,), torch.uint8)
-    t = sc[1280:1280 + 8 * (2 * len(names) + 2)].view(torch.int64).cpu().tolist()
+    t = sc[2048:2048 + 8 * (2 * len(names) + 2)].view(torch.int64).cpu().tolist()
     vt = t[-4:]
     t = t[:-4] + [t[-4], t[-1]]
     print("  vocab: A rows %.2f us, items %.2f us, merge + store %.2f us" % ((vt[1] - vt[0]) / 100.0, (vt[2] - vt[1]) / 100.0, (vt[3] - vt[2]) / 100.0))
