@@ -550,7 +550,7 @@ int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, i
  *   Replaces the step loop of Translator.translate_batch with beam_size 1 (models/Translator.py:77-143: embedding,
  *   models/Decoder.py + models/components/Layers.py:157-228 per layer, Head.py:26-32, the top-1 of Beam.advance, and
  *   the `no active instance` exit of Translator.py:77-81) for batches whose step is bound by launch latency: a grid of
- *   at most one workgroup per CU stays resident and walks the phases of every step separated by grid barriers
+ *   at most one workgroup per CU stays resident and walks the phases of every step, handed on through producer counters
  *   (csrc/decode_resident.hip).  bf16 weights / caches, fp32 accumulation and statistics - the rounding points of the
  *   multi-launch path with projected cross K/V.
  *   care_resident_attn: one post-LN attention block over STATIC keys (inter_attention / attr_attention): q_w [d, d],
@@ -567,7 +567,7 @@ int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, i
  *   the widest phase has items, at most one per CU; every workgroup must be resident).
  *   Requires d == 512, heads == 8, ff in {512, 1024, 2048}, T <= 128, nkeys <= 128, n_layers <= 4, n_att <= 2.
  *   Every workgroup must be resident at the same time (they wait for one another): do not run two of these launches
- *   concurrently on different streams.  A workgroup that waits ~2 s at a barrier aborts the launch: length[0] = -1.
+ *   concurrently on different streams.  A workgroup that waits ~2 s for a phase's producers aborts the launch: length[0] = -1.
  *   The one entry point that issues two operations: a 52-KB memset node (hand-off counters) and the kernel.
  */
 typedef struct care_resident_attn {
