@@ -111,7 +111,8 @@ __device__ __forceinline__ void cst_b4(bf16_t* p, bf16x4 v) { cst8(p, __builtin_
 //   * a buffer is overwritten in phase k + 2 at the earliest by workgroups that waited for ALL producers of phase
 //     k + 1, and the readers of the old contents in phase k + 1 are among those producers;
 //   * every workgroup waits for the first phase of a step (the token choice): all of them read the same `rows ended`.
-// sync (unsigned): [1] rows ended, [2] steps run, [33] abort flag, [512 ..] phase clocks (tools), [1024 + (32 slot + 4
+// sync (unsigned): [1] rows ended, [2] steps run, [33] abort flag, [64] verdict of the step (2 t + all rows ended),
+// [512 ..] phase clocks (tools), [1024 + (32 slot + 4
 // shard) * 8 ...]: counter of (slot, shard), slot = the phase's position within a step.
 constexpr int RES_MAX_SLOTS = 48;
 constexpr int RES_SYNC_BYTES = 4096 + RES_MAX_SLOTS * 8 * 128;
@@ -868,11 +869,41 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
       const RLayer& L = p.L[l];
       if (l == 0) RES_PHASE((gemm_phase<1, A_EMBED, E_QKV, SM>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv)));
       else RES_PHASE((gemm_phase<1, A_LN, E_QKV, SM>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2)));
-      if (l == 0 && t > 1) {  // every row ended with the token chosen in the phase above?  EVERY workgroup waits for it
-        gs.prev = sl_prev;
-        gs.want = np_prev * ex_prev;
-        gs.wait();
-        if (p.early && __hip_atomic_load(p.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.R) {
+      if (l == 0 && t > 1) {
+        // Every row ended with the token chosen in the phase above?  EVERY workgroup must come to the same answer before
+        // it goes on.  The workgroups with self-attention items wait for the phase anyway and read the count themselves;
+        // workgroup 0 (always one of them) publishes the verdict of step t as 2 t + ended in a word of its own line,
+        // which is all the others poll - 250 of them polling the 8 counter shards held up the arrivals at one row.
+        const int bpx0 = (gridDim.x & 7) == 0 ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+        const int x0 = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) : 0, xs0 = (gridDim.x & 7) == 0 ? 8 : 1;
+        const bool attn_part = ((gridDim.x & 7) == 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) < ((p.R - x0 + xs0 - 1) / xs0) * p.H &&
+                               bpx0 > 0;
+        bool all_ended;
+        if (attn_part) {
+          gs.prev = sl_prev;
+          gs.want = np_prev * ex_prev;
+          gs.wait();
+          all_ended = p.early && __hip_atomic_load(p.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.R;
+          if (blockIdx.x == 0 && threadIdx.x == 0)
+            __hip_atomic_store(p.sync + 64, 2u * (unsigned)t + (all_ended ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          __shared__ unsigned s_verdict;
+          if (threadIdx.x == 0) {
+            unsigned v, spins = 0;
+            while ((v = __hip_atomic_load(p.sync + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 2u * (unsigned)t) {
+              __builtin_amdgcn_s_sleep(2);
+              if ((++spins & 63u) == 0 && __hip_atomic_load(p.sync + 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v = ~0u; break; }
+            }
+            s_verdict = v;
+          }
+          __syncthreads();
+          const unsigned v = s_verdict;
+          if (v == ~0u) gs.dead = true;
+          all_ended = (v & 1u) != 0 && !gs.dead;
+          __syncthreads();
+        }
+        if (gs.dead) break;
+        if (all_ended) {
           ended = true;
           if (blockIdx.x == 0 && threadIdx.x == 0) p.sync[2] = (unsigned)(t - 1);
           break;
