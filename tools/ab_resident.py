@@ -1,5 +1,6 @@
-"""Bit-exact regression of the resident decode: the library given as argv[1] against reference outputs saved by a run
-with another library (argv[2] = save | check)."""
+"""Bit-exact regression of the resident decode across library builds (GPU box):
+    CARE_HIP_LIB=<old libcare_hip.so> python tools/ab_resident.py save ; python tools/ab_resident.py check
+30 (model, batch) cases; every case also run three times (eager, captured, replayed) and compared with itself."""
 import os, sys, torch
 sys.path.insert(0, ".")
 from care_amd import get_framework
@@ -25,7 +26,7 @@ for cfg in ("msrvtt_base_ami", "msrvtt_care", "msrvtt_cabase"):
                 out[key] = cur
             else:
                 assert all(torch.equal(a, b) for a, b in zip(cur[:3], out[key][:3])) and cur[3] == out[key][3], (key, rep)
-path = "gpurun_out/_ab_resident.pt"
+path = "gpurun_out/ab_resident.pt"
 if mode == "save":
     torch.save(out, path); print("saved", len(out))
 else:
