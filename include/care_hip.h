@@ -568,6 +568,9 @@ int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, i
  *   Requires d == 512, heads == 8, ff in {512, 1024, 2048}, T <= 128, nkeys <= 128, n_layers <= 4, n_att <= 2.
  *   Every workgroup must be resident at the same time (they wait for one another): do not run two of these launches
  *   concurrently on different streams.  A workgroup that waits ~2 s for a phase's producers aborts the launch: length[0] = -1.
+ *   Environment knobs read per call (tuning / tools / tests, never needed): CARE_RESIDENT_RB, CARE_RESIDENT_SMALL,
+ *   CARE_RESIDENT_HALF_ROWS (forms of three phases), CARE_RESIDENT_PROF_STEP (phase clocks into the scratch),
+ *   CARE_RESIDENT_TEST_GHOST (tests: phases that can never complete, for the watchdog).
  *   The one entry point that issues two operations: a 52-KB memset node (hand-off counters) and the kernel.
  */
 typedef struct care_resident_attn {
