@@ -11,13 +11,13 @@
 //
 // (reference: models/Decoder.py + models/components/Layers.py:157-228 driven step by step from
 // models/Translator.py:77-143; Head.py:26-32; the early exit of Translator.py:77-81 is the device-side
-// `all rows ended` counter, read by every workgroup after the same barrier).
+// `all rows ended` counter, read by every workgroup once the phase that advances it is complete).
 //
 // Layout of a phase (DESIGN.md 4.2d has the measurements):
 //   * GEMM phases: a workgroup owns one 16-row tile (its A rows go through LDS as bf16 once, then live in registers
 //     as MFMA fragments) and walks column items - 16 columns with the 4 waves splitting K, or 64 columns with a wave
 //     per 16 x 16 tile (gemm_phase).  The W fragments (v_mfma_f32_16x16x32_bf16 A operand, 16 B per lane straight from
-//     the [N, K] row-major weight) of the first item are requested BEFORE the workgroup waits at the barrier - weights
+//     the [N, K] row-major weight) of the first item are requested BEFORE the workgroup waits for the previous phase - weights
 //     do not depend on the previous phase - and double-buffered across items.
 //   * LayerNorm is applied ON LOAD: a phase stores the pre-LayerNorm sum (dense + bias + residual, fp32) and
 //     every consumer normalises the 16 rows it needs (it reads all K columns anyway); the consumer of column
@@ -1003,7 +1003,7 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   {
     const char* ps = getenv("CARE_RESIDENT_PROF_STEP");  // tools only: phase clocks of that step -> scratch + 2048
     p.prof_step = ps ? atoi(ps) : 0;
-    p.ghost = getenv("CARE_RESIDENT_TEST_GHOST") ? 8 : 0;  // tests only: barriers that can never complete (watchdog)
+    p.ghost = getenv("CARE_RESIDENT_TEST_GHOST") ? 8 : 0;  // tests only: phases whose producers never all arrive (watchdog)
   }
   p.fed = fed; p.fed_stride = fed_stride; p.score = score; p.length = length; p.fin = finished;
   const int64_t R16 = (rows + 15) / 16 * 16;
