@@ -735,10 +735,20 @@ __device__ __forceinline__ unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf1
 // wave per item, lane = (key slot, 8-dim chunk).  Masking as the reference: masked keys get -1e9, the hybrid bias
 // is added after the mask (models/components/Attention.py:104-111).  The heads of a row go to the waves of ONE XCD
 // (row % 8), so a row's static K/V is read into one L2.
-template <bool SELF>  // SELF: the keys / values are the cache this launch writes (coherent loads), pad mask from `fed`
+// One (row, head) of an attention phase in flight: its query chunk, key / value fragments, mask and bias terms.
+template <int NKB>
+struct AttnItem {
+  int r, hh;
+  float q[8];
+  float add[NKB];
+  bool padded[NKB];
+  bf16x8 kf[NKB], vf[NKB];
+};
+
+template <bool SELF, int NKB>  // SELF: the keys / values are the cache this launch writes (coherent loads), pad mask from `fed`
 __device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
-                                           int rows_per_kv, int nk, const int32_t* pad_tok, const float* bias,
-                                           int bias_ld) {
+                                               int rows_per_kv, int nk, const int32_t* pad_tok, const float* bias,
+                                               int bias_ld) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 3, chunk = lane & 7;
   constexpr int d = 512;
   const int nkb = (nk + 7) >> 3, H = p.H;
@@ -749,8 +759,9 @@ __device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, boo
   const int myslot = slot0 + bpx * wave;
   const int nslots = bpx * 4;
   const int nrows_x = (p.R - x + xs - 1) / xs;  // rows x, x + xs, ...
+  const int nitems = nrows_x * H;
   // a workgroup has an item iff its wave 0 has one (the smallest slot of the four)
-  const bool participant = slot0 < nrows_x * H;
+  const bool participant = slot0 < nitems;
   unsigned nprod = 0;
   for (int xx = 0; xx < xs; ++xx) {
     const int it = ((p.R - xx + xs - 1) / xs) * H;
@@ -760,43 +771,43 @@ __device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, boo
   if (do_wait && participant) gs.wait();
   if (gs.dead) return nprod;
   gs.mark();
-  for (int li = myslot; li < nrows_x * H; li += nslots) {
-    const int r = x + xs * (li / H), hh = li % H;
-    float q[8];
-    {
-      const float4 qa = cld_f4(p.q + (int64_t)r * d + hh * 64 + chunk * 8), qb = cld_f4(p.q + (int64_t)r * d + hh * 64 + chunk * 8 + 4);
-      q[0] = qa.x; q[1] = qa.y; q[2] = qa.z; q[3] = qa.w; q[4] = qb.x; q[5] = qb.y; q[6] = qb.z; q[7] = qb.w;
-    }
-    const bf16_t* kb0 = KV + (int64_t)(r / rows_per_kv) * kv_bs + hh * 64 + chunk * 8;
-    float add[RES_MAXKB];
-    bool padded[RES_MAXKB];
-    bf16x8 kf[RES_MAXKB], vf[RES_MAXKB];
+
+  // every load of an item, unconditionally (li is clamped by the caller): nothing here waits for anything
+  auto load = [&](AttnItem<NKB>& it, int li) {
+    it.r = x + xs * (li / H);
+    it.hh = li % H;
+    const float* qp = p.q + (int64_t)it.r * d + it.hh * 64 + chunk * 8;
+    const float4 qa = cld_f4(qp), qb = cld_f4(qp + 4);
+    it.q[0] = qa.x; it.q[1] = qa.y; it.q[2] = qa.z; it.q[3] = qa.w; it.q[4] = qb.x; it.q[5] = qb.y; it.q[6] = qb.z; it.q[7] = qb.w;
+    const bf16_t* kb0 = KV + (int64_t)(it.r / rows_per_kv) * kv_bs + it.hh * 64 + chunk * 8;
 #pragma unroll
-    for (int kb = 0; kb < RES_MAXKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
       if (kb < nkb) {
         const int j = kb * 8 + slot, jc = j < nk ? j : 0;
-        padded[kb] = pad_tok ? cld_i(pad_tok + (int64_t)r * p.fed_stride + jc) == p.pad : false;
-        add[kb] = bias ? bias[hh * bias_ld + jc] : 0.f;
-        if constexpr (SELF) { kf[kb] = cld_b8(kb0 + (int64_t)jc * 2 * d); vf[kb] = cld_b8(kb0 + (int64_t)jc * 2 * d + d); }
+        it.padded[kb] = pad_tok ? cld_i(pad_tok + (int64_t)it.r * p.fed_stride + jc) == p.pad : false;
+        it.add[kb] = bias ? bias[it.hh * bias_ld + jc] : 0.f;
+        if constexpr (SELF) { it.kf[kb] = cld_b8(kb0 + (int64_t)jc * 2 * d); it.vf[kb] = cld_b8(kb0 + (int64_t)jc * 2 * d + d); }
         else {
-          kf[kb] = *reinterpret_cast<const bf16x8*>(kb0 + (int64_t)jc * 2 * d);
-          vf[kb] = *reinterpret_cast<const bf16x8*>(kb0 + (int64_t)jc * 2 * d + d);
+          it.kf[kb] = *reinterpret_cast<const bf16x8*>(kb0 + (int64_t)jc * 2 * d);
+          it.vf[kb] = *reinterpret_cast<const bf16x8*>(kb0 + (int64_t)jc * 2 * d + d);
         }
       }
-    float s[RES_MAXKB];
+  };
+  auto compute = [&](const AttnItem<NKB>& it) {
+    float s[NKB];
     float m = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < RES_MAXKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
       if (kb < nkb) {
         float dd = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dd = fmaf(q[i], (float)kf[kb][i], dd);
+        for (int i = 0; i < 8; ++i) dd = fmaf(it.q[i], (float)it.kf[kb][i], dd);
         dd += care_dpp_x1(dd);
         dd += care_dpp_x2(dd);
         dd += care_dpp_m8(dd);
         dd *= 0.125f;
-        if (padded[kb]) dd = -1e9f;
-        dd += add[kb];
+        if (it.padded[kb]) dd = -1e9f;
+        dd += it.add[kb];
         s[kb] = kb * 8 + slot < nk ? dd : -INFINITY;
         m = fmaxf(m, s[kb]);
       }
@@ -805,7 +816,7 @@ __device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, boo
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < RES_MAXKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
       if (kb < nkb) { s[kb] = expf(s[kb] - m); sum += s[kb]; }
     sum += __shfl_xor(sum, 8, 64);
     sum += __shfl_xor(sum, 16, 64);
@@ -813,11 +824,11 @@ __device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, boo
     const float inv = 1.0f / sum;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < RES_MAXKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
       if (kb < nkb) {
         const float pw = s[kb] * inv;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = fmaf(pw, (float)vf[kb][i], acc[i]);
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(pw, (float)it.vf[kb][i], acc[i]);
       }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -829,7 +840,32 @@ __device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, boo
       bf16x8 ob;
 #pragma unroll
       for (int i = 0; i < 8; ++i) ob[i] = (bf16_t)acc[i];
-      cst_b8(p.ctx + (int64_t)r * d + hh * 64 + chunk * 8, ob);
+      cst_b8(p.ctx + (int64_t)it.r * d + it.hh * 64 + chunk * 8, ob);
+    }
+  };
+
+  if (myslot < nitems) {
+    AttnItem<NKB> A;
+    load(A, myslot);
+    if (myslot + nslots >= nitems) {
+      compute(A);  // one item per wave (up to 128 rows): nothing to overlap
+    } else if constexpr (NKB <= 8) {
+      // several items per wave: the next item's loads travel while the current one is computed (two register sets;
+      // an item past the last re-reads the last - unconditional loads, see gemm_phase's fetch)
+      AttnItem<NKB> Bq;
+      for (int li = myslot; li < nitems; li += 2 * nslots) {
+        load(Bq, min(li + nslots, nitems - 1));
+        compute(A);
+        if (li + nslots >= nitems) break;
+        load(A, min(li + 2 * nslots, nitems - 1));
+        compute(Bq);
+      }
+    } else {
+      compute(A);
+      for (int li = myslot + nslots; li < nitems; li += nslots) {
+        load(A, li);
+        compute(A);
+      }
     }
   }
   gs.mark();
@@ -908,9 +944,11 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
           if (blockIdx.x == 0 && threadIdx.x == 0) p.sync[2] = (unsigned)(t - 1);
           break;
         }
-        RES_PHASE((attn_phase<true>(p, gs, false, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)));
+        RES_PHASE((p.T <= 32 ? attn_phase<true, 4>(p, gs, false, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)
+                              : attn_phase<true, RES_MAXKB>(p, gs, false, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)));
       } else {
-        RES_PHASE((attn_phase<true>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)));
+        RES_PHASE((p.T <= 32 ? attn_phase<true, 4>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)
+                              : attn_phase<true, RES_MAXKB>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)));
       }
       RES_PHASE((gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, L.o_w, L.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
       const float* g = L.g;
@@ -918,7 +956,8 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
       for (int a = 0; a < L.n_att; ++a) {
         const RAttn& A = L.att[a];
         RES_PHASE((gemm_phase<1, A_LN, E_Q, true>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr)));
-        RES_PHASE((attn_phase<false>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)));
+        RES_PHASE((A.nkeys <= 64 ? attn_phase<false, 8>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)
+                                  : attn_phase<false, RES_MAXKB>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)));
         RES_PHASE((gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
         g = A.g; be = A.be;
       }
