@@ -52,7 +52,65 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads for the CPU oracle (16 was the fastest of 8..128 on the 2x64-core host)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: every rank joins a gloo group, exchanges synthetic caption records through the same "
+                         "care_amd.sharding calls as the real run and rank 0 prints a line marked dry_run (the launcher "
+                         "and the N > 1 plumbing under test on a CPU-only host; nothing is measured)")
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: start `torch.distributed.run --nproc-per-node N bench.py ...` as a
+    CHILD process - this process has not touched the GPU (torch.cuda.device_count() does not initialise it), and it is
+    never replaced by exec - relay the child's output (rank 0's JSON line) and return its exit code."""
+    import subprocess
+
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus {} but this host has {} GPU(s) visible\n".format(args.gpus, have))
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world: int, rank: int) -> None:
+    """The N-rank plumbing without a GPU (gloo): per-rank synthetic records -> pack -> ONE all-gather -> unpack."""
+    from care_amd.sharding import all_gather_records, pack_records, unpack_records
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    B, T = min(args.batch, 64), 29
+    gen = torch.Generator().manual_seed(1000 + rank)
+    fed = torch.randint(4, 10547, (B, T + 1), generator=gen, dtype=torch.int32)
+    length = torch.full((B,), T, dtype=torch.int32)
+    score = torch.full((B,), -float(rank + 1))
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps)):
+        tok, ln, sc = unpack_records(all_gather_records(pack_records(fed, length, score, B)))
+    dt = (time.perf_counter() - t0) / max(1, args.steps)
+    ranks_seen = sorted({int(round(-float(v))) - 1 for v in sc.tolist()})
+    ok = tok.shape[0] == world * B and ranks_seen == list(range(world)) and torch.equal(tok[rank * B:(rank + 1) * B], fed)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(dict(metric="captions/sec (greedy)", value=None, unit="captions/s", n_gpus=world, steps=args.steps,
+                              warmup=args.warmup, dry_run=True, backend="gloo", ranks_seen=ranks_seen,
+                              records_gathered=int(tok.shape[0]), all_gather_us=round(dt * 1e6, 1), exchange_ok=bool(ok))),
+              flush=True)
+    if not ok:
+        raise SystemExit(3)
 
 
 def kernel_model(tag, eng, B, dtype):
@@ -344,8 +402,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))  # one process per GPU: a torchrun child, rank 0's line relayed
     if world != args.gpus:
-        raise SystemExit("--gpus {} but WORLD_SIZE {} (launch with torch.distributed.run)".format(args.gpus, world))
+        raise SystemExit("--gpus {} but WORLD_SIZE {} (torch.distributed.run --nproc-per-node must equal --gpus)".format(args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    if local >= torch.cuda.device_count():
+        raise SystemExit("rank {}: no GPU {} on this host ({} visible)".format(rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("CARE_BENCH_FORCE_DIST") == "1"  # forced: 1-rank RCCL self-test
@@ -420,10 +484,24 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    dist_info = None
     if use_dist:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed, float(rank)], device=dev, dtype=torch.float64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_s = [float(e[0]) for e in every]
+        # the exchange alone: the all-gather of one batch's records, back to back
+        rec = pack_records(*step(), B)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            all_gather_records(rec, gathered)
+        barrier()
+        dist_info = dict(backend="nccl (RCCL)", rccl_ranks_seen=sorted(int(e[1]) for e in every),
+                         per_rank_captions_per_s=[round(B * args.steps / t, 1) for t in per_rank_s],
+                         all_gather_us=round((time.perf_counter() - t1) / 20 * 1e6, 1),
+                         all_gather_bytes_per_rank=int(rec.numel() * rec.element_size()))
+        elapsed = max(per_rank_s)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -569,6 +647,8 @@ def main():
         gflop_per_caption=round(total_fl / 1e9, 4),
         pass_tflops=round(total_fl * value / 1e12, 2),
         roofline=roofline, kernels=per_kernel, cpu_baseline=cpu)
+    if dist_info:
+        line["distributed"] = dist_info
     if world == 1 and not args.no_legs and args.beam == 1:
         del model, eng, feats
         torch.cuda.empty_cache()

@@ -2,17 +2,23 @@
 
     python -m care_amd.build [--force]
 
-hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels to
-the GPU box with the repo snapshot.
+hipcc cross-compiles for gfx950 without a GPU.  Every source is compiled to an object of its own
+(`care_amd/csrc/.obj/`, in parallel, only when it or a header it includes is newer) and the objects are
+linked into the .so.  The .so is git-ignored but travels to the GPU box with the repo snapshot; the
+objects do not (`.gpurunignore`).
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(HERE, "libcare_hip.so")
-SOURCES = ("gemm.hip", "gemm_as.hip", "gemm_vocab.hip", "gemm_store32.hip", "gemm_tile.hip", "gemm_ln.hip", "rowops.hip", "attention.hip", "attention_seq.hip", "attention_latent.hip", "heads.hip", "beam.hip", "beam_sparse.hip", "compact.hip", "backward.hip", "decode_resident.hip")
+SOURCES = ("gemm.hip", "gemm_as.hip", "gemm_vocab.hip", "gemm_store32.hip", "gemm_tile.hip", "gemm_ln.hip", "rowops.hip",
+           "attention.hip", "attention_seq.hip", "attention_latent.hip", "heads.hip", "beam.hip", "beam_sparse.hip",
+           "compact.hip", "backward.hip", "decode_resident.hip", "decode_resident_beam.hip")
 ARCH = "gfx950"
 
 
@@ -23,21 +29,46 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    return hs + [os.path.join(os.path.dirname(HERE), "include", "care_hip.h")]
+
+
+def _sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps += [os.path.join(CSRC, "care_common.h"), os.path.join(os.path.dirname(HERE), "include", "care_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _sources() + _headers())
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
     if not force and not needs_build():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fgpu-rdc" if False else "-fno-gpu-rdc", "-o", LIB] + srcs
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
+    extra = os.environ.get("CARE_HIPCC_FLAGS", "").split()
+    todo, objs = [], []
+    for src in _sources():
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or extra or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            todo.append((src, obj))
+
+    def compile_one(so):
+        cmd = [_hipcc()] + flags + extra + ["-c", so[0], "-o", so[1]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    jobs = jobs or int(os.environ.get("CARE_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
+        list(pool.map(compile_one, todo))
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

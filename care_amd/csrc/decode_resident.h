@@ -1,0 +1,1080 @@
+// decode_resident.h - device code shared by the resident decodes (decode_resident.hip: greedy; decode_resident_beam.hip:
+// beam search): hand-offs between phases, the GEMM / attention phases, LayerNorm on load.  See decode_resident.hip.
+#pragma once
+#include <atomic>
+#include <cstdlib>
+
+#include "care_common.h"
+
+namespace {
+
+constexpr int RES_MAX_LAYERS = 4;
+constexpr int RES_MAXKB = 16;  // key blocks of 8: <= 128 keys per attention
+
+struct RAttn {
+  const bf16_t* q_w; const float* q_b; const bf16_t* o_w; const float* o_b; const float* g; const float* be;
+  const bf16_t* kv; int64_t kv_bs; int nkeys, rows_per_kv; const float* bias; int bias_ld;
+};
+struct RLayer {
+  const bf16_t* qkv_w; const float* qkv_b; const bf16_t* o_w; const float* o_b; const float* g; const float* be;
+  bf16_t* skv;
+  RAttn att[2]; int n_att;
+  const bf16_t* w1; const float* b1; const bf16_t* w2; const float* b2; const float* fg; const float* fbe;
+};
+struct RArgs {
+  RLayer L[RES_MAX_LAYERS]; int n_layers;
+  const float *word, *pos, *sem; int sem_div; const float *emb_g, *emb_be; float eps;
+  const bf16_t* vocab; int V;
+  int d, H, ff, act, R, T, steps, bos, eos, pad, early, prof_step, ghost;
+  int32_t* fed; int fed_stride; float* score; int32_t* length; int32_t* fin;
+  unsigned* sync; float* xres; float* y; float* y2; float* q; bf16_t* ctx; bf16_t* h;
+  float* pmax; int32_t* pidx; float* psum; int parts;
+  // beam search (decode_resident_beam.hip): R = nclips * bm rows, `fed` = the token table addressed through the ancestor
+  // tables (csrc/beam.hip), `score` = the running scores of the beam slots
+  int bm, nclips, need, fin_cap;
+  int32_t* anc[2]; int32_t* done; int32_t* nfin; float* fscore; int32_t* flen; int32_t* fhyp;
+  float* gval; int32_t* ggid;  // per (row, vocabulary part): the RES_BMK best 4-column groups (maximum, group number)
+  bf16_t* hn;                  // the normalised last hidden rows (bf16 [R16, 512]): the B operand of the recomputed logits
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Data that one workgroup writes and another reads INSIDE the launch moves with agent-scope (sc1) accesses: stores
+// write through to the device's coherence point, loads miss the caches that are not coherent across XCDs (a CU's L1,
+// another XCD's L2) - relaxed 4- / 8-byte atomics, which is how the compiler spells them.  No cache-wide writeback or
+// invalidate is needed then, and that is the point: *measured* (tools/micro/barrier_bench.hip, 256 workgroups) a
+// barrier with __threadfence() on either side costs 17 us (one thread fences) to 39 us (every wave does), the
+// counters alone 3.7 us, two-level counters 1.9 us.  Weights, embeddings and the cross K/V (written before the
+// launch) use plain loads and stay in the L2s for all T steps.
+__device__ __forceinline__ unsigned long long cld8(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cst8(void* p, unsigned long long v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float cld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int cld_i(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cst_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cst_i(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+struct U2 { unsigned long long a, b; };
+__device__ __forceinline__ float4 cld_f4(const float* p) {
+  U2 u{cld8(p), cld8(p + 2)};
+  return __builtin_bit_cast(float4, u);
+}
+__device__ __forceinline__ void cst_f4(float* p, float4 v) {
+  const U2 u = __builtin_bit_cast(U2, v);
+  cst8(p, u.a);
+  cst8(p + 2, u.b);
+}
+__device__ __forceinline__ bf16x8 cld_b8(const bf16_t* p) {
+  U2 u{cld8(p), cld8(p + 4)};
+  return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ void cst_b8(bf16_t* p, bf16x8 v) {
+  const U2 u = __builtin_bit_cast(U2, v);
+  cst8(p, u.a);
+  cst8(p + 4, u.b);
+}
+__device__ __forceinline__ void cst_b4(bf16_t* p, bf16x4 v) { cst8(p, __builtin_bit_cast(unsigned long long, v)); }
+
+// Synchronisation between phases: producer-counted hand-offs instead of full grid barriers.  Only the workgroups that
+// HAVE WORK in a phase (`participants`) count themselves in when their stores are acknowledged - one atomic add on the
+// phase's counter, sharded 8 ways by blockIdx % 8 (the XCD; 128-byte lines of their own) - and only the participants
+// of the NEXT phase wait, polling the 8 shards until their sum reaches producers x executions.  Against the two-level
+// barrier with a published generation (every workgroup: group counter -> top counter -> flag -> poll) that is one
+// memory round trip less per phase and no waiting for workgroups that have nothing to do.  Why it is enough:
+//   * a phase reads what the previous phase wrote, or older data whose writers the previous phase's producers waited
+//     for in turn (residual rows, caches, decode state): the order is transitive along the chain of phases;
+//   * a buffer is overwritten in phase k + 2 at the earliest by workgroups that waited for ALL producers of phase
+//     k + 1, and the readers of the old contents in phase k + 1 are among those producers;
+//   * every workgroup waits for the first phase of a step (the token choice): all of them read the same `rows ended`.
+// sync (unsigned): [1] rows ended, [2] steps run, [33] abort flag, [64] verdict of the step (2 t + all rows ended),
+// [512 ..] phase clocks (tools), [1024 + (32 slot + 4
+// shard) * 8 ...]: counter of (slot, shard), slot = the phase's position within a step.
+constexpr int RES_MAX_SLOTS = 48;
+constexpr int RES_SYNC_BYTES = 4096 + RES_MAX_SLOTS * 8 * 128;
+struct GridSync {
+  unsigned* sync;
+  unsigned ghost;  // tests: producers that never arrive are expected too (the watchdog)
+  int slot;        // >= 0: workgroup 0 records the device clock at the phase boundaries of one step (sync + 512, 8-byte slots)
+  bool dead;
+  int cur, prev;   // position of this phase / of the phase it consumes within the step
+  unsigned want;   // what the counters of `prev` must add up to: its producers x the times it has run (0: nothing to wait for)
+  __device__ __forceinline__ void mark() {
+    if (slot >= 0 && slot < 96 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(sync + 512)[slot++] = wall_clock64();
+  }
+  __device__ __forceinline__ unsigned* counter(int sl, int shard) const { return sync + 1024 + (sl * 8 + shard) * 32; }
+  // The hand-off is the form MI355X_MICROARCH.md lists as measured-valid on gfx950 (visibility table, first row): EVERY
+  // store of handed-off bytes is an sc1 (agent-scope, write-through) store, every storing wave drains them
+  // (s_waitcnt vmcnt(0), as inline asm: also a compiler barrier, and invisible to the pass that drops a builtin wait),
+  // the workgroup meets at its barrier (a workgroup-scope release / acquire pair for the compiler: no memory operation
+  // moves across it), ONE lane adds to the phase's sharded counter; the consumer polls every shard with sc1 loads,
+  // joins its workgroup's barrier, and EVERY load of handed-off bytes is an sc1 load to registers.  That is not what the
+  // HIP memory model promises for relaxed atomics (a formal race; no cache-wide release / acquire is executed) - hence
+  // the arch check below, the stress tests of tests/test_gpu_resident.py and -DRES_FENCED: the same protocol with an
+  // agent-scope release before the add and an acquire after the poll (+ ~3 us per hand-off, MI355X_MICROARCH.md fence
+  // table; *measured* here: DESIGN.md 4.2d).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "decode_resident: the fence-free hand-off is validated for gfx950 only (build with -DRES_FENCED elsewhere)"
+#endif
+  __device__ __forceinline__ void arrive(bool participant) {
+    if (!participant) return;       // workgroup-uniform
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's write-through stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#ifdef RES_FENCED
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      __hip_atomic_fetch_add(counter(cur, blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // A workgroup that has spun for ~2 s (workgroups that never became resident: another kernel holds CUs for good, e.g.
+  // a second resident launch on another stream) raises the abort flag; every workgroup then leaves at its next wait,
+  // phases turn into no-ops and length[0] = -1 tells the host (care_decode_resident).
+  __device__ __forceinline__ void wait() {
+    __shared__ int s_dead;
+    if (want == 0) return;  // the first phase of the launch
+    if (threadIdx.x < 64) {
+      const unsigned need = want + ghost;
+      const unsigned* c = counter(prev, threadIdx.x & 7);
+      int d = 0;
+      unsigned spins = 0;
+      unsigned long long t0 = 0;
+      for (;;) {
+        unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // lanes 0 .. 7: the 8 shards
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        if (v >= need) break;  // (the same sum in every group of 8 lanes)
+#ifndef RES_POLL_SLEEP
+#define RES_POLL_SLEEP 1
+#endif
+        __builtin_amdgcn_s_sleep(RES_POLL_SLEEP);
+        if ((++spins & 63u) == 0) {
+          if (__hip_atomic_load(sync + 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { d = 1; break; }
+          if ((spins & 4095u) == 0) {
+            const unsigned long long now = wall_clock64();  // 100 MHz
+            if (!t0) t0 = now;
+            else if (now - t0 > 200000000ull) {
+              __hip_atomic_store(sync + 33, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              d = 1;
+              break;
+            }
+          }
+        }
+      }
+      if (threadIdx.x == 0) {
+        s_dead = d;
+#ifdef RES_FENCED
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      }
+    }
+    __syncthreads();
+    dead = dead || s_dead != 0;
+  }
+};
+
+__device__ __forceinline__ float res_act(float v, int act) {
+  if (act == CARE_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == CARE_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+
+__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// (max, arg-max, sum exp) merge; ties go to the lower column
+__device__ __forceinline__ void amax_merge(float& m, int& i, float& s, float om, int oi, float os) {
+  const float nm = fmaxf(m, om);
+  const float a = m == -INFINITY ? 0.f : s * expf(m - nm);
+  const float b = om == -INFINITY ? 0.f : os * expf(om - nm);
+  if (om > m || (om == m && oi < i)) i = oi;
+  m = nm;
+  s = a + b;
+}
+
+// Wave-wide sum through the DPP data path (the scan of care_wave_max_dpp with + : row_shr 1, 2, 4, 8, then
+// row_bcast15 / row_bcast31; lanes without a source add 0); every lane gets the total.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define RES_DPP_ADD(CTRL, ROWMASK) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false))
+  RES_DPP_ADD(0x111, 0xF);
+  RES_DPP_ADD(0x112, 0xF);
+  RES_DPP_ADD(0x114, 0xF);
+  RES_DPP_ADD(0x118, 0xF);
+  RES_DPP_ADD(0x142, 0xA);
+  RES_DPP_ADD(0x143, 0xC);
+#undef RES_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Sortable 64-bit keys (beam search): a float mapped to an unsigned that orders like the float (-inf lowest) in the
+// high word, ~index in the low word - the maximum key = the largest value, the LOWEST index among equals (the order
+// of torch.topk on distinct values / csrc/beam.hip: value desc, index asc).
+__device__ __forceinline__ unsigned f_ord(float f) {
+  const unsigned u = __builtin_bit_cast(unsigned, f);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float f_unord(unsigned k) { return __builtin_bit_cast(float, k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
+__device__ __forceinline__ unsigned long long key_of(float v, unsigned idx) { return ((unsigned long long)f_ord(v) << 32) | (0xffffffffu - idx); }
+__device__ __forceinline__ float key_val(unsigned long long k) { return f_unord((unsigned)(k >> 32)); }
+__device__ __forceinline__ unsigned key_idx(unsigned long long k) { return 0xffffffffu - (unsigned)k; }
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long k) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)k, CTRL, 0xF, 0xF, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(k >> 32), CTRL, 0xF, 0xF, true);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long max_u64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+// every lane of a 16-lane row gets the row's maximum: lane ^ 1, lane ^ 2 (quad_perm), then the mirrored lane of the
+// 8-lane half and of the row - after each step the groups that meet hold their own maxima (no LDS round trip)
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long k) {
+  k = max_u64(k, dpp_u64<0xB1>(k));
+  k = max_u64(k, dpp_u64<0x4E>(k));
+  k = max_u64(k, dpp_u64<0x141>(k));
+  k = max_u64(k, dpp_u64<0x140>(k));
+  return k;
+}
+// ... and every lane of the wave the wave's: the four row maxima through scalar registers
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+  k = row16_max_u64(k);
+  unsigned long long m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, q * 16);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), q * 16);
+    m = max_u64(m, ((unsigned long long)hi << 32) | lo);
+  }
+  return m;
+}
+
+constexpr int RES_NP = 4;  // column-group partials per lane: V <= 64 * 64 * RES_NP
+
+// Token choice of step `ts` for the 4 rows r0 .. r0 + 3 of a wave (all lanes get the tokens): reduce the
+// column-group partials of the vocabulary phase (ties: the lowest column); WRITER: also advance the rows' state
+// (Translator.py:91-109 / the top-1 of Beam.advance).  Every load of the 4 rows is issued before the first use.
+template <bool WRITER>
+__device__ __forceinline__ void select4(const RArgs& p, int r0, int ts, int lane, int (&tok)[4]) {
+  float pm[4][RES_NP], ps[4][RES_NP];
+  int pi[4][RES_NP], fin[4];
+  float sc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + i;
+    const bool rok = r < p.R;
+#pragma unroll
+    for (int k = 0; k < RES_NP; ++k) {
+      const int c = lane + 64 * k;
+      const bool ok = rok && c < p.parts;
+      const int64_t o = (int64_t)(rok ? r : 0) * p.parts + (c < p.parts ? c : 0);
+      pm[i][k] = cld_f(p.pmax + o);
+      pi[i][k] = cld_i(p.pidx + o);
+      if (WRITER) ps[i][k] = cld_f(p.psum + o);
+      if (!ok) { pm[i][k] = -INFINITY; pi[i][k] = 0x7fffffff; if (WRITER) ps[i][k] = 0.f; }
+    }
+    if (WRITER) { fin[i] = cld_i(p.fin + (rok ? r : 0)); sc[i] = cld_f(p.score + (rok ? r : 0)); }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (r0 + i >= p.R) break;  // rows past the batch (wave-uniform)
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < RES_NP; ++k)
+      if (pm[i][k] > best || (pm[i][k] == best && pi[i][k] < bi)) { best = pm[i][k]; bi = pi[i][k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    tok[i] = bi;
+    if (WRITER) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < RES_NP; ++k) s += pm[i][k] == -INFINITY ? 0.f : ps[i][k] * expf(pm[i][k] - best);
+      s = wave_sum_dpp(s);
+      const int r = r0 + i;
+      if (lane == 0 && r < p.R) {
+        cst_i(p.fed + (int64_t)r * p.fed_stride + ts, bi);  // ended rows keep running, frozen
+        if (!fin[i]) {
+          cst_f(p.score + r, sc[i] - logf(s));
+          cst_i(p.length + r, ts);
+          if (bi == p.eos || ts >= p.T) {
+            cst_i(p.fin + r, 1);
+            __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+  }
+}
+
+// The decode state of rows rb .. rb + 3 at the top of step t: fresh rows at t = 1 (fed = BOS, zeros), else the token
+// choice of step t - 1 with its score / length / end-flag update.
+__device__ __forceinline__ void advance_state4(const RArgs& p, int rb, int t, int lane, int (&tok)[4]) {
+  if (t > 1) {
+    select4<true>(p, rb, t - 1, lane, tok);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (rb + i < p.R) {
+      const int r = rb + i;
+      for (int c = lane; c <= p.T; c += 64) cst_i(p.fed + (int64_t)r * p.fed_stride + c, c == 0 ? p.bos : 0);
+      if (lane == 0) { cst_f(p.score + r, 0.f); cst_i(p.length + r, 0); cst_i(p.fin + r, 0); }
+    }
+}
+__device__ __forceinline__ void advance_state4(const RArgs& p, int rb, int t, int lane) {
+  int tok[4];
+  advance_state4(p, rb, t, lane, tok);
+}
+
+enum { A_EMBED = 0, A_LN = 1, A_BF16 = 2, A_EMBEDB = 3 };  // A_EMBEDB: beam search - the token is in the table already
+enum { E_QKV = 0, E_Q = 1, E_RES = 2, E_ACT = 3, E_VOCAB = 4, E_VOCABK = 5 };  // E_VOCABK: beam search - best groups per row
+constexpr int RES_BMK = 5;  // beam search: groups kept per (row, vocabulary part) = the largest beam size of the resident form
+
+// Beam search, step 1: the state of rows rb .. rb + 3 as the host-side initialisation of engine.beam leaves it - token
+// table [BOS, EOS ...], both ancestor tables = the row itself, scores 0 - and, by the first row of a clip, the clip's
+// flags and (zeroed) finished lists.
+__device__ __forceinline__ void beam_init_rows4(const RArgs& p, int rb, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (rb + i < p.R) {
+      const int r = rb + i;
+      for (int c = lane; c <= p.T; c += 64) {
+        cst_i(p.fed + (int64_t)r * p.fed_stride + c, c == 0 ? p.bos : p.eos);
+        cst_i(p.anc[0] + (int64_t)r * p.fed_stride + c, r);
+        cst_i(p.anc[1] + (int64_t)r * p.fed_stride + c, r);
+      }
+      if (lane == 0) cst_f(p.score + r, 0.f);
+      if (r % p.bm == 0) {
+        const int b = r / p.bm;
+        if (lane == 0) { cst_i(p.done + b, 0); cst_i(p.nfin + b, 0); }
+        for (int c = lane; c < p.fin_cap; c += 64) { cst_f(p.fscore + (int64_t)b * p.fin_cap + c, 0.f); cst_i(p.flen + (int64_t)b * p.fin_cap + c, 0); }
+        for (int c = lane; c < p.fin_cap * p.fed_stride; c += 64) cst_i(p.fhyp + (int64_t)b * p.fin_cap * p.fed_stride + c, 0);
+      }
+    }
+}
+
+// 16 rows of the A operand -> LDS (bf16 [16][lda]), d = 512.  A_EMBED / A_LN: a wave owns 4 rows, a lane 2 float4 of
+// each; the rows stay in registers between the statistics and the normalisation (rowops.hip row_layernorm), all
+// loads of the 4 rows issued together: fetch_a_rows requests them ...
+template <int AMODE>
+__device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, bool writer, const float* ysrc, const float* ysrc2,
+                                             float4 (&v)[4][2]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int d = 512;
+  const int rb = r0 + wave * 4;
+  if constexpr (AMODE == A_EMBED || AMODE == A_EMBEDB) {
+    int tok[4] = {p.bos, p.bos, p.bos, p.bos};
+    if constexpr (AMODE == A_EMBED) {
+      if (writer) advance_state4(p, rb, t, lane, tok);
+      else if (t > 1) select4<false>(p, rb, t - 1, lane, tok);
+    } else {  // beam search: beam_advance_phase wrote the token of slot r at position t - 1 (tokphys[r][t - 1], beam.hip)
+      if (t > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tok[i] = cld_i(p.fed + (int64_t)(rb + i < p.R ? rb + i : 0) * p.fed_stride + (t - 1));
+      } else if (writer) {
+        beam_init_rows4(p, rb, lane);
+      }
+    }
+    const float* pp = p.pos + (int64_t)(t - 1) * d;
+    const float4 p0 = *reinterpret_cast<const float4*>(pp + lane * 4), p1 = *reinterpret_cast<const float4*>(pp + 256 + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rb + i < p.R ? rb + i : 0;
+      const float* w = p.word + (int64_t)(rb + i < p.R ? tok[i] : 0) * d;
+      v[i][0] = *reinterpret_cast<const float4*>(w + lane * 4);
+      v[i][1] = *reinterpret_cast<const float4*>(w + 256 + lane * 4);
+      add4(v[i][0], p0);
+      add4(v[i][1], p1);
+      if (p.sem) {
+        const float* sm = p.sem + (int64_t)(r / p.sem_div) * d;
+        add4(v[i][0], *reinterpret_cast<const float4*>(sm + lane * 4));
+        add4(v[i][1], *reinterpret_cast<const float4*>(sm + 256 + lane * 4));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rb + i < p.R ? rb + i : 0;
+      v[i][0] = cld_f4(ysrc + (int64_t)r * d + lane * 4);
+      v[i][1] = cld_f4(ysrc + (int64_t)r * d + 256 + lane * 4);
+    }
+    if (ysrc2) {  // the second K half of a two-workgroup FFN dense2 (ffn2_phase<true>): y = y + y2
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = rb + i < p.R ? rb + i : 0;
+        add4(v[i][0], cld_f4(ysrc2 + (int64_t)r * d + lane * 4));
+        add4(v[i][1], cld_f4(ysrc2 + (int64_t)r * d + 256 + lane * 4));
+      }
+    }
+  }
+}
+
+// ... and their LayerNorm into the LDS tile (+ the fp32 rows for the residual when write_x)
+__device__ __forceinline__ void finish_a_rows(const RArgs& p, int r0, const float4 (&v)[4][2], const float* g, const float* be,
+                                              bool write_x, bf16_t* sA, int lda, bool write_hn = false) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int d = 512;
+  const float4 g0 = *reinterpret_cast<const float4*>(g + lane * 4), g1 = *reinterpret_cast<const float4*>(g + 256 + lane * 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(be + lane * 4), b1 = *reinterpret_cast<const float4*>(be + 256 + lane * 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = wave * 4 + i, r = r0 + rr;
+    bf16_t* dst = sA + rr * lda;
+    if (r >= p.R) {  // rows past the batch: zeros into the tile
+      *reinterpret_cast<uint2*>(dst + lane * 4) = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(dst + 256 + lane * 4) = make_uint2(0u, 0u);
+      continue;
+    }
+    const float s = ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
+    const float mean = wave_sum_dpp(s) * (1.0f / d);
+    float qq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float a = v[i][c].x - mean, b = v[i][c].y - mean, cc = v[i][c].z - mean, e = v[i][c].w - mean;
+      qq += (a * a + b * b) + (cc * cc + e * e);
+    }
+    const float var = wave_sum_dpp(qq) * (1.0f / d);
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float4 gg = c ? g1 : g0, bb = c ? b1 : b0;
+      float4 o;
+      o.x = (v[i][c].x - mean) * rstd * gg.x + bb.x;
+      o.y = (v[i][c].y - mean) * rstd * gg.y + bb.y;
+      o.z = (v[i][c].z - mean) * rstd * gg.z + bb.z;
+      o.w = (v[i][c].w - mean) * rstd * gg.w + bb.w;
+      bf16x4 ob;
+      ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
+      *reinterpret_cast<bf16x4*>(dst + c * 256 + lane * 4) = ob;
+      if (write_x) cst_f4(p.xres + (int64_t)r * d + c * 256 + lane * 4, o);
+      if (write_hn) cst_b4(p.hn + (int64_t)r * d + c * 256 + lane * 4, ob);
+    }
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void load_a_bf16(const RArgs& p, int r0, const bf16_t* src, bf16_t* sA, int lda) {
+  constexpr int per_row = K / 8, NC = 16 * per_row / 256;  // 16-byte chunks per thread, all in flight together
+  bf16x8 v[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = threadIdx.x + 256 * i, rr = c / per_row, c8 = c - rr * per_row;
+    v[i] = cld_b8(src + (int64_t)(r0 + rr < p.R ? r0 + rr : 0) * K + c8 * 8);
+    if (r0 + rr >= p.R) v[i] = bf16x8{};
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = threadIdx.x + 256 * i, rr = c / per_row, c8 = c - rr * per_row;
+    *reinterpret_cast<bf16x8*>(sA + rr * lda + c8 * 8) = v[i];
+  }
+}
+
+template <int NF>
+__device__ __forceinline__ void load_w(bf16x8 (&wf)[NF], const bf16_t* wp) {
+#pragma unroll
+  for (int i = 0; i < NF; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wp + i * 32);
+}
+
+// Which (row tile, column items) a workgroup takes in a GEMM phase.  Workgroups are dealt to the 8 XCDs round-robin
+// (blockIdx % 8) and each XCD has an L2 of its own, so the column items - the WEIGHT slices - follow the XCD: the
+// workgroups of XCD x take items x, x + 8, ... for every row tile, and a weight slice is read into one L2 only,
+// where it stays for all T steps (by row tile first, every XCD would stream the whole vocabulary matrix per step).
+// helper: when the phase leaves workgroups without an item, one of them per row tile (XCD 7's first idle slot) is the
+// row tile's `helper` - it advances the rows' decode state (score, length, end flags: select4<true>) off the path of
+// the workgroups that multiply; otherwise (`helped` false) the workgroup of column item 0 does that too.
+struct PhaseMap {
+  int rt, c0, nper; bool has, helped, helper;
+  __device__ __forceinline__ PhaseMap(int RT, int CI) {
+    const int G = gridDim.x, b = blockIdx.x;
+    helped = helper = false;
+    if ((G & 7) == 0 && (G >> 3) >= RT) {
+      const int x = b & 7, j = b >> 3, nsl = (G >> 3) / RT, cs = j / RT;
+      rt = j - cs * RT; c0 = x + 8 * cs; nper = 8 * nsl; has = cs < nsl && c0 < CI;
+      const int csh = CI > 7 ? (CI - 7 + 7) >> 3 : 0;  // first slot of XCD 7 without an item: 7 + 8 csh >= CI
+      helped = csh < nsl;
+      helper = helped && x == 7 && cs == csh;
+    } else {
+      nper = G / RT; rt = b % RT; c0 = b / RT; has = c0 < nper && c0 < CI;
+    }
+    np_ = (unsigned)(RT * (nper < CI ? nper : CI));
+    nh_ = helped ? (unsigned)RT : 0u;
+  }
+  unsigned np_, nh_;  // workgroups with an item / helpers in this phase (the same numbers in every workgroup)
+};
+
+// One GEMM phase: out[R, N] = A[R, K] W[N, K]^T (+ bias, epilogue EPI), K = 512 * KC.  A workgroup loads (and
+// normalises) the 16 A rows of its row tile ONCE and walks its column items with two sets of W fragments: the next
+// item's travel while the current one is multiplied.
+//   KSPLIT = false: item = 64 columns, a wave owns a 16x16 output tile over the whole K (the vocabulary phase; QKV and
+//                   FFN dense1 above 64 rows);
+//   KSPLIT = true : item = 16 columns, the 4 waves split K and wave 0 adds the partial tiles through LDS - 4x the
+//                   items, 1/4 of the W bytes per wave (what a GEMM over a few rows waits for is its CU's read rate
+//                   from L2): the N = 512 phases always, QKV and FFN dense1 up to 64 rows.
+// E_VOCAB keeps a running (max, arg-max, sum exp) per lane over the workgroup's items and merges lanes and waves once,
+// after the last item: one partial per (row, workgroup of the row tile), p.parts of them per row.
+template <int KC, int AMODE, int EPI, bool KSPLIT, int RTB = 1>
+__device__ __forceinline__ unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf16_t* sA, const bf16_t* W,
+                                           const float* bias, int N, const void* asrc, const float* g, const float* be,
+                                           bool write_x, int t, bf16_t* skv, const float* asrc2 = nullptr) {
+  // RTB: 16-row tiles a workgroup multiplies with ONE fetch of its W fragments (their A rows side by side in LDS):
+  // the weight traffic of a phase is (row tiles / RTB) x the matrix - what bounds the vocabulary phase at 128 rows.
+  constexpr int K = 512 * KC, NF = KSPLIT ? 4 * KC : 16 * KC;
+  constexpr int lda = K + 8;
+  static_assert(NF <= 16, "two sets of W fragments: <= 128 VGPRs");
+  __shared__ float s_pm[4][16];
+  __shared__ int s_pi[4][16];
+  __shared__ float s_ps[4][16];
+  __shared__ f32x4 s_red[2][3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
+  const int RT = (p.R + 15) >> 4, RG = (RT + RTB - 1) / RTB, CI = KSPLIT ? (N + 15) >> 4 : (N + 63) >> 6;
+  const PhaseMap pm(RG, CI);
+  const int r0 = pm.rt * 16 * RTB;
+  // this wave's tile of column item c: columns n0(c) .. + 16; its K range starts at koff
+  const int koff = KSPLIT ? wave * (K / 4) : 0;
+  auto tile_n0 = [&](int c) { return KSPLIT ? c * 16 : (c * 4 + wave) * 16; };
+  // (unconditional: an item past the last one re-reads the last one's rows.  A branch around the loads would make the
+  // compiler wait for ALL outstanding loads - vmcnt(0) - at its join, i.e. for the fragments just requested, before the
+  // MFMAs of the current item)
+  auto fetch = [&](bf16x8 (&wf)[NF], int c) {
+    load_w<NF>(wf, W + (int64_t)min(tile_n0(min(c, CI - 1)) + l16, N - 1) * K + koff + kg * 8);
+  };
+  float vm[RTB], vs[RTB];  // E_VOCAB: the lane's running partial per row tile
+  int vi[RTB];
+#pragma unroll
+  for (int u = 0; u < RTB; ++u) { vm[u] = -INFINITY; vs[u] = 0.f; vi[u] = 0x7fffffff; }
+  // E_VOCABK: the lane's RES_BMK best 4-column groups so far per row tile (maximum of the group desc; the lane's items
+  // run through ascending columns and a later group enters on `>` only, so equal maxima keep the lower group).  The
+  // row's bm best logits lie in its bm best groups: the bm-th largest group maximum is a lower bound of the bm-th best
+  // logit, and a logit at least that large makes its group's maximum at least that large.
+  constexpr int NL = EPI == E_VOCABK ? RES_BMK : 1;
+  float lv[RTB][NL];
+  int lg[RTB][NL];
+#pragma unroll
+  for (int u = 0; u < RTB; ++u)
+#pragma unroll
+    for (int k = 0; k < NL; ++k) { lv[u][k] = -INFINITY; lg[u][k] = 0x7fffffff; }
+  int par = 0;
+  // the wave's A fragments (its K range of the 16 rows): read from LDS once per phase and kept in registers - every
+  // item of the workgroup multiplies the same rows (per row tile when RTB > 1)
+  bf16x8 af[NF];
+  auto load_af = [&](int u) {
+    const bf16_t* ar = sA + (u * 16 + l16) * lda + koff + kg * 8;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ar + i * 32);
+  };
+  auto item = [&](const bf16x8 (&wf)[NF], int c) {
+    const int n0 = tile_n0(c), nb = n0 + kg * 4;
+    const bool active = n0 < N;
+#pragma unroll
+    for (int u = 0; u < RTB; ++u) {
+      const int r = r0 + u * 16 + l16;  // lane: row r, columns nb .. nb + 3 of its wave's tile
+      if (RTB > 1 && r0 + u * 16 >= p.R) break;
+      float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (EPI == E_RES)
+        if ((!KSPLIT || wave == 0) && active && r < p.R) xr = cld_f4(p.xres + (int64_t)r * 512 + nb);
+      // K in quarters, each with two accumulator chains (even / odd fragments), added as q0 + ((q1 + q2) + q3): the
+      // order in which the K-split form adds its four waves' tiles, so both forms give the same bits
+      constexpr int NQ = (KSPLIT || EPI == E_VOCAB || EPI == E_VOCABK) ? 1 : 4, QF = NF / NQ;  // (the vocabulary phase has one form)
+      f32x4 part[NQ];
+      {
+        if constexpr (RTB > 1) load_af(u);
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) {
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+          if (active) {
+#pragma unroll
+            for (int i = qq * QF; i < (qq + 1) * QF; i += 2) {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[i], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], af[i + 1], acc1, 0, 0, 0);
+            }
+          }
+          part[qq] = acc0 + acc1;
+        }
+      }
+      f32x4 v = part[0];
+      if constexpr (NQ == 4) v = part[0] + ((part[1] + part[2]) + part[3]);
+      if constexpr (KSPLIT) {
+        if (wave > 0) s_red[par][wave - 1][lane] = v;
+        __syncthreads();  // one per tile: the partial tiles alternate between two buffers
+        par ^= 1;
+        if (wave > 0) continue;
+        v = v + ((s_red[par ^ 1][0][lane] + s_red[par ^ 1][1][lane]) + s_red[par ^ 1][2][lane]);
+      }
+      if constexpr (EPI == E_VOCAB || EPI == E_VOCABK) {
+        if (active) {
+          float m4 = -INFINITY;
+          int i4 = 0x7fffffff;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nb + e < N && v[e] > m4) { m4 = v[e]; i4 = nb + e; }
+          if constexpr (EPI == E_VOCABK) {  // branch-free insertion of (m4, group) into the sorted list
+            float x = m4;
+            int gx = nb >> 2;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+              const bool gt = x > lv[u][k];
+              const float nl = gt ? x : lv[u][k], nx = gt ? lv[u][k] : x;
+              const int ng = gt ? gx : lg[u][k], ngx = gt ? lg[u][k] : gx;
+              lv[u][k] = nl; lg[u][k] = ng; x = nx; gx = ngx;
+            }
+          }
+          if (m4 > vm[u]) {  // later items hold higher columns: a tie keeps the earlier one
+            vs[u] = vm[u] == -INFINITY ? 0.f : vs[u] * expf(vm[u] - m4);
+            vm[u] = m4; vi[u] = i4;
+          }
+          if (vm[u] != -INFINITY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (nb + e < N) vs[u] += expf(v[e] - vm[u]);
+          }
+        }
+      } else if (active && r < p.R) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        if constexpr (EPI == E_QKV) {
+          if (nb < 512) {
+            cst_f4(p.q + (int64_t)r * 512 + nb, make_float4(v[0], v[1], v[2], v[3]));
+          } else {
+            bf16x4 ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = (bf16_t)v[e];
+            cst_b4(skv + ((int64_t)r * p.T + (t - 1)) * 1024 + (nb - 512), ob);
+          }
+        } else if constexpr (EPI == E_Q) {
+          cst_f4(p.q + (int64_t)r * 512 + nb, make_float4(v[0], v[1], v[2], v[3]));
+        } else if constexpr (EPI == E_RES) {
+          cst_f4(p.y + (int64_t)r * 512 + nb, make_float4(v[0] + xr.x, v[1] + xr.y, v[2] + xr.z, v[3] + xr.w));
+        } else {  // E_ACT
+          bf16x4 ob;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ob[e] = (bf16_t)res_act(v[e], p.act);
+          cst_b4(p.h + (int64_t)r * N + nb, ob);
+        }
+      }
+    }
+  };
+
+  bf16x8 wa[NF], wb[NF];
+  // who hands this phase's output on: the workgroups with an item (+ the helpers that advance the decode state)
+  const bool participant = pm.has || (AMODE == A_EMBED && pm.helper);
+  const unsigned nprod = pm.np_ + (AMODE == A_EMBED ? pm.nh_ : 0u);
+  if (gs.dead) return nprod;
+  if (pm.has) fetch(wa, pm.c0);
+  if (do_wait && participant) gs.wait();
+  if (gs.dead) return nprod;
+  gs.mark();
+  if constexpr (AMODE == A_EMBED)
+    if (pm.helper) advance_state4(p, r0 + wave * 4, t, lane);
+  if (pm.has) {
+    if constexpr (AMODE == A_BF16) {
+#pragma unroll
+      for (int u = 0; u < RTB; ++u) {
+        if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;
+        load_a_bf16<K>(p, r0 + u * 16, reinterpret_cast<const bf16_t*>(asrc), sA + u * 16 * lda, lda);
+      }
+    } else {  // the rows of every tile requested before the first one is normalised
+      float4 av[RTB][4][2];
+#pragma unroll
+      for (int u = 0; u < RTB; ++u)
+        fetch_a_rows<AMODE>(p, r0 + u * 16, t, pm.c0 == 0 && (AMODE == A_EMBEDB || !pm.helped), reinterpret_cast<const float*>(asrc), asrc2, av[u]);
+#pragma unroll
+      for (int u = 0; u < RTB; ++u) {
+        if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;
+        finish_a_rows(p, r0 + u * 16, av[u], g, be, write_x && pm.c0 == 0, sA + u * 16 * lda, lda, EPI == E_VOCABK && pm.c0 == 0);
+      }
+    }
+    __syncthreads();
+    if constexpr (RTB == 1) load_af(0);
+    if constexpr (EPI == E_VOCAB || EPI == E_VOCABK) gs.mark();
+    if (pm.c0 + pm.nper >= CI) {
+      item(wa, pm.c0);  // one item: nothing to prefetch (most phases at most row counts)
+    } else {
+      for (int c = pm.c0; c < CI; c += 2 * pm.nper) {
+        fetch(wb, c + pm.nper);
+        item(wa, c);
+        if (c + pm.nper >= CI) break;
+        fetch(wa, c + 2 * pm.nper);
+        item(wb, c + pm.nper);
+      }
+    }
+    if constexpr (EPI == E_VOCAB || EPI == E_VOCABK) {
+      gs.mark();
+#pragma unroll
+      for (int u = 0; u < RTB; ++u) {
+        const int r = r0 + u * 16 + l16;
+        if (RTB > 1 && r0 + u * 16 >= p.R) break;
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          const float om = __shfl_xor(vm[u], o, 64), os = __shfl_xor(vs[u], o, 64);
+          const int oi = __shfl_xor(vi[u], o, 64);
+          amax_merge(vm[u], vi[u], vs[u], om, oi, os);
+        }
+        if (u > 0) __syncthreads();  // wave 0 has read the previous tile's entries
+        if (kg == 0) { s_pm[wave][l16] = vm[u]; s_pi[wave][l16] = vi[u]; s_ps[wave][l16] = vs[u]; }
+        __syncthreads();
+        if (wave == 0 && kg == 0 && r < p.R) {
+#pragma unroll
+          for (int w = 1; w < 4; ++w) amax_merge(vm[u], vi[u], vs[u], s_pm[w][l16], s_pi[w][l16], s_ps[w][l16]);
+          cst_f(p.pmax + (int64_t)r * p.parts + pm.c0, vm[u]);
+          cst_i(p.pidx + (int64_t)r * p.parts + pm.c0, vi[u]);
+          cst_f(p.psum + (int64_t)r * p.parts + pm.c0, vs[u]);
+        }
+        if constexpr (EPI == E_VOCABK) {
+          // the 16 lists of a row (4 column groups x 4 waves) -> its RES_BMK best groups of this part: the lists go
+          // through LDS, wave w merges rows 4 w .. 4 w + 3 - one row per 16-lane DPP row, one source list per lane,
+          // RES_BMK rounds of `largest head of the 16 lists` (row16_max_u64), the lane that held it moves its list up
+          __shared__ float s_lv[16][16][RES_BMK];
+          __shared__ int s_lg[16][16][RES_BMK];
+#pragma unroll
+          for (int k = 0; k < RES_BMK; ++k) { s_lv[l16][wave * 4 + kg][k] = lv[u][k]; s_lg[l16][wave * 4 + kg][k] = lg[u][k]; }
+          __syncthreads();
+          const int mrow = wave * 4 + (lane >> 4), msrc = lane & 15, mr = r0 + u * 16 + mrow;
+          float hv[RES_BMK], ov[RES_BMK];
+          int hg[RES_BMK], og[RES_BMK];
+#pragma unroll
+          for (int k = 0; k < RES_BMK; ++k) { hv[k] = s_lv[mrow][msrc][k]; hg[k] = s_lg[mrow][msrc][k]; }
+#pragma unroll
+          for (int k = 0; k < RES_BMK; ++k) {
+            const unsigned long long key = key_of(hv[0], (unsigned)hg[0]), best = row16_max_u64(key);
+            ov[k] = key_val(best); og[k] = (int)key_idx(best);
+            if (key == best) {  // (an empty entry may be `popped` by several lanes at once: their lists are empty anyway)
+#pragma unroll
+              for (int j = 0; j + 1 < RES_BMK; ++j) { hv[j] = hv[j + 1]; hg[j] = hg[j + 1]; }
+              hv[RES_BMK - 1] = -INFINITY; hg[RES_BMK - 1] = 0x7fffffff;
+            }
+          }
+          if (msrc == 0 && mr < p.R) {
+            const int64_t o = ((int64_t)mr * p.parts + pm.c0) * RES_BMK;
+#pragma unroll
+            for (int k = 0; k < RES_BMK; ++k) { cst_f(p.gval + o + k, ov[k]); cst_i(p.ggid + o + k, og[k]); }
+          }
+        }
+      }
+    }
+  }
+  gs.mark();
+  gs.arrive(participant);
+  return nprod;
+}
+
+// FFN dense2 + residual for ff = 2048: out[R, 512] = h[R, 2048] W2^T + b2 + x.  K is added in EIGHTHS of 256 (two
+// accumulator chains each), as half0 = e0 + ((e1 + e2) + e3), half1 = e4 + ((e5 + e6) + e7), y = ((half0 + b) + x) + half1,
+// in both forms - a row's bits do not depend on the form its batch takes:
+//   HALF = false: item = 16 columns, wave w multiplies eighths 2 w and 2 w + 1, wave 0 adds the eight tiles from LDS;
+//   HALF = true (<= 64 rows: 32 items per row tile leave most CUs idle and each fetches 64 KB of W2 - what the phase waits for):
+//                item = (16 columns, K half), wave w multiplies eighth 4 half + w; the half-0 workgroup stores
+//                (half0 + b) + x to y, the half-1 workgroup stores half1 to y2, and the consumers add y + y2 on load.
+template <bool HALF>
+__device__ __forceinline__ unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const bf16_t* W, const float* bias) {
+  constexpr int K = 2048, lda = K + 8, NF = HALF ? 8 : 16;
+  __shared__ f32x4 s_e[2][7][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
+  const int RT = (p.R + 15) >> 4, CI = HALF ? 64 : 32;
+  const PhaseMap pm(RT, CI);
+  const int r0 = pm.rt * 16, r = r0 + l16;
+  auto k0_of = [&](int c) { return HALF ? ((c & 1) * 4 + wave) * 256 : wave * 512; };
+  auto n0_of = [&](int c) { return (HALF ? c >> 1 : c) * 16; };
+  bf16x8 wf[NF];
+  const unsigned nprod = pm.np_;
+  if (gs.dead) return nprod;
+  if (pm.has) load_w<NF>(wf, W + (int64_t)(n0_of(pm.c0) + l16) * K + k0_of(pm.c0) + kg * 8);
+  if (pm.has) gs.wait();
+  if (gs.dead) return nprod;
+  gs.mark();
+  if (pm.has) {
+    int par = 0;
+    bool tile_loaded = false;
+    for (int c = pm.c0; c < CI; c += pm.nper, par ^= 1) {
+      const int n0 = n0_of(c), nb = n0 + kg * 4, k0 = k0_of(c), kh = HALF ? c & 1 : 0;
+      if (c != pm.c0) load_w<NF>(wf, W + (int64_t)(n0 + l16) * K + k0 + kg * 8);
+      float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wave == 0 && kh == 0 && r < p.R) xr = cld_f4(p.xres + (int64_t)r * 512 + nb);
+      if (!tile_loaded || HALF) {  // the 16 rows of h (HALF: the K half of this item) -> LDS
+        if (tile_loaded) __syncthreads();
+        constexpr int KP = HALF ? 1024 : 2048, per_row = KP / 8, NC = 16 * per_row / 256;
+        const int kb = HALF ? kh * 1024 : 0;
+        bf16x8 v[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          const int q = threadIdx.x + 256 * i, rr = q / per_row, c8 = q - rr * per_row;
+          v[i] = cld_b8(p.h + (int64_t)(r0 + rr < p.R ? r0 + rr : 0) * K + kb + c8 * 8);
+          if (r0 + rr >= p.R) v[i] = bf16x8{};
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          const int q = threadIdx.x + 256 * i, rr = q / per_row, c8 = q - rr * per_row;
+          *reinterpret_cast<bf16x8*>(sA + rr * lda + kb + c8 * 8) = v[i];
+        }
+        __syncthreads();
+        tile_loaded = true;
+      }
+      const bf16_t* ar = sA + l16 * lda + k0 + kg * 8;
+      f32x4 e[NF / 8];
+#pragma unroll
+      for (int h8 = 0; h8 < NF / 8; ++h8) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = h8 * 8; i < h8 * 8 + 8; i += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], *reinterpret_cast<const bf16x8*>(ar + i * 32), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], *reinterpret_cast<const bf16x8*>(ar + (i + 1) * 32), acc1, 0, 0, 0);
+        }
+        e[h8] = acc0 + acc1;
+      }
+      // eighth tiles of the other waves -> LDS (slot = eighth - 1 within the item's range; wave 0 keeps its first)
+      if constexpr (HALF) {
+        if (wave > 0) s_e[par][wave - 1][lane] = e[0];
+      } else {
+        if (wave == 0) s_e[par][0][lane] = e[1];
+        else { s_e[par][2 * wave - 1][lane] = e[0]; s_e[par][2 * wave][lane] = e[1]; }
+      }
+      __syncthreads();
+      if (wave == 0 && r < p.R) {
+        if constexpr (HALF) {
+          const f32x4 half = e[0] + ((s_e[par][0][lane] + s_e[par][1][lane]) + s_e[par][2][lane]);
+          if (kh == 0) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
+            cst_f4(p.y + (int64_t)r * 512 + nb, make_float4((half[0] + bv.x) + xr.x, (half[1] + bv.y) + xr.y,
+                                                             (half[2] + bv.z) + xr.z, (half[3] + bv.w) + xr.w));
+          } else {
+            cst_f4(p.y2 + (int64_t)r * 512 + nb, make_float4(half[0], half[1], half[2], half[3]));
+          }
+        } else {
+          const f32x4 half0 = e[0] + ((s_e[par][0][lane] + s_e[par][1][lane]) + s_e[par][2][lane]);
+          const f32x4 half1 = s_e[par][3][lane] + ((s_e[par][4][lane] + s_e[par][5][lane]) + s_e[par][6][lane]);
+          const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
+          cst_f4(p.y + (int64_t)r * 512 + nb, make_float4(((half0[0] + bv.x) + xr.x) + half1[0], ((half0[1] + bv.y) + xr.y) + half1[1],
+                                                           ((half0[2] + bv.z) + xr.z) + half1[2], ((half0[3] + bv.w) + xr.w) + half1[3]));
+        }
+      }
+    }
+  }
+  gs.mark();
+  gs.arrive(pm.has);
+  return nprod;
+}
+
+// One attention phase: ctx[r, h*64 ..] = softmax(q_h K_h^T / 8 (masked, + bias)) V_h for every (row, head); one
+// wave per item, lane = (key slot, 8-dim chunk).  Masking as the reference: masked keys get -1e9, the hybrid bias
+// is added after the mask (models/components/Attention.py:104-111).  The heads of a row go to the waves of ONE XCD
+// (row % 8), so a row's static K/V is read into one L2.
+// One (row, head) of an attention phase in flight: its query chunk, key / value fragments, mask and bias terms.
+template <int NKB>
+struct AttnItem {
+  int r, hh;
+  float q[8];
+  float add[NKB];
+  bool padded[NKB];
+  bf16x8 kf[NKB], vf[NKB];
+};
+
+// ANC (beam search, SELF): key j of row r is position j of the hypothesis in beam slot r - cached, like its token, at the
+// PHYSICAL row anc[r][j] (the ancestor table of csrc/beam.hip: re-ordering beams never moves K / V)
+template <bool SELF, int NKB, bool ANC = false>  // SELF: the keys / values are the cache this launch writes (coherent loads), pad mask from `fed`
+__device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
+                                               int rows_per_kv, int nk, const int32_t* pad_tok, const float* bias,
+                                               int bias_ld, const int32_t* anc = nullptr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 3, chunk = lane & 7;
+  constexpr int d = 512;
+  const int nkb = (nk + 7) >> 3, H = p.H;
+  const bool by_xcd = (gridDim.x & 7) == 0;
+  const int x = by_xcd ? (int)(blockIdx.x & 7) : 0, xs = by_xcd ? 8 : 1;
+  const int bpx = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;  // workgroups per XCD (or all of them)
+  const int slot0 = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int myslot = slot0 + bpx * wave;
+  const int nslots = bpx * 4;
+  const int nrows_x = (p.R - x + xs - 1) / xs;  // rows x, x + xs, ...
+  const int nitems = nrows_x * H;
+  // a workgroup has an item iff its wave 0 has one (the smallest slot of the four)
+  const bool participant = slot0 < nitems;
+  unsigned nprod = 0;
+  for (int xx = 0; xx < xs; ++xx) {
+    const int it = ((p.R - xx + xs - 1) / xs) * H;
+    nprod += (unsigned)(it < bpx ? it : bpx);
+  }
+  if (gs.dead) return nprod;
+  if (do_wait && participant) gs.wait();
+  if (gs.dead) return nprod;
+  gs.mark();
+
+  // every load of an item, unconditionally (li is clamped by the caller): nothing here waits for anything
+  auto load = [&](AttnItem<NKB>& it, int li) {
+    it.r = x + xs * (li / H);
+    it.hh = li % H;
+    const float* qp = p.q + (int64_t)it.r * d + it.hh * 64 + chunk * 8;
+    const float4 qa = cld_f4(qp), qb = cld_f4(qp + 4);
+    it.q[0] = qa.x; it.q[1] = qa.y; it.q[2] = qa.z; it.q[3] = qa.w; it.q[4] = qb.x; it.q[5] = qb.y; it.q[6] = qb.z; it.q[7] = qb.w;
+    const bf16_t* kb0 = KV + (int64_t)(it.r / rows_per_kv) * kv_bs + it.hh * 64 + chunk * 8;
+    int prow[NKB];
+    if constexpr (ANC) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+        if (kb < nkb) {
+          const int j = kb * 8 + slot;
+          prow[kb] = cld_i(anc + (int64_t)it.r * p.fed_stride + (j < nk ? j : 0));
+        }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+      if (kb < nkb) {
+        const int j = kb * 8 + slot, jc = j < nk ? j : 0;
+        if constexpr (ANC) {
+          const bf16_t* kr = KV + (int64_t)prow[kb] * kv_bs + it.hh * 64 + chunk * 8 + (int64_t)jc * 2 * d;
+          it.padded[kb] = cld_i(pad_tok + (int64_t)prow[kb] * p.fed_stride + jc) == p.pad;
+          it.add[kb] = 0.f;
+          it.kf[kb] = cld_b8(kr);
+          it.vf[kb] = cld_b8(kr + d);
+          continue;
+        }
+        it.padded[kb] = pad_tok ? cld_i(pad_tok + (int64_t)it.r * p.fed_stride + jc) == p.pad : false;
+        it.add[kb] = bias ? bias[it.hh * bias_ld + jc] : 0.f;
+        if constexpr (SELF) { it.kf[kb] = cld_b8(kb0 + (int64_t)jc * 2 * d); it.vf[kb] = cld_b8(kb0 + (int64_t)jc * 2 * d + d); }
+        else {
+          it.kf[kb] = *reinterpret_cast<const bf16x8*>(kb0 + (int64_t)jc * 2 * d);
+          it.vf[kb] = *reinterpret_cast<const bf16x8*>(kb0 + (int64_t)jc * 2 * d + d);
+        }
+      }
+  };
+  auto compute = [&](const AttnItem<NKB>& it) {
+    float s[NKB];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+      if (kb < nkb) {
+        float dd = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dd = fmaf(it.q[i], (float)it.kf[kb][i], dd);
+        dd += care_dpp_x1(dd);
+        dd += care_dpp_x2(dd);
+        dd += care_dpp_m8(dd);
+        dd *= 0.125f;
+        if (it.padded[kb]) dd = -1e9f;
+        dd += it.add[kb];
+        s[kb] = kb * 8 + slot < nk ? dd : -INFINITY;
+        m = fmaxf(m, s[kb]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 8, 64));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+      if (kb < nkb) { s[kb] = expf(s[kb] - m); sum += s[kb]; }
+    sum += __shfl_xor(sum, 8, 64);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+      if (kb < nkb) {
+        const float pw = s[kb] * inv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(pw, (float)it.vf[kb][i], acc[i]);
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc[i] += __shfl_xor(acc[i], 8, 64);
+      acc[i] += __shfl_xor(acc[i], 16, 64);
+      acc[i] += __shfl_xor(acc[i], 32, 64);
+    }
+    if (slot == 0) {
+      bf16x8 ob;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ob[i] = (bf16_t)acc[i];
+      cst_b8(p.ctx + (int64_t)it.r * d + it.hh * 64 + chunk * 8, ob);
+    }
+  };
+
+  if (myslot < nitems) {
+    AttnItem<NKB> A;
+    load(A, myslot);
+    if (myslot + nslots >= nitems) {
+      compute(A);  // one item per wave (up to 128 rows): nothing to overlap
+    } else if constexpr (NKB <= 8) {
+      // several items per wave: the next item's loads travel while the current one is computed (two register sets;
+      // an item past the last re-reads the last - unconditional loads, see gemm_phase's fetch)
+      AttnItem<NKB> Bq;
+      for (int li = myslot; li < nitems; li += 2 * nslots) {
+        load(Bq, min(li + nslots, nitems - 1));
+        compute(A);
+        if (li + nslots >= nitems) break;
+        load(A, min(li + 2 * nslots, nitems - 1));
+        compute(Bq);
+      }
+    } else {
+      compute(A);
+      for (int li = myslot + nslots; li < nitems; li += nslots) {
+        load(A, li);
+        compute(A);
+      }
+    }
+  }
+  gs.mark();
+  gs.arrive(participant);
+  return nprod;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Host side, shared by care_decode_resident and care_decode_resident_beam.
+
+// care_resident_layer[] -> RArgs::L; 0 or a CARE_E* code
+inline int res_fill_layers(RArgs& p, const care_resident_layer* layers, int n_layers) {
+  for (int l = 0; l < n_layers; ++l) {
+    const care_resident_layer& s = layers[l];
+    RLayer& L = p.L[l];
+    if (!s.qkv_w || !s.qkv_b || !s.o_w || !s.o_b || !s.ln_g || !s.ln_b || !s.self_kv || !s.w1 || !s.b1 || !s.w2 || !s.b2 ||
+        !s.ffn_g || !s.ffn_b || s.n_att < 0 || s.n_att > 2)
+      return CARE_EINVAL;
+    L.qkv_w = (const bf16_t*)s.qkv_w; L.qkv_b = s.qkv_b; L.o_w = (const bf16_t*)s.o_w; L.o_b = s.o_b; L.g = s.ln_g; L.be = s.ln_b;
+    L.skv = (bf16_t*)s.self_kv;
+    L.n_att = s.n_att;
+    for (int a = 0; a < s.n_att; ++a) {
+      const care_resident_attn& sa = s.att[a];
+      if (!sa.q_w || !sa.q_b || !sa.o_w || !sa.o_b || !sa.ln_g || !sa.ln_b || !sa.kv || sa.rows_per_kv < 1) return CARE_EINVAL;
+      if (sa.nkeys < 1 || sa.nkeys > 8 * RES_MAXKB) return CARE_ESHAPE;
+      RAttn& A = L.att[a];
+      A.q_w = (const bf16_t*)sa.q_w; A.q_b = sa.q_b; A.o_w = (const bf16_t*)sa.o_w; A.o_b = sa.o_b; A.g = sa.ln_g; A.be = sa.ln_b;
+      A.kv = (const bf16_t*)sa.kv; A.kv_bs = sa.kv_batch_stride; A.nkeys = sa.nkeys; A.rows_per_kv = sa.rows_per_kv;
+      A.bias = sa.bias; A.bias_ld = sa.bias_ld;
+    }
+    L.w1 = (const bf16_t*)s.w1; L.b1 = s.b1; L.w2 = (const bf16_t*)s.w2; L.b2 = s.b2; L.fg = s.ffn_g; L.fbe = s.ffn_b;
+  }
+  p.n_layers = n_layers;
+  return 0;
+}
+
+}  // namespace
+extern std::atomic<int> care_res_dbg_prof, care_res_dbg_ghost;  // decode_resident.hip (care_decode_resident_debug)
+namespace {
+
+// Tuning / tool / test knobs of the resident launches: the environment is read ONCE per process (first launch), the
+// debug hooks are set through care_decode_resident_debug (tests, tools/resident_prof.py), never through the environment.
+struct ResKnobs {
+  int rb, small, half_rows, beam_cfg;  // -1: not set
+  ResKnobs() {
+    auto geti = [](const char* n) { const char* e = getenv(n); return e ? atoi(e) : -1; };
+    rb = geti("CARE_RESIDENT_RB"); small = geti("CARE_RESIDENT_SMALL"); half_rows = geti("CARE_RESIDENT_HALF_ROWS");
+    beam_cfg = geti("CARE_RESIDENT_BEAM_CFG");
+  }
+};
+inline const ResKnobs& res_knobs() {
+  static const ResKnobs k;
+  return k;
+}
+
+// Every workgroup of a resident launch must be resident at the same time: the grid is at most one workgroup per CU, and
+// the occupancy query must admit one workgroup of this kernel per CU (registers, LDS).  0 or a CARE_E* / hipError_t code.
+inline int res_check_residency(const void* kernel, int lds, int grid, int cus) {
+  int nb = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, (size_t)lds);
+  if (e != hipSuccess) return (int)e;
+  return (nb >= 1 && grid <= cus) ? 0 : CARE_ESHAPE;
+}
+
+}  // namespace

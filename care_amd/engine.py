@@ -135,6 +135,9 @@ class HipEngine:
         self.segment_steps = int(os.environ.get("CARE_SEGMENT_STEPS", "4"))
         # greedy batches of up to this many clips decode as ONE resident launch (greedy_resident); 0 turns it off
         self.resident_max_rows = int(os.environ.get("CARE_RESIDENT_MAX_ROWS", "256"))
+        # beam search as one resident launch (csrc/decode_resident_beam.hip) up to this many rows = clips x beam_size
+        # (translate.py's default: 128 clips x beam 5); 0: the multi-launch search at every size
+        self.resident_beam_max_rows = int(os.environ.get("CARE_RESIDENT_BEAM_MAX_ROWS", "640"))
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, sd: Dict[str, torch.Tensor], device) -> None:
@@ -436,9 +439,15 @@ class HipEngine:
     # between 2048 and 4096 rows on msrvtt_base_ami: 2048 rows 246 -> 241 us / step, 4096 rows 346 -> 356)
     VOCAB_TILE_MAX_ROWS = int(os.environ.get("CARE_VOCAB_TILE_MAX_ROWS", "2048"))
 
+    def _vocab_as(self, rows: int) -> bool:
+        """The A-stationary vocabulary kernel (against the LDS-tiled one)?  Decided by the pass's INITIAL row count
+        (`_form_rows`), like ln_fusable: compaction must not move a clip from one kernel's summation order to the
+        other's mid-pass."""
+        return self.as_ok and (self._form_rows or rows) > self.VOCAB_TILE_MAX_ROWS
+
     def vocab_parts(self, rows: int) -> int:
         """Column groups per row of the fused vocabulary arg-max for `rows` rows (the kernel vocab_argmax picks)."""
-        if self.as_ok and rows > self.VOCAB_TILE_MAX_ROWS:
+        if self._vocab_as(rows):
             return _lib.load().care_argmax_parts_bf16(rows, self.V)
         if self.bf_act or (self.split3 and self.w["vocab"].data_ptr() in self._w3):
             return _lib.load().care_argmax_parts_tile(self.V)
@@ -449,7 +458,7 @@ class HipEngine:
         (NaiveHead + log_softmax + top-1, Head.py:26-32 / Translator.py:127); the [rows, V] logits never exist.
         bf16, d <= 512: A-stationary kernels; bf16, larger d: the LDS-tiled kernel; fp32 mode: exact-f32 MFMA."""
         d, W = self.d, self.w["vocab"]
-        if self.as_ok and rows > self.VOCAB_TILE_MAX_ROWS:
+        if self._vocab_as(rows):
             call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels),
                  ptr(plab), rows, self.V, d, tag=tag)
         elif self.bf_act:
@@ -1123,26 +1132,98 @@ class HipEngine:
         return fed, length, score
 
     # ------------------------------------------------------------------ resident decode of small batches
+    RESIDENT_MAX_V = 64 * 64 * 4  # csrc/decode_resident.hip: 64 lanes x RES_NP column-group partials of 64 columns
+
     def resident_ok(self, rows: int) -> bool:
         """Greedy decode of `rows` clips as one resident launch (csrc/decode_resident.hip)?  bf16 mode, d_model = 512;
         a form of its own next to the multi-launch one: projected cross K/V, the same rounding points, sums in another
         order - so which of two nearly tied tokens wins can differ between a batch of <= resident_max_rows clips and a
         larger one (the audit of tests/test_gpu_properties.py counts such rows)."""
-        if not (0 < rows <= self.resident_max_rows and self.as_ok and self.d == 512 and self.ff in (512, 1024, 2048) and
-                self.T <= 128 and self.n_layers <= 4 and (not self.attr_att or self.topk <= 128)):
+        if not (0 < rows <= self.resident_max_rows and self._resident_model_ok()):
             return False
-        # one workgroup per CU at most, and at least one per 16-row tile (a partitioned GPU has fewer CUs)
+        return self._resident_fits(rows)
+
+    def _resident_model_ok(self) -> bool:
+        """Every model-side limit care_decode_resident / care_decode_resident_beam enforce (CARE_ESHAPE otherwise)."""
+        return bool(self.as_ok and self.d == 512 and self.ff in (512, 1024, 2048) and self.T <= 128 and self.n_layers <= 4 and
+                    (not self.attr_att or self.topk <= 128) and self.V <= self.RESIDENT_MAX_V and self.Lk <= 128)
+
+    def _resident_fits(self, rows: int, per_tile: int = 1) -> bool:
+        """one workgroup per CU at most, and at least one per group of `per_tile` 16-row tiles (a partitioned GPU has fewer CUs)"""
         if self.device is not None and torch.cuda.is_available():
             if getattr(self, "_cus", None) is None:
                 self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-            return (rows + 15) // 16 <= self._cus
+            return ((rows + 15) // 16 + per_tile - 1) // per_tile <= self._cus // 8 * 8
         return True
+
+    RESIDENT_BEAM_MAX = 5  # csrc/decode_resident.h RES_BMK
+
+    def resident_beam_ok(self, clips: int, bm: int, need: int) -> bool:
+        """Beam search over `clips` clips as one resident launch (csrc/decode_resident_beam.hip)?  The limits of
+        care_decode_resident_beam: the greedy launch's, beam_size <= 5, a hypothesis' positions one per lane (T <= 63)."""
+        rows = clips * bm
+        if not (0 < rows <= self.resident_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and
+                self._resident_model_ok() and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX):
+            return False
+        return self._resident_fits(rows, 2 if rows > 256 else 1)
 
     def small_forms(self, clips: int) -> bool:
         """Batches of <= resident_max_rows clips (bf16, d_model = 512) take the small-batch forms of the pass: the
         embedder as GEMM + LayerNorm launches side by side per modality (encode(small=True)) and, for greedy decoding,
         the resident decode.  `resident_max_rows = 0`: one set of forms at every batch size."""
         return 0 < clips <= self.resident_max_rows and self.as_ok and self.d == 512
+
+    def _resident_layers(self, tag: str, rows: int, rows_per_clip: int, ckv, akv, Lk: int):
+        """care_resident_layer[] of this model for a resident launch over `rows` rows (self-attention caches in the
+        workspaces `tag`skv*; static K/V per clip, shared by its `rows_per_clip` rows)."""
+        w, d, T = self.w, self.d, self.T
+        layers = self._res_layers = (_lib.ResidentLayer * self.n_layers)()  # kept: bench.py re-issues the recorded call
+        for li in range(self.n_layers):
+            L, sa, ffn = layers[li], "d{}_sa".format(li), "d{}_ffn".format(li)
+            L.qkv_w, L.qkv_b, L.o_w, L.o_b = ptr(w[sa + "_qkv_w"]), ptr(w[sa + "_qkv_b"]), ptr(w[sa + "_o_w"]), ptr(w[sa + "_o_b"])
+            L.ln_g, L.ln_b = ptr(w[sa + "_g"]), ptr(w[sa + "_be"])
+            L.self_kv = ptr(self.ws(tag + "skv%d" % li, (rows, T, 2 * d), torch.bfloat16))
+            blocks = [("d{}_ca".format(li), ckv[li], Lk, w["d{}_hb".format(li)])]
+            if self.attr_att:
+                blocks.append(("d{}_aa".format(li), akv[li], self.topk, None))
+            L.n_att = len(blocks)
+            for a, (nm, kv, nkeys, hb) in enumerate(blocks):
+                A = L.att[a]
+                A.q_w, A.q_b, A.o_w, A.o_b = ptr(w[nm + "_q_w"]), ptr(w[nm + "_q_b"]), ptr(w[nm + "_o_w"]), ptr(w[nm + "_o_b"])
+                A.ln_g, A.ln_b = ptr(w[nm + "_g"]), ptr(w[nm + "_be"])
+                A.kv, A.kv_batch_stride, A.nkeys, A.rows_per_kv = ptr(kv), nkeys * 2 * d, nkeys, rows_per_clip
+                A.bias, A.bias_ld = ptr(hb), (hb.stride(0) if hb is not None else 0)
+            L.w1, L.b1, L.w2, L.b2 = ptr(w[ffn + "_w1"]), ptr(w[ffn + "_b1"]), ptr(w[ffn + "_w2"]), ptr(w[ffn + "_b2"])
+            L.ffn_g, L.ffn_b = ptr(w[ffn + "_g"]), ptr(w[ffn + "_be"])
+        return layers
+
+    def beam_resident(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int,
+                      sem_embs: Optional[torch.Tensor] = None, early_exit: bool = True):
+        """Beam search of B clips x bm beams in ONE launch (care_decode_resident_beam): the step loop of
+        Translator.translate_batch (models/Translator.py:77-143) with Beam.advance (misc/Decoding/Beam.py:45-85) on the
+        device, stopping once every clip is done (Translator.py:77-81).  Returns the per-clip results of engine.beam:
+        nfin [B], fscore / flen [B, need + bm], fhyp [B, need + bm, T + 1]; no host synchronisation here."""
+        B, Lk, d = mem.shape
+        T, w, N, cap = self.T, self.w, mem.shape[0] * bm, need + bm
+        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
+        ckv = self.cross_kv(mem, tag="rb_ckv")
+        akv = self.attr_kv(sem_embs, tag="rb_akv") if self.attr_att else None
+        tok = self.ws("rb_tok", (N, T + 1), torch.int32)
+        anc = [self.ws("rb_anc%d" % i, (N, T + 1), torch.int32) for i in range(2)]
+        scores, done, nfin = self.ws("rb_scores", (N,)), self.ws("rb_done", (B,), torch.int32), self.ws("rb_nfin", (B,), torch.int32)
+        fscore, flen = self.ws("rb_fscore", (B, cap)), self.ws("rb_flen", (B, cap), torch.int32)
+        fhyp = self.ws("rb_fhyp", (B, cap, T + 1), torch.int32)
+        layers = self._resident_layers("rb_", N, bm, ckv, akv, Lk)
+        nbytes = _lib.load().care_decode_resident_beam_scratch(B, bm, d, self.ff, self.V)
+        scratch = self.ws("rb_scratch", (nbytes,), torch.uint8)
+        call("care_decode_resident_beam", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem),
+             ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(w["vocab"]), self.V, d, self.H, self.ff, self.act, B, bm, need, T, T,
+             BOS, EOS, PAD, ptr(tok), T + 1, ptr(anc[0]), ptr(anc[1]), ptr(scores), ptr(done), ptr(nfin), ptr(fscore), ptr(flen),
+             ptr(fhyp), cap, ptr(scratch), nbytes, int(bool(early_exit)), int(os.environ.get("CARE_RESIDENT_BLOCKS", "0")),
+             tag="decode_resident_beam")
+        self.last_decode = dict(clips=B, steps=scratch[8:12].view(torch.int32)[0], compactions=0, resident=True,
+                                row_steps=None)
+        return nfin, fscore, flen, fhyp
 
     def greedy_resident(self, mem: torch.Tensor, sem: Optional[torch.Tensor], sem_embs: Optional[torch.Tensor] = None,
                         steps: Optional[int] = None, early_exit: bool = True):
@@ -1158,24 +1239,7 @@ class HipEngine:
         akv = self.attr_kv(sem_embs, tag="r_akv") if self.attr_att else None
         fed = self.ws("r_fed", (B, T + 1), torch.int32)
         score, length, fin = self.ws("r_score", (B,)), self.ws("r_len", (B,), torch.int32), self.ws("r_fin", (B,), torch.int32)
-        layers = self._res_layers = (_lib.ResidentLayer * self.n_layers)()  # kept: bench.py re-issues the recorded call
-        for li in range(self.n_layers):
-            L, sa, ffn = layers[li], "d{}_sa".format(li), "d{}_ffn".format(li)
-            L.qkv_w, L.qkv_b, L.o_w, L.o_b = ptr(w[sa + "_qkv_w"]), ptr(w[sa + "_qkv_b"]), ptr(w[sa + "_o_w"]), ptr(w[sa + "_o_b"])
-            L.ln_g, L.ln_b = ptr(w[sa + "_g"]), ptr(w[sa + "_be"])
-            L.self_kv = ptr(self.ws("r_skv%d" % li, (B, T, 2 * d), torch.bfloat16))
-            blocks = [("d{}_ca".format(li), ckv[li], Lk, w["d{}_hb".format(li)])]
-            if self.attr_att:
-                blocks.append(("d{}_aa".format(li), akv[li], self.topk, None))
-            L.n_att = len(blocks)
-            for a, (nm, kv, nkeys, hb) in enumerate(blocks):
-                A = L.att[a]
-                A.q_w, A.q_b, A.o_w, A.o_b = ptr(w[nm + "_q_w"]), ptr(w[nm + "_q_b"]), ptr(w[nm + "_o_w"]), ptr(w[nm + "_o_b"])
-                A.ln_g, A.ln_b = ptr(w[nm + "_g"]), ptr(w[nm + "_be"])
-                A.kv, A.kv_batch_stride, A.nkeys, A.rows_per_kv = ptr(kv), nkeys * 2 * d, nkeys, 1
-                A.bias, A.bias_ld = ptr(hb), (hb.stride(0) if hb is not None else 0)
-            L.w1, L.b1, L.w2, L.b2 = ptr(w[ffn + "_w1"]), ptr(w[ffn + "_b1"]), ptr(w[ffn + "_w2"]), ptr(w[ffn + "_b2"])
-            L.ffn_g, L.ffn_b = ptr(w[ffn + "_g"]), ptr(w[ffn + "_be"])
+        layers = self._resident_layers("r_", B, 1, ckv, akv, Lk)
         nbytes = _lib.load().care_decode_resident_scratch(B, d, self.ff, self.V)
         scratch = self.ws("r_scratch", (nbytes,), torch.uint8)
         call("care_decode_resident", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem), 1,
@@ -1651,7 +1715,20 @@ class HipEngine:
         # beam search over a small batch: projected cross K/V (two launches less per step than the absorbed form, the
         # beams of a clip share its K/V rows in cache; *measured* 128 clips x 5: 5.97 -> 5.47 ms per pass)
         self._small_pass = self.small_forms(feats[0].shape[0])
-        if self.early_exit if early_exit is None else early_exit:
+        ee = self.early_exit if early_exit is None else early_exit
+        if self.resident_beam_ok(feats[0].shape[0], bm, need):  # encode + ONE resident launch for the whole search
+            def run_resident():
+                self._form_rows = feats[0].shape[0] * bm
+                enc = self.encode(feats, lean, static=True, small=True)
+                return (enc,) + tuple(self.beam_resident(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need,
+                                                         sem_embs=enc.get("semantic_embs"), early_exit=ee))
+            key = ("bres", bm, need, bool(lean), bool(ee), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+            out = self._replay(key, run_resident, use_graph)
+            nb = _lib.load().care_decode_resident_beam_scratch(feats[0].shape[0], bm, self.d, self.ff, self.V)
+            self.last_decode = dict(clips=feats[0].shape[0], steps=self.ws("rb_scratch", (nb,), torch.uint8)[8:12].view(torch.int32)[0],
+                                    compactions=0, resident=True, row_steps=None)
+            return out
+        if ee:
             return self.beam_early_exit(feats, bm, need, lean, use_graph)
 
         def run():

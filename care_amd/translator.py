@@ -51,12 +51,22 @@ class Translator_ARFormer(object):
                 return self._greedy(engine, feats, kwargs.get("use_graph", True))
             return self._beam(engine, feats, kwargs.get("use_graph", True))
 
+    _ABORTED = ("the resident decode timed out at a hand-off: its workgroups never became resident together (another "
+                "long-running kernel holds CUs?); set CARE_RESIDENT_MAX_ROWS=0 / CARE_RESIDENT_BEAM_MAX_ROWS=0")
+
     def _greedy(self, engine, feats, use_graph):
         _, fed, length, score = engine.translate_greedy(list(feats), use_graph=use_graph, lean=True)
         fed, length, score = fed.cpu(), length.cpu().tolist(), score.cpu()
-        if length and length[0] < 0:  # care_decode_resident gave up waiting for its workgroups (include/care_hip.h)
-            raise _lib.CareHipError("the resident decode timed out at a grid barrier: its workgroups never became resident "
-                                    "together (another long-running kernel holds CUs?); set CARE_RESIDENT_MAX_ROWS=0")
+        if length and min(length) < 0:  # care_decode_resident gave up waiting for its workgroups (include/care_hip.h)
+            # once more through the multi-launch decode, which needs no co-residency; raise only if that fails too
+            keep, engine.resident_max_rows = engine.resident_max_rows, 0
+            try:
+                _, fed, length, score = engine.translate_greedy(list(feats), use_graph=False, lean=True)
+                fed, length, score = fed.cpu(), length.cpu().tolist(), score.cpu()
+            finally:
+                engine.resident_max_rows = keep
+            if length and min(length) < 0:
+                raise _lib.CareHipError(self._ABORTED)
         hyps, scores = [], []
         n_best = self.topk
         for i, n in enumerate(length):
@@ -72,6 +82,15 @@ class Translator_ARFormer(object):
         _, nfin, fscore, flen, fhyp = engine.translate_beam(list(feats), self.beam_size, need, use_graph=use_graph,
                                                              lean=True)
         nfin, fscore, flen, fhyp = nfin.cpu().tolist(), fscore.cpu(), flen.cpu(), fhyp.cpu()
+        if nfin and min(nfin) < 0:  # care_decode_resident_beam aborted: the multi-launch search instead (see _greedy)
+            keep, engine.resident_beam_max_rows = engine.resident_beam_max_rows, 0
+            try:
+                _, nfin, fscore, flen, fhyp = engine.translate_beam(list(feats), self.beam_size, need, use_graph=False, lean=True)
+                nfin, fscore, flen, fhyp = nfin.cpu().tolist(), fscore.cpu(), flen.cpu(), fhyp.cpu()
+            finally:
+                engine.resident_beam_max_rows = keep
+            if nfin and min(nfin) < 0:
+                raise _lib.CareHipError(self._ABORTED)
         hyps, scores = [], []
         n_best = self.topk
         for i, nf in enumerate(nfin):

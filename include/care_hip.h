@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 16
+#define CARE_ABI_VERSION 17
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -566,12 +566,15 @@ int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, i
  *   scratch: care_decode_resident_scratch(rows, d, ff, V) bytes, 16-byte aligned.  blocks: workgroups (0 = as many as
  *   the widest phase has items, at most one per CU; every workgroup must be resident).
  *   Requires d == 512, heads == 8, ff in {512, 1024, 2048}, T <= 128, nkeys <= 128, n_layers <= 4, n_att <= 2.
- *   Every workgroup must be resident at the same time (they wait for one another): do not run two of these launches
- *   concurrently on different streams.  A workgroup that waits ~2 s for a phase's producers aborts the launch: length[0] = -1.
- *   Environment knobs read per call (tuning / tools / tests, never needed): CARE_RESIDENT_RB, CARE_RESIDENT_SMALL,
- *   CARE_RESIDENT_HALF_ROWS (forms of three phases), CARE_RESIDENT_PROF_STEP (phase clocks into the scratch),
- *   CARE_RESIDENT_TEST_GHOST (tests: phases that can never complete, for the watchdog).
- *   The one entry point that issues two operations: a 52-KB memset node (hand-off counters) and the kernel.
+ *   Every workgroup must be resident at the same time (they wait for one another): the grid is at most one workgroup
+ *   per CU and the entry point refuses (CARE_ESHAPE, nothing enqueued) unless hipOccupancyMaxActiveBlocksPerMultiprocessor
+ *   admits a workgroup of the kernel per CU; do not run two of these launches concurrently on different streams.  A
+ *   workgroup that waits ~2 s for a phase's producers aborts the launch: EVERY row's length = -1.
+ *   Tuning knobs, read from the environment ONCE per process: CARE_RESIDENT_RB, CARE_RESIDENT_SMALL,
+ *   CARE_RESIDENT_HALF_ROWS (forms of three phases), CARE_RESIDENT_BEAM_CFG (the beam launch's form).
+ *   care_decode_resident_debug(prof_step, ghost): tools / tests only - phase clocks of step `prof_step` into the scratch
+ *   (tools/resident_prof.py); ghost != 0: phases that can never complete (the watchdog test).  Process-wide, default 0 / 0.
+ *   The entry points that issue two operations: a 52-KB memset node (hand-off counters) and the kernel.
  */
 typedef struct care_resident_attn {
   const void* q_w; const float* q_b; const void* o_w; const float* o_b; const float* ln_g; const float* ln_b;
@@ -590,6 +593,34 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
                          const void* vocab_w, int V, int d, int heads, int ff, int act, int rows, int T, int steps,
                          int bos, int eos, int pad, int32_t* fed, int fed_stride, float* score, int32_t* length,
                          int32_t* finished, void* scratch, int64_t scratch_bytes, int early_exit, int blocks, void* stream);
+
+void care_decode_resident_debug(int prof_step, int ghost);
+
+/*
+ * care_decode_resident_beam: BEAM SEARCH over a small batch (clips x beam <= a few hundred rows) as ONE launch.
+ *   Replaces the step loop of Translator.translate_batch for beam_size > 1 (models/Translator.py:77-143 with
+ *   predict_word's log_softmax :127, Beam.advance misc/Decoding/Beam.py:45-85 incl. its quirks - first step row 0 only,
+ *   ended beams offer nothing, hypotheses collected in beam order until `need` = max(beam_size, topk) have ended, forced
+ *   finish at max_len - and the `no active instance` exit of Translator.py:77-81): translate.py's default decode (beam 5,
+ *   batch 128; --latency: batch 1).  Same machinery and rounding points as care_decode_resident; the vocabulary phase
+ *   keeps every row's best 4-column groups and the advance phase recomputes their logits bit for bit
+ *   (csrc/decode_resident_beam.hip), so the [rows, V] logits never exist.
+ *   layers as for care_decode_resident with self_kv bf16 [clips * beam, T, 2 d] and rows_per_kv = beam in every
+ *   attention block; sem (optional) fp32 [clips, d].
+ *   State and outputs (all initialised by the kernel), as care_beam_advance: tok / anc0 / anc1 int32 [clips * beam, stride
+ *   >= T + 1] (token table and the two ancestor tables), scores fp32 [clips * beam], done / nfin int32 [clips], fscore fp32 /
+ *   flen int32 [clips, fin_cap], fhyp int32 [clips, fin_cap, stride]; fin_cap >= need + beam.  Steps run:
+ *   ((int32_t*)scratch)[2].  Aborted launch (see care_decode_resident): EVERY nfin = -1.
+ *   Requires d == 512, heads == 8, ff in {512, 1024, 2048}, T <= 63, beam <= 5, V <= 16384.
+ *   scratch: care_decode_resident_beam_scratch(clips, beam, d, ff, V) bytes, 16-byte aligned.
+ */
+int64_t care_decode_resident_beam_scratch(int clips, int beam, int d, int ff, int V);
+int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, const float* word, const float* pos,
+                              const float* sem, const float* emb_g, const float* emb_b, float eps, const void* vocab_w,
+                              int V, int d, int heads, int ff, int act, int clips, int beam, int need, int T, int steps,
+                              int bos, int eos, int pad, int32_t* tok, int stride, int32_t* anc0, int32_t* anc1,
+                              float* scores, int32_t* done, int32_t* nfin, float* fscore, int32_t* flen, int32_t* fhyp,
+                              int fin_cap, void* scratch, int64_t scratch_bytes, int early_exit, int blocks, void* stream);
 
 /* care_timestamp: out[0] (uint64) = the device wall clock (constant 100 MHz) when the one-thread kernel runs.
  *   Measurement only (bench.py: the duration of a kernel inside a replayed hipGraph); no reference counterpart. */

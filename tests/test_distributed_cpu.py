@@ -143,3 +143,37 @@ def test_sharded_metrics_step_gathers_concept_probabilities(tmp_path, n_clips):
     ref_hyps, _ = g.hyps()
     for i in range(n_clips):
         assert got[0]["fed"][i, 1: int(got[0]["len"][i]) + 1].tolist() == ref_hyps[i][0]
+
+
+def _bench(*args, timeout=300):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(args), env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks_dry():
+    """`python bench.py --gpus 2` (no torchrun around it) starts torch.distributed.run as a child, one process per
+    rank; in --dry-run the ranks form a gloo group, push synthetic records through care_amd.sharding's pack /
+    all-gather / unpack and rank 0's JSON line comes back through the launcher with the child's exit code."""
+    import json
+
+    out = _bench("--gpus", "2", "--dry-run", "--steps", "2")
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1]
+    assert line["records_gathered"] == 128 and line["exchange_ok"]
+
+
+def test_bench_refuses_more_gpus_than_the_host_has():
+    """The plain command on a host with fewer GPUs than asked for: a clear message and a non-zero exit code, before
+    anything is launched."""
+    import torch
+
+    want = torch.cuda.device_count() + 2
+    out = _bench("--gpus", str(want), "--steps", "1", timeout=120)
+    assert out.returncode != 0
+    assert "--gpus {}".format(want) in out.stderr and "visible" in out.stderr

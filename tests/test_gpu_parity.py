@@ -185,10 +185,10 @@ def test_greedy_bf16_matches_up_to_near_ties(golden, form):
     eng = model.engine()
     absorbed = form == "absorbed"
     if absorbed and not eng.latent_capable:
-        pytest.skip("absorbed cross-attention covers d_model = 512 only")
+        pytest.skip("the absorbed cross-attention needs bf16 mode and a d_model of 512 / 768 / 1024")
     if form == "resident":
         if not eng.resident_ok(feats[0].shape[0]):
-            pytest.skip("resident decode covers d_model = 512 in bf16 mode")
+            pytest.skip("the resident decode covers d_model = 512 in bf16 mode")
     else:
         eng.resident_max_rows = 0
         eng.latent = absorbed  # the default is the absorbed form wherever the model allows it, at every batch size
@@ -216,7 +216,7 @@ BEAM_SCORE_TOL = 2e-2   # length-normalised log-prob: bf16 noise on a hypothesis
 BEAM_TIE_TOL = 2e-2     # how close two hypotheses / a pruning decision must be to count as a tie
 
 
-@pytest.mark.parametrize("form", ["projected", "absorbed", "small"])
+@pytest.mark.parametrize("form", ["projected", "absorbed", "small", "resident"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_beam_bf16_vs_oracle(golden, form, use_graph):
     """bf16 beam search (fused two-pass selection, device beam state) vs the reference, per clip:
@@ -227,8 +227,10 @@ def test_beam_bf16_vs_oracle(golden, form, use_graph):
         (fixture `gap_best_slack`), or its final lead over the runner-up was that small (`gap_rank`);
       * a clip with clear margins everywhere (the `peaked` fixture) must be bit-exact.
     use_graph: the hipGraph-captured pass (third call on the same buffers replays) vs eager.
-    form: the cross-attention of the large-batch pass, projected or absorbed, with its fused embedder; `small`: what
-    the engine runs by default for a batch this small (engine.small_forms: unfused embedder, projected K/V)."""
+    form: the cross-attention of the large-batch pass, projected or absorbed, with its fused embedder; `small`: the
+    multi-launch search with the small-batch forms (engine.small_forms: unfused embedder, projected K/V); `resident`:
+    what the engine runs by default for a batch this small - the whole search as ONE launch
+    (csrc/decode_resident_beam.hip: group lists in the vocabulary phase, recomputed candidate logits, Beam.advance)."""
     from care_amd import get_translator
     from oracle import care_cpu
 
@@ -239,11 +241,17 @@ def test_beam_bf16_vs_oracle(golden, form, use_graph):
     eng = model.engine()
     absorbed = form == "absorbed"
     if absorbed and not eng.latent_capable:
-        pytest.skip("absorbed cross-attention covers d_model = 512 only")
-    if form == "small":
+        pytest.skip("the absorbed cross-attention needs bf16 mode and a d_model of 512 / 768 / 1024")
+    bm, need = int(opt["beam_size"]), max(int(opt["beam_size"]), int(opt.get("topk", 1)))
+    if form == "resident":
+        if not eng.resident_beam_ok(feats[0].shape[0], bm, need):
+            pytest.skip("the resident beam search covers d_model = 512 in bf16 mode, beam_size <= 5")
+    elif form == "small":
+        eng.resident_beam_max_rows = 0
         if not eng.small_forms(feats[0].shape[0]):
             pytest.skip("the small-batch forms cover d_model = 512 in bf16 mode")
     else:
+        eng.resident_beam_max_rows = 0
         eng.resident_max_rows = 0
         eng.latent = absorbed
     # the per-row top-k: two passes of the vocabulary GEMM (what large batches use) in the graph variant,
@@ -253,8 +261,10 @@ def test_beam_bf16_vs_oracle(golden, form, use_graph):
     tr = get_translator(opt)
     for _ in range(3 if use_graph else 1):  # first sight (eager), capture, replay
         hyps, scores = tr.translate_batch([model], {"feats": dev}, use_graph=use_graph)
+    if form == "resident":
+        assert eng.last_decode.get("resident") and 1 <= int(eng.last_decode["steps"]) <= eng.T
     if use_graph:
-        assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] in ("beam", "bseg0")), "beam pass was not captured"
+        assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] in ("beam", "bseg0", "bres")), "beam pass was not captured"
     ref_hyps, ref_scores = golden.hyps()
     z = golden.z
     enc = care_cpu.encoding_phase(P, opt, feats)
@@ -352,6 +362,8 @@ def test_bench_under_torchrun_with_rccl():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    d = line["distributed"]  # the N > 1 report: who took part, what each rank did, what the exchange costs
+    assert d["rccl_ranks_seen"] == [0] and d["per_rank_captions_per_s"][0] > 0 and d["all_gather_us"] > 0
 
 
 def test_teacher_forced_fast_path_bf16(golden):

@@ -156,26 +156,36 @@ def test_resident_entry_point_rejects_what_it_does_not_cover():
 
 
 def test_resident_barrier_watchdog_aborts_instead_of_hanging():
-    """A grid that cannot meet at its barriers must give up, not hang: simulated by a counter state in which one more
-    workgroup than exists would have to arrive (the launch zeroes the counters itself, so the kernel is started
-    through the tuning knob that makes it expect workgroups that are not there)."""
-    import os
-
-    from care_amd import _lib
-    from care_amd.translator import Translator_ARFormer
+    """A grid that cannot meet at its hand-offs must give up, not hang: simulated by a counter state in which more
+    workgroups than exist would have to arrive (care_decode_resident_debug(0, 1): the kernel expects producers that are
+    not there).  Every row's length reads -1 - no caller can mistake a re-used workspace's old rows for results - and
+    the Translator decodes the batch once more through the multi-launch path instead of failing; the same for beam
+    search (every clip's count of finished hypotheses = -1)."""
+    from care_amd import _lib, get_translator
 
     boost = {"cls_head.tgt_word_prj.weight": {3: 6.0}}
-    opt, P, model, feats = _setup("msrvtt_base_ami", 2, "bf16", boost=boost)
+    opt, P, model, feats = _setup("msrvtt_base_ami", 5, "bf16", boost=boost)
     eng = model.engine()
-    eng.resident_max_rows = 128
-    os.environ["CARE_RESIDENT_TEST_GHOST"] = "1"  # the kernel counts one ghost workgroup into every barrier
+    eng.resident_max_rows = eng.resident_beam_max_rows = 0   # what the multi-launch path gives
+    want = get_translator(opt).translate_batch([model], {"feats": feats}, use_graph=False)
+    opt5 = dict(opt, beam_size=5)
+    want5 = get_translator(opt5).translate_batch([model], {"feats": feats}, use_graph=False)
+    eng.resident_max_rows, eng.resident_beam_max_rows = 128, 640
+    _lib.load().care_decode_resident_debug(0, 1)
     try:
         _, fed, length, score = eng.translate_greedy(feats, use_graph=False, lean=True)
         torch.cuda.synchronize()
-        assert int(length[0]) == -1 and int(eng.last_decode["steps"]) == -1
-        with pytest.raises(_lib.CareHipError):
-            Translator_ARFormer(opt)._greedy(eng, feats, False)
+        assert length.tolist() == [-1] * 5 and int(eng.last_decode["steps"]) == -1
+        got = get_translator(opt).translate_batch([model], {"feats": feats}, use_graph=False)
+        assert got[0] == want[0]
+        _, nfin, _, _, _ = eng.translate_beam(feats, 5, 5, use_graph=False, lean=True)
+        torch.cuda.synchronize()
+        assert nfin.tolist() == [-1] * 5 and int(eng.last_decode["steps"]) == -1
+        got5 = get_translator(opt5).translate_batch([model], {"feats": feats}, use_graph=False)
+        assert got5[0] == want5[0]
     finally:
-        del os.environ["CARE_RESIDENT_TEST_GHOST"]
+        _lib.load().care_decode_resident_debug(0, 0)
     _, fed, length, score = eng.translate_greedy(feats, use_graph=False, lean=True)
     assert int(length.min()) >= 1
+    _, nfin, _, _, _ = eng.translate_beam(feats, 5, 5, use_graph=False, lean=True)
+    assert int(nfin.min()) >= 1 and eng.last_decode.get("resident")

@@ -1,0 +1,134 @@
+"""GPU: beam search over a small batch as ONE resident launch (csrc/decode_resident_beam.hip, care_decode_resident_beam:
+the step loop of Translator.translate_batch with Beam.advance, models/Translator.py:77-143, misc/Decoding/Beam.py:45-85)
+against the multi-launch search of the same mode, the CPU oracle, and its own invariants.  The golden beam fixtures run
+through it in tests/test_gpu_parity.py (form `resident`)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_properties import PEAKED_ROWS, _setup  # noqa: E402
+
+
+def _beam(eng, feats, bm=5, need=5, **kw):
+    _, nfin, fscore, flen, fhyp = eng.translate_beam(feats, bm, need, lean=True, **kw)
+    return nfin.clone(), fscore.clone(), flen.clone(), fhyp.clone()
+
+
+def _best(nfin, fscore, flen, fhyp, i):
+    """(tokens, length-normalised score) of clip i's best finished hypothesis (Beam.sort_finished: stable, best first)."""
+    items = [(float(fscore[i, j]) / int(flen[i, j]), -j) for j in range(int(nfin[i]))]
+    s, j = max(items)
+    j = -j
+    return fhyp[i, j, : int(flen[i, j])].tolist(), s
+
+
+# rows = clips x 5: one row tile (5, 15), the K-split forms (60), one row tile per workgroup (65, 255), several row
+# tiles per workgroup and weight fetch (260, 640 = translate.py's default batch)
+@pytest.mark.parametrize("config,B", [("msrvtt_care", 1), ("msrvtt_base_ami", 3), ("msrvtt_care", 12), ("msrvtt_cabase", 13),
+                                      ("msrvtt_base_ami", 51), ("msrvtt_care", 52), ("msrvtt_care", 128), ("msvd_base_i", 128)])
+def test_resident_beam_against_multi_launch_and_oracle(config, B):
+    """Peaked (trained-like) logits: the resident search and the multi-launch search (projected cross K/V: the same
+    rounding points) must report the same winner wherever the oracle's search is decided by clear margins, and nearly
+    always otherwise; a sample of clips is audited against the oracle (its winner, or a near-tie under exact scoring)."""
+    from oracle import care_cpu
+    from test_gpu_parity import BEAM_TIE_TOL, BF16_LSE_PEAKED, CLEAR_MARGIN
+
+    opt, P, model, feats = _setup(config, B, "bf16", seed=189, boost=PEAKED_ROWS)
+    opt = dict(opt, beam_size=5)
+    eng = model.engine()
+    eng.resident_max_rows = 256  # (the small-batch forms of the encode for both searches)
+    eng.resident_beam_max_rows = 0
+    ml = _beam(eng, feats, use_graph=False)
+    assert not eng.last_decode.get("resident")
+    eng.resident_beam_max_rows = 640
+    assert eng.resident_beam_ok(B, 5, 5)
+    rs = _beam(eng, feats, use_graph=False)
+    assert eng.last_decode.get("resident") and 1 <= int(eng.last_decode["steps"]) <= eng.T
+    assert int(rs[0].min()) >= 1 and int(rs[0].max()) <= 10
+    same = 0
+    for i in range(B):
+        (ha, sa), (hb, sb) = _best(*rs, i), _best(*ml, i)
+        if ha == hb:
+            same += 1
+            assert abs(sa - sb) < 2e-2
+    assert same >= B - max(1, B // 16), "{} of {} winners differ between the two forms".format(B - same, B)
+    idx = sorted(set(int(i) for i in torch.linspace(0, B - 1, min(B, 8)).round().tolist()))
+    sample = [f[idx].cpu() for f in feats]
+    hyps, scores, gaps = care_cpu.translate_batch(P, opt, sample, return_gaps=True)
+    inputs = care_cpu.inputs_for_decoder(opt, care_cpu.encoding_phase(P, opt, sample))
+    for j, i in enumerate(idx):
+        h, s = _best(*rs, i)
+        one = {k: v[j:j + 1] for k, v in inputs.items()}
+        exact = care_cpu.score_hypothesis(P, opt, one, h)
+        assert abs(s - exact) < BF16_LSE_PEAKED, (i, s, exact)
+        r = hyps[j][0]
+        if gaps[j]["best_slack"] >= CLEAR_MARGIN and gaps[j]["rank"] >= 0.05:
+            assert h == r, "clip {}: clear reference margins but the resident winner differs".format(i)
+        if h != r:
+            assert (abs(exact - scores[j][0]) < BEAM_TIE_TOL or gaps[j]["best_slack"] < BEAM_TIE_TOL or
+                    gaps[j]["rank"] < BEAM_TIE_TOL), (i, h, exact, r, scores[j][0])
+
+
+@pytest.mark.parametrize("config,B", [("msrvtt_care", 30), ("msrvtt_base_ami", 100)])
+def test_resident_beam_is_deterministic_replayable_and_batch_independent(config, B):
+    """Run after run, eager or replayed from the captured graph: identical finished lists; a clip's hypotheses do not
+    depend on the batch it rides in (alone, in a chunk, in the full batch - across the forms the launch takes by row
+    count; scores move with the merge order of the log-sum-exp partials: 1e-4); early exit == all 29 steps."""
+    boost = {"cls_head.tgt_word_prj.weight": {3: 14.0, 0: 3.0}}  # clips finish at mixed steps, generated PADs
+    opt, P, model, feats = _setup(config, B, "bf16", boost=boost)
+    eng = model.engine()
+    eng.resident_max_rows = 256
+    full = _beam(eng, feats, use_graph=False)
+    assert eng.last_decode.get("resident")
+    steps = int(eng.last_decode["steps"])
+    assert int(full[0].min()) >= 1
+    for it in range(3):  # first sight, capture, replay
+        again = _beam(eng, feats, use_graph=True)
+        for a, b in zip(full, again):
+            assert torch.equal(a, b)
+    assert any(isinstance(v, tuple) for k, v in eng._graphs.items() if k[0] == "bres"), "pass was not captured"
+    fixed = _beam(eng, feats, use_graph=False, early_exit=False)
+    assert int(eng.last_decode["steps"]) == eng.T and steps <= eng.T
+    for a, b in zip(full, fixed):
+        assert torch.equal(a, b)
+    for lo, n in ((0, 1), (3, 12), (B - 7, 7), (B // 2, 13)):
+        sub = [f[lo:lo + n].contiguous() for f in feats]
+        part = _beam(eng, sub, use_graph=False)
+        assert torch.equal(part[0], full[0][lo:lo + n])
+        for i in range(n):
+            k = int(part[0][i])
+            assert torch.equal(part[2][i, :k], full[2][lo + i, :k])
+            assert torch.equal(part[3][i, :k], full[3][lo + i, :k])
+            assert (part[1][i, :k] - full[1][lo + i, :k]).abs().max().item() < 2e-4
+
+
+def test_resident_beam_covers_topk_above_beam_size_and_small_beams():
+    """need = max(beam_size, topk) > beam_size (a clip keeps searching until `need` hypotheses have ended, Beam.py:10)
+    and beam sizes below 5: the same finished lists as the multi-launch search on a peaked model."""
+    opt, P, model, feats = _setup("msrvtt_care", 9, "bf16", seed=189, boost=PEAKED_ROWS)
+    eng = model.engine()
+    eng.resident_max_rows = 256
+    for bm, need in ((5, 8), (2, 2), (3, 4), (4, 4)):
+        eng.resident_beam_max_rows = 0
+        ml = _beam(eng, feats, bm, need, use_graph=False)
+        eng.resident_beam_max_rows = 640
+        rs = _beam(eng, feats, bm, need, use_graph=False)
+        assert eng.last_decode.get("resident")
+        assert torch.equal(rs[0], ml[0]), (bm, need, rs[0].tolist(), ml[0].tolist())
+        same = sum(_best(*rs, i)[0] == _best(*ml, i)[0] for i in range(9))
+        assert same >= 8, (bm, need, same)
+
+
+def test_resident_beam_shape_rules():
+    """care_decode_resident_beam rejects what the resident form does not cover; the engine then keeps the multi-launch search."""
+    from care_amd.configs import make_opt
+    from care_amd.engine import HipEngine
+
+    e = HipEngine(make_opt("msrvtt_care"), "bf16")
+    assert e.resident_beam_ok(128, 5, 5) and e.resident_beam_ok(1, 5, 8) and e.resident_beam_ok(1, 2, 2)
+    assert not e.resident_beam_ok(129, 5, 5) and not e.resident_beam_ok(8, 6, 6) and not e.resident_beam_ok(8, 1, 1)
+    e.resident_beam_max_rows = 0
+    assert not e.resident_beam_ok(1, 5, 5)
+    for cfg, dtype in (("msrvtt_care", "fp32"), ("vatex_care_large", "bf16")):
+        assert not HipEngine(make_opt(cfg), dtype).resident_beam_ok(8, 5, 5)

@@ -100,7 +100,7 @@ def test_abi_library_exports_every_declared_symbol():
 
     build.build()
     header = open(os.path.join(ROOT, "include", "care_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(care_\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|void|const char\*)\s+(care_\w+)\s*\(", header, re.M))
     assert len(declared) >= 18
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
@@ -121,6 +121,9 @@ def test_abi_library_exports_every_declared_symbol():
                      _lib.ResidentAttn.bias.offset]
     assert loaded.care_decode_resident_scratch(1, 512, 2048, 10547) == 53248 + 16 * (512 * 18 + 2048 * 2 + 165 * 12)
     assert loaded.care_decode_resident_scratch(0, 512, 2048, 10547) < 0
+    # ... and of the beam launch: + the group lists [rows16, parts, 5] x (value, group) and the bf16 hidden rows
+    assert loaded.care_decode_resident_beam_scratch(3, 5, 512, 2048, 10547) == 53248 + 16 * (512 * 18 + 2048 * 2 + 165 * 12 + 165 * 40 + 1024)
+    assert loaded.care_decode_resident_beam_scratch(0, 5, 512, 2048, 10547) < 0
     assert loaded.care_version() == int(re.search(r"#define CARE_ABI_VERSION (\d+)", header).group(1))
     assert loaded.care_arch() == b"gfx950"
     assert loaded.care_argmax_parts(10547) == 166

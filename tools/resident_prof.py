@@ -1,9 +1,11 @@
-"""Phase clocks of one step of the resident decode (csrc/decode_resident.hip; CARE_RESIDENT_PROF_STEP): per phase the
-time workgroup 0 spent working (wait returned -> arrive) and the time from its arrive to the next phase's start."""
+"""Phase clocks of one step of the resident decode (csrc/decode_resident.hip; care_decode_resident_debug): per phase the
+time workgroup 0 spent working (wait returned -> arrive) and the time from its arrive to the next phase's start.
+
+    python tools/resident_prof.py [--beam BM] [--config NAME] B [B ...]
+"""
 import os
 import sys
 
-os.environ.setdefault("CARE_RESIDENT_PROF_STEP", "3")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
@@ -11,29 +13,51 @@ from care_amd import _lib, get_framework
 from care_amd.configs import feat_shapes, make_opt
 from care_amd.synth import synth_state_dict
 
+argv = sys.argv[1:]
+bm, config = 1, "msrvtt_base_ami"
+while argv and argv[0].startswith("--"):
+    if argv[0] == "--beam":
+        bm = int(argv[1])
+    elif argv[0] == "--config":
+        config = argv[1]
+    argv = argv[2:]
 dev = torch.device("cuda:0")
-opt = make_opt("msrvtt_base_ami")
+opt = make_opt(config)
 model = get_framework(opt).eval()
 model.load_state_dict(synth_state_dict(0, [(k, tuple(v.shape)) for k, v in model.state_dict().items()]), strict=True)
 model.set_compute_dtype("bf16")
 model.to(dev)
 eng = model.engine()
-names = ["qkv", "self_attn", "dense1", "q2", "cross_attn", "dense2", "ffn1", "ffn2", "vocab"]
-for B in [int(a) for a in sys.argv[1:]] or [1, 128]:
+_lib.load().care_decode_resident_debug(int(os.environ.get("CARE_RESIDENT_PROF_STEP", "3")), 0)
+names = ["qkv", "self_attn", "dense1"]
+for a in range(2 if eng.attr_att else 1):
+    names += ["q%d" % (a + 2), "static_attn%d" % a, "dense%d" % (a + 2)]
+names += ["ffn1", "ffn2", "vocab"] + (["advance"] if bm > 1 else [])
+for B in [int(a) for a in argv] or [1, 128]:
     gen = torch.Generator(device=dev)
     gen.manual_seed(5)
     feats = [torch.randn(s, generator=gen, device=dev) for s in feat_shapes(opt, B)]
+    run = (lambda: eng.translate_beam(feats, bm, bm, use_graph=False, lean=True)) if bm > 1 else \
+          (lambda: eng.translate_greedy(feats, use_graph=False, lean=True))
     for _ in range(3):
-        eng.translate_greedy(feats, use_graph=False, lean=True)
+        run()
     torch.cuda.synchronize()
-    nb = _lib.load().care_decode_resident_scratch(B, eng.d, eng.ff, eng.V)
-    sc = eng.ws("r_scratch", (nb,), torch.uint8)
-    t = sc[2048:2048 + 8 * (2 * len(names) + 2)].view(torch.int64).cpu().tolist()
-    vt = t[-4:]
-    t = t[:-4] + [t[-4], t[-1]]
+    assert eng.last_decode.get("resident"), "this batch does not take the resident form"
+    if bm > 1:
+        nb = _lib.load().care_decode_resident_beam_scratch(B, bm, eng.d, eng.ff, eng.V)
+        sc = eng.ws("rb_scratch", (nb,), torch.uint8)
+    else:
+        nb = _lib.load().care_decode_resident_scratch(B, eng.d, eng.ff, eng.V)
+        sc = eng.ws("r_scratch", (nb,), torch.uint8)
+    # per phase (begin, end), the vocabulary phase with two marks more (A rows done, items done)
+    nmarks = 2 * len(names) + 2
+    t = sc[2048:2048 + 8 * nmarks].view(torch.int64).cpu().tolist()
+    iv = 2 * names.index("vocab")
+    vt = t[iv:iv + 4]
+    t = t[:iv] + [vt[0], vt[3]] + t[iv + 4:]
+    print(flush=True); print("B = %d%s: step total %.2f us" % (B, " x beam %d" % bm if bm > 1 else "", (t[-1] - t[0]) / 100.0))
     print("  vocab: A rows %.2f us, items %.2f us, merge + store %.2f us" % ((vt[1] - vt[0]) / 100.0, (vt[2] - vt[1]) / 100.0, (vt[3] - vt[2]) / 100.0))
-    print(flush=True); print("B = %d: step total %.2f us" % (B, (t[-1] - t[0]) / 100.0))
     for i, n in enumerate(names):
         work = (t[2 * i + 1] - t[2 * i]) / 100.0
         gap = (t[2 * i + 2] - t[2 * i + 1]) / 100.0 if 2 * i + 2 < len(t) else float("nan")
-        print("  %-10s work %6.2f us   barrier+prefetch %6.2f us" % (n, work, gap))
+        print("  %-13s work %6.2f us   hand-off + prefetch %6.2f us" % (n, work, gap))
