@@ -34,6 +34,7 @@ struct RArgs {
   int bm, nclips, need, fin_cap;
   int32_t* anc[2]; int32_t* done; int32_t* nfin; float* fscore; int32_t* flen; int32_t* fhyp;
   float* gval; int32_t* ggid;  // per (row, vocabulary part): the RES_BMK best 4-column groups (maximum, group number)
+  int vcap;                    // workgroups of the vocabulary phase (PhaseMap gcap): parts <= 48
   bf16_t* hn;                  // the normalised last hidden rows (bf16 [R16, 512]): the B operand of the recomputed logits
 };
 
@@ -60,20 +61,27 @@ __device__ __forceinline__ float4 cld_f4(const float* p) {
   U2 u{cld8(p), cld8(p + 2)};
   return __builtin_bit_cast(float4, u);
 }
-__device__ __forceinline__ void cst_f4(float* p, float4 v) {
+// 16-byte write-through stores: ONE global_store_dwordx4 sc1 (an 8-byte agent-scope atomic store is the widest the
+// compiler spells; two of them per 16 bytes are twice the instructions and, per MI355X_MICROARCH.md, 2.7 x the time per
+// byte).  Inline asm: the compiler does not count it in its vmcnt bookkeeping - its own waits then wait for more, never
+// for less (vmcnt retires in order) - and GridSync::arrive drains vmcnt(0) before it signals.
+__device__ __forceinline__ void cst16(void* p, f32x4 v) {
+#ifdef RES_NO_ST16
   const U2 u = __builtin_bit_cast(U2, v);
   cst8(p, u.a);
-  cst8(p + 2, u.b);
+  cst8(reinterpret_cast<unsigned long long*>(p) + 1, u.b);
+#else
+  // (the s_nop: a VMEM store of more than 64 bits must not be followed directly by a write of its data registers - a
+  // hazard the compiler resolves for its own stores and cannot see inside an asm statement; without it rows came out wrong)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
 }
+__device__ __forceinline__ void cst_f4(float* p, float4 v) { cst16(p, f32x4{v.x, v.y, v.z, v.w}); }
 __device__ __forceinline__ bf16x8 cld_b8(const bf16_t* p) {
   U2 u{cld8(p), cld8(p + 4)};
   return __builtin_bit_cast(bf16x8, u);
 }
-__device__ __forceinline__ void cst_b8(bf16_t* p, bf16x8 v) {
-  const U2 u = __builtin_bit_cast(U2, v);
-  cst8(p, u.a);
-  cst8(p + 4, u.b);
-}
+__device__ __forceinline__ void cst_b8(bf16_t* p, bf16x8 v) { cst16(p, __builtin_bit_cast(f32x4, v)); }
 __device__ __forceinline__ void cst_b4(bf16_t* p, bf16x4 v) { cst8(p, __builtin_bit_cast(unsigned long long, v)); }
 
 // Synchronisation between phases: producer-counted hand-offs instead of full grid barriers.  Only the workgroups that
@@ -179,6 +187,19 @@ struct GridSync {
 __device__ __forceinline__ float res_act(float v, int act) {
   if (act == CARE_ACT_RELU) return fmaxf(v, 0.0f);
   if (act == CARE_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+
+// exp on the hardware's exp2 (v_exp_f32, ~1 ulp): the sum-exp of the vocabulary phase and the softmax weights of the
+// attention phases, whose accurate expf was a third of their vector instructions; arguments are <= 0 there, exp(-inf) = 0.
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+// sum over the 16 lanes of a DPP row, in every lane: lane ^ 1, lane ^ 2, the mirrored lane of the 8-lane half, of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += care_dpp<0xB1>(v);
+  v += care_dpp<0x4E>(v);
+  v += care_dpp<0x141>(v);
+  v += care_dpp<0x140>(v);
   return v;
 }
 
@@ -358,102 +379,115 @@ __device__ __forceinline__ void beam_init_rows4(const RArgs& p, int rb, int lane
     }
 }
 
-// 16 rows of the A operand -> LDS (bf16 [16][lda]), d = 512.  A_EMBED / A_LN: a wave owns 4 rows, a lane 2 float4 of
-// each; the rows stay in registers between the statistics and the normalisation (rowops.hip row_layernorm), all
-// loads of the 4 rows issued together: fetch_a_rows requests them ...
+// 16 rows of the A operand -> LDS (bf16 [16][lda]), d = 512.  A_EMBED / A_LN: a wave owns 4 rows SIDE BY SIDE - the 16
+// lanes of DPP row q take row 4 wave + q, lane `sub` its columns 4 sub + 64 k (k < 8: 256 contiguous bytes per row
+// and load instruction) - so the two LayerNorm statistics of the four rows are ONE pair of 4-step DPP reductions
+// (row16_sum) instead of eight 7-step wave reductions in series: the A stage was most of the time of every GEMM phase
+// (*measured*, tools/resident_prof.py: 8.0 of 9.2 us in the QKV phase at 128 rows, 16.9 of 21.2 at 640 rows).
+// All loads of the rows are issued together: fetch_a_rows requests them ...
+// The token this lane's row (r0 + 4 wave + lane / 16) feeds at step t.  Requested for EVERY row tile of the workgroup
+// before the first word row is fetched (gemm_phase): the word row depends on the token, vmcnt retires in issue order, so
+// token -> word row per tile in turn is two memory round trips PER TILE in series (*measured* 640 rows, 4 tiles per
+// workgroup: 19.8 us of the QKV phase).
 template <int AMODE>
-__device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, bool writer, const float* ysrc, const float* ysrc2,
-                                             float4 (&v)[4][2]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int d = 512;
-  const int rb = r0 + wave * 4;
-  if constexpr (AMODE == A_EMBED || AMODE == A_EMBEDB) {
-    int tok[4] = {p.bos, p.bos, p.bos, p.bos};
-    if constexpr (AMODE == A_EMBED) {
-      if (writer) advance_state4(p, rb, t, lane, tok);
-      else if (t > 1) select4<false>(p, rb, t - 1, lane, tok);
-    } else {  // beam search: beam_advance_phase wrote the token of slot r at position t - 1 (tokphys[r][t - 1], beam.hip)
-      if (t > 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tok[i] = cld_i(p.fed + (int64_t)(rb + i < p.R ? rb + i : 0) * p.fed_stride + (t - 1));
-      } else if (writer) {
-        beam_init_rows4(p, rb, lane);
-      }
+__device__ __forceinline__ int fetch_token(const RArgs& p, int r0, int t, bool writer) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
+  const int rb = r0 + wave * 4, row = rb + q;
+  int tok[4] = {p.bos, p.bos, p.bos, p.bos};
+  if constexpr (AMODE == A_EMBED) {
+    if (writer) advance_state4(p, rb, t, lane, tok);
+    else if (t > 1) select4<false>(p, rb, t - 1, lane, tok);
+    return row < p.R ? (q == 0 ? tok[0] : q == 1 ? tok[1] : q == 2 ? tok[2] : tok[3]) : 0;
+  } else {  // beam search: beam_advance_phase wrote the token of slot r at position t - 1 (tokphys[r][t - 1], beam.hip)
+    if (t == 1) {
+      if (writer) beam_init_rows4(p, rb, lane);
+      return row < p.R ? p.bos : 0;
     }
-    const float* pp = p.pos + (int64_t)(t - 1) * d;
-    const float4 p0 = *reinterpret_cast<const float4*>(pp + lane * 4), p1 = *reinterpret_cast<const float4*>(pp + 256 + lane * 4);
+    const int tk = cld_i(p.fed + (int64_t)(row < p.R ? row : 0) * p.fed_stride + (t - 1));
+    return row < p.R ? tk : 0;
+  }
+}
+
+template <int AMODE>
+__device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, int mytok, const float* ysrc, const float* ysrc2,
+                                             float4 (&v)[8]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, sub = lane & 15;
+  constexpr int d = 512;
+  const int rb = r0 + wave * 4, row = rb + q, rc = row < p.R ? row : 0;
+  if constexpr (AMODE == A_EMBED || AMODE == A_EMBEDB) {
+    const float* pp = p.pos + (int64_t)(t - 1) * d + sub * 4;
+    const float* w = p.word + (int64_t)mytok * d + sub * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = rb + i < p.R ? rb + i : 0;
-      const float* w = p.word + (int64_t)(rb + i < p.R ? tok[i] : 0) * d;
-      v[i][0] = *reinterpret_cast<const float4*>(w + lane * 4);
-      v[i][1] = *reinterpret_cast<const float4*>(w + 256 + lane * 4);
-      add4(v[i][0], p0);
-      add4(v[i][1], p1);
-      if (p.sem) {
-        const float* sm = p.sem + (int64_t)(r / p.sem_div) * d;
-        add4(v[i][0], *reinterpret_cast<const float4*>(sm + lane * 4));
-        add4(v[i][1], *reinterpret_cast<const float4*>(sm + 256 + lane * 4));
-      }
+    for (int k = 0; k < 8; ++k) {
+      v[k] = *reinterpret_cast<const float4*>(w + 64 * k);
+      add4(v[k], *reinterpret_cast<const float4*>(pp + 64 * k));
+    }
+    if (p.sem) {
+      const float* sm = p.sem + (int64_t)(rc / p.sem_div) * d + sub * 4;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) add4(v[k], *reinterpret_cast<const float4*>(sm + 64 * k));
     }
   } else {
+    const float* y = ysrc + (int64_t)rc * d + sub * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = rb + i < p.R ? rb + i : 0;
-      v[i][0] = cld_f4(ysrc + (int64_t)r * d + lane * 4);
-      v[i][1] = cld_f4(ysrc + (int64_t)r * d + 256 + lane * 4);
-    }
+    for (int k = 0; k < 8; ++k) v[k] = cld_f4(y + 64 * k);
     if (ysrc2) {  // the second K half of a two-workgroup FFN dense2 (ffn2_phase<true>): y = y + y2
+      const float* y2 = ysrc2 + (int64_t)rc * d + sub * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = rb + i < p.R ? rb + i : 0;
-        add4(v[i][0], cld_f4(ysrc2 + (int64_t)r * d + lane * 4));
-        add4(v[i][1], cld_f4(ysrc2 + (int64_t)r * d + 256 + lane * 4));
-      }
+      for (int k = 0; k < 8; ++k) add4(v[k], cld_f4(y2 + 64 * k));
     }
   }
 }
 
-// ... and their LayerNorm into the LDS tile (+ the fp32 rows for the residual when write_x)
-__device__ __forceinline__ void finish_a_rows(const RArgs& p, int r0, const float4 (&v)[4][2], const float* g, const float* be,
-                                              bool write_x, bf16_t* sA, int lda, bool write_hn = false) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ... and their LayerNorm into the LDS tile (+ the fp32 rows for the residual when write_x, + the bf16 rows when write_hn)
+struct LnGB { float4 g[8], b[8]; };  // this lane's columns of the LayerNorm weight / bias
+__device__ __forceinline__ void load_gb(LnGB& w, const float* g, const float* be) {
+  const int sub = threadIdx.x & 15;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    w.g[k] = *reinterpret_cast<const float4*>(g + sub * 4 + 64 * k);
+    w.b[k] = *reinterpret_cast<const float4*>(be + sub * 4 + 64 * k);
+  }
+}
+// (the weights come in registers, requested before the rows: loaded inside the loop below they would each wait behind
+// the loop's write-through stores - the compiler keeps a plain load behind an atomic store it cannot tell apart from it)
+// write_x / write_hn: bit k set = this workgroup stores column slice k (columns 4 sub + 64 k) of the normalised rows -
+// the fp32 rows (the residual of the phase after next) / the bf16 rows (beam search: the advance phase's B operand).  The
+// first 8 workgroups of a row group take a slice each (gemm_phase): one workgroup writing all 2 KB of every row in
+// write-through stores was what the phase's consumers waited for (*measured* 640 rows: 17.6 us in the QKV phase).
+__device__ __forceinline__ void finish_a_rows(const RArgs& p, int r0, const float4 (&v)[8], const LnGB& w,
+                                              unsigned write_x, bf16_t* sA, int lda, unsigned write_hn = 0u) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, sub = lane & 15;
   constexpr int d = 512;
-  const float4 g0 = *reinterpret_cast<const float4*>(g + lane * 4), g1 = *reinterpret_cast<const float4*>(g + 256 + lane * 4);
-  const float4 b0 = *reinterpret_cast<const float4*>(be + lane * 4), b1 = *reinterpret_cast<const float4*>(be + 256 + lane * 4);
+  const int rr = wave * 4 + q, r = r0 + rr;
+  const bool live = r < p.R;  // rows past the batch: zeros into the tile
+  float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rr = wave * 4 + i, r = r0 + rr;
-    bf16_t* dst = sA + rr * lda;
-    if (r >= p.R) {  // rows past the batch: zeros into the tile
-      *reinterpret_cast<uint2*>(dst + lane * 4) = make_uint2(0u, 0u);
-      *reinterpret_cast<uint2*>(dst + 256 + lane * 4) = make_uint2(0u, 0u);
-      continue;
-    }
-    const float s = ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
-    const float mean = wave_sum_dpp(s) * (1.0f / d);
-    float qq = 0.f;
+  for (int k = 0; k < 8; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  const float mean = row16_sum(s) * (1.0f / d);
+  float qq = 0.f;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const float a = v[i][c].x - mean, b = v[i][c].y - mean, cc = v[i][c].z - mean, e = v[i][c].w - mean;
-      qq += (a * a + b * b) + (cc * cc + e * e);
-    }
-    const float var = wave_sum_dpp(qq) * (1.0f / d);
-    const float rstd = 1.0f / sqrtf(var + p.eps);
+  for (int k = 0; k < 8; ++k) {
+    const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, e = v[k].w - mean;
+    qq += (a * a + b * b) + (cc * cc + e * e);
+  }
+  const float var = row16_sum(qq) * (1.0f / d);
+  const float rstd = 1.0f / sqrtf(var + p.eps);
+  bf16_t* dst = sA + rr * lda + sub * 4;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const float4 gg = c ? g1 : g0, bb = c ? b1 : b0;
-      float4 o;
-      o.x = (v[i][c].x - mean) * rstd * gg.x + bb.x;
-      o.y = (v[i][c].y - mean) * rstd * gg.y + bb.y;
-      o.z = (v[i][c].z - mean) * rstd * gg.z + bb.z;
-      o.w = (v[i][c].w - mean) * rstd * gg.w + bb.w;
-      bf16x4 ob;
-      ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
-      *reinterpret_cast<bf16x4*>(dst + c * 256 + lane * 4) = ob;
-      if (write_x) cst_f4(p.xres + (int64_t)r * d + c * 256 + lane * 4, o);
-      if (write_hn) cst_b4(p.hn + (int64_t)r * d + c * 256 + lane * 4, ob);
-    }
+  for (int k = 0; k < 8; ++k) {
+    const float4 gg = w.g[k], bb = w.b[k];
+    float4 o;
+    o.x = (v[k].x - mean) * rstd * gg.x + bb.x;
+    o.y = (v[k].y - mean) * rstd * gg.y + bb.y;
+    o.z = (v[k].z - mean) * rstd * gg.z + bb.z;
+    o.w = (v[k].w - mean) * rstd * gg.w + bb.w;
+    bf16x4 ob;
+    ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
+    if (!live) ob = bf16x4{};
+    *reinterpret_cast<bf16x4*>(dst + 64 * k) = ob;
+    if (live && ((write_x >> k) & 1u)) cst_f4(p.xres + (int64_t)r * d + sub * 4 + 64 * k, o);
+    if (live && ((write_hn >> k) & 1u)) cst_b4(p.hn + (int64_t)r * d + sub * 4 + 64 * k, ob);
   }
 }
 
@@ -489,8 +523,10 @@ __device__ __forceinline__ void load_w(bf16x8 (&wf)[NF], const bf16_t* wp) {
 // the workgroups that multiply; otherwise (`helped` false) the workgroup of column item 0 does that too.
 struct PhaseMap {
   int rt, c0, nper; bool has, helped, helper;
-  __device__ __forceinline__ PhaseMap(int RT, int CI) {
-    const int G = gridDim.x, b = blockIdx.x;
+  // gcap > 0: only the first gcap workgroups take part (the others have no item) - beam search caps the vocabulary
+  // phase so that a row has at most 48 partial lists for the advance phase to merge
+  __device__ __forceinline__ PhaseMap(int RT, int CI, int gcap = 0) {
+    const int G = gcap > 0 && gcap < (int)gridDim.x ? gcap : (int)gridDim.x, b = blockIdx.x;
     helped = helper = false;
     if ((G & 7) == 0 && (G >> 3) >= RT) {
       const int x = b & 7, j = b >> 3, nsl = (G >> 3) / RT, cs = j / RT;
@@ -501,6 +537,7 @@ struct PhaseMap {
     } else {
       nper = G / RT; rt = b % RT; c0 = b / RT; has = c0 < nper && c0 < CI;
     }
+    if (b >= G) has = helper = false;
     np_ = (unsigned)(RT * (nper < CI ? nper : CI));
     nh_ = helped ? (unsigned)RT : 0u;
   }
@@ -520,7 +557,7 @@ struct PhaseMap {
 template <int KC, int AMODE, int EPI, bool KSPLIT, int RTB = 1>
 __device__ __forceinline__ unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf16_t* sA, const bf16_t* W,
                                            const float* bias, int N, const void* asrc, const float* g, const float* be,
-                                           bool write_x, int t, bf16_t* skv, const float* asrc2 = nullptr) {
+                                           bool write_x, int t, bf16_t* skv, const float* asrc2 = nullptr, int gcap = 0) {
   // RTB: 16-row tiles a workgroup multiplies with ONE fetch of its W fragments (their A rows side by side in LDS):
   // the weight traffic of a phase is (row tiles / RTB) x the matrix - what bounds the vocabulary phase at 128 rows.
   constexpr int K = 512 * KC, NF = KSPLIT ? 4 * KC : 16 * KC;
@@ -532,7 +569,7 @@ __device__ __forceinline__ unsigned gemm_phase(const RArgs& p, GridSync& gs, boo
   __shared__ f32x4 s_red[2][3][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
   const int RT = (p.R + 15) >> 4, RG = (RT + RTB - 1) / RTB, CI = KSPLIT ? (N + 15) >> 4 : (N + 63) >> 6;
-  const PhaseMap pm(RG, CI);
+  const PhaseMap pm(RG, CI, gcap);
   const int r0 = pm.rt * 16 * RTB;
   // this wave's tile of column item c: columns n0(c) .. + 16; its K range starts at koff
   const int koff = KSPLIT ? wave * (K / 4) : 0;
@@ -567,16 +604,32 @@ __device__ __forceinline__ unsigned gemm_phase(const RArgs& p, GridSync& gs, boo
 #pragma unroll
     for (int i = 0; i < NF; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ar + i * 32);
   };
-  auto item = [&](const bf16x8 (&wf)[NF], int c) {
+  // what an item's epilogue reads from memory - its bias, the residual rows - is requested by `preload` BEFORE the next
+  // item's weight fragments: vmcnt retires in issue order, so a load issued behind the prefetch would make the epilogue
+  // wait for the whole prefetch (the double buffer was no buffer in every phase with several items per workgroup)
+  struct Pre { float4 bv; float4 xr[RTB]; };
+  auto preload = [&](Pre& P, int c) {
+    const int n0 = tile_n0(c), nb = n0 + kg * 4;
+    P.bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EPI != E_VOCAB && EPI != E_VOCABK)
+      if (n0 < N) P.bv = *reinterpret_cast<const float4*>(bias + nb);
+#pragma unroll
+    for (int u = 0; u < RTB; ++u) {
+      P.xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (EPI == E_RES) {
+        const int r = r0 + u * 16 + l16;
+        if ((!KSPLIT || wave == 0) && n0 < N && r < p.R) P.xr[u] = cld_f4(p.xres + (int64_t)r * 512 + nb);
+      }
+    }
+  };
+  auto item = [&](const bf16x8 (&wf)[NF], int c, const Pre& P) {
     const int n0 = tile_n0(c), nb = n0 + kg * 4;
     const bool active = n0 < N;
 #pragma unroll
     for (int u = 0; u < RTB; ++u) {
       const int r = r0 + u * 16 + l16;  // lane: row r, columns nb .. nb + 3 of its wave's tile
       if (RTB > 1 && r0 + u * 16 >= p.R) break;
-      float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (EPI == E_RES)
-        if ((!KSPLIT || wave == 0) && active && r < p.R) xr = cld_f4(p.xres + (int64_t)r * 512 + nb);
+      const float4 xr = P.xr[u];
       // K in quarters, each with two accumulator chains (even / odd fragments), added as q0 + ((q1 + q2) + q3): the
       // order in which the K-split form adds its four waves' tiles, so both forms give the same bits
       constexpr int NQ = (KSPLIT || EPI == E_VOCAB || EPI == E_VOCABK) ? 1 : 4, QF = NF / NQ;  // (the vocabulary phase has one form)
@@ -624,17 +677,17 @@ __device__ __forceinline__ unsigned gemm_phase(const RArgs& p, GridSync& gs, boo
             }
           }
           if (m4 > vm[u]) {  // later items hold higher columns: a tie keeps the earlier one
-            vs[u] = vm[u] == -INFINITY ? 0.f : vs[u] * expf(vm[u] - m4);
+            vs[u] = vm[u] == -INFINITY ? 0.f : vs[u] * fexp(vm[u] - m4);
             vm[u] = m4; vi[u] = i4;
           }
           if (vm[u] != -INFINITY) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (nb + e < N) vs[u] += expf(v[e] - vm[u]);
+              if (nb + e < N) vs[u] += fexp(v[e] - vm[u]);
           }
         }
       } else if (active && r < p.R) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
+        const float4 bv = P.bv;
         v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
         if constexpr (EPI == E_QKV) {
           if (nb < 512) {
@@ -678,32 +731,47 @@ __device__ __forceinline__ unsigned gemm_phase(const RArgs& p, GridSync& gs, boo
         load_a_bf16<K>(p, r0 + u * 16, reinterpret_cast<const bf16_t*>(asrc), sA + u * 16 * lda, lda);
       }
     } else {  // the rows of every tile requested before the first one is normalised
-      float4 av[RTB][4][2];
+      float4 av[RTB][8];
+      LnGB gb;
+      load_gb(gb, g, be);
+      // who stores the normalised rows: column slice k by the workgroup of item k when the row group has 8 of them
+      const unsigned wmask = (pm.nper >= 8 && CI >= 8) ? (pm.c0 < 8 ? 1u << pm.c0 : 0u) : (pm.c0 == 0 ? 0xffu : 0u);
+      int mytok[RTB];
+#pragma unroll
+      for (int u = 0; u < RTB; ++u) {
+        mytok[u] = 0;
+        if constexpr (AMODE == A_EMBED || AMODE == A_EMBEDB)
+          mytok[u] = fetch_token<AMODE>(p, r0 + u * 16, t, pm.c0 == 0 && (AMODE == A_EMBEDB || !pm.helped));
+      }
 #pragma unroll
       for (int u = 0; u < RTB; ++u)
-        fetch_a_rows<AMODE>(p, r0 + u * 16, t, pm.c0 == 0 && (AMODE == A_EMBEDB || !pm.helped), reinterpret_cast<const float*>(asrc), asrc2, av[u]);
+        fetch_a_rows<AMODE>(p, r0 + u * 16, t, mytok[u], reinterpret_cast<const float*>(asrc), asrc2, av[u]);
 #pragma unroll
       for (int u = 0; u < RTB; ++u) {
         if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;
-        finish_a_rows(p, r0 + u * 16, av[u], g, be, write_x && pm.c0 == 0, sA + u * 16 * lda, lda, EPI == E_VOCABK && pm.c0 == 0);
+        finish_a_rows(p, r0 + u * 16, av[u], gb, write_x ? wmask : 0u, sA + u * 16 * lda, lda, EPI == E_VOCABK ? wmask : 0u);
       }
     }
     __syncthreads();
     if constexpr (RTB == 1) load_af(0);
-    if constexpr (EPI == E_VOCAB || EPI == E_VOCABK) gs.mark();
+    gs.mark();
+    Pre Pa, Pb;
+    preload(Pa, pm.c0);
     if (pm.c0 + pm.nper >= CI) {
-      item(wa, pm.c0);  // one item: nothing to prefetch (most phases at most row counts)
+      item(wa, pm.c0, Pa);  // one item: nothing to prefetch (most phases at most row counts)
     } else {
       for (int c = pm.c0; c < CI; c += 2 * pm.nper) {
+        preload(Pb, min(c + pm.nper, CI - 1));
         fetch(wb, c + pm.nper);
-        item(wa, c);
+        item(wa, c, Pa);
         if (c + pm.nper >= CI) break;
+        preload(Pa, min(c + 2 * pm.nper, CI - 1));
         fetch(wa, c + 2 * pm.nper);
-        item(wb, c + pm.nper);
+        item(wb, c + pm.nper, Pb);
       }
     }
+    gs.mark();
     if constexpr (EPI == E_VOCAB || EPI == E_VOCABK) {
-      gs.mark();
 #pragma unroll
       for (int u = 0; u < RTB; ++u) {
         const int r = r0 + u * 16 + l16;
@@ -858,6 +926,82 @@ __device__ __forceinline__ unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf1
   return nprod;
 }
 
+// lane ^ 8 / ^ 16 / ^ 32 exchanges of the attention reductions without the LDS crossbar: row_ror:8 (DPP), and the
+// gfx950 row / half swaps - v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of
+// its second, v_permlane32_swap the upper half of the first with the lower half of the second; with both operands = v the
+// two results are (lower partner, upper partner) in every lane.  a + b == b + a: the sums are those of __shfl_xor, bit for bit.
+__device__ __forceinline__ float x16_sum(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+  return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ float x32_sum(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+  return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ float x16_max(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+  return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+}
+__device__ __forceinline__ float x32_max(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+  return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+}
+
+// One (row, head) of attention on fragments in registers: lane = (key slot = lane >> 3, 8-dim chunk = lane & 7); scores /
+// softmax in registers, the 8 key slots merged by three exchange steps.  Masking as the reference: masked keys get
+// -1e9, the hybrid bias is added after the mask (models/components/Attention.py:104-111).
+template <int NKB>
+__device__ __forceinline__ void attn_one(const float (&q)[8], const bf16x8 (&kf)[NKB], const bf16x8 (&vf)[NKB], const float (&add)[NKB],
+                                         const bool (&padded)[NKB], int nk, int nkb, int slot, float (&acc)[8]) {
+  float s[NKB];
+  float m = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+    if (kb < nkb) {
+      float dd = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dd = fmaf(q[i], (float)kf[kb][i], dd);
+      dd += care_dpp_x1(dd);
+      dd += care_dpp_x2(dd);
+      dd += care_dpp_m8(dd);
+      dd *= 0.125f;
+      if (padded[kb]) dd = -1e9f;
+      dd += add[kb];
+      s[kb] = kb * 8 + slot < nk ? dd : -INFINITY;
+      m = fmaxf(m, s[kb]);
+    }
+  m = fmaxf(m, care_dpp_x8(m));
+  m = x16_max(m);
+  m = x32_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+    if (kb < nkb) { s[kb] = fexp(s[kb] - m); sum += s[kb]; }
+  sum += care_dpp_x8(sum);
+  sum = x16_sum(sum);
+  sum = x32_sum(sum);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+    if (kb < nkb) {
+      const float pw = s[kb] * inv;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(pw, (float)vf[kb][i], acc[i]);
+    }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] += care_dpp_x8(acc[i]);
+    acc[i] = x16_sum(acc[i]);
+    acc[i] = x32_sum(acc[i]);
+  }
+}
+
 // One attention phase: ctx[r, h*64 ..] = softmax(q_h K_h^T / 8 (masked, + bias)) V_h for every (row, head); one
 // wave per item, lane = (key slot, 8-dim chunk).  Masking as the reference: masked keys get -1e9, the hybrid bias
 // is added after the mask (models/components/Attention.py:104-111).  The heads of a row go to the waves of ONE XCD
@@ -940,48 +1084,8 @@ __device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, boo
       }
   };
   auto compute = [&](const AttnItem<NKB>& it) {
-    float s[NKB];
-    float m = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-      if (kb < nkb) {
-        float dd = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dd = fmaf(it.q[i], (float)it.kf[kb][i], dd);
-        dd += care_dpp_x1(dd);
-        dd += care_dpp_x2(dd);
-        dd += care_dpp_m8(dd);
-        dd *= 0.125f;
-        if (it.padded[kb]) dd = -1e9f;
-        dd += it.add[kb];
-        s[kb] = kb * 8 + slot < nk ? dd : -INFINITY;
-        m = fmaxf(m, s[kb]);
-      }
-    m = fmaxf(m, __shfl_xor(m, 8, 64));
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-      if (kb < nkb) { s[kb] = expf(s[kb] - m); sum += s[kb]; }
-    sum += __shfl_xor(sum, 8, 64);
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-      if (kb < nkb) {
-        const float pw = s[kb] * inv;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = fmaf(pw, (float)it.vf[kb][i], acc[i]);
-      }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      acc[i] += __shfl_xor(acc[i], 8, 64);
-      acc[i] += __shfl_xor(acc[i], 16, 64);
-      acc[i] += __shfl_xor(acc[i], 32, 64);
-    }
+    float acc[8];
+    attn_one<NKB>(it.q, it.kf, it.vf, it.add, it.padded, nk, nkb, slot, acc);
     if (slot == 0) {
       bf16x8 ob;
 #pragma unroll
@@ -1019,6 +1123,83 @@ __device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, boo
   return nprod;
 }
 
+
+// Beam search: the bm rows of a clip attend to the SAME static keys (its memory / concept rows, whatever its beams
+// hold).  One wave per (clip, head) fetches the head's K / V fragments ONCE and runs its bm queries past them - a fifth
+// of the fragment traffic of a wave per (row, head), and one item per wave at 128 clips instead of five in series.  The
+// arithmetic per row is attn_one's: the same bits as attn_phase.  The heads of a clip go to the waves of ONE XCD.
+template <int NKB>
+__device__ __forceinline__ unsigned attn_shared_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
+                                                      int bm, int nk, const float* bias, int bias_ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 3, chunk = lane & 7;
+  constexpr int d = 512;
+  const int nkb = (nk + 7) >> 3, H = p.H, nclips = p.R / bm;
+  const bool by_xcd = (gridDim.x & 7) == 0;
+  const int x = by_xcd ? (int)(blockIdx.x & 7) : 0, xs = by_xcd ? 8 : 1;
+  const int bpx = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int slot0 = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int myslot = slot0 + bpx * wave, nslots = bpx * 4;
+  const int nitems = ((nclips - x + xs - 1) / xs) * H;
+  const bool participant = slot0 < nitems;
+  unsigned nprod = 0;
+  for (int xx = 0; xx < xs; ++xx) {
+    const int it = ((nclips - xx + xs - 1) / xs) * H;
+    nprod += (unsigned)(it < bpx ? it : bpx);
+  }
+  if (gs.dead) return nprod;
+  // the keys / values were written before the launch: the first item's fragments travel while the workgroup waits
+  bf16x8 kf[NKB], vf[NKB];
+  float add[NKB];
+  bool padded[NKB];
+  auto load_kv = [&](int li) {
+    const int clip = x + xs * (li / H), hh = li % H;
+    const bf16_t* kb0 = KV + (int64_t)clip * kv_bs + hh * 64 + chunk * 8;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+      if (kb < nkb) {
+        const int j = kb * 8 + slot, jc = j < nk ? j : 0;
+        padded[kb] = false;
+        add[kb] = bias ? bias[hh * bias_ld + jc] : 0.f;
+        kf[kb] = *reinterpret_cast<const bf16x8*>(kb0 + (int64_t)jc * 2 * d);
+        vf[kb] = *reinterpret_cast<const bf16x8*>(kb0 + (int64_t)jc * 2 * d + d);
+      }
+  };
+  if (myslot < nitems) load_kv(myslot);
+  if (do_wait && participant) gs.wait();
+  if (gs.dead) return nprod;
+  gs.mark();
+  for (int li = myslot; li < nitems; li += nslots) {
+    const int clip = x + xs * (li / H), hh = li % H;
+    if (li != myslot) load_kv(li);
+    float q[RES_BMK][8];
+#pragma unroll
+    for (int i = 0; i < RES_BMK; ++i)
+      if (i < bm) {
+        const float* qp = p.q + (int64_t)(clip * bm + i) * d + hh * 64 + chunk * 8;
+        const float4 qa = cld_f4(qp), qb = cld_f4(qp + 4);
+        q[i][0] = qa.x; q[i][1] = qa.y; q[i][2] = qa.z; q[i][3] = qa.w; q[i][4] = qb.x; q[i][5] = qb.y; q[i][6] = qb.z; q[i][7] = qb.w;
+      }
+#pragma unroll
+    for (int i = 0; i < RES_BMK; ++i)
+      if (i < bm) {
+        // (the fragments are opaque to the compiler per row: it would otherwise hoist their 2 x 8 NKB bf16 -> fp32
+        // conversions out of the row loop - 256 registers at 128 keys, all of them spilled)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(kf[kb]), "+v"(vf[kb]));
+        float acc[8];
+        attn_one<NKB>(q[i], kf, vf, add, padded, nk, nkb, slot, acc);
+        if (slot == 0) {
+          bf16x8 ob;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)acc[e];
+          cst_b8(p.ctx + (int64_t)(clip * bm + i) * d + hh * 64 + chunk * 8, ob);
+        }
+      }
+  }
+  gs.mark();
+  gs.arrive(participant);
+  return nprod;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Host side, shared by care_decode_resident and care_decode_resident_beam.

@@ -26,73 +26,97 @@
 
 namespace {
 
-constexpr int RES_MAXE = 16;  // group-list entries per lane in the advance phase: parts x RES_BMK <= 64 x RES_MAXE
+constexpr int RES_MAXE = 4;   // group-list entries per lane in the advance phase: parts x RES_BMK <= 64 x RES_MAXE (parts <= 48: RArgs::vcap)
 
 // One phase: log_softmax + Beam.advance for every clip (models/Translator.py:127, misc/Decoding/Beam.py:45-85).
 // One workgroup per clip.  Waves 0 .. 3 take the clip's rows (row i -> wave i % 4): log-sum-exp of the row from the
 // vocabulary partials, the row's bm best groups from the parts' lists (per-lane sorted lists, then bm rounds of
 // `largest head in the wave`), the 4 bm logits of those groups recomputed (see above), the bm best of them as
-// log-probabilities (value desc, column asc) -> LDS.  Wave 0 then runs the state machine of csrc/beam.hip's
-// beam_advance_wave_kernel on the bm x bm candidates (lane = candidate; ancestor rows one position per lane).
-__device__ __forceinline__ unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t) {
+// log-probabilities (value desc, column asc) -> LDS.  The LAST wave (one row at most) then runs the state machine of
+// csrc/beam.hip's beam_advance_wave_kernel on the bm x bm candidates (lane = candidate; ancestor rows one position per
+// lane).  What bounds the phase is the number of DEPENDENT memory round trips (~1.5 us each through the coherent
+// path), so: every row's partials are requested before the first is used (a wave with two rows has both in flight),
+// and ALL the state the advance reads - flags, scores, the clip's rows of the ancestor and token tables, whichever
+// parents win - is requested by its wave at the top of the phase: after the barrier it computes and stores.
+struct BeamRowIn {
+  float pm[RES_NP], ps[RES_NP];
+  float ev[RES_MAXE];
+  int eg[RES_MAXE];
+};
+
+__device__ __forceinline__ unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, unsigned char* scratch_lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
   const int G = gridDim.x, bm = p.bm, stride = p.fed_stride;
   const unsigned nprod = (unsigned)(p.nclips < G ? p.nclips : G);
   const bool participant = (int)blockIdx.x < p.nclips;
-  __shared__ float s_cv[8][RES_BMK];
-  __shared__ int s_ci[8][RES_BMK];
+  float (*s_cv)[RES_BMK] = reinterpret_cast<float (*)[RES_BMK]>(scratch_lds);
+  int (*s_ci)[RES_BMK] = reinterpret_cast<int (*)[RES_BMK]>(scratch_lds + 8 * RES_BMK * 4);
   if (gs.dead) return nprod;
   if (participant) gs.wait();
   if (gs.dead) return nprod;
   gs.mark();
   const int32_t* anc_old = p.anc[(t - 1) & 1];
   int32_t* anc_new = p.anc[t & 1];
+  const int NE = p.parts * RES_BMK, NEL = (NE + 63) >> 6;
   for (int c = blockIdx.x; c < p.nclips; c += G) {
     const int row0 = c * bm;
-    for (int i = wave; i < bm; i += 4) {
-      const int r = row0 + i;
-      // ---- everything this row needs that does not depend on anything computed here, requested first
-      bf16x8 af[16];  // the row's normalised hidden state as B fragments (every column of the MFMA = this row)
+    // ---- the advance wave's state, requested before anything else (lane = position j of the tables)
+    int st_done = 0, st_nf = 0, st_anc[RES_BMK], st_tok[RES_BMK];
+    float st_sc[RES_BMK];
+    if (wave == 3) {
+      st_done = cld_i(p.done + c);
+      st_nf = cld_i(p.nfin + c);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) af[q] = cld_b8(p.hn + (int64_t)r * 512 + kg * 8 + q * 32);
-      float pm[RES_NP], ps[RES_NP];
+      for (int i = 0; i < RES_BMK; ++i) {
+        const int64_t o = (int64_t)(row0 + (i < bm ? i : 0)) * stride + (lane < stride ? lane : 0);
+        st_anc[i] = cld_i(anc_old + o);
+        st_tok[i] = cld_i(p.fed + o);
+        st_sc[i] = cld_f(p.score + row0 + (i < bm ? i : 0));
+      }
+    }
+    // ---- the partials of this wave's rows (i = wave, wave + 4), all requested before the first is used
+    BeamRowIn in[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int i = wave + 4 * s;
+      if (i >= bm) break;  // (wave-uniform)
+      const int r = row0 + i;
 #pragma unroll
       for (int k = 0; k < RES_NP; ++k) {
         const int cpart = lane + 64 * k;
         const bool ok = cpart < p.parts;
-        pm[k] = cld_f(p.pmax + (int64_t)r * p.parts + (ok ? cpart : 0));
-        ps[k] = cld_f(p.psum + (int64_t)r * p.parts + (ok ? cpart : 0));
-        if (!ok) { pm[k] = -INFINITY; ps[k] = 0.f; }
+        in[s].pm[k] = cld_f(p.pmax + (int64_t)r * p.parts + (ok ? cpart : 0));
+        in[s].ps[k] = cld_f(p.psum + (int64_t)r * p.parts + (ok ? cpart : 0));
+        if (!ok) { in[s].pm[k] = -INFINITY; in[s].ps[k] = 0.f; }
       }
-      const int NE = p.parts * RES_BMK, NEL = (NE + 63) >> 6;
-      float ev[RES_MAXE];
-      int eg[RES_MAXE];
 #pragma unroll
       for (int k = 0; k < RES_MAXE; ++k)
         if (k < NEL) {
           const int e = lane + 64 * k;
           const bool ok = e < NE;
-          ev[k] = cld_f(p.gval + (int64_t)r * NE + (ok ? e : 0));
-          eg[k] = cld_i(p.ggid + (int64_t)r * NE + (ok ? e : 0));
-          if (!ok) { ev[k] = -INFINITY; eg[k] = 0x7fffffff; }
+          in[s].ev[k] = cld_f(p.gval + (int64_t)r * NE + (ok ? e : 0));
+          in[s].eg[k] = cld_i(p.ggid + (int64_t)r * NE + (ok ? e : 0));
+          if (!ok) { in[s].ev[k] = -INFINITY; in[s].eg[k] = 0x7fffffff; }
         }
-      // ---- log-sum-exp of the row
-      float mloc = pm[0];
-#pragma unroll
-      for (int k = 1; k < RES_NP; ++k) mloc = fmaxf(mloc, pm[k]);
-      const float M = care_wave_max_dpp(mloc);
-      float sloc = 0.f;
-#pragma unroll
-      for (int k = 0; k < RES_NP; ++k) sloc += pm[k] == -INFINITY ? 0.f : ps[k] * expf(pm[k] - M);
-      const float logS = logf(wave_sum_dpp(sloc));
-      // ---- the row's bm best groups
+    }
+    // The three stages of a row, as lambdas so that a wave with two rows can run the second row's group selection while
+    // the first row's weight fragments travel:
+    //   groups: the row's bm best groups from the parts' lists;
+    //   issue : their 4 bm logits again - MFMA rows = the columns of groups (tile 0: groups 0 .. 3, tile 1: 4 .. 7), lane
+    //           (l16, kg) fetches the weight row of column 4 gsel[4 tile + l16 / 4] + l16 % 4 and receives the logits of
+    //           columns 4 gsel[4 tile + kg] + 0 .. 3; both tiles' weight rows and the row's hidden state (B fragments:
+    //           every column of the MFMA = this row) are requested together;
+    //   finish: log-sum-exp of the row, the products in gemm_phase's accumulation order (two chains over even / odd k
+    //           fragments), one candidate per lane (l16 < 8: tile l16 / 4, element l16 % 4 of the lane's group), bm
+    //           rounds of arg-best (value desc, column asc) -> LDS.
+    auto groups = [&](int sl, int (&gsel)[RES_BMK]) {
       unsigned long long hk[RES_BMK];
 #pragma unroll
       for (int k = 0; k < RES_BMK; ++k) hk[k] = 0ull;
 #pragma unroll
       for (int k = 0; k < RES_MAXE; ++k)
         if (k < NEL) {
-          unsigned long long x = ev[k] == -INFINITY ? 0ull : key_of(ev[k], (unsigned)eg[k]);
+          unsigned long long x = in[sl].ev[k] == -INFINITY ? 0ull : key_of(in[sl].ev[k], (unsigned)in[sl].eg[k]);
 #pragma unroll
           for (int j = 0; j < RES_BMK; ++j) {
             const bool gt = x > hk[j];
@@ -101,7 +125,6 @@ __device__ __forceinline__ unsigned beam_advance_phase(const RArgs& p, GridSync&
             hk[j] = hi;
           }
         }
-      int gsel[RES_BMK];
 #pragma unroll
       for (int k = 0; k < RES_BMK; ++k) {
         const unsigned long long best = wave_max_u64(hk[0]);
@@ -112,37 +135,53 @@ __device__ __forceinline__ unsigned beam_advance_phase(const RArgs& p, GridSync&
           hk[RES_BMK - 1] = 0ull;
         }
       }
-      // ---- their 4 bm logits again: MFMA rows = the columns of groups (tile 0: groups 0 .. 3, tile 1: 4 .. 7), lane
-      // (l16, kg) fetches the weight row of column 4 gsel[4 tile + l16 / 4] + l16 % 4 and receives the logits of columns
-      // 4 gsel[4 tile + kg] + 0 .. 3; the accumulation order is gemm_phase's (two chains over even / odd k fragments)
-      f32x4 vt[2];
-      int gout[2];
+    };
+    auto issue = [&](int r, const int (&gsel)[RES_BMK], int (&gout)[2], bf16x8 (&wf0)[16], bf16x8 (&wf1)[16], bf16x8 (&af)[16]) {
+      int gl[2];
 #pragma unroll
       for (int tile = 0; tile < 2; ++tile) {
-        vt[tile] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        gout[tile] = 0;
-        if (tile * 4 >= bm) continue;  // (wave-uniform)
-        int gl = gsel[tile * 4];
-        gout[tile] = gsel[tile * 4];
+        gl[tile] = gout[tile] = gsel[tile * 4 < RES_BMK ? tile * 4 : 0];
 #pragma unroll
         for (int q = 1; q < 4; ++q)
           if (tile * 4 + q < RES_BMK) {
-            if ((l16 >> 2) == q) gl = gsel[tile * 4 + q];
+            if ((l16 >> 2) == q) gl[tile] = gsel[tile * 4 + q];
             if (kg == q) gout[tile] = gsel[tile * 4 + q];
           }
-        const int col = min(gl * 4 + (l16 & 3), p.V - 1);
-        const bf16_t* wp = p.vocab + (int64_t)col * 512 + kg * 8;
-        bf16x8 wf[16];
-        load_w<16>(wf, wp);
+      }
+      load_w<16>(wf0, p.vocab + (int64_t)min(gl[0] * 4 + (l16 & 3), p.V - 1) * 512 + kg * 8);
+      if (bm > 4) load_w<16>(wf1, p.vocab + (int64_t)min(gl[1] * 4 + (l16 & 3), p.V - 1) * 512 + kg * 8);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) af[q] = cld_b8(p.hn + (int64_t)r * 512 + kg * 8 + q * 32);
+    };
+    auto finish = [&](int sl, int i, const int (&gout)[2], const bf16x8 (&wf0)[16], const bf16x8 (&wf1)[16], const bf16x8 (&af)[16]) {
+      float mloc = in[sl].pm[0];
+#pragma unroll
+      for (int k = 1; k < RES_NP; ++k) mloc = fmaxf(mloc, in[sl].pm[k]);
+      const float M = care_wave_max_dpp(mloc);
+      float sloc = 0.f;
+#pragma unroll
+      for (int k = 0; k < RES_NP; ++k) sloc += in[sl].pm[k] == -INFINITY ? 0.f : in[sl].ps[k] * expf(in[sl].pm[k] - M);
+      const float logS = logf(wave_sum_dpp(sloc));
+      f32x4 vt[2];
+      {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q], af[q], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q + 1], af[q + 1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[q], af[q], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[q + 1], af[q + 1], acc1, 0, 0, 0);
         }
-        vt[tile] = acc0 + acc1;
+        vt[0] = acc0 + acc1;
       }
-      // ---- one candidate per lane (l16 < 8: tile l16 / 4, element l16 % 4 of the lane's group), bm rounds of arg-best
+      vt[1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (bm > 4) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[q], af[q], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[q + 1], af[q + 1], acc1, 0, 0, 0);
+        }
+        vt[1] = acc0 + acc1;
+      }
       const int ctile = (l16 >> 2) & 1, ce = l16 & 3, cgrp = ctile * 4 + kg;
       const f32x4 vsel = ctile ? vt[1] : vt[0];
       const float cval = ce == 0 ? vsel[0] : ce == 1 ? vsel[1] : ce == 2 ? vsel[2] : vsel[3];
@@ -158,34 +197,70 @@ __device__ __forceinline__ unsigned beam_advance_phase(const RArgs& p, GridSync&
           s_ci[i][k] = best ? (int)key_idx(best) : 0;
         }
       }
+    };
+    if (wave < bm) {
+      const bool two = wave + 4 < bm;  // (wave-uniform)
+      int gsel[RES_BMK], gsel1[RES_BMK], gout[2];
+      bf16x8 wf0[16], wf1[16], af[16];
+      groups(0, gsel);
+      gs.mark();
+      issue(row0 + wave, gsel, gout, wf0, wf1, af);
+      if (two) groups(1, gsel1);  // (while the first row's fragments travel)
+      finish(0, wave, gout, wf0, wf1, af);
+      gs.mark();
+      if (two) {
+        issue(row0 + wave + 4, gsel1, gout, wf0, wf1, af);
+        finish(1, wave + 4, gout, wf0, wf1, af);
+      }
     }
     __syncthreads();
-    if (wave == 0) {
-      // ---------------- Beam.advance (csrc/beam.hip beam_advance_wave_kernel, on coherent accesses) ----------------
+    gs.mark();
+    if (wave == 3) {
+      // ---------------- Beam.advance (csrc/beam.hip beam_advance_wave_kernel) on the prefetched state ----------------
       const int b = c;
-      if (cld_i(p.done + b)) {
+      if (st_done) {
         // frozen clip: keep the tables valid so the (ignored) rows keep reading defined memory
-        for (int i = 0; i < bm; ++i) {
-          const int64_t o = (int64_t)(row0 + i) * stride;
-          if (lane < t) cst_i(anc_new + o + lane, cld_i(anc_old + o + lane));
-          if (lane == 0) { cst_i(anc_new + o + t, row0 + i); cst_i(p.fed + o + t, p.eos); }
-        }
+#pragma unroll
+        for (int i = 0; i < RES_BMK; ++i)
+          if (i < bm) {
+            const int64_t o = (int64_t)(row0 + i) * stride;
+            if (lane < t) cst_i(anc_new + o + lane, st_anc[i]);
+            if (lane == 0) { cst_i(anc_new + o + t, row0 + i); cst_i(p.fed + o + t, p.eos); }
+          }
       } else {
         // candidate pool, lane = i * bm + j: (value, flat index i * V + col); ended beams offer nothing
-        // (Beam.py:52-54); first step: row 0 only (Beam.py:55-56)
+        // (Beam.py:52-54: the token at position t - 1 of the hypothesis in slot i, which lives at anc_old[i][t - 1],
+        // a row of this clip); first step: row 0 only (Beam.py:55-56)
         const int n_src = (t == 1) ? 1 : bm;
         const int ci = lane / bm, cj = lane % bm;
         bool live = lane < n_src * bm;
+        // tokens at position t - 1 of the clip's physical rows (lane t - 1 holds them), then per slot through its ancestor
+        int ended_mask = 0;
+        if (t > 1) {
+#pragma unroll
+          for (int i = 0; i < RES_BMK; ++i)
+            if (i < bm) {
+              const int prow = __shfl(st_anc[i], t - 1, 64) - row0;  // physical row (within the clip) of slot i's last token
+              int tk = p.eos + 1;
+#pragma unroll
+              for (int j = 0; j < RES_BMK; ++j)
+                if (j < bm && prow == j) tk = __shfl(st_tok[j], t - 1, 64);
+              if (tk == p.eos) ended_mask |= 1 << i;
+            }
+        }
         float v = -INFINITY;
         int col = 0;
         if (live) {
-          if (t > 1) {
-            const int prow = cld_i(anc_old + (int64_t)(row0 + ci) * stride + (t - 1));
-            if (cld_i(p.fed + (int64_t)prow * stride + (t - 1)) == p.eos) live = false;
-          }
+          if ((ended_mask >> ci) & 1) live = false;
           v = s_cv[ci][cj];
           col = s_ci[ci][cj];
-          if (t > 1) v = v + cld_f(p.score + row0 + ci);
+          if (t > 1) {
+            float so = st_sc[0];
+#pragma unroll
+            for (int i = 1; i < RES_BMK; ++i)
+              if (ci == i) so = st_sc[i];
+            v = v + so;
+          }
         }
         unsigned long long key = live ? key_of(v, (unsigned)(ci * p.V + col)) : 0ull;
         float sc[RES_BMK];
@@ -202,12 +277,18 @@ __device__ __forceinline__ unsigned beam_advance_phase(const RArgs& p, GridSync&
             }
           }
         }
-        // rewire ancestors (lane = position), record tokens and scores
+        // rewire ancestors (lane = position): slot i inherits its parent's row of the old table
         int anew[RES_BMK];
 #pragma unroll
         for (int i = 0; i < RES_BMK; ++i) {
           anew[i] = 0;
-          if (i < bm && lane < t) anew[i] = cld_i(anc_old + (int64_t)(row0 + parent[i]) * stride + lane);
+          if (i < bm) {
+            int a = st_anc[0];
+#pragma unroll
+            for (int j = 1; j < RES_BMK; ++j)
+              if (parent[i] == j) a = st_anc[j];
+            anew[i] = lane < t ? a : 0;
+          }
         }
 #pragma unroll
         for (int i = 0; i < RES_BMK; ++i)
@@ -217,15 +298,22 @@ __device__ __forceinline__ unsigned beam_advance_phase(const RArgs& p, GridSync&
             if (lane == 0) { cst_i(anc_new + dst + t, row0 + i); cst_i(p.fed + dst + t, tok[i]); cst_f(p.score + row0 + i, sc[i]); }
           }
         // finished hypotheses, in beam order, stop as soon as `need` are collected (Beam.py:72-77)
-        int nf = cld_i(p.nfin + b);
+        int nf = st_nf;
         bool is_done = false;
         auto record = [&](int i_anew, int i_tok, float i_sc) {  // hypothesis of one beam: positions 1..t, one per lane
           if (nf < p.fin_cap) {
             const int64_t slot = (int64_t)b * p.fin_cap + nf;
             if (lane == 0) { cst_f(p.fscore + slot, i_sc); cst_i(p.flen + slot, t); }
             if (lane >= 1 && lane <= t) {
-              // position t is the token just chosen (not read back from memory this wave has just written)
-              const int token = lane < t ? cld_i(p.fed + (int64_t)i_anew * stride + lane) : i_tok;
+              // position `lane` of the hypothesis lives at physical row i_anew (a row of this clip: its token is in
+              // the prefetched table); position t is the token just chosen
+              int token = i_tok;
+              if (lane < t) {
+                token = st_tok[0];
+#pragma unroll
+                for (int j = 1; j < RES_BMK; ++j)
+                  if (i_anew - row0 == j) token = st_tok[j];
+              }
               cst_i(p.fhyp + slot * stride + (lane - 1), token);
             }
           }
@@ -257,7 +345,7 @@ __device__ __forceinline__ unsigned beam_advance_phase(const RArgs& p, GridSync&
         }
       }
     }
-    __syncthreads();
+    if (c + G < p.nclips) __syncthreads();  // (s_cv is written again)
   }
   gs.mark();
   gs.arrive(participant);
@@ -341,8 +429,13 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p) {
       for (int a = 0; a < L.n_att; ++a) {
         const RAttn& A = L.att[a];
         RES_PHASE((gemm_phase<1, A_LN, E_Q, KD, RD>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr)));
-        RES_PHASE((A.nkeys <= 64 ? attn_phase<false, 8>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)
-                                  : attn_phase<false, RES_MAXKB>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)));
+        // more (row, head) pairs than waves: a wave per (clip, head) with the clip's keys fetched once for its beams
+        if (p.R * p.H > 4 * (int)gridDim.x)
+          RES_PHASE((A.nkeys <= 64 ? attn_shared_phase<8>(p, gs, true, A.kv, A.kv_bs, p.bm, A.nkeys, A.bias, A.bias_ld)
+                                    : attn_shared_phase<RES_MAXKB>(p, gs, true, A.kv, A.kv_bs, p.bm, A.nkeys, A.bias, A.bias_ld)));
+        else
+          RES_PHASE((A.nkeys <= 64 ? attn_phase<false, 8>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)
+                                    : attn_phase<false, RES_MAXKB>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)));
         RES_PHASE((gemm_phase<1, A_BF16, E_RES, KD, RD>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
         g = A.g; be = A.be;
       }
@@ -351,8 +444,8 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p) {
       else RES_PHASE((gemm_phase<KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr)));
     }
     const RLayer& LL = p.L[p.n_layers - 1];
-    RES_PHASE((gemm_phase<1, A_LN, E_VOCABK, false, RV>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2)));
-    RES_PHASE((beam_advance_phase(p, gs, t)));
+    RES_PHASE((gemm_phase<1, A_LN, E_VOCABK, false, RV>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2, p.vcap)));
+    RES_PHASE((beam_advance_phase(p, gs, t, smem)));
   }
 #undef RES_PHASE
   if (gs.dead) {  // aborted (GridSync::wait): every clip's count of finished hypotheses = -1
@@ -409,6 +502,9 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   const int rows = clips * beam;
   RArgs p{};
   if (const int rc = res_fill_layers(p, layers, n_layers)) return rc;
+  for (int l = 0; l < n_layers; ++l)
+    for (int a = 0; a < p.L[l].n_att; ++a)
+      if (p.L[l].att[a].rows_per_kv != beam) return CARE_EINVAL;  // the beams of a clip share its static keys (attn_shared_phase)
   p.word = word; p.pos = pos; p.sem = sem; p.sem_div = beam; p.emb_g = emb_g; p.emb_be = emb_b; p.eps = eps;
   p.vocab = (const bf16_t*)vocab_w; p.V = V;
   p.d = d; p.H = heads; p.ff = ff; p.act = act; p.R = rows; p.T = T; p.steps = steps; p.bos = bos; p.eos = eos; p.pad = pad; p.early = early_exit;
@@ -459,8 +555,13 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   // a workgroup per row group of every phase at least (the widest count of row groups: one row tile per workgroup)
   const int RGmax = cfg == 2 ? (RT + rdd - 1) / rdd : RT;
   if (grid < RGmax) return CARE_ESHAPE;
-  while (grid > 8 && beam_parts(grid, RG, CIV) > maxparts) grid -= 8;  // the advance phase reads parts x RES_BMK entries per row
-  p.parts = beam_parts(grid, RG, CIV);
+  // the advance phase merges parts x RES_BMK list entries per row, RES_MAXE per lane: the vocabulary phase runs on the
+  // first vcap workgroups only - 6 per (row group, XCD) where the grid allows: 48 partial lists per row (*measured* 1 clip
+  // x beam 5: 165 lists per row made the advance phase 25 us)
+  int vcap = 48 * RG < grid ? 48 * RG : grid;
+  while (vcap > 8 && beam_parts(vcap, RG, CIV) > maxparts) vcap -= 8;
+  p.vcap = vcap;
+  p.parts = beam_parts(vcap, RG, CIV);
   if (p.parts > maxparts || p.parts > 64 * RES_NP || p.parts < 1) return CARE_ESHAPE;
   const int kmax = ff > d ? ff : d;
   int lds = 16 * (kmax + 8) * 2;

@@ -29,10 +29,12 @@ model.set_compute_dtype("bf16")
 model.to(dev)
 eng = model.engine()
 _lib.load().care_decode_resident_debug(int(os.environ.get("CARE_RESIDENT_PROF_STEP", "3")), 0)
-names = ["qkv", "self_attn", "dense1"]
+# (phase, marks): a GEMM phase stamps wait-returned / A rows in LDS / items done / stores issued, the others begin / end
+# (the advance: begin / rows' candidates in LDS / end)
+phases = [("qkv", 4), ("self_attn", 2), ("dense1", 4)]
 for a in range(2 if eng.attr_att else 1):
-    names += ["q%d" % (a + 2), "static_attn%d" % a, "dense%d" % (a + 2)]
-names += ["ffn1", "ffn2", "vocab"] + (["advance"] if bm > 1 else [])
+    phases += [("q%d" % (a + 2), 4), ("static_attn%d" % a, 2), ("dense%d" % (a + 2), 4)]
+phases += [("ffn1", 4), ("ffn2", 2), ("vocab", 4)] + ([("advance", 5)] if bm > 1 else [])
 for B in [int(a) for a in argv] or [1, 128]:
     gen = torch.Generator(device=dev)
     gen.manual_seed(5)
@@ -49,15 +51,18 @@ for B in [int(a) for a in argv] or [1, 128]:
     else:
         nb = _lib.load().care_decode_resident_scratch(B, eng.d, eng.ff, eng.V)
         sc = eng.ws("r_scratch", (nb,), torch.uint8)
-    # per phase (begin, end), the vocabulary phase with two marks more (A rows done, items done)
-    nmarks = 2 * len(names) + 2
-    t = sc[2048:2048 + 8 * nmarks].view(torch.int64).cpu().tolist()
-    iv = 2 * names.index("vocab")
-    vt = t[iv:iv + 4]
-    t = t[:iv] + [vt[0], vt[3]] + t[iv + 4:]
-    print(flush=True); print("B = %d%s: step total %.2f us" % (B, " x beam %d" % bm if bm > 1 else "", (t[-1] - t[0]) / 100.0))
-    print("  vocab: A rows %.2f us, items %.2f us, merge + store %.2f us" % ((vt[1] - vt[0]) / 100.0, (vt[2] - vt[1]) / 100.0, (vt[3] - vt[2]) / 100.0))
-    for i, n in enumerate(names):
-        work = (t[2 * i + 1] - t[2 * i]) / 100.0
-        gap = (t[2 * i + 2] - t[2 * i + 1]) / 100.0 if 2 * i + 2 < len(t) else float("nan")
-        print("  %-13s work %6.2f us   hand-off + prefetch %6.2f us" % (n, work, gap))
+    nmarks = sum(n for _, n in phases)
+    t = [v / 100.0 for v in sc[2048:2048 + 8 * nmarks].view(torch.int64).cpu().tolist()]
+    print(flush=True); print("B = %d%s: step total %.2f us (workgroup 0)" % (B, " x beam %d" % bm if bm > 1 else "", t[-1] - t[0]))
+    i = 0
+    for name, n in phases:
+        m = t[i:i + n]
+        nxt = t[i + n] if i + n < len(t) else float("nan")
+        if n == 4:
+            detail = "A rows %5.2f  items %5.2f  epilogue %5.2f" % (m[1] - m[0], m[2] - m[1], m[3] - m[2])
+        elif n == 5:
+            detail = "first row: groups %5.2f  logits %5.2f  | all rows %5.2f  advance %5.2f" % (m[1] - m[0], m[2] - m[1], m[3] - m[0], m[4] - m[3])
+        else:
+            detail = ""
+        print("  %-13s work %6.2f us   hand-off + prefetch %6.2f us   %s" % (name, m[-1] - m[0], nxt - m[-1], detail))
+        i += n
