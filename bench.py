@@ -211,13 +211,21 @@ def extra_legs(dev, main_dtype, legs):
     legs["msrvtt_base_ami_fp32"] = greedy_leg("msrvtt_base_ami", "fp32", 4096)[0]
     # the mode between the two: fp32 storage, every GEMM as three fp16 MFMA passes over hi/lo pieces (fp32-grade results)
     legs["msrvtt_base_ami_fp16x3"] = greedy_leg("msrvtt_base_ami", "fp16x3", 4096)[0]
+    legs["msrvtt_base_ami_fp16x3_B16384"] = greedy_leg("msrvtt_base_ami", "fp16x3", 16384, iters=3)[0]
     # the reference's own operating point: translate.py batch 128 (translate.py:137); a step here is a latency
     legs["msrvtt_base_ami_B128"] = greedy_leg("msrvtt_base_ami", main_dtype, 128, iters=20)[0]
     legs["msrvtt_base_ami_B1"] = greedy_leg("msrvtt_base_ami", main_dtype, 1, iters=20)[0]
-    # BASELINE configs[3]: d_model = 1024
+    # the concept-guided model at translate.py's batch (greedy)
+    legs["msrvtt_care_B128"] = greedy_leg("msrvtt_care", main_dtype, 128, iters=20)[0]
+    # BASELINE configs[3]: d_model = 1024 - at the batch that fills the chip, and at the 32 clips per GPU that config names
+    # ("batch = 256 sharded over 8 x MI355X")
     legs["vatex_care_large"] = greedy_leg("vatex_care_large", main_dtype, 4096)[0]
-    # BASELINE configs[4]: CARE, beam 5 (opts.py beam_size 5), and at the reference's batch of 128
-    for B in (4096, 128):
+    legs["vatex_care_large_B16384"] = greedy_leg("vatex_care_large", main_dtype, 16384, iters=3)[0]
+    legs["vatex_care_large_B32"] = greedy_leg("vatex_care_large", main_dtype, 32, iters=20)[0]
+    # BASELINE configs[4]: CARE, beam 5 (opts.py beam_size 5): a large batch, the reference's batch of 128
+    # (translate.py:137,144) and its latency mode (translate.py:208-209: one clip) - the last two as ONE resident launch
+    # per search (csrc/decode_resident_beam.hip)
+    for B in (4096, 128, 1):
         eng = None
         opt, eng = build("msrvtt_care_beam5", main_dtype)
         feats = feats_for(opt, B)
@@ -227,7 +235,10 @@ def extra_legs(dev, main_dtype, legs):
         dt = _timed(run, 5 if B > 128 else 20)
         legs["msrvtt_care_beam5_B%d" % B] = dict(config="msrvtt_care_beam5", dtype=main_dtype, clips_per_step=B, beam_size=5,
                                                   rows_per_decoder_step=5 * B, captions_per_s=round(B / dt, 1),
-                                                  ms_per_pass=round(dt * 1e3, 3), decoder_step_us=round(dt * 1e6 / eng.T, 2))
+                                                  ms_per_pass=round(dt * 1e3, 3), decoder_step_us=round(dt * 1e6 / eng.T, 2),
+                                                  resident_launch=bool(eng.last_decode.get("resident")))
+        if B == 1:
+            legs["msrvtt_care_beam5_B1"]["ms_per_caption"] = round(dt * 1e3, 3)
     # a model that ENDS its captions (EOS row of the vocabulary projection x 5: mixed lengths, mean ~8 like trained
     # captions; random-init weights never emit EOS): early termination + compaction against the fixed 29 steps
     boost = {"cls_head.tgt_word_prj.weight": {3: 5.0}}

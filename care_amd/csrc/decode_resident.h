@@ -8,6 +8,11 @@
 
 namespace {
 
+#ifdef RES_NOINLINE
+#define RES_PHASE_FN __device__ __attribute__((noinline))
+#else
+#define RES_PHASE_FN __device__ __forceinline__
+#endif
 constexpr int RES_MAX_LAYERS = 4;
 constexpr int RES_MAXKB = 16;  // key blocks of 8: <= 128 keys per attention
 
@@ -555,7 +560,7 @@ struct PhaseMap {
 // E_VOCAB keeps a running (max, arg-max, sum exp) per lane over the workgroup's items and merges lanes and waves once,
 // after the last item: one partial per (row, workgroup of the row tile), p.parts of them per row.
 template <int KC, int AMODE, int EPI, bool KSPLIT, int RTB = 1>
-__device__ __forceinline__ unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf16_t* sA, const bf16_t* W,
+RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf16_t* sA, const bf16_t* W,
                                            const float* bias, int N, const void* asrc, const float* g, const float* be,
                                            bool write_x, int t, bf16_t* skv, const float* asrc2 = nullptr, int gcap = 0) {
   // RTB: 16-row tiles a workgroup multiplies with ONE fetch of its W fragments (their A rows side by side in LDS):
@@ -838,7 +843,7 @@ __device__ __forceinline__ unsigned gemm_phase(const RArgs& p, GridSync& gs, boo
 //                item = (16 columns, K half), wave w multiplies eighth 4 half + w; the half-0 workgroup stores
 //                (half0 + b) + x to y, the half-1 workgroup stores half1 to y2, and the consumers add y + y2 on load.
 template <bool HALF>
-__device__ __forceinline__ unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const bf16_t* W, const float* bias) {
+RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const bf16_t* W, const float* bias) {
   constexpr int K = 2048, lda = K + 8, NF = HALF ? 8 : 16;
   __shared__ f32x4 s_e[2][7][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
@@ -1019,7 +1024,7 @@ struct AttnItem {
 // ANC (beam search, SELF): key j of row r is position j of the hypothesis in beam slot r - cached, like its token, at the
 // PHYSICAL row anc[r][j] (the ancestor table of csrc/beam.hip: re-ordering beams never moves K / V)
 template <bool SELF, int NKB, bool ANC = false>  // SELF: the keys / values are the cache this launch writes (coherent loads), pad mask from `fed`
-__device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
+RES_PHASE_FN unsigned attn_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
                                                int rows_per_kv, int nk, const int32_t* pad_tok, const float* bias,
                                                int bias_ld, const int32_t* anc = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 3, chunk = lane & 7;
@@ -1129,7 +1134,7 @@ __device__ __forceinline__ unsigned attn_phase(const RArgs& p, GridSync& gs, boo
 // of the fragment traffic of a wave per (row, head), and one item per wave at 128 clips instead of five in series.  The
 // arithmetic per row is attn_one's: the same bits as attn_phase.  The heads of a clip go to the waves of ONE XCD.
 template <int NKB>
-__device__ __forceinline__ unsigned attn_shared_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
+RES_PHASE_FN unsigned attn_shared_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
                                                       int bm, int nk, const float* bias, int bias_ld) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 3, chunk = lane & 7;
   constexpr int d = 512;

@@ -44,7 +44,7 @@ struct BeamRowIn {
   int eg[RES_MAXE];
 };
 
-__device__ __forceinline__ unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, unsigned char* scratch_lds) {
+RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, unsigned char* scratch_lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
   const int G = gridDim.x, bm = p.bm, stride = p.fed_stride;
   const unsigned nprod = (unsigned)(p.nclips < G ? p.nclips : G);

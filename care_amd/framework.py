@@ -10,9 +10,12 @@ reference's parameter naming; the arithmetic is done by `HipEngine` (care_amd/en
 through the C ABI of libcare_hip.so.  There is no eager/CPU fallback: a forward call
 without the HIP library or a GPU raises.
 
-Training (autograd) is not implemented in this round: the kernels are forward-only, so a
-module in `.train()` mode raises NotImplementedError instead of silently running a
-different path.
+Training mode (`model.train()`; models/Wrapper.py:423-435 -> Framework.py:215-237 under autograd): `forward` /
+`feedforward_step` route to care_amd/training.py - the same forward with dropout active, as torch.autograd.Functions
+whose forward AND backward are HIP kernels (csrc/backward.hip).  The eval-only entry points (`encoding_phase`,
+`decoding_phase`, the Translator) raise NotImplementedError in training mode instead of silently running without
+dropout; configurations training.py does not cover (other encoders, concept heads without mean pooling + channel
+concat, several captions per clip) raise too.
 """
 import math
 import os

@@ -319,6 +319,11 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
     dec_mod = opt.get("modality_for_decoder") or modality
     pred_mod = opt.get("modality_for_predictor") or modality
     has_concepts = "attribute" in opt.get("crits", [])
+    if has_concepts and not (opt.get("attribute_prediction_mean_pooling") and opt.get("attribute_prediction_channel_concat")):
+        # (the eval engine makes the same restriction, engine.load_weights; computing the mean-pooled channel-concat
+        # head for a model configured otherwise would train the wrong function)
+        raise NotImplementedError("training mode covers the concept head with attribute_prediction_mean_pooling and "
+                                  "attribute_prediction_channel_concat (pred_attribute.py:78-131) only")
     has_container = "SemanticContainer" in opt.get("predictors_to_be_added", [])
     use_attr_type = opt.get("use_attr_type", "") if has_container else ""
     topk = int(opt.get("use_attr_topk", 30))
