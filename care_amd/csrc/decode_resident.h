@@ -663,14 +663,45 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
         if (wave > 0) continue;
         v = v + ((s_red[par ^ 1][0][lane] + s_red[par ^ 1][1][lane]) + s_red[par ^ 1][2][lane]);
       }
-      if constexpr (EPI == E_VOCAB || EPI == E_VOCABK) {
+      if constexpr (EPI == E_VOCABK) {
+        // beam search: the 16 columns of the wave's tile all exist except in the last item of the matrix (wave-uniform):
+        // no per-element bounds, no column of the maximum (the group number is the lane's), one max3 chain; the sum of
+        // exponentials runs against the lane's running maximum (rescaled when it moves - a later maximum is >= : no overflow)
+        if (active) {
+          const bool full = n0 + 16 <= N;
+          float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+          if (!full) {
+            if (nb + 0 >= N) x0 = -INFINITY;
+            if (nb + 1 >= N) x1 = -INFINITY;
+            if (nb + 2 >= N) x2 = -INFINITY;
+            if (nb + 3 >= N) x3 = -INFINITY;
+          }
+          const float m4 = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+          {  // branch-free insertion of (m4, group) into the sorted list
+            float x = m4;
+            int gx = nb >> 2;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+              const bool gt = x > lv[u][k];
+              const float nl = gt ? x : lv[u][k], nx = gt ? lv[u][k] : x;
+              const int ng = gt ? gx : lg[u][k], ngx = gt ? lg[u][k] : gx;
+              lv[u][k] = nl; lg[u][k] = ng; x = nx; gx = ngx;
+            }
+          }
+          if (m4 > vm[u]) {
+            vs[u] = vm[u] == -INFINITY ? 0.f : vs[u] * fexp(vm[u] - m4);
+            vm[u] = m4;
+          }
+          if (vm[u] != -INFINITY) vs[u] += (fexp(x0 - vm[u]) + fexp(x1 - vm[u])) + (fexp(x2 - vm[u]) + fexp(x3 - vm[u]));
+        }
+      } else if constexpr (EPI == E_VOCAB) {
         if (active) {
           float m4 = -INFINITY;
           int i4 = 0x7fffffff;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (nb + e < N && v[e] > m4) { m4 = v[e]; i4 = nb + e; }
-          if constexpr (EPI == E_VOCABK) {  // branch-free insertion of (m4, group) into the sorted list
+          if constexpr (EPI == E_VOCABK) {  // (unreachable: the beam form is above)
             float x = m4;
             int gx = nb >> 2;
 #pragma unroll
@@ -852,21 +883,32 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
   const int r0 = pm.rt * 16, r = r0 + l16;
   auto k0_of = [&](int c) { return HALF ? ((c & 1) * 4 + wave) * 256 : wave * 512; };
   auto n0_of = [&](int c) { return (HALF ? c >> 1 : c) * 16; };
-  bf16x8 wf[NF];
+  bf16x8 wa[NF], wb[NF];
   const unsigned nprod = pm.np_;
   if (gs.dead) return nprod;
-  if (pm.has) load_w<NF>(wf, W + (int64_t)(n0_of(pm.c0) + l16) * K + k0_of(pm.c0) + kg * 8);
+  // (unconditional, clamped: see gemm_phase's fetch)
+  auto fetchw = [&](bf16x8 (&wf)[NF], int c) {
+    const int cc = min(c, CI - 1);
+    load_w<NF>(wf, W + (int64_t)(n0_of(cc) + l16) * K + k0_of(cc) + kg * 8);
+  };
+  // what an item's epilogue reads from memory, requested BEFORE the next item's weight fragments (vmcnt retires in order)
+  struct Pre { float4 xr, bv; };
+  auto preload = [&](Pre& P, int c) {
+    const int cc = min(c, CI - 1), nb = n0_of(cc) + kg * 4, kh = HALF ? cc & 1 : 0;
+    P.xr = make_float4(0.f, 0.f, 0.f, 0.f);
+    P.bv = *reinterpret_cast<const float4*>(bias + nb);
+    if (wave == 0 && kh == 0 && r < p.R) P.xr = cld_f4(p.xres + (int64_t)r * 512 + nb);
+  };
+  if (pm.has) fetchw(wa, pm.c0);
   if (pm.has) gs.wait();
   if (gs.dead) return nprod;
   gs.mark();
   if (pm.has) {
     int par = 0;
     bool tile_loaded = false;
-    for (int c = pm.c0; c < CI; c += pm.nper, par ^= 1) {
+    auto item = [&](const bf16x8 (&wf)[NF], int c, const Pre& P) {
       const int n0 = n0_of(c), nb = n0 + kg * 4, k0 = k0_of(c), kh = HALF ? c & 1 : 0;
-      if (c != pm.c0) load_w<NF>(wf, W + (int64_t)(n0 + l16) * K + k0 + kg * 8);
-      float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (wave == 0 && kh == 0 && r < p.R) xr = cld_f4(p.xres + (int64_t)r * 512 + nb);
+      const float4 xr = P.xr;
       if (!tile_loaded || HALF) {  // the 16 rows of h (HALF: the K half of this item) -> LDS
         if (tile_loaded) __syncthreads();
         constexpr int KP = HALF ? 1024 : 2048, per_row = KP / 8, NC = 16 * per_row / 256;
@@ -907,10 +949,10 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
       }
       __syncthreads();
       if (wave == 0 && r < p.R) {
+        const float4 bv = P.bv;
         if constexpr (HALF) {
           const f32x4 half = e[0] + ((s_e[par][0][lane] + s_e[par][1][lane]) + s_e[par][2][lane]);
           if (kh == 0) {
-            const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
             cst_f4(p.y + (int64_t)r * 512 + nb, make_float4((half[0] + bv.x) + xr.x, (half[1] + bv.y) + xr.y,
                                                              (half[2] + bv.z) + xr.z, (half[3] + bv.w) + xr.w));
           } else {
@@ -919,10 +961,27 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
         } else {
           const f32x4 half0 = e[0] + ((s_e[par][0][lane] + s_e[par][1][lane]) + s_e[par][2][lane]);
           const f32x4 half1 = s_e[par][3][lane] + ((s_e[par][4][lane] + s_e[par][5][lane]) + s_e[par][6][lane]);
-          const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
           cst_f4(p.y + (int64_t)r * 512 + nb, make_float4(((half0[0] + bv.x) + xr.x) + half1[0], ((half0[1] + bv.y) + xr.y) + half1[1],
                                                            ((half0[2] + bv.z) + xr.z) + half1[2], ((half0[3] + bv.w) + xr.w) + half1[3]));
         }
+      }
+      par ^= 1;
+    };
+    // two sets of weight fragments: the next item's travel while the current one is multiplied (*measured* 640 rows, 5
+    // items per workgroup, each waiting for its own 64 KB from L2: 18 us in this phase)
+    Pre Pa, Pb;
+    preload(Pa, pm.c0);
+    if (pm.c0 + pm.nper >= CI) {
+      item(wa, pm.c0, Pa);
+    } else {
+      for (int c = pm.c0; c < CI; c += 2 * pm.nper) {
+        preload(Pb, c + pm.nper);
+        fetchw(wb, c + pm.nper);
+        item(wa, c, Pa);
+        if (c + pm.nper >= CI) break;
+        preload(Pa, c + 2 * pm.nper);
+        fetchw(wa, c + 2 * pm.nper);
+        item(wb, c + pm.nper, Pb);
       }
     }
   }

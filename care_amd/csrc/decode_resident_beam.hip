@@ -535,16 +535,18 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   hipError_t e = hipGetDevice(&dev);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e != hipSuccess) return (int)e;
-  // The forms by row count (CARE_RESIDENT_BEAM_CFG = 0 / 1 / 2 forces one): up to 64 rows the K-split forms of the
-  // greedy launch; up to 256 rows one row tile per workgroup (two in the vocabulary phase from 128 rows); beyond, several
-  // row tiles per workgroup and weight fetch in every GEMM phase.
+  // The forms by row count (CARE_RESIDENT_BEAM_CFG = 0 .. 3 forces one): up to 64 rows the K-split forms of the
+  // greedy launch; up to 512 rows one row tile per workgroup (two in the vocabulary phase from 128 rows); beyond, several
+  // row tiles per workgroup and weight fetch in every GEMM phase (2 / 2 / 2 / 4: form 3; 4 / 2 / 4 / 4: form 2).
   const ResKnobs& kn = res_knobs();
-  int cfg = rows <= 64 ? 0 : rows <= 256 ? 1 : 2;
-  if (kn.beam_cfg >= 0 && kn.beam_cfg <= 2) cfg = kn.beam_cfg;
+  // (*measured*, us per step of the whole pass, forms 1 / 2 / 3: 260 rows 149 / 162 / 154, 480 rows 161 / 174 / 168,
+  // 640 rows 196 / 193 / 188)
+  int cfg = rows <= 64 ? 0 : rows <= 512 ? 1 : 3;
+  if (kn.beam_cfg >= 0 && kn.beam_cfg <= 3) cfg = kn.beam_cfg;
   if (ff != 2048) cfg = 0;  // (one form for the narrow FFNs)
   const int RT = (int)(R16 / 16), CIV = (V + 63) / 64;
-  const int rv = cfg == 2 ? 4 : (cfg == 1 && rows >= 128 && ff == 2048) ? 2 : 1;
-  const int rq = cfg == 2 ? 4 : 1, rdd = cfg == 2 ? 2 : 1, rf = cfg == 2 ? 4 : 1;
+  const int rv = cfg >= 2 ? 4 : (cfg == 1 && rows >= 128 && ff == 2048) ? 2 : 1;
+  const int rq = cfg == 2 ? 4 : cfg == 3 ? 2 : 1, rdd = cfg >= 2 ? 2 : 1, rf = cfg == 2 ? 4 : cfg == 3 ? 2 : 1;
   const int RG = (RT + rv - 1) / rv;
   int want = RG * CIV;
   if ((rows * heads + 3) / 4 > want) want = (rows * heads + 3) / 4;
@@ -553,7 +555,7 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   grid = (grid + 7) / 8 * 8;  // whole rounds over the 8 XCDs (PhaseMap)
   if (grid > cus) grid = cus;
   // a workgroup per row group of every phase at least (the widest count of row groups: one row tile per workgroup)
-  const int RGmax = cfg == 2 ? (RT + rdd - 1) / rdd : RT;
+  const int RGmax = cfg >= 2 ? (RT + rdd - 1) / rdd : RT;
   if (grid < RGmax) return CARE_ESHAPE;
   // the advance phase merges parts x RES_BMK list entries per row, RES_MAXE per lane: the vocabulary phase runs on the
   // first vcap workgroups only - 6 per (row group, XCD) where the grid allows: 48 partial lists per row (*measured* 1 clip
@@ -586,6 +588,7 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   else if (cfg == 0) RESB_LAUNCH(4, 1, 1, 1, 1, true, true, 2);
   else if (cfg == 1 && rv == 2) RESB_LAUNCH(4, 1, 1, 1, 2, false, true, 3);
   else if (cfg == 1) RESB_LAUNCH(4, 1, 1, 1, 1, false, true, 4);
+  else if (cfg == 3) RESB_LAUNCH(4, 2, 2, 2, 4, false, false, 6);
   else RESB_LAUNCH(4, 4, 2, 4, 4, false, false, 5);
 #undef RESB_LAUNCH
   return care_launch_status();

@@ -597,6 +597,7 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
   // pass 1: v = acc + bias (+ residual) (+ position), row sums
   float rsum[4] = {0.f, 0.f, 0.f, 0.f};
   {
+    int dep = 0;
     int64_t roff[4], poff[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -615,8 +616,8 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
 #pragma unroll
       for (int mt = 2 * mth; mt < 2 * mth + 2; ++mt) {
         if constexpr (EPI == 1) {
-          r[mt][0] = *reinterpret_cast<const float4*>(p.res + roff[mt] + c);
-          r[mt][1] = *reinterpret_cast<const float4*>(p.res + roff[mt] + c + 4);
+          r[mt][0] = *reinterpret_cast<const float4*>(p.res + roff[mt] + c + dep);
+          r[mt][1] = *reinterpret_cast<const float4*>(p.res + roff[mt] + c + 4 + dep);
         }
         if constexpr (EPI == 2) {
           q[mt][0] = *reinterpret_cast<const float4*>(p.pos + poff[mt] + c);
@@ -639,7 +640,13 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
         }
         rsum[mt] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
       }
-      __builtin_amdgcn_sched_barrier(0);  // two rows x one column group of loads in flight at a time (registers)
+      // two rows x one column group of loads in flight at a time (registers).  Neither sched_barrier nor a "memory"
+      // clobber holds the loads of the later groups back (plain loads the kernel never clobbers: the compiler issued all
+      // 32 of them ahead of the first add and, with the 128 accumulators live, spilled half - 88 B of scratch per lane
+      // and a vmcnt(0) per spilled piece).  A data dependency does: `dep` (always 0) is an output of an asm statement
+      // that reads a sum of this group, and part of the next group's addresses.
+      asm volatile("" : "+v"(dep) : "v"(rsum[2 * mth]), "v"(rsum[2 * mth + 1]));
+      __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -678,11 +685,16 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
     rstd[mt] = 1.0f / sqrtf(((t.x + t.y) + (t.z + t.w)) * (1.0f / LN_N) + p.eps);
     orow[mt] = (int64_t)(grow[mt] / p.grp) * p.out_grp_rows + p.out_row_off + (grow[mt] % p.grp);
   }
+  // (the weight / bias pointers pass through an empty asm here: loads through them cannot be hoisted above this point,
+  // i.e. into the first pass, where the 128 accumulators leave no room for them)
+  const float* gam = p.gamma;
+  const float* bet = p.beta;
+  asm volatile("" : "+s"(gam), "+s"(bet));
 #pragma unroll
   for (int pq = 0; pq < 4; ++pq) {
     const int c = col0 + 32 * pq;
-    const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + c), g1 = *reinterpret_cast<const float4*>(p.gamma + c + 4);
-    const float4 e0 = *reinterpret_cast<const float4*>(p.beta + c), e1 = *reinterpret_cast<const float4*>(p.beta + c + 4);
+    const float4 g0 = *reinterpret_cast<const float4*>(gam + c), g1 = *reinterpret_cast<const float4*>(gam + c + 4);
+    const float4 e0 = *reinterpret_cast<const float4*>(bet + c), e1 = *reinterpret_cast<const float4*>(bet + c + 4);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (grow[mt] >= p.M) continue;
