@@ -45,7 +45,11 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in _sources() + _headers())
 
 
-def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
+def build(force: bool = False, verbose: bool = True, jobs: int = 0, out: str = None, flags_extra=(), sources=None) -> str:
+    """out / flags_extra / sources: a VARIANT build (tools: e.g. the fenced hand-offs of the resident decodes,
+    -DRES_FENCED) into a library of its own, objects under .obj/<name>/; the default build is untouched."""
+    if out:
+        return _build_variant(out, list(flags_extra), sources, verbose)
     if not force and not needs_build():
         return LIB
     os.makedirs(OBJ, exist_ok=True)
@@ -75,6 +79,40 @@ def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
     return LIB
 
 
+def _build_variant(out: str, flags_extra, sources, verbose: bool) -> str:
+    name = os.path.splitext(os.path.basename(out))[0]
+    odir = os.path.join(OBJ, name)
+    os.makedirs(odir, exist_ok=True)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"] + list(flags_extra)
+    variant = set(sources or SOURCES)
+    objs, todo = [], []
+    for src in _sources():
+        base = os.path.basename(src)
+        if base in variant:
+            obj = os.path.join(odir, base[:-4] + ".o")
+            todo.append((src, obj))
+        else:  # untouched sources: the default build's objects
+            obj = os.path.join(OBJ, base[:-4] + ".o")
+            if not os.path.exists(obj):
+                raise RuntimeError("run the default build first ({} is missing)".format(obj))
+        objs.append(obj)
+
+    def compile_one(so):
+        cmd = [_hipcc()] + flags + ["-c", so[0], "-o", so[1]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        list(pool.map(compile_one, todo))
+    subprocess.run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", out] + objs, check=True)
+    return out
+
+
 if __name__ == "__main__":
+    if "--fenced" in sys.argv:  # the resident decodes with agent-scope release / acquire fences at every hand-off
+        print(build(out=os.path.join(HERE, "libcare_hip_fenced.so"), flags_extra=["-DRES_FENCED"],
+                    sources=("decode_resident.hip", "decode_resident_beam.hip")))
+        sys.exit(0)
     build(force="--force" in sys.argv)
     print(LIB)

@@ -13,53 +13,79 @@ namespace {
 
 // ------------------------------------------------------------------ LayerNorm backward
 // s = x (+ res); y = (s - mean) * rstd * gamma + beta.  ds = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
-// dgamma += dy * xhat, dbeta += dy (atomics into zero-initialised [d] buffers).  One wave per row, d <= 2048.
+// dgamma += dy * xhat, dbeta += dy into zero-initialised [d] buffers.  One wave per row at a time, LN_BWD_ROWS rows per
+// workgroup: a lane keeps the dgamma / dbeta contributions of its columns in registers over its wave's rows, the four
+// waves meet in LDS, and the workgroup adds ONE value per column to the global sums (the first version issued two
+// atomics per element - 1.9 M onto 512 addresses for [1856, 512]: 90 us per launch, rocprofv3 round 4).  d <= 2048.
+constexpr int LN_BWD_ROWS = 16;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, int64_t ldx, const float* res, int64_t ldres,
                                                      const float* gamma, const float* dy, int64_t lddy, float eps, float* ds,
                                                      int64_t ldds, float* dgamma, float* dbeta, int rows, int d) {
-  const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int MAXC = 32;  // columns per lane: d <= 2048
-  float s[MAXC], g[MAXC];
-  float sum = 0.f;
+  __shared__ float s_dg[3][2048], s_db[3][2048];
+  float ag[MAXC], ab[MAXC];
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    s[i] = 0.f;
-    if (c < d) {
-      s[i] = x[(int64_t)r * ldx + c] + (res ? res[(int64_t)r * ldres + c] : 0.f);
-      sum += s[i];
+  for (int i = 0; i < MAXC; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
+    const int r = blockIdx.x * LN_BWD_ROWS + rr;
+    if (r >= rows) break;  // (wave-uniform)
+    float s[MAXC], g[MAXC];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      s[i] = 0.f;
+      if (c < d) {
+        s[i] = x[(int64_t)r * ldx + c] + (res ? res[(int64_t)r * ldres + c] : 0.f);
+        sum += s[i];
+      }
+    }
+    const float mean = care_wave_sum(sum) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+      if (lane + 64 * i < d) { const float a = s[i] - mean; q += a * a; }
+    const float rstd = 1.0f / sqrtf(care_wave_sum(q) / (float)d + eps);
+    float mg = 0.f, mgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      g[i] = 0.f;
+      if (c < d) {
+        const float xh = (s[i] - mean) * rstd;
+        const float dyv = dy[(int64_t)r * lddy + c];
+        g[i] = dyv * gamma[c];
+        mg += g[i];
+        mgx += g[i] * xh;
+        ag[i] += dyv * xh;
+        ab[i] += dyv;
+        s[i] = xh;
+      }
+    }
+    mg = care_wave_sum(mg) / (float)d;
+    mgx = care_wave_sum(mgx) / (float)d;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d) ds[(int64_t)r * ldds + c] = rstd * (g[i] - mg - s[i] * mgx);
     }
   }
-  const float mean = care_wave_sum(sum) / (float)d;
-  float q = 0.f;
+  if (wave > 0) {
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i)
-    if (lane + 64 * i < d) { const float a = s[i] - mean; q += a * a; }
-  const float rstd = 1.0f / sqrtf(care_wave_sum(q) / (float)d + eps);
-  float mg = 0.f, mgx = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    g[i] = 0.f;
-    if (c < d) {
-      const float xh = (s[i] - mean) * rstd;
-      const float dyv = dy[(int64_t)r * lddy + c];
-      g[i] = dyv * gamma[c];
-      mg += g[i];
-      mgx += g[i] * xh;
-      atomicAdd(dgamma + c, dyv * xh);
-      atomicAdd(dbeta + c, dyv);
-      s[i] = xh;
-    }
+    for (int i = 0; i < MAXC; ++i)
+      if (lane + 64 * i < d) { s_dg[wave - 1][lane + 64 * i] = ag[i]; s_db[wave - 1][lane + 64 * i] = ab[i]; }
   }
-  mg = care_wave_sum(mg) / (float)d;
-  mgx = care_wave_sum(mgx) / (float)d;
+  __syncthreads();
+  if (wave == 0) {
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (c < d) ds[(int64_t)r * ldds + c] = rstd * (g[i] - mg - s[i] * mgx);
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d) {
+        atomicAdd(dgamma + c, ag[i] + ((s_dg[0][c] + s_dg[1][c]) + s_dg[2][c]));
+        atomicAdd(dbeta + c, ab[i] + ((s_db[0][c] + s_db[1][c]) + s_db[2][c]));
+      }
+    }
   }
 }
 
@@ -107,6 +133,36 @@ __global__ void strided_sum_kernel(const float* x, int64_t ldx, float* out, int6
   float s = 0.f;
   for (int k = 0; k < terms; ++k) s += x[((int64_t)r * row_stride + (int64_t)k * term_stride) * ldx + c];
   out[(int64_t)r * ldo + c] = s * scale;
+}
+
+// The same sum for MANY terms per output element (a bias gradient: one output row, terms = every row of dy): the
+// one-thread-per-element kernel above walks its terms in series - 515 us for [1856, 512] -> [512], 8.2 of the 14.2 ms of a
+// training step (rocprofv3, round 4).  Here a workgroup owns (output row, 64 columns): 16 waves, wave w sums terms
+// w, w + 16, ... (64 consecutive floats per wave and term), the 16 partial rows meet in LDS and are added in wave
+// order - the same order every run.
+__global__ __launch_bounds__(1024) void strided_sum_tile_kernel(const float* x, int64_t ldx, float* out, int64_t ldo, int rows, int d,
+                                                                  int terms, int64_t row_stride, int64_t term_stride, float scale) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tiles = (d + 63) >> 6, r = blockIdx.x / tiles, c = (blockIdx.x % tiles) * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < d) {
+    const float* xp = x + (int64_t)r * row_stride * ldx + c;
+    int k = w;
+    for (; k + 16 < terms; k += 32) {  // two independent chains
+      s0 += xp[(int64_t)k * term_stride * ldx];
+      s1 += xp[(int64_t)(k + 16) * term_stride * ldx];
+    }
+    if (k < terms) s0 += xp[(int64_t)k * term_stride * ldx];
+  }
+  part[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && c < d) {
+    float s = part[0][lane];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) s += part[q][lane];
+    out[(int64_t)r * ldo + c] = s * scale;
+  }
 }
 
 // dst[i][c] = scale * src[i / grp][c]  (backward of a mean / sum over groups of `grp` consecutive rows; also a broadcast add's forward operand)
@@ -172,19 +228,27 @@ __device__ __forceinline__ float attn_keep(const AttnBArgs& a, int64_t pidx) {
   return b_uniform(a.seed, (unsigned long long)pidx) >= a.p_drop ? 1.0f / (1.0f - a.p_drop) : 0.f;
 }
 
-// ctx[s, i, 64 h + e] = sum_j keep(i, j) P[s, i, h, j] V[s, j, 64 h + e]: one wave per (sequence, head), lane = e
-__global__ __launch_bounds__(64) void attn_pv_kernel(AttnBArgs a) {
-  const int s = blockIdx.x / a.heads, h = blockIdx.x % a.heads, e = threadIdx.x;
+// ctx[s, i, 64 h + e] = sum_j keep(i, j) P[s, i, h, j] V[s, j, 64 h + e]: one wave per (sequence, head, query i), lane = e.
+// The row of probabilities is fetched (and its dropout mask evaluated) ONCE, key j by lane j % 64, and handed round by
+// readlane; the first version - a wave per (sequence, head) walking all queries, every lane loading and hashing
+// every (i, j) - took 355 us per launch at 64 clips (rocprofv3, round 4).
+__global__ __launch_bounds__(256) void attn_pv_kernel(AttnBArgs a) {
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6), e = threadIdx.x & 63;
+  if (item >= a.nseq * a.heads * a.seq) return;  // (wave-uniform)
+  const int i = item % a.seq, sh = item / a.seq, s = sh / a.heads, h = sh % a.heads;
   const float* Vb = a.V + (int64_t)s * a.kv_bs + h * 64 + e;
-  for (int i = 0; i < a.seq; ++i) {
-    const int64_t prow = ((int64_t)(s * a.seq + i) * a.heads + h) * a.nkeys;
-    float acc = 0.f;
-    for (int j = 0; j < a.nkeys; ++j) {
-      const float pd = a.P[prow + j] * attn_keep(a, prow + j);
-      acc = fmaf(pd, Vb[(int64_t)j * a.kv_rs], acc);
+  const int64_t prow = ((int64_t)(s * a.seq + i) * a.heads + h) * a.nkeys;
+  float acc = 0.f;
+  for (int j0 = 0; j0 < a.nkeys; j0 += 64) {
+    const int j = j0 + e;
+    const float pd = j < a.nkeys ? a.P[prow + j] * attn_keep(a, prow + j) : 0.f;
+    const int n = min(64, a.nkeys - j0);
+    for (int jj = 0; jj < n; ++jj) {
+      const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pd), jj));
+      acc = fmaf(pj, Vb[(int64_t)(j0 + jj) * a.kv_rs], acc);
     }
-    a.ctx[(int64_t)(s * a.seq + i) * a.ldc + h * 64 + e] = acc;
   }
+  a.ctx[(int64_t)(s * a.seq + i) * a.ldc + h * 64 + e] = acc;
 }
 
 // One wave per (sequence, head).  LDS: dS row [nkeys], dK / dV accumulators [nkeys][64].
@@ -258,6 +322,91 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnBArgs a) {
 
 inline unsigned grid1d(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+
+// ------------------------------------------------------------------ C = op(A) B, exact f32, K-major operands
+// The two products of an nn.Linear's backward with the operands as they lie in memory (the first version made
+// .t().contiguous() copies for care_gemm, which multiplies A [M, K] by W [N, K]^T only: 49 copy launches, 0.58 ms of a
+// 5.2 ms step, rocprofv3 round 4):
+//   dx [M, N] = dy [M, K] W [K, N]      (TA = false: A row-major [M, K]);
+//   dW [M, N] = dy^T x, dy [K, M], x [K, N]   (TA = true: A is stored [K, M], the reduction index is its ROW).
+// B is [K, N] row-major in both.  64 x 64 tiles, K steps of 16 through LDS as [k][m] / [k][n] (+ 4 floats of padding),
+// v_mfma_f32_16x16x4_f32 (bit-wise an fp32 fma chain per output), a wave owns 32 x 32 outputs; the next step's tile
+// travels in registers while the current one is multiplied.  Any M, N, K, any leading dimensions (scalar, coalesced loads).
+template <bool TA>
+__global__ __launch_bounds__(256) void gemm_kn_kernel(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                                                       int M, int N, int K) {
+  constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;
+  __shared__ float sA[2][BK][LDT], sB[2][BK][LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ra[4], rb[4];
+  // element q = tid + 256 i of a tile: TA / B: (k = q / 64, c = q % 64) - 64 consecutive floats of a row per wave;
+  // !TA: (m = q / 16, k = q % 16) - 16 consecutive floats of 4 rows per wave-quarter
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i;
+      if constexpr (TA) {
+        const int k = q >> 6, m = q & 63;
+        ra[i] = (k0 + k < K && m0 + m < M) ? A[(int64_t)(k0 + k) * lda + m0 + m] : 0.f;
+      } else {
+        const int m = q >> 4, k = q & 15;
+        ra[i] = (k0 + k < K && m0 + m < M) ? A[(int64_t)(m0 + m) * lda + k0 + k] : 0.f;
+      }
+      const int kb = q >> 6, n = q & 63;
+      rb[i] = (k0 + kb < K && n0 + n < N) ? B[(int64_t)(k0 + kb) * ldb + n0 + n] : 0.f;
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i;
+      if constexpr (TA) sA[buf][q >> 6][q & 63] = ra[i];
+      else sA[buf][q & 15][q >> 4] = ra[i];
+      sB[buf][q >> 6][q & 63] = rb[i];
+    }
+  };
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  const int nk = (K + BK - 1) / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) fetch((kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = sA[buf][kk + kg][wm + 16 * a + l16];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = sB[buf][kk + kg][wn + 16 * b + l16];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    if (kt + 1 < nk) stage(buf ^ 1);
+    __syncthreads();
+  }
+  // D[4 kg + e][l16] of each 16 x 16 tile
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = m0 + wm + 16 * a + 4 * kg + e, c = n0 + wn + 16 * b + l16;
+        if (r < M && c < N) C[(int64_t)r * ldc + c] = acc[a][b][e];
+      }
+}
+
 }  // namespace
 
 extern "C" int care_ln_bwd(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* gamma, const float* dy,
@@ -265,7 +414,7 @@ extern "C" int care_ln_bwd(const float* x, int64_t ldx, const float* res, int64_
                            void* stream) {
   if (!x || !gamma || !dy || !ds || !dgamma || !dbeta || rows <= 0 || d <= 0) return CARE_EINVAL;
   if (d > 2048) return CARE_ESHAPE;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, BST, x, ldx, res, ldres, gamma, dy, lddy, eps, ds, ldds,
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + LN_BWD_ROWS - 1) / LN_BWD_ROWS), dim3(256), 0, BST, x, ldx, res, ldres, gamma, dy, lddy, eps, ds, ldds,
                      dgamma, dbeta, rows, d);
   return care_launch_status();
 }
@@ -286,6 +435,11 @@ extern "C" int care_dropout(const float* x, float* out, int64_t n, float p, uint
 extern "C" int care_strided_sum(const float* x, int64_t ldx, float* out, int64_t ldo, int rows, int d, int terms,
                                 int64_t row_stride, int64_t term_stride, float scale, void* stream) {
   if (!x || !out || rows <= 0 || d <= 0 || terms <= 0) return CARE_EINVAL;
+  if (terms >= 64 && (int64_t)rows * ((d + 63) / 64) < (1 << 20)) {  // few outputs, many terms each: a workgroup per (row, 64 columns)
+    hipLaunchKernelGGL(strided_sum_tile_kernel, dim3(rows * ((d + 63) / 64)), dim3(1024), 0, BST, x, ldx, out, ldo, rows, d, terms,
+                       row_stride, term_stride, scale);
+    return care_launch_status();
+  }
   hipLaunchKernelGGL(strided_sum_kernel, dim3(grid1d((int64_t)rows * d)), dim3(256), 0, BST, x, ldx, out, ldo, rows, d, terms,
                      row_stride, term_stride, scale);
   return care_launch_status();
@@ -326,7 +480,7 @@ extern "C" int care_attn_pv(const float* P, const float* V, int64_t kv_bs, int64
   AttnBArgs a{};
   a.P = P; a.V = V; a.kv_bs = kv_bs; a.kv_rs = kv_rs; a.ctx = ctx; a.ldc = ldc;
   a.nseq = nseq; a.seq = seq; a.nkeys = nkeys; a.heads = heads; a.p_drop = p_drop; a.seed = seed;
-  hipLaunchKernelGGL(attn_pv_kernel, dim3(nseq * heads), dim3(64), 0, BST, a);
+  hipLaunchKernelGGL(attn_pv_kernel, dim3((nseq * heads * seq + 3) / 4), dim3(256), 0, BST, a);
   return care_launch_status();
 }
 
@@ -345,5 +499,16 @@ extern "C" int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const 
   if (lds > 64 * 1024)
     if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel), lds, ok)) return e;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(nseq * heads), dim3(64), lds, BST, a);
+  return care_launch_status();
+}
+
+extern "C" int care_gemm_kn(const float* A, int64_t lda, int a_is_km, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
+                            int N, int K, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return CARE_EINVAL;
+  if (lda < (a_is_km ? M : K) || ldb < N || ldc < N) return CARE_EINVAL;
+  const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+  if (tiles > 0x7fffffff) return CARE_ESHAPE;
+  if (a_is_km) hipLaunchKernelGGL((gemm_kn_kernel<true>), dim3((unsigned)tiles), dim3(256), 0, BST, A, lda, B, ldb, C, ldc, M, N, K);
+  else hipLaunchKernelGGL((gemm_kn_kernel<false>), dim3((unsigned)tiles), dim3(256), 0, BST, A, lda, B, ldb, C, ldc, M, N, K);
   return care_launch_status();
 }

@@ -5,8 +5,8 @@ The reference trains through `LightningModule.training_step` -> `self.captioner(
 PyTorch's autograd recording every op.  Here the same forward is a chain of `torch.autograd.Function`s whose
 forward AND backward are HIP kernels behind the C ABI (include/care_hip.h):
 
-  * every nn.Linear: care_gemm (exact f32 MFMA) forward; backward = the same kernel on transposed operands
-    (dx = dy W, dW = dy^T x) + care_strided_sum for the bias;
+  * every nn.Linear: care_gemm (exact f32 MFMA) forward; backward = care_gemm_kn on the operands as they lie in memory
+    (dx = dy W, dW = dy^T x: no transposed copies) + care_strided_sum for the bias;
   * LayerNorm (+ residual): care_add_ln / care_ln_bwd; activations: care_act; dropout: care_dropout (a counter-based
     generator keyed by (seed, element): the backward re-creates the forward's mask; RNG parity with torch is not a
     goal, SURVEY.md 7.7);
@@ -57,6 +57,15 @@ def _mm(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None) 
     return out
 
 
+def _mm_kn(A: torch.Tensor, B: torch.Tensor, a_is_km: bool) -> torch.Tensor:
+    """op(A) . B with B [K, N]; a_is_km: A is stored [K, M] (care_gemm_kn: the operands as they lie, no transposed copies)."""
+    K, N = B.shape
+    M = A.shape[1] if a_is_km else A.shape[0]
+    out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    call("care_gemm_kn", ptr(A), A.stride(0), int(a_is_km), ptr(B), B.stride(0), ptr(out), N, M, N, K)
+    return out
+
+
 def _strided_sum(x2: torch.Tensor, rows: int, terms: int, row_stride: int, term_stride: int, scale: float = 1.0):
     d = x2.shape[1]
     out = torch.empty(rows, d, device=x2.device, dtype=torch.float32)
@@ -76,8 +85,8 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         dy = _f32c(dy)
-        dx = _mm(dy, W.t().contiguous()) if ctx.needs_input_grad[0] else None
-        dW = _mm(dy.t().contiguous(), x.t().contiguous()) if ctx.needs_input_grad[1] else None
+        dx = _mm_kn(dy, W, False) if ctx.needs_input_grad[0] else None   # dy [M, out] W [out, in]
+        dW = _mm_kn(dy, x, True) if ctx.needs_input_grad[1] else None    # dy^T [out, M] x [M, in]
         db = _strided_sum(dy, 1, dy.shape[0], 0, 1).view(-1) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 17
+#define CARE_ABI_VERSION 18
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -544,6 +544,16 @@ int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, i
                   const float* P, const float* dctx, int64_t ldd, float* dQ, int64_t lddq, float* dK, float* dV,
                   int64_t dkv_bs, int64_t dkv_rs, float* dbias, int bias_ld, int nseq, int seq, int nkeys, int heads,
                   float p_drop, uint64_t seed, void* stream);
+
+/*
+ * care_gemm_kn: C [M, N] = op(A) B in exact f32 (v_mfma_f32_16x16x4_f32), B [K, N] row-major (ldb); a_is_km == 0: A is
+ *   [M, K] row-major (lda), a_is_km != 0: A is stored [K, M] (the reduction index is its row).  The two products of an
+ *   nn.Linear's backward as the operands lie in memory (training mode, models/Wrapper.py:423-435 under autograd):
+ *   dx = dy W (a_is_km = 0, B = the [out, in] weight) and dW = dy^T x (a_is_km = 1, A = dy, B = x).  Any sizes and
+ *   leading dimensions.
+ */
+int care_gemm_kn(const float* A, int64_t lda, int a_is_km, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N,
+                 int K, void* stream);
 
 /*
  * care_decode_resident: the whole greedy decode of a SMALL batch (1 .. a few hundred caption rows) as ONE launch.

@@ -958,3 +958,25 @@ def test_attention_latent_few_rows_is_bit_identical_to_the_streaming_kernel(rows
         s = s + bias[None]
     ref = torch.einsum("rhj,rjc->rhc", torch.softmax(s, -1), mem.float())
     assert (out_big.float() - ref).abs().max().item() < 1.2e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(1856, 512, 10547), (10547, 512, 1856), (64, 64, 16), (1, 1, 1), (70, 33, 50), (512, 2048, 1856)])
+@pytest.mark.parametrize("a_is_km", [False, True])
+def test_gemm_kn_transposed_operands(M, N, K, a_is_km):
+    """care_gemm_kn (the backward products of an nn.Linear on the operands as they lie: dx = dy W, dW = dy^T x) against
+    torch's fp64 product of the same fp32 operands: exact-f32 MFMA sums K terms in fp32, K <= 10547 here."""
+    A = _rand(K, M, seed=1) if a_is_km else _rand(M, K, seed=1)
+    B = _rand(K, N, seed=2)
+    C = torch.full((M, N), float("nan"), device="cuda:0")
+    _call("care_gemm_kn", _p(A), A.stride(0), int(a_is_km), _p(B), B.stride(0), _p(C), N, M, N, K)
+    ref = ((A.t() if a_is_km else A).double() @ B.double())
+    err = (C.double() - ref).abs().max().item()
+    assert err < 2e-6 * math.sqrt(K) * max(1.0, ref.abs().max().item()), err
+    # strided views (leading dimensions beyond the row length)
+    if M >= 64 and K >= 16:
+        Abig = _rand(A.shape[0], A.shape[1] + 5, seed=3)
+        Av = Abig[:, : A.shape[1]]
+        C2 = torch.empty(M, N + 3, device="cuda:0")
+        _call("care_gemm_kn", _p(Av), Av.stride(0), int(a_is_km), _p(B), B.stride(0), _p(C2), C2.stride(0), M, N, K)
+        ref2 = ((Av.t() if a_is_km else Av).double() @ B.double())
+        assert (C2[:, :N].double() - ref2).abs().max().item() < 2e-6 * math.sqrt(K) * max(1.0, ref2.abs().max().item())

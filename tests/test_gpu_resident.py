@@ -189,3 +189,61 @@ def test_resident_barrier_watchdog_aborts_instead_of_hanging():
     assert int(length.min()) >= 1
     _, nfin, _, _, _ = eng.translate_beam(feats, 5, 5, use_graph=False, lean=True)
     assert int(nfin.min()) >= 1 and eng.last_decode.get("resident")
+
+
+def test_resident_launches_under_contention_never_hang():
+    """Two resident launches at a time (two engines, two threads, a HIP stream each) beside a stream of filler kernels
+    that keep the CUs busy: a resident launch needs every one of its workgroups on the chip at once, which nothing
+    guarantees here.  Whatever the scheduler does, every translate_batch call must come back - with the captions of
+    an undisturbed run (a launch that gave up at its watchdog is decoded again by the multi-launch path) - and the
+    whole exercise must end in bounded time: never a hang, never a stale or partial result."""
+    import threading
+    import time
+
+    from care_amd import get_translator
+
+    boost = {"cls_head.tgt_word_prj.weight": {3: 6.0}}
+    jobs = []
+    for config, B, beam in (("msrvtt_base_ami", 96, 1), ("msrvtt_care", 24, 5)):
+        opt, P, model, feats = _setup(config, B, "bf16", boost=boost)
+        opt = dict(opt, beam_size=beam)
+        eng = model.engine()
+        eng.resident_max_rows, eng.resident_beam_max_rows = 128, 640
+        tr = get_translator(opt)
+        want = tr.translate_batch([model], {"feats": feats}, use_graph=False)   # undisturbed
+        assert eng.last_decode.get("resident")
+        jobs.append((tr, model, feats, want))
+    stop = threading.Event()
+    errors, done = [], [0, 0]
+
+    def filler():
+        with torch.cuda.stream(torch.cuda.Stream()):
+            a = torch.randn(4096, 4096, device="cuda:0")
+            while not stop.is_set():
+                for _ in range(20):
+                    a = (a @ a).clamp_(-1.0, 1.0)
+                torch.cuda.current_stream().synchronize()
+
+    def worker(k):
+        tr, model, feats, want = jobs[k]
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(12):
+                    got = tr.translate_batch([model], {"feats": feats}, use_graph=False)
+                    assert got[0] == want[0], "job {}: captions changed under contention".format(k)
+                    done[k] += 1
+        except Exception as exc:  # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(exc)))
+
+    t0 = time.time()
+    threads = [threading.Thread(target=filler)] + [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads[1:]:
+        th.join(timeout=240)
+    stop.set()
+    threads[0].join(timeout=60)
+    torch.cuda.synchronize()
+    assert not any(th.is_alive() for th in threads), "a translate_batch call did not return: {} / {} passes done".format(*done)
+    assert not errors, errors
+    assert done == [12, 12] and time.time() - t0 < 240
