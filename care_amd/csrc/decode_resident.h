@@ -768,8 +768,6 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
       }
     } else {  // the rows of every tile requested before the first one is normalised
       float4 av[RTB][8];
-      LnGB gb;
-      load_gb(gb, g, be);
       // who stores the normalised rows: column slice k by the workgroup of item k when the row group has 8 of them
       const unsigned wmask = (pm.nper >= 8 && CI >= 8) ? (pm.c0 < 8 ? 1u << pm.c0 : 0u) : (pm.c0 == 0 ? 0xffu : 0u);
       int mytok[RTB];
@@ -782,6 +780,8 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
 #pragma unroll
       for (int u = 0; u < RTB; ++u)
         fetch_a_rows<AMODE>(p, r0 + u * 16, t, mytok[u], reinterpret_cast<const float*>(asrc), asrc2, av[u]);
+      LnGB gb;  // (after the rows' requests: the token -> word row chain is what the stage waits for)
+      load_gb(gb, g, be);
 #pragma unroll
       for (int u = 0; u < RTB; ++u) {
         if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;

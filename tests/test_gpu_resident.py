@@ -27,9 +27,11 @@ def _caption_equal(fa, la, fb, lb):
 def test_resident_decode_against_multi_launch_and_oracle(config, B):
     """Peaked (trained-like) logits: the resident form and the multi-launch form (projected cross K/V: the same rounding
     points) must give the same caption wherever the oracle's every step is decided by a clear margin, and nearly
-    always otherwise; scores within the bf16 bar; the resident path must actually have run."""
+    always otherwise (the bars of the multi-launch forms' own audits: at most B // 64 captions may differ, and a
+    differing caption must part from the oracle's at a step its own margin decides by less than GREEDY_TIE_TOL);
+    scores within the bf16 bar; the resident path must actually have run."""
     from oracle import care_cpu
-    from test_gpu_parity import BF16_LSE_PEAKED, CLEAR_MARGIN, _audit_greedy
+    from test_gpu_parity import BF16_LSE_PEAKED, CLEAR_MARGIN, GREEDY_TIE_TOL, _audit_greedy
 
     opt, P, model, feats = _setup(config, B, "bf16", seed=189, boost=PEAKED_ROWS)
     eng = model.engine()
@@ -41,7 +43,7 @@ def test_resident_decode_against_multi_launch_and_oracle(config, B):
     rs = _run(eng, feats, use_graph=False)
     assert eng.last_decode.get("resident") and 1 <= int(eng.last_decode["steps"]) <= eng.T
     same = _caption_equal(rs[0], rs[1], ml[0], ml[1])
-    assert int(same.sum()) >= B - max(1, B // 16), "{} of {} captions differ between the two forms".format(B - int(same.sum()), B)
+    assert int(same.sum()) >= B - max(1, B // 64), "{} of {} captions differ between the two forms".format(B - int(same.sum()), B)
     n = rs[1].clamp(min=1).float()
     assert ((rs[2] - ml[2]).abs() / n)[same].max().item() < 2e-2
     idx = sorted(set(int(i) for i in torch.linspace(0, B - 1, min(B, 12)).round().tolist()))
@@ -56,7 +58,7 @@ def test_resident_decode_against_multi_launch_and_oracle(config, B):
         if h == r:
             assert abs(float(rs[2][i]) / k - scores[j][0]) < BF16_LSE_PEAKED
         else:
-            _audit_greedy(P, opt, {kk: v[j:j + 1] for kk, v in inputs.items()}, h, r, 5e-2)
+            _audit_greedy(P, opt, {kk: v[j:j + 1] for kk, v in inputs.items()}, h, r, GREEDY_TIE_TOL)
 
 
 @pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 100), ("msrvtt_care", 37)])
@@ -247,3 +249,27 @@ def test_resident_launches_under_contention_never_hang():
     assert not any(th.is_alive() for th in threads), "a translate_batch call did not return: {} / {} passes done".format(*done)
     assert not errors, errors
     assert done == [12, 12] and time.time() - t0 < 240
+
+
+def test_unsupported_vocabulary_falls_back_to_the_multi_launch_decode():
+    """A vocabulary beyond the resident kernels' 16384 columns (opts.py takes vocab_size from the corpus): resident_ok /
+    resident_beam_ok say no, small batches decode through the multi-launch path - greedy and beam search - instead of
+    raising CARE_ESHAPE on every call."""
+    from care_amd import get_framework, get_translator
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_feats, synth_state_dict
+
+    opt = make_opt("msrvtt_base_ami", vocab_size=16400)
+    model = get_framework(opt).eval()
+    P = synth_state_dict(3, [(k, tuple(v.shape)) for k, v in model.state_dict().items()],
+                         row_scale={"cls_head.tgt_word_prj.weight": {3: 6.0}})
+    model.load_state_dict(P, strict=True)
+    model.set_compute_dtype("bf16")
+    model.to("cuda:0")
+    eng = model.engine()
+    feats = [f.to("cuda:0") for f in synth_feats(3, feat_shapes(opt, 6))]
+    assert not eng.resident_ok(6) and not eng.resident_beam_ok(6, 5, 5)
+    hyps, scores = get_translator(opt).translate_batch([model], {"feats": feats})
+    assert not eng.last_decode.get("resident") and len(hyps) == 6 and all(1 <= len(h[0]) <= eng.T for h in hyps)
+    hyps5, _ = get_translator(dict(opt, beam_size=5)).translate_batch([model], {"feats": feats})
+    assert not eng.last_decode.get("resident") and len(hyps5) == 6

@@ -254,5 +254,15 @@ def test_small_batch_form_rules(monkeypatch):
         assert not e.resident_ok(8) and not e.small_forms(8), (cfg, dtype)   # d_model 512 + bf16 only
     two = HipEngine(make_opt("msrvtt_base_ami", num_hidden_layers_decoder=2), "bf16")
     assert two.resident_ok(8)
+    # every shape limit of care_decode_resident is checked here, so an unsupported model takes the multi-launch decode
+    # instead of failing on every small batch: a vocabulary beyond 64 x 64 x 4 columns (opts.py takes it from the corpus)
+    big_v = HipEngine(make_opt("msrvtt_base_ami", vocab_size=16385), "bf16")
+    assert not big_v.resident_ok(8) and not big_v.resident_beam_ok(8, 5, 5) and big_v.small_forms(8)
+    assert HipEngine(make_opt("msrvtt_base_ami", vocab_size=16384), "bf16").resident_ok(8)
+    # beam search: rows = clips x beam_size up to resident_beam_max_rows (640), beam_size <= 5
+    assert base.resident_beam_max_rows == 640
+    base.resident_max_rows = 256
+    assert base.resident_beam_ok(128, 5, 5) and not base.resident_beam_ok(129, 5, 5) and not base.resident_beam_ok(4, 6, 6)
+    assert base.resident_beam_ok(1, 5, 8) and not base.resident_beam_ok(1, 1, 1)
     monkeypatch.setenv("CARE_RESIDENT_MAX_ROWS", "64")
     assert HipEngine(make_opt("msrvtt_care"), "bf16").resident_max_rows == 64

@@ -1,0 +1,46 @@
+#!/bin/bash
+# rocprofv3 evidence of the current build (run on the GPU box through gpurun; tools/profiles_post.py turns the output into
+# profiles/<round>_* and regenerates the "Readings" of profiles/README.md):   ROUND=r04 bash tools/profiles.sh
+# Counters are collected in passes of their own (kernel-trace only beside --pmc).
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; ROUND=${ROUND:-r04}; O=$R/gpurun_out/${ROUND}prof; mkdir -p $O
+B="python3 $R/bench.py --no-cpu-baseline --no-legs"
+stats() {  # name, command...: kernel trace with --stats, keeps the summary csv
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o t -- "$@" > $O/$name.log 2>&1
+  f=$(find $O/$name -name "t_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${name}_kernel_stats.csv
+  rm -rf $O/$name
+}
+stats trace $B --steps 5 --warmup 2
+stats trace_vatex $B --steps 5 --warmup 2 --config vatex_care_large --batch 4096
+stats greedy_B128 $B --batch 128 --steps 20 --warmup 3
+stats greedy_B1 $B --batch 1 --steps 20 --warmup 3
+stats beam5_B128 $B --batch 128 --beam 5 --config msrvtt_care_beam5 --steps 20 --warmup 3
+stats beam5_B1 $B --batch 1 --beam 5 --config msrvtt_care_beam5 --steps 20 --warmup 3
+stats train_B64 python3 $R/tools/train_prof.py 64 10
+pmc() {  # name, counters, command...
+  local name=$1 ctr=$2; shift 2
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$name -o t -- "$@" > $O/$name.log 2>&1
+  f=$(find $O/$name -name "t_counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 - "$f" > $O/${name}_counters.txt <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    acc[r["Kernel_Name"][:120]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in acc.items():
+    for c, v in sorted(cs.items()):
+        print("%s\t%s\t%.1f\t%d" % (k, c, sum(v) / len(v), len(v)))
+PY
+  rm -rf $O/$name
+}
+pmc fetch FETCH_SIZE $B --steps 1 --warmup 2 --no-graph
+pmc write WRITE_SIZE $B --steps 1 --warmup 2 --no-graph
+pmc sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" python3 $R/tools/pmc_target.py 32768
+pmc sq_resident "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_IFETCH" python3 $R/bench.py --no-cpu-baseline --no-legs --batch 128 --beam 5 --config msrvtt_care_beam5 --steps 3 --warmup 2 --no-graph
+pmc icache_resident "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" python3 $R/bench.py --no-cpu-baseline --no-legs --batch 128 --beam 5 --config msrvtt_care_beam5 --steps 3 --warmup 2 --no-graph
+cd $R
+python3 tools/resident_prof.py 1 128 > $O/resident_phase_clocks.txt 2>&1
+python3 tools/resident_prof.py --beam 5 --config msrvtt_care 1 128 >> $O/resident_phase_clocks.txt 2>&1
+python3 tools/beam_sweep.py > $O/beam_sweep.txt 2>&1
+tail -1 $O/trace.log | cut -c1-200
+ls -la $O

@@ -1,0 +1,181 @@
+"""gpurun_out/<round>prof/* (tools/profiles.sh) -> profiles/<round>_*, and the "Readings" section of profiles/README.md
+REGENERATED from the committed files (so the text cannot drift from the data):
+
+    python tools/profiles_post.py [round]          # default r04; copies + regenerates
+    python tools/profiles_post.py [round] --readme # only regenerate the readings from profiles/<round>_*
+"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = next((a for a in sys.argv[1:] if not a.startswith("-")), "r04")
+SRC = os.path.join(ROOT, "gpurun_out", ROUND + "prof")
+DST = os.path.join(ROOT, "profiles")
+head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+
+STATS = {"trace": "bench_B32768_bf16", "trace_vatex": "vatex_care_large_B4096_bf16", "greedy_B128": "small_batch_greedy_B128",
+         "greedy_B1": "small_batch_greedy_B1", "beam5_B128": "small_batch_beam5_B128", "beam5_B1": "small_batch_beam5_B1",
+         "train_B64": "training_step_B64"}
+ours = lambda k: "anonymous namespace" in k and "at::native" not in k
+
+
+def counters(name):
+    acc = collections.defaultdict(dict)
+    path = os.path.join(SRC, name + "_counters.txt")
+    if not os.path.exists(path):
+        return acc
+    for line in open(path):
+        k, c, v, n = line.rstrip("\n").split("\t")
+        acc[k][c] = (float(v), int(n))
+    return acc
+
+
+def copy_in():
+    for src, dst in STATS.items():
+        f = os.path.join(SRC, src + "_kernel_stats.csv")
+        if os.path.exists(f):
+            shutil.copy(f, os.path.join(DST, "{}_{}_kernel_stats.csv".format(ROUND, dst)))
+    for name in ("resident_phase_clocks.txt", "beam_sweep.txt"):
+        f = os.path.join(SRC, name)
+        if os.path.exists(f):
+            txt = "".join(l for l in open(f) if "amdgpu.ids" not in l)
+            open(os.path.join(DST, "{}_{}".format(ROUND, name)), "w").write("# build {}\n".format(head) + txt)
+    fetch, write = counters("fetch"), counters("write")
+    if fetch or write:
+        pm = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --no-cpu-baseline --no-legs --steps 1 --warmup 2 "
+                         "--no-graph; a second pass with --pmc WRITE_SIZE (tools/profiles.sh)",
+              "build": head,
+              "note": "average per launch, KB as rocprofv3 reports them; hbm_bytes = 2 x FETCH_SIZE (gfx950 tallies wide 16-B/lane "
+                      "streaming reads at half, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, x 1024",
+              "kernels": []}
+        for k in sorted(set(fetch) | set(write)):
+            if not ours(k):
+                continue
+            f = fetch.get(k, {}).get("FETCH_SIZE", (0.0, 0))
+            w = write.get(k, {}).get("WRITE_SIZE", (0.0, 0))
+            pm["kernels"].append(dict(kernel=k, launches=max(f[1], w[1]), FETCH_SIZE_KB=round(f[0], 1), WRITE_SIZE_KB=round(w[0], 1),
+                                      hbm_bytes=int((2 * f[0] + w[0]) * 1024)))
+        json.dump(pm, open(os.path.join(DST, ROUND + "_bench_B32768_bf16_pmc_fetch_write.json"), "w"), indent=1)
+        # bench.py reads the dominant kernel's traffic from profiles/traffic.json
+        tj_path = os.path.join(DST, "traffic.json")
+        tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+        for e in pm["kernels"]:
+            if "attention_latent_kernel<4, 2>" in e["kernel"] or "attention_latent_kernel<4,2>" in e["kernel"]:
+                tj["msrvtt_base_ami|bf16|B32768|step_cross_attn"] = e["hbm_bytes"]
+        json.dump(tj, open(tj_path, "w"), indent=1)
+    for tag, fname, cmd in (("sq", "_sq_counters.json", "python3 tools/pmc_target.py 32768"),
+                            ("sq_resident", "_sq_counters_resident_beam5_B128.json",
+                             "python3 bench.py --batch 128 --beam 5 --config msrvtt_care_beam5 --no-graph"),
+                            ("icache_resident", "_icache_resident_beam5_B128.json",
+                             "python3 bench.py --batch 128 --beam 5 --config msrvtt_care_beam5 --no-graph")):
+        sq = counters(tag)
+        if not sq:
+            continue
+        out = {"command": "rocprofv3 --pmc <counters below> --kernel-trace -- " + cmd, "build": head,
+               "note": "average per launch.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are summed over waves; parked = SQ_WAIT_ANY / "
+                       "SQ_WAVE_CYCLES (waves at s_waitcnt / barriers / sleeping polls), issue_stall = SQ_WAIT_INST_ANY / "
+                       "SQ_WAVE_CYCLES, active = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES", "kernels": []}
+        for k, cs in sq.items():
+            if not ours(k):
+                continue
+            ent = dict(kernel=k, launches=next(iter(cs.values()))[1])
+            for c, (v, _) in sorted(cs.items()):
+                ent[c] = int(v)
+            wc = max(ent.get("SQ_WAVE_CYCLES", 0), 1)
+            if "SQ_WAVE_CYCLES" in ent:
+                ent["parked_frac"] = round(ent.get("SQ_WAIT_ANY", 0) / wc, 3)
+                ent["issue_stall_frac"] = round(ent.get("SQ_WAIT_INST_ANY", 0) / wc, 3)
+                ent["active_frac"] = round(ent.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3)
+            out["kernels"].append(ent)
+        json.dump(out, open(os.path.join(DST, ROUND + fname), "w"), indent=1)
+
+
+def kernel_stats(name):
+    path = os.path.join(DST, "{}_{}_kernel_stats.csv".format(ROUND, name))
+    if not os.path.exists(path):
+        return []
+    return list(csv.DictReader(open(path)))
+
+
+def short(k):
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "")
+    return re.sub(r"\(.*$", "", k)[:80]
+
+
+def readings():
+    L = ["## Round {} - readings (GENERATED by tools/profiles_post.py from the files of this directory; do not edit)".format(ROUND[1:].lstrip("0")), ""]
+    rows = kernel_stats("bench_B32768_bf16")
+    if rows:
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        L += ["`{}_bench_B32768_bf16_kernel_stats.csv` (`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-legs "
+              "--steps 5 --warmup 2`), our kernels by total time:".format(ROUND), "", "| kernel | calls | average us | share |", "|---|---|---|---|"]
+        for r in rows[:14]:
+            L.append("| `{}` | {} | {:.1f} | {:.1f} % |".format(short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                                 100 * float(r["TotalDurationNs"]) / tot))
+        L.append("")
+        dom = next((r for r in rows if "attention_latent_kernel<4, 2>" in r["Name"] or "attention_latent_kernel<4,2>" in r["Name"]), None)
+        pj = os.path.join(DST, ROUND + "_bench_B32768_bf16_pmc_fetch_write.json")
+        if dom and os.path.exists(pj):
+            e = next((k for k in json.load(open(pj))["kernels"] if "attention_latent_kernel<4" in k["kernel"]), None)
+            alg = 32768 * (84 * 512 * 2 + 2 * 8 * 512 * 2)
+            us = float(dom["AverageNs"]) / 1e3
+            L.append("Dominant kernel `attention_latent_kernel<4, 2>`: {:.1f} us average over {} launches in the trace = {:.2f} TB/s of the "
+                     "{:,} algorithmic bytes = **{:.3f} of the 8 TB/s peak**{}.".format(
+                         us, dom["Calls"], alg / us / 1e6, alg, alg / us / 1e6 / 8.0,
+                         "; PMC traffic {:,} B per launch = {:.4f} x algorithmic".format(e["hbm_bytes"], e["hbm_bytes"] / alg) if e else ""))
+            L.append("")
+    for name, what in (("small_batch_greedy_B1", "greedy, 1 clip"), ("small_batch_greedy_B128", "greedy, 128 clips"),
+                       ("small_batch_beam5_B1", "beam 5, 1 clip"), ("small_batch_beam5_B128", "beam 5, 128 clips (640 rows)")):
+        rows = kernel_stats(name)
+        r = next((r for r in rows if "decode_resident" in r["Name"]), None)
+        if r:
+            L.append("`{}_{}_kernel_stats.csv` ({}): `{}` {:.1f} us per launch = {:.1f} us per decoder step of 29 ({} launches).".format(
+                ROUND, name, what, short(r["Name"]), float(r["AverageNs"]) / 1e3, float(r["AverageNs"]) / 29e3, r["Calls"]))
+    rows = kernel_stats("training_step_B64")
+    if rows:
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        calls = sum(int(r["Calls"]) for r in rows)
+        L += ["", "`{}_training_step_B64_kernel_stats.csv` (`tools/train_prof.py 64 10`: 13 steps): {:.2f} ms of kernels and {:.0f} launches per "
+              "training step; top: ".format(ROUND, tot / 13 / 1e6, calls / 13) +
+              ", ".join("`{}` {:.2f} ms".format(short(r["Name"])[:40], float(r["TotalDurationNs"]) / 13 / 1e6) for r in rows[:5]) + "."]
+    for fname, title in ((ROUND + "_sq_counters.json", "SQ counters at 32768 rows (tools/pmc_target.py)"),
+                         (ROUND + "_sq_counters_resident_beam5_B128.json", "SQ counters of the resident beam launch (128 clips x 5)")):
+        path = os.path.join(DST, fname)
+        if os.path.exists(path):
+            L += ["", "`{}` - {}:".format(fname, title), "", "| kernel | parked | issue-stalled | issuing | LDS bank-conflict cycles |", "|---|---|---|---|---|"]
+            for e in json.load(open(path))["kernels"]:
+                if "parked_frac" in e:
+                    L.append("| `{}` | {:.0%} | {:.0%} | {:.0%} | {} |".format(short(e["kernel"]), e["parked_frac"], e["issue_stall_frac"],
+                                                                        e["active_frac"], e.get("SQ_LDS_BANK_CONFLICT", "-")))
+    path = os.path.join(DST, ROUND + "_icache_resident_beam5_B128.json")
+    if os.path.exists(path):
+        for e in json.load(open(path))["kernels"]:
+            if "SQC_ICACHE_REQ" in e:
+                L += ["", "`{}_icache_resident_beam5_B128.json`: `{}` {:,} instruction-cache requests per launch, {:,} misses + {:,} duplicate "
+                      "misses ({:.2%}).".format(ROUND, short(e["kernel"]), e["SQC_ICACHE_REQ"], e.get("SQC_ICACHE_MISSES", 0),
+                                                e.get("SQC_ICACHE_MISSES_DUPLICATE", 0),
+                                                (e.get("SQC_ICACHE_MISSES", 0) + e.get("SQC_ICACHE_MISSES_DUPLICATE", 0)) / max(e["SQC_ICACHE_REQ"], 1))]
+    for name in ("resident_phase_clocks.txt", "beam_sweep.txt"):
+        if os.path.exists(os.path.join(DST, "{}_{}".format(ROUND, name))):
+            L += ["", "`{}_{}`: {}".format(ROUND, name, "device clock at every phase boundary of decoder step 3, workgroup 0 (tools/resident_prof.py)"
+                                           if "phase" in name else "resident launch against the multi-launch search, whole passes (tools/beam_sweep.py)")]
+    return "\n".join(L) + "\n"
+
+
+if "--readme" not in sys.argv:
+    copy_in()
+path = os.path.join(DST, "README.md")
+txt = open(path).read()
+marker = "## Round {} - readings (GENERATED".format(ROUND[1:].lstrip("0"))
+if marker in txt:
+    txt = txt[: txt.index(marker)].rstrip() + "\n\n"
+else:
+    txt = txt.rstrip() + "\n\n"
+open(path, "w").write(txt + readings())
+print("profiles/README.md: readings of", ROUND, "regenerated")
