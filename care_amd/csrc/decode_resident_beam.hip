@@ -57,7 +57,13 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
   gs.mark();
   const int32_t* anc_old = p.anc[(t - 1) & 1];
   int32_t* anc_new = p.anc[t & 1];
-  const int NE = p.parts * RES_BMK, NEL = (NE + 63) >> 6;
+  // Few row tiles (one clip x beam 5 = ONE tile): the vocabulary phase runs on every workgroup the matrix has column
+  // items for (165 partial lists per row; capped at 48 it took 13 instead of 5 us), and the lists are fetched in TWO
+  // steps: the row's best bm PARTS first - a part's list is sorted, so every group at least as large as the bm-th
+  // largest list head sits in one of the bm parts with the largest heads (the heads = the partial maxima the log-sum-exp
+  // reads anyway) - then those bm x RES_BMK entries.  One more dependent fetch, 25 entries instead of 825.
+  const bool two_step = p.parts * RES_BMK > 64 * RES_MAXE;
+  const int NE = two_step ? RES_BMK * RES_BMK : p.parts * RES_BMK, NEL = (NE + 63) >> 6;
   for (int c = blockIdx.x; c < p.nclips; c += G) {
     const int row0 = c * bm;
     // ---- the advance wave's state, requested before anything else (lane = position j of the tables)
@@ -89,15 +95,46 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
         in[s].ps[k] = cld_f(p.psum + (int64_t)r * p.parts + (ok ? cpart : 0));
         if (!ok) { in[s].pm[k] = -INFINITY; in[s].ps[k] = 0.f; }
       }
+      if (!two_step) {
 #pragma unroll
-      for (int k = 0; k < RES_MAXE; ++k)
-        if (k < NEL) {
-          const int e = lane + 64 * k;
-          const bool ok = e < NE;
-          in[s].ev[k] = cld_f(p.gval + (int64_t)r * NE + (ok ? e : 0));
-          in[s].eg[k] = cld_i(p.ggid + (int64_t)r * NE + (ok ? e : 0));
-          if (!ok) { in[s].ev[k] = -INFINITY; in[s].eg[k] = 0x7fffffff; }
+        for (int k = 0; k < RES_MAXE; ++k)
+          if (k < NEL) {
+            const int e = lane + 64 * k;
+            const bool ok = e < NE;
+            in[s].ev[k] = cld_f(p.gval + (int64_t)r * NE + (ok ? e : 0));
+            in[s].eg[k] = cld_i(p.ggid + (int64_t)r * NE + (ok ? e : 0));
+            if (!ok) { in[s].ev[k] = -INFINITY; in[s].eg[k] = 0x7fffffff; }
+          }
+      }
+    }
+    if (two_step) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int i = wave + 4 * s;
+        if (i >= bm) break;  // (wave-uniform)
+        const int r = row0 + i;
+        // the bm parts with the largest heads (value desc, part asc: a lower part holds lower columns)
+        unsigned long long hk[RES_NP];
+#pragma unroll
+        for (int k = 0; k < RES_NP; ++k) hk[k] = in[s].pm[k] == -INFINITY ? 0ull : key_of(in[s].pm[k], (unsigned)(lane + 64 * k));
+        int myp = 0;  // lane j < bm * RES_BMK fetches entry j % RES_BMK of the (j / RES_BMK)-th best part
+#pragma unroll
+        for (int k = 0; k < RES_BMK; ++k) {
+          unsigned long long loc = hk[0];
+#pragma unroll
+          for (int q = 1; q < RES_NP; ++q) loc = max_u64(loc, hk[q]);
+          const unsigned long long best = wave_max_u64(loc);
+#pragma unroll
+          for (int q = 0; q < RES_NP; ++q)
+            if (hk[q] == best) hk[q] = 0ull;
+          if (lane / RES_BMK == k) myp = best ? (int)key_idx(best) : -1;
         }
+        const bool ok = lane < RES_BMK * RES_BMK && myp >= 0;
+        const int64_t o = ((int64_t)r * p.parts + (ok ? myp : 0)) * RES_BMK + lane % RES_BMK;
+        in[s].ev[0] = cld_f(p.gval + o);
+        in[s].eg[0] = cld_i(p.ggid + o);
+        if (!ok) { in[s].ev[0] = -INFINITY; in[s].eg[0] = 0x7fffffff; }
+      }
     }
     // The three stages of a row, as lambdas so that a wave with two rows can run the second row's group selection while
     // the first row's weight fragments travel:
@@ -474,7 +511,7 @@ int64_t care_decode_resident_beam_scratch(int clips, int beam, int d, int ff, in
   if (clips < 1 || beam < 1 || d < 1 || ff < 1 || V < 1) return CARE_EINVAL;
   const int64_t rows = (int64_t)clips * beam, R16 = (rows + 15) / 16 * 16;
   int64_t parts = (V + 63) / 64;
-  if (parts > 64 * RES_MAXE / RES_BMK) parts = 64 * RES_MAXE / RES_BMK;
+  if (parts > 64 * RES_NP) parts = 64 * RES_NP;
   // sync | xres, y, y2, q fp32 [R16, d] | ctx bf16 [R16, d] | h bf16 [R16, ff] | pmax, pidx, psum [R16, parts] |
   // gval, ggid [R16, parts, RES_BMK] | hn bf16 [R16, d]
   return RES_SYNC_BYTES + R16 * d * 4 * 4 + R16 * d * 2 + R16 * ff * 2 + R16 * parts * 12 + R16 * parts * RES_BMK * 8 + R16 * d * 2;
@@ -515,7 +552,7 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   p.anc[0] = anc0; p.anc[1] = anc1; p.done = done; p.nfin = nfin; p.fscore = fscore; p.flen = flen; p.fhyp = fhyp;
   const int64_t R16 = (rows + 15) / 16 * 16;
   int64_t maxparts = (V + 63) / 64;
-  if (maxparts > 64 * RES_MAXE / RES_BMK) maxparts = 64 * RES_MAXE / RES_BMK;
+  if (maxparts > 64 * RES_NP) maxparts = 64 * RES_NP;
   unsigned char* b = (unsigned char*)scratch;
   p.sync = (unsigned*)b; b += RES_SYNC_BYTES;
   p.xres = (float*)b; b += R16 * d * 4;
@@ -560,7 +597,8 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   // the advance phase merges parts x RES_BMK list entries per row, RES_MAXE per lane: the vocabulary phase runs on the
   // first vcap workgroups only - 6 per (row group, XCD) where the grid allows: 48 partial lists per row (*measured* 1 clip
   // x beam 5: 165 lists per row made the advance phase 25 us)
-  int vcap = 48 * RG < grid ? 48 * RG : grid;
+  // ... a single row group (<= 16 rows at one tile per workgroup) takes every workgroup and the two-step fetch instead
+  int vcap = RG == 1 ? grid : (48 * RG < grid ? 48 * RG : grid);
   while (vcap > 8 && beam_parts(vcap, RG, CIV) > maxparts) vcap -= 8;
   p.vcap = vcap;
   p.parts = beam_parts(vcap, RG, CIV);
