@@ -329,48 +329,48 @@ inline unsigned grid1d(int64_t n) { return (unsigned)((n + 255) / 256); }
 // 5.2 ms step, rocprofv3 round 4):
 //   dx [M, N] = dy [M, K] W [K, N]      (TA = false: A row-major [M, K]);
 //   dW [M, N] = dy^T x, dy [K, M], x [K, N]   (TA = true: A is stored [K, M], the reduction index is its ROW).
-// B is [K, N] row-major in both.  64 x 64 tiles, K steps of 16 through LDS as [k][m] / [k][n] (+ 4 floats of padding),
-// v_mfma_f32_16x16x4_f32 (bit-wise an fp32 fma chain per output), a wave owns 32 x 32 outputs; the next step's tile
+// B is [K, N] row-major in both.  64 x 64 or 128 x 128 tiles, K steps of 16 through LDS as [k][m] / [k][n] (+ 4 floats of padding),
+// v_mfma_f32_16x16x4_f32 (bit-wise an fp32 fma chain per output), a wave owns a quarter of the tile; the next step's tile
 // travels in registers while the current one is multiplied.  Any M, N, K, any leading dimensions (scalar, coalesced loads).
-template <bool TA>
+template <bool TA, int BT>  // BT x BT output tiles (64 or 128): a wave owns (BT / 2) x (BT / 2) outputs
 __global__ __launch_bounds__(256) void gemm_kn_kernel(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                                                        int M, int N, int K) {
-  constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;
+  constexpr int BM = BT, BN = BT, BK = 16, LDT = BT + 4, NT = BT / 32, NL = BT * BK / 256;  // NT 16 x 16 tiles per wave and side
   __shared__ float sA[2][BK][LDT], sB[2][BK][LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
   const int tiles_n = (N + BN - 1) / BN;
   const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  f32x4 acc[2][2];
+  const int wm = (wave >> 1) * (BT / 2), wn = (wave & 1) * (BT / 2);
+  f32x4 acc[NT][NT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ra[4], rb[4];
-  // element q = tid + 256 i of a tile: TA / B: (k = q / 64, c = q % 64) - 64 consecutive floats of a row per wave;
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ra[NL], rb[NL];
+  // element q = tid + 256 i of a tile: TA / B: (k = q / BT, c = q % BT) - consecutive floats of a row per wave;
   // !TA: (m = q / 16, k = q % 16) - 16 consecutive floats of 4 rows per wave-quarter
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int q = tid + 256 * i;
       if constexpr (TA) {
-        const int k = q >> 6, m = q & 63;
+        const int k = q / BT, m = q % BT;
         ra[i] = (k0 + k < K && m0 + m < M) ? A[(int64_t)(k0 + k) * lda + m0 + m] : 0.f;
       } else {
         const int m = q >> 4, k = q & 15;
         ra[i] = (k0 + k < K && m0 + m < M) ? A[(int64_t)(m0 + m) * lda + k0 + k] : 0.f;
       }
-      const int kb = q >> 6, n = q & 63;
+      const int kb = q / BT, n = q % BT;
       rb[i] = (k0 + kb < K && n0 + n < N) ? B[(int64_t)(k0 + kb) * ldb + n0 + n] : 0.f;
     }
   };
   auto stage = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int q = tid + 256 * i;
-      if constexpr (TA) sA[buf][q >> 6][q & 63] = ra[i];
+      if constexpr (TA) sA[buf][q / BT][q % BT] = ra[i];
       else sA[buf][q & 15][q >> 4] = ra[i];
-      sB[buf][q >> 6][q & 63] = rb[i];
+      sB[buf][q / BT][q % BT] = rb[i];
     }
   };
   fetch(0);
@@ -382,24 +382,24 @@ __global__ __launch_bounds__(256) void gemm_kn_kernel(const float* A, int64_t ld
     if (kt + 1 < nk) fetch((kt + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-      float fa[2], fb[2];
+      float fa[NT], fb[NT];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = sA[buf][kk + kg][wm + 16 * a + l16];
+      for (int a = 0; a < NT; ++a) fa[a] = sA[buf][kk + kg][wm + 16 * a + l16];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) fb[b] = sB[buf][kk + kg][wn + 16 * b + l16];
+      for (int b = 0; b < NT; ++b) fb[b] = sB[buf][kk + kg][wn + 16 * b + l16];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
     if (kt + 1 < nk) stage(buf ^ 1);
     __syncthreads();
   }
   // D[4 kg + e][l16] of each 16 x 16 tile
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = m0 + wm + 16 * a + 4 * kg + e, c = n0 + wn + 16 * b + l16;
@@ -506,9 +506,14 @@ extern "C" int care_gemm_kn(const float* A, int64_t lda, int a_is_km, const floa
                             int N, int K, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return CARE_EINVAL;
   if (lda < (a_is_km ? M : K) || ldb < N || ldc < N) return CARE_EINVAL;
-  const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+  // 128 x 128 tiles where they fill the chip (16 flop per loaded byte at 64 x 64: the vocabulary-sized dW ran at 28 TFLOP/s)
+  const int64_t big = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+  const int bt = big >= 200 ? 128 : 64;
+  const int64_t tiles = (int64_t)((M + bt - 1) / bt) * ((N + bt - 1) / bt);
   if (tiles > 0x7fffffff) return CARE_ESHAPE;
-  if (a_is_km) hipLaunchKernelGGL((gemm_kn_kernel<true>), dim3((unsigned)tiles), dim3(256), 0, BST, A, lda, B, ldb, C, ldc, M, N, K);
-  else hipLaunchKernelGGL((gemm_kn_kernel<false>), dim3((unsigned)tiles), dim3(256), 0, BST, A, lda, B, ldb, C, ldc, M, N, K);
+#define KN_LAUNCH(TA, BT) hipLaunchKernelGGL((gemm_kn_kernel<TA, BT>), dim3((unsigned)tiles), dim3(256), 0, BST, A, lda, B, ldb, C, ldc, M, N, K)
+  if (a_is_km) { if (bt == 128) KN_LAUNCH(true, 128); else KN_LAUNCH(true, 64); }
+  else { if (bt == 128) KN_LAUNCH(false, 128); else KN_LAUNCH(false, 64); }
+#undef KN_LAUNCH
   return care_launch_status();
 }

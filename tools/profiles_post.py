@@ -150,13 +150,15 @@ def readings():
         if os.path.exists(path):
             L += ["", "`{}` - {}:".format(fname, title), "", "| kernel | parked | issue-stalled | issuing | LDS bank-conflict cycles |", "|---|---|---|---|---|"]
             for e in json.load(open(path))["kernels"]:
+                if "resident" in fname and "decode_resident" not in e["kernel"]:
+                    continue
                 if "parked_frac" in e:
                     L.append("| `{}` | {:.0%} | {:.0%} | {:.0%} | {} |".format(short(e["kernel"]), e["parked_frac"], e["issue_stall_frac"],
                                                                         e["active_frac"], e.get("SQ_LDS_BANK_CONFLICT", "-")))
     path = os.path.join(DST, ROUND + "_icache_resident_beam5_B128.json")
     if os.path.exists(path):
         for e in json.load(open(path))["kernels"]:
-            if "SQC_ICACHE_REQ" in e:
+            if "SQC_ICACHE_REQ" in e and "decode_resident" in e["kernel"]:
                 L += ["", "`{}_icache_resident_beam5_B128.json`: `{}` {:,} instruction-cache requests per launch, {:,} misses + {:,} duplicate "
                       "misses ({:.2%}).".format(ROUND, short(e["kernel"]), e["SQC_ICACHE_REQ"], e.get("SQC_ICACHE_MISSES", 0),
                                                 e.get("SQC_ICACHE_MISSES_DUPLICATE", 0),
