@@ -413,43 +413,45 @@ __device__ __forceinline__ int fetch_token(const RArgs& p, int r0, int t, bool w
   }
 }
 
-template <int AMODE>
+template <int AMODE, int D = 512>
 __device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, int mytok, const float* ysrc, const float* ysrc2,
-                                             float4 (&v)[8]) {
+                                             float4 (&v)[D / 64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, sub = lane & 15;
-  constexpr int d = 512;
+  constexpr int d = D, NV = D / 64;
   const int rb = r0 + wave * 4, row = rb + q, rc = row < p.R ? row : 0;
   if constexpr (AMODE == A_EMBED || AMODE == A_EMBEDB) {
     const float* pp = p.pos + (int64_t)(t - 1) * d + sub * 4;
     const float* w = p.word + (int64_t)mytok * d + sub * 4;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NV; ++k) {
       v[k] = *reinterpret_cast<const float4*>(w + 64 * k);
       add4(v[k], *reinterpret_cast<const float4*>(pp + 64 * k));
     }
     if (p.sem) {
       const float* sm = p.sem + (int64_t)(rc / p.sem_div) * d + sub * 4;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) add4(v[k], *reinterpret_cast<const float4*>(sm + 64 * k));
+      for (int k = 0; k < NV; ++k) add4(v[k], *reinterpret_cast<const float4*>(sm + 64 * k));
     }
   } else {
     const float* y = ysrc + (int64_t)rc * d + sub * 4;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = cld_f4(y + 64 * k);
+    for (int k = 0; k < NV; ++k) v[k] = cld_f4(y + 64 * k);
     if (ysrc2) {  // the second K half of a two-workgroup FFN dense2 (ffn2_phase<true>): y = y + y2
       const float* y2 = ysrc2 + (int64_t)rc * d + sub * 4;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) add4(v[k], cld_f4(y2 + 64 * k));
+      for (int k = 0; k < NV; ++k) add4(v[k], cld_f4(y2 + 64 * k));
     }
   }
 }
 
 // ... and their LayerNorm into the LDS tile (+ the fp32 rows for the residual when write_x, + the bf16 rows when write_hn)
-struct LnGB { float4 g[8], b[8]; };  // this lane's columns of the LayerNorm weight / bias
-__device__ __forceinline__ void load_gb(LnGB& w, const float* g, const float* be) {
+template <int D = 512>
+struct LnGB { float4 g[D / 64], b[D / 64]; };  // this lane's columns of the LayerNorm weight / bias
+template <int D = 512>
+__device__ __forceinline__ void load_gb(LnGB<D>& w, const float* g, const float* be) {
   const int sub = threadIdx.x & 15;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < D / 64; ++k) {
     w.g[k] = *reinterpret_cast<const float4*>(g + sub * 4 + 64 * k);
     w.b[k] = *reinterpret_cast<const float4*>(be + sub * 4 + 64 * k);
   }
@@ -460,19 +462,20 @@ __device__ __forceinline__ void load_gb(LnGB& w, const float* g, const float* be
 // the fp32 rows (the residual of the phase after next) / the bf16 rows (beam search: the advance phase's B operand).  The
 // first 8 workgroups of a row group take a slice each (gemm_phase): one workgroup writing all 2 KB of every row in
 // write-through stores was what the phase's consumers waited for (*measured* 640 rows: 17.6 us in the QKV phase).
-__device__ __forceinline__ void finish_a_rows(const RArgs& p, int r0, const float4 (&v)[8], const LnGB& w,
+template <int D = 512>
+__device__ __forceinline__ void finish_a_rows(const RArgs& p, int r0, const float4 (&v)[D / 64], const LnGB<D>& w,
                                               unsigned write_x, bf16_t* sA, int lda, unsigned write_hn = 0u) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, sub = lane & 15;
-  constexpr int d = 512;
+  constexpr int d = D, NV = D / 64;
   const int rr = wave * 4 + q, r = r0 + rr;
   const bool live = r < p.R;  // rows past the batch: zeros into the tile
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  for (int k = 0; k < NV; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   const float mean = row16_sum(s) * (1.0f / d);
   float qq = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < NV; ++k) {
     const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, e = v[k].w - mean;
     qq += (a * a + b * b) + (cc * cc + e * e);
   }
@@ -480,7 +483,7 @@ __device__ __forceinline__ void finish_a_rows(const RArgs& p, int r0, const floa
   const float rstd = 1.0f / sqrtf(var + p.eps);
   bf16_t* dst = sA + rr * lda + sub * 4;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < NV; ++k) {
     const float4 gg = w.g[k], bb = w.b[k];
     float4 o;
     o.x = (v[k].x - mean) * rstd * gg.x + bb.x;
@@ -491,8 +494,8 @@ __device__ __forceinline__ void finish_a_rows(const RArgs& p, int r0, const floa
     ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
     if (!live) ob = bf16x4{};
     *reinterpret_cast<bf16x4*>(dst + 64 * k) = ob;
-    if (live && ((write_x >> k) & 1u)) cst_f4(p.xres + (int64_t)r * d + sub * 4 + 64 * k, o);
-    if (live && ((write_hn >> k) & 1u)) cst_b4(p.hn + (int64_t)r * d + sub * 4 + 64 * k, ob);
+    if (live && ((write_x >> (k & 7)) & 1u)) cst_f4(p.xres + (int64_t)r * d + sub * 4 + 64 * k, o);
+    if (live && ((write_hn >> (k & 7)) & 1u)) cst_b4(p.hn + (int64_t)r * d + sub * 4 + 64 * k, ob);
   }
 }
 
@@ -559,13 +562,13 @@ struct PhaseMap {
 //                   from L2): the N = 512 phases always, QKV and FFN dense1 up to 64 rows.
 // E_VOCAB keeps a running (max, arg-max, sum exp) per lane over the workgroup's items and merges lanes and waves once,
 // after the last item: one partial per (row, workgroup of the row tile), p.parts of them per row.
-template <int KC, int AMODE, int EPI, bool KSPLIT, int RTB = 1>
+template <int K, int AMODE, int EPI, bool KSPLIT, int RTB = 1, int D = 512>
 RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf16_t* sA, const bf16_t* W,
                                            const float* bias, int N, const void* asrc, const float* g, const float* be,
                                            bool write_x, int t, bf16_t* skv, const float* asrc2 = nullptr, int gcap = 0) {
   // RTB: 16-row tiles a workgroup multiplies with ONE fetch of its W fragments (their A rows side by side in LDS):
   // the weight traffic of a phase is (row tiles / RTB) x the matrix - what bounds the vocabulary phase at 128 rows.
-  constexpr int K = 512 * KC, NF = KSPLIT ? 4 * KC : 16 * KC;
+  constexpr int NF = KSPLIT ? K / 128 : K / 32;  // (K: the reduction length; D: the model width = the row length of q / y / xres)
   constexpr int lda = K + 8;
   static_assert(NF <= 16, "two sets of W fragments: <= 128 VGPRs");
   __shared__ float s_pm[4][16];
@@ -623,7 +626,7 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
       P.xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (EPI == E_RES) {
         const int r = r0 + u * 16 + l16;
-        if ((!KSPLIT || wave == 0) && n0 < N && r < p.R) P.xr[u] = cld_f4(p.xres + (int64_t)r * 512 + nb);
+        if ((!KSPLIT || wave == 0) && n0 < N && r < p.R) P.xr[u] = cld_f4(p.xres + (int64_t)r * D + nb);
       }
     }
   };
@@ -726,18 +729,18 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
         const float4 bv = P.bv;
         v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
         if constexpr (EPI == E_QKV) {
-          if (nb < 512) {
-            cst_f4(p.q + (int64_t)r * 512 + nb, make_float4(v[0], v[1], v[2], v[3]));
+          if (nb < D) {
+            cst_f4(p.q + (int64_t)r * D + nb, make_float4(v[0], v[1], v[2], v[3]));
           } else {
             bf16x4 ob;
 #pragma unroll
             for (int e = 0; e < 4; ++e) ob[e] = (bf16_t)v[e];
-            cst_b4(skv + ((int64_t)r * p.T + (t - 1)) * 1024 + (nb - 512), ob);
+            cst_b4(skv + ((int64_t)r * p.T + (t - 1)) * (2 * D) + (nb - D), ob);
           }
         } else if constexpr (EPI == E_Q) {
-          cst_f4(p.q + (int64_t)r * 512 + nb, make_float4(v[0], v[1], v[2], v[3]));
+          cst_f4(p.q + (int64_t)r * D + nb, make_float4(v[0], v[1], v[2], v[3]));
         } else if constexpr (EPI == E_RES) {
-          cst_f4(p.y + (int64_t)r * 512 + nb, make_float4(v[0] + xr.x, v[1] + xr.y, v[2] + xr.z, v[3] + xr.w));
+          cst_f4(p.y + (int64_t)r * D + nb, make_float4(v[0] + xr.x, v[1] + xr.y, v[2] + xr.z, v[3] + xr.w));
         } else {  // E_ACT
           bf16x4 ob;
 #pragma unroll
@@ -767,7 +770,7 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
         load_a_bf16<K>(p, r0 + u * 16, reinterpret_cast<const bf16_t*>(asrc), sA + u * 16 * lda, lda);
       }
     } else {  // the rows of every tile requested before the first one is normalised
-      float4 av[RTB][8];
+      float4 av[RTB][D / 64];
       // who stores the normalised rows: column slice k by the workgroup of item k when the row group has 8 of them
       const unsigned wmask = (pm.nper >= 8 && CI >= 8) ? (pm.c0 < 8 ? 1u << pm.c0 : 0u) : (pm.c0 == 0 ? 0xffu : 0u);
       int mytok[RTB];
@@ -779,13 +782,13 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
       }
 #pragma unroll
       for (int u = 0; u < RTB; ++u)
-        fetch_a_rows<AMODE>(p, r0 + u * 16, t, mytok[u], reinterpret_cast<const float*>(asrc), asrc2, av[u]);
-      LnGB gb;  // (after the rows' requests: the token -> word row chain is what the stage waits for)
-      load_gb(gb, g, be);
+        fetch_a_rows<AMODE, D>(p, r0 + u * 16, t, mytok[u], reinterpret_cast<const float*>(asrc), asrc2, av[u]);
+      LnGB<D> gb;  // (after the rows' requests: the token -> word row chain is what the stage waits for)
+      load_gb<D>(gb, g, be);
 #pragma unroll
       for (int u = 0; u < RTB; ++u) {
         if (RTB > 1 && u > 0 && r0 + u * 16 >= p.R) break;
-        finish_a_rows(p, r0 + u * 16, av[u], gb, write_x ? wmask : 0u, sA + u * 16 * lda, lda, EPI == E_VOCABK ? wmask : 0u);
+        finish_a_rows<D>(p, r0 + u * 16, av[u], gb, write_x ? wmask : 0u, sA + u * 16 * lda, lda, EPI == E_VOCABK ? wmask : 0u);
       }
     }
     __syncthreads();
@@ -873,15 +876,20 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
 //   HALF = true (<= 64 rows: 32 items per row tile leave most CUs idle and each fetches 64 KB of W2 - what the phase waits for):
 //                item = (16 columns, K half), wave w multiplies eighth 4 half + w; the half-0 workgroup stores
 //                (half0 + b) + x to y, the half-1 workgroup stores half1 to y2, and the consumers add y + y2 on load.
-template <bool HALF>
+// KF = ff (2048: d_model 512; 3072 / 4096: d_model 768 / 1024, HALF form only - a wave's K range must fit 16 fragments),
+// D = d_model = the width of the output rows.
+template <bool HALF, int KF = 2048, int D = 512>
 RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const bf16_t* W, const float* bias) {
-  constexpr int K = 2048, lda = K + 8, NF = HALF ? 8 : 16;
+  constexpr int K = KF, KW = HALF ? KF / 8 : KF / 4, NF = KW / 32;  // KW: a wave's K range
+  constexpr int lda = (HALF ? KF / 2 : KF) + 8;                     // the LDS tile holds the K range of the item
+  constexpr int CH = HALF ? NF : 8;                                 // fragments per accumulator pair (see the sum order above)
+  static_assert(NF <= 16 && NF % 2 == 0 && (HALF || NF == 16), "ffn2_phase: K range of a wave");
   __shared__ f32x4 s_e[2][7][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
-  const int RT = (p.R + 15) >> 4, CI = HALF ? 64 : 32;
+  const int RT = (p.R + 15) >> 4, CI = HALF ? D / 8 : D / 16;
   const PhaseMap pm(RT, CI);
   const int r0 = pm.rt * 16, r = r0 + l16;
-  auto k0_of = [&](int c) { return HALF ? ((c & 1) * 4 + wave) * 256 : wave * 512; };
+  auto k0_of = [&](int c) { return HALF ? ((c & 1) * 4 + wave) * KW : wave * KW; };
   auto n0_of = [&](int c) { return (HALF ? c >> 1 : c) * 16; };
   bf16x8 wa[NF], wb[NF];
   const unsigned nprod = pm.np_;
@@ -897,7 +905,7 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
     const int cc = min(c, CI - 1), nb = n0_of(cc) + kg * 4, kh = HALF ? cc & 1 : 0;
     P.xr = make_float4(0.f, 0.f, 0.f, 0.f);
     P.bv = *reinterpret_cast<const float4*>(bias + nb);
-    if (wave == 0 && kh == 0 && r < p.R) P.xr = cld_f4(p.xres + (int64_t)r * 512 + nb);
+    if (wave == 0 && kh == 0 && r < p.R) P.xr = cld_f4(p.xres + (int64_t)r * D + nb);
   };
   if (pm.has) fetchw(wa, pm.c0);
   if (pm.has) gs.wait();
@@ -911,8 +919,8 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
       const float4 xr = P.xr;
       if (!tile_loaded || HALF) {  // the 16 rows of h (HALF: the K half of this item) -> LDS
         if (tile_loaded) __syncthreads();
-        constexpr int KP = HALF ? 1024 : 2048, per_row = KP / 8, NC = 16 * per_row / 256;
-        const int kb = HALF ? kh * 1024 : 0;
+        constexpr int KP = HALF ? KF / 2 : KF, per_row = KP / 8, NC = 16 * per_row / 256;
+        const int kb = HALF ? kh * (KF / 2) : 0;
         bf16x8 v[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
@@ -923,18 +931,18 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
           const int q = threadIdx.x + 256 * i, rr = q / per_row, c8 = q - rr * per_row;
-          *reinterpret_cast<bf16x8*>(sA + rr * lda + kb + c8 * 8) = v[i];
+          *reinterpret_cast<bf16x8*>(sA + rr * lda + c8 * 8) = v[i];
         }
         __syncthreads();
         tile_loaded = true;
       }
-      const bf16_t* ar = sA + l16 * lda + k0 + kg * 8;
-      f32x4 e[NF / 8];
+      const bf16_t* ar = sA + l16 * lda + (k0 - (HALF ? kh * (KF / 2) : 0)) + kg * 8;
+      f32x4 e[NF / CH];
 #pragma unroll
-      for (int h8 = 0; h8 < NF / 8; ++h8) {
+      for (int h8 = 0; h8 < NF / CH; ++h8) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = h8 * 8; i < h8 * 8 + 8; i += 2) {
+        for (int i = h8 * CH; i < h8 * CH + CH; i += 2) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], *reinterpret_cast<const bf16x8*>(ar + i * 32), acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], *reinterpret_cast<const bf16x8*>(ar + (i + 1) * 32), acc1, 0, 0, 0);
         }
@@ -953,15 +961,15 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
         if constexpr (HALF) {
           const f32x4 half = e[0] + ((s_e[par][0][lane] + s_e[par][1][lane]) + s_e[par][2][lane]);
           if (kh == 0) {
-            cst_f4(p.y + (int64_t)r * 512 + nb, make_float4((half[0] + bv.x) + xr.x, (half[1] + bv.y) + xr.y,
+            cst_f4(p.y + (int64_t)r * D + nb, make_float4((half[0] + bv.x) + xr.x, (half[1] + bv.y) + xr.y,
                                                              (half[2] + bv.z) + xr.z, (half[3] + bv.w) + xr.w));
           } else {
-            cst_f4(p.y2 + (int64_t)r * 512 + nb, make_float4(half[0], half[1], half[2], half[3]));
+            cst_f4(p.y2 + (int64_t)r * D + nb, make_float4(half[0], half[1], half[2], half[3]));
           }
         } else {
           const f32x4 half0 = e[0] + ((s_e[par][0][lane] + s_e[par][1][lane]) + s_e[par][2][lane]);
           const f32x4 half1 = s_e[par][3][lane] + ((s_e[par][4][lane] + s_e[par][5][lane]) + s_e[par][6][lane]);
-          cst_f4(p.y + (int64_t)r * 512 + nb, make_float4(((half0[0] + bv.x) + xr.x) + half1[0], ((half0[1] + bv.y) + xr.y) + half1[1],
+          cst_f4(p.y + (int64_t)r * D + nb, make_float4(((half0[0] + bv.x) + xr.x) + half1[0], ((half0[1] + bv.y) + xr.y) + half1[1],
                                                            ((half0[2] + bv.z) + xr.z) + half1[2], ((half0[3] + bv.w) + xr.w) + half1[3]));
         }
       }
@@ -1082,12 +1090,12 @@ struct AttnItem {
 
 // ANC (beam search, SELF): key j of row r is position j of the hypothesis in beam slot r - cached, like its token, at the
 // PHYSICAL row anc[r][j] (the ancestor table of csrc/beam.hip: re-ordering beams never moves K / V)
-template <bool SELF, int NKB, bool ANC = false>  // SELF: the keys / values are the cache this launch writes (coherent loads), pad mask from `fed`
+template <bool SELF, int NKB, bool ANC = false, int D = 512>  // SELF: the keys / values are the cache this launch writes (coherent loads), pad mask from `fed`
 RES_PHASE_FN unsigned attn_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
                                                int rows_per_kv, int nk, const int32_t* pad_tok, const float* bias,
                                                int bias_ld, const int32_t* anc = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 3, chunk = lane & 7;
-  constexpr int d = 512;
+  constexpr int d = D;
   const int nkb = (nk + 7) >> 3, H = p.H;
   const bool by_xcd = (gridDim.x & 7) == 0;
   const int x = by_xcd ? (int)(blockIdx.x & 7) : 0, xs = by_xcd ? 8 : 1;

@@ -37,14 +37,18 @@ namespace {
 
 // KCF = ff / 512; RB: row tiles per workgroup in the vocabulary phase; SM (few row tiles): QKV and FFN dense1 as
 // 16-column K-split items too (the same bits either way: gemm_phase adds K in the same order in both forms)
-template <int KCF, int RB, bool SM, bool HF>  // HF (ff = 2048, <= 64 rows): FFN dense2 over two workgroups per column tile
+// D = d_model.  D = 768 / 1024 (ff = 4 D; config/archs.yaml:15-26): the K-split forms in EVERY GEMM phase (a wave's K range
+// is D / 4: 6 / 8 fragments), the vocabulary phase included, and FFN dense2 over two workgroups per column tile - up to 64
+// rows (BASELINE configs[3]: 32 clips per GPU).
+template <int KCF, int RB, bool SM, bool HF, int D = 512>  // HF (ff = 2048, <= 64 rows): FFN dense2 over two workgroups per column tile
 __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
   GridSync gs{p.sync, (unsigned)p.ghost, -1, false, 0, 0, 0u};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = p.d;
-  const float* y2 = (KCF == 4 && HF) ? p.y2 : nullptr;  // the second K half of FFN dense2, added by its consumers
+  constexpr bool WIDE = D != 512;
+  const float* y2 = ((KCF == 4 && HF) || WIDE) ? p.y2 : nullptr;  // the second K half of FFN dense2, added by its consumers
   bool ended = false;
   // the phase a phase consumes: its position within the step, its producers, how many times it has run
   int sl = 0, sl_prev = 0;
@@ -65,8 +69,8 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
     sl = 0;
     for (int l = 0; l < p.n_layers; ++l) {
       const RLayer& L = p.L[l];
-      if (l == 0) RES_PHASE((gemm_phase<1, A_EMBED, E_QKV, SM>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv)));
-      else RES_PHASE((gemm_phase<1, A_LN, E_QKV, SM>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2)));
+      if (l == 0) RES_PHASE((gemm_phase<D, A_EMBED, E_QKV, SM, 1, D>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv)));
+      else RES_PHASE((gemm_phase<D, A_LN, E_QKV, SM, 1, D>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2)));
       if (l == 0 && t > 1) {
         // Every row ended with the token chosen in the phase above?  EVERY workgroup must come to the same answer before
         // it goes on.  The workgroups with self-attention items wait for the phase anyway and read the count themselves;
@@ -106,30 +110,31 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
           if (blockIdx.x == 0 && threadIdx.x == 0) p.sync[2] = (unsigned)(t - 1);
           break;
         }
-        RES_PHASE((p.T <= 32 ? attn_phase<true, 4>(p, gs, false, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)
-                              : attn_phase<true, RES_MAXKB>(p, gs, false, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)));
+        RES_PHASE((p.T <= 32 ? attn_phase<true, 4, false, D>(p, gs, false, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)
+                              : attn_phase<true, RES_MAXKB, false, D>(p, gs, false, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)));
       } else {
-        RES_PHASE((p.T <= 32 ? attn_phase<true, 4>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)
-                              : attn_phase<true, RES_MAXKB>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)));
+        RES_PHASE((p.T <= 32 ? attn_phase<true, 4, false, D>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)
+                              : attn_phase<true, RES_MAXKB, false, D>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0)));
       }
-      RES_PHASE((gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, L.o_w, L.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
+      RES_PHASE((gemm_phase<D, A_BF16, E_RES, true, 1, D>(p, gs, true, sA, L.o_w, L.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
       const float* g = L.g;
       const float* be = L.be;
       for (int a = 0; a < L.n_att; ++a) {
         const RAttn& A = L.att[a];
-        RES_PHASE((gemm_phase<1, A_LN, E_Q, true>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr)));
-        RES_PHASE((A.nkeys <= 64 ? attn_phase<false, 8>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)
-                                  : attn_phase<false, RES_MAXKB>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)));
-        RES_PHASE((gemm_phase<1, A_BF16, E_RES, true>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
+        RES_PHASE((gemm_phase<D, A_LN, E_Q, true, 1, D>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr)));
+        RES_PHASE((A.nkeys <= 64 ? attn_phase<false, 8, false, D>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)
+                                  : attn_phase<false, RES_MAXKB, false, D>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)));
+        RES_PHASE((gemm_phase<D, A_BF16, E_RES, true, 1, D>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
         g = A.g; be = A.be;
       }
-      RES_PHASE((gemm_phase<1, A_LN, E_ACT, SM>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr)));
-      if constexpr (KCF == 4) RES_PHASE((ffn2_phase<HF>(p, gs, sA, L.w2, L.b2)));
-      else RES_PHASE((gemm_phase<KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr)));
+      RES_PHASE((gemm_phase<D, A_LN, E_ACT, SM, 1, D>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr)));
+      if constexpr (WIDE) RES_PHASE((ffn2_phase<true, 512 * KCF, D>(p, gs, sA, L.w2, L.b2)));
+      else if constexpr (KCF == 4) RES_PHASE((ffn2_phase<HF>(p, gs, sA, L.w2, L.b2)));
+      else RES_PHASE((gemm_phase<512 * KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr)));
     }
     if (ended) break;
     const RLayer& LL = p.L[p.n_layers - 1];
-    RES_PHASE((gemm_phase<1, A_LN, E_VOCAB, false, RB>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2)));
+    RES_PHASE((gemm_phase<D, A_LN, E_VOCAB, WIDE, RB, D>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2)));
   }
 #undef RES_PHASE
   if (!ended && !gs.dead) {  // every workgroup: the vocabulary partials of the last step are complete
@@ -152,8 +157,8 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   }
 }
 
-std::atomic<unsigned long long> g_res_lds_done[6];
-std::atomic<int> g_res_ok[6];  // residency checked (res_check_residency) for this instantiation
+std::atomic<unsigned long long> g_res_lds_done[8];
+std::atomic<int> g_res_ok[8];  // residency checked (res_check_residency) for this instantiation
 
 }  // namespace
 
@@ -168,7 +173,9 @@ void care_decode_resident_debug(int prof_step, int ghost) {
 
 int64_t care_decode_resident_scratch(int rows, int d, int ff, int V) {
   if (rows < 1 || d < 1 || ff < 1 || V < 1) return CARE_EINVAL;
-  const int64_t R16 = (rows + 15) / 16 * 16, parts = (V + 63) / 64;
+  const int64_t R16 = (rows + 15) / 16 * 16;
+  int64_t parts = d == 512 ? (V + 63) / 64 : (V + 15) / 16;  // column items of the vocabulary phase (16 columns each when d_model > 512)
+  if (parts > 64 * RES_NP) parts = 64 * RES_NP;
   // sync | xres, y, y2, q fp32 [R16, d] | ctx bf16 [R16, d] | h bf16 [R16, ff] | pmax, pidx, psum [R16, parts]
   return RES_SYNC_BYTES + R16 * d * 4 * 4 + R16 * d * 2 + R16 * ff * 2 + R16 * parts * 12;
 }
@@ -182,8 +189,10 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
     return CARE_EINVAL;
   if (n_layers < 1 || n_layers > RES_MAX_LAYERS || rows < 1 || T < 1 || steps < 1 || steps > T || V < 1 || fed_stride < T + 1)
     return CARE_EINVAL;
-  if (d != 512 || heads * 64 != d || (ff != 512 && ff != 1024 && ff != 2048) || T > 8 * RES_MAXKB || V > 64 * 64 * RES_NP)
-    return CARE_ESHAPE;
+  const bool wide = d != 512;  // d_model 768 / 1024 with ff = 4 d_model, up to 64 rows (decode_resident_kernel's D)
+  if (heads * 64 != d || T > 8 * RES_MAXKB || V > 64 * 64 * RES_NP) return CARE_ESHAPE;
+  if (!wide && ff != 512 && ff != 1024 && ff != 2048) return CARE_ESHAPE;
+  if (wide && ((d != 768 && d != 1024) || ff != 4 * d || rows > 64)) return CARE_ESHAPE;
   if (act < CARE_ACT_NONE || act > CARE_ACT_GELU) return CARE_EDTYPE;
   if (scratch_bytes < care_decode_resident_scratch(rows, d, ff, V) || !care_aligned16(scratch)) return CARE_EINVAL;
   RArgs p{};
@@ -195,7 +204,7 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   p.ghost = care_res_dbg_ghost.load() ? 8 : 0;   // tests: phases whose producers never all arrive (the watchdog)
   p.fed = fed; p.fed_stride = fed_stride; p.score = score; p.length = length; p.fin = finished;
   const int64_t R16 = (rows + 15) / 16 * 16;
-  p.parts = (V + 63) / 64;
+  p.parts = wide ? ((V + 15) / 16 < 64 * RES_NP ? (V + 15) / 16 : 64 * RES_NP) : (V + 63) / 64;  // (the layout's stride; the launch's count below)
   unsigned char* b = (unsigned char*)scratch;
   p.sync = (unsigned*)b; b += RES_SYNC_BYTES;
   p.xres = (float*)b; b += R16 * d * 4;
@@ -215,13 +224,13 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   const ResKnobs& kn = res_knobs();
   // every workgroup must be resident (they wait for one another): at most one per CU; no more than the widest phase
   // has items (the vocabulary groups x row tiles, or a wave per (row, head))
-  const int RT = (int)(R16 / 16), CIV = (V + 63) / 64;
+  const int RT = (int)(R16 / 16), CIV = wide ? (V + 15) / 16 : (V + 63) / 64;  // column items of the vocabulary phase
   // row tiles a workgroup multiplies per fetch of its vocabulary fragments: 2 from 128 rows (ff = 2048 builds) - the 8
   // workgroups of an XCD that share a column item ask its L2 for the same 64 KB at the same time, and two row tiles per
   // fetch halve those requests while doubling the rows a workgroup normalises (*measured*, same box, us per step:
   // 128 rows 77.6 -> 76.5, 96 rows 73.1 -> 73.0; ms per pass with 1 / 2 / 4 row tiles: 192 rows 3.20 / 3.04 / 3.24,
   // 256 rows 3.38 / 3.25 / 3.44)
-  int rb = (ff == 2048 && rows >= 128) ? 2 : 1;
+  int rb = (ff == 2048 && rows >= 128 && !wide) ? 2 : 1;
   if (kn.rb >= 0 && ff == 2048) rb = kn.rb >= 2 ? 2 : 1;  // tuning (CARE_RESIDENT_RB)
   const int RG = (RT + rb - 1) / rb;
   int want = RT * CIV;
@@ -235,23 +244,24 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
     p.parts = nper < CIV ? nper : CIV;
     if (p.parts > 64 * RES_NP) return CARE_ESHAPE;
   }
-  const int kmax = ff > d ? ff : d;
+  const int kmax = wide ? (ff / 2 > d ? ff / 2 : d) : (ff > d ? ff : d);  // (wide: FFN dense2's tile holds a K half)
   int lds = 16 * (kmax + 8) * 2;
   if (rb * 16 * (512 + 8) * 2 > lds) lds = rb * 16 * (512 + 8) * 2;
   hipStream_t st = (hipStream_t)stream;
   const dim3 g(grid), blk(256);
   int rc;
   // (the residency check comes before anything is enqueued: a refused launch leaves the stream untouched)
-#define RES_LAUNCH(KCF, RB, SM, HF, SLOT)                                                                               \
+#define RES_LAUNCH(KCF, RB, SM, HF, SLOT) RES_LAUNCH_D(KCF, RB, SM, HF, 512, SLOT)
+#define RES_LAUNCH_D(KCF, RB, SM, HF, DM, SLOT)                                                                         \
   do {                                                                                                                  \
-    const void* kfn = (const void*)decode_resident_kernel<KCF, RB, SM, HF>;                                             \
+    const void* kfn = (const void*)decode_resident_kernel<KCF, RB, SM, HF, DM>;                                         \
     if ((rc = care_allow_dynamic_lds(kfn, lds, g_res_lds_done[SLOT]))) return rc;                                        \
     if (!g_res_ok[SLOT].load(std::memory_order_acquire)) {                                                              \
       if ((rc = res_check_residency(kfn, lds, grid, cus))) return rc;                                                   \
       g_res_ok[SLOT].store(1, std::memory_order_release);                                                               \
     }                                                                                                                   \
     if ((e = hipMemsetAsync(p.sync, 0, RES_SYNC_BYTES, st)) != hipSuccess) return (int)e;                               \
-    hipLaunchKernelGGL((decode_resident_kernel<KCF, RB, SM, HF>), g, blk, lds, st, p);                                  \
+    hipLaunchKernelGGL((decode_resident_kernel<KCF, RB, SM, HF, DM>), g, blk, lds, st, p);                              \
   } while (0)
   // QKV / FFN dense1 in 16-column K-split items up to 64 rows (*measured* us / step with / without: 1 row 43.6 / 47.1,
   // 32 rows 60.7 / 65.0, 64 rows 66.0 / 67.7, 128 rows 76.9 / 77.5 with 8.1 against 4.6 us in FFN dense1); FFN dense2
@@ -259,13 +269,16 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   // 16 rows 1.59 / 1.68, 32 rows 1.69 / 1.86, 64 rows 1.94 / 2.00)
   const bool small = kn.small >= 0 ? kn.small != 0 : rows <= 64;       // tuning (CARE_RESIDENT_SMALL)
   const bool half = rows <= (kn.half_rows >= 0 ? kn.half_rows : 64);   // tuning (CARE_RESIDENT_HALF_ROWS)
-  if (ff == 512) RES_LAUNCH(1, 1, true, false, 0);
+  if (d == 768) RES_LAUNCH_D(6, 1, true, true, 768, 6);
+  else if (d == 1024) RES_LAUNCH_D(8, 1, true, true, 1024, 7);
+  else if (ff == 512) RES_LAUNCH(1, 1, true, false, 0);
   else if (ff == 1024) RES_LAUNCH(2, 1, true, false, 1);
   else if (rb == 2) RES_LAUNCH(4, 2, false, false, 3);
   else if (small && half) RES_LAUNCH(4, 1, true, true, 5);
   else if (small) RES_LAUNCH(4, 1, true, false, 4);
   else RES_LAUNCH(4, 1, false, false, 2);
 #undef RES_LAUNCH
+#undef RES_LAUNCH_D
   return care_launch_status();
 }
 

@@ -456,16 +456,16 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p) {
     t_run = t;
     for (int l = 0; l < p.n_layers; ++l) {
       const RLayer& L = p.L[l];
-      if (l == 0) RES_PHASE((gemm_phase<1, A_EMBEDB, E_QKV, SM, RQ>(p, gs, !first_waited, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv)));
-      else RES_PHASE((gemm_phase<1, A_LN, E_QKV, SM, RQ>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2)));
+      if (l == 0) RES_PHASE((gemm_phase<512, A_EMBEDB, E_QKV, SM, RQ>(p, gs, !first_waited, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv)));
+      else RES_PHASE((gemm_phase<512, A_LN, E_QKV, SM, RQ>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2)));
       RES_PHASE((p.T <= 32 ? attn_phase<true, 4, true>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0, p.anc[(t - 1) & 1])
                             : attn_phase<true, RES_MAXKB, true>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0, p.anc[(t - 1) & 1])));
-      RES_PHASE((gemm_phase<1, A_BF16, E_RES, KD, RD>(p, gs, true, sA, L.o_w, L.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
+      RES_PHASE((gemm_phase<512, A_BF16, E_RES, KD, RD>(p, gs, true, sA, L.o_w, L.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
       const float* g = L.g;
       const float* be = L.be;
       for (int a = 0; a < L.n_att; ++a) {
         const RAttn& A = L.att[a];
-        RES_PHASE((gemm_phase<1, A_LN, E_Q, KD, RD>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr)));
+        RES_PHASE((gemm_phase<512, A_LN, E_Q, KD, RD>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr)));
         // more (row, head) pairs than waves: a wave per (clip, head) with the clip's keys fetched once for its beams
         if (p.R * p.H > 4 * (int)gridDim.x)
           RES_PHASE((A.nkeys <= 64 ? attn_shared_phase<8>(p, gs, true, A.kv, A.kv_bs, p.bm, A.nkeys, A.bias, A.bias_ld)
@@ -473,15 +473,15 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p) {
         else
           RES_PHASE((A.nkeys <= 64 ? attn_phase<false, 8>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)
                                     : attn_phase<false, RES_MAXKB>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)));
-        RES_PHASE((gemm_phase<1, A_BF16, E_RES, KD, RD>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
+        RES_PHASE((gemm_phase<512, A_BF16, E_RES, KD, RD>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
         g = A.g; be = A.be;
       }
-      RES_PHASE((gemm_phase<1, A_LN, E_ACT, SM, RF>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr)));
+      RES_PHASE((gemm_phase<512, A_LN, E_ACT, SM, RF>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr)));
       if constexpr (KCF == 4) RES_PHASE((ffn2_phase<HF>(p, gs, sA, L.w2, L.b2)));
-      else RES_PHASE((gemm_phase<KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr)));
+      else RES_PHASE((gemm_phase<512 * KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr)));
     }
     const RLayer& LL = p.L[p.n_layers - 1];
-    RES_PHASE((gemm_phase<1, A_LN, E_VOCABK, false, RV>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2, p.vcap)));
+    RES_PHASE((gemm_phase<512, A_LN, E_VOCABK, false, RV>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2, p.vcap)));
     RES_PHASE((beam_advance_phase(p, gs, t, smem)));
   }
 #undef RES_PHASE

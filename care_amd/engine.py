@@ -1141,12 +1141,21 @@ class HipEngine:
         larger one (the audit of tests/test_gpu_properties.py counts such rows)."""
         if not (0 < rows <= self.resident_max_rows and self._resident_model_ok()):
             return False
+        if self.d != 512 and rows > self.RESIDENT_WIDE_MAX_ROWS:
+            return False
         return self._resident_fits(rows)
 
-    def _resident_model_ok(self) -> bool:
-        """Every model-side limit care_decode_resident / care_decode_resident_beam enforce (CARE_ESHAPE otherwise)."""
-        return bool(self.as_ok and self.d == 512 and self.ff in (512, 1024, 2048) and self.T <= 128 and self.n_layers <= 4 and
-                    (not self.attr_att or self.topk <= 128) and self.V <= self.RESIDENT_MAX_V and self.Lk <= 128)
+    RESIDENT_WIDE_MAX_ROWS = 64  # d_model 768 / 1024: the K-split forms only (csrc/decode_resident.hip, template D)
+
+    def _resident_model_ok(self, beam: bool = False) -> bool:
+        """Every model-side limit care_decode_resident / care_decode_resident_beam enforce (CARE_ESHAPE otherwise):
+        bf16 mode; d_model 512 (ff 512 / 1024 / 2048), or - greedy only - d_model 768 / 1024 with ff = 4 d_model."""
+        if not (self.bf and self.wt == torch.bfloat16 and self.T <= 128 and self.n_layers <= 4 and
+                (not self.attr_att or self.topk <= 128) and self.V <= self.RESIDENT_MAX_V and self.Lk <= 128):
+            return False
+        if self.d == 512:
+            return bool(self.as_ok and self.ff in (512, 1024, 2048))
+        return bool(not beam and self.d in (768, 1024) and self.ff == 4 * self.d and self.bf_act)
 
     def _resident_fits(self, rows: int, per_tile: int = 1) -> bool:
         """one workgroup per CU at most, and at least one per group of `per_tile` 16-row tiles (a partitioned GPU has fewer CUs)"""
@@ -1163,7 +1172,7 @@ class HipEngine:
         care_decode_resident_beam: the greedy launch's, beam_size <= 5, a hypothesis' positions one per lane (T <= 63)."""
         rows = clips * bm
         if not (0 < rows <= self.resident_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and
-                self._resident_model_ok() and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX):
+                self._resident_model_ok(beam=True) and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX):
             return False
         return self._resident_fits(rows, 2 if rows > 256 else 1)
 
@@ -1452,7 +1461,7 @@ class HipEngine:
         if self.resident_ok(feats[0].shape[0]):  # small batch: encode + one resident launch for the whole decode
             def run_resident():
                 self._form_rows = feats[0].shape[0]
-                enc = self.encode(feats, lean, static=True, small=True)
+                enc = self.encode(feats, lean, static=True, small=self.small_forms(feats[0].shape[0]))
                 return (enc,) + tuple(self.greedy_resident(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
                                                            sem_embs=enc.get("semantic_embs"), early_exit=ee))
             key = ("gres", bool(lean), bool(ee), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))

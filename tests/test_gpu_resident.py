@@ -23,7 +23,9 @@ def _caption_equal(fa, la, fb, lb):
 
 
 @pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 1), ("msrvtt_base_ami", 17), ("msrvtt_base_ami", 128),
-                                      ("msrvtt_care", 5), ("msrvtt_care", 100), ("msrvtt_cabase", 33), ("msvd_base_i", 64)])
+                                      ("msrvtt_care", 5), ("msrvtt_care", 100), ("msrvtt_cabase", 33), ("msvd_base_i", 64),
+                                      # d_model 1024 / 768 (round 4: the K-split forms, BASELINE configs[3]'s 32 clips per GPU)
+                                      ("vatex_care_large", 32), ("vatex_care_large", 3), ("care_median_gelu", 64)])
 def test_resident_decode_against_multi_launch_and_oracle(config, B):
     """Peaked (trained-like) logits: the resident form and the multi-launch form (projected cross K/V: the same rounding
     points) must give the same caption wherever the oracle's every step is decided by a clear margin, and nearly
