@@ -218,7 +218,7 @@ def extra_legs(dev, main_dtype, legs):
     # the concept-guided model at translate.py's batch (greedy)
     legs["msrvtt_care_B128"] = greedy_leg("msrvtt_care", main_dtype, 128, iters=20)[0]
     # BASELINE configs[3]: d_model = 1024 - at the batch that fills the chip, and at the 32 clips per GPU that config names
-    # ("batch = 256 sharded over 8 x MI355X")
+    # ("batch = 256 sharded over 8 x MI355X": one resident launch per decode since round 4, csrc/decode_resident.hip D = 1024)
     legs["vatex_care_large"] = greedy_leg("vatex_care_large", main_dtype, 4096)[0]
     legs["vatex_care_large_B16384"] = greedy_leg("vatex_care_large", main_dtype, 16384, iters=3)[0]
     legs["vatex_care_large_B32"] = greedy_leg("vatex_care_large", main_dtype, 32, iters=20)[0]

@@ -38,7 +38,7 @@ namespace {
 // KCF = ff / 512; RB: row tiles per workgroup in the vocabulary phase; SM (few row tiles): QKV and FFN dense1 as
 // 16-column K-split items too (the same bits either way: gemm_phase adds K in the same order in both forms)
 // D = d_model.  D = 768 / 1024 (ff = 4 D; config/archs.yaml:15-26): the K-split forms in EVERY GEMM phase (a wave's K range
-// is D / 4: 6 / 8 fragments), the vocabulary phase included, and FFN dense2 over two workgroups per column tile - up to 64
+// is D / 4: 6 / 8 fragments), the vocabulary phase included, and FFN dense2 over two workgroups per column tile - up to 128
 // rows (BASELINE configs[3]: 32 clips per GPU).
 template <int KCF, int RB, bool SM, bool HF, int D = 512>  // HF (ff = 2048, <= 64 rows): FFN dense2 over two workgroups per column tile
 __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
@@ -189,10 +189,10 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
     return CARE_EINVAL;
   if (n_layers < 1 || n_layers > RES_MAX_LAYERS || rows < 1 || T < 1 || steps < 1 || steps > T || V < 1 || fed_stride < T + 1)
     return CARE_EINVAL;
-  const bool wide = d != 512;  // d_model 768 / 1024 with ff = 4 d_model, up to 64 rows (decode_resident_kernel's D)
+  const bool wide = d != 512;  // d_model 768 / 1024 with ff = 4 d_model, up to 128 rows (decode_resident_kernel's D)
   if (heads * 64 != d || T > 8 * RES_MAXKB || V > 64 * 64 * RES_NP) return CARE_ESHAPE;
   if (!wide && ff != 512 && ff != 1024 && ff != 2048) return CARE_ESHAPE;
-  if (wide && ((d != 768 && d != 1024) || ff != 4 * d || rows > 64)) return CARE_ESHAPE;
+  if (wide && ((d != 768 && d != 1024) || ff != 4 * d || rows > 128)) return CARE_ESHAPE;
   if (act < CARE_ACT_NONE || act > CARE_ACT_GELU) return CARE_EDTYPE;
   if (scratch_bytes < care_decode_resident_scratch(rows, d, ff, V) || !care_aligned16(scratch)) return CARE_EINVAL;
   RArgs p{};

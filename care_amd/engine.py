@@ -1145,7 +1145,7 @@ class HipEngine:
             return False
         return self._resident_fits(rows)
 
-    RESIDENT_WIDE_MAX_ROWS = 64  # d_model 768 / 1024: the K-split forms only (csrc/decode_resident.hip, template D)
+    RESIDENT_WIDE_MAX_ROWS = 128  # d_model 768 / 1024: the K-split forms only (csrc/decode_resident.hip, template D)
 
     def _resident_model_ok(self, beam: bool = False) -> bool:
         """Every model-side limit care_decode_resident / care_decode_resident_beam enforce (CARE_ESHAPE otherwise):

@@ -575,7 +575,9 @@ int care_gemm_kn(const float* A, int64_t lda, int a_is_km, const float* B, int64
  *   steps run is left in ((int32_t*)scratch)[2].
  *   scratch: care_decode_resident_scratch(rows, d, ff, V) bytes, 16-byte aligned.  blocks: workgroups (0 = as many as
  *   the widest phase has items, at most one per CU; every workgroup must be resident).
- *   Requires d == 512, heads == 8, ff in {512, 1024, 2048}, T <= 128, nkeys <= 128, n_layers <= 4, n_att <= 2.
+ *   Requires heads == d / 64, T <= 128, nkeys <= 128, n_layers <= 4, n_att <= 2, V <= 16384 and either d == 512 with ff in
+ *   {512, 1024, 2048} (any row count one workgroup per 16-row tile fits) or d in {768, 1024} with ff == 4 d and
+ *   rows <= 128 (config/archs.yaml:15-26: the `median` / `large` architectures, K-split forms in every phase).
  *   Every workgroup must be resident at the same time (they wait for one another): the grid is at most one workgroup
  *   per CU and the entry point refuses (CARE_ESHAPE, nothing enqueued) unless hipOccupancyMaxActiveBlocksPerMultiprocessor
  *   admits a workgroup of the kernel per CU; do not run two of these launches concurrently on different streams.  A

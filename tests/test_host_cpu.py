@@ -250,9 +250,9 @@ def test_small_batch_form_rules(monkeypatch):
     for cfg, dtype in (("msrvtt_base_ami", "fp32"), ("msrvtt_care", "fp16x3"), ("vatex_care_large", "fp32")):
         e = HipEngine(make_opt(cfg), dtype)
         assert not e.resident_ok(8) and not e.small_forms(8), (cfg, dtype)   # bf16 mode only
-    for cfg in ("vatex_care_large", "care_median_gelu"):   # d_model 1024 / 768 (ff = 4 d_model): greedy, up to 64 rows
+    for cfg in ("vatex_care_large", "care_median_gelu"):   # d_model 1024 / 768 (ff = 4 d_model): greedy, up to 128 rows
         e = HipEngine(make_opt(cfg), "bf16")
-        assert e.resident_ok(1) and e.resident_ok(32) and e.resident_ok(64) and not e.resident_ok(65), cfg
+        assert e.resident_ok(1) and e.resident_ok(32) and e.resident_ok(128) and not e.resident_ok(129), cfg
         assert not e.small_forms(8) and not e.resident_beam_ok(4, 5, 5), cfg
     two = HipEngine(make_opt("msrvtt_base_ami", num_hidden_layers_decoder=2), "bf16")
     assert two.resident_ok(8)
