@@ -155,9 +155,11 @@ struct GridSync {
       unsigned long long t0 = 0;
       for (;;) {
         unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // lanes 0 .. 7: the 8 shards
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
+        // (the 8 shards through the DPP data path: lane ^ 1, lane ^ 2, the mirrored lane of the 8 - three dependent
+        // ds_bpermute round trips per poll before)
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
         if (v >= need) break;  // (the same sum in every group of 8 lanes)
 #ifndef RES_POLL_SLEEP
 #define RES_POLL_SLEEP 1
@@ -209,6 +211,43 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 __device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// lane ^ 8 / ^ 16 / ^ 32 exchanges of the attention reductions without the LDS crossbar: row_ror:8 (DPP), and the
+// gfx950 row / half swaps - v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of
+// its second, v_permlane32_swap the upper half of the first with the lower half of the second; with both operands = v the
+// two results are (lower partner, upper partner) in every lane.  a + b == b + a: the sums are those of __shfl_xor, bit for bit.
+__device__ __forceinline__ float x16_sum(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+  return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ float x32_sum(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+  return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ float x16_max(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+  return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+}
+__device__ __forceinline__ float x32_max(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+  return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+}
+
+// the partner lane's value of the lane ^ 16 / lane ^ 32 exchange (the swaps return (lower partner, upper partner))
+__device__ __forceinline__ int x16_other(int v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return (threadIdx.x & 16) ? (int)r[0] : (int)r[1];
+}
+__device__ __forceinline__ int x32_other(int v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
+}
+__device__ __forceinline__ float x16_other(float v) { return __builtin_bit_cast(float, x16_other(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float x32_other(float v) { return __builtin_bit_cast(float, x32_other(__builtin_bit_cast(int, v))); }
 
 // (max, arg-max, sum exp) merge; ties go to the lower column
 __device__ __forceinline__ void amax_merge(float& m, int& i, float& s, float om, int oi, float os) {
@@ -309,11 +348,11 @@ __device__ __forceinline__ void select4(const RArgs& p, int r0, int ts, int lane
 #pragma unroll
     for (int k = 0; k < RES_NP; ++k)
       if (pm[i][k] > best || (pm[i][k] == best && pi[i][k] < bi)) { best = pm[i][k]; bi = pi[i][k]; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    {  // the wave's best (value desc, column asc) as the maximum of a sortable 64-bit key: DPP + readlane, no LDS round trips
+      // (six dependent ds_bpermute pairs per row before)
+      const unsigned long long kbest = wave_max_u64(key_of(best, (unsigned)bi));
+      best = key_val(kbest);
+      bi = (int)key_idx(kbest);
     }
     tok[i] = bi;
     if (WRITER) {
@@ -815,11 +854,9 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
       for (int u = 0; u < RTB; ++u) {
         const int r = r0 + u * 16 + l16;
         if (RTB > 1 && r0 + u * 16 >= p.R) break;
-#pragma unroll
-        for (int o = 16; o < 64; o <<= 1) {
-          const float om = __shfl_xor(vm[u], o, 64), os = __shfl_xor(vs[u], o, 64);
-          const int oi = __shfl_xor(vi[u], o, 64);
-          amax_merge(vm[u], vi[u], vs[u], om, oi, os);
+        {  // the four column groups of a row (lane ^ 16, lane ^ 32): row / half swaps, no LDS round trips
+          amax_merge(vm[u], vi[u], vs[u], x16_other(vm[u]), x16_other(vi[u]), x16_other(vs[u]));
+          amax_merge(vm[u], vi[u], vs[u], x32_other(vm[u]), x32_other(vi[u]), x32_other(vs[u]));
         }
         if (u > 0) __syncthreads();  // wave 0 has read the previous tile's entries
         if (kg == 0) { s_pm[wave][l16] = vm[u]; s_pi[wave][l16] = vi[u]; s_ps[wave][l16] = vs[u]; }
@@ -996,31 +1033,6 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
   gs.mark();
   gs.arrive(pm.has);
   return nprod;
-}
-
-// lane ^ 8 / ^ 16 / ^ 32 exchanges of the attention reductions without the LDS crossbar: row_ror:8 (DPP), and the
-// gfx950 row / half swaps - v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of
-// its second, v_permlane32_swap the upper half of the first with the lower half of the second; with both operands = v the
-// two results are (lower partner, upper partner) in every lane.  a + b == b + a: the sums are those of __shfl_xor, bit for bit.
-__device__ __forceinline__ float x16_sum(float v) {
-  const int iv = __builtin_bit_cast(int, v);
-  const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
-  return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
-}
-__device__ __forceinline__ float x32_sum(float v) {
-  const int iv = __builtin_bit_cast(int, v);
-  const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
-  return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
-}
-__device__ __forceinline__ float x16_max(float v) {
-  const int iv = __builtin_bit_cast(int, v);
-  const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
-  return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
-}
-__device__ __forceinline__ float x32_max(float v) {
-  const int iv = __builtin_bit_cast(int, v);
-  const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
-  return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
 }
 
 // One (row, head) of attention on fragments in registers: lane = (key slot = lane >> 3, 8-dim chunk = lane & 7); scores /
