@@ -452,6 +452,82 @@ __device__ __forceinline__ int fetch_token(const RArgs& p, int r0, int t, bool w
   }
 }
 
+// NV 16-byte pieces of a handed-over fp32 row (base + 256 k bytes) as NV global_load_dwordx4 sc1 - the widest agent-scope
+// atomic load the compiler spells is 8 bytes, two instructions per piece, and a row group with the second FFN half in
+// flight was 64 load instructions per lane (vmcnt counts 63).  ONE asm statement issues the loads AND waits for them: the
+// compiler cannot know when an asm load's destination becomes valid, so nothing may touch it in between (plain loads
+// requested before the statement stay in flight under it; the wait covers them too).
+template <int NV>
+__device__ __forceinline__ void cld16_row(const float* base, float4 (&v)[NV]) {
+  static_assert(NV == 8 || NV == 12 || NV == 16, "row pieces");
+  f32x4 r[NV];
+  if constexpr (NV == 8) {
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %2, %8, off offset:512 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:768 sc1\n\t"
+        "global_load_dwordx4 %4, %8, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:1280 sc1\n\t"
+        "global_load_dwordx4 %6, %8, off offset:1536 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:1792 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "v"(base)
+        : "memory");
+  } else if constexpr (NV == 12) {
+    asm volatile(
+        "global_load_dwordx4 %0, %12, off sc1\n\tglobal_load_dwordx4 %1, %12, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %2, %12, off offset:512 sc1\n\tglobal_load_dwordx4 %3, %12, off offset:768 sc1\n\t"
+        "global_load_dwordx4 %4, %12, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %12, off offset:1280 sc1\n\t"
+        "global_load_dwordx4 %6, %12, off offset:1536 sc1\n\tglobal_load_dwordx4 %7, %12, off offset:1792 sc1\n\t"
+        "global_load_dwordx4 %8, %12, off offset:2048 sc1\n\tglobal_load_dwordx4 %9, %12, off offset:2304 sc1\n\t"
+        "global_load_dwordx4 %10, %12, off offset:2560 sc1\n\tglobal_load_dwordx4 %11, %12, off offset:2816 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
+          "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11])
+        : "v"(base)
+        : "memory");
+  } else {
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %16, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %2, %16, off offset:512 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:768 sc1\n\t"
+        "global_load_dwordx4 %4, %16, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %16, off offset:1280 sc1\n\t"
+        "global_load_dwordx4 %6, %16, off offset:1536 sc1\n\tglobal_load_dwordx4 %7, %16, off offset:1792 sc1\n\t"
+        "global_load_dwordx4 %8, %16, off offset:2048 sc1\n\tglobal_load_dwordx4 %9, %16, off offset:2304 sc1\n\t"
+        "global_load_dwordx4 %10, %16, off offset:2560 sc1\n\tglobal_load_dwordx4 %11, %16, off offset:2816 sc1\n\t"
+        "global_load_dwordx4 %12, %16, off offset:3072 sc1\n\tglobal_load_dwordx4 %13, %16, off offset:3328 sc1\n\t"
+        "global_load_dwordx4 %14, %16, off offset:3584 sc1\n\tglobal_load_dwordx4 %15, %16, off offset:3840 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
+          "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+        : "v"(base)
+        : "memory");
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = make_float4(r[k][0], r[k][1], r[k][2], r[k][3]);
+}
+
+// ... two rows of 8 pieces (y and the second FFN half y2) in ONE statement: 16 loads in flight, one wait
+__device__ __forceinline__ void cld16_row2(const float* a, const float* b, float4 (&v)[8], float4 (&w)[8]) {
+  f32x4 r[16];
+  asm volatile(
+      "global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %16, off offset:256 sc1\n\t"
+      "global_load_dwordx4 %2, %16, off offset:512 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:768 sc1\n\t"
+      "global_load_dwordx4 %4, %16, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %16, off offset:1280 sc1\n\t"
+      "global_load_dwordx4 %6, %16, off offset:1536 sc1\n\tglobal_load_dwordx4 %7, %16, off offset:1792 sc1\n\t"
+      "global_load_dwordx4 %8, %17, off sc1\n\tglobal_load_dwordx4 %9, %17, off offset:256 sc1\n\t"
+      "global_load_dwordx4 %10, %17, off offset:512 sc1\n\tglobal_load_dwordx4 %11, %17, off offset:768 sc1\n\t"
+      "global_load_dwordx4 %12, %17, off offset:1024 sc1\n\tglobal_load_dwordx4 %13, %17, off offset:1280 sc1\n\t"
+      "global_load_dwordx4 %14, %17, off offset:1536 sc1\n\tglobal_load_dwordx4 %15, %17, off offset:1792 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
+        "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+      : "v"(a), "v"(b)
+      : "memory");
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = make_float4(r[k][0], r[k][1], r[k][2], r[k][3]);
+    w[k] = make_float4(r[8 + k][0], r[8 + k][1], r[8 + k][2], r[8 + k][3]);
+  }
+}
+
 template <int AMODE, int D = 512>
 __device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, int mytok, const float* ysrc, const float* ysrc2,
                                              float4 (&v)[D / 64]) {
@@ -472,6 +548,7 @@ __device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, int 
       for (int k = 0; k < NV; ++k) add4(v[k], *reinterpret_cast<const float4*>(sm + 64 * k));
     }
   } else {
+#ifdef RES_LD8
     const float* y = ysrc + (int64_t)rc * d + sub * 4;
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = cld_f4(y + 64 * k);
@@ -480,6 +557,21 @@ __device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, int 
 #pragma unroll
       for (int k = 0; k < NV; ++k) add4(v[k], cld_f4(y2 + 64 * k));
     }
+#else
+    if (ysrc2) {  // the second K half of a two-workgroup FFN dense2 (ffn2_phase<true>): y = y + y2
+      float4 w2[NV];
+      if constexpr (NV == 8) {
+        cld16_row2(ysrc + (int64_t)rc * d + sub * 4, ysrc2 + (int64_t)rc * d + sub * 4, v, w2);
+      } else {
+        cld16_row<NV>(ysrc + (int64_t)rc * d + sub * 4, v);
+        cld16_row<NV>(ysrc2 + (int64_t)rc * d + sub * 4, w2);
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) add4(v[k], w2[k]);
+    } else {
+      cld16_row<NV>(ysrc + (int64_t)rc * d + sub * 4, v);
+    }
+#endif
   }
 }
 
