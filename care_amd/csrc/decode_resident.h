@@ -528,6 +528,55 @@ __device__ __forceinline__ void cld16_row2(const float* a, const float* b, float
   }
 }
 
+// ... N (4 or 8) pieces at addresses of their own / 16 pieces at 8 bases -+ 2048 bytes (two tile rows 4096 bytes apart)
+__device__ __forceinline__ void cld16_x4(const void* a0, const void* a1, const void* a2, const void* a3, bf16x8 (&v)[4]) {
+  f32x4 r[4];
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+      "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+      : "memory");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = __builtin_bit_cast(bf16x8, r[k]);
+}
+__device__ __forceinline__ void cld16_x8(const void* const (&a)[8], bf16x8 (&v)[8]) {
+  f32x4 r[8];
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
+      : "memory");
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = __builtin_bit_cast(bf16x8, r[k]);
+}
+// piece i at `first + 4096 i` bytes, i < 16 (the 16 rows of a K = 2048 bf16 tile): 8 bases, offsets -2048 / +2048
+__device__ __forceinline__ void cld16_x16_rows4k(const unsigned char* first, bf16x8 (&v)[16]) {
+  f32x4 r[16];
+  const unsigned char* b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = first + 8192 * j + 2048;
+  asm volatile(
+      "global_load_dwordx4 %0, %16, off offset:-2048 sc1\n\tglobal_load_dwordx4 %1, %16, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %2, %17, off offset:-2048 sc1\n\tglobal_load_dwordx4 %3, %17, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %4, %18, off offset:-2048 sc1\n\tglobal_load_dwordx4 %5, %18, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %6, %19, off offset:-2048 sc1\n\tglobal_load_dwordx4 %7, %19, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %8, %20, off offset:-2048 sc1\n\tglobal_load_dwordx4 %9, %20, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %10, %21, off offset:-2048 sc1\n\tglobal_load_dwordx4 %11, %21, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %12, %22, off offset:-2048 sc1\n\tglobal_load_dwordx4 %13, %22, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %14, %23, off offset:-2048 sc1\n\tglobal_load_dwordx4 %15, %23, off offset:2048 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
+        "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+      : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7])
+      : "memory");
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = __builtin_bit_cast(bf16x8, r[k]);
+}
+
 template <int AMODE, int D = 512>
 __device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, int mytok, const float* ysrc, const float* ysrc2,
                                              float4 (&v)[D / 64]) {
@@ -634,11 +683,27 @@ template <int K>
 __device__ __forceinline__ void load_a_bf16(const RArgs& p, int r0, const bf16_t* src, bf16_t* sA, int lda) {
   constexpr int per_row = K / 8, NC = 16 * per_row / 256;  // 16-byte chunks per thread, all in flight together
   bf16x8 v[NC];
+  if constexpr (NC == 4 || NC == 8) {
+    const void* a[NC];
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = threadIdx.x + 256 * i, rr = c / per_row, c8 = c - rr * per_row;
-    v[i] = cld_b8(src + (int64_t)(r0 + rr < p.R ? r0 + rr : 0) * K + c8 * 8);
-    if (r0 + rr >= p.R) v[i] = bf16x8{};
+    for (int i = 0; i < NC; ++i) {
+      const int c = threadIdx.x + 256 * i, rr = c / per_row, c8 = c - rr * per_row;
+      a[i] = src + (int64_t)(r0 + rr < p.R ? r0 + rr : 0) * K + c8 * 8;
+    }
+    if constexpr (NC == 4) cld16_x4(a[0], a[1], a[2], a[3], v);
+    else cld16_x8(a, v);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = threadIdx.x + 256 * i, rr = c / per_row;
+      if (r0 + rr >= p.R) v[i] = bf16x8{};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = threadIdx.x + 256 * i, rr = c / per_row, c8 = c - rr * per_row;
+      v[i] = cld_b8(src + (int64_t)(r0 + rr < p.R ? r0 + rr : 0) * K + c8 * 8);
+      if (r0 + rr >= p.R) v[i] = bf16x8{};
+    }
   }
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
@@ -1051,11 +1116,32 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
         constexpr int KP = HALF ? KF / 2 : KF, per_row = KP / 8, NC = 16 * per_row / 256;
         const int kb = HALF ? kh * (KF / 2) : 0;
         bf16x8 v[NC];
+        if constexpr (NC == 16 && KF == 2048 && !HALF) {
+          // row i of the tile, this thread's 16 bytes: 4096 bytes apart (rows past the batch lie inside the scratch too)
+          cld16_x16_rows4k(reinterpret_cast<const unsigned char*>(p.h + (int64_t)r0 * K + threadIdx.x * 8), v);
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-          const int q = threadIdx.x + 256 * i, rr = q / per_row, c8 = q - rr * per_row;
-          v[i] = cld_b8(p.h + (int64_t)(r0 + rr < p.R ? r0 + rr : 0) * K + kb + c8 * 8);
-          if (r0 + rr >= p.R) v[i] = bf16x8{};
+          for (int i = 0; i < NC; ++i)
+            if (r0 + i >= p.R) v[i] = bf16x8{};
+        } else if constexpr (NC == 8) {
+          const void* a[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int q = threadIdx.x + 256 * i, rr = q / per_row, c8 = q - rr * per_row;
+            a[i] = p.h + (int64_t)(r0 + rr < p.R ? r0 + rr : 0) * K + kb + c8 * 8;
+          }
+          cld16_x8(a, v);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int q = threadIdx.x + 256 * i, rr = q / per_row;
+            if (r0 + rr >= p.R) v[i] = bf16x8{};
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NC; ++i) {
+            const int q = threadIdx.x + 256 * i, rr = q / per_row, c8 = q - rr * per_row;
+            v[i] = cld_b8(p.h + (int64_t)(r0 + rr < p.R ? r0 + rr : 0) * K + kb + c8 * 8);
+            if (r0 + rr >= p.R) v[i] = bf16x8{};
+          }
         }
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
