@@ -414,6 +414,10 @@ def test_early_exit_and_compaction_equal_the_fixed_length_pass(config, dtype, B)
         assert any(k[0] == "gseg" and isinstance(g, tuple) for k, g in eng._graphs.items()), "no segment was captured"
     if B >= 2048:
         assert any(k[0] == "gseg" and k[4] < B for k in eng._graphs), "no compacted segment ran"
+    if B == 4096:
+        # ... and one of them BELOW the row count at which the vocabulary arg-max changes kernels (engine.VOCAB_TILE_MAX_ROWS):
+        # the kernel form follows the pass's initial row count (engine._vocab_as), so the tokens above stay bit-identical
+        assert any(k[0] == "gseg" and k[4] <= eng.VOCAB_TILE_MAX_ROWS for k in eng._graphs), sorted(k[4] for k in eng._graphs if k[0] == "gseg")
     # new inputs in the same buffers: the captured segments must follow them (and a different finish pattern)
     for f in feats:
         f.copy_(f.flip(0))
