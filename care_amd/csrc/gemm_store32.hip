@@ -53,7 +53,9 @@ struct SArgs {
 
 __device__ __forceinline__ float s_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <int BDEPTH>
+// GELU is a template parameter: erff inlined behind a run-time test in every epilogue piece made the kernel 6872
+// instructions (55 KB) against 2658 without it - the relu / plain launches of the headline pass carried it along.
+template <int BDEPTH, bool GELU>
 __global__ __launch_bounds__(512, 2) void gemm_store32_kernel(SArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -136,8 +138,8 @@ __global__ __launch_bounds__(512, 2) void gemm_store32_kernel(SArgs p) {
       v[4 * g + 2] = ap[4 * g + 2] + bv.z; v[4 * g + 3] = ap[4 * g + 3] + bv.w;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (p.act == CARE_ACT_RELU) v[4 * g + j] = fmaxf(v[4 * g + j], 0.0f);
-        else if (p.act == CARE_ACT_GELU) v[4 * g + j] = s_gelu(v[4 * g + j]);
+        if constexpr (GELU) v[4 * g + j] = s_gelu(v[4 * g + j]);
+        else if (p.act == CARE_ACT_RELU) v[4 * g + j] = fmaxf(v[4 * g + j], 0.0f);
       }
     };
     auto out_store = [&](int tile, const float (&v)[16]) -> int {
@@ -316,9 +318,15 @@ extern "C" int care_store32_launch(const void* A, int64_t lda, const void* W, co
   // 16-byte stores: destinations and leading dimensions must allow them
   const int e0 = c0_bf16 ? 8 : 4, e1 = c1_bf16 ? 8 : 4;
   if ((ldc0 % e0) || !care_aligned16(C0) || (n_split < N && ((ldc1 % e1) || !care_aligned16(C1)))) return CARE_EALIGN;
-  static std::atomic<unsigned long long> lds_ok{0};
-  if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_store32_kernel<4>), S_LDS, lds_ok)) return e;
   const int blocks = p.total_items < 256 ? p.total_items : 256;
-  hipLaunchKernelGGL((gemm_store32_kernel<4>), dim3(blocks), dim3(512), S_LDS, (hipStream_t)stream, p);
+  if (act == CARE_ACT_GELU) {
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_store32_kernel<4, true>), S_LDS, lds_ok)) return e;
+    hipLaunchKernelGGL((gemm_store32_kernel<4, true>), dim3(blocks), dim3(512), S_LDS, (hipStream_t)stream, p);
+  } else {
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_store32_kernel<4, false>), S_LDS, lds_ok)) return e;
+    hipLaunchKernelGGL((gemm_store32_kernel<4, false>), dim3(blocks), dim3(512), S_LDS, (hipStream_t)stream, p);
+  }
   return care_launch_status();
 }

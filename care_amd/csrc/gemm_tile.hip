@@ -21,8 +21,16 @@
 //   * epilogues: bias + activation + (split) store in bf16 / fp32 - or per-row (max, first arg-max,
 //     sum exp) of the 64 columns of every wave, the vocabulary projection of greedy decoding
 //     (models/Head.py:26-32, Translator.py:127), optionally with the label logit (teacher-forced scoring);
-//   * blocks are numbered XCD-aware: the blocks of one XCD (blockIdx % 8) walk a contiguous run of tiles,
-//     row tiles fastest, so an XCD's L2 keeps the W column tile it is multiplying.
+//   * blocks are numbered XCD-aware: the blocks of one XCD (blockIdx % 8) walk a contiguous run of tiles in bands of 8
+//     row tiles (tile_of_block), so the 32 tiles an XCD works on at a time share 8 A panels and 4 W panels in its L2.
+// What bounds it (*measured*, round 4): 4096^3 1296 TFLOP/s, 8192^3 1372 on random operands
+// (0.52-0.55 of the dense bf16 peak; zero-filled operands read 18-20 % higher: clocks).  With the LDS-DMA removed the
+// loop runs at 1.8-2.0 PFLOP/s, with 15 of 16 MFMAs removed no faster than whole: the tile is bound by FETCHING its
+// operands (tools/micro/dma_rate.hip: this tile's fetch alone runs at 24.5-25 TB/s chip-wide in pieces of 8 rows x 128 B,
+// 15.7-17.4 TB/s in pieces of 16 rows x 64 B).  Two-wave-group variants of the 256 x 256 tile (8 waves of 128 x 64, the
+// groups one barrier apart so one multiplies while the other reads and issues DMA; K steps of 32 in rings of 4 and 5, K
+// steps of 64 in row groups with 64 KB in flight; one persistent with the next tile's first stages in flight across the
+// epilogue) were built, verified, and landed within 2 % of this kernel on every shape: not kept.
 #include <cstdlib>
 
 #include "care_common.h"
@@ -38,12 +46,28 @@ struct TArgs {
   int n_split, M, N, K, act;
   float* pmax; int32_t* pidx; float* psum; int parts;
   const int32_t* labels; float* plab;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, group;  // group: row tiles per band of the block -> tile map
   int a_wrap;  // K steps (of 64) after which the A columns start over: see care_gemm_tile_split3 (INT_MAX otherwise)
   int64_t a_bs, w_bs, c_bs; int bias_bs;  // batched launches (blockIdx.y): element offsets per batch of A, W, C0, bias
 };
 
 enum { EPI_STORE = 0, EPI_ARGMAX = 1, EPI_ARGMAX_LAB = 2 };
+
+// Block -> output tile.  Blocks are dealt to the 8 XCDs round robin and in order, so the 32 workgroups an XCD runs at a
+// time are 32 CONSECUTIVE numbers of its run (bijective for any grid size); inside a run the tiles go in bands of
+// `group` row tiles, row tile fastest inside a band: those 32 tiles are `group` row tiles x 32 / group column tiles and
+// the XCD's L2 fetches group + 32 / group operand panels for them, not 32 + 1 (all row tiles of one column tile:
+// *measured* M = 65536, N = 4096, K = 1024: every A panel missed the L2, the kernel ran at the 8 TB/s of the
+// Infinity Cache with 1 MFMA in 16 removed and at 1.3 x the rate with the loads removed).
+__device__ __forceinline__ void tile_of_block(const int tiles_m, const int tiles_n, const int group, int& tm, int& tn) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  const int band = group * tiles_n, b = t / band, o = t - b * band;
+  const int rows = min(group, tiles_m - b * group);
+  tm = b * group + o % rows;
+  tn = o / rows;
+}
 
 __device__ __forceinline__ float t_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
@@ -52,11 +76,158 @@ __device__ __forceinline__ void t_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory");
 }
 
+// The epilogue of a wave's (16 MT) x 64 outputs:
+// acc[m][n][j] = out[row row0 + 16 m + fr][column col0 + 4 n + j], col0 = (the wave's first column) + 16 fg
+// GELU is a template parameter: erff inlined for the 16 MT values of a lane behind a run-time test was ~ 9000 instructions
+// of epilogue, more than the instruction cache holds - *measured* 13 100 cycles per tile and wave group with the
+// activation OFF (s_memtime stamps around the epilogue of a persistent variant of this tile), a sixth of a 256 x 256 x 1024 tile.
+template <int EPI, int MT, bool GELU>
+__device__ __forceinline__ void tile_epilogue(const TArgs& p, f32x4 (&acc)[MT][4], int row0, int col0, int fr, int fg) {
+  if constexpr (EPI == EPI_STORE) {
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = 0.0f;
+    if (p.bias) {
+      if (col0 + 16 <= p.N && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 4 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[4 * g + j] = b4[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (col0 + j < p.N) bv[j] = p.bias[col0 + j];
+      }
+    }
+    const bool second = col0 >= p.n_split;  // n_split % 16 == 0: a lane's 16 columns never straddle it
+    unsigned char* C = reinterpret_cast<unsigned char*>(second ? p.C1 : p.C0);
+    const int64_t ld = second ? p.ldc1 : p.ldc0;
+    const bool isb = (second ? p.c1_bf16 : p.c0_bf16) != 0;
+    const int cc = col0 - (second ? p.n_split : 0);
+    const int nvalid = min(16, (second ? p.N : min(p.N, p.n_split)) - col0);  // columns of this lane inside the destination
+    const bool vec = nvalid == 16 && ((ld & 7) == 0) && ((cc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    // the wave's 64 columns whole and in one destination (wave-uniform): the four lanes of a row trade 16-byte chunks so
+    // that ONE store instruction writes 64 contiguous bytes of every row (bf16) - *measured* on the 256 x 256 tile: a
+    // lane storing its own 32 bytes as two 16-byte pieces (64 separate 16-byte writes per instruction) took 13 200
+    // cycles per wave group and tile, a sixth of the tile's time at K = 1024
+    const int colw = col0 - fg * 16;
+    const bool wide = isb && vec && colw + 64 <= (second ? p.N : min(p.N, p.n_split)) && (colw >= p.n_split || colw + 64 <= p.n_split);
+    const bool wide_u = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_ballot_w64(!wide) == 0 && (int)(__builtin_amdgcn_ballot_w64(!wide) >> 32) == 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row = row0 + m * 16 + fr;
+      float v[16];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = acc[m][n][j] + bv[4 * n + j];
+          if constexpr (GELU) x = t_gelu(x);
+          else x = p.act == CARE_ACT_RELU ? fmaxf(x, 0.0f) : x;
+          v[4 * n + j] = x;
+        }
+      if (wide_u) {
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o0[j] = (bf16_t)v[j]; o1[j] = (bf16_t)v[8 + j]; }
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4 lo = __builtin_bit_cast(i32x4, o0), hi = __builtin_bit_cast(i32x4, o1), x, y;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {  // lanes fg < 2: (own lo, partner's lo); fg >= 2: (partner's hi, own hi) - chunks (c, c + 4)
+          const auto r = __builtin_amdgcn_permlane32_swap(lo[d], hi[d], false, false);
+          x[d] = (int)r[0]; y[d] = (int)r[1];
+        }
+        const int c = fg < 2 ? 2 * fg : 2 * fg - 3;
+        if (row < p.M) {
+          bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (int64_t)row * ld + (cc - fg * 16) + 8 * c;
+          *reinterpret_cast<i32x4*>(dst) = x;
+          *reinterpret_cast<i32x4*>(dst + 32) = y;
+        }
+        continue;
+      }
+      if (row >= p.M || nvalid <= 0) continue;
+      if (isb) {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (int64_t)row * ld + cc;
+        if (vec) {
+          bf16x8 o0, o1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { o0[j] = (bf16_t)v[j]; o1[j] = (bf16_t)v[8 + j]; }
+          *reinterpret_cast<bf16x8*>(dst) = o0;
+          *reinterpret_cast<bf16x8*>(dst + 8) = o1;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j < nvalid) dst[j] = (bf16_t)v[j];
+        }
+      } else {
+        float* dst = reinterpret_cast<float*>(C) + (int64_t)row * ld + cc;
+        if (vec) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(dst + 4 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j < nvalid) dst[j] = v[j];
+        }
+      }
+    }
+  } else {
+    // per row of this wave's 64 columns: max, FIRST arg-max, sum exp(x - max) [, the logit of the label column]
+    const int part = (col0 - fg * 16) >> 6;  // one partial per 64 columns, whatever the tile shape
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row = row0 + m * 16 + fr;
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = col0 + 4 * n + j;
+          const float x = col < p.N ? acc[m][n][j] : -INFINITY;
+          if (x > best) { best = x; bi = col; }  // columns ascend: the first maximum is kept
+        }
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      float s = 0.0f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col0 + 4 * n + j < p.N) s += __expf(acc[m][n][j] - best);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      float lv = -INFINITY;
+      if constexpr (EPI == EPI_ARGMAX_LAB) {
+        const int lab = p.labels[min(row, p.M - 1)];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (col0 + 4 * n + j == lab) lv = acc[m][n][j];
+        lv = fmaxf(lv, __shfl_xor(lv, 16, 64));
+        lv = fmaxf(lv, __shfl_xor(lv, 32, 64));
+      }
+      if (fg == 0 && row < p.M && part < p.parts) {
+        const int64_t o = (int64_t)row * p.parts + part;
+        p.pmax[o] = best; p.pidx[o] = bi; p.psum[o] = s;
+        if constexpr (EPI == EPI_ARGMAX_LAB) p.plab[o] = lv;
+      }
+    }
+  }
+}
+
 // BK = K elements per ring stage: 64 (128-byte LDS rows, two MFMA k-steps per stage) or 32 (64-byte rows, one k-step:
 // twice the stages in the same LDS, i.e. more K steps of prefetch for the same bytes in use).  Swizzle of a 64-byte
 // row's four 16-byte chunks: chunk ^= G[(row >> 2) & 3], G = {0, 3, 2, 1} - the 16 lanes of every ds_read_b128 lane
 // group ({0-3, 12-15, 20-27}, ...) then fall on 16 different 16-byte slots of the 256-byte bank row.
-template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false, int BK = 64>
+template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false, int BK = 64, bool GELU = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
   constexpr int NW = WGM * WGN, BM = 64 * WTM * WGM, BN = 64 * WGN;
   constexpr int MT = 4 * WTM;             // 16-row accumulator tiles of a wave (its (64 WTM) x 64 outputs)
@@ -75,14 +246,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
-  // XCD-aware tile number (bijective for any grid size)
-  int t;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  const int m0 = (t % p.tiles_m) * BM, n0 = (t / p.tiles_m) * BN;
+  int tm, tn;
+  tile_of_block(p.tiles_m, p.tiles_n, p.group, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
   if (gridDim.y > 1) {  // batched: one independent product per blockIdx.y (the per-head projections of the absorbed attention)
     const int b = blockIdx.y;
     p.A += (int64_t)b * p.a_bs;
@@ -169,122 +335,30 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
     }
   }
 
-  // ------------------------------------------------------------------ epilogue
-  // acc[m][n][j] = out[row m0 + 64 WTM wm + 16 m + fr][column n0 + 64 wn + 16 fg + 4 n + j]
-  const int col0 = n0 + wn * 64 + fg * 16;  // first of this lane's 16 consecutive columns
-  if constexpr (EPI == EPI_STORE) {
-    float bv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) bv[j] = (p.bias && col0 + j < p.N) ? p.bias[col0 + j] : 0.0f;
-    const bool second = col0 >= p.n_split;  // n_split % 16 == 0: a lane's 16 columns never straddle it
-    unsigned char* C = reinterpret_cast<unsigned char*>(second ? p.C1 : p.C0);
-    const int64_t ld = second ? p.ldc1 : p.ldc0;
-    const bool isb = (second ? p.c1_bf16 : p.c0_bf16) != 0;
-    const int cc = col0 - (second ? p.n_split : 0);
-    const int nvalid = min(16, (second ? p.N : min(p.N, p.n_split)) - col0);  // columns of this lane inside the destination
-    const bool vec = nvalid == 16 && ((ld & 7) == 0) && ((cc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int row = m0 + wm * 64 * WTM + m * 16 + fr;
-      float v[16];
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float x = acc[m][n][j] + bv[4 * n + j];
-          if (p.act == CARE_ACT_RELU) x = fmaxf(x, 0.0f);
-          else if (p.act == CARE_ACT_GELU) x = t_gelu(x);
-          v[4 * n + j] = x;
-        }
-      if (row >= p.M || nvalid <= 0) continue;
-      if (isb) {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (int64_t)row * ld + cc;
-        if (vec) {
-          bf16x8 o0, o1;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { o0[j] = (bf16_t)v[j]; o1[j] = (bf16_t)v[8 + j]; }
-          *reinterpret_cast<bf16x8*>(dst) = o0;
-          *reinterpret_cast<bf16x8*>(dst + 8) = o1;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (j < nvalid) dst[j] = (bf16_t)v[j];
-        }
-      } else {
-        float* dst = reinterpret_cast<float*>(C) + (int64_t)row * ld + cc;
-        if (vec) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(dst + 4 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-        } else {
-#pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (j < nvalid) dst[j] = v[j];
-        }
-      }
-    }
-  } else {
-    // per row of this wave's 64 columns: max, FIRST arg-max, sum exp(x - max) [, the logit of the label column]
-    const int part = (n0 >> 6) + wn;  // one partial per 64 columns, whatever the tile shape
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int row = m0 + wm * 64 * WTM + m * 16 + fr;
-      float best = -INFINITY;
-      int bi = 0x7fffffff;
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int col = col0 + 4 * n + j;
-          const float x = col < p.N ? acc[m][n][j] : -INFINITY;
-          if (x > best) { best = x; bi = col; }  // columns ascend: the first maximum is kept
-        }
-#pragma unroll
-      for (int o = 16; o < 64; o <<= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-      }
-      float s = 0.0f;
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (col0 + 4 * n + j < p.N) s += __expf(acc[m][n][j] - best);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      float lv = -INFINITY;
-      if constexpr (EPI == EPI_ARGMAX_LAB) {
-        const int lab = p.labels[min(row, p.M - 1)];
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (col0 + 4 * n + j == lab) lv = acc[m][n][j];
-        lv = fmaxf(lv, __shfl_xor(lv, 16, 64));
-        lv = fmaxf(lv, __shfl_xor(lv, 32, 64));
-      }
-      if (fg == 0 && row < p.M && part < p.parts) {
-        const int64_t o = (int64_t)row * p.parts + part;
-        p.pmax[o] = best; p.pidx[o] = bi; p.psum[o] = s;
-        if constexpr (EPI == EPI_ARGMAX_LAB) p.plab[o] = lv;
-      }
-    }
-  }
+  tile_epilogue<EPI, MT, GELU>(p, acc, m0 + wm * 64 * WTM, n0 + wn * 64 + fg * 16, fr, fg);
 }
 
-template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false, int BK = 64>
+int tile_group(int tiles_m) {
+  static const int g = [] { const char* e = getenv("CARE_TILE_GROUP"); return e ? atoi(e) : 8; }();
+  return g > 0 ? g : tiles_m;  // 0: the whole column of row tiles (the map before the bands)
+}
+
+template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false, int BK = 64, bool GELU = false>
 int launch_tile(TArgs& p, hipStream_t st, int batch = 1) {
+  if constexpr (EPI == EPI_STORE && !GELU)
+    if (p.act == CARE_ACT_GELU) return launch_tile<WGM, WGN, WTM, STAGES, EPI, F16, BK, true>(p, st, batch);
   constexpr int BM = 64 * WTM * WGM, BN = 64 * WGN;
   constexpr int lds = STAGES * (BM + BN) * BK * 2;
   if (BK == 32 && F16) p.a_wrap *= 2;  // a_wrap is handed over in K steps of 64
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
+  p.group = tile_group(p.tiles_m);
   if (lds > 64 * 1024) {
     static std::atomic<unsigned long long> done{0};
-    const int rc = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16, BK>), lds, done);
+    const int rc = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16, BK, GELU>), lds, done);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL((gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16, BK>), dim3(p.tiles_m * p.tiles_n, batch), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((gemm_tile_kernel<WGM, WGN, WTM, STAGES, EPI, F16, BK, GELU>), dim3(p.tiles_m * p.tiles_n, batch), dim3(64 * WGM * WGN), lds, st, p);
   return care_launch_status();
 }
 

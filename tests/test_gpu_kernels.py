@@ -715,7 +715,7 @@ def test_fused_beam_selection_equals_logits_plus_beam_select(M, V, bm):
         assert (got_v[over] - ref_v[over]).abs().max().item() < 1e-3
 
 
-TILE_SHAPES = [(1, 1024, 1024), (5, 10547, 1024), (64, 768, 768), (100, 3072, 1024), (257, 4096, 1024), (300, 1024, 4096),
+TILE_SHAPES = [(1, 1024, 1024), (700, 520, 64), (300, 256, 128), (5, 10547, 1024), (64, 768, 768), (100, 3072, 1024), (257, 4096, 1024), (300, 1024, 4096),
                (130, 640, 640), (200, 768, 3072), (1000, 48, 512), (4096, 1024, 1024), (513, 10547, 768), (777, 2304, 768),
                (4096 + 19, 3072, 1024), (2048, 512, 2048)]
 

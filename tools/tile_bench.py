@@ -14,11 +14,13 @@ DEV = "cuda:0"
 
 def main():
     shapes = [(4096, 3072, 1024), (4096, 1024, 1024), (4096, 4096, 1024), (4096, 1024, 4096), (4096, 10547, 1024),
-              (4096 * 114, 2048, 1024), (4096, 2304, 768), (4096, 10547, 768), (20480, 1024, 1024), (20480, 4096, 1024),
-              (4096 * 29, 1536, 512), (4096 * 29, 512, 2048), (128, 3072, 1024), (640, 4096, 1024)]
+              (16384, 3072, 1024), (16384, 1024, 1024), (16384, 4096, 1024), (16384, 1024, 4096), (16384, 10547, 1024),
+              (4096 * 114, 2048, 1024), (4096, 2304, 768), (4096, 10547, 768), (16384, 2304, 768), (16384, 768, 3072),
+              (4096 * 29, 1536, 512), (4096 * 29, 512, 2048), (4096 * 29, 2048, 512), (4096 * 29, 10547, 512),
+              (4096, 4096, 4096), (8192, 8192, 8192), (640, 4096, 1024)]
     if len(sys.argv) > 1:
         shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
-    cfgs = ["222", "122", "123", "212", "242", "4412"]
+    cfgs = ["222", "4412", "90"]
     p = lambda t: t.data_ptr()
     for M, N, K in shapes:
         A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
@@ -36,7 +38,7 @@ def main():
                                             M, N, K, 0))
             line += " %s: %7.1f us %6.1f TF |" % (cfg, t, fl / t / 1e6)
         if N > 8192:
-            for cfg in ("4412", "4414"):
+            for cfg in ("4412", "90"):
                 os.environ["CARE_TILE_CFG"] = cfg
                 t = time_call(lambda: _lib.call("care_gemm_tile_argmax", p(A), K, p(W), p(pm), p(pi), p(ps), None, None, M, N, K))
                 line += " argmax %s: %7.1f us %6.1f TF |" % (cfg, t, fl / t / 1e6)
