@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -72,6 +72,7 @@ SIGNATURES = {
     "care_decode_resident_beam": [_P, _I, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I,
                                   _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _P],
     "care_gemm_kn": [_P, _L, _I, _P, _L, _P, _L, _I, _I, _I, _P],
+    "care_gemm_kn_splitk": [_P, _L, _I, _P, _L, _P, _L, _L, _I, _I, _I, _I, _P],
     "care_ln_bwd": [_P, _L, _P, _L, _P, _P, _L, _F, _P, _L, _P, _P, _I, _I, _P],
     "care_act": [_P, _P, _P, _L, _I, _P],
     "care_dropout": [_P, _P, _L, _F, _U, _P],
@@ -96,7 +97,8 @@ PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_argmax_
          "care_beam_sparse_applies": (c_int, [c_int, c_int, c_int, c_int]),
          "care_decode_resident_scratch": (c_int64, [c_int, c_int, c_int, c_int]),
          "care_decode_resident_beam_scratch": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
-         "care_decode_resident_debug": (None, [c_int, c_int])}
+         "care_decode_resident_debug": (None, [c_int, c_int]),
+         "care_gemm_kn_splits": (c_int, [c_int, c_int, c_int])}
 
 
 class ResidentAttn(ctypes.Structure):

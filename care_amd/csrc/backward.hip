@@ -17,13 +17,15 @@ namespace {
 // workgroup: a lane keeps the dgamma / dbeta contributions of its columns in registers over its wave's rows, the four
 // waves meet in LDS, and the workgroup adds ONE value per column to the global sums (the first version issued two
 // atomics per element - 1.9 M onto 512 addresses for [1856, 512]: 90 us per launch, rocprofv3 round 4).  d <= 2048.
+// MAXC = columns per lane (d <= 64 MAXC) is a template parameter: sized for d = 2048 the unrolled loops carried four
+// times the instructions and registers a d_model = 512 row needs (35 us per launch at [1856, 512], rocprofv3 round 4).
 constexpr int LN_BWD_ROWS = 16;
+template <int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, int64_t ldx, const float* res, int64_t ldres,
                                                      const float* gamma, const float* dy, int64_t lddy, float eps, float* ds,
                                                      int64_t ldds, float* dgamma, float* dbeta, int rows, int d) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int MAXC = 32;  // columns per lane: d <= 2048
-  __shared__ float s_dg[3][2048], s_db[3][2048];
+  __shared__ float s_dg[3][64 * MAXC], s_db[3][64 * MAXC];
   float ag[MAXC], ab[MAXC];
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
@@ -334,7 +336,7 @@ inline unsigned grid1d(int64_t n) { return (unsigned)((n + 255) / 256); }
 // travels in registers while the current one is multiplied.  Any M, N, K, any leading dimensions (scalar, coalesced loads).
 template <bool TA, int BT>  // BT x BT output tiles (64 or 128): a wave owns (BT / 2) x (BT / 2) outputs
 __global__ __launch_bounds__(256) void gemm_kn_kernel(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
-                                                       int M, int N, int K) {
+                                                       int M, int N, int K, int kchunk, int64_t c_slab) {
   constexpr int BM = BT, BN = BT, BK = 16, LDT = BT + 4, NT = BT / 32, NL = BT * BK / 256;  // NT 16 x 16 tiles per wave and side
   __shared__ float sA[2][BK][LDT], sB[2][BK][LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
@@ -373,13 +375,17 @@ __global__ __launch_bounds__(256) void gemm_kn_kernel(const float* A, int64_t ld
       sB[buf][q / BT][q % BT] = rb[i];
     }
   };
-  fetch(0);
+  // split K (gridDim.y > 1): this block multiplies K elements [kbeg, kend) into slab blockIdx.y of C
+  const int kbeg = blockIdx.y * kchunk;
+  K = min(K, kbeg + kchunk);
+  C += (int64_t)blockIdx.y * c_slab;
+  fetch(kbeg);
   stage(0);
   __syncthreads();
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K - kbeg + BK - 1) / BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) fetch((kt + 1) * BK);
+    if (kt + 1 < nk) fetch(kbeg + (kt + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
       float fa[NT], fb[NT];
@@ -414,8 +420,12 @@ extern "C" int care_ln_bwd(const float* x, int64_t ldx, const float* res, int64_
                            void* stream) {
   if (!x || !gamma || !dy || !ds || !dgamma || !dbeta || rows <= 0 || d <= 0) return CARE_EINVAL;
   if (d > 2048) return CARE_ESHAPE;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + LN_BWD_ROWS - 1) / LN_BWD_ROWS), dim3(256), 0, BST, x, ldx, res, ldres, gamma, dy, lddy, eps, ds, ldds,
-                     dgamma, dbeta, rows, d);
+  const dim3 grid((rows + LN_BWD_ROWS - 1) / LN_BWD_ROWS);
+#define LN_BWD_LAUNCH(C) hipLaunchKernelGGL(ln_bwd_kernel<C>, grid, dim3(256), 0, BST, x, ldx, res, ldres, gamma, dy, lddy, eps, ds, ldds, dgamma, dbeta, rows, d)
+  if (d <= 512) LN_BWD_LAUNCH(8);
+  else if (d <= 1024) LN_BWD_LAUNCH(16);
+  else LN_BWD_LAUNCH(32);
+#undef LN_BWD_LAUNCH
   return care_launch_status();
 }
 
@@ -502,18 +512,46 @@ extern "C" int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const 
   return care_launch_status();
 }
 
-extern "C" int care_gemm_kn(const float* A, int64_t lda, int a_is_km, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
-                            int N, int K, void* stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return CARE_EINVAL;
-  if (lda < (a_is_km ? M : K) || ldb < N || ldc < N) return CARE_EINVAL;
+// ksplit > 1: K is cut into ksplit ranges (multiples of 16), range s multiplied into slab s of C (C + s c_slab, each
+// [M, ldc]); the caller adds the slabs (care_strided_sum: terms = ksplit, in order - deterministic).  For products with
+// few output tiles and a long K: dx = dlogits W at 64 clips is 232 tiles of 64 x 64 with K = 10547 - 523 us as one
+// workgroup of one wave per SIMD per tile (rocprofv3, round 4).
+extern "C" int care_gemm_kn_splitk(const float* A, int64_t lda, int a_is_km, const float* B, int64_t ldb, float* C, int64_t ldc,
+                                   int64_t c_slab, int M, int N, int K, int ksplit, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ksplit <= 0 || ksplit > 64) return CARE_EINVAL;
+  if (lda < (a_is_km ? M : K) || ldb < N || ldc < N || (ksplit > 1 && c_slab < (int64_t)M * ldc)) return CARE_EINVAL;
   // 128 x 128 tiles where they fill the chip (16 flop per loaded byte at 64 x 64: the vocabulary-sized dW ran at 28 TFLOP/s)
   const int64_t big = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
   const int bt = big >= 200 ? 128 : 64;
   const int64_t tiles = (int64_t)((M + bt - 1) / bt) * ((N + bt - 1) / bt);
   if (tiles > 0x7fffffff) return CARE_ESHAPE;
-#define KN_LAUNCH(TA, BT) hipLaunchKernelGGL((gemm_kn_kernel<TA, BT>), dim3((unsigned)tiles), dim3(256), 0, BST, A, lda, B, ldb, C, ldc, M, N, K)
+  const int kchunk = ((K + ksplit - 1) / ksplit + 15) / 16 * 16;
+  const int splits = (K + kchunk - 1) / kchunk;  // <= ksplit; the slabs past it are not written
+  if (splits != ksplit) return CARE_ESHAPE;      // (pick ksplit so that every slab gets a range: care_gemm_kn_splits)
+#define KN_LAUNCH(TA, BT) hipLaunchKernelGGL((gemm_kn_kernel<TA, BT>), dim3((unsigned)tiles, ksplit), dim3(256), 0, BST, A, lda, B, ldb, C, ldc, M, N, K, kchunk, c_slab)
   if (a_is_km) { if (bt == 128) KN_LAUNCH(true, 128); else KN_LAUNCH(true, 64); }
   else { if (bt == 128) KN_LAUNCH(false, 128); else KN_LAUNCH(false, 64); }
 #undef KN_LAUNCH
   return care_launch_status();
+}
+
+// how many K ranges care_gemm_kn_splitk should be given for this product (1: do not split)
+extern "C" int care_gemm_kn_splits(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return CARE_EINVAL;
+  const int64_t big = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+  const int bt = big >= 200 ? 128 : 64;
+  const int64_t tiles = (int64_t)((M + bt - 1) / bt) * ((N + bt - 1) / bt);
+  if (tiles >= 512 || K < 2048) return 1;
+  int ks = (int)((1024 + tiles - 1) / tiles);
+  ks = ks < 2 ? 2 : (ks > 8 ? 8 : ks);
+  for (; ks > 1; --ks) {  // every slab must get a range
+    const int kchunk = ((K + ks - 1) / ks + 15) / 16 * 16;
+    if ((K + kchunk - 1) / kchunk == ks) break;
+  }
+  return ks;
+}
+
+extern "C" int care_gemm_kn(const float* A, int64_t lda, int a_is_km, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
+                            int N, int K, void* stream) {
+  return care_gemm_kn_splitk(A, lda, a_is_km, B, ldb, C, ldc, 0, M, N, K, 1, stream);
 }

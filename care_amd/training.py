@@ -28,6 +28,7 @@ from typing import Any, Dict, List, Optional
 
 import torch
 
+from . import _lib
 from ._lib import ACT_CODES, CARE_F32, call, ptr
 from .constants import PAD
 
@@ -61,6 +62,11 @@ def _mm_kn(A: torch.Tensor, B: torch.Tensor, a_is_km: bool) -> torch.Tensor:
     """op(A) . B with B [K, N]; a_is_km: A is stored [K, M] (care_gemm_kn: the operands as they lie, no transposed copies)."""
     K, N = B.shape
     M = A.shape[1] if a_is_km else A.shape[0]
+    ks = _lib.load().care_gemm_kn_splits(M, N, K)
+    if ks > 1:  # few output tiles, long K (dx = dlogits W): K ranges into slabs, added in order
+        slabs = torch.empty(ks * M, N, device=A.device, dtype=torch.float32)
+        call("care_gemm_kn_splitk", ptr(A), A.stride(0), int(a_is_km), ptr(B), B.stride(0), ptr(slabs), N, M * N, M, N, K, ks)
+        return _strided_sum(slabs, M, ks, 1, M)  # row r of slab k = row k M + r
     out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     call("care_gemm_kn", ptr(A), A.stride(0), int(a_is_km), ptr(B), B.stride(0), ptr(out), N, M, N, K)
     return out

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 18
+#define CARE_ABI_VERSION 19
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -554,6 +554,15 @@ int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const float* V, i
  */
 int care_gemm_kn(const float* A, int64_t lda, int a_is_km, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N,
                  int K, void* stream);
+/* The same product with K cut into `ksplit` ranges, range s multiplied into slab s of C (C + s * c_slab floats, each
+ * [M, ldc]); the caller adds the slabs in order (care_strided_sum: terms = ksplit, row_stride = 1, term_stride = M rows:
+ * deterministic).  For few output tiles
+ * and a long K (dx = dlogits W: M = 1856, N = 512, K = 10547).  care_gemm_kn_splits(M, N, K) -> the ksplit to use (1: do
+ * not split); any other ksplit must give every slab a range (ceil(K / ksplit) rounded up to 16) or CARE_ESHAPE.
+ * Reference: the backward of nn.Linear under autograd (models/Wrapper.py:423-435 trains through it). */
+int care_gemm_kn_splitk(const float* A, int64_t lda, int a_is_km, const float* B, int64_t ldb, float* C, int64_t ldc,
+                        int64_t c_slab, int M, int N, int K, int ksplit, void* stream);
+int care_gemm_kn_splits(int M, int N, int K);
 
 /*
  * care_decode_resident: the whole greedy decode of a SMALL batch (1 .. a few hundred caption rows) as ONE launch.

@@ -960,6 +960,34 @@ def test_attention_latent_few_rows_is_bit_identical_to_the_streaming_kernel(rows
     assert (out_big.float() - ref).abs().max().item() < 1.2e-2 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(1856, 512, 10547, 0), (300, 100, 2049, 3), (64, 64, 4096, 8), (1856, 512, 10547, 7)])
+@pytest.mark.parametrize("a_is_km", [False, True])
+def test_gemm_kn_split_k(M, N, K, ks, a_is_km):
+    """care_gemm_kn_splitk: K ranges into slabs + care_strided_sum in order = the product (ks = 0: the count
+    care_gemm_kn_splits picks); two runs are bit-identical (no atomics); a ksplit that leaves a slab without a range is refused."""
+    from care_amd import _lib
+
+    lib = _lib.load()
+    if ks == 0:
+        ks = lib.care_gemm_kn_splits(M, N, K)
+        assert ks > 1
+    A = _rand(K, M, seed=4) if a_is_km else _rand(M, K, seed=4)
+    B = _rand(K, N, seed=5)
+    outs = []
+    for _ in range(2):
+        slabs = torch.full((ks * M, N), float("nan"), device="cuda:0")
+        _call("care_gemm_kn_splitk", _p(A), A.stride(0), int(a_is_km), _p(B), B.stride(0), _p(slabs), N, M * N, M, N, K, ks)
+        C = torch.empty(M, N, device="cuda:0")
+        _call("care_strided_sum", _p(slabs), N, _p(C), N, M, N, ks, 1, M, 1.0)
+        outs.append(C)
+    ref = ((A.t() if a_is_km else A).double() @ B.double())
+    assert (outs[0].double() - ref).abs().max().item() < 2e-6 * math.sqrt(K) * max(1.0, ref.abs().max().item())
+    assert torch.equal(outs[0], outs[1])
+    assert lib.care_gemm_kn_splits(10547, 512, 1856) == 1 and lib.care_gemm_kn_splits(1856, 512, 512) == 1
+    with pytest.raises(_lib.CareHipError):  # 17 ranges of 16 cover K = 260 in 17 slabs, not 20
+        _call("care_gemm_kn_splitk", _p(A), A.stride(0), int(a_is_km), _p(B), B.stride(0), _p(slabs), N, M * N, M, N, 260, 20)
+
+
 @pytest.mark.parametrize("M,N,K", [(1856, 512, 10547), (10547, 512, 1856), (64, 64, 16), (1, 1, 1), (70, 33, 50), (512, 2048, 1856)])
 @pytest.mark.parametrize("a_is_km", [False, True])
 def test_gemm_kn_transposed_operands(M, N, K, a_is_km):
