@@ -37,10 +37,12 @@ template <typename WT> struct KTraits;
 template <> struct KTraits<float>  { static constexpr int BK = 32; };
 template <> struct KTraits<bf16_t> { static constexpr int BK = 64; };
 
+// GELU is a template parameter of the kernel (erff inlined behind a run-time test for every one of a lane's 64 outputs was
+// most of the 128 x 128 kernel's 7800 instructions: see csrc/gemm_tile.hip, tile_epilogue)
+template <bool GELU>
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == CARE_ACT_RELU) return fmaxf(v, 0.0f);
-  if (act == CARE_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-  return v;
+  if constexpr (GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  return act == CARE_ACT_RELU ? fmaxf(v, 0.0f) : v;
 }
 
 __device__ __forceinline__ void store_out(void* C, int64_t ld, int is_bf16, int row, int col, float v) {
@@ -53,7 +55,7 @@ __device__ __forceinline__ void store_out(void* C, int64_t ld, int is_bf16, int 
 //   (care_split3_weight), the A tile of virtual column block k0 comes from real columns k0 % K, converted to its
 //   high piece in the first two thirds and to its low piece in the last; v_mfma_f32_16x16x32_f16.  What is dropped
 //   (A_lo W_lo) is ~2^-22 of a product: fp32-grade, at a third of the bf16 rate instead of the exact-f32 MFMA's 1/16.
-template <typename WT, int BM, int BN, bool ARGMAX, bool SPLIT = false>
+template <typename WT, int BM, int BN, bool ARGMAX, bool SPLIT = false, bool GELU = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   constexpr int BK = KTraits<WT>::BK;
   constexpr bool BF = sizeof(WT) == 2;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
           const int row = row_base + m * 16 + j;
           if (row >= p.M) continue;
-          float v = apply_act(acc[m][n][j] + bv, p.act);
+          float v = apply_act<GELU>(acc[m][n][j] + bv, p.act);
           if (!second) store_out(p.C0, p.ldc0, p.c0_bf16, row, col, v);
           else store_out(p.C1, p.ldc1, p.c1_bf16, row, col - p.n_split, v);
         }
@@ -252,11 +254,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
-template <typename WT, int BM, int BN, bool ARGMAX, bool SPLIT = false>
+template <typename WT, int BM, int BN, bool ARGMAX, bool SPLIT = false, bool GELU = false>
 int launch(const GemmArgs& p, hipStream_t st) {
+  if constexpr (!ARGMAX && !GELU)
+    if (p.act == CARE_ACT_GELU) return launch<WT, BM, BN, ARGMAX, SPLIT, true>(p, st);
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const size_t lds = 2 * (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<WT, BM, BN, ARGMAX, SPLIT>), dim3(tiles), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<WT, BM, BN, ARGMAX, SPLIT, GELU>), dim3(tiles), dim3(256), lds, st, p);
   return care_launch_status();
 }
 
