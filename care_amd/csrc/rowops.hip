@@ -77,6 +77,70 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* x, int64_t ldx
   row_layernorm(v, nv4, lane, d, gamma, beta, eps, out + orow * ldo, outb ? outb + orow * ldo : nullptr);
 }
 
+// The same kernel for d = 256 NV exactly, no position table, no split-K slabs (every LayerNorm launch of the d_model
+// 768 / 1024 decode steps): with the row length a template parameter every load of the row, the residual, gamma and
+// beta is issued before the first use - the general kernel above tests `c4 < nv4`, `res`, `pos` and the slab count at run
+// time, hipcc branches around each load and waits for it at the join, and a row is three or four HBM round trips in
+// series (*measured* 16384 rows x 1024: 70 -> 41 us per launch, 3.4 -> 5.8 TB/s of its 235 MB).  The arithmetic is
+// row_layernorm's in the same order; hipcc contracts the two bodies' multiply-adds differently, so a few rows in a
+// hundred differ in the last bit or two of their fp32 values (1.4e-6 at most, tests/test_gpu_kernels.py).  Which kernel
+// a LayerNorm takes depends on the model's d and the call site (position table, slabs), never on the batch.
+template <int NV, bool RES>
+__global__ __launch_bounds__(256) void add_ln_fixed_kernel(const float* x, int64_t ldx, const float* res, int64_t ldres,
+                                                           const float* gamma, const float* beta, float eps, float* out,
+                                                           bf16_t* outb, int64_t ldo, int rows, int d, int grp, int out_grp_rows,
+                                                           int out_row_off) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float4 v[NV], rs[NV], g[NV], b[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + (lane + 64 * i) * 4);
+  if constexpr (RES) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) rs[i] = *reinterpret_cast<const float4*>(res + (int64_t)r * ldres + (lane + 64 * i) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    g[i] = *reinterpret_cast<const float4*>(gamma + (lane + 64 * i) * 4);
+    b[i] = *reinterpret_cast<const float4*>(beta + (lane + 64 * i) * 4);
+  }
+  if constexpr (RES) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) add4(v[i], rs[i]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = care_wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+    q += (a * a + bb * bb) + (c * c + e * e);
+  }
+  const float var = care_wave_sum(q) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const int64_t orow = (int64_t)(r / grp) * out_grp_rows + out_row_off + (r % grp);
+  float* o_row = out + orow * ldo;
+  bf16_t* ob_row = outb ? outb + orow * ldo : nullptr;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * g[i].x + b[i].x;
+    o.y = (v[i].y - mean) * rstd * g[i].y + b[i].y;
+    o.z = (v[i].z - mean) * rstd * g[i].z + b[i].z;
+    o.w = (v[i].w - mean) * rstd * g[i].w + b[i].w;
+    *reinterpret_cast<float4*>(o_row + c4 * 4) = o;
+    if (ob_row) {
+      bf16x4 ob;
+      ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
+      *reinterpret_cast<bf16x4*>(ob_row + c4 * 4) = ob;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void group_mean_kernel(const float* x, int64_t ldx, int in_grp_rows, int in_row_off,
                                                          int grp, float* out, int64_t ldo, int col_off, int groups,
                                                          int d) {
@@ -359,6 +423,21 @@ extern "C" int care_add_ln(const float* x, int64_t ldx, const float* res, int64_
   if (d % 4 != 0 || d > 2048 || nslab < 1 || nslab > 16) return CARE_ESHAPE;
   if ((ldx % 4) || (ldo % 4) || (res && (ldres % 4)) || (slab_stride % 4) || !care_aligned16(x) || !care_aligned16(out))
     return CARE_EALIGN;
+  if (!pos && nslab == 1 && (d == 512 || d == 768 || d == 1024 || d == 2048)) {
+    bf16_t* ob = reinterpret_cast<bf16_t*>(out_bf16);
+    const dim3 grid((rows + 3) / 4);
+#define ADD_LN_FIXED(NV)                                                                                                     \
+  do {                                                                                                                       \
+    if (res) hipLaunchKernelGGL((add_ln_fixed_kernel<NV, true>), grid, dim3(256), 0, ST, x, ldx, res, ldres, gamma, beta, eps, out, ob, ldo, rows, d, grp, out_grp_rows, out_row_off); \
+    else hipLaunchKernelGGL((add_ln_fixed_kernel<NV, false>), grid, dim3(256), 0, ST, x, ldx, res, ldres, gamma, beta, eps, out, ob, ldo, rows, d, grp, out_grp_rows, out_row_off);   \
+  } while (0)
+    if (d == 512) ADD_LN_FIXED(2);
+    else if (d == 768) ADD_LN_FIXED(3);
+    else if (d == 1024) ADD_LN_FIXED(4);
+    else ADD_LN_FIXED(8);
+#undef ADD_LN_FIXED
+    return care_launch_status();
+  }
   hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, x, ldx, res, ldres, pos, gamma, beta, eps,
                      out, reinterpret_cast<bf16_t*>(out_bf16), ldo, rows, d, grp, out_grp_rows, out_row_off, nslab,
                      slab_stride);

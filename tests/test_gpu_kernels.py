@@ -219,6 +219,32 @@ def test_vocab_argmax_256_row_panels(M, N, min_parts, monkeypatch):
     assert (best - ref.max(1).values.float()).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("d", [512, 768, 1024, 2048])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_add_ln_fixed_length_kernel(d, with_res):
+    """care_add_ln takes a kernel specialised by row length for d in {512, 768, 1024, 2048} without a position table or
+    slabs (every load issued before the first use); a table of zeros sends the same rows through the general kernel:
+    same arithmetic in the same order up to the compiler's fma contraction - the fp32 rows agree to the last bit or
+    two; ragged row count, nothing written past the rows."""
+    rows, grp = 37 * 4 + 3, 7
+    x, res = _rand(rows, d, seed=11, scale=3.0), _rand(rows, d, seed=12)
+    g, b = _rand(d, seed=13) + 1.0, _rand(d, seed=14)
+    zeros = torch.zeros(grp, d, device=DEV)
+    outs = []
+    for pos in (None, zeros):
+        out = torch.full((rows + grp, d), float("nan"), device=DEV)
+        outb = torch.zeros(rows + grp, d, device=DEV, dtype=torch.bfloat16)
+        _call("care_add_ln", _p(x), d, _p(res) if with_res else None, d, _p(pos) if pos is not None else None, _p(g), _p(b), 1e-12,
+              _p(out), _p(outb), d, rows, d, grp, grp, 0, 1, 0)
+        outs.append((out, outb))
+    torch.cuda.synchronize()
+    assert (outs[0][0][:rows] - outs[1][0][:rows]).abs().max().item() <= 3e-6
+    assert (outs[0][1][:rows].float() - outs[1][1][:rows].float()).abs().max().item() <= 4e-2  # a bf16 rounding boundary at most
+    ref = torch.nn.functional.layer_norm((x + res) if with_res else x, (d,), g, b, 1e-12)
+    assert (outs[0][0][:rows] - ref).abs().max().item() < 2e-5
+    assert bool(torch.isnan(outs[0][0][rows:]).all())  # nothing written past the rows
+
+
 def test_add_ln_group_mean_embed():
     rows, d, grp = 56, 512, 28
     x, res = _rand(rows, d, seed=9), _rand(rows, d, seed=10)
