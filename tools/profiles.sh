@@ -13,6 +13,7 @@ stats() {  # name, command...: kernel trace with --stats, keeps the summary csv
 }
 stats trace $B --steps 5 --warmup 2
 stats trace_vatex $B --steps 5 --warmup 2 --config vatex_care_large --batch 4096
+stats trace_vatex16k $B --steps 3 --warmup 2 --config vatex_care_large --batch 16384
 stats greedy_B128 $B --batch 128 --steps 20 --warmup 3
 stats greedy_B1 $B --batch 1 --steps 20 --warmup 3
 stats beam5_B128 $B --batch 128 --beam 5 --config msrvtt_care_beam5 --steps 20 --warmup 3

@@ -19,10 +19,10 @@ SRC = os.path.join(ROOT, "gpurun_out", ROUND + "prof")
 DST = os.path.join(ROOT, "profiles")
 head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 
-STATS = {"trace": "bench_B32768_bf16", "trace_vatex": "vatex_care_large_B4096_bf16", "greedy_B128": "small_batch_greedy_B128",
+STATS = {"trace": "bench_B32768_bf16", "trace_vatex": "vatex_care_large_B4096_bf16", "trace_vatex16k": "vatex_care_large_B16384_bf16", "greedy_B128": "small_batch_greedy_B128",
          "greedy_B1": "small_batch_greedy_B1", "beam5_B128": "small_batch_beam5_B128", "beam5_B1": "small_batch_beam5_B1",
          "train_B64": "training_step_B64"}
-ours = lambda k: "anonymous namespace" in k and "at::native" not in k
+ours = lambda k: ("anonymous namespace" in k or k.startswith("_ZN12_GLOBAL__N_1") or k.startswith("_Z17split2_act")) and "at::native" not in k
 
 
 def counters(name):
@@ -137,6 +137,12 @@ def readings():
         if r:
             L.append("`{}_{}_kernel_stats.csv` ({}): `{}` {:.1f} us per launch = {:.1f} us per decoder step of 29 ({} launches).".format(
                 ROUND, name, what, short(r["Name"]), float(r["AverageNs"]) / 1e3, float(r["AverageNs"]) / 29e3, r["Calls"]))
+    rows = [r for r in kernel_stats("vatex_care_large_B16384_bf16") if ours(r["Name"])]
+    if rows:
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        L += ["", "`{}_vatex_care_large_B16384_bf16_kernel_stats.csv` (d_model 1024 at the batch that fills the chip), our kernels by share: ".format(ROUND) +
+              ", ".join("`{}` {:.1f} % ({:.0f} us)".format(short(r["Name"])[:48], 100.0 * float(r["TotalDurationNs"]) / tot, float(r["AverageNs"]) / 1e3)
+                        for r in rows[:6]) + "."]
     rows = kernel_stats("training_step_B64")
     if rows:
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
