@@ -87,6 +87,59 @@ void run(const unsigned char* A, const unsigned char* W, int M, int N, int K, fl
          1024 / ROWB, ROWB, SWZ ? " chunks permuted in the row" : "", DEPTH, DEPTH * 8, REG ? "registers" : "LDS-DMA  ", best * 1e3, bytes / best / 1e9, bytes / best / 1e6 / 256);
 }
 
+
+// ---- a weight image that EVERY workgroup streams (csrc/gemm_ln.hip: the packed W of the row-panel GEMMs, 32 KB per K
+// step from L2): by how a 1-KB piece is cut out of the 32-KB stage.  MODE 0: 1 KB contiguous (care_pack_ln_weight's
+// order); 1: four runs of 256 B, 8 KB apart; 2: eight runs of 128 B, 4 KB apart.  LOADERS of the 8 waves issue.
+template <int MODE, int LOADERS>
+__global__ __launch_bounds__(512) void packed_kernel(const unsigned char* W, int nk, int blocks_per_wg, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= LOADERS) return;
+  constexpr int PPW = 32 / LOADERS;  // pieces per wave and stage
+  const unsigned lane_off = MODE == 0 ? lane * 16u : MODE == 1 ? (unsigned)(lane >> 4) * 32u * 256u + (lane & 15) * 16u
+                                                               : (unsigned)(lane >> 3) * 32u * 128u + (lane & 7) * 16u;
+  const unsigned piece_step = MODE == 0 ? 1024u : MODE == 1 ? 256u : 128u;
+  int slot = 0;
+  for (int b = 0; b < blocks_per_wg; ++b)
+    for (int s = 0; s < nk; ++s) {
+      const unsigned char* st = W + (size_t)s * 32768;
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st + q * piece_step + lane_off),
+                                         (__attribute__((address_space(3))) void*)(smem + (wave * 16 + slot) * 1024), 16, 0, 0);
+        slot = (slot + 1) & 15;
+        asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      }
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 99) sink[0] = 1.f;
+}
+
+template <int MODE, int LOADERS>
+void run_packed(const unsigned char* W, float* sink) {
+  const int nk = 64, per = 28;  // K = 2048; 28 row blocks per workgroup (917504 rows / 128 / 256)
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&packed_kernel<MODE, LOADERS>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((packed_kernel<MODE, LOADERS>), dim3(256), dim3(512), 128 * 1024, 0, W, nk, per, sink);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    if (rep && ms < best) best = ms;
+  }
+  const double bytes = 256.0 * per * nk * 32768.0;
+  printf("packed 2-MB weight image, every workgroup streams it 28 times, %d loader waves, pieces %s: %8.1f us  %6.2f TB/s  (%5.1f cycles of a CU per 1-KB piece at 2.1 GHz)\n",
+         LOADERS, MODE == 0 ? "1 x 1024 B        " : MODE == 1 ? "4 x 256 B, 8 KB apart" : "8 x 128 B, 4 KB apart", best * 1e3, bytes / best / 1e9,
+         best * 1e-3 * 2.1e9 / (per * nk * 32.0));
+}
+
 int main() {
   setvbuf(stdout, nullptr, _IONBF, 0);
   const int M = 65536, N = 4096, K = 1024;  // buffers sized for 65536 x 4096 (A) and 4096 x 4096 (W) elements
@@ -114,5 +167,7 @@ int main() {
   // a small problem: one tile per CU, operands hot in the caches after the first repetition
   run<64, 12, 0>(A, W, 4096, 4096, K, sink);
   run<128, 12, 0>(A, W, 4096, 4096, K, sink);
+  run_packed<0, 4>(W, sink); run_packed<1, 4>(W, sink); run_packed<2, 4>(W, sink);
+  run_packed<0, 8>(W, sink); run_packed<1, 8>(W, sink); run_packed<2, 8>(W, sink);
   return 0;
 }
