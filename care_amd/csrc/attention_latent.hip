@@ -376,9 +376,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
 
 // ------------------------------------------------------------------ d_model = 1024 / 768: several waves per row
 // The same algorithm with the row's dims cut into NW slices of DW: a workgroup of NW waves owns a row, wave w streams and
-// multiplies dims [DW w, DW w + DW) - its own ring, its own query fragments and accumulators (NW = 2, DW = 512 for
-// d_model 1024: exactly the single-wave kernel's footprint per wave; NW = 3, DW = 256 for d_model 768: 512-byte LDS rows,
-// two key rows per LDS-DMA instruction).  What the slices share is the score: each wave has the partial dot products over
+// multiplies dims [DW w, DW w + DW) - its own ring, its own query fragments and accumulators (NW = 4, DW = 256 for
+// d_model 1024 - round 4; NW = 2, DW = 512, the single-wave kernel's footprint per wave, before; NW = 3, DW = 256 for
+// d_model 768: 512-byte LDS rows, two key rows per LDS-DMA instruction).  What the slices share is the score: each wave has the partial dot products over
 // its dims, they swap them through NW x 1 KB of LDS (double-buffered by chunk parity, one raw s_barrier per chunk - the
 // DMAs in flight are not drained) and every wave adds the NW partials in the SAME order, so all take identical softmax
 // decisions; 16 / 12 heads fill the MFMA N axis.  Per row and step Lk x d x 2 B of memory + 2 x H x d x 2 B of q~ / c~
@@ -835,9 +835,15 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
   static const int pair_ok = [] { const char* e = getenv("CARE_LAT_PAIR"); return e ? atoi(e) : 1; }();  // A/B switch
   p.paired = pair_ok && heads <= 8 && rows_per_kv > 1 && rows % rows_per_kv == 0;
   hipStream_t st = (hipStream_t)stream;
-  if (d == 2 * LAT_D) {  // d_model = 1024: two waves per row, 512 dims each (attention_latentN_kernel)
+  if (d == 2 * LAT_D) {  // d_model = 1024: four waves per row, 256 dims each (attention_latentN_kernel)
     p.paired = 0;
-    return launch_latentN<2, 512, 2>(p, st);
+    // *measured* (vatex_care_large, 16384 rows x 84 keys, 16 heads, same box): two waves x 512 dims 952 us per launch,
+    // four x 256 with a ring of 2 chunks 809 (6.05 TB/s of the algorithmic bytes), with 3 chunks 831: twice the waves per
+    // CU (8 instead of 4 at two workgroups per CU) cover the per-chunk exchange of partial scores and its barrier
+    static const int ncfg = [] { const char* e = getenv("CARE_LATN_CFG"); return e ? atoi(e) : 1; }();  // tuning / A-B
+    if (ncfg == 0) return launch_latentN<2, 512, 2>(p, st);
+    if (ncfg == 2) return launch_latentN<4, 256, 3>(p, st);
+    return launch_latentN<4, 256, 2>(p, st);
   }
   if (d == 768) {        // d_model = 768: three waves per row, 256 dims each
     p.paired = 0;
