@@ -852,7 +852,9 @@ extern "C" int care_attention_latent(const void* qt, int64_t ldq, const void* me
   // few rows: one wave per row with the whole head of the row's stream in flight (attention_latent_few_kernel)
   static const int few_rows = [] { const char* e = getenv("CARE_LAT_FEW_ROWS"); return e ? atoi(e) : 256; }();
   if (rows <= few_rows && !p.paired) return launch_latent_few(p, st);
-  // tuning: 0 = 4 waves x 2 slots, 1 = 3 waves x 3 slots (read once; initialisation is thread-safe)
+  // tuning: 0 = 4 waves x 2 slots, 1 = 3 waves x 3 slots (read once; initialisation is thread-safe).  (Round 4: the
+  // several-waves-per-row kernel as two waves of 256 dims at this d_model: 736 / 582 / 572 us with rings of 2 / 3 / 4
+  // chunks against 560 here - the exchange of partial scores buys nothing when a row fits one wave.)
   static const int cfg = [] { const char* e = getenv("CARE_LAT_CFG"); return e ? atoi(e) : 0; }();
   if (cfg == 1) return launch_latent<3, 3>(p, st);
   if (cfg == 2) return launch_latent<3, 2>(p, st);
