@@ -222,6 +222,8 @@ def extra_legs(dev, main_dtype, legs):
     legs["vatex_care_large"] = greedy_leg("vatex_care_large", main_dtype, 4096)[0]
     legs["vatex_care_large_B16384"] = greedy_leg("vatex_care_large", main_dtype, 16384, iters=3)[0]
     legs["vatex_care_large_B32"] = greedy_leg("vatex_care_large", main_dtype, 32, iters=20)[0]
+    # d_model = 768 (archs.yaml "median", GELU) at the batch that fills the chip
+    legs["care_median_gelu_B16384"] = greedy_leg("care_median_gelu", main_dtype, 16384, iters=3)[0]
     # BASELINE configs[4]: CARE, beam 5 (opts.py beam_size 5): a large batch, the reference's batch of 128
     # (translate.py:137,144) and its latency mode (translate.py:208-209: one clip) - the last two as ONE resident launch
     # per search (csrc/decode_resident_beam.hip)

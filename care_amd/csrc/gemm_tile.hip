@@ -23,7 +23,7 @@
 //     (models/Head.py:26-32, Translator.py:127), optionally with the label logit (teacher-forced scoring);
 //   * blocks are numbered XCD-aware: the blocks of one XCD (blockIdx % 8) walk a contiguous run of tiles in bands of 8
 //     row tiles (tile_of_block), so the 32 tiles an XCD works on at a time share 8 A panels and 4 W panels in its L2.
-// What bounds it (*measured*, round 4; DESIGN.md section 4.4): 4096^3 1296 TFLOP/s, 8192^3 1372 on random operands
+// What bounds it (*measured*, round 4; DESIGN.md section 4.1d): 4096^3 1296 TFLOP/s, 8192^3 1372 on random operands
 // (0.52-0.55 of the dense bf16 peak; zero-filled operands read 18-20 % higher: clocks).  With the LDS-DMA removed the
 // loop runs at 1.8-2.0 PFLOP/s, with 15 of 16 MFMAs removed no faster than whole: the tile is bound by FETCHING its
 // operands (tools/micro/dma_rate.hip: this tile's fetch alone runs at 24.5-25 TB/s chip-wide in pieces of 8 rows x 128 B,
@@ -113,8 +113,13 @@ __device__ __forceinline__ void tile_epilogue(const TArgs& p, f32x4 (&acc)[MT][4
     // lane storing its own 32 bytes as two 16-byte pieces (64 separate 16-byte writes per instruction) took 13 200
     // cycles per wave group and tile, a sixth of the tile's time at K = 1024
     const int colw = col0 - fg * 16;
-    const bool wide = isb && vec && colw + 64 <= (second ? p.N : min(p.N, p.n_split)) && (colw >= p.n_split || colw + 64 <= p.n_split);
+    const bool whole = vec && colw + 64 <= (second ? p.N : min(p.N, p.n_split)) && (colw >= p.n_split || colw + 64 <= p.n_split);
+    const bool wide = isb && whole, wide32 = !isb && whole;
     const bool wide_u = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_ballot_w64(!wide) == 0 && (int)(__builtin_amdgcn_ballot_w64(!wide) >> 32) == 0);
+    // fp32 outputs: a lane's 16 columns are FOUR 16-byte chunks of the row's sixteen; a 4 x 4 transpose over the row's four
+    // lanes (v_permlane32_swap, then v_permlane16_swap: lane fg ends up with chunks fg, fg + 4, fg + 8, fg + 12) makes every
+    // store instruction 64 contiguous bytes per row here too
+    const bool wide32_u = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_ballot_w64(!wide32) == 0 && (int)(__builtin_amdgcn_ballot_w64(!wide32) >> 32) == 0);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int row = row0 + m * 16 + fr;
@@ -144,6 +149,30 @@ __device__ __forceinline__ void tile_epilogue(const TArgs& p, f32x4 (&acc)[MT][4
           bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (int64_t)row * ld + (cc - fg * 16) + 8 * c;
           *reinterpret_cast<i32x4*>(dst) = x;
           *reinterpret_cast<i32x4*>(dst + 32) = y;
+        }
+        continue;
+      }
+      if (wide32_u) {
+        int x[4][4], y[4][4];  // [chunk slot][dword]
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {  // step 1 (lane ^ 32): chunks (0, 2) and (1, 3) trade halves
+          const auto r02 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, v[d]), __builtin_bit_cast(int, v[8 + d]), false, false);
+          const auto r13 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, v[4 + d]), __builtin_bit_cast(int, v[12 + d]), false, false);
+          x[0][d] = (int)r02[0]; x[2][d] = (int)r02[1];
+          x[1][d] = (int)r13[0]; x[3][d] = (int)r13[1];
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {  // step 2 (lane ^ 16): slots (0, 1) and (2, 3)
+          const auto r01 = __builtin_amdgcn_permlane16_swap(x[0][d], x[1][d], false, false);
+          const auto r23 = __builtin_amdgcn_permlane16_swap(x[2][d], x[3][d], false, false);
+          y[0][d] = (int)r01[0]; y[1][d] = (int)r01[1];
+          y[2][d] = (int)r23[0]; y[3][d] = (int)r23[1];
+        }
+        if (row < p.M) {
+          typedef int i32x4 __attribute__((ext_vector_type(4)));
+          float* dst = reinterpret_cast<float*>(C) + (int64_t)row * ld + (cc - fg * 16) + 4 * fg;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) *reinterpret_cast<i32x4*>(dst + 16 * k) = i32x4{y[k][0], y[k][1], y[k][2], y[k][3]};
         }
         continue;
       }
