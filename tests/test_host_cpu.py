@@ -127,6 +127,15 @@ def test_abi_library_exports_every_declared_symbol():
     assert loaded.care_version() == int(re.search(r"#define CARE_ABI_VERSION (\d+)", header).group(1))
     assert loaded.care_arch() == b"gfx950"
     assert loaded.care_argmax_parts(10547) == 166
+    # the K ranges of the training backward's few-tile products (csrc/backward.hip: care_gemm_kn_splits): dx = dlogits W at
+    # 64 clips is split, dW and the d x d products are not; every slab gets a range of a multiple of 16
+    assert loaded.care_gemm_kn_splits(1856, 512, 10547) == 5
+    assert loaded.care_gemm_kn_splits(10547, 512, 1856) == 1 and loaded.care_gemm_kn_splits(1856, 512, 512) == 1
+    for M, N, K in [(64, 64, 2048), (300, 100, 2049), (1856, 512, 10547), (128, 512, 4100)]:
+        ks = loaded.care_gemm_kn_splits(M, N, K)
+        chunk = -(-(-(-K // ks)) // 16) * 16
+        assert 1 <= ks <= 8 and -(-K // chunk) == ks
+    assert loaded.care_gemm_kn_splits(0, 1, 1) < 0
     assert loaded.care_argmax_parts_bf16(1024, 10547) % 8 == 0
     # the column split of the A-stationary GEMM (csrc/gemm_as.hip: pick_ns), at its measured optima
     for rows, parts in [(1, 512), (4096, 16), (8192, 8), (16384, 4), (20480, 8), (32768, 2), (65536, 1)]:
