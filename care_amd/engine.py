@@ -407,7 +407,7 @@ class HipEngine:
         """bf16 mirror workspace of a GEMM-input activation (None unless as_ok)."""
         return self.ws(name + "#bf", shape, torch.bfloat16) if self.bf_act else None
 
-    def gemm(self, A, W, bias, out, act=0, out2=None, n_split=None, tag=None):
+    def gemm(self, A, W, bias, out, act=0, out2=None, n_split=None, tag=None, tile=False):
         """out = act(A @ W^T + bias).  bf16 weights + bf16 A -> A-stationary kernel (csrc/gemm_as.hip) for
         K <= 512, the LDS-tiled bf16 kernel (csrc/gemm_tile.hip) for larger K; anything else -> the generic
         fp32-activation kernel (csrc/gemm.hip)."""
@@ -419,7 +419,7 @@ class HipEngine:
         if W.dtype == torch.bfloat16 and A.dtype == torch.bfloat16:
             if K % 64 or A.stride(0) % 8:
                 raise ValueError("bf16 A operand needs K % 64 == 0 and a 16-byte aligned row stride (got K = {})".format(K))
-            if K <= 512 and K % 128 == 0 and os.environ.get("CARE_FORCE_TILE", "0") == "0":
+            if K <= 512 and K % 128 == 0 and not tile and os.environ.get("CARE_FORCE_TILE", "0") == "0":
                 call("care_gemm_bf16", ptr(A), A.stride(0), _code(A), ptr(W), *tail, tag=tag)
             else:
                 call("care_gemm_tile", ptr(A), A.stride(0), ptr(W), *tail, tag=tag)
@@ -737,11 +737,17 @@ class HipEngine:
         return out
 
     # ------------------------------------------------------------------ cross K/V (once per clip)
-    def cross_kv(self, mem: torch.Tensor, tag="ckv") -> List[torch.Tensor]:
+    # the resident decodes' cross K/V from this many memory rows up go through the LDS-tiled GEMM: the A-stationary kernels
+    # want many 128- / 256-row panels, and 128 clips are 42 panels of 256 on 256 CUs (*measured* 10752 x 1024 x 512:
+    # 36.4 against 19.6 us; 5376 rows 20.6 / 12.6; 84 rows 6.1 / 8.1 - below the threshold nothing changes)
+    RESIDENT_CKV_TILE_ROWS = 2048
+
+    def cross_kv(self, mem: torch.Tensor, tag="ckv", resident=False) -> List[torch.Tensor]:
         """K/V of the static memory for every decoder layer: [B, Lk, 2d] in the weight dtype.
 
         The reference re-projects them at every step for every beam copy
         (Attention.py:63-67 called from Layers.py:206-213); here once per clip.
+        `resident`: for the one-launch decodes of small batches (their own form of the arithmetic already, resident_ok).
         """
         B, Lk, d = mem.shape
         mem = mem.contiguous()
@@ -752,7 +758,8 @@ class HipEngine:
         for li in range(self.n_layers):
             nm = "d{}_ca".format(li)
             kv = self.ws("{}{}".format(tag, li), (B * Lk, 2 * d), self.wt)
-            out.append(self.gemm(src2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv, tag="cross_kv_gemm"))
+            out.append(self.gemm(src2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv, tag="cross_kv_gemm",
+                                 tile=resident and src2.dtype == torch.bfloat16 and B * Lk >= self.RESIDENT_CKV_TILE_ROWS))
         return out
 
     LATENT_MIN_ROWS = 1
@@ -1215,7 +1222,7 @@ class HipEngine:
         B, Lk, d = mem.shape
         T, w, N, cap = self.T, self.w, mem.shape[0] * bm, need + bm
         sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
-        ckv = self.cross_kv(mem, tag="rb_ckv")
+        ckv = self.cross_kv(mem, tag="rb_ckv", resident=True)
         akv = self.attr_kv(sem_embs, tag="rb_akv") if self.attr_att else None
         tok = self.ws("rb_tok", (N, T + 1), torch.int32)
         anc = [self.ws("rb_anc%d" % i, (N, T + 1), torch.int32) for i in range(2)]
@@ -1244,7 +1251,7 @@ class HipEngine:
         T, w = self.T, self.w
         steps = T if steps is None else steps
         sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
-        ckv = self.cross_kv(mem, tag="r_ckv")
+        ckv = self.cross_kv(mem, tag="r_ckv", resident=True)
         akv = self.attr_kv(sem_embs, tag="r_akv") if self.attr_att else None
         fed = self.ws("r_fed", (B, T + 1), torch.int32)
         score, length, fin = self.ws("r_score", (B,)), self.ws("r_len", (B,), torch.int32), self.ws("r_fin", (B,), torch.int32)
