@@ -779,6 +779,8 @@ class HipEngine:
         2 x the small-batch step rate; `resident_max_rows = 0` restores one form at every size."""
         return self.latent_ok and rows >= self.LATENT_MIN_ROWS and not getattr(self, "_small_pass", False)
 
+    Q_TILE_MIN_ROWS = int(os.environ.get("CARE_Q_TILE_MIN_ROWS", "8192"))
+
     def cross_src(self, mem: torch.Tensor, rows: int):
         """What the decoder's cross-attention reads at every step: per-layer projected K/V
         (cross_kv, a list of [B*Lk, 2d] tensors), or - absorbed form - the bf16 memory itself
@@ -1056,8 +1058,11 @@ class HipEngine:
             hb = w["d{}_hb".format(li)]
             if isinstance(ckv, tuple):  # absorbed form (cross_src)
                 H = self.H
+                # d x d with a bf16 output at >= 8192 rows: the LDS-tiled kernel (*measured* in situ, 32768 rows: 25.3 against
+                # 32-34 us on the A-stationary one, which wins the wider QKV / FFN1 products; decided by the pass's INITIAL
+                # row count like every other choice of form)
                 q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2b", (N, d), torch.bfloat16),
-                               tag="step_dxd_gemm")
+                               tag="step_dxd_gemm", tile=d == 512 and (self._form_rows or N) >= self.Q_TILE_MIN_ROWS)
                 qt = self.ws(tag + "qt", (N, H * d), torch.bfloat16)
                 if d == 512:
                     call("care_head_expand", ptr(q2), d, ptr(w[nm + "_wkt"]), ptr(qt), H * d, N, H, tag="step_head_expand")
