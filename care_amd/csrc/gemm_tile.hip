@@ -396,15 +396,17 @@ int launch_tile(TArgs& p, hipStream_t st, int batch = 1) {
 // per CU) below.  *Measured* (tools/tile_bench.py, one MI355X, bf16 out): M = 4096, K = 1024: N = 4096 952 vs 701
 // TFLOP/s, N = 3072 (192 big tiles) 843 vs 580, N = 2304 / K = 768 (144) 576 vs 484, N = 1024 (64) 314 vs 483;
 // M = 466944, N = 2048 929 vs 682; 8 waves of 128 x 64 (2422) and 256 x 128 tiles (422, 2222) lie in between.
-int pick_cfg(int M, int N) {
+// (K <= 512 - the d_model 512 products routed here - with between half a chip and three quarters of big tiles: 16384 x
+// 512 x 512 22.8 us as 128 big tiles, 16.2 as 512 small ones; at K = 768 and 144 big tiles the big tile still wins.)
+int pick_cfg(int M, int N, int K) {
   if (const char* e = getenv("CARE_TILE_CFG")) return atoi(e);
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  return t256 >= 128 ? 4412 : 222;
+  return t256 >= 192 || (t256 >= 128 && K > 512) ? 4412 : 222;
 }
 
 template <int EPI>
 int dispatch(TArgs& p, hipStream_t st) {
-  switch (pick_cfg(p.M, p.N)) {
+  switch (pick_cfg(p.M, p.N, p.K)) {
     case 42: return launch_tile<4, 2, 1, 3, EPI>(p, st);
     case 423: return launch_tile<4, 2, 1, 3, EPI>(p, st);
     case 422: return launch_tile<4, 2, 1, 2, EPI>(p, st);
@@ -532,7 +534,7 @@ extern "C" int care_gemm_tile_split3(const void* A2, const void* W3, const float
   p.bias = bias; p.C0 = C0; p.ldc0 = ldc0; p.c0_bf16 = c0_dtype == CARE_BF16;
   p.C1 = C1; p.ldc1 = ldc1; p.c1_bf16 = c1_dtype == CARE_BF16; p.n_split = n_split; p.act = act;
   hipStream_t st = (hipStream_t)stream;
-  return pick_cfg(M, N) == 4412 ? launch_tile<4, 4, 1, 2, EPI_STORE, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_STORE, true>(p, st);
+  return pick_cfg(M, N, 3 * K) == 4412 ? launch_tile<4, 4, 1, 2, EPI_STORE, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_STORE, true>(p, st);
 }
 
 // the fused vocabulary arg-max (care_gemm_tile_argmax) on split products: fp32-grade logits, never written
@@ -545,7 +547,7 @@ extern "C" int care_gemm_tile_split3_argmax(const void* A2, const void* W3, floa
   split3_args(p, A2, W3, M, N, K);
   p.pmax = pmax; p.pidx = pidx; p.psum = psum; p.parts = care_argmax_parts_tile(N);
   hipStream_t st = (hipStream_t)stream;
-  return pick_cfg(M, N) == 4412 ? launch_tile<4, 4, 1, 2, EPI_ARGMAX, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_ARGMAX, true>(p, st);
+  return pick_cfg(M, N, 3 * K) == 4412 ? launch_tile<4, 4, 1, 2, EPI_ARGMAX, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_ARGMAX, true>(p, st);
 }
 extern "C" int care_argmax_parts_tile(int N) { return N > 0 ? (N + 63) / 64 : CARE_EINVAL; }
 
