@@ -12,12 +12,14 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
 
 LIB_PATH = os.environ.get("CARE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcare_hip.so")
+# library variants (care_amd/build.py): "" = libcare_hip.so (16-bit type bf16), "f16" = libcare_hip_f16.so (IEEE half)
+VARIANT_H16 = {"": "bf16", "f16": "fp16"}
 
 # name -> argtypes, in the exact order of include/care_hip.h
 _P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
@@ -90,7 +92,8 @@ SIGNATURES = {
     "care_remap_rows": [_P, _L, _P, _I, _P],
     "care_beam_advance": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
-PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_argmax_parts": (c_int, [c_int]),
+PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_source_hash": (c_char_p, []),
+         "care_build_flags": (c_char_p, []), "care_h16": (c_char_p, []), "care_argmax_parts": (c_int, [c_int]),
          "care_argmax_parts_bf16": (c_int, [c_int, c_int]),
          "care_argmax_parts_tile": (c_int, [c_int]),
          "care_argmax_parts_bf16_min": (c_int, [c_int, c_int, c_int, c_int, c_int]),
@@ -98,6 +101,7 @@ PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_argmax_
          "care_decode_resident_scratch": (c_int64, [c_int, c_int, c_int, c_int]),
          "care_decode_resident_beam_scratch": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
          "care_decode_resident_debug": (None, [c_int, c_int]),
+         "care_resident_set_fenced": (None, [c_int]), "care_resident_fenced": (c_int, []),
          "care_gemm_kn_splits": (c_int, [c_int, c_int, c_int])}
 
 
@@ -114,21 +118,53 @@ class ResidentLayer(ctypes.Structure):
                 ("self_kv", c_void_p), ("att", ResidentAttn * 2), ("n_att", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("ffn_g", c_void_p), ("ffn_b", c_void_p)]
 
-_lib = None
+_libs = {}
 
 
 class CareHipError(RuntimeError):
     pass
 
 
-def load(path: str = LIB_PATH):
-    """Load the library once; raises if it is absent or has the wrong ABI."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def variant_path(variant: str = "") -> str:
+    if variant == "":
+        return LIB_PATH
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcare_hip_{}.so".format(variant))
+
+
+def _ensure_current(variant: str, path: str) -> None:
+    """The library must come from THIS tree's sources: care_amd/build.py's source hash (kernel sources, headers, flags)
+    is compiled into it.  Stale or missing -> rebuilt when hipcc is at hand, refused otherwise.  A library named through
+    CARE_HIP_LIB (tools: ablation builds with flags of their own) is taken as it is."""
+    if variant == "" and os.environ.get("CARE_HIP_LIB"):
+        return
+    from . import build as _build
+    if not _build.have_sources():
+        return
+    if not _build.needs_build(variant):
+        return
+    why = "missing" if not os.path.exists(path) else "built from other sources (hash {} != tree {})".format(
+        _build.embedded_hash(path), _build.source_hash(variant))
+    if os.environ.get("CARE_NO_REBUILD") or not _build.have_hipcc():
+        raise CareHipError("{} is {} - run `python -m care_amd.build{}` (the HIP path has no CPU/PyTorch fallback)".format(
+            path, why, " --variant " + variant if variant else ""))
+    import sys
+    print("care_amd: {} is {}: rebuilding".format(os.path.basename(path), why), file=sys.stderr, flush=True)
+    _build.build(variant=variant, verbose=False)
+
+
+def load(path: str = None, variant: str = ""):
+    """Load the library of `variant` once; raises if it is absent, stale (and cannot be rebuilt) or has the wrong ABI."""
+    if variant in _libs and path is None:
+        return _libs[variant]
+    if variant not in VARIANT_H16:
+        raise CareHipError("unknown library variant {!r}".format(variant))
+    explicit = path is not None
+    path = path or variant_path(variant)
+    if not explicit:
+        _ensure_current(variant, path)
     if not os.path.exists(path):
         raise CareHipError(
-            "libcare_hip.so not found at {} - run `python -m care_amd.build` "
+            "{} not found - run `python -m care_amd.build` "
             "(the HIP path has no CPU/PyTorch fallback)".format(path))
     lib = ctypes.CDLL(path)
     for name, (res, args) in PLAIN.items():
@@ -138,9 +174,18 @@ def load(path: str = LIB_PATH):
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype, fn.argtypes = c_int, args
     if lib.care_version() != ABI_VERSION:
-        raise CareHipError("libcare_hip.so ABI {} != expected {}".format(lib.care_version(), ABI_VERSION))
-    _lib = lib
+        raise CareHipError("{} ABI {} != expected {}".format(os.path.basename(path), lib.care_version(), ABI_VERSION))
+    if lib.care_h16().decode() != VARIANT_H16[variant]:
+        raise CareHipError("{} was compiled for 16-bit type {}, variant {!r} needs {}".format(
+            path, lib.care_h16().decode(), variant, VARIANT_H16[variant]))
+    if not explicit:
+        _libs[variant] = lib
     return lib
+
+
+def source_hash(variant: str = "") -> str:
+    """The source hash the loaded library of `variant` carries (care_amd/build.py)."""
+    return load(variant=variant).care_source_hash().decode()
 
 
 def exported_symbols():
@@ -167,13 +212,13 @@ STAMP = None
 LAST_CALL = {}  # tag -> (function name, args): lets bench.py re-launch one kernel back to back
 
 
-def call(name: str, *args, tag: str = None):
-    """Invoke an ABI function on torch's current stream; raise on any non-zero status."""
-    fn = getattr(load(), name)
+def call(name: str, *args, tag: str = None, variant: str = ""):
+    """Invoke an ABI function (of the library `variant`) on torch's current stream; raise on any non-zero status."""
+    lib = load(variant=variant)
+    fn = getattr(lib, name)
     if STAMP is not None and tag == STAMP["tag"] and 2 * STAMP["n"] + 2 <= STAMP["buf"].numel():
         base, i = STAMP["buf"].data_ptr(), STAMP["n"]
         STAMP["n"] = i + 1
-        lib = load()
         lib.care_timestamp(base + 16 * i, stream_ptr())
         rc = fn(*args, stream_ptr())
         lib.care_timestamp(base + 16 * i + 8, stream_ptr())
@@ -183,7 +228,7 @@ def call(name: str, *args, tag: str = None):
         rc = fn(*args, stream_ptr())
         end.record()
         TIMING.setdefault(tag, []).append((start, end))
-        LAST_CALL[tag] = (name, args)
+        LAST_CALL[tag] = (name, args, variant)
     else:
         rc = fn(*args, stream_ptr())
     if rc != 0:
@@ -198,8 +243,8 @@ def argmax_parts(n: int, m: int = 0, bf16: bool = False) -> int:
 def relaunch_avg_us(tag: str, iters: int = 50) -> float:
     """Average duration of the last launch recorded under `tag`, re-issued `iters` times back to
     back on the current stream between two HIP events (kernels on the path are idempotent)."""
-    name, args = LAST_CALL[tag]
-    fn = getattr(load(), name)
+    name, args, variant = LAST_CALL[tag]
+    fn = getattr(load(variant=variant), name)
     for _ in range(3):
         fn(*args, stream_ptr())
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

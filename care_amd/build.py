@@ -1,12 +1,23 @@
-"""Build libcare_hip.so (hand-written gfx950 kernels + C ABI) in-tree with hipcc.
+"""Build libcare_hip*.so (hand-written gfx950 kernels + C ABI) in-tree with hipcc.
 
-    python -m care_amd.build [--force]
+    python -m care_amd.build [--force] [--variant f16] [--all]
 
-hipcc cross-compiles for gfx950 without a GPU.  Every source is compiled to an object of its own
-(`care_amd/csrc/.obj/`, in parallel, only when it or a header it includes is newer) and the objects are
-linked into the .so.  The .so is git-ignored but travels to the GPU box with the repo snapshot; the
-objects do not (`.gpurunignore`).
+hipcc cross-compiles for gfx950 without a GPU.  Every source is compiled to an object of its own (in parallel, only
+when it or a header is newer) and the objects are linked into the .so.  The .so is git-ignored but travels to the GPU
+box with the repo snapshot; the objects do not (`.gpurunignore`).
+
+**The binary is bound to its sources.**  `source_hash(variant)` = SHA-256 over the bytes of every `csrc/*.hip`,
+`csrc/*.h`, `include/care_hip.h` and the compile flags; it is compiled into the library (`csrc/version.hip`,
+`care_source_hash()`), and `needs_build()` / `care_amd._lib.load()` compare the library's hash with the tree's - not
+modification times.  A stale library is rebuilt (or, without hipcc, refused), never silently used.  Objects live under
+`.obj/<variant>-<hash of the flags>/`, so a build with other flags (CARE_HIPCC_FLAGS, a tool's -D switches) never mixes
+its objects with the default build's.
+
+Variants (same sources, same ABI, a library each):
+  ""    libcare_hip.so      16-bit storage / MFMA operands are bf16 (the throughput mode `bf16`; fp32 / fp16x3 modes too)
+  "f16" libcare_hip_f16.so  the SAME kernels with IEEE fp16 as the 16-bit type (-DCARE_H16_FP16): compute mode `fp16`
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -15,11 +26,22 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, ".obj")
-LIB = os.path.join(HERE, "libcare_hip.so")
 SOURCES = ("gemm.hip", "gemm_as.hip", "gemm_vocab.hip", "gemm_store32.hip", "gemm_tile.hip", "gemm_ln.hip", "rowops.hip",
            "attention.hip", "attention_seq.hip", "attention_latent.hip", "heads.hip", "beam.hip", "beam_sparse.hip",
-           "compact.hip", "backward.hip", "decode_resident.hip", "decode_resident_beam.hip")
+           "compact.hip", "backward.hip", "decode_resident.hip", "decode_resident_beam.hip", "decode_chain.hip")
+VERSION_SRC = "version.hip"  # compiled on every link with the hash / flags of the build
 ARCH = "gfx950"
+BASE_FLAGS = ("--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc")
+VARIANTS = {"": (), "f16": ("-DCARE_H16_FP16",)}
+HASH_MARK = b"CARE_SRC_HASH="
+LAST_BUILD = {}  # variant -> "compiled" | "reused" (what the last build() call of this process did)
+
+
+def lib_path(variant: str = "") -> str:
+    return os.path.join(HERE, "libcare_hip{}.so".format("_" + variant if variant else ""))
+
+
+LIB = lib_path("")
 
 
 def _hipcc() -> str:
@@ -27,6 +49,14 @@ def _hipcc() -> str:
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
             return cand
     return "hipcc"
+
+
+def have_hipcc() -> bool:
+    c = _hipcc()
+    if os.path.isabs(c):
+        return os.path.exists(c)
+    from shutil import which
+    return which(c) is not None
 
 
 def _headers():
@@ -38,81 +68,116 @@ def _sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def variant_flags(variant: str = "", flags_extra=()):
+    if variant not in VARIANTS:
+        raise ValueError("unknown library variant {!r} (have {})".format(variant, sorted(VARIANTS)))
+    return list(VARIANTS[variant]) + os.environ.get("CARE_HIPCC_FLAGS", "").split() + list(flags_extra)
+
+
+def have_sources() -> bool:
+    return os.path.isdir(CSRC) and os.path.exists(os.path.join(CSRC, VERSION_SRC))
+
+
+def source_hash(variant: str = "", flags_extra=()) -> str:
+    """SHA-256 (hex, 32 chars) of the kernel sources, headers and compile flags of a variant."""
+    h = hashlib.sha256()
+    files = sorted(set(_sources() + _headers() + [os.path.join(CSRC, VERSION_SRC)]))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join(list(BASE_FLAGS) + variant_flags(variant, flags_extra)).encode())
+    return h.hexdigest()[:32]
+
+
+def embedded_hash(path: str):
+    """The source hash a built library carries (None: not a library of this build system)."""
+    try:
+        with open(path, "rb") as fh:
+            blob = fh.read()
+    except OSError:
+        return None
+    i = blob.find(HASH_MARK)
+    if i < 0:
+        return None
+    return blob[i + len(HASH_MARK): i + len(HASH_MARK) + 32].decode("ascii", "replace")
+
+
+def needs_build(variant: str = "") -> bool:
+    p = lib_path(variant)
+    if not os.path.exists(p):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in _sources() + _headers())
+    if not have_sources():
+        return False
+    return embedded_hash(p) != source_hash(variant)
 
 
-def build(force: bool = False, verbose: bool = True, jobs: int = 0, out: str = None, flags_extra=(), sources=None) -> str:
-    """out / flags_extra / sources: a VARIANT build (tools: e.g. the fenced hand-offs of the resident decodes,
-    -DRES_FENCED) into a library of its own, objects under .obj/<name>/; the default build is untouched."""
-    if out:
-        return _build_variant(out, list(flags_extra), sources, verbose)
-    if not force and not needs_build():
-        return LIB
-    os.makedirs(OBJ, exist_ok=True)
+def _compile_link(out: str, variant: str, flags_extra, force: bool, verbose: bool, jobs: int) -> None:
+    vflags = variant_flags(variant, flags_extra)
+    flags = list(BASE_FLAGS) + vflags
+    key = hashlib.sha256(" ".join(flags).encode()).hexdigest()[:8]
+    odir = os.path.join(OBJ, "{}-{}".format(variant or "default", key))
+    os.makedirs(odir, exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in _headers())
-    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
-    extra = os.environ.get("CARE_HIPCC_FLAGS", "").split()
     todo, objs = [], []
     for src in _sources():
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(odir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or extra or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            todo.append((src, obj))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            todo.append((src, obj, ()))
+    vobj = os.path.join(odir, "version.o")
+    objs.append(vobj)
+    todo.append((os.path.join(CSRC, VERSION_SRC), vobj,
+                 ('-DCARE_SRC_HASH_STR="{}"'.format(source_hash(variant, flags_extra)),
+                  '-DCARE_BUILD_FLAGS_STR="{}"'.format(" ".join(vflags).replace('"', "'")))))
 
-    def compile_one(so):
-        cmd = [_hipcc()] + flags + extra + ["-c", so[0], "-o", so[1]]
+    def compile_one(job):
+        cmd = [_hipcc()] + flags + list(job[2]) + ["-c", job[0], "-o", job[1]]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
     jobs = jobs or int(os.environ.get("CARE_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    # the slowest translation units first (the resident decodes take minutes, most others seconds)
+    slow = ("decode_resident_beam", "decode_resident", "decode_chain", "gemm_tile", "attention.")
+    todo.sort(key=lambda j: next((i for i, s in enumerate(slow) if s in os.path.basename(j[0])), len(slow)))
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
         list(pool.map(compile_one, todo))
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + objs
+    tmp = out + ".tmp"
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    os.replace(tmp, out)
 
 
-def _build_variant(out: str, flags_extra, sources, verbose: bool) -> str:
-    name = os.path.splitext(os.path.basename(out))[0]
-    odir = os.path.join(OBJ, name)
-    os.makedirs(odir, exist_ok=True)
-    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"] + list(flags_extra)
-    variant = set(sources or SOURCES)
-    objs, todo = [], []
-    for src in _sources():
-        base = os.path.basename(src)
-        if base in variant:
-            obj = os.path.join(odir, base[:-4] + ".o")
-            todo.append((src, obj))
-        else:  # untouched sources: the default build's objects
-            obj = os.path.join(OBJ, base[:-4] + ".o")
-            if not os.path.exists(obj):
-                raise RuntimeError("run the default build first ({} is missing)".format(obj))
-        objs.append(obj)
+def build(force: bool = False, verbose: bool = True, jobs: int = 0, out: str = None, flags_extra=(), variant: str = "") -> str:
+    """Build (or reuse) the library of `variant`; LAST_BUILD[variant] says which.  out / flags_extra: a TOOL build
+    (ablation switches, e.g. -DRES_NOINLINE) into a library of its own - objects keyed by the flags, the default
+    library untouched."""
+    if out:
+        _compile_link(out, variant, flags_extra, force, verbose, jobs)
+        return out
+    p = lib_path(variant)
+    if not force and not needs_build(variant):
+        LAST_BUILD[variant] = "reused"
+        return p
+    _compile_link(p, variant, (), force, verbose, jobs)
+    LAST_BUILD[variant] = "compiled"
+    return p
 
-    def compile_one(so):
-        cmd = [_hipcc()] + flags + ["-c", so[0], "-o", so[1]]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-        list(pool.map(compile_one, todo))
-    subprocess.run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", out] + objs, check=True)
-    return out
+def build_all(force: bool = False, verbose: bool = True) -> dict:
+    return {v: build(force=force, verbose=verbose, variant=v) for v in VARIANTS}
 
 
 if __name__ == "__main__":
-    if "--fenced" in sys.argv:  # the resident decodes with agent-scope release / acquire fences at every hand-off
-        print(build(out=os.path.join(HERE, "libcare_hip_fenced.so"), flags_extra=["-DRES_FENCED"],
-                    sources=("decode_resident.hip", "decode_resident_beam.hip")))
+    force = "--force" in sys.argv
+    if "--all" in sys.argv:
+        for v, p in build_all(force=force).items():
+            print("{} [{}] {}".format(p, LAST_BUILD[v], embedded_hash(p)))
         sys.exit(0)
-    build(force="--force" in sys.argv)
-    print(LIB)
+    v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    p = build(force=force, variant=v)
+    print("{} [{}] {}".format(p, LAST_BUILD[v], embedded_hash(p)))

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + roff[ks & 3] + (ks >> 2) * 256);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s, 0, 0, 0);
+        s = care_mfma_16x16x32_h16(a, qf[ks], s, 0, 0, 0);
       }
       // lane (head fr, group fg) holds keys c*16 + fg*4 + r
       s += *reinterpret_cast<const f32x4*>(sbias + headc * 128 + c * CH_KEYS + fg * 4);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attention_latent_kernel(LatArgs
             : "memory");
 #pragma unroll
         for (int m = 0; m < 8; ++m)
-          acc[g * 8 + m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[m], pb, acc[g * 8 + m], 0, 0, 0);
+          acc[g * 8 + m] = care_mfma_16x16x16_h16(a[m], pb, acc[g * 8 + m], 0, 0, 0);
       }
     }
 
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attention_latentN_kernel(LatArgs p
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + roff[ks & 3] + (ks >> 2) * 256);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s, 0, 0, 0);
+        s = care_mfma_16x16x32_h16(a, qf[ks], s, 0, 0, 0);
       }
       {
         const unsigned xb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)xch;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attention_latentN_kernel(LatArgs p
             : "memory");
 #pragma unroll
         for (int m = 0; m < 8; ++m)
-          acc[g * 8 + m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[m], pb, acc[g * 8 + m], 0, 0, 0);
+          acc[g * 8 + m] = care_mfma_16x16x16_h16(a[m], pb, acc[g * 8 + m], 0, 0, 0);
       }
     }
 
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(64, 1) void attention_latent_few_kernel(LatArgs p) 
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + roff[ks & 3] + (ks >> 2) * 256);
-      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s, 0, 0, 0);
+      s = care_mfma_16x16x32_h16(a, qf[ks], s, 0, 0, 0);
     }
     s += *reinterpret_cast<const f32x4*>(sbias + headc * 128 + c * CH_KEYS + fg * 4);
     float cm = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(64, 1) void attention_latent_few_kernel(LatArgs p) 
           : "memory");
 #pragma unroll
       for (int m = 0; m < 8; ++m)
-        acc[g * 8 + m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[m], pb, acc[g * 8 + m], 0, 0, 0);
+        acc[g * 8 + m] = care_mfma_16x16x16_h16(a[m], pb, acc[g * 8 + m], 0, 0, 0);
     }
   }
 

@@ -112,8 +112,8 @@ __global__ __launch_bounds__(SEQ_WAVES * 64) void attention_seq_kernel(SeqArgs p
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qt][0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qt][1], a, 0, 0, 0);
+        a = care_mfma_16x16x32_h16(k0, qf[qt][0], a, 0, 0, 0);
+        a = care_mfma_16x16x32_h16(k1, qf[qt][1], a, 0, 0, 0);
         st[kb][qt] = a;
       }
     }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(SEQ_WAVES * 64) void attention_seq_kernel(SeqArgs p
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
-          acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[dt], pb[kb][qt], acc[dt][qt], 0, 0, 0);
+          acc[dt][qt] = care_mfma_16x16x16_h16(a[dt], pb[kb][qt], acc[dt][qt], 0, 0, 0);
     }
 
     // ---- store: lane (query column fr, group fg) holds dims 16 dt + 4 fg + r

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void sparse_collect_kernel(SpArgs p) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) {  // operand roles and k order of the first pass: bit-identical logits
         const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + boff(half * 16 + k));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[k], acc, 0, 0, 0);
+        acc = care_mfma_32x32x16_h16(b, a[k], acc, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

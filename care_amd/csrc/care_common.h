@@ -4,11 +4,52 @@
 #include <stdint.h>
 #include "../../include/care_hip.h"
 
-typedef __bf16 bf16_t;
+// The 16-bit storage type of the library (weights, activation mirrors, K/V caches, MFMA operands).  ONE source, two
+// libraries: libcare_hip.so with bfloat16 (8 significand bits: compute mode `bf16`) and libcare_hip_f16.so with IEEE half
+// (-DCARE_H16_FP16: 11 significand bits at the same bytes and the same MFMA rate: compute mode `fp16`, care_amd/build.py).
+// `bf16_t` / `bf16x8` are the historical names of that type in the kernels; read them as "the library's 16-bit float".
+// Accumulators, LayerNorm / softmax statistics and the residual stream are fp32 in both.  The split-fp16 products of the
+// concept embedder and of fp16x3 mode name _Float16 explicitly and are the same in both libraries.
+#ifdef CARE_H16_FP16
+typedef _Float16 h16_t;
+#define CARE_H16_NAME "fp16"
+#else
+typedef __bf16 h16_t;
+#define CARE_H16_NAME "bf16"
+#endif
+typedef h16_t bf16_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef h16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef float care_f32x16 __attribute__((ext_vector_type(16)));
+typedef short care_s16x4 __attribute__((ext_vector_type(4)));
+
+// The library's MFMAs on its 16-bit type (the trailing cbsz / abid / blgp arguments of the builtins are always 0 here and
+// are accepted only so that call sites read like the builtin): v_mfma_f32_{16x16x32,32x32x16,16x16x16}_{bf16,f16}.
+__device__ __forceinline__ f32x4 care_mfma_16x16x32_h16(bf16x8 a, bf16x8 b, f32x4 c, int = 0, int = 0, int = 0) {
+#ifdef CARE_H16_FP16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ care_f32x16 care_mfma_32x32x16_h16(bf16x8 a, bf16x8 b, care_f32x16 c, int = 0, int = 0, int = 0) {
+#ifdef CARE_H16_FP16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+// (operands as four 16-bit lanes in a short4, the form the bf16 _1k builtin takes)
+__device__ __forceinline__ f32x4 care_mfma_16x16x16_h16(care_s16x4 a, care_s16x4 b, f32x4 c, int = 0, int = 0, int = 0) {
+#ifdef CARE_H16_FP16
+  typedef _Float16 hx4 __attribute__((ext_vector_type(4)));
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(hx4, a), __builtin_bit_cast(hx4, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+#endif
+}
 
 #define CARE_WAVE 64
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 
 #include "care_common.h"
 
@@ -40,6 +41,7 @@ struct RArgs {
   int32_t* anc[2]; int32_t* done; int32_t* nfin; float* fscore; int32_t* flen; int32_t* fhyp;
   float* gval; int32_t* ggid;  // per (row, vocabulary part): the RES_BMK best 4-column groups (maximum, group number)
   int vcap;                    // workgroups of the vocabulary phase (PhaseMap gcap): parts <= 48
+  int fenced;                  // hand-offs with an agent-scope release / acquire pair (GridSync; care_resident_set_fenced)
   bf16_t* hn;                  // the normalised last hidden rows (bf16 [R16, 512]): the B operand of the recomputed logits
 };
 
@@ -123,21 +125,24 @@ struct GridSync {
   // moves across it), ONE lane adds to the phase's sharded counter; the consumer polls every shard with sc1 loads,
   // joins its workgroup's barrier, and EVERY load of handed-off bytes is an sc1 load to registers.  That is not what the
   // HIP memory model promises for relaxed atomics (a formal race; no cache-wide release / acquire is executed) - hence
-  // the arch check below, the stress tests of tests/test_gpu_resident.py and -DRES_FENCED: the same protocol with an
-  // agent-scope release before the add and an acquire after the poll (+ ~3 us per hand-off, MI355X_MICROARCH.md fence
-  // table; *measured* here: DESIGN.md 4.2d).
+  // the arch check below, the stress tests of tests/test_gpu_resident.py and `fenced`: the same protocol with an
+  // agent-scope release before the add and an acquire after the poll (+ ~1 .. 4 us per hand-off, MI355X_MICROARCH.md fence
+  // table; *measured* here: DESIGN.md 4.2d) - a RUN-TIME choice of every launch (RArgs::fenced): the host side takes the
+  // fence-free form only on the configuration the stress tests validated (a gfx950 device with all 256 CUs in one
+  // partition) unless care_resident_set_fenced says otherwise (res_fenced_for_device).
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
-#error "decode_resident: the fence-free hand-off is validated for gfx950 only (build with -DRES_FENCED elsewhere)"
+#error "decode_resident: the fence-free hand-off is validated for gfx950 only"
 #endif
+  bool fenced = false;
   __device__ __forceinline__ void arrive(bool participant) {
     if (!participant) return;       // workgroup-uniform
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's write-through stores are acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-#ifdef RES_FENCED
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+      if (fenced) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __hip_atomic_fetch_add(counter(cur, blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -180,10 +185,10 @@ struct GridSync {
       }
       if (threadIdx.x == 0) {
         s_dead = d;
-#ifdef RES_FENCED
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+        if (fenced) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
       }
     }
     __syncthreads();
@@ -846,8 +851,8 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
           if (active) {
 #pragma unroll
             for (int i = qq * QF; i < (qq + 1) * QF; i += 2) {
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[i], acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], af[i + 1], acc1, 0, 0, 0);
+              acc0 = care_mfma_16x16x32_h16(wf[i], af[i], acc0, 0, 0, 0);
+              acc1 = care_mfma_16x16x32_h16(wf[i + 1], af[i + 1], acc1, 0, 0, 0);
             }
           }
           part[qq] = acc0 + acc1;
@@ -1158,8 +1163,8 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = h8 * CH; i < h8 * CH + CH; i += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], *reinterpret_cast<const bf16x8*>(ar + i * 32), acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i + 1], *reinterpret_cast<const bf16x8*>(ar + (i + 1) * 32), acc1, 0, 0, 0);
+          acc0 = care_mfma_16x16x32_h16(wf[i], *reinterpret_cast<const bf16x8*>(ar + i * 32), acc0, 0, 0, 0);
+          acc1 = care_mfma_16x16x32_h16(wf[i + 1], *reinterpret_cast<const bf16x8*>(ar + (i + 1) * 32), acc1, 0, 0, 0);
         }
         e[h8] = acc0 + acc1;
       }
@@ -1494,7 +1499,26 @@ inline int res_fill_layers(RArgs& p, const care_resident_layer* layers, int n_la
 
 }  // namespace
 extern std::atomic<int> care_res_dbg_prof, care_res_dbg_ghost;  // decode_resident.hip (care_decode_resident_debug)
+extern std::atomic<int> care_res_fenced_mode;                   // decode_resident.hip (care_resident_set_fenced): -1 auto, 0, 1
 namespace {
+
+// Which hand-off a resident launch on the current device takes: the fence-free one only where it was validated
+// (tests/test_gpu_resident.py's stress / contention tests run on gfx950 with all 256 CUs in one partition); any other
+// device, partition mode or an explicit care_resident_set_fenced(1) / CARE_RESIDENT_FENCED=1 gets the release / acquire
+// pair.  care_resident_set_fenced(0) forces the fence-free form (the validated arch is still a compile-time condition).
+inline int res_fenced_for_device() {
+  int mode = care_res_fenced_mode.load();
+  if (mode < 0) {
+    static const int env = [] { const char* e = getenv("CARE_RESIDENT_FENCED"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    mode = env;
+  }
+  if (mode >= 0) return mode;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+  const bool gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+  return (gfx950 && prop.multiProcessorCount == 256) ? 0 : 1;
+}
 
 // Tuning / tool / test knobs of the resident launches: the environment is read ONCE per process (first launch), the
 // debug hooks are set through care_decode_resident_debug (tests, tools/resident_prof.py), never through the environment.

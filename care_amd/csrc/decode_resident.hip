@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
   GridSync gs{p.sync, (unsigned)p.ghost, -1, false, 0, 0, 0u};
+  gs.fenced = p.fenced != 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = p.d;
   constexpr bool WIDE = D != 512;
@@ -163,8 +164,12 @@ std::atomic<int> g_res_ok[8];  // residency checked (res_check_residency) for th
 }  // namespace
 
 std::atomic<int> care_res_dbg_prof{0}, care_res_dbg_ghost{0};  // care_decode_resident_debug (shared with decode_resident_beam.hip)
+std::atomic<int> care_res_fenced_mode{-1};                      // care_resident_set_fenced
 
 extern "C" {
+
+void care_resident_set_fenced(int mode) { care_res_fenced_mode.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
+int care_resident_fenced(void) { return res_fenced_for_device(); }
 
 void care_decode_resident_debug(int prof_step, int ghost) {
   care_res_dbg_prof.store(prof_step);
@@ -201,7 +206,8 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
   p.vocab = (const bf16_t*)vocab_w; p.V = V;
   p.d = d; p.H = heads; p.ff = ff; p.act = act; p.R = rows; p.T = T; p.steps = steps; p.bos = bos; p.eos = eos; p.pad = pad; p.early = early_exit;
   p.prof_step = care_res_dbg_prof.load();        // tools: phase clocks of that step -> scratch + 2048
-  p.ghost = care_res_dbg_ghost.load() ? 8 : 0;   // tests: phases whose producers never all arrive (the watchdog)
+  p.ghost = care_res_dbg_ghost.load() ? 8 : 0;
+  p.fenced = res_fenced_for_device();   // tests: phases whose producers never all arrive (the watchdog)
   p.fed = fed; p.fed_stride = fed_stride; p.score = score; p.length = length; p.fin = finished;
   const int64_t R16 = (rows + 15) / 16 * 16;
   p.parts = wide ? ((V + 15) / 16 < 64 * RES_NP ? (V + 15) / 16 : 64 * RES_NP) : (V + 63) / 64;  // (the layout's stride; the launch's count below)

@@ -204,8 +204,8 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[q], af[q], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[q + 1], af[q + 1], acc1, 0, 0, 0);
+          acc0 = care_mfma_16x16x32_h16(wf0[q], af[q], acc0, 0, 0, 0);
+          acc1 = care_mfma_16x16x32_h16(wf0[q + 1], af[q + 1], acc1, 0, 0, 0);
         }
         vt[0] = acc0 + acc1;
       }
@@ -214,8 +214,8 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[q], af[q], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[q + 1], af[q + 1], acc1, 0, 0, 0);
+          acc0 = care_mfma_16x16x32_h16(wf1[q], af[q], acc0, 0, 0, 0);
+          acc1 = care_mfma_16x16x32_h16(wf1[q + 1], af[q + 1], acc1, 0, 0, 0);
         }
         vt[1] = acc0 + acc1;
       }
@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
   GridSync gs{p.sync, (unsigned)p.ghost, -1, false, 0, 0, 0u};
+  gs.fenced = p.fenced != 0;
   const int d = p.d;
   constexpr bool HF = KCF == 4 && SM;
   const float* y2 = HF ? p.y2 : nullptr;  // the second K half of FFN dense2, added by its consumers
@@ -547,6 +548,7 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   p.d = d; p.H = heads; p.ff = ff; p.act = act; p.R = rows; p.T = T; p.steps = steps; p.bos = bos; p.eos = eos; p.pad = pad; p.early = early_exit;
   p.prof_step = care_res_dbg_prof.load();
   p.ghost = care_res_dbg_ghost.load() ? 8 : 0;
+  p.fenced = res_fenced_for_device();
   p.fed = tok; p.fed_stride = stride; p.score = scores; p.length = nullptr; p.fin = nullptr;
   p.bm = beam; p.nclips = clips; p.need = need; p.fin_cap = fin_cap;
   p.anc[0] = anc0; p.anc[1] = anc1; p.done = done; p.nfin = nfin; p.fscore = fscore; p.flen = flen; p.fhyp = fhyp;

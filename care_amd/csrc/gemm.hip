@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
               acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[m]), __builtin_bit_cast(f16x8, fb[n]),
                                                                  acc[m][n], 0, 0, 0);
             } else {
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+              acc[m][n] = care_mfma_16x16x32_h16(fa[m], fb[n], acc[m][n], 0, 0, 0);
             }
       } else {
         f32x4 fa[MT], fb[NT];

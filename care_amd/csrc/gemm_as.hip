@@ -218,11 +218,11 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
           fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff[(ks + BDEPTH) & 3] + ((ks + BDEPTH) >> 2) * 256);
         if (CARE_AS_DBG & 2) { asm volatile("" :: "v"(b)); continue; }
         if constexpr (MODE != STREAM_STORE) {  // D[row of A][col = W row]: a lane sees 1 column, 4 rows
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], b, acc[1], 0, 0, 0);
+          acc[0] = care_mfma_16x16x32_h16(a[0][ks], b, acc[0], 0, 0, 0);
+          acc[1] = care_mfma_16x16x32_h16(a[1][ks], b, acc[1], 0, 0, 0);
         } else {  // swapped: a lane holds 4 CONSECUTIVE output columns of one row
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[0][ks], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[1][ks], acc[1], 0, 0, 0);
+          acc[0] = care_mfma_16x16x32_h16(b, a[0][ks], acc[0], 0, 0, 0);
+          acc[1] = care_mfma_16x16x32_h16(b, a[1][ks], acc[1], 0, 0, 0);
         }
 #ifndef CARE_AS_NOPIN
         __builtin_amdgcn_sched_barrier(0);  // pinned k-step order (see compute_woven)
@@ -425,8 +425,8 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
           fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff[(ks + BDEPTH) & 3] + ((ks + BDEPTH) >> 2) * 256);
         if (CARE_AS_DBG & 2) asm volatile("" :: "v"(b));
         else {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], b, acc[1], 0, 0, 0);
+          acc[0] = care_mfma_16x16x32_h16(a[0][ks], b, acc[0], 0, 0, 0);
+          acc[1] = care_mfma_16x16x32_h16(a[1][ks], b, acc[1], 0, 0, 0);
         }
       }
       if ((ks & 1) && !(CARE_AS_DBG & 16)) argmax_one(accp, c0, ks >> 1);

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256 * RG, RG == 1 ? 1 : 2) void gemm_ln_kernel(LnAr
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt)  // swapped: lane holds 4 consecutive columns of one row
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = care_mfma_16x16x32_h16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -314,7 +314,7 @@ __device__ __forceinline__ f32x4 ln2_mfma(const bf16x8& b, const bf16x8& a, cons
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
   } else {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+    return care_mfma_16x16x32_h16(b, a, c, 0, 0, 0);
   }
 }
 
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
     for (int t = 0; t < 2; ++t) {
       if constexpr (AF32) {  // pairs -> one v_cvt_pk_bf16_f32 each
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef h16_t bf16x2 __attribute__((ext_vector_type(2)));
         if constexpr (REP == 3) {  // split products: fp16 pieces (11 bits each) in the bf16-typed fragment registers
           // (whole 32-bit pairs are moved: an element-wise bit_cast of the halves made hipcc drop the odd ones)
           typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

@@ -260,8 +260,8 @@ __global__ __launch_bounds__(512, 2) void gemm_store32_kernel(SArgs p) {
       for (int ks = 0; ks < 32; ++ks) {
         const bf16x8 b = fb[ks % BDEPTH];
         if (ks + BDEPTH < 32) fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff(ks + BDEPTH));
-        if (ks == 0) ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        else ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[ks], ac, 0, 0, 0);
+        if (ks == 0) ac = care_mfma_32x32x16_h16(b, a[0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else ac = care_mfma_32x32x16_h16(b, a[ks], ac, 0, 0, 0);
         if constexpr (PREV) {
           if (ks % 6 == 5 && ks / 6 < 4) out_piece(ap, t - 1, ks / 6, v);   // pieces after k-steps 5, 11, 17, 23
           if (ks == 27) { st_hist2 = st_hist1; st_hist1 = st_hist0; st_hist0 = out_store(t - 1, v); }

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fb[n]), __builtin_bit_cast(f16x8, fa[m]),
                                                                acc[m][n], 0, 0, 0);
           } else {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[n], fa[m], acc[m][n], 0, 0, 0);
+            acc[m][n] = care_mfma_16x16x32_h16(fb[n], fa[m], acc[m][n], 0, 0, 0);
           }
     }
   }

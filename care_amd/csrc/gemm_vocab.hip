@@ -261,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
         const bf16x8 b = fb[ks % BDEPTH];
         if (ks + BDEPTH < 32 && !(CARE_V32_DBG & 32)) fb[ks % BDEPTH] = *reinterpret_cast<const bf16x8*>(sb + boff(ks + BDEPTH));
         if (CARE_V32_DBG & 2) asm volatile("" :: "v"(b));
-        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[ks], acc, 0, 0, 0);  // D[n][m]: lane = row m, 16 columns n
+        else acc = care_mfma_32x32x16_h16(b, a[ks], acc, 0, 0, 0);  // D[n][m]: lane = row m, 16 columns n
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (STATS) {

@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void head_expand_kernel(const bf16_t* q, int64
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[2 * k + half][0], af[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[2 * k + half][1], af[1], acc, 0, 0, 0);
+        acc = care_mfma_16x16x32_h16(bw[2 * k + half][0], af[0], acc, 0, 0, 0);
+        acc = care_mfma_16x16x32_h16(bw[2 * k + half][1], af[1], acc, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[half * 4 + j] = (bf16_t)acc[j];
       }
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const bf16_t* ct, int6
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + roff[ks & 3] + (ks >> 2) * 256);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ks], a, acc, 0, 0, 0);
+      acc = care_mfma_16x16x32_h16(bw[ks], a, acc, 0, 0, 0);
     }
     // lane (batch row fr, group fg) holds output columns h*64 + wave*16 + fg*4 + 0..3
     const int T = blockIdx.y + n * gridDim.y;

@@ -565,5 +565,3 @@ extern "C" int care_score_logits(const float* logits, int64_t ld, int V, const i
   return care_launch_status();
 }
 
-extern "C" int care_version(void) { return CARE_ABI_VERSION; }
-extern "C" const char* care_arch(void) { return "gfx950"; }

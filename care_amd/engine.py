@@ -18,6 +18,7 @@ post-LN, eval-mode dropout is identity).
 import collections
 import contextlib
 import ctypes
+import functools
 import os
 import weakref
 from typing import Dict, List, Optional
@@ -25,12 +26,12 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_CODES, CARE_BF16, CARE_F32, call, ptr
+from ._lib import ACT_CODES, CARE_BF16, CARE_F32, ptr
 from .constants import BOS, EOS, PAD
 
 
 def _code(t: Optional[torch.Tensor]) -> int:
-    return CARE_BF16 if (t is not None and t.dtype == torch.bfloat16) else CARE_F32
+    return CARE_BF16 if (t is not None and t.dtype in (torch.bfloat16, torch.float16)) else CARE_F32  # (CARE_BF16: the library's 16-bit type)
 
 
 class _LaneOutputs(dict):
@@ -69,11 +70,20 @@ class _LaneOutputs(dict):
 
 class HipEngine:
     def __init__(self, opt: dict, dtype: str = "fp32"):
-        if dtype not in ("fp32", "bf16", "fp16x3"):
-            raise ValueError("compute dtype must be 'fp32', 'bf16' or 'fp16x3', got {!r}".format(dtype))
+        if dtype not in ("fp32", "bf16", "fp16", "fp16x3"):
+            raise ValueError("compute dtype must be 'fp32', 'bf16', 'fp16' or 'fp16x3', got {!r}".format(dtype))
         self.opt = opt
         self.dtype = dtype
-        self.wt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        # The 16-bit modes are ONE set of kernels compiled for two storage types (care_amd/build.py): `bf16` runs
+        # libcare_hip.so, `fp16` the same sources with IEEE half as the 16-bit type (libcare_hip_f16.so: 11 significand
+        # bits instead of 8 at the same bytes and the same MFMA rate; range 65504 - every 16-bit tensor of this path is a
+        # LayerNorm output, an attention context, a projected key / value or an FFN hidden value, all O(1 .. 100); raw
+        # features are multiplied from fp32 LDS stages rounded per fragment, so |feature| < 65504 is the one input
+        # condition, checked by `check_fp16_range`).  fp32 and fp16x3 modes use the default library.
+        self.variant = "f16" if dtype == "fp16" else ""
+        self.h16 = torch.float16 if dtype == "fp16" else torch.bfloat16
+        self.call = functools.partial(_lib.call, variant=self.variant)
+        self.wt = self.h16 if dtype in ("bf16", "fp16") else torch.float32
         # 'fp16x3': fp32 storage everywhere (activations, K/V caches, weights' masters) like 'fp32', but every GEMM
         # multiplies hi/lo fp16 pieces of both operands - a_hi w_hi + a_hi w_lo + a_lo w_hi, three fp16 MFMA passes,
         # what is dropped is ~2^-22 of a product - on the LDS-tiled kernel instead of the exact-f32 MFMA (1/16 of
@@ -139,10 +149,15 @@ class HipEngine:
         # (translate.py's default: 128 clips x beam 5); 0: the multi-launch search at every size
         self.resident_beam_max_rows = int(os.environ.get("CARE_RESIDENT_BEAM_MAX_ROWS", "640"))
 
+    @property
+    def lib(self):
+        """The ctypes library of this engine's compute mode (libcare_hip.so, or libcare_hip_f16.so for 'fp16')."""
+        return _lib.load(variant=self.variant)
+
     # ------------------------------------------------------------------ weights
     def load_weights(self, sd: Dict[str, torch.Tensor], device) -> None:
         """Pack a reference-named state dict into the device layout the kernels read."""
-        _lib.load()
+        self.lib  # (loads - and, when stale, rebuilds - the library of this mode: raises without it)
         if not torch.cuda.is_available():
             raise _lib.CareHipError("no HIP device: the captioning path has no CPU fallback")
         self.device = torch.device(device)
@@ -214,14 +229,14 @@ class HipEngine:
             # streams (csrc/gemm_ln.hip, care_pack_ln_weight): 1 KB of full cache lines per DMA instruction
             for name in [k for k in w if k.startswith("enc_w_") or k.endswith("_o_w") or k.endswith("_ffn_w2")]:
                 W = w[name]
-                if W is not None and W.dtype == torch.bfloat16 and W.shape[0] == 512 and W.shape[1] % 128 == 0:
+                if W is not None and W.dtype == self.h16 and W.shape[0] == 512 and W.shape[1] % 128 == 0:
                     Wp = torch.empty_like(W)
-                    call("care_pack_ln_weight", ptr(W), ptr(Wp), 512, W.shape[1])
+                    self.call("care_pack_ln_weight", ptr(W), ptr(Wp), 512, W.shape[1])
                     w[name + "#packed"] = Wp
                 elif (W is not None and name.startswith("enc_w_") and W.dtype == torch.float32 and W.shape[0] == 512 and
                       W.shape[1] % 64 == 0 and opt["encoder"] == "Embedder" and os.environ.get("CARE_ENC_SPLIT", "1") != "0"):
-                    Ws = torch.empty(3 * W.shape[1] * 512, device=self.device, dtype=torch.bfloat16)
-                    call("care_pack_ln_weight_split", ptr(W), ptr(Ws), 512, W.shape[1])
+                    Ws = torch.empty(3 * W.shape[1] * 512, device=self.device, dtype=self.h16)
+                    self.call("care_pack_ln_weight_split", ptr(W), ptr(Ws), 512, W.shape[1])
                     w[name + "#split"] = Ws
         if self.bf and self.has_concepts and opt["encoder"] == "Embedder" and os.environ.get("CARE_ENC_SPLIT", "1") != "0":
             # concept models the fused kernel does not cover (d_model != 512): the embedder GEMM with split products
@@ -231,7 +246,7 @@ class HipEngine:
                 # (d_model = 512 too: small batches take this form instead of the fused kernel, see encode(small=True))
                 if W.dtype == torch.float32 and W.shape[1] % 64 == 0:
                     W3 = torch.empty(W.shape[0], 3 * W.shape[1], device=self.device, dtype=torch.float16)
-                    call("care_split3_weight", ptr(W), ptr(W3), W.shape[0], W.shape[1])
+                    self.call("care_split3_weight", ptr(W), ptr(W3), W.shape[0], W.shape[1])
                     w["enc_w_" + ch + "#split3"] = W3
         self._w3 = {}
         if self.split3:
@@ -239,7 +254,7 @@ class HipEngine:
                 if (isinstance(W, torch.Tensor) and W.dim() == 2 and W.dtype == torch.float32 and W.shape[1] % 64 == 0 and
                         "#" not in name and not name.startswith(("word", "pos", "attr_word", "attr_pos", "enc_pos_"))):
                     W3 = torch.empty(W.shape[0], 3 * W.shape[1], device=self.device, dtype=torch.float16)
-                    call("care_split3_weight", ptr(W), ptr(W3), W.shape[0], W.shape[1])
+                    self.call("care_split3_weight", ptr(W), ptr(W3), W.shape[0], W.shape[1])
                     self._w3[W.data_ptr()] = W3
         self.w = w
         self._graphs.clear()
@@ -261,7 +276,7 @@ class HipEngine:
                 # constant, which the softmax cancels); W_v, b_v are applied to the latent context
                 H = self.H
                 wkt = wk.detach().to(torch.float32).view(H, 64, self.d).permute(0, 2, 1) * 0.125
-                w[name + "_wkt"] = wkt.contiguous().to(self.device, torch.bfloat16)
+                w[name + "_wkt"] = wkt.contiguous().to(self.device, self.h16)
                 w[name + "_v_w"], w[name + "_v_b"] = wt(wv), f32(bv)
         w[name + "_o_w"], w[name + "_o_b"] = wt(sd[p + ".dense.weight"]), f32(sd[p + ".dense.bias"])
         w[name + "_g"], w[name + "_be"] = f32(sd[p + ".LayerNorm.weight"]), f32(sd[p + ".LayerNorm.bias"])
@@ -343,7 +358,7 @@ class HipEngine:
 
     @property
     def bf(self) -> bool:
-        return self.wt == torch.bfloat16
+        return self.dtype in ("bf16", "fp16")
 
     @property
     def as_ok(self) -> bool:
@@ -379,7 +394,7 @@ class HipEngine:
     @property
     def act_dtype(self):
         """dtype of activations that are ONLY GEMM inputs (attention context, FFN hidden)."""
-        return torch.bfloat16 if self.bf_act else torch.float32
+        return self.h16 if self.bf_act else torch.float32
 
     # Rows (clips x beam) from which the per-row top-k of beam search runs as two passes of the vocabulary GEMM
     # (no [rows, V] logits in memory).  Below it the logits are written (a few MB, cache resident) and
@@ -392,7 +407,7 @@ class HipEngine:
     def _beam_sparse_ws(self, tag: str, rows: int):
         """Workspaces of the sparse second pass (csrc/beam_sparse.hip) - (tile maxima [tiles, rows] fp32, per-tile
         row counts + work-unit prefix sums [2 tiles + 1], per-tile row lists [tiles, rows]) - or None where the 256-row statistics kernel does not apply."""
-        if os.environ.get("CARE_BEAM_SPARSE", "1") == "0" or not _lib.load().care_beam_sparse_applies(rows, self.V, self.d, 1):
+        if os.environ.get("CARE_BEAM_SPARSE", "1") == "0" or not self.lib.care_beam_sparse_applies(rows, self.V, self.d, 1):
             return None
         tiles = (self.V + 31) // 32
         return (self.ws(tag + "stmax", (tiles, rows)), self.ws(tag + "stcount", (2 * tiles + 1,), torch.int32),
@@ -405,7 +420,7 @@ class HipEngine:
 
     def wsb(self, name: str, shape) -> Optional[torch.Tensor]:
         """bf16 mirror workspace of a GEMM-input activation (None unless as_ok)."""
-        return self.ws(name + "#bf", shape, torch.bfloat16) if self.bf_act else None
+        return self.ws(name + "#bf", shape, self.h16) if self.bf_act else None
 
     def gemm(self, A, W, bias, out, act=0, out2=None, n_split=None, tag=None, tile=False):
         """out = act(A @ W^T + bias).  bf16 weights + bf16 A -> A-stationary kernel (csrc/gemm_as.hip) for
@@ -416,23 +431,23 @@ class HipEngine:
         assert W.shape[1] == K and A.stride(1) == 1 and out.stride(-1) == 1
         tail = (ptr(bias), ptr(out), out.stride(0), _code(out), ptr(out2),
                 out2.stride(0) if out2 is not None else 0, _code(out2), N if n_split is None else n_split, M, N, K, act)
-        if W.dtype == torch.bfloat16 and A.dtype == torch.bfloat16:
+        if W.dtype == self.h16 and A.dtype == self.h16:
             if K % 64 or A.stride(0) % 8:
                 raise ValueError("bf16 A operand needs K % 64 == 0 and a 16-byte aligned row stride (got K = {})".format(K))
             if K <= 512 and K % 128 == 0 and not tile and os.environ.get("CARE_FORCE_TILE", "0") == "0":
-                call("care_gemm_bf16", ptr(A), A.stride(0), _code(A), ptr(W), *tail, tag=tag)
+                self.call("care_gemm_bf16", ptr(A), A.stride(0), _code(A), ptr(W), *tail, tag=tag)
             else:
-                call("care_gemm_tile", ptr(A), A.stride(0), ptr(W), *tail, tag=tag)
+                self.call("care_gemm_tile", ptr(A), A.stride(0), ptr(W), *tail, tag=tag)
         else:
             if A.dtype != torch.float32:
                 raise ValueError("generic GEMM takes fp32 activations")
             W3 = self._w3.get(W.data_ptr()) if self.split3 else None
             if W3 is not None and A.stride(0) % 4 == 0:
                 a2 = self.ws("split_a2", (M, 2 * K), torch.float16)
-                call("care_split2_act", ptr(A), A.stride(0), ptr(a2), M, K)
-                call("care_gemm_tile_split3", ptr(a2), ptr(W3), *tail, tag=tag)
+                self.call("care_split2_act", ptr(A), A.stride(0), ptr(a2), M, K)
+                self.call("care_gemm_tile_split3", ptr(a2), ptr(W3), *tail, tag=tag)
             else:
-                call("care_gemm", ptr(A), A.stride(0), ptr(W), _code(W), *tail, tag=tag)
+                self.call("care_gemm", ptr(A), A.stride(0), ptr(W), _code(W), *tail, tag=tag)
         return out
 
     # up to this many rows the vocabulary arg-max of a d_model <= 512 model runs on the LDS-tiled kernel too (measured crossover
@@ -448,10 +463,10 @@ class HipEngine:
     def vocab_parts(self, rows: int) -> int:
         """Column groups per row of the fused vocabulary arg-max for `rows` rows (the kernel vocab_argmax picks)."""
         if self._vocab_as(rows):
-            return _lib.load().care_argmax_parts_bf16(rows, self.V)
+            return self.lib.care_argmax_parts_bf16(rows, self.V)
         if self.bf_act or (self.split3 and self.w["vocab"].data_ptr() in self._w3):
-            return _lib.load().care_argmax_parts_tile(self.V)
-        return _lib.load().care_argmax_parts(self.V)
+            return self.lib.care_argmax_parts_tile(self.V)
+        return self.lib.care_argmax_parts(self.V)
 
     def vocab_argmax(self, x, xb, rows, pmax, pidx, psum, labels=None, plab=None, tag="step_vocab_argmax"):
         """Per-row (max, arg-max, sum exp) partials of the vocabulary projection of the last hidden state
@@ -459,10 +474,10 @@ class HipEngine:
         bf16, d <= 512: A-stationary kernels; bf16, larger d: the LDS-tiled kernel; fp32 mode: exact-f32 MFMA."""
         d, W = self.d, self.w["vocab"]
         if self._vocab_as(rows):
-            call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels),
+            self.call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels),
                  ptr(plab), rows, self.V, d, tag=tag)
         elif self.bf_act:
-            call("care_gemm_tile_argmax", ptr(xb), d, ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels), ptr(plab),
+            self.call("care_gemm_tile_argmax", ptr(xb), d, ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels), ptr(plab),
                  rows, self.V, d, tag=tag)
         else:
             if labels is not None:
@@ -470,17 +485,17 @@ class HipEngine:
             W3 = self._w3.get(W.data_ptr()) if self.split3 else None
             if W3 is not None:
                 a2 = self.ws("split_a2v", (rows, 2 * d), torch.float16)
-                call("care_split2_act", ptr(x), x.stride(0), ptr(a2), rows, d)
-                call("care_gemm_tile_split3_argmax", ptr(a2), ptr(W3), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
+                self.call("care_split2_act", ptr(x), x.stride(0), ptr(a2), rows, d)
+                self.call("care_gemm_tile_split3_argmax", ptr(a2), ptr(W3), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
             else:
-                call("care_gemm_argmax", ptr(x), d, ptr(W), _code(W), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
+                self.call("care_gemm_argmax", ptr(x), d, ptr(W), _code(W), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
 
     def add_ln(self, x, res, g, be, out, outb=None, grp=None, out_grp_rows=None, out_row_off=0, pos=None, nslab=1, tag=None):
         """out = LN(sum of the nslab slabs of x + res); x is [rows, d] or [nslab, rows, d]."""
         rows, d = x.shape[-2], x.shape[-1]
         grp = rows if grp is None else grp
         out_grp_rows = grp if out_grp_rows is None else out_grp_rows
-        call("care_add_ln", ptr(x), x.stride(-2), ptr(res), res.stride(0) if res is not None else 0, ptr(pos), ptr(g),
+        self.call("care_add_ln", ptr(x), x.stride(-2), ptr(res), res.stride(0) if res is not None else 0, ptr(pos), ptr(g),
              ptr(be), self.eps, ptr(out), ptr(outb), out.stride(-2), rows, d, grp, out_grp_rows, out_row_off,
              nslab, x.stride(0) if nslab > 1 else 0, tag=tag)
         return out
@@ -504,11 +519,11 @@ class HipEngine:
         grp = rows if grp is None else grp
         out_grp_rows = grp if out_grp_rows is None else out_grp_rows
         if Wp is not None and pos is None and os.environ.get("CARE_LN_PACKED", "1") != "0":
-            call("care_gemm_ln_packed", ptr(A), A.stride(0), _code(A), ptr(Wp), ptr(bias), ptr(res),
+            self.call("care_gemm_ln_packed", ptr(A), A.stride(0), _code(A), ptr(Wp), ptr(bias), ptr(res),
                  res.stride(0) if res is not None else 0, ptr(g), ptr(be), self.eps, ptr(out), ptr(outb),
                  (out if out is not None else outb).stride(-2), rows, self.d, K, grp, out_grp_rows, out_row_off, tag=tag)
             return out
-        call("care_gemm_ln", ptr(A), A.stride(0), _code(A), ptr(W), ptr(bias), ptr(res),
+        self.call("care_gemm_ln", ptr(A), A.stride(0), _code(A), ptr(W), ptr(bias), ptr(res),
              res.stride(0) if res is not None else 0, ptr(pos), ptr(g), ptr(be), self.eps, ptr(out), ptr(outb),
              (out if out is not None else outb).stride(-2), rows, self.d, K, grp, out_grp_rows, out_row_off, tag=tag)
         return out
@@ -516,7 +531,7 @@ class HipEngine:
     def attention(self, Q, K, V, ctx, kv_batch_stride, kv_row_stride, rows_per_kv, nkeys, anc=None, causal=False,
                   seq=1, pad_tok=None, bias=None, tag=None):
         rows = Q.shape[0]
-        call("care_attention", ptr(Q), Q.stride(0), ptr(K), ptr(V), _code(K), kv_batch_stride, kv_row_stride,
+        self.call("care_attention", ptr(Q), Q.stride(0), ptr(K), ptr(V), _code(K), kv_batch_stride, kv_row_stride,
              rows_per_kv, ptr(anc), anc.stride(0) if anc is not None else 0, nkeys, 1 if causal else 0, seq, 0,
              ptr(pad_tok), pad_tok.stride(0) if pad_tok is not None else 0, PAD, ptr(bias),
              bias.stride(0) if bias is not None else 0, ptr(ctx), ctx.stride(0), _code(ctx), rows, self.H, tag=tag)
@@ -528,7 +543,7 @@ class HipEngine:
         forward; the fused attention kernels never materialise them)."""
         rows = Q.shape[0]
         probs = torch.empty(rows, self.H, nkeys, device=self.device)
-        call("care_attention_probs", ptr(Q), Q.stride(0), ptr(K), _code(K), kv_batch_stride, kv_row_stride, rows_per_kv,
+        self.call("care_attention_probs", ptr(Q), Q.stride(0), ptr(K), _code(K), kv_batch_stride, kv_row_stride, rows_per_kv,
              nkeys, 1 if causal else 0, seq, ptr(pad_tok), pad_tok.stride(0) if pad_tok is not None else 0, PAD,
              ptr(bias), bias.stride(0) if bias is not None else 0, ptr(probs), rows, self.H)
         return probs
@@ -562,7 +577,7 @@ class HipEngine:
         fuse = self.ln_fusable(rows) if fuse is None else fuse
         split = self.as_ok and self.ff % 512 == 0 and self.ff >= 1024
         h = self.gemm(xb if xb is not None else x, w[name + "_w1"], w[name + "_b1"],
-                      self.ws(tag + "h", (rows, self.ff), torch.bfloat16 if (split or self.bf_act) else torch.float32),
+                      self.ws(tag + "h", (rows, self.ff), self.h16 if (split or self.bf_act) else torch.float32),
                       act=self.act, tag=gemm_tag)
         w2 = w[name + "_w2"]
         if split and fuse and not ln_kw.get("pos"):
@@ -573,7 +588,7 @@ class HipEngine:
             # K = ff > 512: split K over blocks into fp32 slabs; the LayerNorm kernel sums them
             ns = self.ff // 512
             f = self.ws(tag + "fslab", (ns, rows, d))
-            call("care_gemm_bf16_splitk", ptr(h), h.stride(0), _code(h), ptr(w2), ptr(w[name + "_b2"]), ptr(f), d,
+            self.call("care_gemm_bf16_splitk", ptr(h), h.stride(0), _code(h), ptr(w2), ptr(w[name + "_b2"]), ptr(f), d,
                  f.stride(0), rows, d, self.ff, tag=gemm_tag)
             return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, nslab=ns,
                                tag="step_add_ln" if gemm_tag else None, **ln_kw)
@@ -601,7 +616,7 @@ class HipEngine:
                 all(int(self.opt["dim_" + ch]) % 128 == 0 for ch in self.modality))
 
     def _prep_one(self, f):
-        if f.dtype == torch.bfloat16 and self.feats_bf16_ok:
+        if f.dtype == self.h16 and self.feats_bf16_ok:
             return f.to(self.device).contiguous()
         return f.to(self.device, torch.float32).contiguous()
 
@@ -624,7 +639,7 @@ class HipEngine:
         new = (lambda name, shape, dt=torch.float32: self.ws("enc_out_" + name, shape, dt)) if static else \
               (lambda name, shape, dt=torch.float32: torch.empty(shape, device=self.device, dtype=dt))
         mem = None if lean else new("mem", (B, self.Lk, d))
-        memb = new("memb", (B, self.Lk, d), torch.bfloat16) if self.bf_act else None
+        memb = new("memb", (B, self.Lk, d), self.h16) if self.bf_act else None
         means = None if lean else new("means", (B, len(self.modality) * d))
         # small batches, Embedder: the modalities' launches are a few microseconds of latency-bound work each - they run
         # side by side on streams of their own (forked from / joined to the caller's stream; also inside a capture)
@@ -647,7 +662,7 @@ class HipEngine:
                 x2 = x.view(B * n, x.shape[2])
                 Ws = w.get("enc_w_" + ch + "#split")
                 fused = (opt["encoder"] == "Embedder" and self.as_ok and d == 512 and
-                         (w["enc_w_" + ch].dtype == torch.bfloat16 or Ws is not None) and x2.shape[1] % 32 == 0)
+                         (w["enc_w_" + ch].dtype == self.h16 or Ws is not None) and x2.shape[1] % 32 == 0)
                 if small and fused and (Ws is None or w.get("enc_w_" + ch + "#split3") is not None):
                     fused = False  # (concept models: the split products through the LDS-tiled kernel, below)
                 W3 = w.get("enc_w_" + ch + "#split3")
@@ -657,11 +672,11 @@ class HipEngine:
                     lin = self.ws("enc_lin" + sfx, (B * n, d))
                     if os.environ.get("CARE_ENC_TILE", "1") != "0":  # fp16 pieces of the features once, then the LDS-tiled kernel
                         a2 = self.ws("enc_a2" + sfx, (B * n, 2 * x2.shape[1]), torch.float16)
-                        call("care_split2_act", ptr(x2), x2.stride(0), ptr(a2), B * n, x2.shape[1], tag="enc_split")
-                        call("care_gemm_tile_split3", ptr(a2), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0), CARE_F32,
+                        self.call("care_split2_act", ptr(x2), x2.stride(0), ptr(a2), B * n, x2.shape[1], tag="enc_split")
+                        self.call("care_gemm_tile_split3", ptr(a2), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0), CARE_F32,
                              None, 0, 0, d, B * n, d, x2.shape[1], 0, tag="enc_gemm")
                     else:
-                        call("care_gemm_split3", ptr(x2), x2.stride(0), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
+                        self.call("care_gemm_split3", ptr(x2), x2.stride(0), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
                              B * n, d, x2.shape[1], tag="enc_gemm")
                 else:
                     lin = self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch], self.ws("enc_lin" + sfx, (B * n, d)), tag="enc_gemm")
@@ -674,7 +689,7 @@ class HipEngine:
                     dst, dstb, grp_rows, off = self.ws("enc_side_" + ch, (B, n, d)), None, n, 0
                 ln_kw = dict(grp=n, out_grp_rows=grp_rows, out_row_off=off)
                 if fused and Ws is not None:  # the same, fp32 operands as hi/lo fp16 pieces (concept models)
-                    call("care_gemm_ln_split", ptr(x2), x2.stride(0), ptr(Ws), ptr(w["enc_b_" + ch]), ptr(w["enc_g_" + ch]),
+                    self.call("care_gemm_ln_split", ptr(x2), x2.stride(0), ptr(Ws), ptr(w["enc_b_" + ch]), ptr(w["enc_g_" + ch]),
                          ptr(w["enc_be_" + ch]), self.eps, ptr(dst), ptr(dstb), dst.stride(-2), B * n, d, x2.shape[1], n,
                          grp_rows, off, tag="enc_gemm")
                 elif fused:  # Linear + bias + LayerNorm in one kernel, raw fp32 features streamed by LDS-DMA
@@ -695,7 +710,7 @@ class HipEngine:
                             h, hb = self.ws("enc_h%d" % (li + 1), (B * n, d)), self.wsb("enc_h%d" % (li + 1), (B * n, d))
                             self._ffn(nm + "_ffn", h1, h1b, h, hb, "enc_")
                 if not lean:
-                    call("care_group_mean", ptr(dst), d, grp_rows, off, n, ptr(means), means.stride(0), mi * d, B, d)
+                    self.call("care_group_mean", ptr(dst), d, grp_rows, off, n, ptr(means), means.stride(0), mi * d, B, d)
         for st in side:
             cur.wait_stream(st)
         if lean:
@@ -713,7 +728,7 @@ class HipEngine:
             scores = self.gemm(pm, w["attr_w"], w["attr_b"], self.ws("attr_scores", (B, kp)))
             preds = new("preds", (B, kp))
             avg = new("avg", (B,))
-            call("care_concept_finish", ptr(scores), kp, ptr(preds), kp, ptr(avg), B, self.k_attr)
+            self.call("care_concept_finish", ptr(scores), kp, ptr(preds), kp, ptr(avg), B, self.k_attr)
             out["preds_attr"] = preds[:, : self.k_attr]
             out["avg_prob_attr"] = avg
             if self.has_container:
@@ -722,7 +737,7 @@ class HipEngine:
                     dst, dstb, grp_rows, off = mem, memb, self.Lk, self.concept_off
                 else:
                     dst, dstb, grp_rows, off = new("sem_embs", (B, self.topk, d)), None, self.topk, 0
-                call("care_concept_topk_embed", ptr(preds), kp, self.k_attr, self.topk, ptr(w["attr_word"]),
+                self.call("care_concept_topk_embed", ptr(preds), kp, self.k_attr, self.topk, ptr(w["attr_word"]),
                      ptr(w["attr_pos"]), ptr(w["attr_g"]), ptr(w["attr_be"]), self.eps, ptr(labels), ptr(dst),
                      ptr(dstb), d, grp_rows, off, B, d)
                 out["semantic_labels"] = labels
@@ -759,7 +774,7 @@ class HipEngine:
             nm = "d{}_ca".format(li)
             kv = self.ws("{}{}".format(tag, li), (B * Lk, 2 * d), self.wt)
             out.append(self.gemm(src2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv, tag="cross_kv_gemm",
-                                 tile=resident and src2.dtype == torch.bfloat16 and B * Lk >= self.RESIDENT_CKV_TILE_ROWS))
+                                 tile=resident and src2.dtype == self.h16 and B * Lk >= self.RESIDENT_CKV_TILE_ROWS))
         return out
 
     LATENT_MIN_ROWS = 1
@@ -788,11 +803,11 @@ class HipEngine:
         if not self.latent_for(rows):
             return self.cross_kv(mem)
         mem = mem.contiguous()
-        if mem.dtype == torch.bfloat16:  # lean encode: the bf16 memory is all there is
+        if mem.dtype == self.h16:  # lean encode: the bf16 memory is all there is
             return (mem,) * self.n_layers
         ref, memb = getattr(self, "_mem_mirror", (None, None))
         if not (memb is not None and ref is not None and ref() is mem):
-            memb = self.ws("lat_mem", tuple(mem.shape), torch.bfloat16)
+            memb = self.ws("lat_mem", tuple(mem.shape), self.h16)
             memb.copy_(mem)
         return (memb,) * self.n_layers
 
@@ -803,7 +818,7 @@ class HipEngine:
         B, n, d = sem_embs.shape
         src = sem_embs.to(self.device, torch.float32).contiguous().view(B * n, d)
         if self.bf_act:  # the bf16 kernels want a bf16 operand
-            srcb = self.ws(tag + "_srcb", (B * n, d), torch.bfloat16)
+            srcb = self.ws(tag + "_srcb", (B * n, d), self.h16)
             srcb.copy_(src)
             src = srcb
         out = []
@@ -854,12 +869,12 @@ class HipEngine:
         (bf16 GEMM inputs, fp32 residual stream and statistics)."""
         w, d, H = self.w, self.d, self.H
         rows = N * t
-        bfw = lambda name, shape: self.ws(name, shape, torch.bfloat16)
+        bfw = lambda name, shape: self.ws(name, shape, self.h16)
         ctx = bfw("tf_ctxb", (rows, d))
         for li in range(self.n_layers):
             nm = "d{}_sa".format(li)
             qkv = self.gemm(xb, w[nm + "_qkv_w"], w[nm + "_qkv_b"], bfw("tf_qkvb", (rows, 3 * d)), tag="tf_qkv_gemm")
-            call("care_attention_seq", ptr(qkv), 3 * d, ptr(qkv[:, d:]), ptr(qkv[:, 2 * d:]), t * 3 * d, 3 * d, 1, t, 1, t,
+            self.call("care_attention_seq", ptr(qkv), 3 * d, ptr(qkv[:, d:]), ptr(qkv[:, 2 * d:]), t * 3 * d, 3 * d, 1, t, 1, t,
                  ptr(ids32), t, PAD, None, 0, ptr(ctx), d, N, H, tag="tf_self_attn")
             x1, x1b = self.ws("tf_x1", (rows, d)), self.wsb("tf_x1", (rows, d))
             self._dense_ln(ctx, nm, x, x1, x1b, rows, "tf_dxd")
@@ -867,7 +882,7 @@ class HipEngine:
             hb = w["d{}_hb".format(li)]
             q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm")
             kv = ckv[li]
-            call("care_attention_seq", ptr(q2), d, ptr(kv), ptr(kv[:, d:]), Lk * 2 * d, 2 * d, per_clip, Lk, 0, t,
+            self.call("care_attention_seq", ptr(q2), d, ptr(kv), ptr(kv[:, d:]), Lk * 2 * d, 2 * d, per_clip, Lk, 0, t,
                  None, 0, PAD, ptr(hb), hb.stride(0) if hb is not None else 0, ptr(ctx), d, N, H, tag="tf_cross_attn")
             x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
             self._dense_ln(ctx, nm, x1, x2, x2b, rows, "tf_dxd")
@@ -875,7 +890,7 @@ class HipEngine:
                 nm = "d{}_aa".format(li)
                 q3 = self.gemm(x2b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm")
                 kv = akv[li]
-                call("care_attention_seq", ptr(q3), d, ptr(kv), ptr(kv[:, d:]), self.topk * 2 * d, 2 * d, per_clip,
+                self.call("care_attention_seq", ptr(q3), d, ptr(kv), ptr(kv[:, d:]), self.topk * 2 * d, 2 * d, per_clip,
                      self.topk, 0, t, None, 0, PAD, None, 0, ptr(ctx), d, N, H, tag="tf_attr_attn")
                 y, yb = self.ws("tf_x2a", (rows, d)), self.wsb("tf_x2a", (rows, d))
                 self._dense_ln(ctx, nm, x2, y, yb, rows, "tf_dxd")
@@ -909,7 +924,7 @@ class HipEngine:
         w, d = self.w, self.d
         N, t = input_ids.shape
         # a lean encode hands over the bf16 memory alone (metrics_step): it is the cross-K/V GEMM's operand as it stands
-        mem = mem.to(self.device) if (mem.dtype == torch.bfloat16 and self.bf_act) else mem.to(self.device, torch.float32)
+        mem = mem.to(self.device) if (mem.dtype == self.h16 and self.bf_act) else mem.to(self.device, torch.float32)
         B, Lk = mem.shape[0], mem.shape[1]
         assert N % B == 0 and t <= self.T + 1
         per_clip = N // B
@@ -921,7 +936,7 @@ class HipEngine:
             assert sem.shape[0] in (B, N)
             sem_div = t * (per_clip if sem.shape[0] == B else 1)
         x, xb = self.ws("tf_x0", (rows, d)), self.wsb("tf_x0", (rows, d))
-        call("care_embed_ln", ptr(ids32), t, 0, None, 0, ptr(w["word"]), ptr(w["pos"]), 0, ptr(sem), sem_div,
+        self.call("care_embed_ln", ptr(ids32), t, 0, None, 0, ptr(w["word"]), ptr(w["pos"]), 0, ptr(sem), sem_div,
              ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(x), ptr(xb), d, rows, t, d, tag="tf_embed")
         ckv = self.cross_kv(mem, tag="tf_ckv")
         if self.attr_att and sem_embs is None:
@@ -1005,13 +1020,13 @@ class HipEngine:
             # without label bookkeeping - from 8192 rows the 256-row panels of csrc/gemm_vocab.hip
             pl = self.ws("sc_lab", (rows,))
             self.vocab_argmax(None, xb, rows, pm, pi, ps, tag="tf_vocab_score")
-            call("care_label_logits", ptr(xb), xb.stride(0), ptr(self.w["vocab"]), ptr(lab32), ptr(pl), rows, self.V, self.d,
+            self.call("care_label_logits", ptr(xb), xb.stride(0), ptr(self.w["vocab"]), ptr(lab32), ptr(pl), rows, self.V, self.d,
                  tag="tf_label_logits")
-            call("care_score_partials_lab", ptr(pm), ptr(pi), ptr(ps), parts, ptr(pl), ptr(logp), ptr(pred), rows)
+            self.call("care_score_partials_lab", ptr(pm), ptr(pi), ptr(ps), parts, ptr(pl), ptr(logp), ptr(pred), rows)
         else:
             out = self.decode_full(input_ids, mem, sem, want_logits="all", sem_embs=sem_embs)
             lg = out["logits"].view(rows, self.V)
-            call("care_score_logits", ptr(lg), lg.stride(0), self.V, ptr(lab32), ptr(logp), ptr(pred), rows)
+            self.call("care_score_logits", ptr(lg), lg.stride(0), self.V, ptr(lab32), ptr(logp), ptr(pred), rows)
         return logp.view(N, t), pred.view(N, t)
 
     def metrics_step(self, feats: List[torch.Tensor], input_ids: torch.Tensor, labels: torch.Tensor):
@@ -1033,7 +1048,7 @@ class HipEngine:
         w, d, T = self.w, self.d, self.T
         x, xb = self.ws(tag + "x0", (N, d)), self.wsb(tag + "x0", (N, d))
         if not embedded:
-            call("care_embed_ln", ptr(tok), tok.stride(0), t - 1, ptr(anc), anc.stride(0) if anc is not None else 0,
+            self.call("care_embed_ln", ptr(tok), tok.stride(0), t - 1, ptr(anc), anc.stride(0) if anc is not None else 0,
                  ptr(w["word"]), ptr(w["pos"]), t - 1, ptr(sem), rows_per_clip, ptr(w["emb_g"]), ptr(w["emb_be"]),
                  self.eps, ptr(x), ptr(xb), d, N, 1, d)
         g = lambda f32, b16: b16 if b16 is not None else f32  # GEMM input: the bf16 mirror when it exists
@@ -1061,23 +1076,23 @@ class HipEngine:
                 # d x d with a bf16 output at >= 8192 rows: the LDS-tiled kernel (*measured* in situ, 32768 rows: 25.3 against
                 # 32-34 us on the A-stationary one, which wins the wider QKV / FFN1 products; decided by the pass's INITIAL
                 # row count like every other choice of form)
-                q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2b", (N, d), torch.bfloat16),
+                q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2b", (N, d), self.h16),
                                tag="step_dxd_gemm", tile=d == 512 and (self._form_rows or N) >= self.Q_TILE_MIN_ROWS)
-                qt = self.ws(tag + "qt", (N, H * d), torch.bfloat16)
+                qt = self.ws(tag + "qt", (N, H * d), self.h16)
                 if d == 512:
-                    call("care_head_expand", ptr(q2), d, ptr(w[nm + "_wkt"]), ptr(qt), H * d, N, H, tag="step_head_expand")
+                    self.call("care_head_expand", ptr(q2), d, ptr(w[nm + "_wkt"]), ptr(qt), H * d, N, H, tag="step_head_expand")
                 else:  # one batched launch: head h multiplies q[:, 64 h : 64 h + 64] by wkt[h] [d, 64]
-                    call("care_gemm_tile_batched", ptr(q2), d, 64, ptr(w[nm + "_wkt"]), 64, d * 64, None, 0, ptr(qt), H * d, d,
+                    self.call("care_gemm_tile_batched", ptr(q2), d, 64, ptr(w[nm + "_wkt"]), 64, d * 64, None, 0, ptr(qt), H * d, d,
                          CARE_BF16, H, N, d, 64, tag="step_head_expand")
-                ct = self.ws(tag + "ct", (N, H * d), torch.bfloat16)
-                call("care_attention_latent", ptr(qt), H * d, ptr(ckv[li]), Lk * d, d, rows_per_clip, Lk, ptr(hb),
+                ct = self.ws(tag + "ct", (N, H * d), self.h16)
+                self.call("care_attention_latent", ptr(qt), H * d, ptr(ckv[li]), Lk * d, d, rows_per_clip, Lk, ptr(hb),
                      hb.stride(0) if hb is not None else 0, ptr(ct), H * d, N, H, d, tag="step_cross_attn")
                 ctx = self._ctx(tag, N)
                 if d == 512:
-                    call("care_head_reduce", ptr(ct), H * d, ptr(w[nm + "_v_w"]), ptr(w[nm + "_v_b"]), ptr(ctx), d, N, H,
+                    self.call("care_head_reduce", ptr(ct), H * d, ptr(w[nm + "_v_w"]), ptr(w[nm + "_v_b"]), ptr(ctx), d, N, H,
                          tag="step_head_reduce")
                 else:  # head h: ctx[:, 64 h : 64 h + 64] = ct[:, h] W_v[64 h : 64 h + 64, :]^T + b_v
-                    call("care_gemm_tile_batched", ptr(ct), H * d, d, ptr(w[nm + "_v_w"]), d, 64 * d, ptr(w[nm + "_v_b"]), 64,
+                    self.call("care_gemm_tile_batched", ptr(ct), H * d, d, ptr(w[nm + "_v_w"]), d, 64 * d, ptr(w[nm + "_v_b"]), 64,
                          ptr(ctx), d, 64, CARE_BF16, H, N, 64, d, tag="step_head_reduce")
             else:
                 q2 = self.gemm(g(x1, x1b), w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)),
@@ -1115,7 +1130,7 @@ class HipEngine:
         B, Lk, d = mem.shape
         T = self.T
         steps = T if steps is None else steps
-        mem = mem.to(self.device, mem.dtype if mem.dtype == torch.bfloat16 else torch.float32)  # bf16: lean encode
+        mem = mem.to(self.device, mem.dtype if mem.dtype == self.h16 else torch.float32)  # bf16: lean encode
         sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
         fed = self.ws("g_fed", (B, T + 1), torch.int32)
         score = self.ws("g_score", (B,))
@@ -1135,11 +1150,11 @@ class HipEngine:
             x, xb = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_", akv=akv, embedded=t > 1)
             self.vocab_argmax(x, xb, B, pmax, pidx, psum)
             if t < steps:  # the token choice and, in the same launch, its embedding = the input of step t + 1
-                call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
+                self.call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
                      ptr(length), ptr(fin), t, T, EOS, B, ptr(self.w["word"]), ptr(self.w["pos"]), ptr(sem), 1,
                      ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps, ptr(x0), ptr(x0b), d, d, tag="step_update_embed")
             else:
-                call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
+                self.call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
                      ptr(length), ptr(fin), t, T, EOS, B)
         return fed, length, score
 
@@ -1162,7 +1177,7 @@ class HipEngine:
     def _resident_model_ok(self, beam: bool = False) -> bool:
         """Every model-side limit care_decode_resident / care_decode_resident_beam enforce (CARE_ESHAPE otherwise):
         bf16 mode; d_model 512 (ff 512 / 1024 / 2048), or - greedy only - d_model 768 / 1024 with ff = 4 d_model."""
-        if not (self.bf and self.wt == torch.bfloat16 and self.T <= 128 and self.n_layers <= 4 and
+        if not (self.bf and self.wt == self.h16 and self.T <= 128 and self.n_layers <= 4 and
                 (not self.attr_att or self.topk <= 128) and self.V <= self.RESIDENT_MAX_V and self.Lk <= 128):
             return False
         if self.d == 512:
@@ -1203,7 +1218,7 @@ class HipEngine:
             L, sa, ffn = layers[li], "d{}_sa".format(li), "d{}_ffn".format(li)
             L.qkv_w, L.qkv_b, L.o_w, L.o_b = ptr(w[sa + "_qkv_w"]), ptr(w[sa + "_qkv_b"]), ptr(w[sa + "_o_w"]), ptr(w[sa + "_o_b"])
             L.ln_g, L.ln_b = ptr(w[sa + "_g"]), ptr(w[sa + "_be"])
-            L.self_kv = ptr(self.ws(tag + "skv%d" % li, (rows, T, 2 * d), torch.bfloat16))
+            L.self_kv = ptr(self.ws(tag + "skv%d" % li, (rows, T, 2 * d), self.h16))
             blocks = [("d{}_ca".format(li), ckv[li], Lk, w["d{}_hb".format(li)])]
             if self.attr_att:
                 blocks.append(("d{}_aa".format(li), akv[li], self.topk, None))
@@ -1235,9 +1250,9 @@ class HipEngine:
         fscore, flen = self.ws("rb_fscore", (B, cap)), self.ws("rb_flen", (B, cap), torch.int32)
         fhyp = self.ws("rb_fhyp", (B, cap, T + 1), torch.int32)
         layers = self._resident_layers("rb_", N, bm, ckv, akv, Lk)
-        nbytes = _lib.load().care_decode_resident_beam_scratch(B, bm, d, self.ff, self.V)
+        nbytes = self.lib.care_decode_resident_beam_scratch(B, bm, d, self.ff, self.V)
         scratch = self.ws("rb_scratch", (nbytes,), torch.uint8)
-        call("care_decode_resident_beam", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem),
+        self.call("care_decode_resident_beam", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem),
              ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(w["vocab"]), self.V, d, self.H, self.ff, self.act, B, bm, need, T, T,
              BOS, EOS, PAD, ptr(tok), T + 1, ptr(anc[0]), ptr(anc[1]), ptr(scores), ptr(done), ptr(nfin), ptr(fscore), ptr(flen),
              ptr(fhyp), cap, ptr(scratch), nbytes, int(bool(early_exit)), int(os.environ.get("CARE_RESIDENT_BLOCKS", "0")),
@@ -1261,9 +1276,9 @@ class HipEngine:
         fed = self.ws("r_fed", (B, T + 1), torch.int32)
         score, length, fin = self.ws("r_score", (B,)), self.ws("r_len", (B,), torch.int32), self.ws("r_fin", (B,), torch.int32)
         layers = self._resident_layers("r_", B, 1, ckv, akv, Lk)
-        nbytes = _lib.load().care_decode_resident_scratch(B, d, self.ff, self.V)
+        nbytes = self.lib.care_decode_resident_scratch(B, d, self.ff, self.V)
         scratch = self.ws("r_scratch", (nbytes,), torch.uint8)
-        call("care_decode_resident", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem), 1,
+        self.call("care_decode_resident", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem), 1,
              ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(w["vocab"]), self.V, d, self.H, self.ff, self.act, B, T, steps,
              BOS, EOS, PAD, ptr(fed), T + 1, ptr(score), ptr(length), ptr(fin), ptr(scratch), nbytes,
              int(bool(early_exit)), int(os.environ.get("CARE_RESIDENT_BLOCKS", "0")), tag="decode_resident")
@@ -1274,7 +1289,7 @@ class HipEngine:
     def _call_rows(self, fn, src, dst, idx, n):
         """care_gather_rows / care_scatter_rows on tensors whose first dim is the row."""
         rb = src[0].numel() * src.element_size()
-        call(fn, ptr(src), src.stride(0) * src.element_size(), ptr(dst), dst.stride(0) * dst.element_size(), ptr(idx), n, rb)
+        self.call(fn, ptr(src), src.stride(0) * src.element_size(), ptr(dst), dst.stride(0) * dst.element_size(), ptr(idx), n, rb)
 
     def _slot_bucket(self, active: int, cap: int) -> int:
         """Row count a compacted decode runs on: `active` rounded up to a granule of cap / 32 (>= 64), so
@@ -1335,14 +1350,14 @@ class HipEngine:
                                           akv=v["akv"], embedded=t > 1)
                 self.vocab_argmax(x, xb, n, pmax, pidx, psum)
                 if t < T:
-                    call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
+                    self.call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
                          ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n, ptr(self.w["word"]),
                          ptr(self.w["pos"]), ptr(v["sem"]), 1, ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps,
                          ptr(v["x0"]), ptr(v["x0b"]), d, d, tag="step_update_embed")
                 else:
-                    call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
+                    self.call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
                          ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n)
-            call("care_active_slots", ptr(v["fin"]), n, ptr(idx), ptr(cnt))
+            self.call("care_active_slots", ptr(v["fin"]), n, ptr(idx), ptr(cnt))
 
         def first_segment():
             """encode, state initialisation and steps 1 .. S on all B slots of buffer set 0."""
@@ -1478,7 +1493,7 @@ class HipEngine:
                                                            sem_embs=enc.get("semantic_embs"), early_exit=ee))
             key = ("gres", bool(lean), bool(ee), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
             out = self._replay(key, run_resident, use_graph)
-            nb = _lib.load().care_decode_resident_scratch(feats[0].shape[0], self.d, self.ff, self.V)
+            nb = self.lib.care_decode_resident_scratch(feats[0].shape[0], self.d, self.ff, self.V)
             self.last_decode = dict(clips=feats[0].shape[0], steps=self.ws("r_scratch", (nb,), torch.uint8)[8:12].view(torch.int32)[0],
                                     compactions=0, resident=True)
             return out
@@ -1557,7 +1572,7 @@ class HipEngine:
         cval, cidx = self.ws(tag + "cval", (N, bm)), self.ws(tag + "cidx", (N, bm), torch.int32)
         fused_sel = self.beam_fused_for(B * bm)  # one form for the whole pass, whatever the compaction leaves
         if fused_sel:
-            s_parts = _lib.load().care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
+            s_parts = self.lib.care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
             s_cap = 64
             s_pmax, s_psum = self.ws(tag + "spmax", (N, s_parts)), self.ws(tag + "spsum", (N, s_parts))
             s_pidx = self.ws(tag + "spidx", (N, s_parts), torch.int32)
@@ -1573,19 +1588,19 @@ class HipEngine:
             if fused_sel:
                 if sparse is not None:
                     # second pass only over the (tile, row) products whose tile maximum reaches the row's threshold
-                    call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                    self.call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
                          ptr(s_pidx), ptr(s_psum), ptr(sparse[0]), N, self.V, d, 8, tag="beam_vocab_stats")
-                    call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                    call("care_beam_sparse_collect", ptr(xb), d, ptr(self.w["vocab"]), ptr(sparse[0]), ptr(s_thr),
+                    self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
+                    self.call("care_beam_sparse_collect", ptr(xb), d, ptr(self.w["vocab"]), ptr(sparse[0]), ptr(s_thr),
                          ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap, ptr(sparse[1]), ptr(sparse[2]), N, self.V, d,
                          tag="beam_vocab_collect")
                 else:
-                    call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                    self.call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
                          ptr(s_pidx), ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
-                    call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                    call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
+                    self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
+                    self.call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
                          ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
-                call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
+                self.call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
                      bm, ptr(xb), d, _code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
             else:
                 src = xb if xb is not None else x
@@ -1593,12 +1608,12 @@ class HipEngine:
                 for lo in range(0, N, chunk):
                     hi = min(N, lo + chunk)
                     self.gemm(src[lo:hi], self.w["vocab"], None, logits[lo:hi], tag="step_vocab_logits")
-                    call("care_beam_select", ptr(logits[lo:hi]), logits.stride(0), self.V, bm, ptr(cval[lo:hi]),
+                    self.call("care_beam_select", ptr(logits[lo:hi]), logits.stride(0), self.V, bm, ptr(cval[lo:hi]),
                          ptr(cidx[lo:hi]), hi - lo, 4 if self._small_pass else 1, tag="step_beam_select")
-            call("care_beam_advance", ptr(cval), ptr(cidx), ptr(v["scores"]), bm, ptr(v["tok"]), ptr(a_old), ptr(a_new),
+            self.call("care_beam_advance", ptr(cval), ptr(cidx), ptr(v["scores"]), bm, ptr(v["tok"]), ptr(a_old), ptr(a_new),
                  ptr(v["done"]), ptr(v["nfin"]), cap, ptr(v["fscore"]), ptr(v["flen"]), ptr(v["fhyp"]), t, T, need, EOS,
                  self.V, T + 1, n)
-        call("care_active_slots", ptr(v["done"]), n, ptr(v["idx"]), ptr(v["cnt"]))
+        self.call("care_active_slots", ptr(v["done"]), n, ptr(v["idx"]), ptr(v["cnt"]))
 
     def beam_early_exit(self, feats: List[torch.Tensor], bm: int, need: int, lean: bool = False, use_graph: bool = True):
         """encode + beam search that stops when every clip is done and drops finished clips between
@@ -1693,7 +1708,7 @@ class HipEngine:
         self._ws_cap = [(m, B), (M, B * bm), (n, B), (N, B * bm)]
         tag = w["tag"]
         idx_r = self.ws(tag + "idx_r", (M,), torch.int32)
-        call("care_expand_index", ptr(idx), m, bm, ptr(idx_r))
+        self.call("care_expand_index", ptr(idx), m, bm, ptr(idx_r))
         cmap = self.ws(tag + "cmap", (n,), torch.int32)
         cmap.zero_()  # clips that are dropped map to clip 0: nothing references their rows any more
         self._call_rows("care_scatter_rows", self._arange(m).view(m, 1), cmap.view(n, 1), idx, m)
@@ -1706,7 +1721,7 @@ class HipEngine:
         self._call_rows("care_gather_rows", v["scores"].view(N, 1), w["scores"].view(M, 1), idx_r, M)
         for a, b in zip(v["anc"], w["anc"]):
             self._call_rows("care_gather_rows", a, b, idx_r, M)
-            call("care_remap_rows", ptr(b), b.numel(), ptr(cmap), bm)
+            self.call("care_remap_rows", ptr(b), b.numel(), ptr(cmap), bm)
         for a, b in zip(v["skv"], w["skv"]):
             self._call_rows("care_gather_rows", a, b, idx_r, M)
 
@@ -1745,7 +1760,7 @@ class HipEngine:
                                                          sem_embs=enc.get("semantic_embs"), early_exit=ee))
             key = ("bres", bm, need, bool(lean), bool(ee), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
             out = self._replay(key, run_resident, use_graph)
-            nb = _lib.load().care_decode_resident_beam_scratch(feats[0].shape[0], bm, self.d, self.ff, self.V)
+            nb = self.lib.care_decode_resident_beam_scratch(feats[0].shape[0], bm, self.d, self.ff, self.V)
             self.last_decode = dict(clips=feats[0].shape[0], steps=self.ws("rb_scratch", (nb,), torch.uint8)[8:12].view(torch.int32)[0],
                                     compactions=0, resident=True, row_steps=None)
             return out
@@ -1766,7 +1781,7 @@ class HipEngine:
         """Beam search of B clips x bm beams, state on the device (csrc/beam.hip)."""
         B, Lk, d = mem.shape
         T, N = self.T, mem.shape[0] * bm
-        mem = mem.to(self.device, mem.dtype if mem.dtype == torch.bfloat16 else torch.float32)  # bf16: lean encode
+        mem = mem.to(self.device, mem.dtype if mem.dtype == self.h16 else torch.float32)  # bf16: lean encode
         sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
         cap = need + bm
         tok = self.ws("b_tok", (N, T + 1), torch.int32)
@@ -1786,7 +1801,7 @@ class HipEngine:
         vpad = (self.V + 63) // 64 * 64  # 16-byte aligned row stride -> the GEMM's vector store path
         fused_sel = self.beam_fused_for(B * bm)
         if fused_sel:
-            s_parts = _lib.load().care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
+            s_parts = self.lib.care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
             s_cap = 64
             s_pmax, s_psum = self.ws("b_spmax", (N, s_parts)), self.ws("b_spsum", (N, s_parts))
             s_pidx = self.ws("b_spidx", (N, s_parts), torch.int32)
@@ -1806,21 +1821,21 @@ class HipEngine:
                 # fused selection (csrc/beam.hip): statistics GEMM -> threshold -> candidate pass -> pick;
                 # the [N, V] logits never exist
                 if sparse is not None:
-                    call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                    self.call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
                          ptr(s_pidx), ptr(s_psum), ptr(sparse[0]), N, self.V, d, 8, tag="beam_vocab_stats")
-                    call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                    call("care_beam_sparse_collect", ptr(xb), d, ptr(self.w["vocab"]), ptr(sparse[0]), ptr(s_thr),
+                    self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
+                    self.call("care_beam_sparse_collect", ptr(xb), d, ptr(self.w["vocab"]), ptr(sparse[0]), ptr(s_thr),
                          ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap, ptr(sparse[1]), ptr(sparse[2]), N, self.V, d,
                          tag="beam_vocab_collect")
                 else:
-                    call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                    self.call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
                          ptr(s_pidx), ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
-                    call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                    call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
+                    self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
+                    self.call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
                          ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
-                call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
+                self.call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
                      bm, ptr(xb), d, _code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
-                call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
+                self.call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
                      ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
                 continue
             # vocabulary logits -> per-row top-bm, in row chunks whose logits (chunk x vpad x 4 B) stay
@@ -1832,8 +1847,8 @@ class HipEngine:
             for lo in range(0, N, chunk):
                 hi = min(N, lo + chunk)
                 self.gemm(src[lo:hi], self.w["vocab"], None, logits[lo:hi])
-                call("care_beam_select", ptr(logits[lo:hi]), logits.stride(0), self.V, bm, ptr(cval[lo:hi]),
+                self.call("care_beam_select", ptr(logits[lo:hi]), logits.stride(0), self.V, bm, ptr(cval[lo:hi]),
                      ptr(cidx[lo:hi]), hi - lo, 4 if self._small_pass else 1)
-            call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
+            self.call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
                  ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
         return nfin, fscore, flen, fhyp

@@ -291,9 +291,11 @@ class TransformerSeq2Seq(nn.Module):
 
     # -- engine management
     def set_compute_dtype(self, dtype: str) -> "TransformerSeq2Seq":
-        """'fp32' (exact f32 MFMA, parity mode), 'bf16' (bf16 MFMA, fp32 accumulation: throughput mode) or 'fp16x3'
-        (fp32 storage, every GEMM as three fp16 MFMA passes over hi/lo pieces: fp32-grade results at about twice
-        fp32 mode's rate - the mode that meets the reference's tolerances without the exact-f32 MFMA)."""
+        """'fp32' (exact f32 MFMA, parity mode), 'bf16' (bf16 MFMA, fp32 accumulation: throughput mode), 'fp16' (the same
+        kernels compiled for IEEE half, libcare_hip_f16.so: bf16's bytes and MFMA rate with 11 significand bits instead
+        of 8 - the 16-bit mode nearest the reference) or 'fp16x3' (fp32 storage, every GEMM as three fp16 MFMA passes
+        over hi/lo pieces: fp32-grade results at about twice fp32 mode's rate - the mode that meets the reference's
+        fp32 tolerances without the exact-f32 MFMA)."""
         if dtype != self._compute_dtype:
             self._compute_dtype = dtype
             self._engine = None

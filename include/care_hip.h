@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 19
+#define CARE_ABI_VERSION 20
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -45,6 +45,20 @@ int care_version(void);
 
 /* Name of the code-object architecture the library was built for ("gfx950"). */
 const char* care_arch(void);
+
+/*
+ * What the library was built from (care_amd/build.py; csrc/version.hip):
+ *   care_source_hash: 32 hex digits of the SHA-256 over csrc/ (.hip and .h), this header and the compile flags - the host
+ *     side (care_amd/_lib.py) compares it with the hash of the tree it runs from and rebuilds or refuses a stale library;
+ *   care_build_flags: the extra compile flags of the build ("" for the default library, "-DCARE_H16_FP16" for the fp16 one);
+ *   care_h16: the 16-bit storage / MFMA operand type the kernels were compiled for, "bf16" (libcare_hip.so) or "fp16"
+ *     (libcare_hip_f16.so).  Wherever this header says CARE_BF16 / "bf16" for a storage type it means THAT type: the two
+ *     libraries are one source, and the fp16 one is the compute mode `fp16` (11 significand bits at bf16's bytes and MFMA
+ *     rate).  Nothing else differs between them.
+ */
+const char* care_source_hash(void);
+const char* care_build_flags(void);
+const char* care_h16(void);
 
 /*
  * care_gemm:  C = act(A * W^T + bias), optionally split over two destinations.
@@ -616,6 +630,17 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
                          int32_t* finished, void* scratch, int64_t scratch_bytes, int early_exit, int blocks, void* stream);
 
 void care_decode_resident_debug(int prof_step, int ghost);
+
+/*
+ * The hand-off between the phases of a resident launch (care_decode_resident, care_decode_resident_beam): by default
+ * (mode -1) fence-free - sc1 write-through stores, a drained vmcnt, one relaxed atomic add; sc1 polls and loads - on the
+ * configuration that form was validated on (a gfx950 device with all 256 CUs in one partition), and with an agent-scope
+ * release before the add / acquire after the poll on any other device or partition mode (+ 1 .. 4 us per hand-off).
+ * care_resident_set_fenced(1 / 0) forces one form for the process (also CARE_RESIDENT_FENCED in the environment, read
+ * once); care_resident_fenced() = the form a launch on the current device would take.
+ */
+void care_resident_set_fenced(int mode);
+int care_resident_fenced(void);
 
 /*
  * care_decode_resident_beam: BEAM SEARCH over a small batch (clips x beam <= a few hundred rows) as ONE launch.

@@ -92,21 +92,48 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
 
 
+def test_library_is_bound_to_its_sources(tmp_path, monkeypatch):
+    """The hash of csrc/ + include/care_hip.h + flags is compiled into the library; a library from other sources is
+    detected without being loaded, and _lib refuses it when it cannot rebuild."""
+    from care_amd import _lib, build
+
+    build.build_all()
+    for variant in build.VARIANTS:
+        assert not build.needs_build(variant)
+        assert build.embedded_hash(build.lib_path(variant)) == build.source_hash(variant)
+        assert _lib.load(variant=variant).care_source_hash().decode() == build.source_hash(variant)
+    assert build.source_hash("") != build.source_hash("f16")                  # the flags are part of the hash
+    assert build.source_hash("", ("-DRES_NOINLINE",)) != build.source_hash("")  # ... a tool build's too
+    # a stale library: same file, other tree hash
+    monkeypatch.setattr(build, "source_hash", lambda variant="", flags_extra=(): "0" * 32)
+    assert build.needs_build("") and build.needs_build("f16")
+    monkeypatch.setenv("CARE_NO_REBUILD", "1")
+    with pytest.raises(_lib.CareHipError, match="built from other sources"):
+        _lib._ensure_current("", build.lib_path(""))
+    # a file that is no library of this build system carries no hash
+    junk = tmp_path / "libjunk.so"
+    junk.write_bytes(b"\x7fELF" + b"\0" * 64)
+    assert build.embedded_hash(str(junk)) is None
+
+
 def test_abi_library_exports_every_declared_symbol():
     """The .so loads and exports exactly the entry points include/care_hip.h declares."""
     import ctypes
 
     from care_amd import _lib, build
 
-    build.build()
+    build.build_all()
     header = open(os.path.join(ROOT, "include", "care_hip.h")).read()
     declared = set(re.findall(r"^(?:int|int64_t|void|const char\*)\s+(care_\w+)\s*\(", header, re.M))
     assert len(declared) >= 18
-    lib = ctypes.CDLL(_lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(lib, name), name
+    for variant in build.VARIANTS:  # the bf16 and the fp16 library: one source, one ABI
+        lib = ctypes.CDLL(build.lib_path(variant))
+        for name in declared:
+            assert hasattr(lib, name), (variant, name)
     assert declared == set(_lib.exported_symbols())
     loaded = _lib.load()
+    assert loaded.care_h16() == b"bf16" and _lib.load(variant="f16").care_h16() == b"fp16"
+    assert _lib.load(variant="f16").care_build_flags() == b"-DCARE_H16_FP16" and loaded.care_build_flags() == b""
     # the two structs of care_decode_resident: ctypes mirrors against the C compiler's layout of the header
     import subprocess
     import tempfile
