@@ -73,6 +73,8 @@ SIGNATURES = {
                              _P, _L, _I, _I, _P],
     "care_decode_resident_beam": [_P, _I, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I,
                                   _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _P],
+    "care_decode_chain_beam": [_P, _I, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I,
+                               _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P],
     "care_gemm_kn": [_P, _L, _I, _P, _L, _P, _L, _I, _I, _I, _P],
     "care_gemm_kn_splitk": [_P, _L, _I, _P, _L, _P, _L, _L, _I, _I, _I, _I, _P],
     "care_ln_bwd": [_P, _L, _P, _L, _P, _P, _L, _F, _P, _L, _P, _P, _I, _I, _P],
@@ -100,6 +102,7 @@ PLAIN = {"care_version": (c_int, []), "care_arch": (c_char_p, []), "care_source_
          "care_beam_sparse_applies": (c_int, [c_int, c_int, c_int, c_int]),
          "care_decode_resident_scratch": (c_int64, [c_int, c_int, c_int, c_int]),
          "care_decode_resident_beam_scratch": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+         "care_decode_chain_beam_scratch": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
          "care_decode_resident_debug": (None, [c_int, c_int]),
          "care_resident_set_fenced": (None, [c_int]), "care_resident_fenced": (c_int, []),
          "care_gemm_kn_splits": (c_int, [c_int, c_int, c_int])}

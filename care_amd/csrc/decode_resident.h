@@ -53,6 +53,18 @@ struct RArgs {
 // barrier with __threadfence() on either side costs 17 us (one thread fences) to 39 us (every wave does), the
 // counters alone 3.7 us, two-level counters 1.9 us.  Weights, embeddings and the cross K/V (written before the
 // launch) use plain loads and stay in the L2s for all T steps.
+// RES_PLAIN_IO (decode_chain.hip: the same phases as KERNELS of their own, one launch per phase): nothing is handed over
+// inside a launch there, so every accessor below is a plain load / store (kernel boundaries order them) and GridSync is empty.
+#ifdef RES_PLAIN_IO
+#define RES_SC1 ""
+__device__ __forceinline__ unsigned long long cld8(const void* p) { return *reinterpret_cast<const unsigned long long*>(p); }
+__device__ __forceinline__ void cst8(void* p, unsigned long long v) { *reinterpret_cast<unsigned long long*>(p) = v; }
+__device__ __forceinline__ float cld_f(const float* p) { return *p; }
+__device__ __forceinline__ int cld_i(const int32_t* p) { return *p; }
+__device__ __forceinline__ void cst_f(float* p, float v) { *p = v; }
+__device__ __forceinline__ void cst_i(int32_t* p, int v) { *p = v; }
+#else
+#define RES_SC1 " sc1"
 __device__ __forceinline__ unsigned long long cld8(const void* p) {
   return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -63,17 +75,24 @@ __device__ __forceinline__ float cld_f(const float* p) { return __hip_atomic_loa
 __device__ __forceinline__ int cld_i(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void cst_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void cst_i(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 struct U2 { unsigned long long a, b; };
 __device__ __forceinline__ float4 cld_f4(const float* p) {
+#ifdef RES_PLAIN_IO
+  return *reinterpret_cast<const float4*>(p);
+#else
   U2 u{cld8(p), cld8(p + 2)};
   return __builtin_bit_cast(float4, u);
+#endif
 }
 // 16-byte write-through stores: ONE global_store_dwordx4 sc1 (an 8-byte agent-scope atomic store is the widest the
 // compiler spells; two of them per 16 bytes are twice the instructions and, per MI355X_MICROARCH.md, 2.7 x the time per
 // byte).  Inline asm: the compiler does not count it in its vmcnt bookkeeping - its own waits then wait for more, never
 // for less (vmcnt retires in order) - and GridSync::arrive drains vmcnt(0) before it signals.
 __device__ __forceinline__ void cst16(void* p, f32x4 v) {
-#ifdef RES_NO_ST16
+#if defined(RES_PLAIN_IO)
+  *reinterpret_cast<f32x4*>(p) = v;
+#elif defined(RES_NO_ST16)
   const U2 u = __builtin_bit_cast(U2, v);
   cst8(p, u.a);
   cst8(reinterpret_cast<unsigned long long*>(p) + 1, u.b);
@@ -85,8 +104,12 @@ __device__ __forceinline__ void cst16(void* p, f32x4 v) {
 }
 __device__ __forceinline__ void cst_f4(float* p, float4 v) { cst16(p, f32x4{v.x, v.y, v.z, v.w}); }
 __device__ __forceinline__ bf16x8 cld_b8(const bf16_t* p) {
+#ifdef RES_PLAIN_IO
+  return *reinterpret_cast<const bf16x8*>(p);
+#else
   U2 u{cld8(p), cld8(p + 4)};
   return __builtin_bit_cast(bf16x8, u);
+#endif
 }
 __device__ __forceinline__ void cst_b8(bf16_t* p, bf16x8 v) { cst16(p, __builtin_bit_cast(f32x4, v)); }
 __device__ __forceinline__ void cst_b4(bf16_t* p, bf16x4 v) { cst8(p, __builtin_bit_cast(unsigned long long, v)); }
@@ -135,6 +158,9 @@ struct GridSync {
 #endif
   bool fenced = false;
   __device__ __forceinline__ void arrive(bool participant) {
+#ifdef RES_PLAIN_IO
+    return;  // (the phase is a kernel of its own: the kernel boundary hands its output over)
+#endif
     if (!participant) return;       // workgroup-uniform
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's write-through stores are acknowledged
     __syncthreads();
@@ -150,6 +176,9 @@ struct GridSync {
   // a second resident launch on another stream) raises the abort flag; every workgroup then leaves at its next wait,
   // phases turn into no-ops and length[0] = -1 tells the host (care_decode_resident).
   __device__ __forceinline__ void wait() {
+#ifdef RES_PLAIN_IO
+    return;
+#endif
     __shared__ int s_dead;
     if (want == 0) return;  // the first phase of the launch
     if (threadIdx.x < 64) {
@@ -468,22 +497,22 @@ __device__ __forceinline__ void cld16_row(const float* base, float4 (&v)[NV]) {
   f32x4 r[NV];
   if constexpr (NV == 8) {
     asm volatile(
-        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:256 sc1\n\t"
-        "global_load_dwordx4 %2, %8, off offset:512 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:768 sc1\n\t"
-        "global_load_dwordx4 %4, %8, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:1280 sc1\n\t"
-        "global_load_dwordx4 %6, %8, off offset:1536 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:1792 sc1\n\t"
+        "global_load_dwordx4 %0, %8, off" RES_SC1 "\n\tglobal_load_dwordx4 %1, %8, off offset:256" RES_SC1 "\n\t"
+        "global_load_dwordx4 %2, %8, off offset:512" RES_SC1 "\n\tglobal_load_dwordx4 %3, %8, off offset:768" RES_SC1 "\n\t"
+        "global_load_dwordx4 %4, %8, off offset:1024" RES_SC1 "\n\tglobal_load_dwordx4 %5, %8, off offset:1280" RES_SC1 "\n\t"
+        "global_load_dwordx4 %6, %8, off offset:1536" RES_SC1 "\n\tglobal_load_dwordx4 %7, %8, off offset:1792" RES_SC1 "\n\t"
         "s_waitcnt vmcnt(0)"
         : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
         : "v"(base)
         : "memory");
   } else if constexpr (NV == 12) {
     asm volatile(
-        "global_load_dwordx4 %0, %12, off sc1\n\tglobal_load_dwordx4 %1, %12, off offset:256 sc1\n\t"
-        "global_load_dwordx4 %2, %12, off offset:512 sc1\n\tglobal_load_dwordx4 %3, %12, off offset:768 sc1\n\t"
-        "global_load_dwordx4 %4, %12, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %12, off offset:1280 sc1\n\t"
-        "global_load_dwordx4 %6, %12, off offset:1536 sc1\n\tglobal_load_dwordx4 %7, %12, off offset:1792 sc1\n\t"
-        "global_load_dwordx4 %8, %12, off offset:2048 sc1\n\tglobal_load_dwordx4 %9, %12, off offset:2304 sc1\n\t"
-        "global_load_dwordx4 %10, %12, off offset:2560 sc1\n\tglobal_load_dwordx4 %11, %12, off offset:2816 sc1\n\t"
+        "global_load_dwordx4 %0, %12, off" RES_SC1 "\n\tglobal_load_dwordx4 %1, %12, off offset:256" RES_SC1 "\n\t"
+        "global_load_dwordx4 %2, %12, off offset:512" RES_SC1 "\n\tglobal_load_dwordx4 %3, %12, off offset:768" RES_SC1 "\n\t"
+        "global_load_dwordx4 %4, %12, off offset:1024" RES_SC1 "\n\tglobal_load_dwordx4 %5, %12, off offset:1280" RES_SC1 "\n\t"
+        "global_load_dwordx4 %6, %12, off offset:1536" RES_SC1 "\n\tglobal_load_dwordx4 %7, %12, off offset:1792" RES_SC1 "\n\t"
+        "global_load_dwordx4 %8, %12, off offset:2048" RES_SC1 "\n\tglobal_load_dwordx4 %9, %12, off offset:2304" RES_SC1 "\n\t"
+        "global_load_dwordx4 %10, %12, off offset:2560" RES_SC1 "\n\tglobal_load_dwordx4 %11, %12, off offset:2816" RES_SC1 "\n\t"
         "s_waitcnt vmcnt(0)"
         : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
           "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11])
@@ -491,14 +520,14 @@ __device__ __forceinline__ void cld16_row(const float* base, float4 (&v)[NV]) {
         : "memory");
   } else {
     asm volatile(
-        "global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %16, off offset:256 sc1\n\t"
-        "global_load_dwordx4 %2, %16, off offset:512 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:768 sc1\n\t"
-        "global_load_dwordx4 %4, %16, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %16, off offset:1280 sc1\n\t"
-        "global_load_dwordx4 %6, %16, off offset:1536 sc1\n\tglobal_load_dwordx4 %7, %16, off offset:1792 sc1\n\t"
-        "global_load_dwordx4 %8, %16, off offset:2048 sc1\n\tglobal_load_dwordx4 %9, %16, off offset:2304 sc1\n\t"
-        "global_load_dwordx4 %10, %16, off offset:2560 sc1\n\tglobal_load_dwordx4 %11, %16, off offset:2816 sc1\n\t"
-        "global_load_dwordx4 %12, %16, off offset:3072 sc1\n\tglobal_load_dwordx4 %13, %16, off offset:3328 sc1\n\t"
-        "global_load_dwordx4 %14, %16, off offset:3584 sc1\n\tglobal_load_dwordx4 %15, %16, off offset:3840 sc1\n\t"
+        "global_load_dwordx4 %0, %16, off" RES_SC1 "\n\tglobal_load_dwordx4 %1, %16, off offset:256" RES_SC1 "\n\t"
+        "global_load_dwordx4 %2, %16, off offset:512" RES_SC1 "\n\tglobal_load_dwordx4 %3, %16, off offset:768" RES_SC1 "\n\t"
+        "global_load_dwordx4 %4, %16, off offset:1024" RES_SC1 "\n\tglobal_load_dwordx4 %5, %16, off offset:1280" RES_SC1 "\n\t"
+        "global_load_dwordx4 %6, %16, off offset:1536" RES_SC1 "\n\tglobal_load_dwordx4 %7, %16, off offset:1792" RES_SC1 "\n\t"
+        "global_load_dwordx4 %8, %16, off offset:2048" RES_SC1 "\n\tglobal_load_dwordx4 %9, %16, off offset:2304" RES_SC1 "\n\t"
+        "global_load_dwordx4 %10, %16, off offset:2560" RES_SC1 "\n\tglobal_load_dwordx4 %11, %16, off offset:2816" RES_SC1 "\n\t"
+        "global_load_dwordx4 %12, %16, off offset:3072" RES_SC1 "\n\tglobal_load_dwordx4 %13, %16, off offset:3328" RES_SC1 "\n\t"
+        "global_load_dwordx4 %14, %16, off offset:3584" RES_SC1 "\n\tglobal_load_dwordx4 %15, %16, off offset:3840" RES_SC1 "\n\t"
         "s_waitcnt vmcnt(0)"
         : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
           "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
@@ -513,14 +542,14 @@ __device__ __forceinline__ void cld16_row(const float* base, float4 (&v)[NV]) {
 __device__ __forceinline__ void cld16_row2(const float* a, const float* b, float4 (&v)[8], float4 (&w)[8]) {
   f32x4 r[16];
   asm volatile(
-      "global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %16, off offset:256 sc1\n\t"
-      "global_load_dwordx4 %2, %16, off offset:512 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:768 sc1\n\t"
-      "global_load_dwordx4 %4, %16, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %16, off offset:1280 sc1\n\t"
-      "global_load_dwordx4 %6, %16, off offset:1536 sc1\n\tglobal_load_dwordx4 %7, %16, off offset:1792 sc1\n\t"
-      "global_load_dwordx4 %8, %17, off sc1\n\tglobal_load_dwordx4 %9, %17, off offset:256 sc1\n\t"
-      "global_load_dwordx4 %10, %17, off offset:512 sc1\n\tglobal_load_dwordx4 %11, %17, off offset:768 sc1\n\t"
-      "global_load_dwordx4 %12, %17, off offset:1024 sc1\n\tglobal_load_dwordx4 %13, %17, off offset:1280 sc1\n\t"
-      "global_load_dwordx4 %14, %17, off offset:1536 sc1\n\tglobal_load_dwordx4 %15, %17, off offset:1792 sc1\n\t"
+      "global_load_dwordx4 %0, %16, off" RES_SC1 "\n\tglobal_load_dwordx4 %1, %16, off offset:256" RES_SC1 "\n\t"
+      "global_load_dwordx4 %2, %16, off offset:512" RES_SC1 "\n\tglobal_load_dwordx4 %3, %16, off offset:768" RES_SC1 "\n\t"
+      "global_load_dwordx4 %4, %16, off offset:1024" RES_SC1 "\n\tglobal_load_dwordx4 %5, %16, off offset:1280" RES_SC1 "\n\t"
+      "global_load_dwordx4 %6, %16, off offset:1536" RES_SC1 "\n\tglobal_load_dwordx4 %7, %16, off offset:1792" RES_SC1 "\n\t"
+      "global_load_dwordx4 %8, %17, off" RES_SC1 "\n\tglobal_load_dwordx4 %9, %17, off offset:256" RES_SC1 "\n\t"
+      "global_load_dwordx4 %10, %17, off offset:512" RES_SC1 "\n\tglobal_load_dwordx4 %11, %17, off offset:768" RES_SC1 "\n\t"
+      "global_load_dwordx4 %12, %17, off offset:1024" RES_SC1 "\n\tglobal_load_dwordx4 %13, %17, off offset:1280" RES_SC1 "\n\t"
+      "global_load_dwordx4 %14, %17, off offset:1536" RES_SC1 "\n\tglobal_load_dwordx4 %15, %17, off offset:1792" RES_SC1 "\n\t"
       "s_waitcnt vmcnt(0)"
       : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
         "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
@@ -537,8 +566,8 @@ __device__ __forceinline__ void cld16_row2(const float* a, const float* b, float
 __device__ __forceinline__ void cld16_x4(const void* a0, const void* a1, const void* a2, const void* a3, bf16x8 (&v)[4]) {
   f32x4 r[4];
   asm volatile(
-      "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-      "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+      "global_load_dwordx4 %0, %4, off" RES_SC1 "\n\tglobal_load_dwordx4 %1, %5, off" RES_SC1 "\n\t"
+      "global_load_dwordx4 %2, %6, off" RES_SC1 "\n\tglobal_load_dwordx4 %3, %7, off" RES_SC1 "\n\ts_waitcnt vmcnt(0)"
       : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
       : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
       : "memory");
@@ -548,10 +577,10 @@ __device__ __forceinline__ void cld16_x4(const void* a0, const void* a1, const v
 __device__ __forceinline__ void cld16_x8(const void* const (&a)[8], bf16x8 (&v)[8]) {
   f32x4 r[8];
   asm volatile(
-      "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
-      "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
-      "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
-      "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+      "global_load_dwordx4 %0, %8, off" RES_SC1 "\n\tglobal_load_dwordx4 %1, %9, off" RES_SC1 "\n\t"
+      "global_load_dwordx4 %2, %10, off" RES_SC1 "\n\tglobal_load_dwordx4 %3, %11, off" RES_SC1 "\n\t"
+      "global_load_dwordx4 %4, %12, off" RES_SC1 "\n\tglobal_load_dwordx4 %5, %13, off" RES_SC1 "\n\t"
+      "global_load_dwordx4 %6, %14, off" RES_SC1 "\n\tglobal_load_dwordx4 %7, %15, off" RES_SC1 "\n\ts_waitcnt vmcnt(0)"
       : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
       : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
       : "memory");
@@ -565,14 +594,14 @@ __device__ __forceinline__ void cld16_x16_rows4k(const unsigned char* first, bf1
 #pragma unroll
   for (int j = 0; j < 8; ++j) b[j] = first + 8192 * j + 2048;
   asm volatile(
-      "global_load_dwordx4 %0, %16, off offset:-2048 sc1\n\tglobal_load_dwordx4 %1, %16, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %2, %17, off offset:-2048 sc1\n\tglobal_load_dwordx4 %3, %17, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %4, %18, off offset:-2048 sc1\n\tglobal_load_dwordx4 %5, %18, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %6, %19, off offset:-2048 sc1\n\tglobal_load_dwordx4 %7, %19, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %8, %20, off offset:-2048 sc1\n\tglobal_load_dwordx4 %9, %20, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %10, %21, off offset:-2048 sc1\n\tglobal_load_dwordx4 %11, %21, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %12, %22, off offset:-2048 sc1\n\tglobal_load_dwordx4 %13, %22, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %14, %23, off offset:-2048 sc1\n\tglobal_load_dwordx4 %15, %23, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %0, %16, off offset:-2048" RES_SC1 "\n\tglobal_load_dwordx4 %1, %16, off offset:2048" RES_SC1 "\n\t"
+      "global_load_dwordx4 %2, %17, off offset:-2048" RES_SC1 "\n\tglobal_load_dwordx4 %3, %17, off offset:2048" RES_SC1 "\n\t"
+      "global_load_dwordx4 %4, %18, off offset:-2048" RES_SC1 "\n\tglobal_load_dwordx4 %5, %18, off offset:2048" RES_SC1 "\n\t"
+      "global_load_dwordx4 %6, %19, off offset:-2048" RES_SC1 "\n\tglobal_load_dwordx4 %7, %19, off offset:2048" RES_SC1 "\n\t"
+      "global_load_dwordx4 %8, %20, off offset:-2048" RES_SC1 "\n\tglobal_load_dwordx4 %9, %20, off offset:2048" RES_SC1 "\n\t"
+      "global_load_dwordx4 %10, %21, off offset:-2048" RES_SC1 "\n\tglobal_load_dwordx4 %11, %21, off offset:2048" RES_SC1 "\n\t"
+      "global_load_dwordx4 %12, %22, off offset:-2048" RES_SC1 "\n\tglobal_load_dwordx4 %13, %22, off offset:2048" RES_SC1 "\n\t"
+      "global_load_dwordx4 %14, %23, off offset:-2048" RES_SC1 "\n\tglobal_load_dwordx4 %15, %23, off offset:2048" RES_SC1 "\n\t"
       "s_waitcnt vmcnt(0)"
       : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
         "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])

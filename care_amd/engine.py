@@ -148,6 +148,13 @@ class HipEngine:
         # beam search as one resident launch (csrc/decode_resident_beam.hip) up to this many rows = clips x beam_size
         # (translate.py's default: 128 clips x beam 5); 0: the multi-launch search at every size
         self.resident_beam_max_rows = int(os.environ.get("CARE_RESIDENT_BEAM_MAX_ROWS", "640"))
+        # ... or as a CHAIN of kernels per step (csrc/decode_chain.hip: the resident launch's phases as launches of their
+        # own, bit-identical results, no residency condition) up to this many rows.  OFF by default (0): *measured*
+        # (tools/beam_sweep.py, profiles/r05_beam_sweep.txt) the chain is slower than the resident launch wherever that
+        # applies (640 rows: 207 against 173 us per step) and slower than the multi-launch search beyond (1280 rows:
+        # 370 against 282) - DESIGN.md 4.2f says where its time goes
+        self.chain_beam_max_rows = int(os.environ.get("CARE_CHAIN_BEAM_MAX_ROWS", "0"))
+        self.chain_segment_steps = int(os.environ.get("CARE_CHAIN_SEGMENT_STEPS", "8"))
 
     @property
     def lib(self):
@@ -755,7 +762,10 @@ class HipEngine:
     # the resident decodes' cross K/V from this many memory rows up go through the LDS-tiled GEMM: the A-stationary kernels
     # want many 128- / 256-row panels, and 128 clips are 42 panels of 256 on 256 CUs (*measured* 10752 x 1024 x 512:
     # 36.4 against 19.6 us; 5376 rows 20.6 / 12.6; 84 rows 6.1 / 8.1 - below the threshold nothing changes)
-    RESIDENT_CKV_TILE_ROWS = 2048
+    # Round 5: the small-batch decodes take the LDS-tiled kernel at EVERY row count - one kernel, one K order (K
+    # steps of 64 into one accumulator per output, whatever the tile shape), so a clip's K/V bits do not depend on the batch
+    # it rides in (84 rows: + 2 us per pass).  -1: the A-stationary kernel instead (tuning).
+    RESIDENT_CKV_TILE_ROWS = 0
 
     def cross_kv(self, mem: torch.Tensor, tag="ckv", resident=False) -> List[torch.Tensor]:
         """K/V of the static memory for every decoder layer: [B, Lk, 2d] in the weight dtype.
@@ -774,7 +784,7 @@ class HipEngine:
             nm = "d{}_ca".format(li)
             kv = self.ws("{}{}".format(tag, li), (B * Lk, 2 * d), self.wt)
             out.append(self.gemm(src2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv, tag="cross_kv_gemm",
-                                 tile=resident and src2.dtype == self.h16 and B * Lk >= self.RESIDENT_CKV_TILE_ROWS))
+                                 tile=resident and src2.dtype == self.h16 and self.RESIDENT_CKV_TILE_ROWS >= 0))
         return out
 
     LATENT_MIN_ROWS = 1
@@ -1203,6 +1213,14 @@ class HipEngine:
             return False
         return self._resident_fits(rows, 2 if rows > 256 else 1)
 
+    def chain_beam_ok(self, clips: int, bm: int, need: int) -> bool:
+        """Beam search over `clips` clips with every step a chain of kernels (csrc/decode_chain.hip)?  The model-side
+        limits of the resident beam launch (its phases are the chain's kernels); no residency condition, so the row
+        count is bounded only by where the large-batch forms take over (`chain_beam_max_rows`)."""
+        rows = clips * bm
+        return bool(0 < rows <= self.chain_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and
+                    self._resident_model_ok(beam=True) and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX)
+
     def small_forms(self, clips: int) -> bool:
         """Batches of <= resident_max_rows clips (bf16, d_model = 512) take the small-batch forms of the pass: the
         embedder as GEMM + LayerNorm launches side by side per modality (encode(small=True)) and, for greedy decoding,
@@ -1260,6 +1278,80 @@ class HipEngine:
         self.last_decode = dict(clips=B, steps=scratch[8:12].view(torch.int32)[0], compactions=0, resident=True,
                                 row_steps=None)
         return nfin, fscore, flen, fhyp
+
+    def _chain_state(self, B: int, bm: int, need: int):
+        T, N, cap = self.T, B * bm, need + bm
+        return dict(tok=self.ws("cb_tok", (N, T + 1), torch.int32),
+                    anc=[self.ws("cb_anc%d" % i, (N, T + 1), torch.int32) for i in range(2)],
+                    scores=self.ws("cb_scores", (N,)), done=self.ws("cb_done", (B,), torch.int32),
+                    nfin=self.ws("cb_nfin", (B,), torch.int32), fscore=self.ws("cb_fscore", (B, cap)),
+                    flen=self.ws("cb_flen", (B, cap), torch.int32), fhyp=self.ws("cb_fhyp", (B, cap, T + 1), torch.int32),
+                    idx=self.ws("cb_idx", (B,), torch.int32), cnt=self.ws("cb_cnt", (1,), torch.int32))
+
+    def beam_chain_steps(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int, t0: int, t1: int,
+                         sem_embs: Optional[torch.Tensor] = None, count_live: bool = True):
+        """Steps t0 .. t1 of the beam search of B clips x bm beams as chains of kernels (care_decode_chain_beam: 10
+        launches per step for a one-layer decoder; models/Translator.py:77-143, misc/Decoding/Beam.py:45-85), the beam
+        state of csrc/beam.hip in the `cb_` workspaces; t0 == 1 also projects the clips' static K/V and initialises the
+        state.  Ends with the partition of the clips by `done` (care_active_slots: cb_cnt = clips still live).  No host
+        synchronisation here."""
+        B, Lk, d = mem.shape
+        T, w, N, cap = self.T, self.w, mem.shape[0] * bm, need + bm
+        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
+        kvs = self.__dict__.setdefault("_chain_kv", {})
+        if t0 == 1:  # (static workspaces: the handles of a (clips, beam) stay valid for the later segments' graphs)
+            kvs[(B, bm)] = (self.cross_kv(mem, tag="cb_ckv", resident=True),
+                            self.attr_kv(sem_embs, tag="cb_akv") if self.attr_att else None)
+        ckv, akv = kvs[(B, bm)]
+        v = self._chain_state(B, bm, need)
+        layers = self._resident_layers("cb_", N, bm, ckv, akv, Lk)
+        nbytes = self.lib.care_decode_chain_beam_scratch(B, bm, d, self.ff, self.V)
+        scratch = self.ws("cb_scratch", (nbytes,), torch.uint8)
+        self.call("care_decode_chain_beam", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem),
+                  ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(w["vocab"]), self.V, d, self.H, self.ff, self.act, B, bm, need, T,
+                  t0, t1, BOS, EOS, PAD, ptr(v["tok"]), T + 1, ptr(v["anc"][0]), ptr(v["anc"][1]), ptr(v["scores"]), ptr(v["done"]),
+                  ptr(v["nfin"]), ptr(v["fscore"]), ptr(v["flen"]), ptr(v["fhyp"]), cap, ptr(scratch), nbytes,
+                  int(os.environ.get("CARE_CHAIN_FORM", "-1")), tag="decode_chain_beam")
+        if count_live:
+            self.call("care_active_slots", ptr(v["done"]), B, ptr(v["idx"]), ptr(v["cnt"]))
+        return v
+
+    def translate_beam_chain(self, feats: List[torch.Tensor], bm: int, need: int, use_graph: bool = True, lean: bool = False,
+                             early_exit: bool = True):
+        """encode + beam search with chained steps.  The pass runs in segments of `chain_segment_steps` steps, each a
+        hipGraph of its own (the first with the encoder and the static K/V projection); between segments the host reads
+        ONE counter - the clips still live - and stops when none is (`if not active_inst_idx_list: break`,
+        models/Translator.py:77-81).  early_exit=False: all T steps in one graph.  No compaction: the chain serves the
+        row counts below those at which moving the survivors pays (engine.beam_early_exit)."""
+        B, T = feats[0].shape[0], self.T
+        S = max(1, self.chain_segment_steps) if early_exit else T
+        fkey = (tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        box = {}
+
+        def first():
+            self._form_rows = B * bm
+            enc = self.encode(feats, lean, static=True, small=self.small_forms(B))
+            box["enc"] = enc
+            v = self.beam_chain_steps(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need, 1, min(S, T),
+                                      sem_embs=enc.get("semantic_embs"), count_live=early_exit)
+            return enc, v
+
+        enc, v = self._replay(("bchain", 0, S, bm, need, bool(lean), bool(early_exit)) + fkey, first, use_graph)
+        t = min(S, T) + 1
+        stats = dict(clips=B, steps=t - 1, row_steps=B * bm * (t - 1), compactions=0, chain=True)
+        self.last_decode = stats
+        while t <= T:
+            if early_exit and int(v["cnt"].item()) == 0:
+                break
+            t1 = min(t + S - 1, T)
+            tt = t
+            self._replay(("bchain", tt, t1, bm, need, B, bool(lean)) + fkey,
+                         lambda: self.beam_chain_steps(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need,
+                                                       tt, t1, sem_embs=enc.get("semantic_embs")), use_graph)
+            stats["steps"] = t1
+            stats["row_steps"] += B * bm * (t1 - tt + 1)
+            t = t1 + 1
+        return enc, v["nfin"], v["fscore"], v["flen"], v["fhyp"]
 
     def greedy_resident(self, mem: torch.Tensor, sem: Optional[torch.Tensor], sem_embs: Optional[torch.Tensor] = None,
                         steps: Optional[int] = None, early_exit: bool = True):
@@ -1764,6 +1856,8 @@ class HipEngine:
             self.last_decode = dict(clips=feats[0].shape[0], steps=self.ws("rb_scratch", (nb,), torch.uint8)[8:12].view(torch.int32)[0],
                                     compactions=0, resident=True, row_steps=None)
             return out
+        if self.chain_beam_ok(feats[0].shape[0], bm, need):  # every step a chain of ~10 kernels (csrc/decode_chain.hip)
+            return self.translate_beam_chain(feats, bm, need, use_graph, lean, ee)
         if ee:
             return self.beam_early_exit(feats, bm, need, lean, use_graph)
 

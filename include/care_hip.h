@@ -672,6 +672,29 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
  *   Measurement only (bench.py: the duration of a kernel inside a replayed hipGraph); no reference counterpart. */
 int care_timestamp(void* out, void* stream);
 
+/*
+ * care_decode_chain_beam: steps t0 .. t1 of a BEAM SEARCH as a chain of kernels - the phases of care_decode_resident_beam,
+ *   each a launch of its own (10 per step for a one-layer decoder) with a grid sized by the phase's items; for batches
+ *   beyond what one resident launch serves well (a few hundred rows) up to thousands of rows.  Replaces the same reference
+ *   code as care_decode_resident_beam (models/Translator.py:77-143, misc/Decoding/Beam.py:45-85) with the SAME arithmetic
+ *   per row (the device code is shared; plain loads / stores instead of agent-scope ones): hypotheses and scores are
+ *   bit-identical to the resident launch's.  Arguments as care_decode_resident_beam; [t0, t1] the steps to run (1-based;
+ *   t0 == 1 initialises the beam state and zeroes the `clips done` counter ((uint32_t*)scratch)[1]; later calls continue
+ *   on the same state and scratch); the caller decides between calls whether any clip is still live (`done`).  There is
+ *   no residency condition and no hand-off protocol: any grid, any number of concurrent streams.  form: -1 = by row
+ *   count (<= 64 rows K-split items; <= 256 one row tile per workgroup; beyond, 2 / 2 / 2 / 4 row tiles per weight fetch
+ *   in QKV / the d x d products / FFN dense1 / the vocabulary), 0 / 1 / 3 force one - a row's bits are the same in all.
+ *   scratch: care_decode_chain_beam_scratch(clips, beam, d, ff, V) bytes, 16-byte aligned.
+ *   Requires d == 512, heads == 8, ff in {512, 1024, 2048}, beam <= 5, T <= 63, V <= 16384, nkeys <= 128, n_att <= 2.
+ */
+int64_t care_decode_chain_beam_scratch(int clips, int beam, int d, int ff, int V);
+int care_decode_chain_beam(const care_resident_layer* layers, int n_layers, const float* word, const float* pos,
+                           const float* sem, const float* emb_g, const float* emb_b, float eps, const void* vocab_w,
+                           int V, int d, int heads, int ff, int act, int clips, int beam, int need, int T, int t0, int t1,
+                           int bos, int eos, int pad, int32_t* tok, int stride, int32_t* anc0, int32_t* anc1,
+                           float* scores, int32_t* done, int32_t* nfin, float* fscore, int32_t* flen, int32_t* fhyp,
+                           int fin_cap, void* scratch, int64_t scratch_bytes, int form, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
