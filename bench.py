@@ -207,6 +207,10 @@ def extra_legs(dev, main_dtype, legs):
 
     # BASELINE configs[2]: the concept-guided (CARE) path
     legs["msrvtt_care_greedy"] = greedy_leg("msrvtt_care", main_dtype, 16384)[0]
+    # the headline workload in the OTHER 16-bit mode: fp16 (the same kernels compiled for IEEE half, libcare_hip_f16.so) -
+    # bf16's bytes and MFMA rate, 8 x smaller error (fp16_hidden_state_error below)
+    if main_dtype == "bf16":
+        legs["msrvtt_base_ami_fp16"] = greedy_leg("msrvtt_base_ami", "fp16", 32768, iters=4)[0]
     # fp32 parity mode (the only mode inside north_star's 1e-5 tolerance)
     legs["msrvtt_base_ami_fp32"] = greedy_leg("msrvtt_base_ami", "fp32", 4096)[0]
     # the mode between the two: fp32 storage, every GEMM as three fp16 MFMA passes over hi/lo pieces (fp32-grade results)
@@ -241,6 +245,32 @@ def extra_legs(dev, main_dtype, legs):
                                                   resident_launch=bool(eng.last_decode.get("resident")))
         if B == 1:
             legs["msrvtt_care_beam5_B1"]["ms_per_caption"] = round(dt * 1e3, 3)
+    # ---- batch sweep (B in {1, 64, 128, 256, 1024, 4096}; translate.py:136 lets a user pick any
+    # batch): greedy d = 512 and beam 5 across the hand-overs between the forms of the decode - the resident launch (greedy
+    # <= engine.resident_max_rows clips, beam <= engine.resident_beam_max_rows rows), the multi-launch small forms, the
+    # large-batch forms.  captions/s must grow with B through every hand-over (tests/test_gpu_properties.py asserts it on
+    # the GPU box); engine.py's crossover constants cite this table (profiles/r05_batch_sweep.json).
+    sweep = {"greedy": {}, "beam5": {}}
+    opt, eng = build("msrvtt_base_ami", main_dtype)
+    for B in (1, 64, 128, 256, 512, 1024, 2048, 4096):
+        feats = feats_for(opt, B)
+        run = lambda: eng.translate_greedy(feats, use_graph=True, lean=True)
+        for _ in range(3):
+            run()
+        dt = _timed(run, 20 if B <= 512 else 8)
+        sweep["greedy"][str(B)] = dict(captions_per_s=round(B / dt, 1), decoder_step_us=round(dt * 1e6 / eng.T, 2),
+                                       form="resident" if eng.last_decode.get("resident") else "multi-launch")
+    opt, eng = build("msrvtt_care_beam5", main_dtype)
+    for B in (1, 32, 64, 128, 256, 512, 1024, 4096):
+        feats = feats_for(opt, B)
+        run = lambda: eng.translate_beam(feats, 5, 5, use_graph=True, lean=True)
+        for _ in range(3):
+            run()
+        dt = _timed(run, 20 if B <= 128 else 6)
+        sweep["beam5"][str(B)] = dict(captions_per_s=round(B / dt, 1), decoder_step_us=round(dt * 1e6 / eng.T, 2), rows=5 * B,
+                                      form="resident" if eng.last_decode.get("resident") else
+                                      "chain" if eng.last_decode.get("chain") else "multi-launch")
+    legs["batch_sweep"] = dict(config_greedy="msrvtt_base_ami", config_beam5="msrvtt_care_beam5", dtype=main_dtype, **sweep)
     # a model that ENDS its captions (EOS row of the vocabulary projection x 5: mixed lengths, mean ~8 like trained
     # captions; random-init weights never emit EOS): early termination + compaction against the fixed 29 steps
     boost = {"cls_head.tgt_word_prj.weight": {3: 5.0}}
@@ -342,15 +372,20 @@ def extra_legs(dev, main_dtype, legs):
             g_tr = torch.randn_like(out["logits"]) * 1e-3
         torch.autograd.backward([out["logits"]], [g_tr])
 
-    for _ in range(2):
-        train_step()
-    dt_tr = _timed(train_step, 5)
     fl_tr = 3.0 * fl  # forward + the two backward products of every GEMM, per clip (same shapes as the teacher-forced forward)
-    legs["training_step"] = dict(config="msrvtt_care", dtype="f32", clips_per_step=Btr,
-                                 what="model.train(); forward + backward through care_amd/training.py (autograd Functions over HIP kernels), "
-                                      "gradient of a fixed cotangent on the logits; no loss, no optimiser",
-                                 ms_per_step=round(dt_tr * 1e3, 3), clips_per_s=round(Btr / dt_tr, 1),
-                                 tflops=round(fl_tr * Btr / dt_tr / 1e12, 2))
+    for Btr, name in ((64, "training_step"), (512, "training_step_B512")):
+        f_tr = feats_for(opt, Btr)
+        ids_tr = synth_input_ids(7, Btr, opt["max_len"] - 1, opt["vocab_size"]).to(dev)
+        batch = {"feats": f_tr, "input_ids": ids_tr}
+        g_tr = None
+        for _ in range(2):
+            train_step()
+        dt_tr = _timed(train_step, 5)
+        legs[name] = dict(config="msrvtt_care", dtype="f32", clips_per_step=Btr,
+                          what="model.train(); forward + backward through care_amd/training.py (autograd Functions over HIP kernels), "
+                               "gradient of a fixed cotangent on the logits; no loss, no optimiser",
+                          ms_per_step=round(dt_tr * 1e3, 3), clips_per_s=round(Btr / dt_tr, 1),
+                          tflops=round(fl_tr * Btr / dt_tr / 1e12, 2))
     model_tr.eval()
     del model_tr, batch, f_tr, ids_tr, g_tr
 
@@ -403,13 +438,14 @@ def extra_legs(dev, main_dtype, legs):
         f = [x.to(dev) for x in synth_feats(3, feat_shapes(opt, 64))]
         ids = synth_input_ids(3, 64, opt["max_len"] - 1, opt["vocab_size"]).to(dev)
         hid = {}
-        for dt_ in ("fp32", "bf16"):
+        for dt_ in ("fp32", "bf16", "fp16"):
             model.set_compute_dtype(dt_)
             hid[dt_] = model.feedforward_step({"feats": f, "input_ids": ids})["hidden_states"].float().clone()
-        diff = (hid["bf16"] - hid["fp32"]).abs()
-        legs["bf16_hidden_state_error"] = dict(max_abs=round(float(diff.max()), 5), mean_abs=round(float(diff.mean()), 6),
-                                               against="fp32 mode of the same engine (itself within 1e-5 of the reference)",
-                                               sample="teacher-forced hidden states, 64 clips x 29 positions x 512")
+        for dt_ in ("bf16", "fp16"):
+            diff = (hid[dt_] - hid["fp32"]).abs()
+            legs[dt_ + "_hidden_state_error"] = dict(max_abs=round(float(diff.max()), 5), mean_abs=round(float(diff.mean()), 6),
+                                                     against="fp32 mode of the same engine (itself within 1e-5 of the reference)",
+                                                     sample="teacher-forced hidden states, 64 clips x 29 positions x 512")
     return legs
 
 

@@ -45,6 +45,18 @@ struct RArgs {
   bf16_t* hn;                  // the normalised last hidden rows (bf16 [R16, 512]): the B operand of the recomputed logits
 };
 
+// The argument block of a resident launch is ~150 pointers and sizes.  Taken by value into a kernel whose step loop calls
+// ten inlined phases, its loop-invariant fields are hoisted out of the loop into SGPRs the kernel does not have (round 4:
+// 560 - 600 SGPR spills, ~110 v_readlane per tile block of a phase's epilogue).  The resident kernels therefore read it
+// where it lies - the kernarg segment (constant address space, s_load) - through a pointer that an empty asm statement
+// makes opaque at every use: a field is loaded in the phase that needs it and lives no longer.
+typedef const __attribute__((address_space(4))) RArgs* ResKArgs;
+__device__ __forceinline__ const RArgs& res_args(ResKArgs k) {
+  asm volatile("" : "+s"(k));
+  return *(const RArgs*)k;
+}
+#define RES_KARGS() ((ResKArgs)__builtin_amdgcn_kernarg_segment_ptr())
+
 // ---------------------------------------------------------------------------------------------------------------
 // Data that one workgroup writes and another reads INSIDE the launch moves with agent-scope (sc1) accesses: stores
 // write through to the device's coherence point, loads miss the caches that are not coherent across XCDs (a CU's L1,
@@ -493,9 +505,17 @@ __device__ __forceinline__ int fetch_token(const RArgs& p, int r0, int t, bool w
 // requested before the statement stay in flight under it; the wait covers them too).
 template <int NV>
 __device__ __forceinline__ void cld16_row(const float* base, float4 (&v)[NV]) {
-  static_assert(NV == 8 || NV == 12 || NV == 16, "row pieces");
+  static_assert(NV == 4 || NV == 8 || NV == 12 || NV == 16, "row pieces");
   f32x4 r[NV];
-  if constexpr (NV == 8) {
+  if constexpr (NV == 4) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off" RES_SC1 "\n\tglobal_load_dwordx4 %1, %4, off offset:256" RES_SC1 "\n\t"
+        "global_load_dwordx4 %2, %4, off offset:512" RES_SC1 "\n\tglobal_load_dwordx4 %3, %4, off offset:768" RES_SC1 "\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "v"(base)
+        : "memory");
+  } else if constexpr (NV == 8) {
     asm volatile(
         "global_load_dwordx4 %0, %8, off" RES_SC1 "\n\tglobal_load_dwordx4 %1, %8, off offset:256" RES_SC1 "\n\t"
         "global_load_dwordx4 %2, %8, off offset:512" RES_SC1 "\n\tglobal_load_dwordx4 %3, %8, off offset:768" RES_SC1 "\n\t"
@@ -642,15 +662,30 @@ __device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, int 
     }
 #else
     if (ysrc2) {  // the second K half of a two-workgroup FFN dense2 (ffn2_phase<true>): y = y + y2
-      float4 w2[NV];
       if constexpr (NV == 8) {
+        float4 w2[NV];
         cld16_row2(ysrc + (int64_t)rc * d + sub * 4, ysrc2 + (int64_t)rc * d + sub * 4, v, w2);
-      } else {
-        cld16_row<NV>(ysrc + (int64_t)rc * d + sub * 4, v);
-        cld16_row<NV>(ysrc2 + (int64_t)rc * d + sub * 4, w2);
-      }
 #pragma unroll
-      for (int k = 0; k < NV; ++k) add4(v[k], w2[k]);
+        for (int k = 0; k < NV; ++k) add4(v[k], w2[k]);
+      } else {
+        // d_model 768 / 1024: the second row arrives in pieces of 8 (+ 4) float4 added as they land - two whole rows of 12 /
+        // 16 pieces side by side (+ the asm's own outputs) were 128 - 192 registers of the A stage (round 4's scratch)
+        cld16_row<NV>(ysrc + (int64_t)rc * d + sub * 4, v);
+        float4 w8[8];
+        cld16_row<8>(ysrc2 + (int64_t)rc * d + sub * 4, w8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) add4(v[k], w8[k]);
+        if constexpr (NV == 16) {
+          cld16_row<8>(ysrc2 + (int64_t)rc * d + sub * 4 + 512, w8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) add4(v[8 + k], w8[k]);
+        } else {
+          float4 w4[4];
+          cld16_row<4>(ysrc2 + (int64_t)rc * d + sub * 4 + 512, w4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) add4(v[8 + k], w4[k]);
+        }
+      }
     } else {
       cld16_row<NV>(ysrc + (int64_t)rc * d + sub * 4, v);
     }
@@ -659,15 +694,40 @@ __device__ __forceinline__ void fetch_a_rows(const RArgs& p, int r0, int t, int 
 }
 
 // ... and their LayerNorm into the LDS tile (+ the fp32 rows for the residual when write_x, + the bf16 rows when write_hn)
+// d_model 512: in registers (16 float4).  d_model 768 / 1024: through LDS - 24 / 32 float4 per lane next to the row pieces
+// were what spilled in the wide instances (round 4: 216 / 412 B of scratch per lane); an LDS read does not queue behind the
+// loop's write-through stores either (lgkmcnt, not vmcnt).
 template <int D = 512>
-struct LnGB { float4 g[D / 64], b[D / 64]; };  // this lane's columns of the LayerNorm weight / bias
+struct LnGB {
+  float4 g[D > 512 ? 1 : D / 64], b[D > 512 ? 1 : D / 64];
+  const float* sg; const float* sb;
+  __device__ __forceinline__ float4 G(int k) const {
+    if constexpr (D > 512) return *reinterpret_cast<const float4*>(sg + (threadIdx.x & 15) * 4 + 64 * k);
+    else return g[k];
+  }
+  __device__ __forceinline__ float4 B(int k) const {
+    if constexpr (D > 512) return *reinterpret_cast<const float4*>(sb + (threadIdx.x & 15) * 4 + 64 * k);
+    else return b[k];
+  }
+};
 template <int D = 512>
 __device__ __forceinline__ void load_gb(LnGB<D>& w, const float* g, const float* be) {
-  const int sub = threadIdx.x & 15;
+  if constexpr (D > 512) {
+    __shared__ __attribute__((aligned(16))) float s_g[D], s_b[D];
+    __syncthreads();  // (the previous phase's readers of the two rows are past them)
+    for (int i = threadIdx.x; i < D / 4; i += 256) {
+      reinterpret_cast<float4*>(s_g)[i] = reinterpret_cast<const float4*>(g)[i];
+      reinterpret_cast<float4*>(s_b)[i] = reinterpret_cast<const float4*>(be)[i];
+    }
+    __syncthreads();
+    w.sg = s_g; w.sb = s_b;
+  } else {
+    const int sub = threadIdx.x & 15;
 #pragma unroll
-  for (int k = 0; k < D / 64; ++k) {
-    w.g[k] = *reinterpret_cast<const float4*>(g + sub * 4 + 64 * k);
-    w.b[k] = *reinterpret_cast<const float4*>(be + sub * 4 + 64 * k);
+    for (int k = 0; k < D / 64; ++k) {
+      w.g[k] = *reinterpret_cast<const float4*>(g + sub * 4 + 64 * k);
+      w.b[k] = *reinterpret_cast<const float4*>(be + sub * 4 + 64 * k);
+    }
   }
 }
 // (the weights come in registers, requested before the rows: loaded inside the loop below they would each wait behind
@@ -698,7 +758,7 @@ __device__ __forceinline__ void finish_a_rows(const RArgs& p, int r0, const floa
   bf16_t* dst = sA + rr * lda + sub * 4;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const float4 gg = w.g[k], bb = w.b[k];
+    const float4 gg = w.G(k), bb = w.B(k);
     float4 o;
     o.x = (v[k].x - mean) * rstd * gg.x + bb.x;
     o.y = (v[k].y - mean) * rstd * gg.y + bb.y;
@@ -986,7 +1046,21 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
   const bool participant = pm.has || (AMODE == A_EMBED && pm.helper);
   const unsigned nprod = pm.np_ + (AMODE == A_EMBED ? pm.nh_ : 0u);
   if (gs.dead) return nprod;
+  // RES_W3 (-DRES_W3=1; OFF): THREE sets of W fragments when a workgroup has several items, the second requested before
+  // the hand-off wait like the first - twice the weight bytes in flight per CU.  Built on the reading that an item waits
+  // for its 64 KB of weights from L2 (*measured* 640 beam rows: 16.9 us for the 7 items of a vocabulary workgroup against
+  // ~1.1 us of MFMA + statistics each) and *measured* SLOWER (round 5, same box, us per step of the whole pass, two sets /
+  // three: beam 5 at 128 clips 169.4 / 176.2, 64 clips 141.5 / 144.3; greedy 128 clips 62.0 / 63.6, 256 clips 93.4 / 97.2;
+  // d_model 1024 at 32 clips 87.6 / 91.8): the third set lives in AGPRs the compiler copies through, and the items were not
+  // waiting for bytes in flight.  Kept as a switch for the next profile.
+#ifndef RES_W3
+#define RES_W3 0
+#endif
+  constexpr bool W3 = RES_W3 != 0;
+  const bool multi = pm.has && pm.c0 + pm.nper < CI;
+  bf16x8 wc[W3 ? NF : 1];
   if (pm.has) fetch(wa, pm.c0);
+  if (W3 && multi) fetch(wb, pm.c0 + pm.nper);
   if (do_wait && participant) gs.wait();
   if (gs.dead) return nprod;
   gs.mark();
@@ -1026,8 +1100,25 @@ RES_PHASE_FN unsigned gemm_phase(const RArgs& p, GridSync& gs, bool do_wait, bf1
     gs.mark();
     Pre Pa, Pb;
     preload(Pa, pm.c0);
-    if (pm.c0 + pm.nper >= CI) {
+    if (!multi) {
       item(wa, pm.c0, Pa);  // one item: nothing to prefetch (most phases at most row counts)
+    } else if constexpr (W3) {
+      Pre Pc;
+      const int n1 = pm.nper;
+      preload(Pb, min(pm.c0 + n1, CI - 1));
+      for (int c = pm.c0; c < CI; c += 3 * n1) {
+        preload(Pc, min(c + 2 * n1, CI - 1));
+        if constexpr (NF > 1) fetch(wc, c + 2 * n1);
+        item(wa, c, Pa);
+        if (c + n1 >= CI) break;
+        preload(Pa, min(c + 3 * n1, CI - 1));
+        fetch(wa, c + 3 * n1);
+        item(wb, c + n1, Pb);
+        if (c + 2 * n1 >= CI) break;
+        preload(Pb, min(c + 4 * n1, CI - 1));
+        fetch(wb, c + 4 * n1);
+        if constexpr (NF > 1) item(wc, c + 2 * n1, Pc);
+      }
     } else {
       for (int c = pm.c0; c < CI; c += 2 * pm.nper) {
         preload(Pb, min(c + pm.nper, CI - 1));
@@ -1135,7 +1226,11 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
     P.bv = *reinterpret_cast<const float4*>(bias + nb);
     if (wave == 0 && kh == 0 && r < p.R) P.xr = cld_f4(p.xres + (int64_t)r * D + nb);
   };
+  constexpr bool W3 = RES_W3 != 0;  // three sets of W fragments, two requested before the hand-off wait: see gemm_phase
+  const bool multi = pm.has && pm.c0 + pm.nper < CI;
+  bf16x8 wc[W3 ? NF : 1];
   if (pm.has) fetchw(wa, pm.c0);
+  if (W3 && multi) fetchw(wb, pm.c0 + pm.nper);
   if (pm.has) gs.wait();
   if (gs.dead) return nprod;
   gs.mark();
@@ -1228,8 +1323,25 @@ RES_PHASE_FN unsigned ffn2_phase(const RArgs& p, GridSync& gs, bf16_t* sA, const
     // items per workgroup, each waiting for its own 64 KB from L2: 18 us in this phase)
     Pre Pa, Pb;
     preload(Pa, pm.c0);
-    if (pm.c0 + pm.nper >= CI) {
+    if (!multi) {
       item(wa, pm.c0, Pa);
+    } else if constexpr (W3) {
+      Pre Pc;
+      const int n1 = pm.nper;
+      preload(Pb, pm.c0 + n1);
+      for (int c = pm.c0; c < CI; c += 3 * n1) {
+        preload(Pc, c + 2 * n1);
+        if constexpr (NF > 1) fetchw(wc, c + 2 * n1);
+        item(wa, c, Pa);
+        if (c + n1 >= CI) break;
+        preload(Pa, c + 3 * n1);
+        fetchw(wa, c + 3 * n1);
+        item(wb, c + n1, Pb);
+        if (c + 2 * n1 >= CI) break;
+        preload(Pb, c + 4 * n1);
+        fetchw(wb, c + 4 * n1);
+        if constexpr (NF > 1) item(wc, c + 2 * n1, Pc);
+      }
     } else {
       for (int c = pm.c0; c < CI; c += 2 * pm.nper) {
         preload(Pb, c + pm.nper);

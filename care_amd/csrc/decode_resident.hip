@@ -41,7 +41,9 @@ namespace {
 // is D / 4: 6 / 8 fragments), the vocabulary phase included, and FFN dense2 over two workgroups per column tile - up to 128
 // rows (BASELINE configs[3]: 32 clips per GPU).
 template <int KCF, int RB, bool SM, bool HF, int D = 512>  // HF (ff = 2048, <= 64 rows): FFN dense2 over two workgroups per column tile
-__global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
+__global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p_by_value) {  // (read through the kernarg segment: res_args)
+  const ResKArgs kargs = RES_KARGS();
+#define p (res_args(kargs))
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
   GridSync gs{p.sync, (unsigned)p.ghost, -1, false, 0, 0, 0u};
@@ -157,6 +159,8 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p) {
     if (blockIdx.x == 0 && threadIdx.x == 0) p.sync[2] = (unsigned)p.steps;
   }
 }
+
+#undef p
 
 std::atomic<unsigned long long> g_res_lds_done[8];
 std::atomic<int> g_res_ok[8];  // residency checked (res_check_residency) for this instantiation

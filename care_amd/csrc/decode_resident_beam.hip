@@ -30,7 +30,9 @@ namespace {
 // (vocabulary); SM (<= 64 rows): QKV and FFN dense1 in 16-column K-split items, FFN dense2 over two workgroups per
 // column tile (the forms of decode_resident.hip).
 template <int KCF, int RQ, int RD, int RF, int RV, bool SM, bool KD>  // KD: the N = 512 products in K-split items
-__global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p) {
+__global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p_by_value) {  // (read through the kernarg segment: res_args)
+  const ResKArgs kargs = RES_KARGS();
+#define p (res_args(kargs))
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
   GridSync gs{p.sync, (unsigned)p.ghost, -1, false, 0, 0, 0u};
@@ -130,6 +132,8 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) p.sync[2] = (unsigned)(ended ? t_run : p.steps);
 }
+
+#undef p
 
 constexpr int RES_BEAM_KERNELS = 8;
 std::atomic<unsigned long long> g_resb_lds_done[RES_BEAM_KERNELS];
