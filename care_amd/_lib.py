@@ -66,6 +66,8 @@ SIGNATURES = {
     "care_beam_sparse_collect": [_P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "care_gemm_collect_bf16": [_P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "care_beam_pick": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _L, _I, _P, _I, _I, _P, _P, _I, _P],
+    "care_gemm_tile_beam": [_P, _L, _P, _P, _P, _P, _I, _I, _I, _P],
+    "care_beam_pick_groups": [_P, _P, _P, _I, _I, _P, _L, _P, _I, _I, _P, _P, _I, _P],
     "care_beam_select": [_P, _L, _I, _I, _P, _P, _I, _I, _P],
     "care_attention_probs": [_P, _L, _P, _I, _L, _L, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     "care_timestamp": [_P, _P],

@@ -27,7 +27,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, ".obj")
 SOURCES = ("gemm.hip", "gemm_as.hip", "gemm_vocab.hip", "gemm_store32.hip", "gemm_tile.hip", "gemm_ln.hip", "rowops.hip",
-           "attention.hip", "attention_seq.hip", "attention_latent.hip", "heads.hip", "beam.hip", "beam_sparse.hip",
+           "attention.hip", "attention_seq.hip", "attention_latent.hip", "heads.hip", "beam.hip", "beam_sparse.hip", "beam_pick.hip",
            "compact.hip", "backward.hip", "decode_resident.hip", "decode_resident_beam.hip", "decode_chain.hip")
 VERSION_SRC = "version.hip"  # compiled on every link with the hash / flags of the build
 ARCH = "gfx950"

@@ -46,12 +46,13 @@ struct TArgs {
   int n_split, M, N, K, act;
   float* pmax; int32_t* pidx; float* psum; int parts;
   const int32_t* labels; float* plab;
+  float* gmax;  // EPI_BEAM: per (row, 64-column part) the maxima of its sixteen 4-column groups
   int tiles_m, tiles_n, group;  // group: row tiles per band of the block -> tile map
   int a_wrap;  // K steps (of 64) after which the A columns start over: see care_gemm_tile_split3 (INT_MAX otherwise)
   int64_t a_bs, w_bs, c_bs; int bias_bs;  // batched launches (blockIdx.y): element offsets per batch of A, W, C0, bias
 };
 
-enum { EPI_STORE = 0, EPI_ARGMAX = 1, EPI_ARGMAX_LAB = 2 };
+enum { EPI_STORE = 0, EPI_ARGMAX = 1, EPI_ARGMAX_LAB = 2, EPI_BEAM = 3 };
 
 // Block -> output tile.  Blocks are dealt to the 8 XCDs round robin and in order, so the 32 workgroups an XCD runs at a
 // time are 32 CONSECUTIVE numbers of its run (bijective for any grid size); inside a run the tiles go in bands of
@@ -245,8 +246,26 @@ __device__ __forceinline__ void tile_epilogue(const TArgs& p, f32x4 (&acc)[MT][4
       }
       if (fg == 0 && row < p.M && part < p.parts) {
         const int64_t o = (int64_t)row * p.parts + part;
-        p.pmax[o] = best; p.pidx[o] = bi; p.psum[o] = s;
+        p.pmax[o] = best; p.psum[o] = s;
+        if constexpr (EPI != EPI_BEAM) p.pidx[o] = bi;
         if constexpr (EPI == EPI_ARGMAX_LAB) p.plab[o] = lv;
+      }
+      if constexpr (EPI == EPI_BEAM) {
+        // beam search: the maxima of this lane's four 4-column groups (groups 4 fg .. 4 fg + 3 of the part) - a row's bm best
+        // logits lie in its bm best groups (the bm-th largest group maximum is a lower bound of the bm-th best logit),
+        // which care_beam_pick_groups recomputes; one 16-byte store per lane and row
+        if (row < p.M && part < p.parts) {
+          f32x4 gm;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            float g4 = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (col0 + 4 * n + j < p.N) g4 = fmaxf(g4, acc[m][n][j]);
+            gm[n] = g4;
+          }
+          *reinterpret_cast<f32x4*>(p.gmax + ((int64_t)row * p.parts + part) * 16 + fg * 4) = gm;
+        }
       }
     }
   }
@@ -550,6 +569,18 @@ extern "C" int care_gemm_tile_split3_argmax(const void* A2, const void* W3, floa
   return pick_cfg(M, N, 3 * K) == 4412 ? launch_tile<4, 4, 1, 2, EPI_ARGMAX, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_ARGMAX, true>(p, st);
 }
 extern "C" int care_argmax_parts_tile(int N) { return N > 0 ? (N + 63) / 64 : CARE_EINVAL; }
+
+extern "C" int care_gemm_tile_beam(const void* A, int64_t lda, const void* W, float* pmax, float* psum, float* gmax, int M,
+                                   int N, int K, void* stream) {
+  int rc = tile_check(A, lda, W, M, N, K);
+  if (rc) return rc;
+  if (!pmax || !psum || !gmax || !care_aligned16(gmax)) return CARE_EINVAL;
+  TArgs p{};
+  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.ldw = K;
+  p.n_split = N; p.M = M; p.N = N; p.K = K;
+  p.pmax = pmax; p.psum = psum; p.gmax = gmax; p.parts = care_argmax_parts_tile(N);
+  return dispatch<EPI_BEAM>(p, (hipStream_t)stream);
+}
 
 extern "C" int care_gemm_tile_argmax(const void* A, int64_t lda, const void* W, float* pmax, int32_t* pidx, float* psum,
                                      const int32_t* labels, float* plab, int M, int N, int K, void* stream) {

@@ -403,13 +403,14 @@ class HipEngine:
         """dtype of activations that are ONLY GEMM inputs (attention context, FFN hidden)."""
         return self.h16 if self.bf_act else torch.float32
 
-    # Rows (clips x beam) from which the per-row top-k of beam search runs as two passes of the vocabulary GEMM
-    # (no [rows, V] logits in memory).  Below it the logits are written (a few MB, cache resident) and
-    # care_beam_select reads them: two launches per step instead of four.  Both forms pick the same columns in
-    # the same order (tests/test_gpu_kernels.py::test_fused_beam_selection_...), log-probabilities within 2e-5.
-    # *Measured* beam 5: 128 clips 6.35 vs 7.59 ms per pass (unfused vs fused), 512 clips 10.7 vs 10.9,
-    # 1024 clips 16.6 vs 15.8.  The form is fixed for a pass by its INITIAL row count.
-    BEAM_FUSED_MIN_ROWS = 4096
+    # Rows (clips x beam) from which the per-row top-k of beam search runs as two passes of the vocabulary GEMM on the
+    # 256-row panels (statistics -> threshold -> sparse collect -> pick: no [rows, V] logits in memory).  Below it the
+    # 16-bit modes take ONE pass of the LDS-tiled kernel that keeps group maxima (beam_groups_for; round 5), fp32 mode and
+    # beam sizes above 5 the materialised logits + care_beam_select.  All forms pick the same columns in the same order
+    # (tests/test_gpu_kernels.py::test_fused_beam_selection_..., test_beam_selection_from_group_maxima_...).
+    # *Measured* round 5 (beam 5, us per step of the whole pass, groups / two-pass): 5120 rows 422 / 497, 10240 rows 726 /
+    # 700, 20480 rows 1266 / 1162 - the group maxima are 12 KB per row and step.  Fixed for a pass by its INITIAL row count.
+    BEAM_FUSED_MIN_ROWS = int(os.environ.get("CARE_BEAM_FUSED_MIN_ROWS", "8192"))
 
     def _beam_sparse_ws(self, tag: str, rows: int):
         """Workspaces of the sparse second pass (csrc/beam_sparse.hip) - (tile maxima [tiles, rows] fp32, per-tile
@@ -425,9 +426,38 @@ class HipEngine:
             return False
         return self.as_ok and rows >= self.BEAM_FUSED_MIN_ROWS
 
+    # Beam selection below BEAM_FUSED_MIN_ROWS in the 16-bit modes (beam_size <= 5): the vocabulary product on the LDS-tiled
+    # kernel keeping per (row, 64-column part) the maximum, sum exp and the maxima of its sixteen 4-column groups
+    # (care_gemm_tile_beam), then one wave per row picks the bm best groups and recomputes their 4 bm logits
+    # (care_beam_pick_groups) - two launches and 12 KB per row instead of the [rows, V] fp32 logits written and read back
+    # (*measured* round 5, beam 5, us per step of the whole multi-launch pass, logits + care_beam_select / groups: 160 rows
+    # 183 / 175, 640 rows 229 / 213, 1280 rows 274 / 245, 2560 rows 320 / 284).
+    # The form is fixed for a pass by its INITIAL row count, like the fused two-pass selection's.
+    BEAM_GROUPS_MIN_ROWS = int(os.environ.get("CARE_BEAM_GROUPS_MIN_ROWS", "1"))
+
+    def beam_groups_for(self, rows: int, bm: int) -> bool:
+        rows = self._form_rows or rows
+        return bool(self.bf_act and not self.beam_fused_for(rows) and bm <= 5 and rows >= self.BEAM_GROUPS_MIN_ROWS and
+                    80 <= self.V <= 16384 and self.d % 64 == 0)
+
+    def _beam_groups_select(self, tag, xb, N, bm, cval, cidx):
+        parts = (self.V + 63) // 64
+        pmax, psum = self.ws(tag + "gpmax", (N, parts)), self.ws(tag + "gpsum", (N, parts))
+        gmax = self.ws(tag + "ggmax", (N, parts, 16))
+        self.call("care_gemm_tile_beam", ptr(xb), xb.stride(0), ptr(self.w["vocab"]), ptr(pmax), ptr(psum), ptr(gmax), N, self.V,
+                  self.d, tag="beam_vocab_groups")
+        self.call("care_beam_pick_groups", ptr(pmax), ptr(psum), ptr(gmax), parts, bm, ptr(xb), xb.stride(0), ptr(self.w["vocab"]),
+                  self.V, self.d, ptr(cval), ptr(cidx), N, tag="beam_pick_groups")
+
     def wsb(self, name: str, shape) -> Optional[torch.Tensor]:
         """bf16 mirror workspace of a GEMM-input activation (None unless as_ok)."""
         return self.ws(name + "#bf", shape, self.h16) if self.bf_act else None
+
+    # *measured* (round 5, tools/greedy_sweep.py / beam_sweep.py with CARE_FORCE_TILE = 0 / 1, us per decoder step of the whole
+    # pass): greedy 512 clips 137 / 141, 1024 166 / 167, 2048 248 / 232, 4096 365 / 339, 8192 590 / 568; beam 5 over 256
+    # clips (1280 rows) 284 / 272, 512 357 / 315, 1024 528 / 496, 2048 (10240 rows) 732 / 700; at 20480 rows the pass does
+    # not move and at 32768 the A-stationary kernels win in situ (DESIGN.md 10d)
+    MID_TILE_ROWS = (1280, 16384)
 
     def gemm(self, A, W, bias, out, act=0, out2=None, n_split=None, tag=None, tile=False):
         """out = act(A @ W^T + bias).  bf16 weights + bf16 A -> A-stationary kernel (csrc/gemm_as.hip) for
@@ -441,7 +471,13 @@ class HipEngine:
         if W.dtype == self.h16 and A.dtype == self.h16:
             if K % 64 or A.stride(0) % 8:
                 raise ValueError("bf16 A operand needs K % 64 == 0 and a 16-byte aligned row stride (got K = {})".format(K))
-            if K <= 512 and K % 128 == 0 and not tile and os.environ.get("CARE_FORCE_TILE", "0") == "0":
+            # K <= 512: the A-stationary kernel (a 128-row panel's activations in registers for the whole K) - except
+            # between MID_TILE_ROWS rows, where its 128 / 256-row panels leave most of the chip idle and the LDS-tiled
+            # kernel's 128 x 128 tiles do not.  The two kernels add K in the same order: BIT-IDENTICAL outputs
+            # (tests/test_gpu_kernels.py::test_tile_and_a_stationary_gemm_agree_bit_for_bit), so the switch is by the
+            # CURRENT row count and changes no caption.
+            mid = self.MID_TILE_ROWS[0] <= M < self.MID_TILE_ROWS[1] and os.environ.get("CARE_FORCE_TILE", "") != "0"
+            if K <= 512 and K % 128 == 0 and not tile and not mid and os.environ.get("CARE_FORCE_TILE", "0") != "1":
                 self.call("care_gemm_bf16", ptr(A), A.stride(0), _code(A), ptr(W), *tail, tag=tag)
             else:
                 self.call("care_gemm_tile", ptr(A), A.stride(0), ptr(W), *tail, tag=tag)
@@ -1663,7 +1699,10 @@ class HipEngine:
         tag = v["tag"]
         cval, cidx = self.ws(tag + "cval", (N, bm)), self.ws(tag + "cidx", (N, bm), torch.int32)
         fused_sel = self.beam_fused_for(B * bm)  # one form for the whole pass, whatever the compaction leaves
-        if fused_sel:
+        groups_sel = self.beam_groups_for(B * bm, bm)
+        if groups_sel:
+            pass
+        elif fused_sel:
             s_parts = self.lib.care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
             s_cap = 64
             s_pmax, s_psum = self.ws(tag + "spmax", (N, s_parts)), self.ws(tag + "spsum", (N, s_parts))
@@ -1677,7 +1716,9 @@ class HipEngine:
         for t in range(t0, t1 + 1):
             a_old, a_new = v["anc"][(t - 1) & 1], v["anc"][t & 1]
             x, xb = self._decode_step(t, N, bm, v["tok"], a_old, v["sem"], v["ckv"], v["skv"], self.Lk, tag, akv=v["akv"])
-            if fused_sel:
+            if groups_sel:
+                self._beam_groups_select(tag, xb, N, bm, cval, cidx)
+            elif fused_sel:
                 if sparse is not None:
                     # second pass only over the (tile, row) products whose tile maximum reaches the row's threshold
                     self.call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
@@ -1894,7 +1935,10 @@ class HipEngine:
         cidx = self.ws("b_cidx", (N, bm), torch.int32)
         vpad = (self.V + 63) // 64 * 64  # 16-byte aligned row stride -> the GEMM's vector store path
         fused_sel = self.beam_fused_for(B * bm)
-        if fused_sel:
+        groups_sel = self.beam_groups_for(B * bm, bm)
+        if groups_sel:
+            logits = None
+        elif fused_sel:
             s_parts = self.lib.care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
             s_cap = 64
             s_pmax, s_psum = self.ws("b_spmax", (N, s_parts)), self.ws("b_spsum", (N, s_parts))
@@ -1911,6 +1955,11 @@ class HipEngine:
         for t in range(1, T + 1):
             a_old, a_new = anc[(t - 1) & 1], anc[t & 1]
             x, xb = self._decode_step(t, N, bm, tok, a_old, sem, ckv, skv, Lk, "b_", akv=akv)
+            if groups_sel:
+                self._beam_groups_select("b_", xb, N, bm, cval, cidx)
+                self.call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
+                     ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
+                continue
             if fused_sel:
                 # fused selection (csrc/beam.hip): statistics GEMM -> threshold -> candidate pass -> pick;
                 # the [N, V] logits never exist

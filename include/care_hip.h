@@ -462,6 +462,24 @@ int care_beam_pick(const float* pmax, const float* psum, int parts, const int32_
                    int rows, void* stream);
 
 /*
+ * Beam selection from GROUP MAXIMA of the LDS-tiled vocabulary product (16-bit modes, a few hundred to a few thousand
+ *   rows; replaces the same reference lines as care_beam_select: models/Translator.py:127, misc/Decoding/Beam.py:60):
+ *     1. care_gemm_tile_beam   : x W^T on csrc/gemm_tile.hip without writing logits - per (row, 64-column part)
+ *        pmax / psum [M, parts] (maximum, sum exp(x - max)) and gmax [M, parts, 16]: the maxima of the part's sixteen
+ *        4-column groups (-inf for groups past N); parts = care_argmax_parts_tile(N);
+ *     2. care_beam_pick_groups : one wave per row - log-sum-exp from the parts; the bm parts with the largest maxima; the
+ *        bm best of their 16 bm groups (a row's bm best logits lie in its bm best groups); those 4 bm logits recomputed
+ *        from A and W (the tile kernel's MFMA, operand roles and K order: the same bits); cand_val / cand_idx [rows, bm]
+ *        = the bm best as log-probabilities (value desc, column asc), the format care_beam_advance reads.
+ *   A bf16 [M, lda] (lda % 8 == 0), W bf16 [N, K], K % 64 == 0, bm <= 5, 80 <= N <= 16384; gmax 16-byte aligned.
+ */
+int care_gemm_tile_beam(const void* A, int64_t lda, const void* W, float* pmax, float* psum, float* gmax, int M,
+                        int N, int K, void* stream);
+int care_beam_pick_groups(const float* pmax, const float* psum, const float* gmax, int parts, int bm, const void* A,
+                          int64_t lda, const void* W, int V, int K, float* cand_val, int32_t* cand_idx, int rows,
+                          void* stream);
+
+/*
  * care_beam_advance: one beam-search step for every clip (B clips x bm beams), on device.
  *   Replaces Beam.advance / Beam.done (misc/Decoding/Beam.py:38-85), the re-ordering of the
  *   beams' prefixes (Beam.get_tentative_hypothesis, :112-117) and the removal of finished

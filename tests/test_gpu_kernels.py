@@ -741,6 +741,45 @@ def test_fused_beam_selection_equals_logits_plus_beam_select(M, V, bm):
         assert (got_v[over] - ref_v[over]).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("M,V,K,bm", [(5, 10547, 512, 5), (300, 10547, 512, 5), (640, 10547, 512, 4), (130, 700, 512, 2), (64, 10547, 1024, 5),
+                                      (2560, 10547, 512, 5), (777, 9000, 768, 3), (33, 80, 512, 5)])
+def test_beam_selection_from_group_maxima_equals_logits_plus_beam_select(M, V, K, bm):
+    """care_gemm_tile_beam -> care_beam_pick_groups  ==  the logits of the SAME tile kernel + care_beam_select: identical
+    columns in identical order (the recomputed candidates are the tile kernel's bits), log-probabilities within 2e-5
+    (the log-sum-exp is merged from 64-column parts); with exact ties between columns, a plateau of equal logits across
+    groups and parts at the top of one row, and a ragged last part."""
+    from care_amd import _lib
+
+    A = _rand(M, K, seed=61).to(torch.bfloat16)
+    W = _rand(V, K, seed=62, scale=0.05).to(torch.bfloat16)
+    W[17] = W[40]                        # an exact tie between two columns of every row (same part, different groups)
+    if V > 5000:
+        W[3000:3100] = W[2999]           # a 101-column plateau over two parts ...
+        A[1] = (W[2999].float() * 40).to(torch.bfloat16)   # ... which IS the top of row 1: the bm lowest columns win
+    ld = (V + 63) // 64 * 64
+    logits = torch.empty(M, ld, device=DEV)
+    _call("care_gemm_tile", _p(A), K, _p(W), None, _p(logits), ld, 0, None, 0, 0, V, M, V, K, 0)
+    ref_v = torch.zeros(M, bm, device=DEV); ref_i = torch.zeros(M, bm, device=DEV, dtype=torch.int32)
+    _call("care_beam_select", _p(logits), ld, V, bm, _p(ref_v), _p(ref_i), M, 1)
+    parts = _lib.load().care_argmax_parts_tile(V)
+    pmax = torch.full((M, parts), float("nan"), device=DEV); psum = torch.full((M, parts), float("nan"), device=DEV)
+    gmax = torch.full((M, parts, 16), float("nan"), device=DEV)
+    got_v = torch.zeros(M, bm, device=DEV); got_i = torch.zeros(M, bm, device=DEV, dtype=torch.int32)
+    _call("care_gemm_tile_beam", _p(A), K, _p(W), _p(pmax), _p(psum), _p(gmax), M, V, K)
+    _call("care_beam_pick_groups", _p(pmax), _p(psum), _p(gmax), parts, bm, _p(A), K, _p(W), V, K, _p(got_v), _p(got_i), M)
+    torch.cuda.synchronize()
+    # the epilogue's statistics against the logits themselves
+    lg = logits[:, :V]
+    pad = torch.full((M, parts * 64 - V), float("-inf"), device=DEV)
+    blocks = torch.cat([lg, pad], 1).view(M, parts, 16, 4)
+    assert torch.equal(gmax, blocks.max(-1).values)
+    assert torch.equal(pmax, blocks.view(M, parts, 64).max(-1).values)
+    assert torch.equal(got_i, ref_i)     # bit-identical logits -> identical order, ties included
+    assert (got_v - ref_v).abs().max().item() < 2e-5
+    if V > 5000:
+        assert got_i[1].tolist() == [2999, 3000, 3001, 3002, 3003][:bm]
+
+
 TILE_SHAPES = [(1, 1024, 1024), (700, 520, 64), (300, 256, 128), (5, 10547, 1024), (64, 768, 768), (100, 3072, 1024), (257, 4096, 1024), (300, 1024, 4096),
                (130, 640, 640), (200, 768, 3072), (1000, 48, 512), (4096, 1024, 1024), (513, 10547, 768), (777, 2304, 768),
                (4096 + 19, 3072, 1024), (2048, 512, 2048)]
@@ -769,6 +808,39 @@ def test_gemm_tile(M, N, K, act, out_bf16, cfg, monkeypatch):
     torch.cuda.synchronize()
     assert (dst.double() - ref).abs().max().item() < (4e-2 if out_bf16 else 3e-3)
     assert float(out[M:].float().min()) == 7.0 and float(out[:, N:].float().min()) == 7.0
+
+
+@pytest.mark.parametrize("M,N,act,split", [(640, 1536, 0, True), (1280, 512, 0, False), (2560, 2048, 1, False), (4099, 512, 0, False),
+                                           (12000, 1536, 0, True), (16000, 2048, 2, False)])
+def test_tile_and_a_stationary_gemm_agree_bit_for_bit(M, N, act, split):
+    """engine.gemm moves the K = 512 products of a decode step from the A-stationary kernel (csrc/gemm_as.hip) to the
+    LDS-tiled one (csrc/gemm_tile.hip) between engine.MID_TILE_ROWS rows: both add K in ascending order into one
+    accumulator per output, so every output - fp32 or rounded to bf16, one destination or q | K,V split - is the same
+    bit pattern and the switch changes no caption at any batch size."""
+    K = 512
+    A = _rand(M, K, seed=81).to(torch.bfloat16).contiguous()
+    Wb = _rand(N, K, seed=82, scale=1 / math.sqrt(K)).to(torch.bfloat16).contiguous()
+    bias = _rand(N, seed=83)
+    outs = []
+    for fn in ("care_gemm_bf16", "care_gemm_tile"):
+        if split:   # q fp32 | K, V bf16 (the QKV product writes the cache directly)
+            o0 = torch.zeros(M, 512, device=DEV)
+            o1 = torch.zeros(M, N - 512, device=DEV, dtype=torch.bfloat16)
+            tail = (_p(bias), _p(o0), 512, 0, _p(o1), N - 512, 1, 512, M, N, K, act)
+        else:
+            o0 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16 if act else torch.float32)
+            o1 = None
+            tail = (_p(bias), _p(o0), N, 1 if act else 0, None, 0, 0, N, M, N, K, act)
+        if fn == "care_gemm_bf16":
+            _call(fn, _p(A), K, 1, _p(Wb), *tail)
+        else:
+            _call(fn, _p(A), K, _p(Wb), *tail)
+        outs.append((o0, o1))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0])
+    if split:
+        assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].float().abs().max()) > 0.1
 
 
 def test_gemm_tile_split_destinations_and_odd_leading_dimension():
