@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the captioning hot path (BASELINE.json metric: greedy captions/sec + decoder-step us).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|fp32] [--config NAME]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|fp16|fp32|fp16x3] [--config NAME]
 
 One "step" = one full pass of the hot path over one batch of B synthetic clips per GPU:
 per-modality embedding -> (concept head) -> cross-K/V projection -> 29 greedy decoder
@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3, "fp16x3": 2500.0 / 3}   # fp16x3: three 16-bit MFMA passes per product
+MFMA_PEAK_TF = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp16x3": 2500.0 / 3}   # fp16x3: three 16-bit MFMA passes per product
 
 
 def parse():
@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32768, help="clips per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp16x3"])
     ap.add_argument("--config", default="msrvtt_base_ami")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--beam", type=int, default=1, help="beam size > 1: time the beam-search pass instead (extra, "
@@ -67,19 +67,35 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _visible_gpus() -> int:
+    """GPUs this process could use, counted WITHOUT touching the HIP runtime (the relaunch below must come from a process
+    that never initialised the GPU): the render nodes of /dev/dri, cut by HIP / ROCR_VISIBLE_DEVICES when set."""
+    import glob
+    n = len(glob.glob("/dev/dri/renderD*"))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` outside torchrun: start `torch.distributed.run --nproc-per-node N bench.py ...` as a
-    CHILD process - this process has not touched the GPU (torch.cuda.device_count() does not initialise it), and it is
-    never replaced by exec - relay the child's output (rank 0's JSON line) and return its exit code."""
+    CHILD process (subprocess - never os.exec*: on this pool a process that has initialised the GPU must not be
+    replaced, and this one stays a plain parent that has not touched the HIP runtime at all: the GPU count comes from
+    /dev/dri), relay the child's output (rank 0's JSON line) and return its exit code.  Every rank also exits with
+    `no GPU` on its own when its device is missing."""
     import subprocess
 
     if not args.dry_run:
-        have = torch.cuda.device_count()
-        if have < args.gpus:
+        have = _visible_gpus()
+        if have < args.gpus and not (have == 0 and os.path.exists("/dev/kfd")):  # (no render nodes listed but a KFD: unknown - let the ranks say)
             sys.stderr.write("bench.py: --gpus {} but this host has {} GPU(s) visible\n".format(args.gpus, have))
             return 2
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun picks the rendezvous port itself (c10d on a free port of 127.0.0.1) - no port chosen here
+    # and released before torchrun binds it, so concurrent self-launches cannot collide
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.run(cmd, env=env).returncode
 
@@ -116,7 +132,7 @@ def dry_run(args, world: int, rank: int) -> None:
 def kernel_model(tag, eng, B, dtype):
     """Algorithmic bytes and flops of ONE launch of a tagged kernel."""
     d, H, ff, V, Lk, T = eng.d, eng.H, eng.ff, eng.V, eng.Lk, eng.T
-    es = 2 if dtype == "bf16" else 4
+    es = 2 if dtype in ("bf16", "fp16") else 4
     if tag == "step_cross_attn" and eng.latent_for(B):
         # absorbed form: ONE bf16 copy of the clip's memory, expanded query in, latent context out
         return dict(bytes=B * (Lk * d * 2 + 2 * H * d * 2), flops=B * 4.0 * H * Lk * d, bound="hbm")
@@ -685,7 +701,7 @@ def main():
     line = dict(
         metric="captions/sec (greedy)", value=round(value, 1), unit="captions/s", n_gpus=world, steps=args.steps,
         warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak",
-        vs_baseline=None, dtype={"bf16": "bf16", "fp32": "f32", "fp16x3": "f16x3"}[args.dtype], data="synthetic",
+        vs_baseline=None, dtype={"bf16": "bf16", "fp16": "f16", "fp32": "f32", "fp16x3": "f16x3"}[args.dtype], data="synthetic",
         config=dict(workload="MSRVTT Transformer/base task=Base feats=ViT modality=ami greedy "
                              "(BASELINE.json configs[1]): [B,28,128]+[B,28,2048]+[B,28,512] fp32 feats, d=512, "
                              "V=10547, 29 decoder steps" if args.config == "msrvtt_base_ami" else args.config,

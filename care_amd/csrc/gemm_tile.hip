@@ -442,6 +442,11 @@ int dispatch(TArgs& p, hipStream_t st) {
     case 212: return launch_tile<2, 1, 1, 2, EPI>(p, st);   // 128 x 64, 2 waves
     case 242: return launch_tile<2, 4, 1, 2, EPI>(p, st);   // 128 x 256, 8 waves
     case 2223: return launch_tile<2, 2, 2, 3, EPI>(p, st);
+    case 112: return launch_tile<1, 1, 1, 2, EPI>(p, st);   // 64 x 64, ONE wave: few-row products that a 128 x 128 tiling
+    case 114: return launch_tile<1, 1, 1, 4, EPI>(p, st);   // leaves on a fraction of the CUs (640 x 512: 20 tiles)
+    case 124: return launch_tile<1, 2, 1, 4, EPI>(p, st);
+    case 214: return launch_tile<2, 1, 1, 4, EPI>(p, st);
+    case 224: return launch_tile<2, 2, 1, 4, EPI>(p, st);   // 128 x 128, four stages of 32 KB
     default: return launch_tile<2, 2, 1, 2, EPI>(p, st);
   }
 }

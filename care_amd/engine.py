@@ -28,47 +28,14 @@ import torch
 from . import _lib
 from ._lib import ACT_CODES, CARE_BF16, CARE_F32, ptr
 from .constants import BOS, EOS, PAD
+from .engine_beam import BeamMixin
+from .engine_decode import DecodeMixin
+from .engine_encode import EncodeMixin
+from .engine_resident import ResidentMixin
+from .engine_util import _LaneOutputs, _code  # noqa: F401
 
 
-def _code(t: Optional[torch.Tensor]) -> int:
-    return CARE_BF16 if (t is not None and t.dtype in (torch.bfloat16, torch.float16)) else CARE_F32  # (CARE_BF16: the library's 16-bit type)
-
-
-class _LaneOutputs(dict):
-    """Encoder outputs of a pass that ran as several batch lanes.  Every value is per clip (first
-    dim = clips of the lane), so the full-batch tensor is the concatenation of the lanes'; it is
-    built on access only - the captioning loop never reads these (translator.py), and
-    `encoder_hidden_states` alone is 2.9 GB at B = 16384."""
-
-    def __init__(self, parts):
-        super().__init__((k, None) for k in parts[0])
-        self._parts = parts
-
-    @staticmethod
-    def _join(vals):
-        if vals[0] is None:
-            return None
-        if isinstance(vals[0], (list, tuple)):
-            return [torch.cat([v[i] for v in vals], 0) for i in range(len(vals[0]))]
-        return torch.cat(vals, 0)
-
-    def __getitem__(self, k):
-        super().__getitem__(k)  # KeyError for unknown names
-        # joined on EVERY access: the lanes' tensors are static graph outputs that the next replay
-        # overwrites, so a cached concatenation would go stale
-        return self._join([pt[k] for pt in self._parts])
-
-    def get(self, k, default=None):
-        return self[k] if k in self else default
-
-    def items(self):
-        return [(k, self[k]) for k in self]
-
-    def values(self):
-        return [self[k] for k in self]
-
-
-class HipEngine:
+class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
     def __init__(self, opt: dict, dtype: str = "fp32"):
         if dtype not in ("fp32", "bf16", "fp16", "fp16x3"):
             raise ValueError("compute dtype must be 'fp32', 'bf16', 'fp16' or 'fp16x3', got {!r}".format(dtype))
@@ -403,52 +370,6 @@ class HipEngine:
         """dtype of activations that are ONLY GEMM inputs (attention context, FFN hidden)."""
         return self.h16 if self.bf_act else torch.float32
 
-    # Rows (clips x beam) from which the per-row top-k of beam search runs as two passes of the vocabulary GEMM on the
-    # 256-row panels (statistics -> threshold -> sparse collect -> pick: no [rows, V] logits in memory).  Below it the
-    # 16-bit modes take ONE pass of the LDS-tiled kernel that keeps group maxima (beam_groups_for; round 5), fp32 mode and
-    # beam sizes above 5 the materialised logits + care_beam_select.  All forms pick the same columns in the same order
-    # (tests/test_gpu_kernels.py::test_fused_beam_selection_..., test_beam_selection_from_group_maxima_...).
-    # *Measured* round 5 (beam 5, us per step of the whole pass, groups / two-pass): 5120 rows 422 / 497, 10240 rows 726 /
-    # 700, 20480 rows 1266 / 1162 - the group maxima are 12 KB per row and step.  Fixed for a pass by its INITIAL row count.
-    BEAM_FUSED_MIN_ROWS = int(os.environ.get("CARE_BEAM_FUSED_MIN_ROWS", "8192"))
-
-    def _beam_sparse_ws(self, tag: str, rows: int):
-        """Workspaces of the sparse second pass (csrc/beam_sparse.hip) - (tile maxima [tiles, rows] fp32, per-tile
-        row counts + work-unit prefix sums [2 tiles + 1], per-tile row lists [tiles, rows]) - or None where the 256-row statistics kernel does not apply."""
-        if os.environ.get("CARE_BEAM_SPARSE", "1") == "0" or not self.lib.care_beam_sparse_applies(rows, self.V, self.d, 1):
-            return None
-        tiles = (self.V + 31) // 32
-        return (self.ws(tag + "stmax", (tiles, rows)), self.ws(tag + "stcount", (2 * tiles + 1,), torch.int32),
-                self.ws(tag + "stlist", (tiles, rows), torch.int32))
-
-    def beam_fused_for(self, rows: int) -> bool:
-        if os.environ.get("CARE_BEAM_FUSED", "1") == "0":
-            return False
-        return self.as_ok and rows >= self.BEAM_FUSED_MIN_ROWS
-
-    # Beam selection below BEAM_FUSED_MIN_ROWS in the 16-bit modes (beam_size <= 5): the vocabulary product on the LDS-tiled
-    # kernel keeping per (row, 64-column part) the maximum, sum exp and the maxima of its sixteen 4-column groups
-    # (care_gemm_tile_beam), then one wave per row picks the bm best groups and recomputes their 4 bm logits
-    # (care_beam_pick_groups) - two launches and 12 KB per row instead of the [rows, V] fp32 logits written and read back
-    # (*measured* round 5, beam 5, us per step of the whole multi-launch pass, logits + care_beam_select / groups: 160 rows
-    # 183 / 175, 640 rows 229 / 213, 1280 rows 274 / 245, 2560 rows 320 / 284).
-    # The form is fixed for a pass by its INITIAL row count, like the fused two-pass selection's.
-    BEAM_GROUPS_MIN_ROWS = int(os.environ.get("CARE_BEAM_GROUPS_MIN_ROWS", "1"))
-
-    def beam_groups_for(self, rows: int, bm: int) -> bool:
-        rows = self._form_rows or rows
-        return bool(self.bf_act and not self.beam_fused_for(rows) and bm <= 5 and rows >= self.BEAM_GROUPS_MIN_ROWS and
-                    80 <= self.V <= 16384 and self.d % 64 == 0)
-
-    def _beam_groups_select(self, tag, xb, N, bm, cval, cidx):
-        parts = (self.V + 63) // 64
-        pmax, psum = self.ws(tag + "gpmax", (N, parts)), self.ws(tag + "gpsum", (N, parts))
-        gmax = self.ws(tag + "ggmax", (N, parts, 16))
-        self.call("care_gemm_tile_beam", ptr(xb), xb.stride(0), ptr(self.w["vocab"]), ptr(pmax), ptr(psum), ptr(gmax), N, self.V,
-                  self.d, tag="beam_vocab_groups")
-        self.call("care_beam_pick_groups", ptr(pmax), ptr(psum), ptr(gmax), parts, bm, ptr(xb), xb.stride(0), ptr(self.w["vocab"]),
-                  self.V, self.d, ptr(cval), ptr(cidx), N, tag="beam_pick_groups")
-
     def wsb(self, name: str, shape) -> Optional[torch.Tensor]:
         """bf16 mirror workspace of a GEMM-input activation (None unless as_ok)."""
         return self.ws(name + "#bf", shape, self.h16) if self.bf_act else None
@@ -591,950 +512,6 @@ class HipEngine:
              ptr(bias), bias.stride(0) if bias is not None else 0, ptr(probs), rows, self.H)
         return probs
 
-    def _ctx(self, tag, rows):
-        """Attention context buffer: only ever read by the output projection GEMM."""
-        return self.ws(tag + "ctx", (rows, self.d), self.act_dtype)
-
-    def _mha_self_full(self, name, x, xb, seq, pad_tok, causal, tag, aux=None):
-        """Self-attention sub-block over whole sequences (teacher forcing / encoder).
-        x fp32 (residual), xb its bf16 mirror or None.  Returns (x1, x1b).
-        aux (dict): also the attention probabilities and the pre-residual projection (`text_context`)."""
-        rows, d = x.shape
-        w = self.w
-        qkv = self.gemm(xb if xb is not None else x, w[name + "_qkv_w"], w[name + "_qkv_b"],
-                        self.ws(tag + "qkv", (rows, 3 * d)))
-        ctx = self.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], self._ctx(tag, rows), seq * 3 * d, 3 * d,
-                             seq, seq, causal=causal, seq=seq, pad_tok=pad_tok)
-        o = self.gemm(ctx, w[name + "_o_w"], w[name + "_o_b"], self.ws(tag + "o", (rows, d)))
-        x1, x1b = self.ws(tag + "x1", (rows, d)), self.wsb(tag + "x1", (rows, d))
-        self.add_ln(o, x, w[name + "_g"], w[name + "_be"], x1, x1b)
-        if aux is not None:
-            aux["probs"] = self.attention_probs(qkv, qkv[:, d:], seq * 3 * d, 3 * d, seq, seq, causal=causal, seq=seq,
-                                                pad_tok=pad_tok)
-            aux["context"], aux["embs"] = o.clone(), x1.clone()
-        return x1, x1b
-
-    def _ffn(self, name, x, xb, out, outb, tag, gemm_tag=None, fuse=None, **ln_kw):
-        rows, d = x.shape
-        w = self.w
-        fuse = self.ln_fusable(rows) if fuse is None else fuse
-        split = self.as_ok and self.ff % 512 == 0 and self.ff >= 1024
-        h = self.gemm(xb if xb is not None else x, w[name + "_w1"], w[name + "_b1"],
-                      self.ws(tag + "h", (rows, self.ff), self.h16 if (split or self.bf_act) else torch.float32),
-                      act=self.act, tag=gemm_tag)
-        w2 = w[name + "_w2"]
-        if split and fuse and not ln_kw.get("pos"):
-            # dense2 + bias + residual + LayerNorm in one kernel: no split-K slabs at all
-            return self.gemm_ln(h, w2, w[name + "_b2"], x, w[name + "_g"], w[name + "_be"], out, outb,
-                                tag=(gemm_tag + "_ln") if gemm_tag else None, Wp=w.get(name + "_w2#packed"), **ln_kw)
-        if split and rows < int(os.environ.get("CARE_FFN2_TILE_ROWS", str(self.FFN2_TILE_MIN_ROWS))):
-            # K = ff > 512: split K over blocks into fp32 slabs; the LayerNorm kernel sums them
-            ns = self.ff // 512
-            f = self.ws(tag + "fslab", (ns, rows, d))
-            self.call("care_gemm_bf16_splitk", ptr(h), h.stride(0), _code(h), ptr(w2), ptr(w[name + "_b2"]), ptr(f), d,
-                 f.stride(0), rows, d, self.ff, tag=gemm_tag)
-            return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, nslab=ns,
-                               tag="step_add_ln" if gemm_tag else None, **ln_kw)
-        f = self.gemm(h, w2, w[name + "_b2"], self.ws(tag + "f", (rows, d)), tag=gemm_tag)
-        return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, tag="step_add_ln" if gemm_tag else None, **ln_kw)
-
-    # ------------------------------------------------------------------ encoder + concept head
-    @property
-    def lean_ok(self) -> bool:
-        """The captioning loop of a model WITHOUT a concept head consumes nothing of the encoder but the
-        bf16 memory (the A operand of the cross-K/V projection, or what the absorbed cross-attention
-        reads).  `encode(..., lean=True)` then skips what nobody reads: the fp32 copy of the memory
-        (5.6 GB of stores at B = 32768) and the per-modality frame means (a second pass over it)."""
-        if os.environ.get("CARE_LEAN", "1") == "0":  # A/B switch
-            return False
-        return (self.as_ok and self.d == 512 and not self.has_concepts and self.opt["encoder"] == "Embedder" and
-                all(ch in self.dec_mod and int(self.opt["dim_" + ch]) % 32 == 0 for ch in self.modality))
-
-    @property
-    def feats_bf16_ok(self) -> bool:
-        """bf16 feature tensors are taken as they are (no widening copy): the fused embedder of a model without a
-        concept head multiplies bf16-rounded features anyway, so features a loader rounded on the host (the same
-        round-to-nearest-even) give bit-identical products at half the PCIe / HBM bytes."""
-        return (self.as_ok and self.d == 512 and not self.has_concepts and self.opt["encoder"] == "Embedder" and
-                all(int(self.opt["dim_" + ch]) % 128 == 0 for ch in self.modality))
-
-    def _prep_one(self, f):
-        if f.dtype == self.h16 and self.feats_bf16_ok:
-            return f.to(self.device).contiguous()
-        return f.to(self.device, torch.float32).contiguous()
-
-    def _prep_feats(self, feats):
-        return [self._prep_one(f) for f in feats[: len(self.modality)]]
-
-    def encode(self, feats: List[torch.Tensor], lean: bool = False, static: bool = False, small: bool = False) -> Dict[str, torch.Tensor]:
-        """`Seq2SeqBase.encoding_phase` (models/Framework.py:150-187); outputs are fresh tensors.
-        lean (translate path only, see lean_ok): returns just {"encoder_hidden_states": bf16 memory}.
-        static (translate path only): the memory lives in engine-owned buffers that the next call
-        overwrites - so that decode segments captured as hipGraphs keep reading valid addresses.
-        small (the resident decode's batches, <= resident_max_rows clips): the embedder as GEMM + LayerNorm launches
-        instead of the fused kernel, whose 128-row blocks leave most of the chip idle below ~1000 clips (*measured*
-        128 clips: 118 us per modality fused)."""
-        w, d, opt = self.w, self.d, self.opt
-        if len(feats) < len(self.modality):
-            raise ValueError("expected {} feature tensors, got {}".format(len(self.modality), len(feats)))
-        B = feats[0].shape[0]
-        lean = lean and self.lean_ok
-        new = (lambda name, shape, dt=torch.float32: self.ws("enc_out_" + name, shape, dt)) if static else \
-              (lambda name, shape, dt=torch.float32: torch.empty(shape, device=self.device, dtype=dt))
-        mem = None if lean else new("mem", (B, self.Lk, d))
-        memb = new("memb", (B, self.Lk, d), self.h16) if self.bf_act else None
-        means = None if lean else new("means", (B, len(self.modality) * d))
-        # small batches, Embedder: the modalities' launches are a few microseconds of latency-bound work each - they run
-        # side by side on streams of their own (forked from / joined to the caller's stream; also inside a capture)
-        cur = torch.cuda.current_stream()
-        side = []
-        if small and opt["encoder"] == "Embedder" and len(self.modality) > 1:
-            if len(getattr(self, "_enc_streams", ())) < len(self.modality) - 1:
-                self._enc_streams = [torch.cuda.Stream(device=self.device) for _ in range(len(self.modality) - 1)]
-            side = self._enc_streams[: len(self.modality) - 1]
-        for mi, ch in enumerate(self.modality):
-            st = side[mi - 1] if side and mi > 0 else None
-            sfx = "_" + ch if side else ""
-            if st is not None:
-                st.wait_stream(cur)
-            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-                x = self._prep_one(feats[mi])
-                n = x.shape[1]
-                if n != self.rows_of[ch]:
-                    raise ValueError("modality `{}`: {} rows, expected {}".format(ch, n, self.rows_of[ch]))
-                x2 = x.view(B * n, x.shape[2])
-                Ws = w.get("enc_w_" + ch + "#split")
-                fused = (opt["encoder"] == "Embedder" and self.as_ok and d == 512 and
-                         (w["enc_w_" + ch].dtype == self.h16 or Ws is not None) and x2.shape[1] % 32 == 0)
-                if small and fused and (Ws is None or w.get("enc_w_" + ch + "#split3") is not None):
-                    fused = False  # (concept models: the split products through the LDS-tiled kernel, below)
-                W3 = w.get("enc_w_" + ch + "#split3")
-                if fused:
-                    lin = None
-                elif W3 is not None:
-                    lin = self.ws("enc_lin" + sfx, (B * n, d))
-                    if os.environ.get("CARE_ENC_TILE", "1") != "0":  # fp16 pieces of the features once, then the LDS-tiled kernel
-                        a2 = self.ws("enc_a2" + sfx, (B * n, 2 * x2.shape[1]), torch.float16)
-                        self.call("care_split2_act", ptr(x2), x2.stride(0), ptr(a2), B * n, x2.shape[1], tag="enc_split")
-                        self.call("care_gemm_tile_split3", ptr(a2), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0), CARE_F32,
-                             None, 0, 0, d, B * n, d, x2.shape[1], 0, tag="enc_gemm")
-                    else:
-                        self.call("care_gemm_split3", ptr(x2), x2.stride(0), ptr(W3), ptr(w["enc_b_" + ch]), ptr(lin), lin.stride(0),
-                             B * n, d, x2.shape[1], tag="enc_gemm")
-                else:
-                    lin = self.gemm(x2, w["enc_w_" + ch], w["enc_b_" + ch], self.ws("enc_lin" + sfx, (B * n, d)), tag="enc_gemm")
-                in_mem = ch in self.dec_mod
-                if in_mem:
-                    dst, dstb, grp_rows, off = mem, memb, self.Lk, self.mem_off[ch]
-                    if dst is None and not fused:  # lean + unfused: the LayerNorm kernel writes an fp32 row too
-                        dst = self.ws("enc_mem_f32", (B, self.Lk, d))
-                else:
-                    dst, dstb, grp_rows, off = self.ws("enc_side_" + ch, (B, n, d)), None, n, 0
-                ln_kw = dict(grp=n, out_grp_rows=grp_rows, out_row_off=off)
-                if fused and Ws is not None:  # the same, fp32 operands as hi/lo fp16 pieces (concept models)
-                    self.call("care_gemm_ln_split", ptr(x2), x2.stride(0), ptr(Ws), ptr(w["enc_b_" + ch]), ptr(w["enc_g_" + ch]),
-                         ptr(w["enc_be_" + ch]), self.eps, ptr(dst), ptr(dstb), dst.stride(-2), B * n, d, x2.shape[1], n,
-                         grp_rows, off, tag="enc_gemm")
-                elif fused:  # Linear + bias + LayerNorm in one kernel, raw fp32 features streamed by LDS-DMA
-                    self.gemm_ln(x2, w["enc_w_" + ch], w["enc_b_" + ch], None, w["enc_g_" + ch], w["enc_be_" + ch],
-                                 dst, dstb, tag="enc_gemm", Wp=w.get("enc_w_" + ch + "#packed"), **ln_kw)
-                elif opt["encoder"] == "Embedder":
-                    self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], dst, dstb, **ln_kw)
-                else:  # MultiTransformerEncoder
-                    h, hb = self.ws("enc_h0", (B * n, d)), self.wsb("enc_h0", (B * n, d))
-                    self.add_ln(lin, None, w["enc_g_" + ch], w["enc_be_" + ch], h, hb, grp=n, pos=w["enc_pos_" + ch])
-                    n_enc = int(opt["num_hidden_layers_encoder"])
-                    for li in range(n_enc):
-                        nm = "enc{}{}".format(ch, li)
-                        h1, h1b = self._mha_self_full(nm + "_sa", h, hb, n, None, False, "enc_")
-                        if li == n_enc - 1:
-                            self._ffn(nm + "_ffn", h1, h1b, dst, dstb, "enc_", **ln_kw)
-                        else:
-                            h, hb = self.ws("enc_h%d" % (li + 1), (B * n, d)), self.wsb("enc_h%d" % (li + 1), (B * n, d))
-                            self._ffn(nm + "_ffn", h1, h1b, h, hb, "enc_")
-                if not lean:
-                    self.call("care_group_mean", ptr(dst), d, grp_rows, off, n, ptr(means), means.stride(0), mi * d, B, d)
-        for st in side:
-            cur.wait_stream(st)
-        if lean:
-            return {"encoder_hidden_states": memb}
-        out: Dict[str, torch.Tensor] = {"encoder_hidden_states": mem}
-        out["mean_encoder_hidden_states"] = [means[:, mi * d:(mi + 1) * d] for mi, ch in enumerate(self.modality)
-                                             if ch in self.dec_mod]
-        if self.has_concepts:
-            if self.pred_mod == self.modality:
-                pm = means
-            else:
-                pm = torch.cat([means[:, mi * d:(mi + 1) * d] for mi, ch in enumerate(self.modality)
-                                if ch in self.pred_mod], dim=1).contiguous()
-            kp = self._kpad()
-            scores = self.gemm(pm, w["attr_w"], w["attr_b"], self.ws("attr_scores", (B, kp)))
-            preds = new("preds", (B, kp))
-            avg = new("avg", (B,))
-            self.call("care_concept_finish", ptr(scores), kp, ptr(preds), kp, ptr(avg), B, self.k_attr)
-            out["preds_attr"] = preds[:, : self.k_attr]
-            out["avg_prob_attr"] = avg
-            if self.has_container:
-                labels = new("labels", (B, self.topk), torch.int64)
-                if self.concat:
-                    dst, dstb, grp_rows, off = mem, memb, self.Lk, self.concept_off
-                else:
-                    dst, dstb, grp_rows, off = new("sem_embs", (B, self.topk, d)), None, self.topk, 0
-                self.call("care_concept_topk_embed", ptr(preds), kp, self.k_attr, self.topk, ptr(w["attr_word"]),
-                     ptr(w["attr_pos"]), ptr(w["attr_g"]), ptr(w["attr_be"]), self.eps, ptr(labels), ptr(dst),
-                     ptr(dstb), d, grp_rows, off, B, d)
-                out["semantic_labels"] = labels
-                out["semantic_embs"] = dst[:, off: off + self.topk]
-                if self.sem:
-                    out["semantic_hidden_states"] = self.gemm(preds, w["s2h_w"], w["s2h_b"], new("sem_hidden", (B, d)))
-                else:
-                    out["semantic_hidden_states"] = None
-        # bf16 mirror of the memory: the A operand of the cross-K/V projection (internal).  Matched by
-        # tensor IDENTITY (weakref), not by address: another tensor may later live at the same address.
-        self._mem_mirror = (weakref.ref(mem), memb)
-        return out
-
-    # ------------------------------------------------------------------ cross K/V (once per clip)
-    # the resident decodes' cross K/V from this many memory rows up go through the LDS-tiled GEMM: the A-stationary kernels
-    # want many 128- / 256-row panels, and 128 clips are 42 panels of 256 on 256 CUs (*measured* 10752 x 1024 x 512:
-    # 36.4 against 19.6 us; 5376 rows 20.6 / 12.6; 84 rows 6.1 / 8.1 - below the threshold nothing changes)
-    # Round 5 (ADVICE r4): the small-batch decodes take the LDS-tiled kernel at EVERY row count - one kernel, one K order (K
-    # steps of 64 into one accumulator per output, whatever the tile shape), so a clip's K/V bits do not depend on the batch
-    # it rides in (84 rows: + 2 us per pass).  -1: the A-stationary kernel instead (tuning).
-    RESIDENT_CKV_TILE_ROWS = 0
-
-    def cross_kv(self, mem: torch.Tensor, tag="ckv", resident=False) -> List[torch.Tensor]:
-        """K/V of the static memory for every decoder layer: [B, Lk, 2d] in the weight dtype.
-
-        The reference re-projects them at every step for every beam copy
-        (Attention.py:63-67 called from Layers.py:206-213); here once per clip.
-        `resident`: for the one-launch decodes of small batches (their own form of the arithmetic already, resident_ok).
-        """
-        B, Lk, d = mem.shape
-        mem = mem.contiguous()
-        ref, memb = getattr(self, "_mem_mirror", (None, None))
-        src = memb if (self.bf_act and memb is not None and ref is not None and ref() is mem) else mem
-        src2 = src.view(B * Lk, d)
-        out = []
-        for li in range(self.n_layers):
-            nm = "d{}_ca".format(li)
-            kv = self.ws("{}{}".format(tag, li), (B * Lk, 2 * d), self.wt)
-            out.append(self.gemm(src2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv, tag="cross_kv_gemm",
-                                 tile=resident and src2.dtype == self.h16 and self.RESIDENT_CKV_TILE_ROWS >= 0))
-        return out
-
-    LATENT_MIN_ROWS = 1
-
-    def latent_for(self, rows: int) -> bool:
-        """Absorbed cross-attention for a decode over `rows` rows?  The FORM OF THE ARITHMETIC is a
-        property of the model and its compute mode (bf16, d_model = 512: absorbed; otherwise projected
-        K/V), NOT of the batch a clip happens to be in: the two forms are two bf16 roundings of the same
-        algebra, and switching between them by row count (round 1: from 2048 rows) made a clip's
-        caption depend on the size of its batch wherever two tokens were nearly tied.  The price: the
-        absorbed form has two more launches per step, which small, launch-bound batches feel
-        (*measured* round 1: -15% at 32 rows, -1% at 1024; +5% at 2048, +13% at 16384).
-        `engine.latent = False` (CARE_LATENT=0) selects projected K/V for every size instead;
-        LATENT_MIN_ROWS > 1 restores a row threshold (tuning only).
-        This is the MULTI-LAUNCH decode.  Greedy batches of <= resident_max_rows clips (256) take the resident decode
-        instead (resident_ok): one launch, projected K/V - a deliberate exception to the rule above, bought with
-        2 x the small-batch step rate; `resident_max_rows = 0` restores one form at every size."""
-        return self.latent_ok and rows >= self.LATENT_MIN_ROWS and not getattr(self, "_small_pass", False)
-
-    Q_TILE_MIN_ROWS = int(os.environ.get("CARE_Q_TILE_MIN_ROWS", "8192"))
-
-    def cross_src(self, mem: torch.Tensor, rows: int):
-        """What the decoder's cross-attention reads at every step: per-layer projected K/V
-        (cross_kv, a list of [B*Lk, 2d] tensors), or - absorbed form - the bf16 memory itself
-        ([B, Lk, d], shared by all layers; a tuple marks it)."""
-        if not self.latent_for(rows):
-            return self.cross_kv(mem)
-        mem = mem.contiguous()
-        if mem.dtype == self.h16:  # lean encode: the bf16 memory is all there is
-            return (mem,) * self.n_layers
-        ref, memb = getattr(self, "_mem_mirror", (None, None))
-        if not (memb is not None and ref is not None and ref() is mem):
-            memb = self.ws("lat_mem", tuple(mem.shape), self.h16)
-            memb.copy_(mem)
-        return (memb,) * self.n_layers
-
-    def attr_kv(self, sem_embs: torch.Tensor, tag="akv") -> Optional[List[torch.Tensor]]:
-        """K/V of the concept embeddings [B, topk, d] for the attr_attention block (CABase)."""
-        if not self.attr_att:
-            return None
-        B, n, d = sem_embs.shape
-        src = sem_embs.to(self.device, torch.float32).contiguous().view(B * n, d)
-        if self.bf_act:  # the bf16 kernels want a bf16 operand
-            srcb = self.ws(tag + "_srcb", (B * n, d), self.h16)
-            srcb.copy_(src)
-            src = srcb
-        out = []
-        for li in range(self.n_layers):
-            nm = "d{}_aa".format(li)
-            kv = self.ws("{}{}".format(tag, li), (B * n, 2 * d), self.wt)
-            out.append(self.gemm(src, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv))
-        return out
-
-    def _attr_block(self, li, x, xb, akv, rows_per_clip, tag, aux=None):
-        """Third post-LN attention block over the concept rows (Layers.py:139-154,218-225)."""
-        w, d = self.w, self.d
-        rows = x.shape[0]
-        nm = "d{}_aa".format(li)
-        q = self.gemm(xb if xb is not None else x, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q3", (rows, d)))
-        kv = akv[li]
-        ctx = self.attention(q, kv, kv[:, d:], self._ctx(tag, rows), self.topk * 2 * d, 2 * d, rows_per_clip,
-                             self.topk)
-        o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (rows, d)))
-        y, yb = self.ws(tag + "x2a", (rows, d)), self.wsb(tag + "x2a", (rows, d))
-        self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], y, yb)
-        if aux is not None:
-            aux["probs"] = self.attention_probs(q, kv, self.topk * 2 * d, 2 * d, rows_per_clip, self.topk)
-        return y, yb
-
-    # ------------------------------------------------------------------ teacher-forced decoder
-    def tf_fast_ok(self, t: int, want_aux: bool) -> bool:
-        """Teacher-forced forward on the fast kernels (_decode_full_fast): bf16 mode, d_model = 512, no auxiliary
-        dict entries (attention probabilities etc. are not materialised by the fused kernels)."""
-        return (self.as_ok and self.d == 512 and not want_aux and t <= 32 and
-                os.environ.get("CARE_TF_FAST", "1") != "0")
-
-    def _dense_ln(self, ctx, name, res, out, outb, rows, tag):
-        """dense -> (+ residual) -> LayerNorm of an attention block (SubLayers.py:69-79): one fused kernel from
-        ~10 K rows (ln_fusable), the A-stationary GEMM + LayerNorm pair below."""
-        w = self.w
-        if self.ln_fusable(rows):
-            return self.gemm_ln(ctx, w[name + "_o_w"], w[name + "_o_b"], res, w[name + "_g"], w[name + "_be"], out, outb,
-                                tag=tag + "_ln", Wp=w.get(name + "_o_w#packed"))
-        o = self.gemm(ctx, w[name + "_o_w"], w[name + "_o_b"], self.ws("tf_o", (rows, self.d)), tag=tag + "_gemm")
-        return self.add_ln(o, res, w[name + "_g"], w[name + "_be"], out, outb)
-
-    def _decode_full_fast(self, x, xb, ids32, N, t, B, Lk, per_clip, ckv, akv, want_logits, hidden_fp32=True):
-        """The teacher-forced decoder (Decoder/Transformer.py:161-268 with Lq = t) on the kernels of the decode path:
-        bf16 QKV / Wq / FFN1 through the store GEMMs, dense + residual + LayerNorm and FFN2 fused (gemm_ln), and both
-        attentions through care_attention_seq - one wave per (sequence, head), the keys and values of a sequence read
-        once for its t query positions, QK^T and PV on the matrix cores.  Same operand roundings as a decode step
-        (bf16 GEMM inputs, fp32 residual stream and statistics)."""
-        w, d, H = self.w, self.d, self.H
-        rows = N * t
-        bfw = lambda name, shape: self.ws(name, shape, self.h16)
-        ctx = bfw("tf_ctxb", (rows, d))
-        for li in range(self.n_layers):
-            nm = "d{}_sa".format(li)
-            qkv = self.gemm(xb, w[nm + "_qkv_w"], w[nm + "_qkv_b"], bfw("tf_qkvb", (rows, 3 * d)), tag="tf_qkv_gemm")
-            self.call("care_attention_seq", ptr(qkv), 3 * d, ptr(qkv[:, d:]), ptr(qkv[:, 2 * d:]), t * 3 * d, 3 * d, 1, t, 1, t,
-                 ptr(ids32), t, PAD, None, 0, ptr(ctx), d, N, H, tag="tf_self_attn")
-            x1, x1b = self.ws("tf_x1", (rows, d)), self.wsb("tf_x1", (rows, d))
-            self._dense_ln(ctx, nm, x, x1, x1b, rows, "tf_dxd")
-            nm = "d{}_ca".format(li)
-            hb = w["d{}_hb".format(li)]
-            q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm")
-            kv = ckv[li]
-            self.call("care_attention_seq", ptr(q2), d, ptr(kv), ptr(kv[:, d:]), Lk * 2 * d, 2 * d, per_clip, Lk, 0, t,
-                 None, 0, PAD, ptr(hb), hb.stride(0) if hb is not None else 0, ptr(ctx), d, N, H, tag="tf_cross_attn")
-            x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
-            self._dense_ln(ctx, nm, x1, x2, x2b, rows, "tf_dxd")
-            if self.attr_att:
-                nm = "d{}_aa".format(li)
-                q3 = self.gemm(x2b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm")
-                kv = akv[li]
-                self.call("care_attention_seq", ptr(q3), d, ptr(kv), ptr(kv[:, d:]), self.topk * 2 * d, 2 * d, per_clip,
-                     self.topk, 0, t, None, 0, PAD, None, 0, ptr(ctx), d, N, H, tag="tf_attr_attn")
-                y, yb = self.ws("tf_x2a", (rows, d)), self.wsb("tf_x2a", (rows, d))
-                self._dense_ln(ctx, nm, x2, y, yb, rows, "tf_dxd")
-                x2, x2b = y, yb
-            last = li == self.n_layers - 1
-            xb = self.wsb("tf_x3", (rows, d))
-            if last and not hidden_fp32 and self.ln_fusable(rows) and self.ff % 512 == 0 and self.ff >= 1024:
-                x = None  # scoring only reads the bf16 mirror
-            else:
-                x = torch.empty(rows, d, device=self.device) if last else self.ws("tf_x3", (rows, d))
-            self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, "tf_", gemm_tag="tf_ffn_gemm")
-        self._last_tf_bf16 = xb
-        out = {"hidden_states": x.view(N, t, d) if x is not None else None}
-        if want_logits == "all":
-            out["logits"] = self.gemm(xb, w["vocab"], None, torch.empty(rows, self.V, device=self.device),
-                                      tag="tf_vocab_logits").view(N, t, self.V)
-        elif want_logits == "last":
-            src = xb.view(N, t, d)[:, -1, :]
-            out["logits"] = self.gemm(src, w["vocab"], None, torch.empty(N, self.V, device=self.device))
-        return out
-
-    def decode_full(self, input_ids: torch.Tensor, mem: torch.Tensor, sem: Optional[torch.Tensor],
-                    want_logits: str = "all", sem_embs: Optional[torch.Tensor] = None,
-                    want_aux: bool = False, hidden_fp32: bool = True) -> Dict[str, torch.Tensor]:
-        """`TransformerDecoder.forward` + `NaiveHead` on whole sequences (Lq = t).
-
-        Used by feedforward_step (Framework.py:215-234) and by the stateless
-        `decoding_phase` API.  `mem` may hold fewer clips than `input_ids` has rows
-        (rows_per_clip = N / B consecutive rows share a clip).
-        """
-        w, d = self.w, self.d
-        N, t = input_ids.shape
-        # a lean encode hands over the bf16 memory alone (metrics_step): it is the cross-K/V GEMM's operand as it stands
-        mem = mem.to(self.device) if (mem.dtype == self.h16 and self.bf_act) else mem.to(self.device, torch.float32)
-        B, Lk = mem.shape[0], mem.shape[1]
-        assert N % B == 0 and t <= self.T + 1
-        per_clip = N // B
-        rows = N * t
-        ids32 = input_ids.to(self.device, torch.int32).contiguous()
-        sem_div = 1
-        if sem is not None:
-            sem = sem.to(self.device, torch.float32).contiguous()
-            assert sem.shape[0] in (B, N)
-            sem_div = t * (per_clip if sem.shape[0] == B else 1)
-        x, xb = self.ws("tf_x0", (rows, d)), self.wsb("tf_x0", (rows, d))
-        self.call("care_embed_ln", ptr(ids32), t, 0, None, 0, ptr(w["word"]), ptr(w["pos"]), 0, ptr(sem), sem_div,
-             ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(x), ptr(xb), d, rows, t, d, tag="tf_embed")
-        ckv = self.cross_kv(mem, tag="tf_ckv")
-        if self.attr_att and sem_embs is None:
-            raise KeyError("this model attends to `semantic_embs` (use_attr_type={!r})".format(self.use_attr_type))
-        akv = self.attr_kv(sem_embs, tag="tf_akv") if self.attr_att else None
-        if self.tf_fast_ok(t, want_aux):
-            return self._decode_full_fast(x, xb, ids32, N, t, B, Lk, per_clip, ckv, akv, want_logits, hidden_fp32)
-        # auxiliary outputs of TransformerDecoder.forward (Decoder/Transformer.py:239-252), on request
-        A = None
-        if want_aux:
-            A = dict(all_hidden_states=[x.clone().view(N, t, d)], intra=[], inter=[], attr=[])
-        for li in range(self.n_layers):
-            a_sa = {} if want_aux else None
-            x1, x1b = self._mha_self_full("d{}_sa".format(li), x, xb, t, ids32, True, "tf_", aux=a_sa)
-            nm = "d{}_ca".format(li)
-            q = self.gemm(x1b if x1b is not None else x1, w[nm + "_q_w"], w[nm + "_q_b"], self.ws("tf_q", (rows, d)))
-            kv = ckv[li]
-            ctx = self.attention(q, kv, kv[:, d:], self._ctx("tf_", rows), Lk * 2 * d, 2 * d, per_clip * t, Lk,
-                                 bias=w["d{}_hb".format(li)])
-            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws("tf_o", (rows, d)))
-            x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
-            self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
-            if want_aux:
-                A["intra"].append(a_sa["probs"].view(N, t, self.H, t).permute(0, 2, 1, 3))
-                A["inter"].append(self.attention_probs(q, kv, Lk * 2 * d, 2 * d, per_clip * t, Lk,
-                                                       bias=w["d{}_hb".format(li)]).view(N, t, self.H, Lk).permute(0, 2, 1, 3))
-                A["text_context"], A["self_embs"] = a_sa["context"].view(N, t, d), a_sa["embs"].view(N, t, d)
-                A["context"], A["cross_embs"] = o.clone().view(N, t, d), x2.clone().view(N, t, d)
-            if self.attr_att:
-                a_at = {} if want_aux else None
-                x2, x2b = self._attr_block(li, x2, x2b, akv, per_clip * t, "tf_", aux=a_at)
-                if want_aux:
-                    A["attr"].append(a_at["probs"].view(N, t, self.H, self.topk).permute(0, 2, 1, 3))
-            last = li == self.n_layers - 1
-            x = torch.empty(rows, d, device=self.device) if last else self.ws("tf_x3", (rows, d))
-            xb = self.wsb("tf_x3", (rows, d))
-            self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, "tf_")
-            if want_aux:
-                A["all_hidden_states"].append(x.view(N, t, d) if last else x.clone().view(N, t, d))
-        hidden = x.view(N, t, d)
-        self._last_tf_bf16 = xb
-        out = {"hidden_states": hidden}
-        if want_aux:
-            # word embeddings of the input ids, without position / LayerNorm (get_sentence_embeddings, :107-116)
-            sent = torch.empty(rows, d, device=self.device)
-            self._call_rows("care_gather_rows", w["word"], sent, ids32.view(rows), rows)
-            out.update(all_hidden_states=A["all_hidden_states"], all_intra_attentions=tuple(A["intra"]),
-                       all_inter_attentions=tuple(A["inter"]), attention_probs=A["inter"][-1].mean(1),
-                       context=A["context"], text_context=A["text_context"], self_embs=A["self_embs"],
-                       cross_embs=A["cross_embs"], input_embs=A["all_hidden_states"][0],
-                       input_embs_exclude_bos=A["all_hidden_states"][0][:, 1:, :], sentence_embs=sent.view(N, t, d))
-            if self.opt.get("use_attr"):
-                out.update(attr_attention_probs=tuple(A["attr"]), gate_probs=())
-        if want_logits == "all":
-            out["logits"] = self.gemm(xb if xb is not None else x, w["vocab"], None,
-                                      torch.empty(rows, self.V, device=self.device)).view(N, t, self.V)
-        elif want_logits == "last":
-            src = (xb if xb is not None else x).view(N, t, d)[:, -1, :]
-            out["logits"] = self.gemm(src, w["vocab"], None, torch.empty(N, self.V, device=self.device))
-        return out
-
-    def score_teacher_forced(self, input_ids, labels, mem, sem, sem_embs=None):
-        """Metrics step (crit_lang.py:75-103): per position log p(label) and arg-max token.
-
-        bf16 A-stationary path: the vocabulary GEMM keeps running (max, argmax, sum-exp, label
-        logit) per row and never writes the [B*T, V] logits; otherwise logits are materialised
-        and scored by care_score_logits.  Returns (logp fp32 [N, t], pred int32 [N, t]).
-        """
-        N, t = input_ids.shape
-        rows = N * t
-        lab32 = labels.to(self.device, torch.int32).contiguous().view(rows)
-        logp = torch.empty(rows, device=self.device)
-        pred = torch.empty(rows, device=self.device, dtype=torch.int32)
-        if self.bf_act:
-            out = self.decode_full(input_ids, mem, sem, want_logits="none", sem_embs=sem_embs, hidden_fp32=False)
-            xb = self._last_tf_bf16
-            parts = self.vocab_parts(rows)
-            pm, pi = self.ws("sc_pmax", (rows, parts)), self.ws("sc_pidx", (rows, parts), torch.int32)
-            ps = self.ws("sc_psum", (rows, parts))
-            # the label logit as a dot product of its own (rows x d MACs): the statistics then come from the kernel
-            # without label bookkeeping - from 8192 rows the 256-row panels of csrc/gemm_vocab.hip
-            pl = self.ws("sc_lab", (rows,))
-            self.vocab_argmax(None, xb, rows, pm, pi, ps, tag="tf_vocab_score")
-            self.call("care_label_logits", ptr(xb), xb.stride(0), ptr(self.w["vocab"]), ptr(lab32), ptr(pl), rows, self.V, self.d,
-                 tag="tf_label_logits")
-            self.call("care_score_partials_lab", ptr(pm), ptr(pi), ptr(ps), parts, ptr(pl), ptr(logp), ptr(pred), rows)
-        else:
-            out = self.decode_full(input_ids, mem, sem, want_logits="all", sem_embs=sem_embs)
-            lg = out["logits"].view(rows, self.V)
-            self.call("care_score_logits", ptr(lg), lg.stride(0), self.V, ptr(lab32), ptr(logp), ptr(pred), rows)
-        return logp.view(N, t), pred.view(N, t)
-
-    def metrics_step(self, feats: List[torch.Tensor], input_ids: torch.Tensor, labels: torch.Tensor):
-        """The eval metrics step (models/Wrapper.py:182-184 -> Framework.py:215-237 -> misc/Crit/crit_lang.py:75-103)
-        as ONE pass: encode + teacher-forced decoder + fused scoring.  Returns (logp [N, t], pred [N, t], enc):
-        the log-probability of every label token, the arg-max token, and the encoder outputs (with `preds_attr` for
-        the concept metrics).  A model without a concept head encodes lean - nothing of the fp32 memory or the frame
-        means is read by the scoring - and no [N * t, V] logits exist at any point."""
-        self._begin_pass()
-        enc = self.encode(self._prep_feats(feats), lean=not self.has_concepts)
-        logp, pred = self.score_teacher_forced(input_ids, labels, enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
-                                               sem_embs=enc.get("semantic_embs"))
-        return logp, pred, enc
-
-    # ------------------------------------------------------------------ incremental decode step
-    def _decode_step(self, t, N, rows_per_clip, tok, anc, sem, ckv, skv, Lk, tag, akv=None, embedded=False):
-        """One decoder step for N rows: new token at position t-1 -> final hidden (fp32, bf16 mirror).
-        embedded: the step's input activations were already written by care_greedy_update_embed."""
-        w, d, T = self.w, self.d, self.T
-        x, xb = self.ws(tag + "x0", (N, d)), self.wsb(tag + "x0", (N, d))
-        if not embedded:
-            self.call("care_embed_ln", ptr(tok), tok.stride(0), t - 1, ptr(anc), anc.stride(0) if anc is not None else 0,
-                 ptr(w["word"]), ptr(w["pos"]), t - 1, ptr(sem), rows_per_clip, ptr(w["emb_g"]), ptr(w["emb_be"]),
-                 self.eps, ptr(x), ptr(xb), d, N, 1, d)
-        g = lambda f32, b16: b16 if b16 is not None else f32  # GEMM input: the bf16 mirror when it exists
-        fuse_ln = self.ln_fusable(self._form_rows or N)  # by the pass's INITIAL row count, not what compaction left
-        for li in range(self.n_layers):
-            nm = "d{}_sa".format(li)
-            cache = skv[li]  # [N, T, 2d]
-            q = self.ws(tag + "q", (N, d))
-            self.gemm(g(x, xb), w[nm + "_qkv_w"], w[nm + "_qkv_b"], q, out2=cache[:, t - 1, :], n_split=d,
-                      tag="step_qkv_gemm")
-            flat = cache.view(N * T, 2 * d)
-            ctx = self.attention(q, flat, flat[:, d:], self._ctx(tag, N), T * 2 * d, 2 * d, 1, t, anc=anc,
-                                 pad_tok=tok, tag="step_self_attn")
-            x1, x1b = self.ws(tag + "x1", (N, d)), self.wsb(tag + "x1", (N, d))
-            if fuse_ln:
-                self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x, w[nm + "_g"], w[nm + "_be"], x1, x1b,
-                             tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
-            else:
-                o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
-                self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b, tag="step_add_ln")
-            nm = "d{}_ca".format(li)
-            hb = w["d{}_hb".format(li)]
-            if isinstance(ckv, tuple):  # absorbed form (cross_src)
-                H = self.H
-                # d x d with a bf16 output at >= 8192 rows: the LDS-tiled kernel (*measured* in situ, 32768 rows: 25.3 against
-                # 32-34 us on the A-stationary one, which wins the wider QKV / FFN1 products; decided by the pass's INITIAL
-                # row count like every other choice of form)
-                q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2b", (N, d), self.h16),
-                               tag="step_dxd_gemm", tile=d == 512 and (self._form_rows or N) >= self.Q_TILE_MIN_ROWS)
-                qt = self.ws(tag + "qt", (N, H * d), self.h16)
-                if d == 512:
-                    self.call("care_head_expand", ptr(q2), d, ptr(w[nm + "_wkt"]), ptr(qt), H * d, N, H, tag="step_head_expand")
-                else:  # one batched launch: head h multiplies q[:, 64 h : 64 h + 64] by wkt[h] [d, 64]
-                    self.call("care_gemm_tile_batched", ptr(q2), d, 64, ptr(w[nm + "_wkt"]), 64, d * 64, None, 0, ptr(qt), H * d, d,
-                         CARE_BF16, H, N, d, 64, tag="step_head_expand")
-                ct = self.ws(tag + "ct", (N, H * d), self.h16)
-                self.call("care_attention_latent", ptr(qt), H * d, ptr(ckv[li]), Lk * d, d, rows_per_clip, Lk, ptr(hb),
-                     hb.stride(0) if hb is not None else 0, ptr(ct), H * d, N, H, d, tag="step_cross_attn")
-                ctx = self._ctx(tag, N)
-                if d == 512:
-                    self.call("care_head_reduce", ptr(ct), H * d, ptr(w[nm + "_v_w"]), ptr(w[nm + "_v_b"]), ptr(ctx), d, N, H,
-                         tag="step_head_reduce")
-                else:  # head h: ctx[:, 64 h : 64 h + 64] = ct[:, h] W_v[64 h : 64 h + 64, :]^T + b_v
-                    self.call("care_gemm_tile_batched", ptr(ct), H * d, d, ptr(w[nm + "_v_w"]), d, 64 * d, ptr(w[nm + "_v_b"]), 64,
-                         ptr(ctx), d, 64, CARE_BF16, H, N, 64, d, tag="step_head_reduce")
-            else:
-                q2 = self.gemm(g(x1, x1b), w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)),
-                               tag="step_dxd_gemm")
-                kv = ckv[li]
-                ctx = self.attention(q2, kv, kv[:, d:], self._ctx(tag, N), Lk * 2 * d, 2 * d, rows_per_clip, Lk,
-                                     bias=hb, tag="step_cross_attn")
-            x2, x2b = self.ws(tag + "x2", (N, d)), self.wsb(tag + "x2", (N, d))
-            if fuse_ln:
-                self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x1, w[nm + "_g"], w[nm + "_be"], x2, x2b,
-                             tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
-            else:
-                o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
-                self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b, tag="step_add_ln")
-            if self.attr_att:
-                x2, x2b = self._attr_block(li, x2, x2b, akv, rows_per_clip, tag)
-            x, xb = self.ws(tag + "x3_%d" % (li & 1), (N, d)), self.wsb(tag + "x3_%d" % (li & 1), (N, d))
-            # the last layer's hidden state feeds the vocabulary projection only, which reads the bf16 mirror:
-            # the fused kernel then skips the fp32 copy (67 MB of stores per step at 32768 rows)
-            bf16_only = (li == self.n_layers - 1 and xb is not None and fuse_ln and self.as_ok and
-                         self.ff % 512 == 0 and self.ff >= 1024)
-            self._ffn("d{}_ffn".format(li), x2, x2b, None if bf16_only else x, xb, tag, gemm_tag="step_ffn_gemm",
-                      fuse=fuse_ln)
-            if bf16_only:
-                x = None
-        return x, xb
-
-    def greedy(self, mem: torch.Tensor, sem: Optional[torch.Tensor], steps: Optional[int] = None,
-               sem_embs: Optional[torch.Tensor] = None):
-        """Greedy decoding (= beam search with beam_size 1, models/Wrapper.py:34-35) of B clips.
-
-        Returns device tensors: fed int32 [B, T+1] (column 0 = BOS), length int32 [B],
-        score fp32 [B] (sum of chosen log-probs).  No host synchronisation inside.
-        """
-        B, Lk, d = mem.shape
-        T = self.T
-        steps = T if steps is None else steps
-        mem = mem.to(self.device, mem.dtype if mem.dtype == self.h16 else torch.float32)  # bf16: lean encode
-        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
-        fed = self.ws("g_fed", (B, T + 1), torch.int32)
-        score = self.ws("g_score", (B,))
-        length = self.ws("g_len", (B,), torch.int32)
-        fin = self.ws("g_fin", (B,), torch.int32)
-        fed.zero_(); fed[:, 0] = BOS
-        score.zero_(); length.zero_(); fin.zero_()
-        ckv = self.cross_src(mem, B)
-        akv = self.attr_kv(sem_embs) if self.attr_att else None
-        skv = [self.ws("g_skv%d" % li, (B, T, 2 * d), self.wt) for li in range(self.n_layers)]
-        parts = self.vocab_parts(B)
-        pmax = self.ws("g_pmax", (B, parts))
-        pidx = self.ws("g_pidx", (B, parts), torch.int32)
-        psum = self.ws("g_psum", (B, parts))
-        x0, x0b = self.ws("g_x0", (B, d)), self.wsb("g_x0", (B, d))  # the workspaces _decode_step embeds into
-        for t in range(1, steps + 1):
-            x, xb = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_", akv=akv, embedded=t > 1)
-            self.vocab_argmax(x, xb, B, pmax, pidx, psum)
-            if t < steps:  # the token choice and, in the same launch, its embedding = the input of step t + 1
-                self.call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
-                     ptr(length), ptr(fin), t, T, EOS, B, ptr(self.w["word"]), ptr(self.w["pos"]), ptr(sem), 1,
-                     ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps, ptr(x0), ptr(x0b), d, d, tag="step_update_embed")
-            else:
-                self.call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
-                     ptr(length), ptr(fin), t, T, EOS, B)
-        return fed, length, score
-
-    # ------------------------------------------------------------------ resident decode of small batches
-    RESIDENT_MAX_V = 64 * 64 * 4  # csrc/decode_resident.hip: 64 lanes x RES_NP column-group partials of 64 columns
-
-    def resident_ok(self, rows: int) -> bool:
-        """Greedy decode of `rows` clips as one resident launch (csrc/decode_resident.hip)?  bf16 mode, d_model = 512;
-        a form of its own next to the multi-launch one: projected cross K/V, the same rounding points, sums in another
-        order - so which of two nearly tied tokens wins can differ between a batch of <= resident_max_rows clips and a
-        larger one (the audit of tests/test_gpu_properties.py counts such rows)."""
-        if not (0 < rows <= self.resident_max_rows and self._resident_model_ok()):
-            return False
-        if self.d != 512 and rows > self.RESIDENT_WIDE_MAX_ROWS:
-            return False
-        return self._resident_fits(rows)
-
-    RESIDENT_WIDE_MAX_ROWS = 128  # d_model 768 / 1024: the K-split forms only (csrc/decode_resident.hip, template D)
-
-    def _resident_model_ok(self, beam: bool = False) -> bool:
-        """Every model-side limit care_decode_resident / care_decode_resident_beam enforce (CARE_ESHAPE otherwise):
-        bf16 mode; d_model 512 (ff 512 / 1024 / 2048), or - greedy only - d_model 768 / 1024 with ff = 4 d_model."""
-        if not (self.bf and self.wt == self.h16 and self.T <= 128 and self.n_layers <= 4 and
-                (not self.attr_att or self.topk <= 128) and self.V <= self.RESIDENT_MAX_V and self.Lk <= 128):
-            return False
-        if self.d == 512:
-            return bool(self.as_ok and self.ff in (512, 1024, 2048))
-        return bool(not beam and self.d in (768, 1024) and self.ff == 4 * self.d and self.bf_act)
-
-    def _resident_fits(self, rows: int, per_tile: int = 1) -> bool:
-        """one workgroup per CU at most, and at least one per group of `per_tile` 16-row tiles (a partitioned GPU has fewer CUs)"""
-        if self.device is not None and torch.cuda.is_available():
-            if getattr(self, "_cus", None) is None:
-                self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-            return ((rows + 15) // 16 + per_tile - 1) // per_tile <= self._cus // 8 * 8
-        return True
-
-    RESIDENT_BEAM_MAX = 5  # csrc/decode_resident.h RES_BMK
-
-    def resident_beam_ok(self, clips: int, bm: int, need: int) -> bool:
-        """Beam search over `clips` clips as one resident launch (csrc/decode_resident_beam.hip)?  The limits of
-        care_decode_resident_beam: the greedy launch's, beam_size <= 5, a hypothesis' positions one per lane (T <= 63)."""
-        rows = clips * bm
-        if not (0 < rows <= self.resident_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and
-                self._resident_model_ok(beam=True) and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX):
-            return False
-        return self._resident_fits(rows, 2 if rows > 256 else 1)
-
-    def chain_beam_ok(self, clips: int, bm: int, need: int) -> bool:
-        """Beam search over `clips` clips with every step a chain of kernels (csrc/decode_chain.hip)?  The model-side
-        limits of the resident beam launch (its phases are the chain's kernels); no residency condition, so the row
-        count is bounded only by where the large-batch forms take over (`chain_beam_max_rows`)."""
-        rows = clips * bm
-        return bool(0 < rows <= self.chain_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and
-                    self._resident_model_ok(beam=True) and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX)
-
-    def small_forms(self, clips: int) -> bool:
-        """Batches of <= resident_max_rows clips (bf16, d_model = 512) take the small-batch forms of the pass: the
-        embedder as GEMM + LayerNorm launches side by side per modality (encode(small=True)) and, for greedy decoding,
-        the resident decode.  `resident_max_rows = 0`: one set of forms at every batch size."""
-        return 0 < clips <= self.resident_max_rows and self.as_ok and self.d == 512
-
-    def _resident_layers(self, tag: str, rows: int, rows_per_clip: int, ckv, akv, Lk: int):
-        """care_resident_layer[] of this model for a resident launch over `rows` rows (self-attention caches in the
-        workspaces `tag`skv*; static K/V per clip, shared by its `rows_per_clip` rows)."""
-        w, d, T = self.w, self.d, self.T
-        layers = self._res_layers = (_lib.ResidentLayer * self.n_layers)()  # kept: bench.py re-issues the recorded call
-        for li in range(self.n_layers):
-            L, sa, ffn = layers[li], "d{}_sa".format(li), "d{}_ffn".format(li)
-            L.qkv_w, L.qkv_b, L.o_w, L.o_b = ptr(w[sa + "_qkv_w"]), ptr(w[sa + "_qkv_b"]), ptr(w[sa + "_o_w"]), ptr(w[sa + "_o_b"])
-            L.ln_g, L.ln_b = ptr(w[sa + "_g"]), ptr(w[sa + "_be"])
-            L.self_kv = ptr(self.ws(tag + "skv%d" % li, (rows, T, 2 * d), self.h16))
-            blocks = [("d{}_ca".format(li), ckv[li], Lk, w["d{}_hb".format(li)])]
-            if self.attr_att:
-                blocks.append(("d{}_aa".format(li), akv[li], self.topk, None))
-            L.n_att = len(blocks)
-            for a, (nm, kv, nkeys, hb) in enumerate(blocks):
-                A = L.att[a]
-                A.q_w, A.q_b, A.o_w, A.o_b = ptr(w[nm + "_q_w"]), ptr(w[nm + "_q_b"]), ptr(w[nm + "_o_w"]), ptr(w[nm + "_o_b"])
-                A.ln_g, A.ln_b = ptr(w[nm + "_g"]), ptr(w[nm + "_be"])
-                A.kv, A.kv_batch_stride, A.nkeys, A.rows_per_kv = ptr(kv), nkeys * 2 * d, nkeys, rows_per_clip
-                A.bias, A.bias_ld = ptr(hb), (hb.stride(0) if hb is not None else 0)
-            L.w1, L.b1, L.w2, L.b2 = ptr(w[ffn + "_w1"]), ptr(w[ffn + "_b1"]), ptr(w[ffn + "_w2"]), ptr(w[ffn + "_b2"])
-            L.ffn_g, L.ffn_b = ptr(w[ffn + "_g"]), ptr(w[ffn + "_be"])
-        return layers
-
-    def beam_resident(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int,
-                      sem_embs: Optional[torch.Tensor] = None, early_exit: bool = True):
-        """Beam search of B clips x bm beams in ONE launch (care_decode_resident_beam): the step loop of
-        Translator.translate_batch (models/Translator.py:77-143) with Beam.advance (misc/Decoding/Beam.py:45-85) on the
-        device, stopping once every clip is done (Translator.py:77-81).  Returns the per-clip results of engine.beam:
-        nfin [B], fscore / flen [B, need + bm], fhyp [B, need + bm, T + 1]; no host synchronisation here."""
-        B, Lk, d = mem.shape
-        T, w, N, cap = self.T, self.w, mem.shape[0] * bm, need + bm
-        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
-        ckv = self.cross_kv(mem, tag="rb_ckv", resident=True)
-        akv = self.attr_kv(sem_embs, tag="rb_akv") if self.attr_att else None
-        tok = self.ws("rb_tok", (N, T + 1), torch.int32)
-        anc = [self.ws("rb_anc%d" % i, (N, T + 1), torch.int32) for i in range(2)]
-        scores, done, nfin = self.ws("rb_scores", (N,)), self.ws("rb_done", (B,), torch.int32), self.ws("rb_nfin", (B,), torch.int32)
-        fscore, flen = self.ws("rb_fscore", (B, cap)), self.ws("rb_flen", (B, cap), torch.int32)
-        fhyp = self.ws("rb_fhyp", (B, cap, T + 1), torch.int32)
-        layers = self._resident_layers("rb_", N, bm, ckv, akv, Lk)
-        nbytes = self.lib.care_decode_resident_beam_scratch(B, bm, d, self.ff, self.V)
-        scratch = self.ws("rb_scratch", (nbytes,), torch.uint8)
-        self.call("care_decode_resident_beam", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem),
-             ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(w["vocab"]), self.V, d, self.H, self.ff, self.act, B, bm, need, T, T,
-             BOS, EOS, PAD, ptr(tok), T + 1, ptr(anc[0]), ptr(anc[1]), ptr(scores), ptr(done), ptr(nfin), ptr(fscore), ptr(flen),
-             ptr(fhyp), cap, ptr(scratch), nbytes, int(bool(early_exit)), int(os.environ.get("CARE_RESIDENT_BLOCKS", "0")),
-             tag="decode_resident_beam")
-        self.last_decode = dict(clips=B, steps=scratch[8:12].view(torch.int32)[0], compactions=0, resident=True,
-                                row_steps=None)
-        return nfin, fscore, flen, fhyp
-
-    def _chain_state(self, B: int, bm: int, need: int):
-        T, N, cap = self.T, B * bm, need + bm
-        return dict(tok=self.ws("cb_tok", (N, T + 1), torch.int32),
-                    anc=[self.ws("cb_anc%d" % i, (N, T + 1), torch.int32) for i in range(2)],
-                    scores=self.ws("cb_scores", (N,)), done=self.ws("cb_done", (B,), torch.int32),
-                    nfin=self.ws("cb_nfin", (B,), torch.int32), fscore=self.ws("cb_fscore", (B, cap)),
-                    flen=self.ws("cb_flen", (B, cap), torch.int32), fhyp=self.ws("cb_fhyp", (B, cap, T + 1), torch.int32),
-                    idx=self.ws("cb_idx", (B,), torch.int32), cnt=self.ws("cb_cnt", (1,), torch.int32))
-
-    def beam_chain_steps(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int, t0: int, t1: int,
-                         sem_embs: Optional[torch.Tensor] = None, count_live: bool = True):
-        """Steps t0 .. t1 of the beam search of B clips x bm beams as chains of kernels (care_decode_chain_beam: 10
-        launches per step for a one-layer decoder; models/Translator.py:77-143, misc/Decoding/Beam.py:45-85), the beam
-        state of csrc/beam.hip in the `cb_` workspaces; t0 == 1 also projects the clips' static K/V and initialises the
-        state.  Ends with the partition of the clips by `done` (care_active_slots: cb_cnt = clips still live).  No host
-        synchronisation here."""
-        B, Lk, d = mem.shape
-        T, w, N, cap = self.T, self.w, mem.shape[0] * bm, need + bm
-        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
-        kvs = self.__dict__.setdefault("_chain_kv", {})
-        if t0 == 1:  # (static workspaces: the handles of a (clips, beam) stay valid for the later segments' graphs)
-            kvs[(B, bm)] = (self.cross_kv(mem, tag="cb_ckv", resident=True),
-                            self.attr_kv(sem_embs, tag="cb_akv") if self.attr_att else None)
-        ckv, akv = kvs[(B, bm)]
-        v = self._chain_state(B, bm, need)
-        layers = self._resident_layers("cb_", N, bm, ckv, akv, Lk)
-        nbytes = self.lib.care_decode_chain_beam_scratch(B, bm, d, self.ff, self.V)
-        scratch = self.ws("cb_scratch", (nbytes,), torch.uint8)
-        self.call("care_decode_chain_beam", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem),
-                  ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(w["vocab"]), self.V, d, self.H, self.ff, self.act, B, bm, need, T,
-                  t0, t1, BOS, EOS, PAD, ptr(v["tok"]), T + 1, ptr(v["anc"][0]), ptr(v["anc"][1]), ptr(v["scores"]), ptr(v["done"]),
-                  ptr(v["nfin"]), ptr(v["fscore"]), ptr(v["flen"]), ptr(v["fhyp"]), cap, ptr(scratch), nbytes,
-                  int(os.environ.get("CARE_CHAIN_FORM", "-1")), tag="decode_chain_beam")
-        if count_live:
-            self.call("care_active_slots", ptr(v["done"]), B, ptr(v["idx"]), ptr(v["cnt"]))
-        return v
-
-    def translate_beam_chain(self, feats: List[torch.Tensor], bm: int, need: int, use_graph: bool = True, lean: bool = False,
-                             early_exit: bool = True):
-        """encode + beam search with chained steps.  The pass runs in segments of `chain_segment_steps` steps, each a
-        hipGraph of its own (the first with the encoder and the static K/V projection); between segments the host reads
-        ONE counter - the clips still live - and stops when none is (`if not active_inst_idx_list: break`,
-        models/Translator.py:77-81).  early_exit=False: all T steps in one graph.  No compaction: the chain serves the
-        row counts below those at which moving the survivors pays (engine.beam_early_exit)."""
-        B, T = feats[0].shape[0], self.T
-        S = max(1, self.chain_segment_steps) if early_exit else T
-        fkey = (tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-        box = {}
-
-        def first():
-            self._form_rows = B * bm
-            enc = self.encode(feats, lean, static=True, small=self.small_forms(B))
-            box["enc"] = enc
-            v = self.beam_chain_steps(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need, 1, min(S, T),
-                                      sem_embs=enc.get("semantic_embs"), count_live=early_exit)
-            return enc, v
-
-        enc, v = self._replay(("bchain", 0, S, bm, need, bool(lean), bool(early_exit)) + fkey, first, use_graph)
-        t = min(S, T) + 1
-        stats = dict(clips=B, steps=t - 1, row_steps=B * bm * (t - 1), compactions=0, chain=True)
-        self.last_decode = stats
-        while t <= T:
-            if early_exit and int(v["cnt"].item()) == 0:
-                break
-            t1 = min(t + S - 1, T)
-            tt = t
-            self._replay(("bchain", tt, t1, bm, need, B, bool(lean)) + fkey,
-                         lambda: self.beam_chain_steps(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need,
-                                                       tt, t1, sem_embs=enc.get("semantic_embs")), use_graph)
-            stats["steps"] = t1
-            stats["row_steps"] += B * bm * (t1 - tt + 1)
-            t = t1 + 1
-        return enc, v["nfin"], v["fscore"], v["flen"], v["fhyp"]
-
-    def greedy_resident(self, mem: torch.Tensor, sem: Optional[torch.Tensor], sem_embs: Optional[torch.Tensor] = None,
-                        steps: Optional[int] = None, early_exit: bool = True):
-        """Greedy decoding of B clips in ONE launch: the step loop of Translator.translate_batch with beam_size 1
-        (models/Translator.py:77-143) runs on the device, phases of a step separated by grid barriers, and stops once
-        every clip has ended (Translator.py:77-81).  Returns device tensors fed int32 [B, T + 1], length int32 [B],
-        score fp32 [B]; `self.last_decode["steps"]` is a 0-dim DEVICE tensor (no host synchronisation here)."""
-        B, Lk, d = mem.shape
-        T, w = self.T, self.w
-        steps = T if steps is None else steps
-        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
-        ckv = self.cross_kv(mem, tag="r_ckv", resident=True)
-        akv = self.attr_kv(sem_embs, tag="r_akv") if self.attr_att else None
-        fed = self.ws("r_fed", (B, T + 1), torch.int32)
-        score, length, fin = self.ws("r_score", (B,)), self.ws("r_len", (B,), torch.int32), self.ws("r_fin", (B,), torch.int32)
-        layers = self._resident_layers("r_", B, 1, ckv, akv, Lk)
-        nbytes = self.lib.care_decode_resident_scratch(B, d, self.ff, self.V)
-        scratch = self.ws("r_scratch", (nbytes,), torch.uint8)
-        self.call("care_decode_resident", ctypes.addressof(layers), self.n_layers, ptr(w["word"]), ptr(w["pos"]), ptr(sem), 1,
-             ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(w["vocab"]), self.V, d, self.H, self.ff, self.act, B, T, steps,
-             BOS, EOS, PAD, ptr(fed), T + 1, ptr(score), ptr(length), ptr(fin), ptr(scratch), nbytes,
-             int(bool(early_exit)), int(os.environ.get("CARE_RESIDENT_BLOCKS", "0")), tag="decode_resident")
-        self.last_decode = dict(clips=B, steps=scratch[8:12].view(torch.int32)[0], compactions=0, resident=True)
-        return fed, length, score
-
-    # ------------------------------------------------------------------ greedy with early exit + compaction
-    def _call_rows(self, fn, src, dst, idx, n):
-        """care_gather_rows / care_scatter_rows on tensors whose first dim is the row."""
-        rb = src[0].numel() * src.element_size()
-        self.call(fn, ptr(src), src.stride(0) * src.element_size(), ptr(dst), dst.stride(0) * dst.element_size(), ptr(idx), n, rb)
-
-    def _slot_bucket(self, active: int, cap: int) -> int:
-        """Row count a compacted decode runs on: `active` rounded up to a granule of cap / 32 (>= 64), so
-        that the captured segments of different batches meet the same few shapes."""
-        g = max(64, cap // 32)
-        return min(cap, (active + g - 1) // g * g)
-
-    def greedy_early_exit(self, feats: List[torch.Tensor], lean: bool = False, use_graph: bool = True):
-        """encode + greedy decode that STOPS when every clip has ended and drops ended clips from the
-        batch on the way (the reference: models/Translator.py:77-81 `if not active_inst_idx_list: break`,
-        :194-209 `collect_active_part`; per step and on the host there).
-
-        The 29 steps run in segments of `segment_steps`; after a segment one counter comes back to the
-        host - the rows still active.  None: done.  At most 3/4 of the slots in use: the active rows are
-        gathered to the front of a second set of buffers (K/V caches, memory, next-step inputs, tokens:
-        csrc/compact.hip) and the following segments run on that many rows (rounded up to a bucket;
-        the padding rows are ended clips that ride along).  Rows are independent end to end and the row-count
-        switches of the ENGINE (fused dense+LayerNorm, beam selection form, cross-attention form) are taken from the
-        pass's initial row count (`_form_rows`), so a clip meets the same kernel forms as in the fixed-length pass;
-        what still follows the current row count are two tilings INSIDE the library (QKV / FFN1 and the vocabulary
-        arg-max move from 256-row to 128-row panels below 8192 rows): the same bf16 products and the same arg-max
-        columns, fp32 sums in another order (scores within 1e-4).  A segment is captured into a hipGraph the
-        second time its (first step, row count, buffer set) comes up.  Results are per CLIP:
-        fed int32 [B, T + 1] (column 0 = BOS), length int32 [B], score fp32 [B]."""
-        feats = self._prep_feats(feats)
-        B, T, d = feats[0].shape[0], self.T, self.d
-        # small batches are launch-bound: a segment boundary (one host round trip + one more graph launch,
-        # ~40 us) costs as much as several of their steps, so they check twice as rarely and never compact
-        S = max(1, self.segment_steps) * (1 if B >= 2048 else 2)
-        out_fed = self.ws("ge_out_fed", (B, T + 1), torch.int32)
-        out_len = self.ws("ge_out_len", (B,), torch.int32)
-        out_score = self.ws("ge_out_score", (B,))
-        idx = self.ws("ge_idx", (B,), torch.int32)
-        cnt = self.ws("ge_cnt", (1,), torch.int32)
-        fkey = (tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-        st = {}
-
-        def state(par, n):
-            """Views of buffer set `par` for n slots (allocated at full size once)."""
-            self._ws_cap = (n, B)
-            tag = "g%d_" % par
-            v = dict(tag=tag, n=n,
-                     fed=self.ws(tag + "fed", (n, T + 1), torch.int32), score=self.ws(tag + "score", (n,)),
-                     length=self.ws(tag + "len", (n,), torch.int32), fin=self.ws(tag + "fin", (n,), torch.int32),
-                     clip=self.ws(tag + "clip", (n,), torch.int32),
-                     x0=self.ws(tag + "x0", (n, d)), x0b=self.wsb(tag + "x0", (n, d)),
-                     skv=[self.ws(tag + "skv%d" % li, (n, T, 2 * d), self.wt) for li in range(self.n_layers)])
-            return v
-
-        def run_steps(v, t0, t1, enc=None):
-            n = v["n"]
-            self._ws_cap = (n, B)
-            parts = self.vocab_parts(n)
-            pmax, psum = self.ws(v["tag"] + "pmax", (n, parts)), self.ws(v["tag"] + "psum", (n, parts))
-            pidx = self.ws(v["tag"] + "pidx", (n, parts), torch.int32)
-            for t in range(t0, t1 + 1):
-                x, xb = self._decode_step(t, n, 1, v["fed"], None, v["sem"], v["ckv"], v["skv"], self.Lk, v["tag"],
-                                          akv=v["akv"], embedded=t > 1)
-                self.vocab_argmax(x, xb, n, pmax, pidx, psum)
-                if t < T:
-                    self.call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
-                         ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n, ptr(self.w["word"]),
-                         ptr(self.w["pos"]), ptr(v["sem"]), 1, ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps,
-                         ptr(v["x0"]), ptr(v["x0b"]), d, d, tag="step_update_embed")
-                else:
-                    self.call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
-                         ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n)
-            self.call("care_active_slots", ptr(v["fin"]), n, ptr(idx), ptr(cnt))
-
-        def first_segment():
-            """encode, state initialisation and steps 1 .. S on all B slots of buffer set 0."""
-            self._ws_cap = None
-            enc = self.encode(feats, lean, static=True)
-            mem = enc["encoder_hidden_states"]
-            sem = enc.get("semantic_hidden_states")
-            v = state(0, B)
-            v["fed"].zero_(); v["fed"][:, 0] = BOS
-            v["score"].zero_(); v["length"].zero_(); v["fin"].zero_()
-            v["clip"].copy_(self._arange(B))
-            v["sem"] = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
-            self._ws_cap = None  # cross_src / attr_kv work on all B clips
-            v["ckv"] = self.cross_src(mem, B)
-            v["akv"] = self.attr_kv(enc.get("semantic_embs")) if self.attr_att else None
-            run_steps(v, 1, min(S, T))
-            return enc, v
-
-        replayable = lambda key, fn: self._replay(key, fn, use_graph)
-
-        try:
-            self._form_rows = B
-            enc, v = replayable(("gseg0", self.latent_ok, bool(lean), S) + fkey, first_segment)
-            par, t = 0, min(S, T) + 1
-            stats = dict(clips=B, steps=t - 1, row_steps=B * (t - 1), compactions=0)
-            self.last_decode = stats  # what the last pass actually ran (tests, bench)
-            while True:
-                active = int(cnt.item())  # the one host round trip per segment
-                if active == 0 or t > T:
-                    break
-                n_new = self._slot_bucket(active, B)
-                if n_new * 4 <= v["n"] * 3 and v["n"] >= 2048:
-                    v = self._compact(v, state(par ^ 1, n_new), idx, active, out_fed, out_len, out_score)
-                    par ^= 1
-                    stats["compactions"] += 1
-                t1 = min(t + S - 1, T)
-                vv = v
-                replayable(("gseg", par, t, t1, v["n"], B, self.latent_ok), lambda: run_steps(vv, t, t1))
-                stats["steps"] = t1
-                stats["row_steps"] += v["n"] * (t1 - t + 1)
-                t = t1 + 1
-            n = v["n"]
-            self._call_rows("care_scatter_rows", v["fed"], out_fed, v["clip"], n)
-            self._call_rows("care_scatter_rows", v["length"].view(n, 1), out_len.view(B, 1), v["clip"], n)
-            self._call_rows("care_scatter_rows", v["score"].view(n, 1), out_score.view(B, 1), v["clip"], n)
-        finally:
-            self._ws_cap = None
-        return enc, out_fed, out_len, out_score
-
     def _replay(self, key, fn, use_graph=True):
         """fn() eagerly the first time `key` is seen (allocates every workspace), captured into a hipGraph the
         second time, replayed afterwards.  Returns fn's result (static tensors once captured)."""
@@ -1553,445 +530,3 @@ class HipEngine:
             self._graph_put(key, entry)
         entry[0].replay()
         return entry[1]
-
-    def _arange(self, n):
-        t = self._ws_get("arange", (n,), torch.int32)
-        torch.arange(n, device=self.device, dtype=torch.int32, out=t)  # refilled: an evicted buffer comes back empty
-        return t
-
-    def _compact(self, v, w, idx, active, out_fed, out_len, out_score):
-        """Results of every slot of `v` -> the per-clip outputs; then the first w['n'] slots of the
-        partition `idx` (active ones first, ended ones as padding) -> buffer set `w`."""
-        n, m = v["n"], w["n"]
-        B = out_fed.shape[0]
-        self._call_rows("care_scatter_rows", v["fed"], out_fed, v["clip"], n)
-        self._call_rows("care_scatter_rows", v["length"].view(n, 1), out_len.view(B, 1), v["clip"], n)
-        self._call_rows("care_scatter_rows", v["score"].view(n, 1), out_score.view(B, 1), v["clip"], n)
-        for k in ("fed", "x0", "x0b"):
-            if v[k] is not None:
-                self._call_rows("care_gather_rows", v[k], w[k], idx, m)
-        for k in ("score", "length", "fin", "clip"):
-            self._call_rows("care_gather_rows", v[k].view(n, 1), w[k].view(m, 1), idx, m)
-        for a, b in zip(v["skv"], w["skv"]):
-            self._call_rows("care_gather_rows", a, b, idx, m)
-        tag = w["tag"]
-        self._ws_cap = (m, B)
-
-        def moved(name, src, per=1):
-            """Per-clip tensor with `per` rows per clip ([n * per, ...] or, per = 1, [n, ...]) -> m clips."""
-            if src is None:
-                return None
-            s2 = src.view(n, -1)
-            dst = self.ws(tag + name, (m, s2.shape[1]), src.dtype)
-            self._call_rows("care_gather_rows", s2, dst, idx, m)
-            return dst.view((m * per,) + tuple(src.shape[1:])) if per > 1 else dst.view((m,) + tuple(src.shape[1:]))
-
-        w["sem"] = moved("sem", v["sem"])
-        if isinstance(v["ckv"], tuple):  # absorbed form: one bf16 memory [n, Lk, d] shared by the layers
-            w["ckv"] = (moved("mem", v["ckv"][0]),) * len(v["ckv"])
-        else:                            # projected K/V: [n * Lk, 2d] per layer
-            w["ckv"] = [moved("ckv%d" % i, kv, self.Lk) for i, kv in enumerate(v["ckv"])]
-        w["akv"] = [moved("akv%d" % i, kv, self.topk) for i, kv in enumerate(v["akv"])] if v["akv"] is not None else None
-        w["clip"][active:].fill_(-1)     # padding slots: ended clips whose results are already out
-        return w
-
-    def translate_greedy(self, feats: List[torch.Tensor], use_graph: bool = True, lean: bool = False,
-                         early_exit: Optional[bool] = None):
-        """encode + greedy decode of one batch; replayed from a hipGraph when possible.
-
-        One pass issues ~360-440 kernel launches (12-15 per step); driven from Python that is
-        host-bound, so the whole pass is captured once per (batch, input buffers) into a
-        hipGraph (torch.cuda.CUDAGraph on the same stream capture) and replayed.  The graph
-        is keyed on the input pointers: callers that re-use their feature buffers (bench,
-        pinned double-buffered loaders) replay; a first-seen buffer set runs eagerly.
-        Returns (enc_outputs, fed, length, score) - static tensors when replayed.
-        lean: the caller reads nothing of enc_outputs (the Translator): encode(..., lean=True).
-        """
-        feats = self._prep_feats(feats)
-        self._begin_pass()
-        lanes = self.lanes_for(feats[0].shape[0]) if use_graph else 1
-        if lanes > 1:
-            return self._translate_greedy_lanes(feats, lanes, lean)
-        ee = self.early_exit if early_exit is None else early_exit
-        if self.resident_ok(feats[0].shape[0]):  # small batch: encode + one resident launch for the whole decode
-            def run_resident():
-                self._form_rows = feats[0].shape[0]
-                enc = self.encode(feats, lean, static=True, small=self.small_forms(feats[0].shape[0]))
-                return (enc,) + tuple(self.greedy_resident(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
-                                                           sem_embs=enc.get("semantic_embs"), early_exit=ee))
-            key = ("gres", bool(lean), bool(ee), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-            out = self._replay(key, run_resident, use_graph)
-            nb = self.lib.care_decode_resident_scratch(feats[0].shape[0], self.d, self.ff, self.V)
-            self.last_decode = dict(clips=feats[0].shape[0], steps=self.ws("r_scratch", (nb,), torch.uint8)[8:12].view(torch.int32)[0],
-                                    compactions=0, resident=True)
-            return out
-        if ee:
-            # stop when every clip has ended, drop ended clips on the way (greedy_early_exit)
-            return self.greedy_early_exit(feats, lean, use_graph)
-
-        def run():
-            self._form_rows = feats[0].shape[0]
-            enc = self.encode(feats, lean)
-            return (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
-                                              sem_embs=enc.get("semantic_embs")))
-
-        key = ("greedy", self.latent_ok, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-        return self._replay(key, run, use_graph)
-
-    def lanes_for(self, B: int) -> int:
-        """Batch lanes of a graph-replayed greedy pass.
-
-        A pass alternates HBM-bound kernels (attention, 44% of the time at B = 16384) with
-        MFMA-bound ones (the GEMMs); two half-batches on two HIP streams inside the one captured
-        graph let the one kind fill the other's idle unit and hide every kernel's tail.  Measured
-        (bf16 Base `ami`, one MI355X): +8% at B = 4096, +5% at 8192/16384; at B <= 2048 the
-        kernels are too short and the extra graph edges cost more than they hide (-3%..-30%), and
-        4 lanes are never better than 2.
-
-        A tuning knob, OFF by default (`self.lanes` = 1; `CARE_LANES` or `engine.lanes = 2` turn it
-        on): with two lanes the kernels share the chip, so per-kernel durations - and with them the
-        roofline accounting of bench.py and profiles/ - no longer describe a kernel on its own.
-        """
-        env = os.environ.get("CARE_LANES")
-        n = int(env) if env else int(self.lanes)
-        return max(1, min(n, B))
-
-    def _translate_greedy_lanes(self, feats, lanes, lean=False):
-        """translate_greedy with the batch cut into `lanes` contiguous clip ranges, each with its own
-        workspaces and HIP stream, forked from and joined to the capture stream inside ONE hipGraph.
-        Clips are independent, so the results are those of the single-lane pass."""
-        B = feats[0].shape[0]
-        bounds = [(B * i // lanes, B * (i + 1) // lanes) for i in range(lanes)]
-        if len(getattr(self, "_lane_streams", ())) < lanes:
-            self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
-
-        def run():
-            cur = torch.cuda.current_stream()
-            parts = []
-            try:
-                for i, (lo, hi) in enumerate(bounds):
-                    st = self._lane_streams[i]
-                    st.wait_stream(cur)
-                    with torch.cuda.stream(st):
-                        self._lane = i + 1  # workspace namespace of this lane (see ws)
-                        enc = self.encode([f[lo:hi] for f in feats], lean)
-                        parts.append((enc,) + tuple(self.greedy(enc["encoder_hidden_states"],
-                                                                enc.get("semantic_hidden_states"),
-                                                                sem_embs=enc.get("semantic_embs"))))
-            finally:
-                self._lane = 0
-            for st in self._lane_streams[:lanes]:
-                cur.wait_stream(st)
-            return (_LaneOutputs([pt[0] for pt in parts]),) + tuple(torch.cat([pt[k] for pt in parts], 0)
-                                                                     for k in (1, 2, 3))
-
-        key = ("greedy", lanes, self.latent_ok, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-        return self._replay(key, run, True)
-
-    # ------------------------------------------------------------------ beam search with early exit + compaction
-    def _beam_steps(self, v, t0, t1, bm, need):
-        """Steps t0 .. t1 of the beam search on the n clips (n * bm rows) of state `v`; ends with the
-        partition of the clip slots (care_active_slots on `done`)."""
-        n, T, d = v["n"], self.T, self.d
-        N, cap = n * bm, need + bm
-        B = v["B"]
-        self._ws_cap = [(n, B), (N, B * bm)]
-        tag = v["tag"]
-        cval, cidx = self.ws(tag + "cval", (N, bm)), self.ws(tag + "cidx", (N, bm), torch.int32)
-        fused_sel = self.beam_fused_for(B * bm)  # one form for the whole pass, whatever the compaction leaves
-        groups_sel = self.beam_groups_for(B * bm, bm)
-        if groups_sel:
-            pass
-        elif fused_sel:
-            s_parts = self.lib.care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
-            s_cap = 64
-            s_pmax, s_psum = self.ws(tag + "spmax", (N, s_parts)), self.ws(tag + "spsum", (N, s_parts))
-            s_pidx = self.ws(tag + "spidx", (N, s_parts), torch.int32)
-            s_thr, s_cnt = self.ws(tag + "sthr", (N,)), self.ws(tag + "scnt", (N,), torch.int32)
-            s_cval, s_cidx = self.ws(tag + "scval", (N, s_cap)), self.ws(tag + "scidx", (N, s_cap), torch.int32)
-            sparse = self._beam_sparse_ws(tag, N)
-        else:
-            vpad = (self.V + 63) // 64 * 64
-            logits = self.ws(tag + "logits", (N, vpad))[:, : self.V]
-        for t in range(t0, t1 + 1):
-            a_old, a_new = v["anc"][(t - 1) & 1], v["anc"][t & 1]
-            x, xb = self._decode_step(t, N, bm, v["tok"], a_old, v["sem"], v["ckv"], v["skv"], self.Lk, tag, akv=v["akv"])
-            if groups_sel:
-                self._beam_groups_select(tag, xb, N, bm, cval, cidx)
-            elif fused_sel:
-                if sparse is not None:
-                    # second pass only over the (tile, row) products whose tile maximum reaches the row's threshold
-                    self.call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
-                         ptr(s_pidx), ptr(s_psum), ptr(sparse[0]), N, self.V, d, 8, tag="beam_vocab_stats")
-                    self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                    self.call("care_beam_sparse_collect", ptr(xb), d, ptr(self.w["vocab"]), ptr(sparse[0]), ptr(s_thr),
-                         ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap, ptr(sparse[1]), ptr(sparse[2]), N, self.V, d,
-                         tag="beam_vocab_collect")
-                else:
-                    self.call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
-                         ptr(s_pidx), ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
-                    self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                    self.call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
-                         ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
-                self.call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
-                     bm, ptr(xb), d, _code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
-            else:
-                src = xb if xb is not None else x
-                chunk = int(os.environ.get("CARE_BEAM_CHUNK", "0")) or max(128, (176 << 20) // (logits.stride(0) * 4) // 128 * 128)
-                for lo in range(0, N, chunk):
-                    hi = min(N, lo + chunk)
-                    self.gemm(src[lo:hi], self.w["vocab"], None, logits[lo:hi], tag="step_vocab_logits")
-                    self.call("care_beam_select", ptr(logits[lo:hi]), logits.stride(0), self.V, bm, ptr(cval[lo:hi]),
-                         ptr(cidx[lo:hi]), hi - lo, 4 if self._small_pass else 1, tag="step_beam_select")
-            self.call("care_beam_advance", ptr(cval), ptr(cidx), ptr(v["scores"]), bm, ptr(v["tok"]), ptr(a_old), ptr(a_new),
-                 ptr(v["done"]), ptr(v["nfin"]), cap, ptr(v["fscore"]), ptr(v["flen"]), ptr(v["fhyp"]), t, T, need, EOS,
-                 self.V, T + 1, n)
-        self.call("care_active_slots", ptr(v["done"]), n, ptr(v["idx"]), ptr(v["cnt"]))
-
-    def beam_early_exit(self, feats: List[torch.Tensor], bm: int, need: int, lean: bool = False, use_graph: bool = True):
-        """encode + beam search that stops when every clip is done and drops finished clips between
-        segments (models/Translator.py:77-81,194-209), like greedy_early_exit: the clip-level state
-        (memory, finished lists ...) and the bm rows of every surviving clip (tokens, scores, K/V cache,
-        ancestor tables - whose entries are physical row numbers and are renumbered) move to the front of
-        a second buffer set.  Results per CLIP: nfin [B], fscore / flen [B, need + bm], fhyp [B, need + bm, T + 1]."""
-        feats = self._prep_feats(feats)
-        B, T, d = feats[0].shape[0], self.T, self.d
-        cap = need + bm
-        S = max(1, self.segment_steps) * (1 if B * bm >= 2048 else 2)
-        out = dict(nfin=self.ws("be_out_nfin", (B,), torch.int32), fscore=self.ws("be_out_fscore", (B, cap)),
-                   flen=self.ws("be_out_flen", (B, cap), torch.int32), fhyp=self.ws("be_out_fhyp", (B, cap, T + 1), torch.int32))
-        idx, cnt = self.ws("be_idx", (B,), torch.int32), self.ws("be_cnt", (1,), torch.int32)
-        fkey = (tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-
-        def state(par, n):
-            N = n * bm
-            self._ws_cap = [(n, B), (N, B * bm)]
-            tag = "b%d_" % par
-            return dict(tag=tag, n=n, B=B, idx=idx, cnt=cnt,
-                        tok=self.ws(tag + "tok", (N, T + 1), torch.int32),
-                        anc=[self.ws(tag + "anc%d" % i, (N, T + 1), torch.int32) for i in range(2)],
-                        scores=self.ws(tag + "scores", (N,)),
-                        skv=[self.ws(tag + "skv%d" % li, (N, T, 2 * d), self.wt) for li in range(self.n_layers)],
-                        done=self.ws(tag + "done", (n,), torch.int32), nfin=self.ws(tag + "nfin", (n,), torch.int32),
-                        fscore=self.ws(tag + "fscore", (n, cap)), flen=self.ws(tag + "flen", (n, cap), torch.int32),
-                        fhyp=self.ws(tag + "fhyp", (n, cap, T + 1), torch.int32), clip=self.ws(tag + "clip", (n,), torch.int32))
-
-        def first_segment():
-            self._ws_cap = None
-            enc = self.encode(feats, lean, static=True, small=self.small_forms(B))
-            mem, sem = enc["encoder_hidden_states"], enc.get("semantic_hidden_states")
-            v = state(0, B)
-            N = B * bm
-            v["tok"].fill_(EOS); v["tok"][:, 0] = BOS
-            rows = self._arange(N)
-            for a in v["anc"]:
-                a.copy_(rows.unsqueeze(1).expand(N, T + 1))
-            for k in ("scores", "done", "nfin", "fscore", "flen", "fhyp"):
-                v[k].zero_()
-            v["clip"].copy_(self._arange(B))
-            v["sem"] = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
-            self._ws_cap = None
-            v["ckv"] = self.cross_src(mem, N)
-            v["akv"] = self.attr_kv(enc.get("semantic_embs")) if self.attr_att else None
-            self._beam_steps(v, 1, min(S, T), bm, need)
-            return enc, v
-
-        replayable = lambda key, fn: self._replay(key, fn, use_graph)
-
-        def flush(v):
-            """finished lists of every slot of v -> the per-clip outputs"""
-            n = v["n"]
-            self._call_rows("care_scatter_rows", v["nfin"].view(n, 1), out["nfin"].view(B, 1), v["clip"], n)
-            for k in ("fscore", "flen"):
-                self._call_rows("care_scatter_rows", v[k], out[k], v["clip"], n)
-            self._call_rows("care_scatter_rows", v["fhyp"].view(n, -1), out["fhyp"].view(B, -1), v["clip"], n)
-
-        try:
-            self._form_rows = B * bm
-            enc, v = replayable(("bseg0", bm, need, self.latent_ok and not self._small_pass, bool(lean), S) + fkey, first_segment)
-            par, t = 0, min(S, T) + 1
-            stats = dict(clips=B, steps=t - 1, row_steps=B * bm * (t - 1), compactions=0)
-            self.last_decode = stats
-            while True:
-                active = int(cnt.item())
-                if active == 0 or t > T:
-                    break
-                m = self._slot_bucket(active, B)
-                if m * 4 <= v["n"] * 3 and v["n"] * bm >= 2048:
-                    flush(v)
-                    v = self._compact_beam(v, state(par ^ 1, m), idx, active, bm)
-                    par ^= 1
-                    stats["compactions"] += 1
-                t1 = min(t + S - 1, T)
-                vv = v
-                replayable(("bseg", par, t, t1, v["n"], B, bm, need, self.latent_ok and not self._small_pass), lambda: self._beam_steps(vv, t, t1, bm, need))
-                stats["steps"] = t1
-                stats["row_steps"] += v["n"] * bm * (t1 - t + 1)
-                t = t1 + 1
-            flush(v)
-        finally:
-            self._ws_cap = None
-        return enc, out["nfin"], out["fscore"], out["flen"], out["fhyp"]
-
-    def _compact_beam(self, v, w, idx, active, bm):
-        """The first w['n'] clips of the partition `idx` (unfinished first, finished ones as padding) and their rows
-        -> buffer set `w`; ancestor entries are renumbered to the rows' new places."""
-        n, m, B = v["n"], w["n"], v["B"]
-        N, M = n * bm, m * bm
-        self._ws_cap = [(m, B), (M, B * bm), (n, B), (N, B * bm)]
-        tag = w["tag"]
-        idx_r = self.ws(tag + "idx_r", (M,), torch.int32)
-        self.call("care_expand_index", ptr(idx), m, bm, ptr(idx_r))
-        cmap = self.ws(tag + "cmap", (n,), torch.int32)
-        cmap.zero_()  # clips that are dropped map to clip 0: nothing references their rows any more
-        self._call_rows("care_scatter_rows", self._arange(m).view(m, 1), cmap.view(n, 1), idx, m)
-        for k in ("done", "nfin", "clip"):
-            self._call_rows("care_gather_rows", v[k].view(n, 1), w[k].view(m, 1), idx, m)
-        for k in ("fscore", "flen"):
-            self._call_rows("care_gather_rows", v[k], w[k], idx, m)
-        self._call_rows("care_gather_rows", v["fhyp"].view(n, -1), w["fhyp"].view(m, -1), idx, m)
-        self._call_rows("care_gather_rows", v["tok"], w["tok"], idx_r, M)
-        self._call_rows("care_gather_rows", v["scores"].view(N, 1), w["scores"].view(M, 1), idx_r, M)
-        for a, b in zip(v["anc"], w["anc"]):
-            self._call_rows("care_gather_rows", a, b, idx_r, M)
-            self.call("care_remap_rows", ptr(b), b.numel(), ptr(cmap), bm)
-        for a, b in zip(v["skv"], w["skv"]):
-            self._call_rows("care_gather_rows", a, b, idx_r, M)
-
-        def moved(name, src, per=1):
-            if src is None:
-                return None
-            s2 = src.view(n, -1)
-            dst = self.ws(tag + name, (m, s2.shape[1]), src.dtype)
-            self._call_rows("care_gather_rows", s2, dst, idx, m)
-            return dst.view((m * per,) + tuple(src.shape[1:])) if per > 1 else dst.view((m,) + tuple(src.shape[1:]))
-
-        w["sem"] = moved("sem", v["sem"])
-        if isinstance(v["ckv"], tuple):
-            w["ckv"] = (moved("mem", v["ckv"][0]),) * len(v["ckv"])
-        else:
-            w["ckv"] = [moved("ckv%d" % i, kv, self.Lk) for i, kv in enumerate(v["ckv"])]
-        w["akv"] = [moved("akv%d" % i, kv, self.topk) for i, kv in enumerate(v["akv"])] if v["akv"] is not None else None
-        w["clip"][active:].fill_(-1)
-        return w
-
-    def translate_beam(self, feats: List[torch.Tensor], bm: int, need: int, use_graph: bool = True, lean: bool = False,
-                       early_exit: Optional[bool] = None):
-        """encode + beam search of one batch, replayed from a hipGraph when the input buffers repeat
-        (same policy as translate_greedy).  Returns (enc_outputs, nfin, fscore, flen, fhyp)."""
-        feats = self._prep_feats(feats)
-        self._begin_pass()
-        # beam search over a small batch: projected cross K/V (two launches less per step than the absorbed form, the
-        # beams of a clip share its K/V rows in cache; *measured* 128 clips x 5: 5.97 -> 5.47 ms per pass)
-        self._small_pass = self.small_forms(feats[0].shape[0])
-        ee = self.early_exit if early_exit is None else early_exit
-        if self.resident_beam_ok(feats[0].shape[0], bm, need):  # encode + ONE resident launch for the whole search
-            def run_resident():
-                self._form_rows = feats[0].shape[0] * bm
-                enc = self.encode(feats, lean, static=True, small=True)
-                return (enc,) + tuple(self.beam_resident(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need,
-                                                         sem_embs=enc.get("semantic_embs"), early_exit=ee))
-            key = ("bres", bm, need, bool(lean), bool(ee), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-            out = self._replay(key, run_resident, use_graph)
-            nb = self.lib.care_decode_resident_beam_scratch(feats[0].shape[0], bm, self.d, self.ff, self.V)
-            self.last_decode = dict(clips=feats[0].shape[0], steps=self.ws("rb_scratch", (nb,), torch.uint8)[8:12].view(torch.int32)[0],
-                                    compactions=0, resident=True, row_steps=None)
-            return out
-        if self.chain_beam_ok(feats[0].shape[0], bm, need):  # every step a chain of ~10 kernels (csrc/decode_chain.hip)
-            return self.translate_beam_chain(feats, bm, need, use_graph, lean, ee)
-        if ee:
-            return self.beam_early_exit(feats, bm, need, lean, use_graph)
-
-        def run():
-            self._form_rows = feats[0].shape[0] * bm
-            enc = self.encode(feats, lean, small=self.small_forms(feats[0].shape[0]))
-            return (enc,) + tuple(self.beam(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), bm, need,
-                                            sem_embs=enc.get("semantic_embs")))
-
-        key = ("beam", bm, need, self.latent_ok and not self._small_pass, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
-        return self._replay(key, run, use_graph)
-
-    def beam(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int,
-             sem_embs: Optional[torch.Tensor] = None):
-        """Beam search of B clips x bm beams, state on the device (csrc/beam.hip)."""
-        B, Lk, d = mem.shape
-        T, N = self.T, mem.shape[0] * bm
-        mem = mem.to(self.device, mem.dtype if mem.dtype == self.h16 else torch.float32)  # bf16: lean encode
-        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
-        cap = need + bm
-        tok = self.ws("b_tok", (N, T + 1), torch.int32)
-        anc = [self.ws("b_anc%d" % i, (N, T + 1), torch.int32) for i in range(2)]
-        tok.fill_(EOS); tok[:, 0] = BOS
-        rows = torch.arange(N, device=self.device, dtype=torch.int32)
-        for a in anc:
-            a.copy_(rows.unsqueeze(1).expand(N, T + 1))
-        scores = self.ws("b_scores", (N,)); scores.zero_()
-        done = self.ws("b_done", (B,), torch.int32); done.zero_()
-        nfin = self.ws("b_nfin", (B,), torch.int32); nfin.zero_()
-        fscore = self.ws("b_fscore", (B, cap)); fscore.zero_()
-        flen = self.ws("b_flen", (B, cap), torch.int32); flen.zero_()
-        fhyp = self.ws("b_fhyp", (B, cap, T + 1), torch.int32); fhyp.zero_()
-        cval = self.ws("b_cval", (N, bm))
-        cidx = self.ws("b_cidx", (N, bm), torch.int32)
-        vpad = (self.V + 63) // 64 * 64  # 16-byte aligned row stride -> the GEMM's vector store path
-        fused_sel = self.beam_fused_for(B * bm)
-        groups_sel = self.beam_groups_for(B * bm, bm)
-        if groups_sel:
-            logits = None
-        elif fused_sel:
-            s_parts = self.lib.care_argmax_parts_bf16_min(N, self.V, d, 1, 8)  # bf16 rows (code 1)
-            s_cap = 64
-            s_pmax, s_psum = self.ws("b_spmax", (N, s_parts)), self.ws("b_spsum", (N, s_parts))
-            s_pidx = self.ws("b_spidx", (N, s_parts), torch.int32)
-            s_thr, s_cnt = self.ws("b_sthr", (N,)), self.ws("b_scnt", (N,), torch.int32)
-            s_cval, s_cidx = self.ws("b_scval", (N, s_cap)), self.ws("b_scidx", (N, s_cap), torch.int32)
-            sparse = self._beam_sparse_ws("b_", N)
-            logits = None
-        else:
-            logits = self.ws("b_logits", (N, vpad))[:, : self.V]
-        ckv = self.cross_src(mem, N)
-        akv = self.attr_kv(sem_embs) if self.attr_att else None
-        skv = [self.ws("b_skv%d" % li, (N, T, 2 * d), self.wt) for li in range(self.n_layers)]
-        for t in range(1, T + 1):
-            a_old, a_new = anc[(t - 1) & 1], anc[t & 1]
-            x, xb = self._decode_step(t, N, bm, tok, a_old, sem, ckv, skv, Lk, "b_", akv=akv)
-            if groups_sel:
-                self._beam_groups_select("b_", xb, N, bm, cval, cidx)
-                self.call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
-                     ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
-                continue
-            if fused_sel:
-                # fused selection (csrc/beam.hip): statistics GEMM -> threshold -> candidate pass -> pick;
-                # the [N, V] logits never exist
-                if sparse is not None:
-                    self.call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
-                         ptr(s_pidx), ptr(s_psum), ptr(sparse[0]), N, self.V, d, 8, tag="beam_vocab_stats")
-                    self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                    self.call("care_beam_sparse_collect", ptr(xb), d, ptr(self.w["vocab"]), ptr(sparse[0]), ptr(s_thr),
-                         ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap, ptr(sparse[1]), ptr(sparse[2]), N, self.V, d,
-                         tag="beam_vocab_collect")
-                else:
-                    self.call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
-                         ptr(s_pidx), ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
-                    self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                    self.call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
-                         ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
-                self.call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
-                     bm, ptr(xb), d, _code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
-                self.call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
-                     ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
-                continue
-            # vocabulary logits -> per-row top-bm, in row chunks whose logits (chunk x vpad x 4 B) stay
-            # inside the 256 MB Infinity Cache between the GEMM's stores and beam_select's loads
-            src = xb if xb is not None else x
-            # (*measured*, 20480 rows x 10560: chunks of 4096 rows = 173 MB +4% on the whole beam pass;
-            # 5120 rows = 216 MB no gain, 2048 rows +1%)
-            chunk = int(os.environ.get("CARE_BEAM_CHUNK", "0")) or max(128, (176 << 20) // (vpad * 4) // 128 * 128)
-            for lo in range(0, N, chunk):
-                hi = min(N, lo + chunk)
-                self.gemm(src[lo:hi], self.w["vocab"], None, logits[lo:hi])
-                self.call("care_beam_select", ptr(logits[lo:hi]), logits.stride(0), self.V, bm, ptr(cval[lo:hi]),
-                     ptr(cidx[lo:hi]), hi - lo, 4 if self._small_pass else 1)
-            self.call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
-                 ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
-        return nfin, fscore, flen, fhyp

@@ -1,0 +1,655 @@
+"""HipEngine, the decoder: one decode step (`_decode_step`: DecoderLayer, models/components/Layers.py:157-228), the
+teacher-forced forward and fused scoring (Framework.py:215-237), and the greedy loops - fixed length, early exit with
+compaction, batch lanes (models/Translator.py:35-133 with beam_size 1).  Methods of care_amd.engine.HipEngine."""
+import ctypes
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_CODES, CARE_BF16, CARE_F32, ptr
+from .constants import BOS, EOS, PAD
+from .engine_util import _LaneOutputs, _code
+
+
+class DecodeMixin:
+    def _ctx(self, tag, rows):
+        """Attention context buffer: only ever read by the output projection GEMM."""
+        return self.ws(tag + "ctx", (rows, self.d), self.act_dtype)
+
+    def _mha_self_full(self, name, x, xb, seq, pad_tok, causal, tag, aux=None):
+        """Self-attention sub-block over whole sequences (teacher forcing / encoder).
+        x fp32 (residual), xb its bf16 mirror or None.  Returns (x1, x1b).
+        aux (dict): also the attention probabilities and the pre-residual projection (`text_context`)."""
+        rows, d = x.shape
+        w = self.w
+        qkv = self.gemm(xb if xb is not None else x, w[name + "_qkv_w"], w[name + "_qkv_b"],
+                        self.ws(tag + "qkv", (rows, 3 * d)))
+        ctx = self.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], self._ctx(tag, rows), seq * 3 * d, 3 * d,
+                             seq, seq, causal=causal, seq=seq, pad_tok=pad_tok)
+        o = self.gemm(ctx, w[name + "_o_w"], w[name + "_o_b"], self.ws(tag + "o", (rows, d)))
+        x1, x1b = self.ws(tag + "x1", (rows, d)), self.wsb(tag + "x1", (rows, d))
+        self.add_ln(o, x, w[name + "_g"], w[name + "_be"], x1, x1b)
+        if aux is not None:
+            aux["probs"] = self.attention_probs(qkv, qkv[:, d:], seq * 3 * d, 3 * d, seq, seq, causal=causal, seq=seq,
+                                                pad_tok=pad_tok)
+            aux["context"], aux["embs"] = o.clone(), x1.clone()
+        return x1, x1b
+
+    def _ffn(self, name, x, xb, out, outb, tag, gemm_tag=None, fuse=None, **ln_kw):
+        rows, d = x.shape
+        w = self.w
+        fuse = self.ln_fusable(rows) if fuse is None else fuse
+        split = self.as_ok and self.ff % 512 == 0 and self.ff >= 1024
+        h = self.gemm(xb if xb is not None else x, w[name + "_w1"], w[name + "_b1"],
+                      self.ws(tag + "h", (rows, self.ff), self.h16 if (split or self.bf_act) else torch.float32),
+                      act=self.act, tag=gemm_tag)
+        w2 = w[name + "_w2"]
+        if split and fuse and not ln_kw.get("pos"):
+            # dense2 + bias + residual + LayerNorm in one kernel: no split-K slabs at all
+            return self.gemm_ln(h, w2, w[name + "_b2"], x, w[name + "_g"], w[name + "_be"], out, outb,
+                                tag=(gemm_tag + "_ln") if gemm_tag else None, Wp=w.get(name + "_w2#packed"), **ln_kw)
+        if split and rows < int(os.environ.get("CARE_FFN2_TILE_ROWS", str(self.FFN2_TILE_MIN_ROWS))):
+            # K = ff > 512: split K over blocks into fp32 slabs; the LayerNorm kernel sums them
+            ns = self.ff // 512
+            f = self.ws(tag + "fslab", (ns, rows, d))
+            self.call("care_gemm_bf16_splitk", ptr(h), h.stride(0), _code(h), ptr(w2), ptr(w[name + "_b2"]), ptr(f), d,
+                 f.stride(0), rows, d, self.ff, tag=gemm_tag)
+            return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, nslab=ns,
+                               tag="step_add_ln" if gemm_tag else None, **ln_kw)
+        f = self.gemm(h, w2, w[name + "_b2"], self.ws(tag + "f", (rows, d)), tag=gemm_tag)
+        return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, tag="step_add_ln" if gemm_tag else None, **ln_kw)
+
+    def _attr_block(self, li, x, xb, akv, rows_per_clip, tag, aux=None):
+        """Third post-LN attention block over the concept rows (Layers.py:139-154,218-225)."""
+        w, d = self.w, self.d
+        rows = x.shape[0]
+        nm = "d{}_aa".format(li)
+        q = self.gemm(xb if xb is not None else x, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q3", (rows, d)))
+        kv = akv[li]
+        ctx = self.attention(q, kv, kv[:, d:], self._ctx(tag, rows), self.topk * 2 * d, 2 * d, rows_per_clip,
+                             self.topk)
+        o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (rows, d)))
+        y, yb = self.ws(tag + "x2a", (rows, d)), self.wsb(tag + "x2a", (rows, d))
+        self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], y, yb)
+        if aux is not None:
+            aux["probs"] = self.attention_probs(q, kv, self.topk * 2 * d, 2 * d, rows_per_clip, self.topk)
+        return y, yb
+
+    # ------------------------------------------------------------------ teacher-forced decoder
+    def tf_fast_ok(self, t: int, want_aux: bool) -> bool:
+        """Teacher-forced forward on the fast kernels (_decode_full_fast): bf16 mode, d_model = 512, no auxiliary
+        dict entries (attention probabilities etc. are not materialised by the fused kernels)."""
+        return (self.as_ok and self.d == 512 and not want_aux and t <= 32 and
+                os.environ.get("CARE_TF_FAST", "1") != "0")
+
+    def _dense_ln(self, ctx, name, res, out, outb, rows, tag):
+        """dense -> (+ residual) -> LayerNorm of an attention block (SubLayers.py:69-79): one fused kernel from
+        ~10 K rows (ln_fusable), the A-stationary GEMM + LayerNorm pair below."""
+        w = self.w
+        if self.ln_fusable(rows):
+            return self.gemm_ln(ctx, w[name + "_o_w"], w[name + "_o_b"], res, w[name + "_g"], w[name + "_be"], out, outb,
+                                tag=tag + "_ln", Wp=w.get(name + "_o_w#packed"))
+        o = self.gemm(ctx, w[name + "_o_w"], w[name + "_o_b"], self.ws("tf_o", (rows, self.d)), tag=tag + "_gemm")
+        return self.add_ln(o, res, w[name + "_g"], w[name + "_be"], out, outb)
+
+    def _decode_full_fast(self, x, xb, ids32, N, t, B, Lk, per_clip, ckv, akv, want_logits, hidden_fp32=True):
+        """The teacher-forced decoder (Decoder/Transformer.py:161-268 with Lq = t) on the kernels of the decode path:
+        bf16 QKV / Wq / FFN1 through the store GEMMs, dense + residual + LayerNorm and FFN2 fused (gemm_ln), and both
+        attentions through care_attention_seq - one wave per (sequence, head), the keys and values of a sequence read
+        once for its t query positions, QK^T and PV on the matrix cores.  Same operand roundings as a decode step
+        (bf16 GEMM inputs, fp32 residual stream and statistics)."""
+        w, d, H = self.w, self.d, self.H
+        rows = N * t
+        bfw = lambda name, shape: self.ws(name, shape, self.h16)
+        ctx = bfw("tf_ctxb", (rows, d))
+        for li in range(self.n_layers):
+            nm = "d{}_sa".format(li)
+            qkv = self.gemm(xb, w[nm + "_qkv_w"], w[nm + "_qkv_b"], bfw("tf_qkvb", (rows, 3 * d)), tag="tf_qkv_gemm")
+            self.call("care_attention_seq", ptr(qkv), 3 * d, ptr(qkv[:, d:]), ptr(qkv[:, 2 * d:]), t * 3 * d, 3 * d, 1, t, 1, t,
+                 ptr(ids32), t, PAD, None, 0, ptr(ctx), d, N, H, tag="tf_self_attn")
+            x1, x1b = self.ws("tf_x1", (rows, d)), self.wsb("tf_x1", (rows, d))
+            self._dense_ln(ctx, nm, x, x1, x1b, rows, "tf_dxd")
+            nm = "d{}_ca".format(li)
+            hb = w["d{}_hb".format(li)]
+            q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm")
+            kv = ckv[li]
+            self.call("care_attention_seq", ptr(q2), d, ptr(kv), ptr(kv[:, d:]), Lk * 2 * d, 2 * d, per_clip, Lk, 0, t,
+                 None, 0, PAD, ptr(hb), hb.stride(0) if hb is not None else 0, ptr(ctx), d, N, H, tag="tf_cross_attn")
+            x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
+            self._dense_ln(ctx, nm, x1, x2, x2b, rows, "tf_dxd")
+            if self.attr_att:
+                nm = "d{}_aa".format(li)
+                q3 = self.gemm(x2b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm")
+                kv = akv[li]
+                self.call("care_attention_seq", ptr(q3), d, ptr(kv), ptr(kv[:, d:]), self.topk * 2 * d, 2 * d, per_clip,
+                     self.topk, 0, t, None, 0, PAD, None, 0, ptr(ctx), d, N, H, tag="tf_attr_attn")
+                y, yb = self.ws("tf_x2a", (rows, d)), self.wsb("tf_x2a", (rows, d))
+                self._dense_ln(ctx, nm, x2, y, yb, rows, "tf_dxd")
+                x2, x2b = y, yb
+            last = li == self.n_layers - 1
+            xb = self.wsb("tf_x3", (rows, d))
+            if last and not hidden_fp32 and self.ln_fusable(rows) and self.ff % 512 == 0 and self.ff >= 1024:
+                x = None  # scoring only reads the bf16 mirror
+            else:
+                x = torch.empty(rows, d, device=self.device) if last else self.ws("tf_x3", (rows, d))
+            self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, "tf_", gemm_tag="tf_ffn_gemm")
+        self._last_tf_bf16 = xb
+        out = {"hidden_states": x.view(N, t, d) if x is not None else None}
+        if want_logits == "all":
+            out["logits"] = self.gemm(xb, w["vocab"], None, torch.empty(rows, self.V, device=self.device),
+                                      tag="tf_vocab_logits").view(N, t, self.V)
+        elif want_logits == "last":
+            src = xb.view(N, t, d)[:, -1, :]
+            out["logits"] = self.gemm(src, w["vocab"], None, torch.empty(N, self.V, device=self.device))
+        return out
+
+    def decode_full(self, input_ids: torch.Tensor, mem: torch.Tensor, sem: Optional[torch.Tensor],
+                    want_logits: str = "all", sem_embs: Optional[torch.Tensor] = None,
+                    want_aux: bool = False, hidden_fp32: bool = True) -> Dict[str, torch.Tensor]:
+        """`TransformerDecoder.forward` + `NaiveHead` on whole sequences (Lq = t).
+
+        Used by feedforward_step (Framework.py:215-234) and by the stateless
+        `decoding_phase` API.  `mem` may hold fewer clips than `input_ids` has rows
+        (rows_per_clip = N / B consecutive rows share a clip).
+        """
+        w, d = self.w, self.d
+        N, t = input_ids.shape
+        # a lean encode hands over the bf16 memory alone (metrics_step): it is the cross-K/V GEMM's operand as it stands
+        mem = mem.to(self.device) if (mem.dtype == self.h16 and self.bf_act) else mem.to(self.device, torch.float32)
+        B, Lk = mem.shape[0], mem.shape[1]
+        assert N % B == 0 and t <= self.T + 1
+        per_clip = N // B
+        rows = N * t
+        ids32 = input_ids.to(self.device, torch.int32).contiguous()
+        sem_div = 1
+        if sem is not None:
+            sem = sem.to(self.device, torch.float32).contiguous()
+            assert sem.shape[0] in (B, N)
+            sem_div = t * (per_clip if sem.shape[0] == B else 1)
+        x, xb = self.ws("tf_x0", (rows, d)), self.wsb("tf_x0", (rows, d))
+        self.call("care_embed_ln", ptr(ids32), t, 0, None, 0, ptr(w["word"]), ptr(w["pos"]), 0, ptr(sem), sem_div,
+             ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(x), ptr(xb), d, rows, t, d, tag="tf_embed")
+        ckv = self.cross_kv(mem, tag="tf_ckv")
+        if self.attr_att and sem_embs is None:
+            raise KeyError("this model attends to `semantic_embs` (use_attr_type={!r})".format(self.use_attr_type))
+        akv = self.attr_kv(sem_embs, tag="tf_akv") if self.attr_att else None
+        if self.tf_fast_ok(t, want_aux):
+            return self._decode_full_fast(x, xb, ids32, N, t, B, Lk, per_clip, ckv, akv, want_logits, hidden_fp32)
+        # auxiliary outputs of TransformerDecoder.forward (Decoder/Transformer.py:239-252), on request
+        A = None
+        if want_aux:
+            A = dict(all_hidden_states=[x.clone().view(N, t, d)], intra=[], inter=[], attr=[])
+        for li in range(self.n_layers):
+            a_sa = {} if want_aux else None
+            x1, x1b = self._mha_self_full("d{}_sa".format(li), x, xb, t, ids32, True, "tf_", aux=a_sa)
+            nm = "d{}_ca".format(li)
+            q = self.gemm(x1b if x1b is not None else x1, w[nm + "_q_w"], w[nm + "_q_b"], self.ws("tf_q", (rows, d)))
+            kv = ckv[li]
+            ctx = self.attention(q, kv, kv[:, d:], self._ctx("tf_", rows), Lk * 2 * d, 2 * d, per_clip * t, Lk,
+                                 bias=w["d{}_hb".format(li)])
+            o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws("tf_o", (rows, d)))
+            x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
+            self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
+            if want_aux:
+                A["intra"].append(a_sa["probs"].view(N, t, self.H, t).permute(0, 2, 1, 3))
+                A["inter"].append(self.attention_probs(q, kv, Lk * 2 * d, 2 * d, per_clip * t, Lk,
+                                                       bias=w["d{}_hb".format(li)]).view(N, t, self.H, Lk).permute(0, 2, 1, 3))
+                A["text_context"], A["self_embs"] = a_sa["context"].view(N, t, d), a_sa["embs"].view(N, t, d)
+                A["context"], A["cross_embs"] = o.clone().view(N, t, d), x2.clone().view(N, t, d)
+            if self.attr_att:
+                a_at = {} if want_aux else None
+                x2, x2b = self._attr_block(li, x2, x2b, akv, per_clip * t, "tf_", aux=a_at)
+                if want_aux:
+                    A["attr"].append(a_at["probs"].view(N, t, self.H, self.topk).permute(0, 2, 1, 3))
+            last = li == self.n_layers - 1
+            x = torch.empty(rows, d, device=self.device) if last else self.ws("tf_x3", (rows, d))
+            xb = self.wsb("tf_x3", (rows, d))
+            self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, "tf_")
+            if want_aux:
+                A["all_hidden_states"].append(x.view(N, t, d) if last else x.clone().view(N, t, d))
+        hidden = x.view(N, t, d)
+        self._last_tf_bf16 = xb
+        out = {"hidden_states": hidden}
+        if want_aux:
+            # word embeddings of the input ids, without position / LayerNorm (get_sentence_embeddings, :107-116)
+            sent = torch.empty(rows, d, device=self.device)
+            self._call_rows("care_gather_rows", w["word"], sent, ids32.view(rows), rows)
+            out.update(all_hidden_states=A["all_hidden_states"], all_intra_attentions=tuple(A["intra"]),
+                       all_inter_attentions=tuple(A["inter"]), attention_probs=A["inter"][-1].mean(1),
+                       context=A["context"], text_context=A["text_context"], self_embs=A["self_embs"],
+                       cross_embs=A["cross_embs"], input_embs=A["all_hidden_states"][0],
+                       input_embs_exclude_bos=A["all_hidden_states"][0][:, 1:, :], sentence_embs=sent.view(N, t, d))
+            if self.opt.get("use_attr"):
+                out.update(attr_attention_probs=tuple(A["attr"]), gate_probs=())
+        if want_logits == "all":
+            out["logits"] = self.gemm(xb if xb is not None else x, w["vocab"], None,
+                                      torch.empty(rows, self.V, device=self.device)).view(N, t, self.V)
+        elif want_logits == "last":
+            src = (xb if xb is not None else x).view(N, t, d)[:, -1, :]
+            out["logits"] = self.gemm(src, w["vocab"], None, torch.empty(N, self.V, device=self.device))
+        return out
+
+    def score_teacher_forced(self, input_ids, labels, mem, sem, sem_embs=None):
+        """Metrics step (crit_lang.py:75-103): per position log p(label) and arg-max token.
+
+        bf16 A-stationary path: the vocabulary GEMM keeps running (max, argmax, sum-exp, label
+        logit) per row and never writes the [B*T, V] logits; otherwise logits are materialised
+        and scored by care_score_logits.  Returns (logp fp32 [N, t], pred int32 [N, t]).
+        """
+        N, t = input_ids.shape
+        rows = N * t
+        lab32 = labels.to(self.device, torch.int32).contiguous().view(rows)
+        logp = torch.empty(rows, device=self.device)
+        pred = torch.empty(rows, device=self.device, dtype=torch.int32)
+        if self.bf_act:
+            out = self.decode_full(input_ids, mem, sem, want_logits="none", sem_embs=sem_embs, hidden_fp32=False)
+            xb = self._last_tf_bf16
+            parts = self.vocab_parts(rows)
+            pm, pi = self.ws("sc_pmax", (rows, parts)), self.ws("sc_pidx", (rows, parts), torch.int32)
+            ps = self.ws("sc_psum", (rows, parts))
+            # the label logit as a dot product of its own (rows x d MACs): the statistics then come from the kernel
+            # without label bookkeeping - from 8192 rows the 256-row panels of csrc/gemm_vocab.hip
+            pl = self.ws("sc_lab", (rows,))
+            self.vocab_argmax(None, xb, rows, pm, pi, ps, tag="tf_vocab_score")
+            self.call("care_label_logits", ptr(xb), xb.stride(0), ptr(self.w["vocab"]), ptr(lab32), ptr(pl), rows, self.V, self.d,
+                 tag="tf_label_logits")
+            self.call("care_score_partials_lab", ptr(pm), ptr(pi), ptr(ps), parts, ptr(pl), ptr(logp), ptr(pred), rows)
+        else:
+            out = self.decode_full(input_ids, mem, sem, want_logits="all", sem_embs=sem_embs)
+            lg = out["logits"].view(rows, self.V)
+            self.call("care_score_logits", ptr(lg), lg.stride(0), self.V, ptr(lab32), ptr(logp), ptr(pred), rows)
+        return logp.view(N, t), pred.view(N, t)
+
+    def metrics_step(self, feats: List[torch.Tensor], input_ids: torch.Tensor, labels: torch.Tensor):
+        """The eval metrics step (models/Wrapper.py:182-184 -> Framework.py:215-237 -> misc/Crit/crit_lang.py:75-103)
+        as ONE pass: encode + teacher-forced decoder + fused scoring.  Returns (logp [N, t], pred [N, t], enc):
+        the log-probability of every label token, the arg-max token, and the encoder outputs (with `preds_attr` for
+        the concept metrics).  A model without a concept head encodes lean - nothing of the fp32 memory or the frame
+        means is read by the scoring - and no [N * t, V] logits exist at any point."""
+        self._begin_pass()
+        enc = self.encode(self._prep_feats(feats), lean=not self.has_concepts)
+        logp, pred = self.score_teacher_forced(input_ids, labels, enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
+                                               sem_embs=enc.get("semantic_embs"))
+        return logp, pred, enc
+
+    # ------------------------------------------------------------------ incremental decode step
+    def _decode_step(self, t, N, rows_per_clip, tok, anc, sem, ckv, skv, Lk, tag, akv=None, embedded=False):
+        """One decoder step for N rows: new token at position t-1 -> final hidden (fp32, bf16 mirror).
+        embedded: the step's input activations were already written by care_greedy_update_embed."""
+        w, d, T = self.w, self.d, self.T
+        x, xb = self.ws(tag + "x0", (N, d)), self.wsb(tag + "x0", (N, d))
+        if not embedded:
+            self.call("care_embed_ln", ptr(tok), tok.stride(0), t - 1, ptr(anc), anc.stride(0) if anc is not None else 0,
+                 ptr(w["word"]), ptr(w["pos"]), t - 1, ptr(sem), rows_per_clip, ptr(w["emb_g"]), ptr(w["emb_be"]),
+                 self.eps, ptr(x), ptr(xb), d, N, 1, d)
+        g = lambda f32, b16: b16 if b16 is not None else f32  # GEMM input: the bf16 mirror when it exists
+        fuse_ln = self.ln_fusable(self._form_rows or N)  # by the pass's INITIAL row count, not what compaction left
+        for li in range(self.n_layers):
+            nm = "d{}_sa".format(li)
+            cache = skv[li]  # [N, T, 2d]
+            q = self.ws(tag + "q", (N, d))
+            self.gemm(g(x, xb), w[nm + "_qkv_w"], w[nm + "_qkv_b"], q, out2=cache[:, t - 1, :], n_split=d,
+                      tag="step_qkv_gemm")
+            flat = cache.view(N * T, 2 * d)
+            ctx = self.attention(q, flat, flat[:, d:], self._ctx(tag, N), T * 2 * d, 2 * d, 1, t, anc=anc,
+                                 pad_tok=tok, tag="step_self_attn")
+            x1, x1b = self.ws(tag + "x1", (N, d)), self.wsb(tag + "x1", (N, d))
+            if fuse_ln:
+                self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x, w[nm + "_g"], w[nm + "_be"], x1, x1b,
+                             tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
+            else:
+                o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
+                self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b, tag="step_add_ln")
+            nm = "d{}_ca".format(li)
+            hb = w["d{}_hb".format(li)]
+            if isinstance(ckv, tuple):  # absorbed form (cross_src)
+                H = self.H
+                # d x d with a bf16 output at >= 8192 rows: the LDS-tiled kernel (*measured* in situ, 32768 rows: 25.3 against
+                # 32-34 us on the A-stationary one, which wins the wider QKV / FFN1 products; decided by the pass's INITIAL
+                # row count like every other choice of form)
+                q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2b", (N, d), self.h16),
+                               tag="step_dxd_gemm", tile=d == 512 and (self._form_rows or N) >= self.Q_TILE_MIN_ROWS)
+                qt = self.ws(tag + "qt", (N, H * d), self.h16)
+                if d == 512:
+                    self.call("care_head_expand", ptr(q2), d, ptr(w[nm + "_wkt"]), ptr(qt), H * d, N, H, tag="step_head_expand")
+                else:  # one batched launch: head h multiplies q[:, 64 h : 64 h + 64] by wkt[h] [d, 64]
+                    self.call("care_gemm_tile_batched", ptr(q2), d, 64, ptr(w[nm + "_wkt"]), 64, d * 64, None, 0, ptr(qt), H * d, d,
+                         CARE_BF16, H, N, d, 64, tag="step_head_expand")
+                ct = self.ws(tag + "ct", (N, H * d), self.h16)
+                self.call("care_attention_latent", ptr(qt), H * d, ptr(ckv[li]), Lk * d, d, rows_per_clip, Lk, ptr(hb),
+                     hb.stride(0) if hb is not None else 0, ptr(ct), H * d, N, H, d, tag="step_cross_attn")
+                ctx = self._ctx(tag, N)
+                if d == 512:
+                    self.call("care_head_reduce", ptr(ct), H * d, ptr(w[nm + "_v_w"]), ptr(w[nm + "_v_b"]), ptr(ctx), d, N, H,
+                         tag="step_head_reduce")
+                else:  # head h: ctx[:, 64 h : 64 h + 64] = ct[:, h] W_v[64 h : 64 h + 64, :]^T + b_v
+                    self.call("care_gemm_tile_batched", ptr(ct), H * d, d, ptr(w[nm + "_v_w"]), d, 64 * d, ptr(w[nm + "_v_b"]), 64,
+                         ptr(ctx), d, 64, CARE_BF16, H, N, 64, d, tag="step_head_reduce")
+            else:
+                q2 = self.gemm(g(x1, x1b), w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)),
+                               tag="step_dxd_gemm")
+                kv = ckv[li]
+                ctx = self.attention(q2, kv, kv[:, d:], self._ctx(tag, N), Lk * 2 * d, 2 * d, rows_per_clip, Lk,
+                                     bias=hb, tag="step_cross_attn")
+            x2, x2b = self.ws(tag + "x2", (N, d)), self.wsb(tag + "x2", (N, d))
+            if fuse_ln:
+                self.gemm_ln(ctx, w[nm + "_o_w"], w[nm + "_o_b"], x1, w[nm + "_g"], w[nm + "_be"], x2, x2b,
+                             tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
+            else:
+                o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
+                self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b, tag="step_add_ln")
+            if self.attr_att:
+                x2, x2b = self._attr_block(li, x2, x2b, akv, rows_per_clip, tag)
+            x, xb = self.ws(tag + "x3_%d" % (li & 1), (N, d)), self.wsb(tag + "x3_%d" % (li & 1), (N, d))
+            # the last layer's hidden state feeds the vocabulary projection only, which reads the bf16 mirror:
+            # the fused kernel then skips the fp32 copy (67 MB of stores per step at 32768 rows)
+            bf16_only = (li == self.n_layers - 1 and xb is not None and fuse_ln and self.as_ok and
+                         self.ff % 512 == 0 and self.ff >= 1024)
+            self._ffn("d{}_ffn".format(li), x2, x2b, None if bf16_only else x, xb, tag, gemm_tag="step_ffn_gemm",
+                      fuse=fuse_ln)
+            if bf16_only:
+                x = None
+        return x, xb
+
+    def greedy(self, mem: torch.Tensor, sem: Optional[torch.Tensor], steps: Optional[int] = None,
+               sem_embs: Optional[torch.Tensor] = None):
+        """Greedy decoding (= beam search with beam_size 1, models/Wrapper.py:34-35) of B clips.
+
+        Returns device tensors: fed int32 [B, T+1] (column 0 = BOS), length int32 [B],
+        score fp32 [B] (sum of chosen log-probs).  No host synchronisation inside.
+        """
+        B, Lk, d = mem.shape
+        T = self.T
+        steps = T if steps is None else steps
+        mem = mem.to(self.device, mem.dtype if mem.dtype == self.h16 else torch.float32)  # bf16: lean encode
+        sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
+        fed = self.ws("g_fed", (B, T + 1), torch.int32)
+        score = self.ws("g_score", (B,))
+        length = self.ws("g_len", (B,), torch.int32)
+        fin = self.ws("g_fin", (B,), torch.int32)
+        fed.zero_(); fed[:, 0] = BOS
+        score.zero_(); length.zero_(); fin.zero_()
+        ckv = self.cross_src(mem, B)
+        akv = self.attr_kv(sem_embs) if self.attr_att else None
+        skv = [self.ws("g_skv%d" % li, (B, T, 2 * d), self.wt) for li in range(self.n_layers)]
+        parts = self.vocab_parts(B)
+        pmax = self.ws("g_pmax", (B, parts))
+        pidx = self.ws("g_pidx", (B, parts), torch.int32)
+        psum = self.ws("g_psum", (B, parts))
+        x0, x0b = self.ws("g_x0", (B, d)), self.wsb("g_x0", (B, d))  # the workspaces _decode_step embeds into
+        for t in range(1, steps + 1):
+            x, xb = self._decode_step(t, B, 1, fed, None, sem, ckv, skv, Lk, "g_", akv=akv, embedded=t > 1)
+            self.vocab_argmax(x, xb, B, pmax, pidx, psum)
+            if t < steps:  # the token choice and, in the same launch, its embedding = the input of step t + 1
+                self.call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
+                     ptr(length), ptr(fin), t, T, EOS, B, ptr(self.w["word"]), ptr(self.w["pos"]), ptr(sem), 1,
+                     ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps, ptr(x0), ptr(x0b), d, d, tag="step_update_embed")
+            else:
+                self.call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(fed), T + 1, ptr(score),
+                     ptr(length), ptr(fin), t, T, EOS, B)
+        return fed, length, score
+
+    # ------------------------------------------------------------------ greedy with early exit + compaction
+    def _call_rows(self, fn, src, dst, idx, n):
+        """care_gather_rows / care_scatter_rows on tensors whose first dim is the row."""
+        rb = src[0].numel() * src.element_size()
+        self.call(fn, ptr(src), src.stride(0) * src.element_size(), ptr(dst), dst.stride(0) * dst.element_size(), ptr(idx), n, rb)
+
+    def _slot_bucket(self, active: int, cap: int) -> int:
+        """Row count a compacted decode runs on: `active` rounded up to a granule of cap / 32 (>= 64), so
+        that the captured segments of different batches meet the same few shapes."""
+        g = max(64, cap // 32)
+        return min(cap, (active + g - 1) // g * g)
+
+    def greedy_early_exit(self, feats: List[torch.Tensor], lean: bool = False, use_graph: bool = True):
+        """encode + greedy decode that STOPS when every clip has ended and drops ended clips from the
+        batch on the way (the reference: models/Translator.py:77-81 `if not active_inst_idx_list: break`,
+        :194-209 `collect_active_part`; per step and on the host there).
+
+        The 29 steps run in segments of `segment_steps`; after a segment one counter comes back to the
+        host - the rows still active.  None: done.  At most 3/4 of the slots in use: the active rows are
+        gathered to the front of a second set of buffers (K/V caches, memory, next-step inputs, tokens:
+        csrc/compact.hip) and the following segments run on that many rows (rounded up to a bucket;
+        the padding rows are ended clips that ride along).  Rows are independent end to end and the row-count
+        switches of the ENGINE (fused dense+LayerNorm, beam selection form, cross-attention form) are taken from the
+        pass's initial row count (`_form_rows`), so a clip meets the same kernel forms as in the fixed-length pass;
+        what still follows the current row count are two tilings INSIDE the library (QKV / FFN1 and the vocabulary
+        arg-max move from 256-row to 128-row panels below 8192 rows): the same bf16 products and the same arg-max
+        columns, fp32 sums in another order (scores within 1e-4).  A segment is captured into a hipGraph the
+        second time its (first step, row count, buffer set) comes up.  Results are per CLIP:
+        fed int32 [B, T + 1] (column 0 = BOS), length int32 [B], score fp32 [B]."""
+        feats = self._prep_feats(feats)
+        B, T, d = feats[0].shape[0], self.T, self.d
+        # small batches are launch-bound: a segment boundary (one host round trip + one more graph launch,
+        # ~40 us) costs as much as several of their steps, so they check twice as rarely and never compact
+        S = max(1, self.segment_steps) * (1 if B >= 2048 else 2)
+        out_fed = self.ws("ge_out_fed", (B, T + 1), torch.int32)
+        out_len = self.ws("ge_out_len", (B,), torch.int32)
+        out_score = self.ws("ge_out_score", (B,))
+        idx = self.ws("ge_idx", (B,), torch.int32)
+        cnt = self.ws("ge_cnt", (1,), torch.int32)
+        fkey = (tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        st = {}
+
+        def state(par, n):
+            """Views of buffer set `par` for n slots (allocated at full size once)."""
+            self._ws_cap = (n, B)
+            tag = "g%d_" % par
+            v = dict(tag=tag, n=n,
+                     fed=self.ws(tag + "fed", (n, T + 1), torch.int32), score=self.ws(tag + "score", (n,)),
+                     length=self.ws(tag + "len", (n,), torch.int32), fin=self.ws(tag + "fin", (n,), torch.int32),
+                     clip=self.ws(tag + "clip", (n,), torch.int32),
+                     x0=self.ws(tag + "x0", (n, d)), x0b=self.wsb(tag + "x0", (n, d)),
+                     skv=[self.ws(tag + "skv%d" % li, (n, T, 2 * d), self.wt) for li in range(self.n_layers)])
+            return v
+
+        def run_steps(v, t0, t1, enc=None):
+            n = v["n"]
+            self._ws_cap = (n, B)
+            parts = self.vocab_parts(n)
+            pmax, psum = self.ws(v["tag"] + "pmax", (n, parts)), self.ws(v["tag"] + "psum", (n, parts))
+            pidx = self.ws(v["tag"] + "pidx", (n, parts), torch.int32)
+            for t in range(t0, t1 + 1):
+                x, xb = self._decode_step(t, n, 1, v["fed"], None, v["sem"], v["ckv"], v["skv"], self.Lk, v["tag"],
+                                          akv=v["akv"], embedded=t > 1)
+                self.vocab_argmax(x, xb, n, pmax, pidx, psum)
+                if t < T:
+                    self.call("care_greedy_update_embed", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
+                         ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n, ptr(self.w["word"]),
+                         ptr(self.w["pos"]), ptr(v["sem"]), 1, ptr(self.w["emb_g"]), ptr(self.w["emb_be"]), self.eps,
+                         ptr(v["x0"]), ptr(v["x0b"]), d, d, tag="step_update_embed")
+                else:
+                    self.call("care_greedy_update", ptr(pmax), ptr(pidx), ptr(psum), parts, ptr(v["fed"]), T + 1,
+                         ptr(v["score"]), ptr(v["length"]), ptr(v["fin"]), t, T, EOS, n)
+            self.call("care_active_slots", ptr(v["fin"]), n, ptr(idx), ptr(cnt))
+
+        def first_segment():
+            """encode, state initialisation and steps 1 .. S on all B slots of buffer set 0."""
+            self._ws_cap = None
+            enc = self.encode(feats, lean, static=True)
+            mem = enc["encoder_hidden_states"]
+            sem = enc.get("semantic_hidden_states")
+            v = state(0, B)
+            v["fed"].zero_(); v["fed"][:, 0] = BOS
+            v["score"].zero_(); v["length"].zero_(); v["fin"].zero_()
+            v["clip"].copy_(self._arange(B))
+            v["sem"] = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
+            self._ws_cap = None  # cross_src / attr_kv work on all B clips
+            v["ckv"] = self.cross_src(mem, B)
+            v["akv"] = self.attr_kv(enc.get("semantic_embs")) if self.attr_att else None
+            run_steps(v, 1, min(S, T))
+            return enc, v
+
+        replayable = lambda key, fn: self._replay(key, fn, use_graph)
+
+        try:
+            self._form_rows = B
+            enc, v = replayable(("gseg0", self.latent_ok, bool(lean), S) + fkey, first_segment)
+            par, t = 0, min(S, T) + 1
+            stats = dict(clips=B, steps=t - 1, row_steps=B * (t - 1), compactions=0)
+            self.last_decode = stats  # what the last pass actually ran (tests, bench)
+            while True:
+                active = int(cnt.item())  # the one host round trip per segment
+                if active == 0 or t > T:
+                    break
+                n_new = self._slot_bucket(active, B)
+                if n_new * 4 <= v["n"] * 3 and v["n"] >= 2048:
+                    v = self._compact(v, state(par ^ 1, n_new), idx, active, out_fed, out_len, out_score)
+                    par ^= 1
+                    stats["compactions"] += 1
+                t1 = min(t + S - 1, T)
+                vv = v
+                replayable(("gseg", par, t, t1, v["n"], B, self.latent_ok), lambda: run_steps(vv, t, t1))
+                stats["steps"] = t1
+                stats["row_steps"] += v["n"] * (t1 - t + 1)
+                t = t1 + 1
+            n = v["n"]
+            self._call_rows("care_scatter_rows", v["fed"], out_fed, v["clip"], n)
+            self._call_rows("care_scatter_rows", v["length"].view(n, 1), out_len.view(B, 1), v["clip"], n)
+            self._call_rows("care_scatter_rows", v["score"].view(n, 1), out_score.view(B, 1), v["clip"], n)
+        finally:
+            self._ws_cap = None
+        return enc, out_fed, out_len, out_score
+
+    def _arange(self, n):
+        t = self._ws_get("arange", (n,), torch.int32)
+        torch.arange(n, device=self.device, dtype=torch.int32, out=t)  # refilled: an evicted buffer comes back empty
+        return t
+
+    def _compact(self, v, w, idx, active, out_fed, out_len, out_score):
+        """Results of every slot of `v` -> the per-clip outputs; then the first w['n'] slots of the
+        partition `idx` (active ones first, ended ones as padding) -> buffer set `w`."""
+        n, m = v["n"], w["n"]
+        B = out_fed.shape[0]
+        self._call_rows("care_scatter_rows", v["fed"], out_fed, v["clip"], n)
+        self._call_rows("care_scatter_rows", v["length"].view(n, 1), out_len.view(B, 1), v["clip"], n)
+        self._call_rows("care_scatter_rows", v["score"].view(n, 1), out_score.view(B, 1), v["clip"], n)
+        for k in ("fed", "x0", "x0b"):
+            if v[k] is not None:
+                self._call_rows("care_gather_rows", v[k], w[k], idx, m)
+        for k in ("score", "length", "fin", "clip"):
+            self._call_rows("care_gather_rows", v[k].view(n, 1), w[k].view(m, 1), idx, m)
+        for a, b in zip(v["skv"], w["skv"]):
+            self._call_rows("care_gather_rows", a, b, idx, m)
+        tag = w["tag"]
+        self._ws_cap = (m, B)
+
+        def moved(name, src, per=1):
+            """Per-clip tensor with `per` rows per clip ([n * per, ...] or, per = 1, [n, ...]) -> m clips."""
+            if src is None:
+                return None
+            s2 = src.view(n, -1)
+            dst = self.ws(tag + name, (m, s2.shape[1]), src.dtype)
+            self._call_rows("care_gather_rows", s2, dst, idx, m)
+            return dst.view((m * per,) + tuple(src.shape[1:])) if per > 1 else dst.view((m,) + tuple(src.shape[1:]))
+
+        w["sem"] = moved("sem", v["sem"])
+        if isinstance(v["ckv"], tuple):  # absorbed form: one bf16 memory [n, Lk, d] shared by the layers
+            w["ckv"] = (moved("mem", v["ckv"][0]),) * len(v["ckv"])
+        else:                            # projected K/V: [n * Lk, 2d] per layer
+            w["ckv"] = [moved("ckv%d" % i, kv, self.Lk) for i, kv in enumerate(v["ckv"])]
+        w["akv"] = [moved("akv%d" % i, kv, self.topk) for i, kv in enumerate(v["akv"])] if v["akv"] is not None else None
+        w["clip"][active:].fill_(-1)     # padding slots: ended clips whose results are already out
+        return w
+
+    def translate_greedy(self, feats: List[torch.Tensor], use_graph: bool = True, lean: bool = False,
+                         early_exit: Optional[bool] = None):
+        """encode + greedy decode of one batch; replayed from a hipGraph when possible.
+
+        One pass issues ~360-440 kernel launches (12-15 per step); driven from Python that is
+        host-bound, so the whole pass is captured once per (batch, input buffers) into a
+        hipGraph (torch.cuda.CUDAGraph on the same stream capture) and replayed.  The graph
+        is keyed on the input pointers: callers that re-use their feature buffers (bench,
+        pinned double-buffered loaders) replay; a first-seen buffer set runs eagerly.
+        Returns (enc_outputs, fed, length, score) - static tensors when replayed.
+        lean: the caller reads nothing of enc_outputs (the Translator): encode(..., lean=True).
+        """
+        feats = self._prep_feats(feats)
+        self._begin_pass()
+        lanes = self.lanes_for(feats[0].shape[0]) if use_graph else 1
+        if lanes > 1:
+            return self._translate_greedy_lanes(feats, lanes, lean)
+        ee = self.early_exit if early_exit is None else early_exit
+        if self.resident_ok(feats[0].shape[0]):  # small batch: encode + one resident launch for the whole decode
+            def run_resident():
+                self._form_rows = feats[0].shape[0]
+                enc = self.encode(feats, lean, static=True, small=self.small_forms(feats[0].shape[0]))
+                return (enc,) + tuple(self.greedy_resident(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
+                                                           sem_embs=enc.get("semantic_embs"), early_exit=ee))
+            key = ("gres", bool(lean), bool(ee), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+            try:
+                out = self._replay(key, run_resident, use_graph)
+            except _lib.CareHipError as exc:  # (refused, nothing enqueued: see translate_beam)
+                if "CARE_ESHAPE" not in str(exc):
+                    raise
+                self._resident_refused = True
+                out = None
+            if out is not None:
+                nb = self.lib.care_decode_resident_scratch(feats[0].shape[0], self.d, self.ff, self.V)
+                self.last_decode = dict(clips=feats[0].shape[0], steps=self.ws("r_scratch", (nb,), torch.uint8)[8:12].view(torch.int32)[0],
+                                        compactions=0, resident=True)
+                return out
+        if ee:
+            # stop when every clip has ended, drop ended clips on the way (greedy_early_exit)
+            return self.greedy_early_exit(feats, lean, use_graph)
+
+        def run():
+            self._form_rows = feats[0].shape[0]
+            enc = self.encode(feats, lean)
+            return (enc,) + tuple(self.greedy(enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
+                                              sem_embs=enc.get("semantic_embs")))
+
+        key = ("greedy", self.latent_ok, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        return self._replay(key, run, use_graph)
+
+    def lanes_for(self, B: int) -> int:
+        """Batch lanes of a graph-replayed greedy pass.
+
+        A pass alternates HBM-bound kernels (attention, 44% of the time at B = 16384) with
+        MFMA-bound ones (the GEMMs); two half-batches on two HIP streams inside the one captured
+        graph let the one kind fill the other's idle unit and hide every kernel's tail.  Measured
+        (bf16 Base `ami`, one MI355X): +8% at B = 4096, +5% at 8192/16384; at B <= 2048 the
+        kernels are too short and the extra graph edges cost more than they hide (-3%..-30%), and
+        4 lanes are never better than 2.
+
+        A tuning knob, OFF by default (`self.lanes` = 1; `CARE_LANES` or `engine.lanes = 2` turn it
+        on): with two lanes the kernels share the chip, so per-kernel durations - and with them the
+        roofline accounting of bench.py and profiles/ - no longer describe a kernel on its own.
+        """
+        env = os.environ.get("CARE_LANES")
+        n = int(env) if env else int(self.lanes)
+        return max(1, min(n, B))
+
+    def _translate_greedy_lanes(self, feats, lanes, lean=False):
+        """translate_greedy with the batch cut into `lanes` contiguous clip ranges, each with its own
+        workspaces and HIP stream, forked from and joined to the capture stream inside ONE hipGraph.
+        Clips are independent, so the results are those of the single-lane pass."""
+        B = feats[0].shape[0]
+        bounds = [(B * i // lanes, B * (i + 1) // lanes) for i in range(lanes)]
+        if len(getattr(self, "_lane_streams", ())) < lanes:
+            self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
+
+        def run():
+            cur = torch.cuda.current_stream()
+            parts = []
+            try:
+                for i, (lo, hi) in enumerate(bounds):
+                    st = self._lane_streams[i]
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        self._lane = i + 1  # workspace namespace of this lane (see ws)
+                        enc = self.encode([f[lo:hi] for f in feats], lean)
+                        parts.append((enc,) + tuple(self.greedy(enc["encoder_hidden_states"],
+                                                                enc.get("semantic_hidden_states"),
+                                                                sem_embs=enc.get("semantic_embs"))))
+            finally:
+                self._lane = 0
+            for st in self._lane_streams[:lanes]:
+                cur.wait_stream(st)
+            return (_LaneOutputs([pt[0] for pt in parts]),) + tuple(torch.cat([pt[k] for pt in parts], 0)
+                                                                     for k in (1, 2, 3))
+
+        key = ("greedy", lanes, self.latent_ok, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
+        return self._replay(key, run, True)

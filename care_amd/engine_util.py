@@ -1,0 +1,44 @@
+"""Small helpers shared by the parts of care_amd.engine.HipEngine."""
+from typing import Optional
+
+import torch
+
+from ._lib import CARE_BF16, CARE_F32
+
+
+def _code(t: Optional[torch.Tensor]) -> int:
+    return CARE_BF16 if (t is not None and t.dtype in (torch.bfloat16, torch.float16)) else CARE_F32  # (CARE_BF16: the library's 16-bit type)
+
+
+class _LaneOutputs(dict):
+    """Encoder outputs of a pass that ran as several batch lanes.  Every value is per clip (first
+    dim = clips of the lane), so the full-batch tensor is the concatenation of the lanes'; it is
+    built on access only - the captioning loop never reads these (translator.py), and
+    `encoder_hidden_states` alone is 2.9 GB at B = 16384."""
+
+    def __init__(self, parts):
+        super().__init__((k, None) for k in parts[0])
+        self._parts = parts
+
+    @staticmethod
+    def _join(vals):
+        if vals[0] is None:
+            return None
+        if isinstance(vals[0], (list, tuple)):
+            return [torch.cat([v[i] for v in vals], 0) for i in range(len(vals[0]))]
+        return torch.cat(vals, 0)
+
+    def __getitem__(self, k):
+        super().__getitem__(k)  # KeyError for unknown names
+        # joined on EVERY access: the lanes' tensors are static graph outputs that the next replay
+        # overwrites, so a cached concatenation would go stale
+        return self._join([pt[k] for pt in self._parts])
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self]
+
+    def values(self):
+        return [self[k] for k in self]

@@ -1,9 +1,9 @@
 #!/bin/bash
 # rocprofv3 evidence of the current build (run on the GPU box through gpurun; tools/profiles_post.py turns the output into
-# profiles/<round>_* and regenerates the "Readings" of profiles/README.md):   ROUND=r04 bash tools/profiles.sh
+# profiles/<round>_* and regenerates the "Readings" of profiles/README.md):   ROUND=r05 bash tools/profiles.sh
 # Counters are collected in passes of their own (kernel-trace only beside --pmc).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; ROUND=${ROUND:-r04}; O=$R/gpurun_out/${ROUND}prof; mkdir -p $O
+R=$GRAFT_REPO_ROOT; ROUND=${ROUND:-r05}; O=$R/gpurun_out/${ROUND}prof; mkdir -p $O
 B="python3 $R/bench.py --no-cpu-baseline --no-legs"
 stats() {  # name, command...: kernel trace with --stats, keeps the summary csv
   local name=$1; shift
@@ -19,6 +19,9 @@ stats greedy_B1 $B --batch 1 --steps 20 --warmup 3
 stats beam5_B128 $B --batch 128 --beam 5 --config msrvtt_care_beam5 --steps 20 --warmup 3
 stats beam5_B1 $B --batch 1 --beam 5 --config msrvtt_care_beam5 --steps 20 --warmup 3
 stats train_B64 python3 $R/tools/train_prof.py 64 10
+stats trace_fp16 $B --steps 5 --warmup 2 --dtype fp16
+stats beam5_chain_B128 python3 $R/tools/chain_prof.py 128 3
+stats beam5_multilaunch_B512 python3 $R/tools/beam_sweep.py --only multi-launch 512
 pmc() {  # name, counters, command...
   local name=$1 ctr=$2; shift 2
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$name -o t -- "$@" > $O/$name.log 2>&1
@@ -39,9 +42,21 @@ pmc write WRITE_SIZE $B --steps 1 --warmup 2 --no-graph
 pmc sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" python3 $R/tools/pmc_target.py 32768
 pmc sq_resident "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_IFETCH" python3 $R/bench.py --no-cpu-baseline --no-legs --batch 128 --beam 5 --config msrvtt_care_beam5 --steps 3 --warmup 2 --no-graph
 pmc icache_resident "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" python3 $R/bench.py --no-cpu-baseline --no-legs --batch 128 --beam 5 --config msrvtt_care_beam5 --steps 3 --warmup 2 --no-graph
+# the phases of the resident beam launch ONE KERNEL EACH (the chained step, csrc/decode_chain.hip): counters per phase
+pmc2() {  # name, counters, command...: aggregated per kernel by tools/pmc_agg.py
+  local name=$1 ctr=$2; shift 2
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$name -o t -- "$@" > $O/$name.log 2>&1
+  f=$(find $O/$name -name "t_counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 $R/tools/pmc_agg.py $f chain_ > $O/${name}_counters.txt
+  rm -rf $O/$name
+}
+pmc2 chain_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" python3 $R/tools/chain_prof.py 128 1
+pmc2 chain_sq2 "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY" python3 $R/tools/chain_prof.py 128 1
 cd $R
+python3 tools/greedy_sweep.py 1 64 128 256 512 1024 2048 4096 > $O/greedy_sweep.txt 2>&1
+python3 tools/greedy_sweep.py --config vatex_care_large 1 32 64 128 >> $O/greedy_sweep.txt 2>&1
 python3 tools/resident_prof.py 1 128 > $O/resident_phase_clocks.txt 2>&1
 python3 tools/resident_prof.py --beam 5 --config msrvtt_care 1 128 >> $O/resident_phase_clocks.txt 2>&1
-python3 tools/beam_sweep.py > $O/beam_sweep.txt 2>&1
+python3 tools/beam_sweep.py 1 4 16 32 64 128 256 512 819 > $O/beam_sweep.txt 2>&1
 tail -1 $O/trace.log | cut -c1-200
 ls -la $O

@@ -20,7 +20,7 @@ def main():
               (4096, 4096, 4096), (8192, 8192, 8192), (640, 4096, 1024)]
     if len(sys.argv) > 1:
         shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
-    cfgs = ["222", "4412", "90"]
+    cfgs = os.environ.get("TILE_BENCH_CFGS", "222,4412,90").split(",")
     p = lambda t: t.data_ptr()
     for M, N, K in shapes:
         A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
