@@ -20,8 +20,9 @@
 namespace {
 
 constexpr int PK_NP = 4;  // parts per lane: V <= 64 * 64 * PK_NP
+constexpr int PK_NQ = 8;  // K fragments (of 32) in flight per operand
 
-__global__ __launch_bounds__(256) void beam_pick_groups_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+__global__ __launch_bounds__(256, 4) void beam_pick_groups_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
                                                                const float* __restrict__ gmax, int parts, int bm,
                                                                const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
                                                                int V, int K, float* __restrict__ cand_val,
@@ -102,18 +103,21 @@ __global__ __launch_bounds__(256) void beam_pick_groups_kernel(const float* __re
   const bf16_t* w1 = W + (int64_t)min(gl[1] * 4 + (l16 & 3), V - 1) * K + kg * 8;
   const bf16_t* ar = A + (int64_t)r * lda + kg * 8;
   f32x4 vt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  for (int k0 = 0; k0 < K; k0 += 512) {  // (K in chunks of 16 fragments; one accumulator chain per tile, ascending K)
-    const int nq = min(16, (K - k0) >> 5);
-    bf16x8 wf0[16], wf1[16], af[16];
+  // (K in chunks of PK_NQ fragments - 96 registers of fragments, four waves per SIMD: a row is a chain of four dependent
+  // memory round trips, so rows in flight are what a launch of a few thousand rows needs; one accumulator chain per tile,
+  // ascending K)
+  for (int k0 = 0; k0 < K; k0 += 32 * PK_NQ) {
+    const int nq = min(PK_NQ, (K - k0) >> 5);
+    bf16x8 wf0[PK_NQ], wf1[PK_NQ], af[PK_NQ];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < PK_NQ; ++q) {
       const int o = k0 + min(q, nq - 1) * 32;
       wf0[q] = *reinterpret_cast<const bf16x8*>(w0 + o);
       if (bm > 4) wf1[q] = *reinterpret_cast<const bf16x8*>(w1 + o);
       af[q] = *reinterpret_cast<const bf16x8*>(ar + o);
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int q = 0; q < PK_NQ; ++q)
       if (q < nq) {
         vt[0] = care_mfma_16x16x32_h16(wf0[q], af[q], vt[0], 0, 0, 0);
         if (bm > 4) vt[1] = care_mfma_16x16x32_h16(wf1[q], af[q], vt[1], 0, 0, 0);

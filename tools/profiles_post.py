@@ -1,7 +1,7 @@
 """gpurun_out/<round>prof/* (tools/profiles.sh) -> profiles/<round>_*, and the "Readings" section of profiles/README.md
 REGENERATED from the committed files (so the text cannot drift from the data):
 
-    python tools/profiles_post.py [round]          # default r04; copies + regenerates
+    python tools/profiles_post.py [round]          # default r05; copies + regenerates
     python tools/profiles_post.py [round] --readme # only regenerate the readings from profiles/<round>_*
 """
 import collections
@@ -14,14 +14,15 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = next((a for a in sys.argv[1:] if not a.startswith("-")), "r04")
+ROUND = next((a for a in sys.argv[1:] if not a.startswith("-")), "r05")
 SRC = os.path.join(ROOT, "gpurun_out", ROUND + "prof")
 DST = os.path.join(ROOT, "profiles")
 head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 
 STATS = {"trace": "bench_B32768_bf16", "trace_vatex": "vatex_care_large_B4096_bf16", "trace_vatex16k": "vatex_care_large_B16384_bf16", "greedy_B128": "small_batch_greedy_B128",
          "greedy_B1": "small_batch_greedy_B1", "beam5_B128": "small_batch_beam5_B128", "beam5_B1": "small_batch_beam5_B1",
-         "train_B64": "training_step_B64"}
+         "train_B64": "training_step_B64", "trace_fp16": "bench_B32768_fp16", "beam5_chain_B128": "small_batch_beam5_chain_B128",
+         "beam5_multilaunch_B512": "mid_batch_beam5_multilaunch_B512"}
 ours = lambda k: ("anonymous namespace" in k or k.startswith("_ZN12_GLOBAL__N_1") or k.startswith("_Z17split2_act")) and "at::native" not in k
 
 
@@ -41,11 +42,19 @@ def copy_in():
         f = os.path.join(SRC, src + "_kernel_stats.csv")
         if os.path.exists(f):
             shutil.copy(f, os.path.join(DST, "{}_{}_kernel_stats.csv".format(ROUND, dst)))
-    for name in ("resident_phase_clocks.txt", "beam_sweep.txt"):
+    for name in ("resident_phase_clocks.txt", "beam_sweep.txt", "greedy_sweep.txt"):
         f = os.path.join(SRC, name)
         if os.path.exists(f):
             txt = "".join(l for l in open(f) if "amdgpu.ids" not in l)
             open(os.path.join(DST, "{}_{}".format(ROUND, name)), "w").write("# build {}\n".format(head) + txt)
+    # hardware counters PER PHASE of the beam step (the chained form: one kernel per phase of the resident launch)
+    parts = [os.path.join(SRC, n + "_counters.txt") for n in ("chain_sq1", "chain_sq2")]
+    if all(os.path.exists(f) for f in parts):
+        with open(os.path.join(DST, ROUND + "_chain_phase_counters.txt"), "w") as out:
+            out.write("# build {}\n# rocprofv3 --pmc <counters> --kernel-trace -- python3 tools/chain_prof.py 128 1 (two passes); mean per launch, "
+                      "640 rows = 128 clips x beam 5; kernels = the phases of the resident beam launch (csrc/decode_chain.hip)\n".format(head))
+            for f in parts:
+                out.write(open(f).read())
     fetch, write = counters("fetch"), counters("write")
     if fetch or write:
         pm = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --no-cpu-baseline --no-legs --steps 1 --warmup 2 "
@@ -169,10 +178,29 @@ def readings():
                       "misses ({:.2%}).".format(ROUND, short(e["kernel"]), e["SQC_ICACHE_REQ"], e.get("SQC_ICACHE_MISSES", 0),
                                                 e.get("SQC_ICACHE_MISSES_DUPLICATE", 0),
                                                 (e.get("SQC_ICACHE_MISSES", 0) + e.get("SQC_ICACHE_MISSES_DUPLICATE", 0)) / max(e["SQC_ICACHE_REQ"], 1))]
-    for name in ("resident_phase_clocks.txt", "beam_sweep.txt"):
+    rows = kernel_stats("bench_B32768_fp16")
+    dom = next((r for r in rows if "attention_latent_kernel<4" in r["Name"]), None)
+    if dom:
+        tot = sum(float(r["TotalDurationNs"]) for r in rows if ours(r["Name"]))
+        L += ["", "`{}_bench_B32768_fp16_kernel_stats.csv` (the headline workload in fp16 mode, libcare_hip_f16.so): dominant kernel {:.1f} us "
+              "average, {:.1f} % of our kernels' time.".format(ROUND, float(dom["AverageNs"]) / 1e3, 100 * float(dom["TotalDurationNs"]) / tot)]
+    rows = [r for r in kernel_stats("small_batch_beam5_chain_B128") if "chain_" in r["Name"]]
+    if rows:
+        n = max(int(r["Calls"]) for r in rows) / 29.0  # passes
+        per_step = sum(float(r["TotalDurationNs"]) for r in rows) / (29.0 * n) / 1e3
+        L += ["", "`{}_small_batch_beam5_chain_B128_kernel_stats.csv` (`tools/chain_prof.py 128 3`: the beam step as a chain of kernels, eager): "
+              "{:.0f} us of kernels per decoder step; by phase: ".format(ROUND, per_step) +
+              ", ".join("`{}` {:.1f} us".format(short(r["Name"])[:60], float(r["AverageNs"]) / 1e3) for r in rows[:10]) + "."]
+    path = os.path.join(DST, ROUND + "_chain_phase_counters.txt")
+    if os.path.exists(path):
+        L += ["", "`{}_chain_phase_counters.txt`: SQ counters per phase of the beam step at 640 rows (VALU / MFMA / LDS / VMEM instruction "
+              "counts, wave cycles, waits, LDS bank conflicts) - the resident launch is ONE kernel, the chain gives its phases one each.".format(ROUND)]
+    for name in ("resident_phase_clocks.txt", "beam_sweep.txt", "greedy_sweep.txt"):
         if os.path.exists(os.path.join(DST, "{}_{}".format(ROUND, name))):
-            L += ["", "`{}_{}`: {}".format(ROUND, name, "device clock at every phase boundary of decoder step 3, workgroup 0 (tools/resident_prof.py)"
-                                           if "phase" in name else "resident launch against the multi-launch search, whole passes (tools/beam_sweep.py)")]
+            what = {"resident_phase_clocks.txt": "device clock at every phase boundary of decoder step 3, workgroup 0 (tools/resident_prof.py)",
+                    "beam_sweep.txt": "beam 5 by batch: resident launch / chained step / multi-launch search, whole passes (tools/beam_sweep.py)",
+                    "greedy_sweep.txt": "greedy by batch, d_model 512 and 1024, whole passes (tools/greedy_sweep.py)"}[name]
+            L += ["", "`{}_{}`: {}".format(ROUND, name, what)]
     return "\n".join(L) + "\n"
 
 
