@@ -186,11 +186,18 @@ def readings():
               "average, {:.1f} % of our kernels' time.".format(ROUND, float(dom["AverageNs"]) / 1e3, 100 * float(dom["TotalDurationNs"]) / tot)]
     rows = [r for r in kernel_stats("small_batch_beam5_chain_B128") if "chain_" in r["Name"]]
     if rows:
-        n = max(int(r["Calls"]) for r in rows) / 29.0  # passes
-        per_step = sum(float(r["TotalDurationNs"]) for r in rows) / (29.0 * n) / 1e3
+        def phase(name):  # chain_gemm_kernel<K, AMODE, EPI, ...> -> the phase it is (csrc/decode_resident.h enums)
+            m = re.search(r"chain_gemm_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name) or re.search(r"chain_gemm_kernel<(\d+), (\d+), (\d+)", name)
+            if not m:
+                return short(name)[:40]
+            epi = {0: "QKV", 1: "query", 2: "dense + residual (x 2)", 3: "FFN dense1", 5: "vocabulary (groups)"}.get(int(m.group(3)), "gemm")
+            return epi + (" K=" + m.group(1) if m.group(1) != "512" else "")
+        adv = next((r for r in rows if "chain_advance" in r["Name"]), None)
+        steps = float(adv["Calls"]) if adv else 29.0  # one advance per decoder step
+        per_step = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e3
         L += ["", "`{}_small_batch_beam5_chain_B128_kernel_stats.csv` (`tools/chain_prof.py 128 3`: the beam step as a chain of kernels, eager): "
-              "{:.0f} us of kernels per decoder step; by phase: ".format(ROUND, per_step) +
-              ", ".join("`{}` {:.1f} us".format(short(r["Name"])[:60], float(r["AverageNs"]) / 1e3) for r in rows[:10]) + "."]
+              "{:.0f} us of kernels per decoder step; by phase (average per launch): ".format(ROUND, per_step) +
+              ", ".join("{} {:.1f} us".format(phase(r["Name"]), float(r["AverageNs"]) / 1e3) for r in rows[:10]) + "."]
     path = os.path.join(DST, ROUND + "_chain_phase_counters.txt")
     if os.path.exists(path):
         L += ["", "`{}_chain_phase_counters.txt`: SQ counters per phase of the beam step at 640 rows (VALU / MFMA / LDS / VMEM instruction "
