@@ -287,6 +287,17 @@ def extra_legs(dev, main_dtype, legs):
                                       form="resident" if eng.last_decode.get("resident") else
                                       "chain" if eng.last_decode.get("chain") else "multi-launch")
     legs["batch_sweep"] = dict(config_greedy="msrvtt_base_ami", config_beam5="msrvtt_care_beam5", dtype=main_dtype, **sweep)
+    # BASELINE configs[3] with translate.py's default decode: d_model 1024, beam 5, the 32 clips per GPU of a 256-clip batch
+    # over 8 GPUs (160 rows) - one resident launch since round 5 (csrc/decode_resident_beam.hip, D = 1024)
+    opt, eng = build("vatex_care_large", main_dtype)
+    feats = feats_for(opt, 32)
+    run = lambda: eng.translate_beam(feats, 5, 5, use_graph=True, lean=True)
+    for _ in range(3):
+        run()
+    dt = _timed(run, 20)
+    legs["vatex_care_large_beam5_B32"] = dict(config="vatex_care_large", dtype=main_dtype, clips_per_step=32, beam_size=5,
+                                              rows_per_decoder_step=160, captions_per_s=round(32 / dt, 1), ms_per_pass=round(dt * 1e3, 3),
+                                              decoder_step_us=round(dt * 1e6 / eng.T, 2), resident_launch=bool(eng.last_decode.get("resident")))
     # a model that ENDS its captions (EOS row of the vocabulary projection x 5: mixed lengths, mean ~8 like trained
     # captions; random-init weights never emit EOS): early termination + compaction against the fixed 29 steps
     boost = {"cls_head.tgt_word_prj.weight": {3: 5.0}}

@@ -23,6 +23,10 @@ struct BeamRowIn {
   int eg[RES_MAXE];
 };
 
+// D = d_model.  D > 512 (the `median` / `large` architectures, whose vocabulary phase runs in K-split items): the candidates'
+// logits are recomputed in the K-split form's order - per K quarter two accumulator chains, the quarters added as
+// q0 + ((q1 + q2) + q3) - a quarter's fragments at a time.
+template <int D = 512>
 RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, unsigned char* scratch_lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kg = lane >> 4;
   const int G = gridDim.x, bm = p.bm, stride = p.fed_stride;
@@ -125,6 +129,8 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
     //   finish: log-sum-exp of the row, the products in gemm_phase's accumulation order (two chains over even / odd k
     //           fragments), one candidate per lane (l16 < 8: tile l16 / 4, element l16 % 4 of the lane's group), bm
     //           rounds of arg-best (value desc, column asc) -> LDS.
+    const bf16_t* wide_w[2] = {nullptr, nullptr};  // D > 512: this lane's weight rows / the row's hidden state (issue -> finish)
+    const bf16_t* wide_a = nullptr;
     auto groups = [&](int sl, int (&gsel)[RES_BMK]) {
       unsigned long long hk[RES_BMK];
 #pragma unroll
@@ -164,10 +170,16 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
             if (kg == q) gout[tile] = gsel[tile * 4 + q];
           }
       }
-      load_w<16>(wf0, p.vocab + (int64_t)min(gl[0] * 4 + (l16 & 3), p.V - 1) * 512 + kg * 8);
-      if (bm > 4) load_w<16>(wf1, p.vocab + (int64_t)min(gl[1] * 4 + (l16 & 3), p.V - 1) * 512 + kg * 8);
+      if constexpr (D == 512) {
+        load_w<16>(wf0, p.vocab + (int64_t)min(gl[0] * 4 + (l16 & 3), p.V - 1) * 512 + kg * 8);
+        if (bm > 4) load_w<16>(wf1, p.vocab + (int64_t)min(gl[1] * 4 + (l16 & 3), p.V - 1) * 512 + kg * 8);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) af[q] = cld_b8(p.hn + (int64_t)r * 512 + kg * 8 + q * 32);
+        for (int q = 0; q < 16; ++q) af[q] = cld_b8(p.hn + (int64_t)r * 512 + kg * 8 + q * 32);
+      } else {  // (the fragments are fetched a K quarter at a time by `finish`)
+        wide_w[0] = p.vocab + (int64_t)min(gl[0] * 4 + (l16 & 3), p.V - 1) * D + kg * 8;
+        wide_w[1] = p.vocab + (int64_t)min(gl[1] * 4 + (l16 & 3), p.V - 1) * D + kg * 8;
+        wide_a = p.hn + (int64_t)r * D + kg * 8;
+      }
     };
     auto finish = [&](int sl, int i, const int (&gout)[2], const bf16x8 (&wf0)[16], const bf16x8 (&wf1)[16], const bf16x8 (&af)[16]) {
       float mloc = in[sl].pm[0];
@@ -179,24 +191,53 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
       for (int k = 0; k < RES_NP; ++k) sloc += in[sl].pm[k] == -INFINITY ? 0.f : in[sl].ps[k] * expf(in[sl].pm[k] - M);
       const float logS = logf(wave_sum_dpp(sloc));
       f32x4 vt[2];
-      {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (D == 512) {
+        {
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 16; q += 2) {
-          acc0 = care_mfma_16x16x32_h16(wf0[q], af[q], acc0, 0, 0, 0);
-          acc1 = care_mfma_16x16x32_h16(wf0[q + 1], af[q + 1], acc1, 0, 0, 0);
+          for (int q = 0; q < 16; q += 2) {
+            acc0 = care_mfma_16x16x32_h16(wf0[q], af[q], acc0, 0, 0, 0);
+            acc1 = care_mfma_16x16x32_h16(wf0[q + 1], af[q + 1], acc1, 0, 0, 0);
+          }
+          vt[0] = acc0 + acc1;
         }
-        vt[0] = acc0 + acc1;
-      }
-      vt[1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      if (bm > 4) {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        vt[1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (bm > 4) {
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 16; q += 2) {
-          acc0 = care_mfma_16x16x32_h16(wf1[q], af[q], acc0, 0, 0, 0);
-          acc1 = care_mfma_16x16x32_h16(wf1[q + 1], af[q + 1], acc1, 0, 0, 0);
+          for (int q = 0; q < 16; q += 2) {
+            acc0 = care_mfma_16x16x32_h16(wf1[q], af[q], acc0, 0, 0, 0);
+            acc1 = care_mfma_16x16x32_h16(wf1[q + 1], af[q + 1], acc1, 0, 0, 0);
+          }
+          vt[1] = acc0 + acc1;
         }
-        vt[1] = acc0 + acc1;
+      } else {
+        constexpr int QF = D / 128;  // fragments of a K quarter (what a wave of the K-split vocabulary phase multiplies)
+        f32x4 part[2][4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          bf16x8 a[QF], w0[QF], w1[QF];
+#pragma unroll
+          for (int i = 0; i < QF; ++i) {
+            a[i] = cld_b8(wide_a + (qq * QF + i) * 32);
+            w0[i] = *reinterpret_cast<const bf16x8*>(wide_w[0] + (qq * QF + i) * 32);
+            if (bm > 4) w1[i] = *reinterpret_cast<const bf16x8*>(wide_w[1] + (qq * QF + i) * 32);
+          }
+          f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < QF; i += 2) {
+            a0 = care_mfma_16x16x32_h16(w0[i], a[i], a0, 0, 0, 0);
+            a1 = care_mfma_16x16x32_h16(w0[i + 1], a[i + 1], a1, 0, 0, 0);
+            if (bm > 4) {
+              b0 = care_mfma_16x16x32_h16(w1[i], a[i], b0, 0, 0, 0);
+              b1 = care_mfma_16x16x32_h16(w1[i + 1], a[i + 1], b1, 0, 0, 0);
+            }
+          }
+          part[0][qq] = a0 + a1;
+          part[1][qq] = b0 + b1;
+        }
+        vt[0] = part[0][0] + ((part[0][1] + part[0][2]) + part[0][3]);
+        vt[1] = bm > 4 ? part[1][0] + ((part[1][1] + part[1][2]) + part[1][3]) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       }
       const int ctile = (l16 >> 2) & 1, ce = l16 & 3, cgrp = ctile * 4 + kg;
       const f32x4 vsel = ctile ? vt[1] : vt[0];

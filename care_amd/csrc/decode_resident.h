@@ -1536,11 +1536,11 @@ RES_PHASE_FN unsigned attn_phase(const RArgs& p, GridSync& gs, bool do_wait, con
 // hold).  One wave per (clip, head) fetches the head's K / V fragments ONCE and runs its bm queries past them - a fifth
 // of the fragment traffic of a wave per (row, head), and one item per wave at 128 clips instead of five in series.  The
 // arithmetic per row is attn_one's: the same bits as attn_phase.  The heads of a clip go to the waves of ONE XCD.
-template <int NKB>
+template <int NKB, int D = 512>
 RES_PHASE_FN unsigned attn_shared_phase(const RArgs& p, GridSync& gs, bool do_wait, const bf16_t* KV, int64_t kv_bs,
                                                       int bm, int nk, const float* bias, int bias_ld) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 3, chunk = lane & 7;
-  constexpr int d = 512;
+  constexpr int d = D;
   const int nkb = (nk + 7) >> 3, H = p.H, nclips = p.R / bm;
   const bool by_xcd = (gridDim.x & 7) == 0;
   const int x = by_xcd ? (int)(blockIdx.x & 7) : 0, xs = by_xcd ? 8 : 1;

@@ -29,7 +29,9 @@ namespace {
 // KCF = ff / 512.  Row tiles per workgroup and weight fetch: RQ (QKV), RD (the N = 512 products), RF (FFN dense1), RV
 // (vocabulary); SM (<= 64 rows): QKV and FFN dense1 in 16-column K-split items, FFN dense2 over two workgroups per
 // column tile (the forms of decode_resident.hip).
-template <int KCF, int RQ, int RD, int RF, int RV, bool SM, bool KD>  // KD: the N = 512 products in K-split items
+// D = d_model: 512, or 768 / 1024 (config/archs.yaml:15-26, ff = 4 D, up to 128 rows): the K-split forms in every GEMM phase,
+// the vocabulary included, FFN dense2 over two workgroups per column tile - the forms of decode_resident.hip's wide instances.
+template <int KCF, int RQ, int RD, int RF, int RV, bool SM, bool KD, int D = 512>  // KD: the N = d_model products in K-split items
 __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p_by_value) {  // (read through the kernarg segment: res_args)
   const ResKArgs kargs = RES_KARGS();
 #define p (res_args(kargs))
@@ -38,7 +40,8 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p_by
   GridSync gs{p.sync, (unsigned)p.ghost, -1, false, 0, 0, 0u};
   gs.fenced = p.fenced != 0;
   const int d = p.d;
-  constexpr bool HF = KCF == 4 && SM;
+  constexpr bool WIDE = D != 512;
+  constexpr bool HF = (KCF == 4 && SM) || WIDE;
   const float* y2 = HF ? p.y2 : nullptr;  // the second K half of FFN dense2, added by its consumers
   bool ended = false;
   int sl = 0, sl_prev = 0;
@@ -96,33 +99,34 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p_by
     t_run = t;
     for (int l = 0; l < p.n_layers; ++l) {
       const RLayer& L = p.L[l];
-      if (l == 0) RES_PHASE((gemm_phase<512, A_EMBEDB, E_QKV, SM, RQ>(p, gs, !first_waited, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv)));
-      else RES_PHASE((gemm_phase<512, A_LN, E_QKV, SM, RQ>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2)));
-      RES_PHASE((p.T <= 32 ? attn_phase<true, 4, true>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0, p.anc[(t - 1) & 1])
-                            : attn_phase<true, RES_MAXKB, true>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0, p.anc[(t - 1) & 1])));
-      RES_PHASE((gemm_phase<512, A_BF16, E_RES, KD, RD>(p, gs, true, sA, L.o_w, L.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
+      if (l == 0) RES_PHASE((gemm_phase<D, A_EMBEDB, E_QKV, SM, RQ, D>(p, gs, !first_waited, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv)));
+      else RES_PHASE((gemm_phase<D, A_LN, E_QKV, SM, RQ, D>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2)));
+      RES_PHASE((p.T <= 32 ? attn_phase<true, 4, true, D>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0, p.anc[(t - 1) & 1])
+                            : attn_phase<true, RES_MAXKB, true, D>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0, p.anc[(t - 1) & 1])));
+      RES_PHASE((gemm_phase<D, A_BF16, E_RES, KD, RD, D>(p, gs, true, sA, L.o_w, L.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
       const float* g = L.g;
       const float* be = L.be;
       for (int a = 0; a < L.n_att; ++a) {
         const RAttn& A = L.att[a];
-        RES_PHASE((gemm_phase<512, A_LN, E_Q, KD, RD>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr)));
+        RES_PHASE((gemm_phase<D, A_LN, E_Q, KD, RD, D>(p, gs, true, sA, A.q_w, A.q_b, d, p.y, g, be, true, t, nullptr)));
         // more (row, head) pairs than waves: a wave per (clip, head) with the clip's keys fetched once for its beams
         if (p.R * p.H > 4 * (int)gridDim.x)
-          RES_PHASE((A.nkeys <= 64 ? attn_shared_phase<8>(p, gs, true, A.kv, A.kv_bs, p.bm, A.nkeys, A.bias, A.bias_ld)
-                                    : attn_shared_phase<RES_MAXKB>(p, gs, true, A.kv, A.kv_bs, p.bm, A.nkeys, A.bias, A.bias_ld)));
+          RES_PHASE((A.nkeys <= 64 ? attn_shared_phase<8, D>(p, gs, true, A.kv, A.kv_bs, p.bm, A.nkeys, A.bias, A.bias_ld)
+                                    : attn_shared_phase<RES_MAXKB, D>(p, gs, true, A.kv, A.kv_bs, p.bm, A.nkeys, A.bias, A.bias_ld)));
         else
-          RES_PHASE((A.nkeys <= 64 ? attn_phase<false, 8>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)
-                                    : attn_phase<false, RES_MAXKB>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)));
-        RES_PHASE((gemm_phase<512, A_BF16, E_RES, KD, RD>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
+          RES_PHASE((A.nkeys <= 64 ? attn_phase<false, 8, false, D>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)
+                                    : attn_phase<false, RES_MAXKB, false, D>(p, gs, true, A.kv, A.kv_bs, A.rows_per_kv, A.nkeys, nullptr, A.bias, A.bias_ld)));
+        RES_PHASE((gemm_phase<D, A_BF16, E_RES, KD, RD, D>(p, gs, true, sA, A.o_w, A.o_b, d, p.ctx, nullptr, nullptr, false, t, nullptr)));
         g = A.g; be = A.be;
       }
-      RES_PHASE((gemm_phase<512, A_LN, E_ACT, SM, RF>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr)));
-      if constexpr (KCF == 4) RES_PHASE((ffn2_phase<HF>(p, gs, sA, L.w2, L.b2)));
+      RES_PHASE((gemm_phase<D, A_LN, E_ACT, SM, RF, D>(p, gs, true, sA, L.w1, L.b1, p.ff, p.y, g, be, true, t, nullptr)));
+      if constexpr (WIDE) RES_PHASE((ffn2_phase<true, 512 * KCF, D>(p, gs, sA, L.w2, L.b2)));
+      else if constexpr (KCF == 4) RES_PHASE((ffn2_phase<HF>(p, gs, sA, L.w2, L.b2)));
       else RES_PHASE((gemm_phase<512 * KCF, A_BF16, E_RES, true>(p, gs, true, sA, L.w2, L.b2, d, p.h, nullptr, nullptr, false, t, nullptr)));
     }
     const RLayer& LL = p.L[p.n_layers - 1];
-    RES_PHASE((gemm_phase<512, A_LN, E_VOCABK, false, RV>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2, p.vcap)));
-    RES_PHASE((beam_advance_phase(p, gs, t, smem)));
+    RES_PHASE((gemm_phase<D, A_LN, E_VOCABK, WIDE, RV, D>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2, p.vcap)));
+    RES_PHASE((beam_advance_phase<D>(p, gs, t, smem)));
   }
 #undef RES_PHASE
   if (gs.dead) {  // aborted (GridSync::wait): every clip's count of finished hypotheses = -1
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p_by
 
 #undef p
 
-constexpr int RES_BEAM_KERNELS = 8;
+constexpr int RES_BEAM_KERNELS = 10;
 std::atomic<unsigned long long> g_resb_lds_done[RES_BEAM_KERNELS];
 std::atomic<int> g_resb_ok[RES_BEAM_KERNELS];
 
@@ -152,7 +156,7 @@ extern "C" {
 int64_t care_decode_resident_beam_scratch(int clips, int beam, int d, int ff, int V) {
   if (clips < 1 || beam < 1 || d < 1 || ff < 1 || V < 1) return CARE_EINVAL;
   const int64_t rows = (int64_t)clips * beam, R16 = (rows + 15) / 16 * 16;
-  int64_t parts = (V + 63) / 64;
+  int64_t parts = d == 512 ? (V + 63) / 64 : (V + 15) / 16;  // column items of the vocabulary phase (16 columns each when d_model > 512)
   if (parts > 64 * RES_NP) parts = 64 * RES_NP;
   // sync | xres, y, y2, q fp32 [R16, d] | ctx bf16 [R16, d] | h bf16 [R16, ff] | pmax, pidx, psum [R16, parts] |
   // gval, ggid [R16, parts, RES_BMK] | hn bf16 [R16, d]
@@ -173,9 +177,10 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
     return CARE_EINVAL;
   // the advance phase keeps a hypothesis' positions one per lane (T + 1 <= 64), a clip's candidates one per lane
   // (beam^2 <= 64) and RES_BMK groups per row
-  if (d != 512 || heads * 64 != d || (ff != 512 && ff != 1024 && ff != 2048) || T > 63 || V > 64 * 64 * RES_NP || beam > RES_BMK ||
-      V < 4 * RES_BMK * 4)
-    return CARE_ESHAPE;
+  const bool wide = d != 512;  // d_model 768 / 1024 with ff = 4 d_model, up to 128 rows (the kernel's D)
+  if (heads * 64 != d || T > 63 || V > 64 * 64 * RES_NP || beam > RES_BMK || V < 4 * RES_BMK * 4) return CARE_ESHAPE;
+  if (!wide && ff != 512 && ff != 1024 && ff != 2048) return CARE_ESHAPE;
+  if (wide && ((d != 768 && d != 1024) || ff != 4 * d || (int64_t)clips * beam > 256)) return CARE_ESHAPE;
   if (act < CARE_ACT_NONE || act > CARE_ACT_GELU) return CARE_EDTYPE;
   if (scratch_bytes < care_decode_resident_beam_scratch(clips, beam, d, ff, V) || !care_aligned16(scratch)) return CARE_EINVAL;
   const int rows = clips * beam;
@@ -194,7 +199,7 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   p.bm = beam; p.nclips = clips; p.need = need; p.fin_cap = fin_cap;
   p.anc[0] = anc0; p.anc[1] = anc1; p.done = done; p.nfin = nfin; p.fscore = fscore; p.flen = flen; p.fhyp = fhyp;
   const int64_t R16 = (rows + 15) / 16 * 16;
-  int64_t maxparts = (V + 63) / 64;
+  int64_t maxparts = wide ? (V + 15) / 16 : (V + 63) / 64;
   if (maxparts > 64 * RES_NP) maxparts = 64 * RES_NP;
   unsigned char* b = (unsigned char*)scratch;
   p.sync = (unsigned*)b; b += RES_SYNC_BYTES;
@@ -223,8 +228,8 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   // 640 rows 196 / 193 / 188)
   int cfg = rows <= 64 ? 0 : rows <= 512 ? 1 : 3;
   if (kn.beam_cfg >= 0 && kn.beam_cfg <= 3) cfg = kn.beam_cfg;
-  if (ff != 2048) cfg = 0;  // (one form for the narrow FFNs)
-  const int RT = (int)(R16 / 16), CIV = (V + 63) / 64;
+  if (ff != 2048 || wide) cfg = 0;  // (one form for the narrow FFNs and for d_model 768 / 1024)
+  const int RT = (int)(R16 / 16), CIV = wide ? (V + 15) / 16 : (V + 63) / 64;
   const int rv = cfg >= 2 ? 4 : (cfg == 1 && rows >= 128 && ff == 2048) ? 2 : 1;
   const int rq = cfg == 2 ? 4 : cfg == 3 ? 2 : 1, rdd = cfg >= 2 ? 2 : 1, rf = cfg == 2 ? 4 : cfg == 3 ? 2 : 1;
   const int RG = (RT + rv - 1) / rv;
@@ -246,25 +251,28 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   p.vcap = vcap;
   p.parts = beam_parts(vcap, RG, CIV);
   if (p.parts > maxparts || p.parts > 64 * RES_NP || p.parts < 1) return CARE_ESHAPE;
-  const int kmax = ff > d ? ff : d;
+  const int kmax = wide ? (ff / 2 > d ? ff / 2 : d) : (ff > d ? ff : d);  // (wide: FFN dense2's tile holds a K half)
   int lds = 16 * (kmax + 8) * 2;
   const int rmax = rv > rq ? (rv > rf ? rv : rf) : (rq > rf ? rq : rf);
   if (rmax * 16 * (512 + 8) * 2 > lds) lds = rmax * 16 * (512 + 8) * 2;
   hipStream_t st = (hipStream_t)stream;
   const dim3 g(grid), blk(256);
   int rc;
-#define RESB_LAUNCH(KCF, RQ, RD, RF, RV, SM, KD, SLOT)                                                                      \
+#define RESB_LAUNCH(KCF, RQ, RD, RF, RV, SM, KD, SLOT) RESB_LAUNCH_D(KCF, RQ, RD, RF, RV, SM, KD, 512, SLOT)
+#define RESB_LAUNCH_D(KCF, RQ, RD, RF, RV, SM, KD, DM, SLOT)                                                              \
   do {                                                                                                                  \
-    const void* kfn = (const void*)decode_resident_beam_kernel<KCF, RQ, RD, RF, RV, SM, KD>;                                \
+    const void* kfn = (const void*)decode_resident_beam_kernel<KCF, RQ, RD, RF, RV, SM, KD, DM>;                            \
     if ((rc = care_allow_dynamic_lds(kfn, lds, g_resb_lds_done[SLOT]))) return rc;                                       \
     if (!g_resb_ok[SLOT].load(std::memory_order_acquire)) {                                                             \
       if ((rc = res_check_residency(kfn, lds, grid, cus))) return rc;                                                   \
       g_resb_ok[SLOT].store(1, std::memory_order_release);                                                              \
     }                                                                                                                   \
     if ((e = hipMemsetAsync(p.sync, 0, RES_SYNC_BYTES, st)) != hipSuccess) return (int)e;                               \
-    hipLaunchKernelGGL((decode_resident_beam_kernel<KCF, RQ, RD, RF, RV, SM, KD>), g, blk, lds, st, p);                     \
+    hipLaunchKernelGGL((decode_resident_beam_kernel<KCF, RQ, RD, RF, RV, SM, KD, DM>), g, blk, lds, st, p);                 \
   } while (0)
-  if (ff == 512) RESB_LAUNCH(1, 1, 1, 1, 1, true, true, 0);
+  if (d == 768) RESB_LAUNCH_D(6, 1, 1, 1, 1, true, true, 768, 8);
+  else if (d == 1024) RESB_LAUNCH_D(8, 1, 1, 1, 1, true, true, 1024, 9);
+  else if (ff == 512) RESB_LAUNCH(1, 1, 1, 1, 1, true, true, 0);
   else if (ff == 1024) RESB_LAUNCH(2, 1, 1, 1, 1, true, true, 1);
   else if (cfg == 0) RESB_LAUNCH(4, 1, 1, 1, 1, true, true, 2);
   else if (cfg == 1 && rv == 2) RESB_LAUNCH(4, 1, 1, 1, 2, false, true, 3);
@@ -272,6 +280,7 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   else if (cfg == 3) RESB_LAUNCH(4, 2, 2, 2, 4, false, false, 6);
   else RESB_LAUNCH(4, 4, 2, 4, 4, false, false, 5);
 #undef RESB_LAUNCH
+#undef RESB_LAUNCH_D
   return care_launch_status();
 }
 

@@ -40,7 +40,7 @@ class ResidentMixin:
             return False
         if self.d == 512:
             return bool(self.as_ok and self.ff in (512, 1024, 2048))
-        return bool(not beam and self.d in (768, 1024) and self.ff == 4 * self.d and self.bf_act)
+        return bool(self.d in (768, 1024) and self.ff == 4 * self.d and self.bf_act)  # (greedy and - round 5 - beam search)
 
     def _resident_fits(self, rows: int, per_tile: int = 1) -> bool:
         """one workgroup per CU at most, and at least one per group of `per_tile` 16-row tiles (a partitioned GPU has fewer CUs)"""
@@ -51,6 +51,11 @@ class ResidentMixin:
         return True
 
     RESIDENT_BEAM_MAX = 5  # csrc/decode_resident.h RES_BMK
+    # beam search of the d_model 768 / 1024 models as one resident launch up to this many rows (160 at d_model 1024).  *Measured*
+    # (round 5, tools/beam_sweep.py, us per step of the whole pass, resident / multi-launch): d_model 1024 - 5 rows 103 / 207, 40
+    # rows 131 / 214, 125 rows 171 / 225, 160 rows 196 / 225, 200 rows 232 / 228; d_model 768 - 5 rows 88 / 186, 160 rows 152 / 202,
+    # 255 rows 183 / 207
+    RESIDENT_WIDE_BEAM_MAX_ROWS = int(os.environ.get("CARE_RESIDENT_WIDE_BEAM_MAX_ROWS", "256"))
 
     def resident_beam_ok(self, clips: int, bm: int, need: int) -> bool:
         """Beam search over `clips` clips as one resident launch (csrc/decode_resident_beam.hip)?  The limits of
@@ -59,6 +64,8 @@ class ResidentMixin:
         if not (0 < rows <= self.resident_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and
                 self._resident_model_ok(beam=True) and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX):
             return False
+        if self.d != 512 and rows > (self.RESIDENT_WIDE_BEAM_MAX_ROWS if self.d <= 768 else min(160, self.RESIDENT_WIDE_BEAM_MAX_ROWS)):
+            return False  # (d_model 768 / 1024: the K-split forms; see RESIDENT_WIDE_BEAM_MAX_ROWS)
         # (care_decode_resident_beam packs two row tiles per workgroup only in its forms for MORE than 512 rows; up to 512
         # rows it needs a workgroup per 16-row tile - a partitioned device with fewer CUs than tiles must not be promised
         # the resident form: ADVICE r4)
@@ -69,7 +76,7 @@ class ResidentMixin:
         limits of the resident beam launch (its phases are the chain's kernels); no residency condition, so the row
         count is bounded only by where the large-batch forms take over (`chain_beam_max_rows`)."""
         rows = clips * bm
-        return bool(0 < rows <= self.chain_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and
+        return bool(0 < rows <= self.chain_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and self.d == 512 and
                     self._resident_model_ok(beam=True) and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX)
 
     def small_forms(self, clips: int) -> bool:

@@ -26,7 +26,8 @@ def _best(nfin, fscore, flen, fhyp, i):
 # rows = clips x 5: one row tile (5, 15), the K-split forms (60), one row tile per workgroup (65, 255), several row
 # tiles per workgroup and weight fetch (260, 640 = translate.py's default batch)
 @pytest.mark.parametrize("config,B", [("msrvtt_care", 1), ("msrvtt_base_ami", 3), ("msrvtt_care", 12), ("msrvtt_cabase", 13),
-                                      ("msrvtt_base_ami", 51), ("msrvtt_care", 52), ("msrvtt_care", 128), ("msvd_base_i", 128)])
+                                      ("msrvtt_base_ami", 51), ("msrvtt_care", 52), ("msrvtt_care", 128), ("msvd_base_i", 128),
+                                      ("vatex_care_large", 1), ("vatex_care_large", 32), ("care_median_gelu", 3), ("care_median_gelu", 40)])
 def test_resident_beam_against_multi_launch_and_oracle(config, B):
     """Peaked (trained-like) logits: the resident search and the multi-launch search (projected cross K/V: the same
     rounding points) must report the same winner wherever the oracle's search is decided by clear margins, and nearly
@@ -52,7 +53,10 @@ def test_resident_beam_against_multi_launch_and_oracle(config, B):
         if ha == hb:
             same += 1
             assert abs(sa - sb) < 2e-2
-    assert same >= B - max(1, B // 16), "{} of {} winners differ between the two forms".format(B - same, B)
+    # (d_model 768 / 1024: the multi-launch search takes the ABSORBED cross-attention, the resident launch projected K / V -
+    # two roundings of the same algebra: measured 2 of 25 near-tie flips at d_model 1024, each audited below when sampled)
+    slack = max(1, B // 16) if eng.d == 512 else max(2, B // 8)
+    assert same >= B - slack, "{} of {} winners differ between the two forms".format(B - same, B)
     idx = sorted(set(int(i) for i in torch.linspace(0, B - 1, min(B, 8)).round().tolist()))
     sample = [f[idx].cpu() for f in feats]
     hyps, scores, gaps = care_cpu.translate_batch(P, opt, sample, return_gaps=True)
@@ -130,5 +134,10 @@ def test_resident_beam_shape_rules():
     assert not e.resident_beam_ok(129, 5, 5) and not e.resident_beam_ok(8, 6, 6) and not e.resident_beam_ok(8, 1, 1)
     e.resident_beam_max_rows = 0
     assert not e.resident_beam_ok(1, 5, 5)
-    for cfg, dtype in (("msrvtt_care", "fp32"), ("vatex_care_large", "bf16")):
-        assert not HipEngine(make_opt(cfg), dtype).resident_beam_ok(8, 5, 5)
+    assert not HipEngine(make_opt("msrvtt_care"), "fp32").resident_beam_ok(8, 5, 5)
+    for cfg in ("vatex_care_large", "care_median_gelu"):  # d_model 1024 / 768: up to 128 rows (round 5)
+        w = HipEngine(make_opt(cfg), "bf16")
+        most = 32 if cfg == "vatex_care_large" else 51  # 160 rows at d_model 1024, 255 at 768 (engine_resident.py)
+        assert w.resident_beam_ok(8, 5, 5) and w.resident_beam_ok(most, 5, 5) and not w.resident_beam_ok(most + 1, 5, 5)
+        w.chain_beam_max_rows = 4096
+        assert not w.chain_beam_ok(8, 5, 5)  # (the chained step is d_model 512 only)
