@@ -26,7 +26,8 @@ def _caption_equal(fa, la, fb, lb):
                                       ("msrvtt_care", 5), ("msrvtt_care", 100), ("msrvtt_cabase", 33), ("msvd_base_i", 64),
                                       # d_model 1024 / 768 (round 4: the K-split forms, BASELINE configs[3]'s 32 clips per GPU)
                                       ("vatex_care_large", 32), ("vatex_care_large", 3), ("care_median_gelu", 64)])
-def test_resident_decode_against_multi_launch_and_oracle(config, B):
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_resident_decode_against_multi_launch_and_oracle(config, B, mode):
     """Peaked (trained-like) logits: the resident form and the multi-launch form (projected cross K/V: the same rounding
     points) must give the same caption wherever the oracle's every step is decided by a clear margin, and nearly
     always otherwise: at most B // 32 captions may differ between the forms (measured: 3 of 128; B // 16 until round 4),
@@ -37,9 +38,14 @@ def test_resident_decode_against_multi_launch_and_oracle(config, B):
     (GREEDY_TIE_TOL) is below this model's noise floor;
     scores within the bf16 bar; the resident path must actually have run."""
     from oracle import care_cpu
-    from test_gpu_parity import BF16_LSE_PEAKED, CLEAR_MARGIN, _audit_greedy
+    from test_gpu_parity import CLEAR_MARGIN, MODES, _audit_greedy
 
-    opt, P, model, feats = _setup(config, B, "bf16", seed=189, boost=PEAKED_ROWS)
+    # fp16 mode (round 5; VERDICT r4 weak #2): 8 x less noise on a log-probability, so the bars of the MULTI-LAUNCH audit
+    # hold for the resident form there - a differing caption must part from the oracle at a margin below 1e-2 (twice the
+    # 5e-3 noise bar of one log-probability on this model), scores agree within that bar (measured 3.4e-3), the forms within B // 64 captions
+    lse_bar = MODES[mode]["lse_peaked"]
+    tie_tol, forms_slack, score_bar = (5e-2, max(1, B // 32), 2e-2) if mode == "bf16" else (1e-2, max(1, B // 64), 5e-3)
+    opt, P, model, feats = _setup(config, B, mode, seed=189, boost=PEAKED_ROWS)
     eng = model.engine()
     eng.latent = False
     ml = _run(eng, feats, use_graph=False)
@@ -49,9 +55,9 @@ def test_resident_decode_against_multi_launch_and_oracle(config, B):
     rs = _run(eng, feats, use_graph=False)
     assert eng.last_decode.get("resident") and 1 <= int(eng.last_decode["steps"]) <= eng.T
     same = _caption_equal(rs[0], rs[1], ml[0], ml[1])
-    assert int(same.sum()) >= B - max(1, B // 32), "{} of {} captions differ between the two forms".format(B - int(same.sum()), B)
+    assert int(same.sum()) >= B - forms_slack, "{} of {} captions differ between the two forms".format(B - int(same.sum()), B)
     n = rs[1].clamp(min=1).float()
-    assert ((rs[2] - ml[2]).abs() / n)[same].max().item() < 2e-2
+    assert ((rs[2] - ml[2]).abs() / n)[same].max().item() < score_bar
     idx = sorted(set(int(i) for i in torch.linspace(0, B - 1, min(B, 12)).round().tolist()))
     sample = [f[idx].cpu() for f in feats]
     hyps, scores, gaps = care_cpu.translate_batch(P, opt, sample, return_gaps=True)
@@ -62,9 +68,9 @@ def test_resident_decode_against_multi_launch_and_oracle(config, B):
         if gaps[j]["select"] >= CLEAR_MARGIN:
             assert h == r, "clip {}: clear margins ({:.3f}) but the resident ids differ".format(i, gaps[j]["select"])
         if h == r:
-            assert abs(float(rs[2][i]) / k - scores[j][0]) < BF16_LSE_PEAKED
+            assert abs(float(rs[2][i]) / k - scores[j][0]) < lse_bar
         else:
-            _audit_greedy(P, opt, {kk: v[j:j + 1] for kk, v in inputs.items()}, h, r, 5e-2)
+            _audit_greedy(P, opt, {kk: v[j:j + 1] for kk, v in inputs.items()}, h, r, tie_tol)
 
 
 @pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 100), ("msrvtt_care", 37)])
@@ -163,7 +169,33 @@ def test_resident_entry_point_rejects_what_it_does_not_cover():
     assert lib.care_decode_resident(*args()) == -1                      # layer pointers are NULL
 
 
-def test_resident_barrier_watchdog_aborts_instead_of_hanging():
+@pytest.fixture(params=[0, 1], ids=["fence-free", "fenced"])
+def handoff(request):
+    """Both forms of the hand-off between the phases of a resident launch (care_resident_set_fenced): the fence-free one
+    (what the validated configuration takes by default) and the one with an agent-scope release / acquire pair (what any
+    other device or partition mode gets)."""
+    from care_amd import _lib
+
+    libs = [_lib.load(), _lib.load(variant="f16")]
+    for lib in libs:
+        lib.care_resident_set_fenced(request.param)
+    assert libs[0].care_resident_fenced() == request.param
+    yield request.param
+    for lib in libs:
+        lib.care_resident_set_fenced(-1)
+
+
+def test_resident_handoff_default_is_fence_free_on_the_validated_configuration():
+    from care_amd import _lib
+
+    lib = _lib.load()
+    lib.care_resident_set_fenced(-1)
+    props = torch.cuda.get_device_properties(0)
+    validated = props.gcnArchName.startswith("gfx950") and props.multi_processor_count == 256
+    assert lib.care_resident_fenced() == (0 if validated else 1)
+
+
+def test_resident_barrier_watchdog_aborts_instead_of_hanging(handoff):
     """A grid that cannot meet at its hand-offs must give up, not hang: simulated by a counter state in which more
     workgroups than exist would have to arrive (care_decode_resident_debug(0, 1): the kernel expects producers that are
     not there).  Every row's length reads -1 - no caller can mistake a re-used workspace's old rows for results - and
@@ -199,7 +231,7 @@ def test_resident_barrier_watchdog_aborts_instead_of_hanging():
     assert int(nfin.min()) >= 1 and eng.last_decode.get("resident")
 
 
-def test_resident_launches_under_contention_never_hang():
+def test_resident_launches_under_contention_never_hang(handoff):
     """Two resident launches at a time (two engines, two threads, a HIP stream each) beside a stream of filler kernels
     that keep the CUs busy: a resident launch needs every one of its workgroups on the chip at once, which nothing
     guarantees here.  Whatever the scheduler does, every translate_batch call must come back - with the captions of
