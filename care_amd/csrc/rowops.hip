@@ -15,6 +15,22 @@ constexpr int MAXV = 8;  // float4 per lane: d <= 64 * 4 * 8 = 2048
 __device__ __forceinline__ void row_layernorm(float4 (&v)[MAXV], int nv4, int lane, int d,
                                               const float* gamma, const float* beta, float eps,
                                               float* out, bf16_t* outb = nullptr) {
+  if (gamma == nullptr) {  // (kernel-uniform) no LayerNorm: the plain sum - the sub-blocks of a pre-LN decoder
+    // (models/components/SubLayers.py:55,78: `context + input_tensor` without the LayerNorm) and its un-normalised embedding
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < nv4) {
+        *reinterpret_cast<float4*>(out + c4 * 4) = v[i];
+        if (outb) {
+          bf16x4 ob;
+          ob[0] = (bf16_t)v[i].x; ob[1] = (bf16_t)v[i].y; ob[2] = (bf16_t)v[i].z; ob[3] = (bf16_t)v[i].w;
+          *reinterpret_cast<bf16x4*>(outb + c4 * 4) = ob;
+        }
+      }
+    }
+    return;
+  }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
@@ -419,11 +435,11 @@ extern "C" int care_add_ln(const float* x, int64_t ldx, const float* res, int64_
                            const float* gamma, const float* beta, float eps, float* out, void* out_bf16,
                            int64_t ldo, int rows, int d, int grp, int out_grp_rows, int out_row_off, int nslab,
                            int64_t slab_stride, void* stream) {
-  if (!x || !gamma || !beta || !out || rows <= 0 || d <= 0 || grp <= 0) return CARE_EINVAL;
+  if (!x || ((gamma == nullptr) != (beta == nullptr)) || !out || rows <= 0 || d <= 0 || grp <= 0) return CARE_EINVAL;
   if (d % 4 != 0 || d > 2048 || nslab < 1 || nslab > 16) return CARE_ESHAPE;
   if ((ldx % 4) || (ldo % 4) || (res && (ldres % 4)) || (slab_stride % 4) || !care_aligned16(x) || !care_aligned16(out))
     return CARE_EALIGN;
-  if (!pos && nslab == 1 && (d == 512 || d == 768 || d == 1024 || d == 2048)) {
+  if (gamma && !pos && nslab == 1 && (d == 512 || d == 768 || d == 1024 || d == 2048)) {
     bf16_t* ob = reinterpret_cast<bf16_t*>(out_bf16);
     const dim3 grid((rows + 3) / 4);
 #define ADD_LN_FIXED(NV)                                                                                                     \
@@ -477,7 +493,7 @@ extern "C" int care_embed_ln(const int32_t* tokens, int tok_stride, int tok_off,
                              const float* word, const float* pos, int pos0, const float* sem, int sem_div,
                              const float* gamma, const float* beta, float eps, float* out, void* out_bf16,
                              int64_t ldo, int rows, int seq, int d, void* stream) {
-  if (!tokens || !word || !pos || !gamma || !beta || !out || rows <= 0 || seq <= 0 || sem_div <= 0) return CARE_EINVAL;
+  if (!tokens || !word || !pos || ((gamma == nullptr) != (beta == nullptr)) || !out || rows <= 0 || seq <= 0 || sem_div <= 0) return CARE_EINVAL;
   if (d % 4 != 0 || d > 2048) return CARE_ESHAPE;
   if (ldo % 4) return CARE_EALIGN;
   hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, tokens, tok_stride, tok_off, anc,
@@ -502,7 +518,7 @@ extern "C" int care_greedy_update_embed(const float* pmax, const int32_t* pidx, 
                                         const float* sem, int sem_div, const float* gamma, const float* beta, float eps,
                                         float* out, void* out_bf16, int64_t ldo, int d, void* stream) {
   if (!pmax || !pidx || !psum || !fed || !score || !length || !finished || rows <= 0 || parts <= 0 || !word || !pos ||
-      !gamma || !beta || !out)
+      ((gamma == nullptr) != (beta == nullptr)) || !out)  // (gamma == beta == NULL: no LayerNorm, as care_embed_ln)
     return CARE_EINVAL;
   if (t <= 0 || t >= fed_stride || d <= 0 || d > 64 * 4 * MAXV || (d % 4) || (sem && sem_div <= 0)) return CARE_ESHAPE;
   if ((ldo % 4) || !care_aligned16(word) || !care_aligned16(pos) || !care_aligned16(out) || (sem && !care_aligned16(sem)))

@@ -79,6 +79,12 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         self.topk = int(opt.get("use_attr_topk", 30))
         self.k_attr = int(opt.get("attribute_prediction_k", 500))
         self.n_layers = int(opt["num_hidden_layers_decoder"])
+        # pre-LN decoder (opts.py:68 `--transformer_pre_ln`; SubLayers.py:55,78,140,149; Embeddings.py:130; Decoder/Transformer.py:80,
+        # 233-234): LayerNorm BEFORE every sub-block, the residual sums left as they are, no LayerNorm after the embedding, one
+        # final LayerNorm in front of the head.  Runs through the multi-launch unfused forms in every mode (round 5).
+        self.pre_ln = bool(opt.get("transformer_pre_ln", False))
+        if self.pre_ln and opt["encoder"] != "Embedder":
+            raise ValueError("transformer_pre_ln with a self-attention encoder is outside the hot path")
         self.rows_of = {ch: (int(opt["retrieval_topk"]) if ch == "r" else int(opt["n_frames"])) for ch in self.modality}
         self.mem_off = {}
         off = 0
@@ -185,7 +191,11 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
             w["pos"] = f32(sd[e + ".position_embeddings.weight"])
         else:
             w["pos"] = f32(sd[e + ".position_embeddings.pe"][0])
-        w["emb_g"], w["emb_be"] = f32(sd[e + ".LayerNorm.weight"]), f32(sd[e + ".LayerNorm.bias"])
+        if self.pre_ln:  # no LayerNorm after the embedding sum (Embeddings.py:130); the decoder's final one instead
+            w["emb_g"] = w["emb_be"] = None
+            w["dec_g"], w["dec_be"] = f32(sd["decoder.LayerNorm.weight"]), f32(sd["decoder.LayerNorm.bias"])
+        else:
+            w["emb_g"], w["emb_be"] = f32(sd[e + ".LayerNorm.weight"]), f32(sd[e + ".LayerNorm.bias"])
         for li in range(self.n_layers):
             lp = "decoder.layers.{}".format(li)
             self._pack_attn(w, sd, lp + ".intra_attention", "d{}_sa".format(li), True, wt, f32)
@@ -474,7 +484,22 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         GEMM + LayerNorm kernel pair is faster)."""
         # *measured* (Base `ami`, whole pass): 8192 rows 435 K captions/s unfused vs 420 K fused, 12288 rows
         # 440 K vs 446-451 K
-        return self.as_ok and self.d == 512 and rows >= int(os.environ.get("CARE_LN_MIN_ROWS", "10240"))
+        return self.as_ok and self.d == 512 and not self.pre_ln and rows >= int(os.environ.get("CARE_LN_MIN_ROWS", "10240"))
+
+    # -- the two halves of a sub-block's LayerNorm placement (post-LN: after the residual sum; pre-LN: in front of the block)
+    def _ln_in(self, x, xb, g, be, tag):
+        """The sub-block's input: x itself (post-LN), or LayerNorm(x) (pre-LN, SubLayers.py:55,140) with its 16-bit mirror."""
+        if not self.pre_ln:
+            return x, xb
+        h, hb = self.ws(tag + "preln", tuple(x.shape)), self.wsb(tag + "preln", tuple(x.shape))
+        self.add_ln(x, None, g, be, h, hb)
+        return h, hb
+
+    def _res_ln(self, o, x, g, be, out, outb, **kw):
+        """The sub-block's output: LayerNorm(o + x) (post-LN, SubLayers.py:73-79), or o + x as it is (pre-LN)."""
+        if self.pre_ln:
+            return self.add_ln(o, x, None, None, out, outb, **kw)
+        return self.add_ln(o, x, g, be, out, outb, **kw)
 
     def gemm_ln(self, A, W, bias, res, g, be, out, outb, grp=None, out_grp_rows=None, out_row_off=0, pos=None, tag=None,
                 Wp=None):

@@ -24,13 +24,14 @@ class DecodeMixin:
         aux (dict): also the attention probabilities and the pre-residual projection (`text_context`)."""
         rows, d = x.shape
         w = self.w
-        qkv = self.gemm(xb if xb is not None else x, w[name + "_qkv_w"], w[name + "_qkv_b"],
+        hin, hinb = self._ln_in(x, xb, w[name + "_g"], w[name + "_be"], tag + "sa")
+        qkv = self.gemm(hinb if hinb is not None else hin, w[name + "_qkv_w"], w[name + "_qkv_b"],
                         self.ws(tag + "qkv", (rows, 3 * d)))
         ctx = self.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], self._ctx(tag, rows), seq * 3 * d, 3 * d,
                              seq, seq, causal=causal, seq=seq, pad_tok=pad_tok)
         o = self.gemm(ctx, w[name + "_o_w"], w[name + "_o_b"], self.ws(tag + "o", (rows, d)))
         x1, x1b = self.ws(tag + "x1", (rows, d)), self.wsb(tag + "x1", (rows, d))
-        self.add_ln(o, x, w[name + "_g"], w[name + "_be"], x1, x1b)
+        self._res_ln(o, x, w[name + "_g"], w[name + "_be"], x1, x1b)
         if aux is not None:
             aux["probs"] = self.attention_probs(qkv, qkv[:, d:], seq * 3 * d, 3 * d, seq, seq, causal=causal, seq=seq,
                                                 pad_tok=pad_tok)
@@ -40,9 +41,10 @@ class DecodeMixin:
     def _ffn(self, name, x, xb, out, outb, tag, gemm_tag=None, fuse=None, **ln_kw):
         rows, d = x.shape
         w = self.w
-        fuse = self.ln_fusable(rows) if fuse is None else fuse
+        fuse = (self.ln_fusable(rows) if fuse is None else fuse) and not self.pre_ln
         split = self.as_ok and self.ff % 512 == 0 and self.ff >= 1024
-        h = self.gemm(xb if xb is not None else x, w[name + "_w1"], w[name + "_b1"],
+        hin, hinb = self._ln_in(x, xb, w[name + "_g"], w[name + "_be"], tag + "ffn")
+        h = self.gemm(hinb if hinb is not None else hin, w[name + "_w1"], w[name + "_b1"],
                       self.ws(tag + "h", (rows, self.ff), self.h16 if (split or self.bf_act) else torch.float32),
                       act=self.act, tag=gemm_tag)
         w2 = w[name + "_w2"]
@@ -56,23 +58,24 @@ class DecodeMixin:
             f = self.ws(tag + "fslab", (ns, rows, d))
             self.call("care_gemm_bf16_splitk", ptr(h), h.stride(0), _code(h), ptr(w2), ptr(w[name + "_b2"]), ptr(f), d,
                  f.stride(0), rows, d, self.ff, tag=gemm_tag)
-            return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, nslab=ns,
-                               tag="step_add_ln" if gemm_tag else None, **ln_kw)
+            return self._res_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, nslab=ns,
+                                tag="step_add_ln" if gemm_tag else None, **ln_kw)
         f = self.gemm(h, w2, w[name + "_b2"], self.ws(tag + "f", (rows, d)), tag=gemm_tag)
-        return self.add_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, tag="step_add_ln" if gemm_tag else None, **ln_kw)
+        return self._res_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, tag="step_add_ln" if gemm_tag else None, **ln_kw)
 
     def _attr_block(self, li, x, xb, akv, rows_per_clip, tag, aux=None):
         """Third post-LN attention block over the concept rows (Layers.py:139-154,218-225)."""
         w, d = self.w, self.d
         rows = x.shape[0]
         nm = "d{}_aa".format(li)
-        q = self.gemm(xb if xb is not None else x, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q3", (rows, d)))
+        hin, hinb = self._ln_in(x, xb, w[nm + "_g"], w[nm + "_be"], tag + "aa")
+        q = self.gemm(hinb if hinb is not None else hin, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q3", (rows, d)))
         kv = akv[li]
         ctx = self.attention(q, kv, kv[:, d:], self._ctx(tag, rows), self.topk * 2 * d, 2 * d, rows_per_clip,
                              self.topk)
         o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (rows, d)))
         y, yb = self.ws(tag + "x2a", (rows, d)), self.wsb(tag + "x2a", (rows, d))
-        self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], y, yb)
+        self._res_ln(o, x, w[nm + "_g"], w[nm + "_be"], y, yb)
         if aux is not None:
             aux["probs"] = self.attention_probs(q, kv, self.topk * 2 * d, 2 * d, rows_per_clip, self.topk)
         return y, yb
@@ -81,7 +84,7 @@ class DecodeMixin:
     def tf_fast_ok(self, t: int, want_aux: bool) -> bool:
         """Teacher-forced forward on the fast kernels (_decode_full_fast): bf16 mode, d_model = 512, no auxiliary
         dict entries (attention probabilities etc. are not materialised by the fused kernels)."""
-        return (self.as_ok and self.d == 512 and not want_aux and t <= 32 and
+        return (self.as_ok and self.d == 512 and not want_aux and t <= 32 and not self.pre_ln and
                 os.environ.get("CARE_TF_FAST", "1") != "0")
 
     def _dense_ln(self, ctx, name, res, out, outb, rows, tag):
@@ -185,13 +188,14 @@ class DecodeMixin:
             a_sa = {} if want_aux else None
             x1, x1b = self._mha_self_full("d{}_sa".format(li), x, xb, t, ids32, True, "tf_", aux=a_sa)
             nm = "d{}_ca".format(li)
-            q = self.gemm(x1b if x1b is not None else x1, w[nm + "_q_w"], w[nm + "_q_b"], self.ws("tf_q", (rows, d)))
+            hin, hinb = self._ln_in(x1, x1b, w[nm + "_g"], w[nm + "_be"], "tf_ca")
+            q = self.gemm(hinb if hinb is not None else hin, w[nm + "_q_w"], w[nm + "_q_b"], self.ws("tf_q", (rows, d)))
             kv = ckv[li]
             ctx = self.attention(q, kv, kv[:, d:], self._ctx("tf_", rows), Lk * 2 * d, 2 * d, per_clip * t, Lk,
                                  bias=w["d{}_hb".format(li)])
             o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws("tf_o", (rows, d)))
             x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
-            self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
+            self._res_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b)
             if want_aux:
                 A["intra"].append(a_sa["probs"].view(N, t, self.H, t).permute(0, 2, 1, 3))
                 A["inter"].append(self.attention_probs(q, kv, Lk * 2 * d, 2 * d, per_clip * t, Lk,
@@ -209,6 +213,10 @@ class DecodeMixin:
             self._ffn("d{}_ffn".format(li), x2, x2b, x, xb, "tf_")
             if want_aux:
                 A["all_hidden_states"].append(x.view(N, t, d) if last else x.clone().view(N, t, d))
+        if self.pre_ln:  # the decoder's final LayerNorm (Decoder/Transformer.py:233-234): what the head and the caller see
+            xf, xb = torch.empty(rows, d, device=self.device), self.wsb("tf_xfin", (rows, d))
+            self.add_ln(x, None, w["dec_g"], w["dec_be"], xf, xb)
+            x = xf
         hidden = x.view(N, t, d)
         self._last_tf_bf16 = xb
         out = {"hidden_states": hidden}
@@ -290,7 +298,8 @@ class DecodeMixin:
             nm = "d{}_sa".format(li)
             cache = skv[li]  # [N, T, 2d]
             q = self.ws(tag + "q", (N, d))
-            self.gemm(g(x, xb), w[nm + "_qkv_w"], w[nm + "_qkv_b"], q, out2=cache[:, t - 1, :], n_split=d,
+            hin, hinb = self._ln_in(x, xb, w[nm + "_g"], w[nm + "_be"], tag + "sa")
+            self.gemm(g(hin, hinb), w[nm + "_qkv_w"], w[nm + "_qkv_b"], q, out2=cache[:, t - 1, :], n_split=d,
                       tag="step_qkv_gemm")
             flat = cache.view(N * T, 2 * d)
             ctx = self.attention(q, flat, flat[:, d:], self._ctx(tag, N), T * 2 * d, 2 * d, 1, t, anc=anc,
@@ -301,15 +310,16 @@ class DecodeMixin:
                              tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
             else:
                 o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
-                self.add_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b, tag="step_add_ln")
+                self._res_ln(o, x, w[nm + "_g"], w[nm + "_be"], x1, x1b, tag="step_add_ln")
             nm = "d{}_ca".format(li)
             hb = w["d{}_hb".format(li)]
+            x1in, x1inb = self._ln_in(x1, x1b, w[nm + "_g"], w[nm + "_be"], tag + "ca")
             if isinstance(ckv, tuple):  # absorbed form (cross_src)
                 H = self.H
                 # d x d with a bf16 output at >= 8192 rows: the LDS-tiled kernel (*measured* in situ, 32768 rows: 25.3 against
                 # 32-34 us on the A-stationary one, which wins the wider QKV / FFN1 products; decided by the pass's INITIAL
                 # row count like every other choice of form)
-                q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2b", (N, d), self.h16),
+                q2 = self.gemm(x1inb, w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2b", (N, d), self.h16),
                                tag="step_dxd_gemm", tile=d == 512 and (self._form_rows or N) >= self.Q_TILE_MIN_ROWS)
                 qt = self.ws(tag + "qt", (N, H * d), self.h16)
                 if d == 512:
@@ -328,7 +338,7 @@ class DecodeMixin:
                     self.call("care_gemm_tile_batched", ptr(ct), H * d, d, ptr(w[nm + "_v_w"]), d, 64 * d, ptr(w[nm + "_v_b"]), 64,
                          ptr(ctx), d, 64, CARE_BF16, H, N, 64, d, tag="step_head_reduce")
             else:
-                q2 = self.gemm(g(x1, x1b), w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)),
+                q2 = self.gemm(g(x1in, x1inb), w[nm + "_q_w"], w[nm + "_q_b"], self.ws(tag + "q2", (N, d)),
                                tag="step_dxd_gemm")
                 kv = ckv[li]
                 ctx = self.attention(q2, kv, kv[:, d:], self._ctx(tag, N), Lk * 2 * d, 2 * d, rows_per_clip, Lk,
@@ -339,7 +349,7 @@ class DecodeMixin:
                              tag="step_dxd_ln", Wp=w.get(nm + "_o_w#packed"))
             else:
                 o = self.gemm(ctx, w[nm + "_o_w"], w[nm + "_o_b"], self.ws(tag + "o", (N, d)), tag="step_dxd_gemm")
-                self.add_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b, tag="step_add_ln")
+                self._res_ln(o, x1, w[nm + "_g"], w[nm + "_be"], x2, x2b, tag="step_add_ln")
             if self.attr_att:
                 x2, x2b = self._attr_block(li, x2, x2b, akv, rows_per_clip, tag)
             x, xb = self.ws(tag + "x3_%d" % (li & 1), (N, d)), self.wsb(tag + "x3_%d" % (li & 1), (N, d))
@@ -351,6 +361,10 @@ class DecodeMixin:
                       fuse=fuse_ln)
             if bf16_only:
                 x = None
+        if self.pre_ln:  # the decoder's final LayerNorm in front of the head (Decoder/Transformer.py:233-234)
+            xf, xfb = self.ws(tag + "xfin", (N, d)), self.wsb(tag + "xfin", (N, d))
+            self.add_ln(x, None, w["dec_g"], w["dec_be"], xf, xfb, tag="step_add_ln")
+            x, xb = xf, xfb
         return x, xb
 
     def greedy(self, mem: torch.Tensor, sem: Optional[torch.Tensor], steps: Optional[int] = None,

@@ -33,6 +33,8 @@ class ResidentMixin:
     def _resident_model_ok(self, beam: bool = False) -> bool:
         """Every model-side limit care_decode_resident / care_decode_resident_beam enforce (CARE_ESHAPE otherwise):
         bf16 mode; d_model 512 (ff 512 / 1024 / 2048), or - greedy only - d_model 768 / 1024 with ff = 4 d_model."""
+        if self.pre_ln:  # (the resident phases normalise AFTER the residual sum: post-LN decoders only)
+            return False
         if getattr(self, "_resident_refused", False):  # a launch was refused on this device (CARE_ESHAPE): multi-launch forms
             return False
         if not (self.bf and self.wt == self.h16 and self.T <= 128 and self.n_layers <= 4 and

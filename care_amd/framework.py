@@ -190,7 +190,8 @@ class _DecoderEmbeddings(nn.Module):
         super().__init__()
         self.word_embeddings = nn.Embedding(opt["vocab_size"], opt["dim_hidden"], padding_idx=PAD)
         self.position_embeddings = _position_table(opt, opt["max_len"])
-        self.LayerNorm = nn.LayerNorm(opt["dim_hidden"], eps=opt["layer_norm_eps"])
+        if not opt.get("transformer_pre_ln", False):  # Embeddings.py:130-131: a pre-LN decoder has no LayerNorm here
+            self.LayerNorm = nn.LayerNorm(opt["dim_hidden"], eps=opt["layer_norm_eps"])
 
 
 class _DecoderLayer(nn.Module):
@@ -216,10 +217,12 @@ class _DecoderLayer(nn.Module):
 class TransformerDecoder(nn.Module):
     def __init__(self, opt):
         super().__init__()
-        if opt.get("transformer_pre_ln", False):
-            raise ValueError("pre-LN decoders are outside the hot path (opts.py:68 default False)")
         self.embedding = _DecoderEmbeddings(opt)
         self.layers = nn.ModuleList([_DecoderLayer(opt) for _ in range(opt["num_hidden_layers_decoder"])])
+        if opt.get("transformer_pre_ln", False):  # Decoder/Transformer.py:80-81: the final LayerNorm of a pre-LN decoder
+            if opt["encoder"] != "Embedder":
+                raise ValueError("transformer_pre_ln with a self-attention encoder is outside the hot path")
+            self.LayerNorm = nn.LayerNorm(opt["dim_hidden"], eps=opt["layer_norm_eps"])
 
     def get_word_embeddings(self):
         return self.embedding.word_embeddings

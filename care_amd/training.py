@@ -305,6 +305,8 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
         raise RuntimeError("the model is on `{}`: move it to the MI355X (there is no CPU fallback)".format(dev))
     if opt["encoder"] not in ("Embedder", "MultiTransformerEncoder"):
         raise NotImplementedError("training mode covers the `Embedder` and `MultiTransformerEncoder` encoders")
+    if opt.get("transformer_pre_ln", False):
+        raise NotImplementedError("training mode covers post-LN decoders (the eval-mode path runs pre-LN ones)")
     d, H = int(opt["dim_hidden"]), int(opt["num_attention_heads"])
     eps = float(opt["layer_norm_eps"])
     act = ACT_CODES[opt["hidden_act"]]

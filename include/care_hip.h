@@ -229,6 +229,9 @@ int care_greedy_update_embed(const float* pmax, const int32_t* pidx, const float
  *   operand of the next bf16 GEMM (the same rounding that GEMM would apply on load).
  *   nslab > 1: x is the sum of nslab fp32 slabs spaced slab_stride elements apart (the
  *   split-K partial products of care_gemm_bf16_splitk); nslab = 1 otherwise.
+ *   gamma == beta == NULL: NO LayerNorm - out = x + res (+ pos): the sub-blocks of a pre-LN decoder
+ *   (`transformer_pre_ln`, opts.py:68; SubLayers.py:55,78,140,149: LayerNorm BEFORE the sub-block, the residual sum left
+ *   as it is); care_embed_ln likewise (Embeddings.py:130: no LayerNorm after the embedding sum).
  *   d % 4 == 0, d <= 2048.
  */
 int care_add_ln(const float* x, int64_t ldx, const float* res, int64_t ldres,

@@ -57,7 +57,7 @@ def _split_heads(x: torch.Tensor, n_heads: int) -> torch.Tensor:
 
 def attention_block(P, prefix: str, opt: dict, x: torch.Tensor, memory: Optional[torch.Tensor],
                     mask: Optional[torch.Tensor], aux: Optional[dict] = None) -> torch.Tensor:
-    """Post-LN multi-head attention sub-block.
+    """Multi-head attention sub-block, post-LN (every shipped config) or pre-LN (`transformer_pre_ln`, opts.py:68).
 
     `MultiHeadAttention.forward` (models/components/SubLayers.py:40-81) around
     `ScaledDotProductAttention.forward` (models/components/Attention.py:69-131):
@@ -66,6 +66,10 @@ def attention_block(P, prefix: str, opt: dict, x: torch.Tensor, memory: Optional
     Dropout is identity in eval mode.  `mask`: bool, True = masked, [B, Lq, Lk].
     """
     H = opt["num_attention_heads"]
+    pre_ln = opt.get("transformer_pre_ln", False)
+    x_in = x
+    if pre_ln:  # SubLayers.py:55-56: the LayerNorm comes first; keys / values of a self-attention are the normalised rows too (:62-63)
+        x = _layer_norm(P, prefix + ".LayerNorm", x, opt["layer_norm_eps"])
     kv = x if memory is None else memory
     q = _split_heads(_linear(P, prefix + ".SDPA.query", x), H)
     k = _split_heads(_linear(P, prefix + ".SDPA.key", kv), H)
@@ -80,7 +84,9 @@ def attention_block(P, prefix: str, opt: dict, x: torch.Tensor, memory: Optional
     ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).contiguous()
     ctx = ctx.view(ctx.shape[0], ctx.shape[1], -1)
     context = _linear(P, prefix + ".dense", ctx)  # SubLayers.py:69-70 `context` (dropout is identity)
-    out = _layer_norm(P, prefix + ".LayerNorm", context + x, opt["layer_norm_eps"])
+    out = context + x_in  # :75-76 the residual is the block's INPUT tensor (un-normalised in a pre-LN block)
+    if not pre_ln:
+        out = _layer_norm(P, prefix + ".LayerNorm", out, opt["layer_norm_eps"])  # :78-79
     if aux is not None:
         aux.update(probs=probs, context=context, embs=out)
     return out
@@ -88,9 +94,11 @@ def attention_block(P, prefix: str, opt: dict, x: torch.Tensor, memory: Optional
 
 def ffn_block(P, prefix: str, opt: dict, x: torch.Tensor) -> torch.Tensor:
     """`PositionwiseFeedForward.forward` (SubLayers.py:137-152), post-LN."""
-    h = _activation(opt["hidden_act"], _linear(P, prefix + ".dense1", x))
+    pre_ln = opt.get("transformer_pre_ln", False)
+    xin = _layer_norm(P, prefix + ".LayerNorm", x, opt["layer_norm_eps"]) if pre_ln else x  # :140-141
+    h = _activation(opt["hidden_act"], _linear(P, prefix + ".dense1", xin))
     out = _linear(P, prefix + ".dense2", h) + x
-    return _layer_norm(P, prefix + ".LayerNorm", out, opt["layer_norm_eps"])
+    return out if pre_ln else _layer_norm(P, prefix + ".LayerNorm", out, opt["layer_norm_eps"])  # :149-150
 
 
 # --------------------------------------------------------------------------- encoder
@@ -195,6 +203,8 @@ def decoder_embeddings(P, opt: dict, input_ids: torch.Tensor,
     e = e + pos.unsqueeze(0)
     if "emb" in opt.get("use_attr_type", ""):
         e = e + semantic_hidden_states.unsqueeze(1).expand_as(e)
+    if opt.get("transformer_pre_ln", False):  # Embeddings.py:130-131: no LayerNorm in a pre-LN decoder's embedding
+        return e
     return _layer_norm(P, "decoder.embedding.LayerNorm", e, opt["layer_norm_eps"])
 
 
@@ -236,6 +246,9 @@ def decoder_forward(P, opt: dict, input_ids: torch.Tensor, inputs: Dict[str, tor
                 aux["attr_attention_probs"] += (a3["probs"],)
     if aux is not None:
         aux["attention_probs"] = aux["all_inter_attentions"][-1].mean(1)
+    if opt.get("transformer_pre_ln", False):  # Decoder/Transformer.py:80-81,233-234: the final LayerNorm of a pre-LN decoder
+        assert opt["encoder"] == "Embedder", "pre-LN with a self-attention encoder is outside the hot path"
+        h = _layer_norm(P, "decoder.LayerNorm", h, opt["layer_norm_eps"])
     return h
 
 

@@ -59,6 +59,11 @@ CASES = [
     ("msrvtt_base_ami_peaked_b4", "msrvtt_base_ami", 4, 189, {}, PEAKED),
     ("msrvtt_care_peaked_b3", "msrvtt_care", 3, 373, {}, PEAKED),
     ("msrvtt_care_peaked_beam5_b3", "msrvtt_care_beam5", 3, 373, {}, PEAKED),
+    # pre-LN decoders (opts.py:68 `--transformer_pre_ln`; off in every shipped config, an option of the classes on the path):
+    # LayerNorm in front of every sub-block, no LayerNorm after the embedding, a final one in front of the head
+    ("msrvtt_base_ami_preln_b3", "msrvtt_base_ami", 3, 51, {"transformer_pre_ln": True}, {VOCAB_W: {EOS_ROW: 4.0, PAD_ROW: 3.0}}),
+    ("msrvtt_care_preln_beam5_b2", "msrvtt_care_beam5", 2, 52, {"transformer_pre_ln": True}, {VOCAB_W: {EOS_ROW: 4.0}}),
+    ("msrvtt_cabase_preln_b2", "msrvtt_cabase", 2, 53, {"transformer_pre_ln": True}, {VOCAB_W: {EOS_ROW: 4.0}}),
 ]
 
 

@@ -289,7 +289,19 @@ def test_small_batch_form_rules(monkeypatch):
     for cfg in ("vatex_care_large", "care_median_gelu"):   # d_model 1024 / 768 (ff = 4 d_model): greedy, up to 128 rows
         e = HipEngine(make_opt(cfg), "bf16")
         assert e.resident_ok(1) and e.resident_ok(32) and e.resident_ok(128) and not e.resident_ok(129), cfg
-        assert not e.small_forms(8) and not e.resident_beam_ok(4, 5, 5), cfg
+        # ... and, round 5, beam search (160 rows at d_model 1024, 256 at 768: engine_resident.RESIDENT_WIDE_BEAM_MAX_ROWS)
+        assert not e.small_forms(8) and e.resident_beam_ok(4, 5, 5) and not e.resident_beam_ok(52, 5, 5), cfg
+    # 16-bit modes: fp16 (libcare_hip_f16.so) takes every small-batch form bf16 does
+    h = HipEngine(make_opt("msrvtt_care"), "fp16")
+    assert h.variant == "f16" and h.h16 == torch.float16 and h.resident_ok(128) and h.resident_beam_ok(128, 5, 5) and h.small_forms(8)
+    # pre-LN decoders run the multi-launch unfused forms only (the resident phases normalise after the residual sum)
+    pre = HipEngine(make_opt("msrvtt_care", transformer_pre_ln=True), "bf16")
+    assert pre.pre_ln and not pre.resident_ok(8) and not pre.resident_beam_ok(8, 5, 5) and not pre.ln_fusable(1 << 20)
+    assert not pre.tf_fast_ok(29, False)
+    # mid-size forms: the beam selection from group maxima below BEAM_FUSED_MIN_ROWS (16-bit modes, beam <= 5)
+    assert base.beam_groups_for(640, 5) and base.beam_groups_for(8191, 5) and not base.beam_groups_for(8192, 5)
+    assert not base.beam_groups_for(640, 6) and not HipEngine(make_opt("msrvtt_care"), "fp32").beam_groups_for(640, 5)
+    assert base.MID_TILE_ROWS == (1280, 16384)
     two = HipEngine(make_opt("msrvtt_base_ami", num_hidden_layers_decoder=2), "bf16")
     assert two.resident_ok(8)
     # every shape limit of care_decode_resident is checked here, so an unsupported model takes the multi-launch decode
