@@ -21,6 +21,7 @@ namespace {
 
 constexpr int PK_NP = 4;  // parts per lane: V <= 64 * 64 * PK_NP
 constexpr int PK_NQ = 8;  // K fragments (of 32) in flight per operand
+constexpr int PK_BM = 8;  // beam sizes up to 8 (care_beam_select's and care_beam_advance's limit): two MFMA tiles of four groups
 
 __global__ __launch_bounds__(256, 4) void beam_pick_groups_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
                                                                const float* __restrict__ gmax, int parts, int bm,
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256, 4) void beam_pick_groups_kernel(const float* _
   // entry e = lane + 64 j (j < 2) of the bm x 16 group maxima: group e % 16 of the (e / 16)-th best part
   int mypart[2] = {-1, -1};
 #pragma unroll
-  for (int k = 0; k < RES_BMK; ++k) {
+  for (int k = 0; k < PK_BM; ++k) {
     if (k >= bm) break;
     unsigned long long loc = hk[0];
 #pragma unroll
@@ -76,9 +77,9 @@ __global__ __launch_bounds__(256, 4) void beam_pick_groups_kernel(const float* _
     gk[j] = (ok && v != -INFINITY) ? key_of(v, (unsigned)(mypart[j] * 16 + l16)) : 0ull;
   }
   if (gk[1] > gk[0]) { const unsigned long long x = gk[0]; gk[0] = gk[1]; gk[1] = x; }
-  int gsel[RES_BMK];
+  int gsel[PK_BM];
 #pragma unroll
-  for (int k = 0; k < RES_BMK; ++k) {
+  for (int k = 0; k < PK_BM; ++k) {
     gsel[k] = 0;
     if (k >= bm) continue;
     const unsigned long long best = wave_max_u64(gk[0]);
@@ -91,10 +92,10 @@ __global__ __launch_bounds__(256, 4) void beam_pick_groups_kernel(const float* _
   int gl[2], gout[2];
 #pragma unroll
   for (int tile = 0; tile < 2; ++tile) {
-    gl[tile] = gout[tile] = gsel[tile * 4 < RES_BMK ? tile * 4 : 0];
+    gl[tile] = gout[tile] = gsel[tile * 4 < PK_BM ? tile * 4 : 0];
 #pragma unroll
     for (int q = 1; q < 4; ++q)
-      if (tile * 4 + q < RES_BMK) {
+      if (tile * 4 + q < PK_BM) {
         if ((l16 >> 2) == q) gl[tile] = gsel[tile * 4 + q];
         if (kg == q) gout[tile] = gsel[tile * 4 + q];
       }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, 4) void beam_pick_groups_kernel(const float* _
   const int ccol = (ctile ? gout[1] : gout[0]) * 4 + ce;
   unsigned long long ck = (l16 < 8 && cgrp < bm && ccol < V) ? key_of(cval, (unsigned)ccol) : 0ull;
 #pragma unroll
-  for (int k = 0; k < RES_BMK; ++k) {
+  for (int k = 0; k < PK_BM; ++k) {
     if (k >= bm) break;
     const unsigned long long best = wave_max_u64(ck);
     if (ck == best) ck = 0ull;
@@ -148,7 +149,7 @@ extern "C" int care_beam_pick_groups(const float* pmax, const float* psum, const
                                      int64_t lda, const void* W, int V, int K, float* cand_val, int32_t* cand_idx, int rows,
                                      void* stream) {
   if (!pmax || !psum || !gmax || !A || !W || !cand_val || !cand_idx || rows < 1 || parts < 1 || V < 1) return CARE_EINVAL;
-  if (bm < 1 || bm > RES_BMK || parts > 64 * PK_NP || parts != (V + 63) / 64 || K < 32 || K % 32 || V < 4 * RES_BMK * 4) return CARE_ESHAPE;
+  if (bm < 1 || bm > PK_BM || parts > 64 * PK_NP || parts != (V + 63) / 64 || K < 32 || K % 32 || V < 4 * PK_BM * 4) return CARE_ESHAPE;
   if (!care_aligned16(A) || !care_aligned16(W) || (lda & 7) || (K & 7)) return CARE_EALIGN;
   hipLaunchKernelGGL(beam_pick_groups_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, pmax, psum, gmax, parts, bm,
                      (const bf16_t*)A, lda, (const bf16_t*)W, V, K, cand_val, cand_idx, rows);

@@ -37,7 +37,7 @@ class BeamMixin:
             return False
         return self.as_ok and rows >= self.BEAM_FUSED_MIN_ROWS
 
-    # Beam selection below BEAM_FUSED_MIN_ROWS in the 16-bit modes (beam_size <= 5): the vocabulary product on the LDS-tiled
+    # Beam selection below BEAM_FUSED_MIN_ROWS in the 16-bit modes (beam_size <= 8): the vocabulary product on the LDS-tiled
     # kernel keeping per (row, 64-column part) the maximum, sum exp and the maxima of its sixteen 4-column groups
     # (care_gemm_tile_beam), then one wave per row picks the bm best groups and recomputes their 4 bm logits
     # (care_beam_pick_groups) - two launches and 12 KB per row instead of the [rows, V] fp32 logits written and read back
@@ -48,8 +48,8 @@ class BeamMixin:
 
     def beam_groups_for(self, rows: int, bm: int) -> bool:
         rows = self._form_rows or rows
-        return bool(self.bf_act and not self.beam_fused_for(rows) and bm <= 5 and rows >= self.BEAM_GROUPS_MIN_ROWS and
-                    80 <= self.V <= 16384 and self.d % 64 == 0)
+        return bool(self.bf_act and not self.beam_fused_for(rows) and bm <= 8 and rows >= self.BEAM_GROUPS_MIN_ROWS and
+                    128 <= self.V <= 16384 and self.d % 64 == 0)
 
     def _beam_groups_select(self, tag, xb, N, bm, cval, cidx):
         parts = (self.V + 63) // 64

@@ -474,7 +474,7 @@ int care_beam_pick(const float* pmax, const float* psum, int parts, const int32_
  *        bm best of their 16 bm groups (a row's bm best logits lie in its bm best groups); those 4 bm logits recomputed
  *        from A and W (the tile kernel's MFMA, operand roles and K order: the same bits); cand_val / cand_idx [rows, bm]
  *        = the bm best as log-probabilities (value desc, column asc), the format care_beam_advance reads.
- *   A bf16 [M, lda] (lda % 8 == 0), W bf16 [N, K], K % 64 == 0, bm <= 5, 80 <= N <= 16384; gmax 16-byte aligned.
+ *   A bf16 [M, lda] (lda % 8 == 0), W bf16 [N, K], K % 64 == 0, bm <= 8, 128 <= N <= 16384; gmax 16-byte aligned.
  */
 int care_gemm_tile_beam(const void* A, int64_t lda, const void* W, float* pmax, float* psum, float* gmax, int M,
                         int N, int K, void* stream);

@@ -300,7 +300,8 @@ def test_small_batch_form_rules(monkeypatch):
     assert not pre.tf_fast_ok(29, False)
     # mid-size forms: the beam selection from group maxima below BEAM_FUSED_MIN_ROWS (16-bit modes, beam <= 5)
     assert base.beam_groups_for(640, 5) and base.beam_groups_for(8191, 5) and not base.beam_groups_for(8192, 5)
-    assert not base.beam_groups_for(640, 6) and not HipEngine(make_opt("msrvtt_care"), "fp32").beam_groups_for(640, 5)
+    assert base.beam_groups_for(640, 8) and not base.beam_groups_for(640, 9)
+    assert not HipEngine(make_opt("msrvtt_care"), "fp32").beam_groups_for(640, 5)
     assert base.MID_TILE_ROWS == (1280, 16384)
     two = HipEngine(make_opt("msrvtt_base_ami", num_hidden_layers_decoder=2), "bf16")
     assert two.resident_ok(8)
