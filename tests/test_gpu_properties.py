@@ -240,6 +240,8 @@ PEAKED_ROWS = {"cls_head.tgt_word_prj.weight": {**{r: 12.0 for r in range(6, 46)
 # 61, 63, 55, 61 of 64 with 38, 41, 39, 37, 26, 30 clear-margin clips, every one of those bit-exact) minus 2
 AUDIT_MIN_EXACT = {("msrvtt_base_ami", 32768): 57, ("msrvtt_base_ami", 16384): 61, ("msrvtt_care", 4096): 59,
                    ("msrvtt_base_ami", 12345): 61, ("vatex_care_large", 4096): 53, ("care_median_gelu", 2048): 59}
+# ... and in fp16 mode (measured on the MI355X in round 5, minus 1)
+AUDIT_MIN_EXACT_FP16 = {("msrvtt_base_ami", 32768): 62, ("msrvtt_care", 4096): 63, ("vatex_care_large", 4096): 61}
 
 
 def _audit_record(**kw):
@@ -252,9 +254,13 @@ def _audit_record(**kw):
             f.write(json.dumps(kw) + "\n")
 
 
-@pytest.mark.parametrize("config,B", [("msrvtt_base_ami", 32768), ("msrvtt_base_ami", 16384), ("msrvtt_care", 4096),
-                                      ("msrvtt_base_ami", 12345), ("vatex_care_large", 4096), ("care_median_gelu", 2048)])
-def test_benchmarked_operating_point_against_oracle_sample(config, B):
+@pytest.mark.parametrize("config,B,mode", [("msrvtt_base_ami", 32768, "bf16"), ("msrvtt_base_ami", 16384, "bf16"), ("msrvtt_care", 4096, "bf16"),
+                                           ("msrvtt_base_ami", 12345, "bf16"), ("vatex_care_large", 4096, "bf16"),
+                                           ("care_median_gelu", 2048, "bf16"),
+                                           # the other 16-bit mode (round 5: the same kernels compiled for IEEE half) at the headline
+                                           # batch, on the concept model and at d_model 1024: near-tie margin 1e-2 instead of 5e-2
+                                           ("msrvtt_base_ami", 32768, "fp16"), ("msrvtt_care", 4096, "fp16"), ("vatex_care_large", 4096, "fp16")])
+def test_benchmarked_operating_point_against_oracle_sample(config, B, mode):
     """The code path bench.py times, end to end: bf16, lean encode, absorbed cross-attention, >= 10240
     rows (fused dense+LayerNorm in 128-row blocks, the 8-range vocabulary split), hipGraph replay - B = 32768 is
     bench.py's default batch; `vatex_care_large` / `care_median_gelu` (d_model 1024 / 768) run the LDS-tiled bf16
@@ -264,9 +270,10 @@ def test_benchmarked_operating_point_against_oracle_sample(config, B):
     any other divergence must start at a near-tie; replay == eager bit for bit.  B = 12345: ragged last
     panels in every 64- / 128- / 256-row kernel."""
     from oracle import care_cpu
-    from test_gpu_parity import BF16_LSE_PEAKED, CLEAR_MARGIN, _audit_greedy
+    from test_gpu_parity import CLEAR_MARGIN, MODES, _audit_greedy
 
-    opt, P, model, feats = _setup(config, B, "bf16", seed=189, boost=PEAKED_ROWS)
+    lse_bar, tie_tol = MODES[mode]["lse_peaked"], (5e-2 if mode == "bf16" else 1e-2)
+    opt, P, model, feats = _setup(config, B, mode, seed=189, boost=PEAKED_ROWS)
     eng = model.engine()
     eng.LATENT_MIN_ROWS = type(eng).LATENT_MIN_ROWS  # the engine's own switch points, as in bench.py
     if eng.d == 512:
@@ -295,18 +302,18 @@ def test_benchmarked_operating_point_against_oracle_sample(config, B):
         is_clear = gaps[j]["select"] >= CLEAR_MARGIN
         clear += is_clear
         if is_clear:
-            assert h == r, "clip {}: clear margins ({:.3f}) but bf16 ids differ".format(i, gaps[j]["select"])
+            assert h == r, "clip {}: clear margins ({:.3f}) but the 16-bit ids differ".format(i, gaps[j]["select"])
         if h == r:
             exact += 1
-            assert abs(float(score[i]) / n - scores[j][0]) < BF16_LSE_PEAKED  # peaked rows: logits up to +-30
+            assert abs(float(score[i]) / n - scores[j][0]) < lse_bar  # peaked rows: logits up to +-30
         else:
             # peaked rows scale the logit noise with them (measured logsumexp error up to 2.6e-2 on the
             # peaked fixtures): a step decided by less than 5e-2 may flip, one decided by >= 0.1 may not
-            _audit_greedy(P, opt, {k: v[j:j + 1] for k, v in inputs.items()}, h, r, 5e-2)
-    _audit_record(test="greedy_operating_point", config=config, B=B, sampled=64, exact=exact, clear=clear)
+            _audit_greedy(P, opt, {k: v[j:j + 1] for k, v in inputs.items()}, h, r, tie_tol)
+    _audit_record(test="greedy_operating_point", config=config, B=B, mode=mode, sampled=64, exact=exact, clear=clear)
     # a clear-margin clip that differs fails above; every other difference was audited as a near-tie.  What the count
     # adds is a cap on near-tie flips: AUDIT_MIN_EXACT = the measured count of this (config, B) minus 2
-    assert exact >= clear and exact >= AUDIT_MIN_EXACT.get((config, B), clear), \
+    assert exact >= clear and exact >= (AUDIT_MIN_EXACT if mode == "bf16" else AUDIT_MIN_EXACT_FP16).get((config, B), clear), \
         "operating point {} B={}: {}/64 sampled captions bit-exact, {} with clear margins".format(config, B, exact, clear)
     if eng.d == 512:  # (the d_model 768 / 1024 models of this seed never emit EOS)
         assert len(set(length[idx].tolist())) > 3
