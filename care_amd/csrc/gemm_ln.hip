@@ -305,7 +305,7 @@ int launch_ln(const LnArgs& p, hipStream_t st) {
 #define CARE_LN_A_AUX 0  // cache policy of the A stream's DMA (2 = nt: every A byte is read once)
 #endif
 #ifndef CARE_LN_DBG
-#define CARE_LN_DBG 0  // ablation builds (tools/ln_ablate.sh): 1 no MFMA, 2 no W DMA, 4 no A DMA, 8 no fragment reads
+#define CARE_LN_DBG 0  // ablation builds (tools/variant_lib.py): 1 no MFMA, 2 no W DMA, 4 no A DMA, 8 no fragment reads, 16 no epilogue, 32 no stores
 #endif
 // the step's MFMA: bf16 operands, or - split products - the same registers holding fp16 pieces
 template <bool F16>
@@ -586,6 +586,15 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
   // acc[mt][2p + e][j] = C[row 64 rg + 16 mt + fr][col 128 cg + 32 p + 8 fg + 4 e + j]
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // the rings are dead: their first bytes become the statistics exchange
+  if (CARE_LN_DBG & 16) {  // (ablation: no epilogue)
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) s += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+    if (s == 12345.678f && p.outb) p.outb[0] = (bf16_t)s;
+    return;
+  }
   float* stat = reinterpret_cast<float*>(smem);            // [2 passes][BM rows][4 column groups]
   const int col0 = cg * 128 + 8 * fg;
   int m0e = m0;
@@ -704,6 +713,7 @@ __global__ __launch_bounds__(256 * RG, RG) void gemm_ln2_kernel(LnArgs p) {
       o0.z = (v0[2] - mean[mt]) * rstd[mt] * g0.z + e0.z; o0.w = (v0[3] - mean[mt]) * rstd[mt] * g0.w + e0.w;
       o1.x = (v1[0] - mean[mt]) * rstd[mt] * g1.x + e1.x; o1.y = (v1[1] - mean[mt]) * rstd[mt] * g1.y + e1.y;
       o1.z = (v1[2] - mean[mt]) * rstd[mt] * g1.z + e1.z; o1.w = (v1[3] - mean[mt]) * rstd[mt] * g1.w + e1.w;
+      if (CARE_LN_DBG & 32) { if (o0.x + o0.y + o0.z + o0.w + o1.x + o1.y + o1.z + o1.w != 12345.678f) continue; }  // (ablation: no stores)
       if (p.out) {
         float* op = p.out + orow[mt] * p.ldo + c;
         *reinterpret_cast<float4*>(op) = o0;
@@ -735,6 +745,355 @@ template <bool AF32, int RG, int NSW, int NSA>
 int launch_ln2(const LnArgs& p, hipStream_t st) {
   if (p.res) return launch_ln2e<AF32, RG, NSW, NSA, 1>(p, st);
   return launch_ln2e<AF32, RG, NSW, NSA, 0>(p, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Version 3 (round 5): the feature embedder's form - raw fp32 features, no residual - with the two operand streams on
+// waves OF THEIR OWN and persistent workgroups.
+//
+// What was wrong with version 2 on that shape (M = 917504, K = 2048: 2.86 ms; tools/variant_lib.py ablations, round 5):
+// the two streams alone - in a kernel that does nothing else - take 1.50 ms (tools/micro/emb_stream.hip: the 7.5-GB
+// feature stream from HBM and the 14.7 GB every block re-reads of the packed weight from L2 share the CU's vector memory
+// path, whose returns are in order: 57 GB/s per CU in all, and a wave spends the whole K step ISSUING its 4 - 8 pieces
+// against that back pressure), the K loop without them 1.33 ms, and together 2.45 ms - every wave was a loader, so every
+// wave's MFMAs queued behind its own blocked loads.  Then 0.40 ms of epilogue (LayerNorm + 0.94 GB of stores) during
+// which the one workgroup of a CU had nothing in flight.  Here:
+//   * 12 waves: 8 compute (2 row groups x 4 column groups of 64 x 128, as before - the K step and the LayerNorm in the
+//     accumulator registers are version 2's, bit for bit) and 4 loaders that never touch the matrix pipe: two stream W
+//     by LDS-DMA (16 pieces of 1 KB per K step each, 3 stages of 32 KB), two stream the features through REGISTERS
+//     (global_load_dwordx4, two macro stages of 32 KB in flight per CU beyond the LDS ring), round them to the 16-bit
+//     type ONCE (version 2 converted in every one of the four column-group waves) and write the image the fragment reads
+//     want: 128-byte rows, 16-byte chunk c of row r at position c ^ ((r >> 1) & 7) - conflict-free for the 16-lane
+//     groups of ds_read_b128.  Three waves per SIMD: 168 registers each; a compute wave holds 128 accumulators, 4 A
+//     fragments and two pairs of B fragments;
+//   * persistent workgroups (one per CU, blocks blockIdx.x + i gridDim.x): the streams run on INTO the next block while
+//     the compute waves finish the LayerNorm - all three weight stages and the first feature stages of the next block
+//     are in LDS or in flight when its K loop starts;
+//   * one barrier per K step for all 12 waves (B_g: the reads of stage g are done, stage g + 1 has landed) and the two
+//     of the statistics exchange per block, which the loaders join.
+constexpr int WS_NSW = 3, WS_NSA = 2;
+constexpr int WS_W_BYTES = LN_N * 64;                         // a K step of the packed weight
+constexpr int WS_A_BYTES = 128 * 128;                         // a macro stage (2 K steps): 128 rows x 64 K x 2 B
+constexpr int WS_A_BASE = WS_NSW * WS_W_BYTES;
+constexpr int WS_STAT = WS_A_BASE + WS_NSA * WS_A_BYTES;      // [2 passes][128 rows][4 column groups] floats
+constexpr int WS_PAR = WS_STAT + 2 * 128 * 4 * 4;             // bias | gamma | beta, 512 floats each
+constexpr int WS_LDS = WS_PAR + 3 * LN_N * 4;
+#ifndef CARE_LN3_DBG
+#define CARE_LN3_DBG 0  // ablation builds (tools/variant_lib.py): 1 no MFMA, 2 no W DMA, 4 no feature loads, 8 no fragment reads, 16 no epilogue, 32 no stores
+#endif
+#ifndef CARE_LN3_A_NT
+#define CARE_LN3_A_NT 1  // the feature loads are non-temporal (every byte is read once: 5.4 -> 6.0 TB/s alone, tools/micro/emb_stream.hip)
+#endif
+
+template <bool OUT32>
+__global__ __launch_bounds__(768) void gemm_ln3_kernel(LnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = p.K >> 5, nmac = nk >> 1;                       // the launcher guarantees K % 128 == 0: nmac is even
+  const int nblk = (p.M + 127) >> 7;
+  const int mine = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // >= 1: gridDim.x <= nblk
+  const int total = mine * nk, total_mac = mine * nmac;          // steps / macro stages of this workgroup's streams
+  // (tools: CARE_LN3_DBG & 64 - workgroup 0 stamps its first 256 steps into p.out: [wave][step][4] shader-clock values)
+  auto stamp = [&](int g, int k) {
+    if (!(CARE_LN3_DBG & 64) || blockIdx.x != 0 || g >= 256 || lane != 0) return;
+    reinterpret_cast<unsigned long long*>(p.out)[(wave * 256 + g) * 4 + k] = __builtin_amdgcn_s_memtime();
+  };
+
+  if (wave >= 10) {
+    // ---------------------------------------------------------------- feature loader (two waves: rows 64 al + [0, 64))
+    // Piece i of a macro stage (i < 16): rows 64 al + 4 i + (lane >> 4), the 16-byte chunk lane & 15 of their 256 bytes.
+    // The loads are inline asm with counted waits of their own: hipcc's scoreboard loses the in-order count across the
+    // loop edge and drains the stream (vmcnt(15) .. vmcnt(0): every load of the YOUNGER stages too) before the first use.
+    // A register set is written by a load here and next touched by the wait below, whose "+v" operands order its uses.
+    const int al = wave - 10, q4 = lane >> 4, c16 = lane & 15;
+    const int64_t ldab = p.lda * 4;
+    const unsigned voff = (unsigned)q4 * (unsigned)ldab + (unsigned)c16 * 16u;   // (the launcher: 128 rows of lda floats < 4 GB)
+    const int lw = (64 * al + q4) * 128 + ((((c16 >> 1) ^ (q4 >> 1)) << 4) | ((c16 & 1) << 3));
+    f32x4 R0[16], R1[16];
+    int lbi = 0, lmac = 0;  // block / macro stage in it of the next load
+    const unsigned char* lrow = reinterpret_cast<const unsigned char*>(p.A) + ((int64_t)blockIdx.x * 128 + 64 * al) * ldab;
+    auto load_half = [&](f32x4 (&R)[16], int h) {  // pieces [8 h, 8 h + 8) of the next macro stage of the stream
+#pragma unroll
+      for (int i = 8 * h; i < 8 * h + 8; ++i) {
+        const unsigned char* base = lrow + (int64_t)(4 * i) * ldab + (int64_t)lmac * 256;
+        if (CARE_LN3_DBG & 4) { asm volatile("" : "+v"(R[i])); continue; }
+        // ("+v": the set keeps its registers - an "=v" result may land elsewhere and be COPIED home at the loop edge, in flight)
+        if (CARE_LN3_A_NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : "+v"(R[i]) : "v"(voff), "s"(base) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_nop 0" : "+v"(R[i]) : "v"(voff), "s"(base) : "memory");
+      }
+      if (h == 1 && ++lmac == nmac) {  // past the end of the stream the last macro stage is fetched again (nobody reads it):
+        if (lbi + 1 < mine) { lmac = 0; ++lbi; lrow += (int64_t)gridDim.x * 128 * ldab; }   // no tail cases, constant waits
+        else lmac = nmac - 1;
+      }
+    };
+    // ... of the OLDEST stage in flight have landed (the 24 younger pieces may fly)
+    auto landed = [&](f32x4 (&R)[16], int h, bool steady) {
+      if (steady) asm volatile("s_waitcnt vmcnt(24)" : "+v"(R[8 * h]), "+v"(R[8 * h + 1]), "+v"(R[8 * h + 2]), "+v"(R[8 * h + 3]), "+v"(R[8 * h + 4]), "+v"(R[8 * h + 5]), "+v"(R[8 * h + 6]), "+v"(R[8 * h + 7])::"memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[8 * h]), "+v"(R[8 * h + 1]), "+v"(R[8 * h + 2]), "+v"(R[8 * h + 3]), "+v"(R[8 * h + 4]), "+v"(R[8 * h + 5]), "+v"(R[8 * h + 6]), "+v"(R[8 * h + 7])::"memory");
+    };
+    auto store_half = [&](int m, f32x4 (&R)[16], int h) {  // ... rounded, into the LDS slot of macro stage m
+      unsigned char* dst = smem + WS_A_BASE + (m & 1) * WS_A_BYTES;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef h16_t hx2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int i = 8 * h; i < 8 * h + 8; ++i) {
+        const hx2 lo = __builtin_convertvector(f32x2{R[i][0], R[i][1]}, hx2), hi = __builtin_convertvector(f32x2{R[i][2], R[i][3]}, hx2);
+        bf16x4 o;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = hi[0]; o[3] = hi[1];
+        *reinterpret_cast<bf16x4*>(dst + i * 512 + (lw ^ (((2 * i) & 7) << 4))) = o;
+      }
+    };
+    // half h of macro stage m + 1 goes from its registers into the slot macro stage m - 1 left at B_2m-1, and the registers
+    // take the same half of macro stage m + 3 (straight-line: a branch around either would put copies of the set at the join)
+    auto produce = [&](int m, f32x4 (&R)[16], int h) {
+      landed(R, h, true);
+      store_half(m + 1, R, h);
+      __builtin_amdgcn_sched_barrier(0);
+      load_half(R, h);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { R0[i] = f32x4{0.f, 0.f, 0.f, 0.f}; R1[i] = R0[i]; }
+    load_half(R0, 0); load_half(R0, 1);
+    load_half(R1, 0); load_half(R1, 1);
+    landed(R0, 0, false); landed(R0, 1, false);   // (the prologue waits for everything: once per launch)
+    store_half(0, R0, 0); store_half(0, R0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_half(R0, 0); load_half(R0, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // B_start
+    // period m: the compute waves read macro stage m (steps 2m, 2m + 1)
+    auto period = [&](int m, f32x4 (&R)[16]) {
+      stamp(2 * m, 0);
+      produce(m, R, 0);
+      stamp(2 * m, 1);
+      if (m > 0 && m % nmac == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }  // the previous block's LayerNorm: E1, E2
+      __builtin_amdgcn_s_barrier();   // B_2m
+      stamp(2 * m + 1, 0);
+      produce(m, R, 1);
+      stamp(2 * m + 1, 1);
+      __builtin_amdgcn_s_barrier();   // B_2m+1
+    };
+#pragma unroll 1
+    for (int m = 0; m < total_mac; m += 2) {
+      period(m, R1);
+      period(m + 1, R0);
+    }
+    __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();  // the last block's E1, E2
+    return;
+  }
+
+  if (wave >= 8) {
+    // ---------------------------------------------------------------- weight loader (two waves: half a stage each)
+    const int wl = wave - 8;
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.W) + wl * 16384 + lane * 16;
+    int ikt = 0, islot = 0, issued = 0;  // K step / ring slot / number of the next stage to issue
+    auto issue = [&]() {
+      const unsigned char* s = wsrc + (int64_t)ikt * WS_W_BYTES;
+      unsigned char* d = smem + islot * WS_W_BYTES + wl * 16384;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (!(CARE_LN3_DBG & 2)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(d + i * 1024), 16, 0, 0);
+      ikt = ikt + 1 == nk ? 0 : ikt + 1;
+      islot = islot + 1 == WS_NSW ? 0 : islot + 1;
+      ++issued;
+    };
+    while (issued < min(WS_NSW - 1, total)) issue();
+    if (issued > 1) ln2_wait_vm<16>(); else ln2_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();  // B_start: stage 0 has landed
+    int kt = 0;
+#pragma unroll 1
+    for (int g = 0; g < total; ++g) {
+      // stages < g are read: stage g + NSW - 1 takes the slot of stage g - 1
+      stamp(g, 0);
+      if (issued < min(g + WS_NSW, total)) issue();
+      stamp(g, 1);
+      if (g > 0 && kt == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }  // the previous block's E1, E2
+      if (issued > g + 2) ln2_wait_vm<16>(); else ln2_wait_vm<0>();  // stage g + 1 has landed
+      stamp(g, 2);
+      __builtin_amdgcn_s_barrier();  // B_g
+      stamp(g, 3);
+      kt = kt + 1 == nk ? 0 : kt + 1;
+    }
+    __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();  // the last block's E1, E2
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute waves
+  const int rg = wave >> 2, cg = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int w_off0 = (cg * 128 + 8 * (fr >> 2) + (fr & 3)) * 64 + ((fg ^ ((fr & 4) >> 1)) << 4);   // as version 2
+  const int a_lane = WS_A_BASE + (rg * 64 + fr) * 128 + ((fg ^ ((fr >> 1) & 7)) << 4);
+  float* stat = reinterpret_cast<float*>(smem + WS_STAT);
+  const float* par = reinterpret_cast<const float*>(smem + WS_PAR);
+  for (int i = tid; i < 3 * LN_N; i += 512)   // the epilogue's vectors, once per workgroup (tid < 512 here)
+    reinterpret_cast<float*>(smem + WS_PAR)[i] = i < LN_N ? (p.bias ? p.bias[i] : 0.f) : i < 2 * LN_N ? p.gamma[i - LN_N] : p.beta[i - 2 * LN_N];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // B_start
+  int wslot = 0, g = 0;
+#pragma unroll 1
+  for (int bi = 0; bi < mine; ++bi) {
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      const unsigned char* sw = smem + wslot * WS_W_BYTES + w_off0;
+      const unsigned char* sa = smem + ((g >> 1) & 1) * WS_A_BYTES + (a_lane ^ ((g & 1) << 6));
+      bf16x8 fa[4], fb[2][2];
+      stamp(g, 0);
+      auto rd = [&](const unsigned char* q) {
+        if (CARE_LN3_DBG & 8) { bf16x8 z = {}; asm volatile("" : "+v"(z)); return z; }
+        return *reinterpret_cast<const bf16x8*>(q);
+      };
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) fa[mt] = rd(sa + mt * 16 * 128);
+      fb[0][0] = rd(sw);
+      fb[0][1] = rd(sw + 4 * 64);
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        if (pr < 3) {  // the next pair of B fragments is requested BEFORE this pair's MFMAs (hipcc would reuse the registers)
+          fb[(pr + 1) & 1][0] = rd(sw + (pr + 1) * 32 * 64);
+          fb[(pr + 1) & 1][1] = rd(sw + ((pr + 1) * 32 + 4) * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          if (CARE_LN3_DBG & 1) { asm volatile("" :: "v"(fb[pr & 1][0]), "v"(fb[pr & 1][1]), "v"(fa[mt])); continue; }
+          acc[mt][2 * pr] = care_mfma_16x16x32_h16(fb[pr & 1][0], fa[mt], acc[mt][2 * pr], 0, 0, 0);
+          acc[mt][2 * pr + 1] = care_mfma_16x16x32_h16(fb[pr & 1][1], fa[mt], acc[mt][2 * pr + 1], 0, 0, 0);
+        }
+      }
+      wslot = wslot + 1 == WS_NSW ? 0 : wslot + 1;
+      stamp(g, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment of stage g is in registers
+      __builtin_amdgcn_s_barrier();  // B_g
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---------------------------------------------------------------- epilogue (version 2's arithmetic, no residual; in registers)
+    // acc[mt][2p + e][j] = C[row 64 rg + 16 mt + fr][col 128 cg + 32 p + 8 fg + 4 e + j]
+    const int m0 = ((int)blockIdx.x + bi * (int)gridDim.x) * 128;
+    if (CARE_LN3_DBG & 16) {  // (ablation: no epilogue; the loaders still make its two barriers)
+      float s = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) s += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+      if (s == 12345.678f && p.outb) p.outb[0] = (bf16_t)s;
+      __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();
+      continue;
+    }
+    // (lane coordinates through an empty asm: every address below is recomputed per block - hoisted out of the block loop they
+    // would sit in scratch across the K loop, whose 164 registers are all taken)
+    int lid, grp = p.grp;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+    asm volatile("" : "+s"(grp));
+    const int fre = lid & 15, fge = lid >> 4;
+    auto xlane = [&](float v, int mask) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lid ^ mask) << 2, __builtin_bit_cast(int, v))); };
+    const int col0e = cg * 128 + 8 * fge;
+    const int srow = (rg * 64 + fre) * 4;   // this lane's first row in the statistics exchange (+ 64 floats per tile)
+    // pass 1: v = acc + bias, row sums
+    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(par + col0e + 32 * pq), b1 = *reinterpret_cast<const f32x4*>(par + col0e + 32 * pq + 4);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f32x4& v0 = acc[mt][2 * pq];
+        f32x4& v1 = acc[mt][2 * pq + 1];
+        v0 += b0; v1 += b1;
+        rsum[mt] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float s = rsum[mt];
+      s += xlane(s, 16);
+      s += xlane(s, 32);
+      if (fge == 0) stat[srow + mt * 64 + cg] = s;
+    }
+    __syncthreads();  // E1
+    // pass 2: centred squares
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const float4 t = *reinterpret_cast<const float4*>(stat + srow + mt * 64);
+      const float mean = ((t.x + t.y) + (t.z + t.w)) * (1.0f / LN_N);
+      float q = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        acc[mt][nt] -= mean;   // (v - mean) is what the third pass wants too
+        const float a = acc[mt][nt][0], b = acc[mt][nt][1], c = acc[mt][nt][2], e = acc[mt][nt][3];
+        q += (a * a + b * b) + (c * c + e * e);
+      }
+      q += xlane(q, 16);
+      q += xlane(q, 32);
+      if (fge == 0) stat[128 * 4 + srow + mt * 64 + cg] = q;
+    }
+    __syncthreads();  // E2
+    // pass 3: ((v - mean) * rstd) * gamma + beta, rounded, 16 bytes per lane and row (64 contiguous bytes per row and store)
+    int orow[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const float4 t = *reinterpret_cast<const float4*>(stat + 128 * 4 + srow + mt * 64);
+      const float rstd = 1.0f / sqrtf(((t.x + t.y) + (t.z + t.w)) * (1.0f / LN_N) + p.eps);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) acc[mt][nt] *= rstd;
+      const int grow = m0 + rg * 64 + mt * 16 + fre;   // < M: the launcher sends whole blocks only
+      orow[mt] = (grow / grp) * p.out_grp_rows + p.out_row_off + (grow % grp);
+    }
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+      const int c = col0e + 32 * pq;
+      typedef h16_t hx4 __attribute__((ext_vector_type(4)));
+      hx4 h0[4];
+      {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(par + LN_N + c), e0 = *reinterpret_cast<const f32x4*>(par + 2 * LN_N + c);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 o = acc[mt][2 * pq] * g0 + e0;
+          if (OUT32 && !(CARE_LN3_DBG & 96)) *reinterpret_cast<f32x4*>(p.out + (int64_t)orow[mt] * p.ldo + c) = o;
+          h0[mt] = hx4{(h16_t)o[0], (h16_t)o[1], (h16_t)o[2], (h16_t)o[3]};
+        }
+      }
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(par + LN_N + c + 4), e1 = *reinterpret_cast<const f32x4*>(par + 2 * LN_N + c + 4);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 o = acc[mt][2 * pq + 1] * g1 + e1;
+        if (OUT32 && !(CARE_LN3_DBG & 96)) *reinterpret_cast<f32x4*>(p.out + (int64_t)orow[mt] * p.ldo + c + 4) = o;
+        if (CARE_LN3_DBG & 32) { if (o[0] + o[1] + o[2] + o[3] != 12345.678f) continue; }
+        if (p.outb) {
+          bf16x8 ob;
+          ob[0] = h0[mt][0]; ob[1] = h0[mt][1]; ob[2] = h0[mt][2]; ob[3] = h0[mt][3];
+          ob[4] = (h16_t)o[0]; ob[5] = (h16_t)o[1]; ob[6] = (h16_t)o[2]; ob[7] = (h16_t)o[3];
+          *reinterpret_cast<bf16x8*>(p.outb + (int64_t)orow[mt] * p.ldo + c) = ob;
+        }
+      }
+    }
+    stamp(g - 1, 2);
+  }
+}
+
+int launch_ln3(const LnArgs& p, hipStream_t st) {
+  static std::atomic<unsigned long long> lds_ok{0};
+  static std::atomic<unsigned long long> lds_ok32{0};
+  const bool out32 = p.out != nullptr && !(CARE_LN3_DBG & 64);
+  if (const int e = out32 ? care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_ln3_kernel<true>), WS_LDS, lds_ok32)
+                          : care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_ln3_kernel<false>), WS_LDS, lds_ok)) return e;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    return n;
+  }();
+  const int nblk = (p.M + 127) / 128;
+  if (out32) hipLaunchKernelGGL(gemm_ln3_kernel<true>, dim3(nblk < cus ? nblk : cus), dim3(768), WS_LDS, st, p);
+  else hipLaunchKernelGGL(gemm_ln3_kernel<false>, dim3(nblk < cus ? nblk : cus), dim3(768), WS_LDS, st, p);
+  return care_launch_status();
 }
 
 }  // namespace
@@ -771,6 +1130,11 @@ static int gemm_ln_impl(const void* A, int64_t lda, int a_dtype, const void* W, 
     if (a_dtype != CARE_F32 || res) return CARE_ESHAPE;
     return big ? launch_ln2e<true, 2, 2, 3, 0, 3>(p, st) : launch_ln2e<true, 1, 3, 4, 0, 3>(p, st);
   }
+  // version 3 (loader waves, persistent workgroups): raw fp32 features, no residual, at least a workgroup per CU's worth of
+  // 128-row blocks.  A row's arithmetic is version 2's: the launch rule does not change a result.
+  static const int v3 = [] { const char* e = getenv("CARE_LN_V3"); return e ? atoi(e) : 1; }();  // A/B switch
+  if (v3 && v2 && w_packed == 1 && a_dtype == CARE_F32 && !res && K % 128 == 0 && M % 128 == 0 && M >= 128 * 192 && lda * 4 * 128 < (1ll << 32))
+    return launch_ln3(p, st);
   if (v2 && v2_ok) {
     if (a_dtype == CARE_F32) return big ? launch_ln2<true, 2, 2, 3>(p, st) : launch_ln2<true, 1, 3, 4>(p, st);
     static const int ae = [] { const char* e = getenv("CARE_LN_AE"); return e ? atoi(e) : 1; }();  // A/B switch

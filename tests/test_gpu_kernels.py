@@ -462,6 +462,48 @@ def test_gemm_ln_fused(a_f32, M, K, form, monkeypatch):
     assert torch.equal(outb, out.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("variant", ["", "f16"])
+@pytest.mark.parametrize("out32", [False, True])
+@pytest.mark.parametrize("M,K", [(128 * 192, 128), (28 * 1024, 512), (28 * 1024, 2048), (128 * 300, 128), (128 * 300, 512), (128 * 513, 128),
+                                 (128 * 777, 256)])
+def test_gemm_ln_loader_waves(M, K, out32, variant):
+    """The embedder's form at batch sizes (raw fp32 features, no residual, packed weight, whole 128-row blocks, >= 192 of
+    them): version 3 of the fused kernel - loader waves, persistent workgroups, csrc/gemm_ln.hip - against the plain-weight
+    entry, which stays on version 2: the same bits (a row's arithmetic does not depend on the launch rule), in both
+    libraries, with the grouped output rows of the encoder (28 frames into a memory of 84 rows) and workgroups that own one,
+    two and three blocks."""
+    from care_amd import _lib
+
+    h16 = torch.float16 if variant else torch.bfloat16
+    call = lambda name, *a: _lib.call(name, *a, variant=variant)
+    d, grp = 512, 28 if M % 28 == 0 else M
+    A = _rand(M, K, seed=150)
+    W = _rand(d, K, seed=151, scale=1 / math.sqrt(K)).to(h16).contiguous()
+    bias, g, b = _rand(d, seed=152), _rand(d, seed=153), _rand(d, seed=154)
+    ngrp = M // grp
+    Wp = torch.empty_like(W)
+    call("care_pack_ln_weight", _p(W), _p(Wp), d, K)
+    outs = []
+    for packed in (True, False):
+        out = torch.zeros(ngrp, grp + 56, d, device=DEV) if out32 else None
+        outb = torch.zeros(ngrp, grp + 56, d, device=DEV, dtype=h16)
+        if packed:
+            call("care_gemm_ln_packed", _p(A), K, 0, _p(Wp), _p(bias), None, d, _p(g), _p(b), 1e-12, _p(out), _p(outb), d, M, d, K, grp, grp + 56, 28)
+        else:
+            call("care_gemm_ln", _p(A), K, 0, _p(W), _p(bias), None, d, None, _p(g), _p(b), 1e-12, _p(out), _p(outb), d, M, d, K, grp, grp + 56, 28)
+        outs.append((out, outb))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    if out32:
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[0][0].to(h16))
+    rows = slice(0, 4096)
+    y = A[rows].to(h16).double() @ W.double().t() + bias.double()
+    ref = torch.nn.functional.layer_norm(y, (d,), g.double(), b.double(), 1e-12)
+    got = outs[0][1][:, 28:28 + grp].reshape(M, d)[rows].double()
+    assert (got - ref).abs().max().item() < (4e-3 if variant else 3.2e-2)
+    assert outs[0][1][:, :28].abs().max().item() == 0 and outs[0][1][:, 28 + grp:].abs().max().item() == 0
+
+
 @pytest.mark.parametrize("M,N,K", [(70, 1024, 64), (28 * 41, 1024, 2048), (4500, 768, 512), (28 * 1200, 1024, 128)])
 def test_gemm_split3_products(M, N, K):
     """care_gemm_split3: the generic GEMM with fp32 operands as fp16 hi/lo pieces (one product over 3K) - against the

@@ -1,0 +1,48 @@
+"""The feature embedder's launches alone (fused Linear + LayerNorm on raw fp32 features, bf16 output only - the lean
+encode of the headline pass): M = B * 28 frame rows, K = 2048 / 512 / 128.   python tools/emb_bench.py [B] [K ...]
+CARE_HIP_LIB=<tool build> selects an ablation / experiment library (tools/variant_lib.py)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from care_amd import _lib
+from tools.gemm_bench import time_call
+
+DEV = "cuda:0"
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+    Ks = [int(a) for a in sys.argv[2:]] or [2048, 512, 128]
+    M = B * 28
+    p = lambda t: t.data_ptr()
+    tag = os.environ.get("CARE_HIP_LIB", "default")
+    for K in Ks:
+        A = torch.randn(M, K, device=DEV)
+        W = (torch.randn(512, K, device=DEV) * 0.05).to(torch.bfloat16)
+        bias, g, b = (torch.randn(512, device=DEV) for _ in range(3))
+        outb = torch.empty(M, 512, device=DEV, dtype=torch.bfloat16)
+        Wp = torch.empty_like(W)
+        _lib.call("care_pack_ln_weight", p(W), p(Wp), 512, K)
+        t = time_call(lambda: _lib.call("care_gemm_ln_packed", p(A), K, 0, p(Wp), p(bias), None, 512, p(g), p(b), 1e-12, None, p(outb),
+                                        512, M, 512, K, M, M, 0), iters=4)
+        if os.environ.get("EMB_CHECK", "1") != "0":  # the packed entry (version 3 where it applies) against the unpacked one (version 2)
+            ref = torch.empty_like(outb)
+            _lib.call("care_gemm_ln", p(A), K, 0, p(W), p(bias), None, 512, None, p(g), p(b), 1e-12, None, p(ref), 512, M, 512, K, M, M, 0)
+            torch.cuda.synchronize()
+            same = torch.equal(ref.view(torch.int16), outb.view(torch.int16))
+            x = (A[:4096].to(torch.bfloat16).double() @ W.double().t()) + bias.double()
+            y = torch.nn.functional.layer_norm(x, (512,), g.double(), b.double(), 1e-12)
+            print("    bit-identical to the unpacked entry: %s;  max |err| vs fp64 of the first 4096 rows: %.3e" %
+                  (same, (outb[:4096].double() - y).abs().max().item()), flush=True)
+            del ref
+        nbytes = M * K * 4 + M * 512 * 2
+        print("%-40s M=%6d K=%4d: %8.1f us  %6.1f TF  %5.2f TB/s" % (os.path.basename(tag), M, K, t, 2.0 * M * 512 * K / t / 1e6, nbytes / t / 1e6),
+              flush=True)
+        del A, outb
+
+
+if __name__ == "__main__":
+    main()
