@@ -1096,6 +1096,290 @@ int launch_ln3(const LnArgs& p, hipStream_t st) {
   return care_launch_status();
 }
 
+// ---- the split products (REP = 3 of version 2: a_hi w_hi + a_hi w_lo + a_lo w_hi in fp16 pieces) in version 3's form.
+// A stage is one REAL K step of 32: the weight's w_hi | w_lo images (64 KB; care_pack_ln_weight_split's third image is its
+// first again and is NOT fetched - version 2 streamed all three) and the features' a_hi | a_lo images (128 rows x 64 B
+// each, written by the loader waves: the four column-group waves of version 2 each split every fragment themselves); two
+// stages of each fill the 160 KB, the statistics exchange of the LayerNorm borrows the feature slot that was read last
+// (a third barrier hands it back).  Per accumulator the three products of a step run in version 2's order: the same bits.
+constexpr int WSS_W_STAGE = 2 * WS_W_BYTES;
+constexpr int WSS_A_IMG = 128 * 64, WSS_A_STAGE = 2 * WSS_A_IMG;
+constexpr int WSS_A_BASE = 2 * WSS_W_STAGE;
+constexpr int WSS_LDS = WSS_A_BASE + 2 * WSS_A_STAGE;
+static_assert(WSS_LDS <= 160 * 1024, "LDS budget");
+
+template <bool OUT32>
+__global__ __launch_bounds__(768) void gemm_ln3s_kernel(LnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = p.K >> 5;                                        // the launcher guarantees K % 128 == 0: nk % 4 == 0
+  const int nblk = (p.M + 127) >> 7;
+  const int mine = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = mine * nk;
+
+  if (wave >= 10) {
+    // ---------------------------------------------------------------- feature loader (two waves: rows 64 al + [0, 64))
+    // piece i of a stage (i < 8): rows 64 al + 8 i + (lane >> 3), the 16-byte fp32 chunk lane & 7 of their 128 bytes;
+    // stage s lives in register set s % 4 (the halves of R0, R1), three younger stages in flight behind the one awaited
+    const int al = wave - 10, q8 = lane >> 3, c8 = lane & 7;
+    const int64_t ldab = p.lda * 4;
+    const unsigned voff = (unsigned)q8 * (unsigned)ldab + (unsigned)c8 * 16u;
+    const int lw = (64 * al + q8) * 64 + (((c8 >> 1) << 4) | ((c8 & 1) << 3));
+    f32x4 R0[16], R1[16];
+    int lbi = 0, lkt = 0;
+    const unsigned char* lrow = reinterpret_cast<const unsigned char*>(p.A) + ((int64_t)blockIdx.x * 128 + 64 * al) * ldab;
+    auto load_half = [&](f32x4 (&R)[16], int h) {  // the next stage of the stream into pieces [8 h, 8 h + 8) of a set
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned char* base = lrow + (int64_t)(8 * i) * ldab + (int64_t)lkt * 128;
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : "+v"(R[8 * h + i]) : "v"(voff), "s"(base) : "memory");
+      }
+      if (++lkt == nk) {  // past the end of the stream the last stage is fetched again (nobody reads it)
+        if (lbi + 1 < mine) { lkt = 0; ++lbi; lrow += (int64_t)gridDim.x * 128 * ldab; }
+        else lkt = nk - 1;
+      }
+    };
+    auto landed = [&](f32x4 (&R)[16], int h, bool steady) {
+      if (steady) asm volatile("s_waitcnt vmcnt(24)" : "+v"(R[8 * h]), "+v"(R[8 * h + 1]), "+v"(R[8 * h + 2]), "+v"(R[8 * h + 3]), "+v"(R[8 * h + 4]), "+v"(R[8 * h + 5]), "+v"(R[8 * h + 6]), "+v"(R[8 * h + 7])::"memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[8 * h]), "+v"(R[8 * h + 1]), "+v"(R[8 * h + 2]), "+v"(R[8 * h + 3]), "+v"(R[8 * h + 4]), "+v"(R[8 * h + 5]), "+v"(R[8 * h + 6]), "+v"(R[8 * h + 7])::"memory");
+    };
+    auto store_half = [&](int s, f32x4 (&R)[16], int h) {  // stage s: a = a_hi + a_lo in fp16 pieces, into its slot
+      unsigned char* dst = smem + WSS_A_BASE + (s & 1) * WSS_A_STAGE;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 x = R[8 * h + i];
+        const f16x2 h0 = __builtin_convertvector(f32x2{x[0], x[1]}, f16x2), h1 = __builtin_convertvector(f32x2{x[2], x[3]}, f16x2);
+        const f16x2 l0 = __builtin_convertvector(f32x2{x[0] - (float)h0[0], x[1] - (float)h0[1]}, f16x2);
+        const f16x2 l1 = __builtin_convertvector(f32x2{x[2] - (float)h1[0], x[3] - (float)h1[1]}, f16x2);
+        const int o = i * 512 + (lw ^ ((i & 1) << 5));  // row & 8 = 8 (i & 1): the chunk swizzle of a 64-byte row, chunk ^= (row & 8) >> 2
+        *reinterpret_cast<f16x4*>(dst + o) = f16x4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<f16x4*>(dst + WSS_A_IMG + o) = f16x4{l0[0], l0[1], l1[0], l1[1]};
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { R0[i] = f32x4{0.f, 0.f, 0.f, 0.f}; R1[i] = R0[i]; }
+    load_half(R0, 0); load_half(R0, 1); load_half(R1, 0); load_half(R1, 1);
+    landed(R0, 0, true);
+    store_half(0, R0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_half(R0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // B_start
+    // step g: stage g + 1 goes from its registers (set (g + 1) % 4) into the slot stage g - 1 left at B_g-1; the registers
+    // take stage g + 5.  At a block's first step the LayerNorm of its predecessor runs first, in the slot to be written.
+    int kt = 0;
+    auto step = [&](int g, f32x4 (&R)[16], int h) {
+      if (g > 0 && kt == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }  // E1, E2, E3
+      landed(R, h, true);
+      store_half(g + 1, R, h);
+      __builtin_amdgcn_sched_barrier(0);
+      load_half(R, h);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // B_g
+      kt = kt + 1 == nk ? 0 : kt + 1;
+    };
+#pragma unroll 1
+    for (int g = 0; g < total; g += 4) {
+      step(g, R0, 1); step(g + 1, R1, 0); step(g + 2, R1, 1); step(g + 3, R0, 0);
+    }
+    __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();  // the last block's E1, E2, E3
+    return;
+  }
+
+  if (wave >= 8) {
+    // ---------------------------------------------------------------- weight loader (two waves: 32 of a stage's 64 pieces each)
+    const int wl = wave - 8;
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.W) + wl * 32768 + lane * 16;
+    int ikt = 0;
+    auto issue = [&](int s) {  // stage s: the hi (wl = 0) or lo (wl = 1) image of its K step
+      const unsigned char* src = wsrc + (int64_t)ikt * (3 * WS_W_BYTES);
+      unsigned char* d = smem + (s & 1) * WSS_W_STAGE + wl * 32768;
+#pragma unroll
+      for (int i = 0; i < 32; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(d + i * 1024), 16, 0, 0);
+      ikt = ikt + 1 == nk ? 0 : ikt + 1;
+    };
+    issue(0);
+    ln2_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();  // B_start
+    int kt = 0;
+#pragma unroll 1
+    for (int g = 0; g < total; ++g) {
+      if (g + 1 < total) issue(g + 1);  // into the slot stage g - 1 left at B_g-1 (also while the LayerNorm runs)
+      if (g > 0 && kt == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+      ln2_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();  // B_g
+      kt = kt + 1 == nk ? 0 : kt + 1;
+    }
+    __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute waves
+  const int rg = wave >> 2, cg = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int w_off0 = (cg * 128 + 8 * (fr >> 2) + (fr & 3)) * 64 + ((fg ^ ((fr & 4) >> 1)) << 4);   // as version 2
+  const int a_lane = WSS_A_BASE + (rg * 64 + fr) * 64 + ((fg ^ ((fr & 8) >> 2)) << 4);
+  float* stat = reinterpret_cast<float*>(smem + WSS_A_BASE + WSS_A_STAGE);   // feature slot 1: read last in every block (nk is even)
+  __builtin_amdgcn_s_barrier();  // B_start
+  int g = 0;
+#pragma unroll 1
+  for (int bi = 0; bi < mine; ++bi) {
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      const unsigned char* sw = smem + (g & 1) * WSS_W_STAGE + w_off0;
+      const unsigned char* sa = smem + (g & 1) * WSS_A_STAGE + a_lane;
+      bf16x8 fa[4], fb[2][2];
+      auto rd = [&](const unsigned char* q) { return *reinterpret_cast<const bf16x8*>(q); };
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {  // a_hi w_hi, a_hi w_lo, a_lo w_hi
+        const unsigned char* swp = sw + (pass == 1 ? WS_W_BYTES : 0);
+        if (pass != 1) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) fa[mt] = rd(sa + (pass == 2 ? WSS_A_IMG : 0) + mt * 16 * 64);
+        }
+        fb[0][0] = rd(swp);
+        fb[0][1] = rd(swp + 4 * 64);
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          if (pr < 3) {
+            fb[(pr + 1) & 1][0] = rd(swp + (pr + 1) * 32 * 64);
+            fb[(pr + 1) & 1][1] = rd(swp + ((pr + 1) * 32 + 4) * 64);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            acc[mt][2 * pr] = ln2_mfma<true>(fb[pr & 1][0], fa[mt], acc[mt][2 * pr]);
+            acc[mt][2 * pr + 1] = ln2_mfma<true>(fb[pr & 1][1], fa[mt], acc[mt][2 * pr + 1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment of stage g is in registers
+      __builtin_amdgcn_s_barrier();  // B_g
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---------------------------------------------------------------- epilogue (version 2's arithmetic; the vectors from global memory)
+    const int m0 = ((int)blockIdx.x + bi * (int)gridDim.x) * 128;
+    int lid, grp = p.grp;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+    asm volatile("" : "+s"(grp));
+    const int fre = lid & 15, fge = lid >> 4;
+    auto xlane = [&](float v, int mask) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lid ^ mask) << 2, __builtin_bit_cast(int, v))); };
+    const int col0e = cg * 128 + 8 * fge;
+    const int srow = (rg * 64 + fre) * 4;
+    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + col0e + 32 * pq); b1 = *reinterpret_cast<const f32x4*>(p.bias + col0e + 32 * pq + 4); }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f32x4& v0 = acc[mt][2 * pq];
+        f32x4& v1 = acc[mt][2 * pq + 1];
+        v0 += b0; v1 += b1;
+        rsum[mt] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float s = rsum[mt];
+      s += xlane(s, 16);
+      s += xlane(s, 32);
+      if (fge == 0) stat[srow + mt * 64 + cg] = s;
+    }
+    __syncthreads();  // E1
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const float4 t = *reinterpret_cast<const float4*>(stat + srow + mt * 64);
+      const float mean = ((t.x + t.y) + (t.z + t.w)) * (1.0f / LN_N);
+      float q = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        acc[mt][nt] -= mean;
+        const float a = acc[mt][nt][0], b = acc[mt][nt][1], c = acc[mt][nt][2], e = acc[mt][nt][3];
+        q += (a * a + b * b) + (c * c + e * e);
+      }
+      q += xlane(q, 16);
+      q += xlane(q, 32);
+      if (fge == 0) stat[128 * 4 + srow + mt * 64 + cg] = q;
+    }
+    __syncthreads();  // E2
+    int orow[4];
+    float rstd[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const float4 t = *reinterpret_cast<const float4*>(stat + 128 * 4 + srow + mt * 64);
+      rstd[mt] = 1.0f / sqrtf(((t.x + t.y) + (t.z + t.w)) * (1.0f / LN_N) + p.eps);
+    }
+    __syncthreads();  // E3: the exchange is read - the feature loader may write its slot
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) acc[mt][nt] *= rstd[mt];
+      const int grow = m0 + rg * 64 + mt * 16 + fre;
+      orow[mt] = (grow / grp) * p.out_grp_rows + p.out_row_off + (grow % grp);
+    }
+    const float* gam = p.gamma;
+    const float* bet = p.beta;
+    asm volatile("" : "+s"(gam), "+s"(bet));
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+      const int c = col0e + 32 * pq;
+      typedef h16_t hx4 __attribute__((ext_vector_type(4)));
+      hx4 h0[4];
+      {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam + c), e0 = *reinterpret_cast<const f32x4*>(bet + c);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 o = acc[mt][2 * pq] * g0 + e0;
+          if (OUT32) *reinterpret_cast<f32x4*>(p.out + (int64_t)orow[mt] * p.ldo + c) = o;
+          h0[mt] = hx4{(h16_t)o[0], (h16_t)o[1], (h16_t)o[2], (h16_t)o[3]};
+        }
+      }
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gam + c + 4), e1 = *reinterpret_cast<const f32x4*>(bet + c + 4);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 o = acc[mt][2 * pq + 1] * g1 + e1;
+        if (OUT32) *reinterpret_cast<f32x4*>(p.out + (int64_t)orow[mt] * p.ldo + c + 4) = o;
+        if (p.outb) {
+          bf16x8 ob;
+          ob[0] = h0[mt][0]; ob[1] = h0[mt][1]; ob[2] = h0[mt][2]; ob[3] = h0[mt][3];
+          ob[4] = (h16_t)o[0]; ob[5] = (h16_t)o[1]; ob[6] = (h16_t)o[2]; ob[7] = (h16_t)o[3];
+          *reinterpret_cast<bf16x8*>(p.outb + (int64_t)orow[mt] * p.ldo + c) = ob;
+        }
+      }
+    }
+  }
+}
+
+int launch_ln3s(const LnArgs& p, hipStream_t st) {
+  static std::atomic<unsigned long long> lds_ok{0}, lds_ok32{0};
+  const bool out32 = p.out != nullptr;
+  if (const int e = out32 ? care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_ln3s_kernel<true>), WSS_LDS, lds_ok32)
+                          : care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_ln3s_kernel<false>), WSS_LDS, lds_ok)) return e;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    return n;
+  }();
+  const int nblk = (p.M + 127) / 128;
+  if (out32) hipLaunchKernelGGL(gemm_ln3s_kernel<true>, dim3(nblk < cus ? nblk : cus), dim3(768), WSS_LDS, st, p);
+  else hipLaunchKernelGGL(gemm_ln3s_kernel<false>, dim3(nblk < cus ? nblk : cus), dim3(768), WSS_LDS, st, p);
+  return care_launch_status();
+}
+
 }  // namespace
 
 static int gemm_ln_impl(const void* A, int64_t lda, int a_dtype, const void* W, int w_packed, const float* bias,
@@ -1126,15 +1410,17 @@ static int gemm_ln_impl(const void* A, int64_t lda, int a_dtype, const void* W, 
   // version 2 moves A in 256-byte pieces of a row: K must be a whole number of them
   const bool v2_ok = !pos && K % (a_dtype == CARE_F32 ? 64 : 128) == 0;
   if (w_packed && !(v2 && v2_ok)) return CARE_ESHAPE;  // only the version-2 kernels read the packed order
-  if (w_packed == 2) {  // split products (care_pack_ln_weight_split): fp32 A, no residual
-    if (a_dtype != CARE_F32 || res) return CARE_ESHAPE;
-    return big ? launch_ln2e<true, 2, 2, 3, 0, 3>(p, st) : launch_ln2e<true, 1, 3, 4, 0, 3>(p, st);
-  }
   // version 3 (loader waves, persistent workgroups): raw fp32 features, no residual, at least a workgroup per CU's worth of
   // 128-row blocks.  A row's arithmetic is version 2's: the launch rule does not change a result.
-  static const int v3 = [] { const char* e = getenv("CARE_LN_V3"); return e ? atoi(e) : 1; }();  // A/B switch
-  if (v3 && v2 && w_packed == 1 && a_dtype == CARE_F32 && !res && K % 128 == 0 && M % 128 == 0 && M >= 128 * 192 && lda * 4 * 128 < (1ll << 32))
-    return launch_ln3(p, st);
+  const char* v3e = getenv("CARE_LN_V3");  // A/B switch (read per call: the tests compare the two forms in one process)
+  const bool v3_ok = (!v3e || atoi(v3e)) && v2 && a_dtype == CARE_F32 && !res && K % 128 == 0 && M % 128 == 0 && M >= 128 * 192 &&
+                     lda * 4 * 128 < (1ll << 32);
+  if (v3_ok && w_packed == 1) return launch_ln3(p, st);
+  if (w_packed == 2) {  // split products (care_pack_ln_weight_split): fp32 A, no residual
+    if (a_dtype != CARE_F32 || res) return CARE_ESHAPE;
+    if (v3_ok) return launch_ln3s(p, st);
+    return big ? launch_ln2e<true, 2, 2, 3, 0, 3>(p, st) : launch_ln2e<true, 1, 3, 4, 0, 3>(p, st);
+  }
   if (v2 && v2_ok) {
     if (a_dtype == CARE_F32) return big ? launch_ln2<true, 2, 2, 3>(p, st) : launch_ln2<true, 1, 3, 4>(p, st);
     static const int ae = [] { const char* e = getenv("CARE_LN_AE"); return e ? atoi(e) : 1; }();  // A/B switch

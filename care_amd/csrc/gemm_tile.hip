@@ -30,7 +30,12 @@
 // 15.7-17.4 TB/s in pieces of 16 rows x 64 B).  Two-wave-group variants of the 256 x 256 tile (8 waves of 128 x 64, the
 // groups one barrier apart so one multiplies while the other reads and issues DMA; K steps of 32 in rings of 4 and 5, K
 // steps of 64 in row groups with 64 KB in flight; one persistent with the next tile's first stages in flight across the
-// epilogue) were built, verified, and landed within 2 % of this kernel on every shape: not kept.
+// epilogue) were built, verified, and landed within 2 % of this kernel on every shape: not kept.  Round 5: the wave-specialised
+// persistent form that took the embedder's fused kernel from 2.86 to 2.07 ms (csrc/gemm_ln.hip version 3: 8 compute waves of
+// 128 x 64 + 4 loader waves, A ring of three stages, W ring of two) - same bits, 5 - 13 % SLOWER here on every shape
+// (8192^3 1226 against 1310 TFLOP/s, 118784 x 2048 x 512 732 against 845): this tile is not bound by its streams (37 GB/s
+// per CU against the 57 the embedder's streams reach) but by two 128-accumulator waves per SIMD with 168 registers, which
+// cannot double-buffer their fragments - the sixteen 64-accumulator waves hide the LDS latency by occupancy.  Not kept.
 #include <cstdlib>
 
 #include "care_common.h"

@@ -504,6 +504,41 @@ def test_gemm_ln_loader_waves(M, K, out32, variant):
     assert outs[0][1][:, :28].abs().max().item() == 0 and outs[0][1][:, 28 + grp:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("variant", ["", "f16"])
+@pytest.mark.parametrize("out32", [False, True])
+@pytest.mark.parametrize("M,K", [(128 * 192, 128), (28 * 1024, 512), (28 * 1024, 2048), (128 * 300, 128), (128 * 513, 256)])
+def test_gemm_ln_split_loader_waves(M, K, out32, variant, monkeypatch):
+    """The concept models' embedder at batch sizes (care_gemm_ln_split on whole 128-row blocks, >= 192 of them): version 3 -
+    the hi / lo pieces of the features made once by the loader waves, two of the three weight images fetched - against
+    version 2 (CARE_LN_V3=0, read per call): the same bits, and the split product's accuracy against float64."""
+    from care_amd import _lib
+
+    h16 = torch.float16 if variant else torch.bfloat16
+    call = lambda name, *a: _lib.call(name, *a, variant=variant)
+    d, grp = 512, 28 if M % 28 == 0 else M
+    A = _rand(M, K, seed=160)
+    W = _rand(d, K, seed=161, scale=1 / math.sqrt(K))
+    bias, g, b = _rand(d, seed=162), _rand(d, seed=163), _rand(d, seed=164)
+    ngrp = M // grp
+    Ws = torch.empty(d, 3 * K, device=DEV, dtype=torch.float16)
+    call("care_pack_ln_weight_split", _p(W), _p(Ws), d, K)
+    outs = []
+    for v3 in ("1", "0"):
+        monkeypatch.setenv("CARE_LN_V3", v3)
+        out = torch.zeros(ngrp, grp + 56, d, device=DEV) if out32 else None
+        outb = torch.zeros(ngrp, grp + 56, d, device=DEV, dtype=h16)
+        call("care_gemm_ln_split", _p(A), K, _p(Ws), _p(bias), _p(g), _p(b), 1e-12, _p(out), _p(outb), d, M, d, K, grp, grp + 56, 28)
+        outs.append((out, outb))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    assert outs[0][1][:, :28].abs().max().item() == 0 and outs[0][1][:, 28 + grp:].abs().max().item() == 0
+    if out32:
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[0][0].to(h16))
+        rows = slice(0, 4096)
+        ref = torch.nn.functional.layer_norm(A[rows].double() @ W.double().t() + bias.double(), (d,), g.double(), b.double(), 1e-12)
+        assert (outs[0][0][:, 28:28 + grp].reshape(M, d)[rows].double() - ref).abs().max().item() < 2e-5 * math.sqrt(K / 64)
+
+
 @pytest.mark.parametrize("M,N,K", [(70, 1024, 64), (28 * 41, 1024, 2048), (4500, 768, 512), (28 * 1200, 1024, 128)])
 def test_gemm_split3_products(M, N, K):
     """care_gemm_split3: the generic GEMM with fp32 operands as fp16 hi/lo pieces (one product over 3K) - against the

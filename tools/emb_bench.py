@@ -13,7 +13,34 @@ from tools.gemm_bench import time_call
 DEV = "cuda:0"
 
 
+def split_main(B, Ks):
+    """the concept models' embedder: fp32 weight as fp16 hi / lo pieces (care_gemm_ln_split), version 3 against version 2"""
+    M = B * 28
+    p = lambda t: t.data_ptr()
+    for K in Ks:
+        A = torch.randn(M, K, device=DEV)
+        W = torch.randn(512, K, device=DEV) * 0.05
+        bias, g, b = (torch.randn(512, device=DEV) for _ in range(3))
+        Ws = torch.empty(512, 3 * K, device=DEV, dtype=torch.float16)
+        _lib.call("care_pack_ln_weight_split", p(W), p(Ws), 512, K)
+        res = {}
+        for v3 in ("1", "0"):
+            os.environ["CARE_LN_V3"] = v3
+            outb = torch.zeros(M, 512, device=DEV, dtype=torch.bfloat16)
+            fn = lambda: _lib.call("care_gemm_ln_split", p(A), K, p(Ws), p(bias), p(g), p(b), 1e-12, None, p(outb), 512, M, 512, K, M, M, 0)
+            t = time_call(fn, iters=4)
+            res[v3] = outb
+            print("split embedder version %s  M=%6d K=%4d: %8.1f us  %6.1f TF (3 passes)" % ("3" if v3 == "1" else "2", M, K, t, 6.0 * M * 512 * K / t / 1e6), flush=True)
+        del os.environ["CARE_LN_V3"]
+        x = A[:4096].double() @ W.double().t() + bias.double()
+        y = torch.nn.functional.layer_norm(x, (512,), g.double(), b.double(), 1e-12)
+        print("    the two versions bit-identical: %s;  max |err| vs fp64 of the first 4096 rows: %.3e" %
+              (torch.equal(res["1"].view(torch.int16), res["0"].view(torch.int16)), (res["1"][:4096].double() - y).abs().max().item()), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--split":
+        return split_main(int(sys.argv[2]) if len(sys.argv) > 2 else 16384, [int(a) for a in sys.argv[3:]] or [2048, 512, 128])
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
     Ks = [int(a) for a in sys.argv[2:]] or [2048, 512, 128]
     M = B * 28

@@ -32,11 +32,18 @@ def main():
         pi = torch.empty(M, parts, device=DEV, dtype=torch.int32)
         fl = 2.0 * M * N * K
         line = "M=%6d N=%5d K=%4d " % (M, N, K)
+        first = None
         for cfg in cfgs:
             os.environ["CARE_TILE_CFG"] = cfg
+            out.zero_()
             t = time_call(lambda: _lib.call("care_gemm_tile", p(A), K, p(W), p(bias), p(out), out.stride(0), 1, None, 0, 0, N,
                                             M, N, K, 0))
-            line += " %s: %7.1f us %6.1f TF |" % (cfg, t, fl / t / 1e6)
+            same = ""
+            if first is None:
+                first = out.clone()
+            else:
+                same = " =" if torch.equal(first.view(torch.int16), out.view(torch.int16)) else " DIFFERS"
+            line += " %s: %7.1f us %6.1f TF%s |" % (cfg, t, fl / t / 1e6, same)
         if N > 8192:
             for cfg in ("4412", "90"):
                 os.environ["CARE_TILE_CFG"] = cfg
