@@ -27,7 +27,7 @@
 // bf16 mode only (the fp32 parity mode keeps projected K/V and csrc/attention.hip).
 //
 // What bounds it.  Round 1 read the kernel as limited by bytes in flight (DMA ring alone 6.2 TB/s, full kernel
-// 5.0-5.3).  Round 2's ablation builds (tools/lat_ablate.sh, 32768 rows x 84 keys) found the actual costs: the
+// 5.0-5.3).  Round 2's ablation builds (tools/variant_lib.py, 32768 rows x 84 keys) found the actual costs: the
 // query load at the row start was waited for with vmcnt(0) - the wave's DMA queue drained once per row (658 us;
 // without q~ loads and c~ stores 465) - fixed by sending the query through the ring; the stream's cache policy
 // (673 -> 574 us with non-temporal loads and stores); and the c~ stores, whose cost is their bytes (no stores:
@@ -36,7 +36,7 @@
 #include "care_common.h"
 
 #ifndef CARE_LAT_DBG
-#define CARE_LAT_DBG 0  // ablation builds (tools/lat_ablate.sh): 1 no ct stores, 2 no qt loads, 4 no arithmetic, 8 direct 8-byte stores
+#define CARE_LAT_DBG 0  // ablation builds (tools/variant_lib.py): 1 no ct stores, 2 no qt loads, 4 no arithmetic, 8 direct 8-byte stores
 #endif
 
 // Cache policy of the streams (ablation: -DCARE_LAT_LD_AUX=0 -DCARE_LAT_ST_NT=0).  The clips' memory, q~ and c~ are

@@ -772,6 +772,7 @@ int launch_ln2(const LnArgs& p, hipStream_t st) {
 //   * one barrier per K step for all 12 waves (B_g: the reads of stage g are done, stage g + 1 has landed) and the two
 //     of the statistics exchange per block, which the loaders join.
 constexpr int WS_NSW = 3, WS_NSA = 2;
+constexpr int LN3_MIN_BLOCKS = 8;  // version 3 from this many whole 128-row blocks (tools/emb_bench.py --sweep: ahead of version 2 from 28 blocks down, K = 2048: 55 against 92 us)
 constexpr int WS_W_BYTES = LN_N * 64;                         // a K step of the packed weight
 constexpr int WS_A_BYTES = 128 * 128;                         // a macro stage (2 K steps): 128 rows x 64 K x 2 B
 constexpr int WS_A_BASE = WS_NSW * WS_W_BYTES;
@@ -1413,8 +1414,9 @@ static int gemm_ln_impl(const void* A, int64_t lda, int a_dtype, const void* W, 
   // version 3 (loader waves, persistent workgroups): raw fp32 features, no residual, at least a workgroup per CU's worth of
   // 128-row blocks.  A row's arithmetic is version 2's: the launch rule does not change a result.
   const char* v3e = getenv("CARE_LN_V3");  // A/B switch (read per call: the tests compare the two forms in one process)
-  const bool v3_ok = (!v3e || atoi(v3e)) && v2 && a_dtype == CARE_F32 && !res && K % 128 == 0 && M % 128 == 0 && M >= 128 * 192 &&
-                     lda * 4 * 128 < (1ll << 32);
+  const char* v3m = getenv("CARE_LN_V3_MIN");  // tuning: the fewest 128-row blocks version 3 takes
+  const bool v3_ok = (!v3e || atoi(v3e)) && v2 && a_dtype == CARE_F32 && !res && K % 128 == 0 && M % 128 == 0 &&
+                     M >= 128 * (v3m ? atoi(v3m) : LN3_MIN_BLOCKS) && lda * 4 * 128 < (1ll << 32);
   if (v3_ok && w_packed == 1) return launch_ln3(p, st);
   if (w_packed == 2) {  // split products (care_pack_ln_weight_split): fp32 A, no residual
     if (a_dtype != CARE_F32 || res) return CARE_ESHAPE;

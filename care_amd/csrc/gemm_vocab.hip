@@ -3,7 +3,7 @@
 //     log_softmax + top-1: Translator.py:127, Beam.py:58-70), the [M, V] logits never stored.
 //
 // Why a second kernel beside gemm_as.hip's STREAM_ARGMAX mode.  Ablation of that kernel at M = 32768
-// (tools/as_ablate.sh, round 2): 381 us in all; with the MFMAs, the statistics AND the B-fragment reads
+// (tools/variant_lib.py, round 2): 381 us in all; with the MFMAs, the statistics AND the B-fragment reads
 // removed it still takes 177 us - the time to stream W from L2 into LDS: every 128-row panel sweeps
 // the whole 10.8 MB, 2.76 GB per launch at the ~16 TB/s the L2 -> LDS path gives (65 GB/s per CU),
 // i.e. 128 flop per streamed byte caps the kernel at 2 PFLOP/s before any arithmetic happens.  MFMA

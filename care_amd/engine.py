@@ -389,6 +389,10 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
     # clips (1280 rows) 284 / 272, 512 357 / 315, 1024 528 / 496, 2048 (10240 rows) 732 / 700; at 20480 rows the pass does
     # not move and at 32768 the A-stationary kernels win in situ
     MID_TILE_ROWS = (1280, 16384)
+    # small batches (the resident decodes): frame rows from which the embedder runs as the fused loader-wave kernel instead
+    # of GEMM + LayerNorm launches side by side (*measured* whole pass, fused / unfused: 64 clips 1.709 / 1.652 ms, 128 clips 1.809 /
+    # 1.803, 256 clips 2.637 / 2.689: from 192 clips; CARE_FUSED_SMALL_MIN_ROWS overrides)
+    FUSED_SMALL_MIN_ROWS = int(os.environ.get("CARE_FUSED_SMALL_MIN_ROWS", "5376"))
 
     def gemm(self, A, W, bias, out, act=0, out2=None, n_split=None, tag=None, tile=False):
         """out = act(A @ W^T + bias).  bf16 weights + bf16 A -> A-stationary kernel (csrc/gemm_as.hip) for

@@ -85,7 +85,9 @@ class EncodeMixin:
                 fused = (opt["encoder"] == "Embedder" and self.as_ok and d == 512 and
                          (w["enc_w_" + ch].dtype == self.h16 or Ws is not None) and x2.shape[1] % 32 == 0)
                 if small and fused and (Ws is None or w.get("enc_w_" + ch + "#split3") is not None):
-                    fused = False  # (concept models: the split products through the LDS-tiled kernel, below)
+                    # (concept models: the split products through the LDS-tiled kernel, below) - unless the loader-wave
+                    # kernel takes the rows (version 3 of csrc/gemm_ln.hip: whole 128-row blocks, FUSED_SMALL_MIN_ROWS of them)
+                    fused = (B * n) % 128 == 0 and B * n >= self.FUSED_SMALL_MIN_ROWS and x2.shape[1] % 128 == 0
                 W3 = w.get("enc_w_" + ch + "#split3")
                 if fused:
                     lin = None

@@ -41,6 +41,15 @@ def split_main(B, Ks):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--split":
         return split_main(int(sys.argv[2]) if len(sys.argv) > 2 else 16384, [int(a) for a in sys.argv[3:]] or [2048, 512, 128])
+    if len(sys.argv) > 1 and sys.argv[1] == "--sweep":  # version 3 (forced from one block) against version 2 by row count
+        os.environ["EMB_CHECK"] = "0"
+        for B in (128, 256, 512, 768, 1024, 1536, 2048, 4096):
+            for v3 in ("0", "1"):
+                os.environ["CARE_LN_V3"], os.environ["CARE_LN_V3_MIN"] = v3, "1"
+                sys.argv = [sys.argv[0], str(B), "2048", "512", "128"]
+                print("version", 3 if v3 == "1" else 2, end="  ")
+                main()
+        return
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
     Ks = [int(a) for a in sys.argv[2:]] or [2048, 512, 128]
     M = B * 28
