@@ -540,6 +540,56 @@ def test_gemm_ln_split_loader_waves(M, K, out32, variant, monkeypatch):
         assert (outs[0][0][:, 28:28 + grp].reshape(M, d)[rows].double() - ref).abs().max().item() < 2e-5 * math.sqrt(K / 64)
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_gemm_ln_loader_waves_random_shapes(split, monkeypatch):
+    """Seeded sweep over block counts (one, two, three blocks per workgroup and uneven shares), K, frame groups, output
+    offsets and the optional fp32 output: version 3 (both forms) against version 2, bit for bit, untouched rows left at zero."""
+    from care_amd import _lib
+
+    rng = np.random.RandomState(1234 + int(split))
+    d = 512
+    for trial in range(14):
+        blocks = int(rng.choice([8, 9, 31, 64, 255, 256, 257, 300, 511, 513, 600, 777]))
+        K = int(rng.choice([128, 256, 384, 512, 1024, 2048] if blocks < 400 else [128, 256, 384]))
+        M = 128 * blocks
+        grp = int(rng.choice([g for g in (M, 16, 32, 64, 28) if M % g == 0]))
+        pad, off = int(rng.randint(0, 40)), 0
+        off = int(rng.randint(0, pad + 1))
+        out32 = bool(rng.randint(0, 2))
+        A = _rand(M, K, seed=200 + trial)
+        W = _rand(d, K, seed=300 + trial, scale=1 / math.sqrt(K))
+        bias, g, b = _rand(d, seed=400 + trial), _rand(d, seed=500 + trial), _rand(d, seed=600 + trial)
+        ngrp = M // grp
+        if split:
+            Wx = torch.empty(d, 3 * K, device=DEV, dtype=torch.float16)
+            _lib.call("care_pack_ln_weight_split", _p(W), _p(Wx), d, K)
+        else:
+            Wb = W.to(torch.bfloat16).contiguous()
+            Wx = torch.empty_like(Wb)
+            _lib.call("care_pack_ln_weight", _p(Wb), _p(Wx), d, K)
+        outs = []
+        for v3 in ("1", "0"):
+            monkeypatch.setenv("CARE_LN_V3", v3)
+            out = torch.zeros(ngrp, grp + pad, d, device=DEV) if out32 else None
+            outb = torch.zeros(ngrp, grp + pad, d, device=DEV, dtype=torch.bfloat16)
+            if split:
+                _lib.call("care_gemm_ln_split", _p(A), K, _p(Wx), _p(bias), _p(g), _p(b), 1e-12, _p(out), _p(outb), d, M, d, K, grp, grp + pad, off)
+            else:
+                _lib.call("care_gemm_ln_packed", _p(A), K, 0, _p(Wx), _p(bias), None, d, _p(g), _p(b), 1e-12, _p(out), _p(outb), d, M, d, K, grp,
+                          grp + pad, off)
+            outs.append((out, outb))
+        torch.cuda.synchronize()
+        what = (trial, blocks, K, grp, pad, off, out32)
+        assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16)), what
+        assert outs[0][1].abs().max().item() > 0.1, what
+        if out32:
+            assert torch.equal(outs[0][0], outs[1][0]), what
+        if pad:
+            assert outs[0][1][:, :off].abs().max().item() == 0 if off else True, what
+            assert outs[0][1][:, off + grp:].abs().max().item() == 0 if off < pad else True, what
+        del A, outs
+
+
 @pytest.mark.parametrize("M,N,K", [(70, 1024, 64), (28 * 41, 1024, 2048), (4500, 768, 512), (28 * 1200, 1024, 128)])
 def test_gemm_split3_products(M, N, K):
     """care_gemm_split3: the generic GEMM with fp32 operands as fp16 hi/lo pieces (one product over 3K) - against the
