@@ -36,6 +36,17 @@
 // (8192^3 1226 against 1310 TFLOP/s, 118784 x 2048 x 512 732 against 845): this tile is not bound by its streams (37 GB/s
 // per CU against the 57 the embedder's streams reach) but by two 128-accumulator waves per SIMD with 168 registers, which
 // cannot double-buffer their fragments - the sixteen 64-accumulator waves hide the LDS latency by occupancy.  Not kept.
+// In-kernel stamps of this kernel (tools/tile_ts.py, 16384 x 4096 x 4096): 3700 ticks per K step against 2048 of MFMA for the four
+// waves of a SIMD - every wave waits ~450 ticks for its own stage to land (one stage of prefetch: the stage issued behind a
+// barrier is awaited before the next), the first wave ~1700 at the barrier for the last, whose four DMA pieces took 1200 to
+// issue behind the other fifteen's.  Weaving the pieces into the step's MFMAs (one behind every eight) took 6 % fewer ticks
+// per step and 3 - 10 % MORE time on every shape (8192^3 1232 against 1365 TFLOP/s): not kept either.  Nor was the tile with
+// the operand streams on opposite halves of the workgroup and in opposite phase (waves 8 - 15 issue W stage kt + 1 behind the
+// barrier and then multiply; waves 0 - 7 multiply first and issue A stage kt + 2 afterwards, into a ring of three A stages +
+// two W stages = 160 KB): bit-identical, within +- 4 % on every shape (8192^3 1368 against 1380) - its stamps show the A
+// waves now idle 1750 ticks at the barrier for the W waves, whose blocked issue (~1000 ticks for 32 KB through the CU's
+// in-order memory path) + MFMAs + the 450-tick landing wait of a one-stage-ahead W ring are the period again.  The 64 KB a
+// 256 x 256 x 64 step fetches need 1300 - 2000 ticks of that path against 2048 of MFMA, and 160 KB of LDS hold no third stage.
 #include <cstdlib>
 
 #include "care_common.h"
@@ -280,6 +291,16 @@ __device__ __forceinline__ void tile_epilogue(const TArgs& p, f32x4 (&acc)[MT][4
 // twice the stages in the same LDS, i.e. more K steps of prefetch for the same bytes in use).  Swizzle of a 64-byte
 // row's four 16-byte chunks: chunk ^= G[(row >> 2) & 3], G = {0, 3, 2, 1} - the 16 lanes of every ds_read_b128 lane
 // group ({0-3, 12-15, 20-27}, ...) then fall on 16 different 16-byte slots of the 256-byte bank row.
+#ifndef CARE_TILE_DBG
+#define CARE_TILE_DBG 0  // tools (tools/variant_lib.py, tools/tile_ts.py): 64 - workgroup 0 stamps s_memtime per wave and K step
+#endif
+#if CARE_TILE_DBG & 64
+__device__ unsigned long long tile_stamps[16 * 64 * 4];
+#define TILE_STAMP(kt, k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (kt) < 64 && lane == 0 && wave < 16) tile_stamps[(wave * 64 + (kt)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TILE_STAMP(kt, k) do { } while (0)
+#endif
+
 template <int WGM, int WGN, int WTM, int STAGES, int EPI, bool F16 = false, int BK = 64, bool GELU = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
   constexpr int NW = WGM * WGN, BM = 64 * WTM * WGM, BN = 64 * WGN;
@@ -359,12 +380,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_sched_barrier(0);  // the MFMAs of step kt - 1 (and the waits on their fragments) stay above the barrier
     // step kt has landed when at most the STAGES - 2 younger steps of this wave are outstanding
+    TILE_STAMP(kt, 0);
     if (kt + STAGES - 2 < nk) t_wait_vm<(STAGES - 2) * P>();
     else t_wait_vm<0>();
+    TILE_STAMP(kt, 1);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    TILE_STAMP(kt, 2);
     if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
     __builtin_amdgcn_sched_barrier(0);
+    TILE_STAMP(kt, 3);
     const unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
@@ -388,7 +413,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tile_kernel(TArgs p) {
     }
   }
 
+  TILE_STAMP(nk, 0);
   tile_epilogue<EPI, MT, GELU>(p, acc, m0 + wm * 64 * WTM, n0 + wn * 64 + fg * 16, fr, fg);
+  TILE_STAMP(nk, 1);
 }
 
 int tile_group(int tiles_m) {
@@ -604,3 +631,7 @@ extern "C" int care_gemm_tile_argmax(const void* A, int64_t lda, const void* W, 
   p.labels = labels; p.plab = plab;
   return labels ? dispatch<EPI_ARGMAX_LAB>(p, (hipStream_t)stream) : dispatch<EPI_ARGMAX>(p, (hipStream_t)stream);
 }
+
+#if CARE_TILE_DBG & 64
+extern "C" int care_tile_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tile_stamps), sizeof(tile_stamps)); }
+#endif
