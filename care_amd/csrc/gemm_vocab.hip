@@ -19,6 +19,11 @@
 //     for "new maximum?" (the column search sits in a rarely taken branch), sub / exp / add per logit;
 //   * the statistics of tile t are woven between the MFMAs of tile t + 1 (order pinned per k-step);
 //   * the last tile of a range is simply fetched again past the end (constant vmcnt arithmetic).
+// In-kernel stamps (round 5, tools/v32_ts.py, 32768 rows): a tile takes ~3700 cycles of a SIMD for the 2048 of its two waves'
+// MFMAs.  A wave's 32 MFMAs take ~1740, not 1024: its partner's ~520 cycles of statistics issue ADD to them even though
+// they come from the other wave (one vector issue port per SIMD), then the roles swap - 2 x (1024 + ~520 + LDS reads) +
+// ~650 of barrier and landing waits per tile = the 0.46 of peak this kernel has run at since round 2; the matrix pipe is
+// never short of work, the SIMD's issue port is.
 // Used by care_gemm_argmax_bf16 for bf16 A, K = 512, M >= 8192 without label logits; everything else
 // (and the beam-search / scoring variants) stays on gemm_as.hip.
 #include <cstdlib>
@@ -58,6 +63,13 @@ constexpr int V_LCAP = (V_STAGE - 8) / 8;
 #endif
 #ifndef CARE_V32_DBG
 #define CARE_V32_DBG 0  // ablation: 2 no MFMA, 16 no statistics, 32 no fragment reads
+#endif
+
+#if CARE_V32_DBG & 64  // tools (tools/variant_lib.py, tools/v32_ts.py): workgroup 0 stamps s_memtime per wave and tile
+__device__ unsigned long long v32_stamps[8 * 64 * 4];
+#define V32_STAMP(it, k) do { if (blockIdx.x == 0 && (it) < 64 && lane == 0) v32_stamps[(wave * 64 + (it)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define V32_STAMP(it, k) do { } while (0)
 #endif
 
 template <int BDEPTH, int MODE>
@@ -213,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
       const int it = t - t0;
       // tile t has landed; the two younger tiles (4 DMA instructions each) stay in flight.  Iteration 0
       // drains everything: the A fragments were issued behind the prologue DMAs.
+      V32_STAMP(it, 0);
       if constexpr (!decltype(with_stats)::value) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else if (COLLECT || !p.tile_max) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       else {  // + the tile_max stores issued since this tile's DMA went out (iterations it - 3 .. it - 1 that had statistics)
@@ -223,8 +236,10 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
           default: asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory"); break;
         }
       }
+      V32_STAMP(it, 1);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      V32_STAMP(it, 2);
       stage(t + V_AHEAD, (it + V_AHEAD) % V_RING);  // the slot every wave finished reading last iteration
       __builtin_amdgcn_sched_barrier(0);
 
@@ -264,6 +279,7 @@ __global__ __launch_bounds__(512, 2) void vocab_argmax32_kernel(VArgs p) {
         else acc = care_mfma_32x32x16_h16(b, a[ks], acc, 0, 0, 0);  // D[n][m]: lane = row m, 16 columns n
         __builtin_amdgcn_sched_barrier(0);
       }
+      V32_STAMP(it, 3);
       if constexpr (STATS) {
         if (!stats_first) stats_prev();
       }
@@ -377,3 +393,7 @@ extern "C" int care_vocab32_ranges(int M, int N, int min_parts) {
   }
   return best;
 }
+
+#if CARE_V32_DBG & 64
+extern "C" int care_v32_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(v32_stamps), sizeof(v32_stamps)); }
+#endif
