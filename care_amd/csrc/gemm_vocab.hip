@@ -23,7 +23,8 @@
 // MFMAs.  A wave's 32 MFMAs take ~1740, not 1024: its partner's ~520 cycles of statistics issue ADD to them even though
 // they come from the other wave (one vector issue port per SIMD), then the roles swap - 2 x (1024 + ~520 + LDS reads) +
 // ~650 of barrier and landing waits per tile = the 0.46 of peak this kernel has run at since round 2; the matrix pipe is
-// never short of work, the SIMD's issue port is.
+// never short of work, the SIMD's issue port is.  (The sum of exponentials as two partial sums with v_pk_fma_f32 / v_pk_add_f32 -
+// 16 vector instructions fewer per tile and wave: 350 against 323 us at 32768 rows on the same box.  Not kept.)
 // Used by care_gemm_argmax_bf16 for bf16 A, K = 512, M >= 8192 without label logits; everything else
 // (and the beam-search / scoring variants) stays on gemm_as.hip.
 #include <cstdlib>
