@@ -15,6 +15,11 @@
 //     t + 1; its stores are counted in the vmcnt arithmetic of the ring.
 // Two destinations like care_gemm_bf16 (columns < n_split -> C0, the rest -> C1; each fp32 or bf16,
 // own leading dimension): the QKV projection writes q and, straight into the cache, k | v.
+// In-kernel stamps (round 5, tools/s32_ts.py, 32768 x 2048 x 512): ~4200 cycles per tile for the 2048 of a SIMD's two
+// waves' MFMAs - both waves multiply at once, each with ~100 vector instructions of epilogue woven in, and a phase takes
+// 2650 - 3350 (the second-dispatched half of the workgroup is the slower one); ~330 of landing wait and up to ~900 at the
+// barrier follow.  The activation as a template parameter (a run-time test was a v_max + v_cndmask pair per output) is
+// worth ~1 %: the vector work is not what the phase waits for.
 #include <cstdlib>
 #include <type_traits>
 
@@ -39,7 +44,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CARE_S32_QUAD 1  // fp32 tiles: transpose the pieces inside lane quads before storing (0: one row per lane)
 #endif
 #ifndef CARE_S32_DBG
-#define CARE_S32_DBG 0  // ablation builds: 1 no stores, 2 no bias reads, 4 no activation / conversion either
+#define CARE_S32_DBG 0  // ablation builds: 1 no stores, 2 no bias reads, 4 no activation / conversion either, 8 lane-linear stores, 64 stamps
 #endif
 
 struct SArgs {
@@ -55,7 +60,14 @@ __device__ __forceinline__ float s_gelu(float v) { return 0.5f * v * (1.0f + erf
 
 // GELU is a template parameter: erff inlined behind a run-time test in every epilogue piece made the kernel 6872
 // instructions (55 KB) against 2658 without it - the relu / plain launches of the headline pass carried it along.
-template <int BDEPTH, bool GELU>
+#if CARE_S32_DBG & 64  // tools (tools/variant_lib.py, tools/s32_ts.py): workgroup 0 stamps s_memtime per wave and tile
+__device__ unsigned long long s32_stamps[8 * 64 * 4];
+#define S32_STAMP(it, k) do { if (blockIdx.x == 0 && (it) < 64 && lane == 0) s32_stamps[(wave * 64 + (it)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S32_STAMP(it, k) do { } while (0)
+#endif
+
+template <int BDEPTH, int ACT>  // ACT: CARE_ACT_NONE / RELU / GELU (a run-time test per value was a v_max + v_cndmask pair on every output)
 __global__ __launch_bounds__(512, 2) void gemm_store32_kernel(SArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -138,8 +150,8 @@ __global__ __launch_bounds__(512, 2) void gemm_store32_kernel(SArgs p) {
       v[4 * g + 2] = ap[4 * g + 2] + bv.z; v[4 * g + 3] = ap[4 * g + 3] + bv.w;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if constexpr (GELU) v[4 * g + j] = s_gelu(v[4 * g + j]);
-        else if (p.act == CARE_ACT_RELU) v[4 * g + j] = fmaxf(v[4 * g + j], 0.0f);
+        if constexpr (ACT == CARE_ACT_GELU) v[4 * g + j] = s_gelu(v[4 * g + j]);
+        else if constexpr (ACT == CARE_ACT_RELU) v[4 * g + j] = fmaxf(v[4 * g + j], 0.0f);
       }
     };
     auto out_store = [&](int tile, const float (&v)[16]) -> int {
@@ -244,10 +256,13 @@ __global__ __launch_bounds__(512, 2) void gemm_store32_kernel(SArgs p) {
     auto tile_body = [&](int t, auto with_prev, f32x16& ac, f32x16& ap) {
       constexpr bool PREV = decltype(with_prev)::value;
       const int it = t - t0;
+      S32_STAMP(it, 0);
       if constexpr (!PREV) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // also the A fragments and the bias slice
       else wait_tile();
+      S32_STAMP(it, 1);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      S32_STAMP(it, 2);
       stage(t + S_AHEAD, (it + S_AHEAD) % S_RING);
       __builtin_amdgcn_sched_barrier(0);
 
@@ -268,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void gemm_store32_kernel(SArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      S32_STAMP(it, 3);
       if constexpr (!PREV) { st_hist2 = st_hist1; st_hist1 = st_hist0; st_hist0 = 0; }
     };
     tile_body(t0, std::false_type{}, accA, accB);
@@ -319,14 +335,20 @@ extern "C" int care_store32_launch(const void* A, int64_t lda, const void* W, co
   const int e0 = c0_bf16 ? 8 : 4, e1 = c1_bf16 ? 8 : 4;
   if ((ldc0 % e0) || !care_aligned16(C0) || (n_split < N && ((ldc1 % e1) || !care_aligned16(C1)))) return CARE_EALIGN;
   const int blocks = p.total_items < 256 ? p.total_items : 256;
-  if (act == CARE_ACT_GELU) {
+  auto go = [&](auto actc) -> int {
+    constexpr int A = decltype(actc)::value;
     static std::atomic<unsigned long long> lds_ok{0};
-    if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_store32_kernel<4, true>), S_LDS, lds_ok)) return e;
-    hipLaunchKernelGGL((gemm_store32_kernel<4, true>), dim3(blocks), dim3(512), S_LDS, (hipStream_t)stream, p);
-  } else {
-    static std::atomic<unsigned long long> lds_ok{0};
-    if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_store32_kernel<4, false>), S_LDS, lds_ok)) return e;
-    hipLaunchKernelGGL((gemm_store32_kernel<4, false>), dim3(blocks), dim3(512), S_LDS, (hipStream_t)stream, p);
-  }
+    if (const int e = care_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_store32_kernel<4, A>), S_LDS, lds_ok)) return e;
+    hipLaunchKernelGGL((gemm_store32_kernel<4, A>), dim3(blocks), dim3(512), S_LDS, (hipStream_t)stream, p);
+    return 0;
+  };
+  if (const int e = act == CARE_ACT_GELU ? go(std::integral_constant<int, CARE_ACT_GELU>{})
+                  : act == CARE_ACT_RELU ? go(std::integral_constant<int, CARE_ACT_RELU>{})
+                                         : go(std::integral_constant<int, CARE_ACT_NONE>{}))
+    return e;
   return care_launch_status();
 }
+
+#if CARE_S32_DBG & 64
+extern "C" int care_s32_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s32_stamps), sizeof(s32_stamps)); }
+#endif
