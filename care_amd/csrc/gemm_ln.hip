@@ -1394,6 +1394,23 @@ static int gemm_ln_impl(const void* A, int64_t lda, int a_dtype, const void* W, 
       (res && (ldres % 4)) || (out && !care_aligned16(out)) || (out_bf16 && !care_aligned16(out_bf16)) ||
       (bias && !care_aligned16(bias)))
     return CARE_EALIGN;
+  // A ragged row count in the embedder's form (2990 test clips x 28 frames): the whole multiples of lcm(128, grp) rows go to
+  // version 3 (whole 128-row blocks, whole output groups), the remainder to version 2 - row for row the same bits.
+  if (w_packed && a_dtype == CARE_F32 && !res && !pos && K % 128 == 0 && M % 128 != 0 && grp <= 4096) {
+    const bool ungrouped = grp >= M;  // one group: output row = out_row_off + row
+    int64_t unit = ungrouped ? 128 : grp;
+    while (unit % 128) unit += grp;   // lcm(128, grp): 896 rows for 28 frames
+    const int64_t head = (M / unit) * unit;
+    if (head >= 128 * LN3_MIN_BLOCKS && head < M) {
+      const int64_t adv = (ungrouped ? head : (head / grp) * out_grp_rows) * ldo;  // output elements the head covers
+      int rc = gemm_ln_impl(A, lda, a_dtype, W, w_packed, bias, res, ldres, pos, gamma, beta, eps, out, out_bf16, ldo, (int)head, N, K,
+                            ungrouped ? (int)head : grp, out_grp_rows, out_row_off, stream);
+      if (rc) return rc;
+      return gemm_ln_impl(reinterpret_cast<const float*>(A) + head * lda, lda, a_dtype, W, w_packed, bias, res, ldres, pos, gamma, beta, eps,
+                          out ? out + adv : nullptr, out_bf16 ? reinterpret_cast<bf16_t*>(out_bf16) + adv : nullptr, ldo, (int)(M - head), N, K,
+                          ungrouped ? (int)(M - head) : grp, out_grp_rows, out_row_off, stream);
+    }
+  }
   LnArgs p{};
   p.A = A; p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.bias = bias; p.res = res; p.ldres = ldres;
   p.pos = pos; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out = out; p.outb = reinterpret_cast<bf16_t*>(out_bf16);

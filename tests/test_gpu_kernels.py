@@ -465,7 +465,9 @@ def test_gemm_ln_fused(a_f32, M, K, form, monkeypatch):
 @pytest.mark.parametrize("variant", ["", "f16"])
 @pytest.mark.parametrize("out32", [False, True])
 @pytest.mark.parametrize("M,K", [(128 * 8, 2048), (128 * 21, 512), (128 * 192, 128), (28 * 1024, 512), (28 * 1024, 2048), (128 * 300, 128),
-                                 (128 * 300, 512), (128 * 513, 128), (128 * 777, 256)])
+                                 (128 * 300, 512), (128 * 513, 128), (128 * 777, 256),
+                                 # ragged row counts: whole multiples of lcm(128, frames) rows on version 3, the rest on version 2
+                                 (28 * 2990, 512), (28 * 333, 128), (128 * 40 + 77, 256)])
 def test_gemm_ln_loader_waves(M, K, out32, variant):
     """The embedder's form at batch sizes (raw fp32 features, no residual, packed weight, whole 128-row blocks, >= 192 of
     them): version 3 of the fused kernel - loader waves, persistent workgroups, csrc/gemm_ln.hip - against the plain-weight
@@ -507,7 +509,7 @@ def test_gemm_ln_loader_waves(M, K, out32, variant):
 @pytest.mark.parametrize("variant", ["", "f16"])
 @pytest.mark.parametrize("out32", [False, True])
 @pytest.mark.parametrize("M,K", [(128 * 8, 2048), (128 * 21, 512), (128 * 192, 128), (28 * 1024, 512), (28 * 1024, 2048), (128 * 300, 128),
-                                 (128 * 513, 256)])
+                                 (128 * 513, 256), (28 * 2990, 512), (128 * 40 + 77, 128)])
 def test_gemm_ln_split_loader_waves(M, K, out32, variant, monkeypatch):
     """The concept models' embedder (care_gemm_ln_split on whole 128-row blocks, >= 8 of them): version 3 -
     the hi / lo pieces of the features made once by the loader waves, two of the three weight images fetched - against
