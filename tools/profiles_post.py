@@ -202,11 +202,23 @@ def readings():
     if os.path.exists(path):
         L += ["", "`{}_chain_phase_counters.txt`: SQ counters per phase of the beam step at 640 rows (VALU / MFMA / LDS / VMEM instruction "
               "counts, wave cycles, waits, LDS bank conflicts) - the resident launch is ONE kernel, the chain gives its phases one each.".format(ROUND)]
-    for name in ("resident_phase_clocks.txt", "beam_sweep.txt", "greedy_sweep.txt"):
+    for name in ("resident_phase_clocks.txt", "beam_sweep.txt", "greedy_sweep.txt", "embedder_ablation.txt", "embedder_streams.txt",
+                 "embedder_timeline.txt", "mfma_kernel_timelines.txt"):
         if os.path.exists(os.path.join(DST, "{}_{}".format(ROUND, name))):
             what = {"resident_phase_clocks.txt": "device clock at every phase boundary of decoder step 3, workgroup 0 (tools/resident_prof.py)",
                     "beam_sweep.txt": "beam 5 by batch: resident launch / chained step / multi-launch search, whole passes (tools/beam_sweep.py)",
-                    "greedy_sweep.txt": "greedy by batch, d_model 512 and 1024, whole passes (tools/greedy_sweep.py)"}[name]
+                    "greedy_sweep.txt": "greedy by batch, d_model 512 and 1024, whole passes (tools/greedy_sweep.py)",
+                    "embedder_ablation.txt": "not rocprofv3: `tools/emb_bench.py` on the shipped library and on libraries with ONE translation unit "
+                                             "rebuilt with a switch (`tools/variant_lib.py gemm_ln.hip ... -DCARE_LN3_DBG=n` / `-DCARE_LN_DBG=n`) - the "
+                                             "loader-wave embedder (version 3) and version 2 at 32768 clips, whole and without MFMAs / DMA streams / "
+                                             "fragment reads / epilogue / stores; the concept models' split form, both versions, bit-identity checked",
+                    "embedder_streams.txt": "`tools/micro/emb_stream`: the K = 2048 launch's two operand streams alone, by piece shape, depth, cache "
+                                            "policy, LDS-DMA or registers, with and without a barrier per K step",
+                    "embedder_timeline.txt": "`tools/emb_ts.py` (`-DCARE_LN3_DBG=64`): `s_memtime` stamps per K step of workgroup 0 - a compute wave, a "
+                                             "weight-loader wave, a feature-loader wave",
+                    "mfma_kernel_timelines.txt": "the same kind of stamps for the LDS-tiled GEMM (`tools/tile_ts.py`, two shapes), the vocabulary arg-max "
+                                                 "(`tools/v32_ts.py`), the 256-row store GEMM (`tools/s32_ts.py`), and `tools/micro/mfma_chain` (issue "
+                                                 "interval of dependent MFMAs); DESIGN.md 5.4 and 11 read these four files"}[name]
             L += ["", "`{}_{}`: {}".format(ROUND, name, what)]
     return "\n".join(L) + "\n"
 
