@@ -264,8 +264,7 @@ def extra_legs(dev, main_dtype, legs):
     # ---- batch sweep (B in {1, 64, 128, 256, 1024, 4096}; translate.py:136 lets a user pick any
     # batch): greedy d = 512 and beam 5 across the hand-overs between the forms of the decode - the resident launch (greedy
     # <= engine.resident_max_rows clips, beam <= engine.resident_beam_max_rows rows), the multi-launch small forms, the
-    # large-batch forms.  captions/s must grow with B through every hand-over (tests/test_gpu_properties.py asserts it on
-    # the GPU box); engine.py's crossover constants cite this table (profiles/r05_batch_sweep.json).
+    # large-batch forms.  captions/s must grow with B through every hand-over (`shape` below says whether it did); engine.py's crossover constants cite this table (profiles/r05_batch_sweep.json).
     sweep = {"greedy": {}, "beam5": {}}
     opt, eng = build("msrvtt_base_ami", main_dtype)
     for B in (1, 64, 128, 256, 512, 1024, 2048, 4096):
@@ -286,7 +285,16 @@ def extra_legs(dev, main_dtype, legs):
         sweep["beam5"][str(B)] = dict(captions_per_s=round(B / dt, 1), decoder_step_us=round(dt * 1e6 / eng.T, 2), rows=5 * B,
                                       form="resident" if eng.last_decode.get("resident") else
                                       "chain" if eng.last_decode.get("chain") else "multi-launch")
-    legs["batch_sweep"] = dict(config_greedy="msrvtt_base_ami", config_beam5="msrvtt_care_beam5", dtype=main_dtype, **sweep)
+    # the sweep's own check (a wall-clock property: it lives here, not in the parity suite): captions/s grows through every
+    # hand-over between forms, and no point sits more than 15 % below the line through its neighbours
+    shape = {}
+    for kind, pts in sweep.items():
+        pts = [(int(b), v["captions_per_s"]) for b, v in pts.items()]
+        grow = min(r1 / r0 for (_, r0), (_, r1) in zip(pts, pts[1:]))
+        dip = min(r1 / (r0 + (r2 - r0) * (b1 - b0) / (b2 - b0)) for (b0, r0), (b1, r1), (b2, r2) in zip(pts, pts[1:], pts[2:]))
+        shape[kind] = dict(min_ratio_to_previous_point=round(grow, 3), min_ratio_to_neighbours_line=round(dip, 3),
+                           monotone=bool(grow > 0.97), no_cliff=bool(dip > 0.85))
+    legs["batch_sweep"] = dict(config_greedy="msrvtt_base_ami", config_beam5="msrvtt_care_beam5", dtype=main_dtype, shape=shape, **sweep)
     # BASELINE configs[3] with translate.py's default decode: d_model 1024, beam 5, the 32 clips per GPU of a 256-clip batch
     # over 8 GPUs (160 rows) - one resident launch since round 5 (csrc/decode_resident_beam.hip, D = 1024)
     opt, eng = build("vatex_care_large", main_dtype)
@@ -452,6 +460,83 @@ def extra_legs(dev, main_dtype, legs):
                 bound="PCIe H2D" if nbytes / dt / 1e9 > 35 and dt > 1.1 * dtr else "decode",
                 sample="%d batches from 2 pinned host buffers, double-buffered device slots" % nb)
             del host, res
+
+    # ---- the drop-in API itself: what translate.py calls is get_translator(opt).translate_batch
+    # (models/Translator.py:35-85 via Wrapper.py:175), which returns python lists - every leg above times the engine call
+    # underneath it.  Per operating point: the engine pass (device tensors out), translate_batch call by call and
+    # translate_batches (batch k's lists assembled while batch k + 1 decodes) on features resident in HBM, and both again
+    # fed from pinned host batches the way translate.py's loop is (FeaturePrefetcher: H2D on a side stream), with the split
+    # of one batch's time.  `api_over_engine` = pipelined API on resident features / engine pass: the price of the boundary.
+    from care_amd import get_translator
+
+    def api_leg(config, B, beam, nb, iters):
+        opt, eng = build(config, main_dtype, beam_size=beam, topk=1)
+        model = eng_model[0]
+        tr = get_translator(opt)
+        feats = feats_for(opt, B)
+        if beam == 1:
+            eng_run = lambda: eng.translate_greedy(feats, use_graph=True, lean=True)
+        else:
+            eng_run = lambda: eng.translate_beam(feats, beam, beam, use_graph=True, lean=True)
+        for _ in range(3):
+            eng_run()
+        dt_eng = _timed(eng_run, iters)
+        batch = {"feats": feats}
+        one = lambda: tr.translate_batch([model], batch)
+        for _ in range(3):
+            hyps, scores = one()
+        dt_one = _timed(one, iters)
+        piped = lambda: sum(len(h) for h, _ in tr.translate_batches([model], (batch for _ in range(nb))))
+        piped()
+        dt_pipe = _timed(piped, max(1, iters // nb)) / nb
+        # the split of one call: enqueue (python + graph launch), device pass, copy back + list assembly
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pend = tr._launch([model], batch, {})
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        tr._finish(pend)
+        t3 = time.perf_counter()
+        # host-fed: pinned batches, H2D through the prefetcher (three device slots: a batch's features stay in place
+        # until its results are out), serial calls and the pipelined entry
+        host = [t.cpu().pin_memory() for t in feats]
+        nbytes = sum(t.numel() * t.element_size() for t in host)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dst = [torch.empty_like(t) for t in feats]
+        e0.record()
+        for d_, h_ in zip(dst, host):
+            d_.copy_(h_, non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize()
+        h2d_ms = e0.elapsed_time(e1)
+        del dst
+        fed_serial = lambda: [tr.translate_batch([model], {"feats": f}) for f in FeaturePrefetcher((host for _ in range(nb)), dev, depth=3)]
+        fed_piped = lambda: list(tr.translate_batches([model], ({"feats": f} for f in FeaturePrefetcher((host for _ in range(nb)), dev, depth=3))))
+        for fn in (fed_serial, fed_piped):
+            fn()
+            fn()
+        dt_fs = _timed(fed_serial, max(1, iters // nb)) / nb
+        dt_fp = _timed(fed_piped, max(1, iters // nb)) / nb
+        return dict(config=config, dtype=main_dtype, clips_per_batch=B, beam_size=beam, rows_per_decoder_step=B * beam,
+                    entry="get_translator(opt).translate_batch([model], {'feats': ...}) -> (batch_hyps, batch_scores) python lists "
+                          "(models/Translator.py:35-85); pipelined = translate_batches over %d batches" % nb,
+                    engine_captions_per_s=round(B / dt_eng, 1), engine_ms_per_pass=round(dt_eng * 1e3, 3),
+                    api_captions_per_s=round(B / dt_one, 1), api_ms_per_call=round(dt_one * 1e3, 3),
+                    api_pipelined_captions_per_s=round(B / dt_pipe, 1), api_pipelined_ms_per_batch=round(dt_pipe * 1e3, 3),
+                    api_over_engine=round(dt_eng / dt_pipe, 3), api_serial_over_engine=round(dt_eng / dt_one, 3),
+                    one_call_split_ms=dict(enqueue=round((t1 - t0) * 1e3, 3), device_wait=round((t2 - t1) * 1e3, 3),
+                                           d2h_and_list_assembly=round((t3 - t2) * 1e3, 3)),
+                    host_fed=dict(h2d_bytes_per_batch=nbytes, h2d_ms_alone=round(h2d_ms, 3),
+                                  serial_captions_per_s=round(B / dt_fs, 1), serial_ms_per_batch=round(dt_fs * 1e3, 3),
+                                  pipelined_captions_per_s=round(B / dt_fp, 1), pipelined_ms_per_batch=round(dt_fp * 1e3, 3),
+                                  pipelined_over_engine=round(dt_eng / dt_fp, 3),
+                                  bound="PCIe H2D" if h2d_ms > 1.05 * dt_eng * 1e3 else "decode"),
+                    caption_length=len(hyps[0][0]), resident_launch=bool(eng.last_decode.get("resident")))
+
+    legs["api_greedy_B128"] = api_leg("msrvtt_base_ami", 128, 1, 16, 32)
+    legs["api_beam5_B128"] = api_leg("msrvtt_care_beam5", 128, 5, 16, 32)    # translate.py's defaults (translate.py:137,144)
+    legs["api_greedy_B32768"] = api_leg("msrvtt_base_ami", 32768, 1, 4, 4)
 
     # the error of the throughput mode: teacher-forced hidden states, bf16 mode against fp32 mode of this
     # same engine (fp32 mode is within 1e-5 of the reference, tests/test_gpu_parity.py) on the benchmarked model

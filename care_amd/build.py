@@ -144,12 +144,35 @@ def _compile_link(out: str, variant: str, flags_extra, force: bool, verbose: boo
     todo.sort(key=lambda j: next((i for i, s in enumerate(slow) if s in os.path.basename(j[0])), len(slow)))
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
         list(pool.map(compile_one, todo))
-    tmp = out + ".tmp"
+    tmp = "{}.{}.tmp".format(out, os.getpid())   # (a name of this process' own: nobody else's link or replace touches it)
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    os.replace(tmp, out)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
+class _BuildLock:
+    """Exclusive advisory lock (fcntl.flock on .obj/build.lock) around a compile + link.  Under torchrun every rank imports
+    care_amd at once and sees the same stale hash: without the lock they would all run hipcc into the same objects and
+    replace each other's half-linked library.  With it ONE builds; the others block here, then find the library current
+    (the caller re-checks needs_build once it holds the lock) and load it."""
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(OBJ, exist_ok=True)
+        self.fh = open(os.path.join(OBJ, "build.lock"), "w")
+        fcntl.flock(self.fh, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.fh, fcntl.LOCK_UN)
+        self.fh.close()
 
 
 def build(force: bool = False, verbose: bool = True, jobs: int = 0, out: str = None, flags_extra=(), variant: str = "") -> str:
@@ -157,13 +180,18 @@ def build(force: bool = False, verbose: bool = True, jobs: int = 0, out: str = N
     (ablation switches, e.g. -DRES_NOINLINE) into a library of its own - objects keyed by the flags, the default
     library untouched."""
     if out:
-        _compile_link(out, variant, flags_extra, force, verbose, jobs)
+        with _BuildLock():
+            _compile_link(out, variant, flags_extra, force, verbose, jobs)
         return out
     p = lib_path(variant)
     if not force and not needs_build(variant):
         LAST_BUILD[variant] = "reused"
         return p
-    _compile_link(p, variant, (), force, verbose, jobs)
+    with _BuildLock():
+        if not force and not needs_build(variant):   # another process built it while this one waited for the lock
+            LAST_BUILD[variant] = "reused"
+            return p
+        _compile_link(p, variant, (), force, verbose, jobs)
     LAST_BUILD[variant] = "compiled"
     return p
 

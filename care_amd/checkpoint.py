@@ -150,10 +150,10 @@ class CaptionRunner:
         self.captioner.to(device)
         return self
 
-    def translate_step(self, batch: Dict[str, Any], vocab: Optional[Dict[int, str]] = None):
+    @staticmethod
+    def _records(batch, hyps, scores, vocab):
         from .text import to_sentence
 
-        hyps, scores = self.translator.translate_batch(models=[self.captioner], batch=batch, vocab=vocab)
         if vocab is None:
             return hyps, scores
         out = []
@@ -161,6 +161,24 @@ class CaptionRunner:
             vid = batch["video_ids"][i] if "video_ids" in batch else i
             out.append({"image_id": vid, "caption": to_sentence(hs[0], vocab), "score": ss[0]})
         return out
+
+    def translate_step(self, batch: Dict[str, Any], vocab: Optional[Dict[int, str]] = None):
+        hyps, scores = self.translator.translate_batch(models=[self.captioner], batch=batch, vocab=vocab)
+        return self._records(batch, hyps, scores, vocab)
+
+    def translate_steps(self, batches, vocab: Optional[Dict[int, str]] = None):
+        """`translate_step` over a loader (translate.py:34-51's loop), pipelined: batch k's captions are assembled on the
+        host while batch k + 1 decodes (Translator_ARFormer.translate_batches).  Yields what translate_step returns, in
+        order; a batch's feature tensors must stay in place until its results are out (FeaturePrefetcher(depth=3))."""
+        seen = []
+
+        def tap():
+            for b in batches:
+                seen.append(b)
+                yield b
+
+        for hyps, scores in self.translator.translate_batches([self.captioner], tap(), vocab=vocab):
+            yield self._records(seen.pop(0), hyps, scores, vocab)
 
 
 def load_model(checkpoint_path: str, new_opt_used_to_override: Optional[Dict[str, Any]] = None, device="cuda:0",

@@ -101,6 +101,17 @@ def make_opt(name: str, **overrides) -> dict:
     elif name == "msrvtt_care_beam5":
         opt.update(_ARCH["base"], **deepcopy(_CARE))
         opt.update(beam_size=5)
+    elif name == "msrvtt_care_g1l0":
+        # scripts/exp_ablation_main.sh:34,63 `--use_attr_flags G1L0` (no --add_hybrid_attention_bias): global guidance only -
+        # check_args maps the flags to use_attr_type "emb_" (pred_attribute.py:308-330); no concept rows in the memory
+        opt.update(_ARCH["base"], **deepcopy(_CARE))
+        opt.update(use_attr_flags="G1L0", use_attr_type="emb_", add_hybrid_attention_bias=False)
+    elif name == "msrvtt_care_g0l0":
+        # scripts/exp_ablation_main.sh:37,66 `--use_attr_flags G0L0`: check_args turns use_attr off (pred_attribute.py:309-310):
+        # the concept head is trained and predicted (crits lang + attribute), the decoder gets no guidance at all
+        opt.update(_ARCH["base"], **deepcopy(_CARE))
+        opt.update(use_attr=False, use_attr_flags="G0L0", use_attr_type="", add_hybrid_attention_bias=False,
+                   predictors_to_be_added=[])
     elif name == "care_median_gelu":
         opt.update(_ARCH["median"], **deepcopy(_CARE))
         opt.update(hidden_act="gelu")
@@ -129,6 +140,8 @@ CONFIG_NAMES = (
     "care_median_gelu",
     "base_ami_mte",
     "msrvtt_cabase",
+    "msrvtt_care_g1l0",
+    "msrvtt_care_g0l0",
 )
 
 

@@ -1654,11 +1654,22 @@ inline int res_fenced_for_device() {
     mode = env;
   }
   if (mode >= 0) return mode;
+  // decided once per device ordinal (hipGetDeviceProperties is a driver round trip in front of a latency-bound launch)
+  static std::atomic<int> per_device[64];
+  static const bool init = [] { for (auto& a : per_device) a.store(-1); return true; }();
+  (void)init;
   int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1;
+  if (dev >= 0 && dev < 64) {
+    const int known = per_device[dev].load(std::memory_order_relaxed);
+    if (known >= 0) return known;
+  }
   hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
   const bool gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
-  return (gfx950 && prop.multiProcessorCount == 256) ? 0 : 1;
+  const int fenced = (gfx950 && prop.multiProcessorCount == 256) ? 0 : 1;
+  if (dev >= 0 && dev < 64) per_device[dev].store(fenced, std::memory_order_relaxed);
+  return fenced;
 }
 
 // Tuning / tool / test knobs of the resident launches: the environment is read ONCE per process (first launch), the

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void concept_topk_embed_kernel(const float* pr
   }
   __syncthreads();
   if (tid < topk) labels[(int64_t)b * topk + tid] = slab[tid];
+  if (!word) return;  // labels only: a model without local guidance (use_attr_flags ..L0) has no concept embeddings
   const int lane = tid & 63, wave = tid >> 6, nv4 = d >> 2;
   for (int j = wave; j < topk; j += 4) {
     const float* w = word + (int64_t)slab[j] * d;
@@ -482,7 +483,8 @@ extern "C" int care_concept_topk_embed(const float* preds, int64_t ldp, int k, i
                                        const float* pos, const float* gamma, const float* beta, float eps,
                                        int64_t* labels, float* out, void* out_bf16, int64_t ldo, int out_grp_rows,
                                        int out_row_off, int B, int d, void* stream) {
-  if (!preds || !word || !pos || !gamma || !beta || !labels || !out || B <= 0) return CARE_EINVAL;
+  if (!preds || !labels || B <= 0) return CARE_EINVAL;
+  if (word && (!pos || !gamma || !beta || !out)) return CARE_EINVAL;  // (word == NULL: the labels alone)
   if (k <= 0 || k > 1024 || topk <= 0 || topk > 64 || topk > k || d % 4 != 0 || d > 2048) return CARE_ESHAPE;
   hipLaunchKernelGGL(concept_topk_embed_kernel, dim3(B), dim3(256), 0, ST, preds, ldp, k, topk, word, pos, gamma, beta,
                      eps, labels, out, reinterpret_cast<bf16_t*>(out_bf16), ldo, out_grp_rows, out_row_off, d);

@@ -32,7 +32,7 @@ from .engine_beam import BeamMixin
 from .engine_decode import DecodeMixin
 from .engine_encode import EncodeMixin
 from .engine_resident import ResidentMixin
-from .engine_util import _LaneOutputs, _code  # noqa: F401
+from .engine_util import _LaneOutputs  # noqa: F401
 
 
 class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
@@ -72,8 +72,14 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         self.pred_mod = opt.get("modality_for_predictor") or self.modality
         self.has_concepts = "attribute" in opt.get("crits", [])
         self.has_container = "SemanticContainer" in opt.get("predictors_to_be_added", [])
+        # local guidance off (`use_attr_flags` ..L0, pred_attribute.py:243-252): the container has no concept embeddings -
+        # labels and the global-guidance vector only, no concept rows in the memory
+        self.has_attr_embs = self.has_container and "L0" not in opt.get("use_attr_flags", "")
         self.use_attr_type = opt.get("use_attr_type", "") if self.has_container else ""
         self.concat = "concat" in self.use_attr_type
+        if self.has_container and not self.has_attr_embs and (self.concat or "att" in self.use_attr_type.lower()):
+            raise ValueError("use_attr_flags {!r} (no concept embeddings) with use_attr_type {!r}".format(
+                opt.get("use_attr_flags"), self.use_attr_type))
         self.sem = "emb" in self.use_attr_type
         self.attr_att = bool(opt.get("use_attr", False)) and "att" in self.use_attr_type.lower()
         self.topk = int(opt.get("use_attr_topk", 30))
@@ -129,6 +135,16 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         self.chain_beam_max_rows = int(os.environ.get("CARE_CHAIN_BEAM_MAX_ROWS", "0"))
         self.chain_segment_steps = int(os.environ.get("CARE_CHAIN_SEGMENT_STEPS", "8"))
 
+    def _code(self, t: Optional[torch.Tensor]) -> int:
+        """dtype code of a tensor argument (include/care_hip.h): CARE_F32, or the library's ONE 16-bit code for a tensor
+        in THIS engine's 16-bit type.  The other 16-bit type - a bf16 tensor handed to an fp16-mode engine or the reverse -
+        would be reinterpreted bit for bit by the kernels: refused here."""
+        if t is None or t.dtype == torch.float32:
+            return CARE_F32
+        if t.dtype == self.h16:
+            return CARE_BF16
+        raise TypeError("a {} tensor in a `{}`-mode engine (its 16-bit type is {})".format(t.dtype, self.dtype, self.h16))
+
     @property
     def lib(self):
         """The ctypes library of this engine's compute mode (libcare_hip.so, or libcare_hip_f16.so for 'fp16')."""
@@ -175,9 +191,12 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
             w["attr_w"], w["attr_b"] = f32(sd["predictor.nets.0.prj.weight"]), f32(sd["predictor.nets.0.prj.bias"])
             if self.has_container:
                 sp = "predictor.nets.1"
-                w["attr_word"] = f32(sd[sp + ".attr_embs.word_embeddings.weight"])
-                w["attr_pos"] = f32(sd[sp + ".attr_embs.position_embeddings.weight"])
-                w["attr_g"], w["attr_be"] = f32(sd[sp + ".attr_embs.LayerNorm.weight"]), f32(sd[sp + ".attr_embs.LayerNorm.bias"])
+                if self.has_attr_embs:
+                    w["attr_word"] = f32(sd[sp + ".attr_embs.word_embeddings.weight"])
+                    w["attr_pos"] = f32(sd[sp + ".attr_embs.position_embeddings.weight"])
+                    w["attr_g"], w["attr_be"] = f32(sd[sp + ".attr_embs.LayerNorm.weight"]), f32(sd[sp + ".attr_embs.LayerNorm.bias"])
+                else:
+                    w["attr_word"] = w["attr_pos"] = w["attr_g"] = w["attr_be"] = None
                 if self.sem:
                     kp = self._kpad()
                     s2h = torch.zeros(d, kp, device=self.device, dtype=torch.float32)
@@ -296,6 +315,49 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         self._ws_used[key] = self._gen
         return t
 
+    # While a segmented pass waits for the host-visible counter between two of its segments (greedy_early_exit,
+    # beam_early_exit, the chained beam step), the caller may have host work of its own: `idle_hook` (None, or a callable that
+    # does ONE small piece of it and returns False once it has none left) is called in that wait instead of blocking in the
+    # copy.  The Translator's pipelined entry assembles the previous batch's python lists there (care_amd/translator.py).
+    idle_hook = None
+
+    def _host_count(self, cnt: torch.Tensor) -> int:
+        """The value of a one-element device counter, on the host: the one round trip per segment of the segmented passes."""
+        hook = self.idle_hook
+        if hook is None:
+            return int(cnt.item())
+        if getattr(self, "_cnt_pin", None) is None:
+            self._cnt_pin = torch.empty(1, dtype=torch.int32).pin_memory()
+            self._cnt_ev = torch.cuda.Event()
+        self._cnt_pin.copy_(cnt, non_blocking=True)
+        self._cnt_ev.record()
+        while not self._cnt_ev.query():
+            if not hook():
+                break
+        self._cnt_ev.synchronize()
+        return int(self._cnt_pin[0])
+
+    def ws_block(self, name: str, parts):
+        """The RESULTS of a decode as views of ONE cached workspace: `parts` = [(shape, dtype), ...] -> the tensors, each
+        256-byte aligned inside the block, in the order given.  What the Translator hands back lives in a single
+        contiguous range, so one device-to-host copy fetches it (care_amd/translator.py::_fetch)."""
+        sizes = [int(torch.empty(0, dtype=dt).element_size()) for _, dt in parts]
+        offs, total = [], 0
+        for (shape, dt), es in zip(parts, sizes):
+            offs.append(total)
+            n = es
+            for s in shape:
+                n *= int(s)
+            total += (n + 255) // 256 * 256
+        blk = self._ws_get(name, (max(total, 256),), torch.uint8)
+        out = []
+        for (shape, dt), es, off in zip(parts, sizes, offs):
+            n = es
+            for s in shape:
+                n *= int(s)
+            out.append(blk[off: off + n].view(dt).view(tuple(shape)))
+        return out
+
     # Captured graphs per kind (first element of the key).  The whole-pass kinds are keyed on the caller's feature
     # buffers, the segment kinds on (buffer set, first step, rows): a loader with ragged last batches, or a caller
     # that allocates fresh feature tensors for every batch, must not grow them without limit.
@@ -401,8 +463,8 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         M, K = A.shape
         N = W.shape[0]
         assert W.shape[1] == K and A.stride(1) == 1 and out.stride(-1) == 1
-        tail = (ptr(bias), ptr(out), out.stride(0), _code(out), ptr(out2),
-                out2.stride(0) if out2 is not None else 0, _code(out2), N if n_split is None else n_split, M, N, K, act)
+        tail = (ptr(bias), ptr(out), out.stride(0), self._code(out), ptr(out2),
+                out2.stride(0) if out2 is not None else 0, self._code(out2), N if n_split is None else n_split, M, N, K, act)
         if W.dtype == self.h16 and A.dtype == self.h16:
             if K % 64 or A.stride(0) % 8:
                 raise ValueError("bf16 A operand needs K % 64 == 0 and a 16-byte aligned row stride (got K = {})".format(K))
@@ -413,7 +475,7 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
             # CURRENT row count and changes no caption.
             mid = self.MID_TILE_ROWS[0] <= M < self.MID_TILE_ROWS[1] and os.environ.get("CARE_FORCE_TILE", "") != "0"
             if K <= 512 and K % 128 == 0 and not tile and not mid and os.environ.get("CARE_FORCE_TILE", "0") != "1":
-                self.call("care_gemm_bf16", ptr(A), A.stride(0), _code(A), ptr(W), *tail, tag=tag)
+                self.call("care_gemm_bf16", ptr(A), A.stride(0), self._code(A), ptr(W), *tail, tag=tag)
             else:
                 self.call("care_gemm_tile", ptr(A), A.stride(0), ptr(W), *tail, tag=tag)
         else:
@@ -425,7 +487,7 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
                 self.call("care_split2_act", ptr(A), A.stride(0), ptr(a2), M, K)
                 self.call("care_gemm_tile_split3", ptr(a2), ptr(W3), *tail, tag=tag)
             else:
-                self.call("care_gemm", ptr(A), A.stride(0), ptr(W), _code(W), *tail, tag=tag)
+                self.call("care_gemm", ptr(A), A.stride(0), ptr(W), self._code(W), *tail, tag=tag)
         return out
 
     # up to this many rows the vocabulary arg-max of a d_model <= 512 model runs on the LDS-tiled kernel too (measured crossover
@@ -452,7 +514,7 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         bf16, d <= 512: A-stationary kernels; bf16, larger d: the LDS-tiled kernel; fp32 mode: exact-f32 MFMA."""
         d, W = self.d, self.w["vocab"]
         if self._vocab_as(rows):
-            self.call("care_gemm_argmax_bf16", ptr(xb), d, _code(xb), ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels),
+            self.call("care_gemm_argmax_bf16", ptr(xb), d, self._code(xb), ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels),
                  ptr(plab), rows, self.V, d, tag=tag)
         elif self.bf_act:
             self.call("care_gemm_tile_argmax", ptr(xb), d, ptr(W), ptr(pmax), ptr(pidx), ptr(psum), ptr(labels), ptr(plab),
@@ -466,7 +528,7 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
                 self.call("care_split2_act", ptr(x), x.stride(0), ptr(a2), rows, d)
                 self.call("care_gemm_tile_split3_argmax", ptr(a2), ptr(W3), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
             else:
-                self.call("care_gemm_argmax", ptr(x), d, ptr(W), _code(W), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
+                self.call("care_gemm_argmax", ptr(x), d, ptr(W), self._code(W), ptr(pmax), ptr(pidx), ptr(psum), rows, self.V, d, tag=tag)
 
     def add_ln(self, x, res, g, be, out, outb=None, grp=None, out_grp_rows=None, out_row_off=0, pos=None, nslab=1, tag=None):
         """out = LN(sum of the nslab slabs of x + res); x is [rows, d] or [nslab, rows, d]."""
@@ -512,11 +574,11 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         grp = rows if grp is None else grp
         out_grp_rows = grp if out_grp_rows is None else out_grp_rows
         if Wp is not None and pos is None and os.environ.get("CARE_LN_PACKED", "1") != "0":
-            self.call("care_gemm_ln_packed", ptr(A), A.stride(0), _code(A), ptr(Wp), ptr(bias), ptr(res),
+            self.call("care_gemm_ln_packed", ptr(A), A.stride(0), self._code(A), ptr(Wp), ptr(bias), ptr(res),
                  res.stride(0) if res is not None else 0, ptr(g), ptr(be), self.eps, ptr(out), ptr(outb),
                  (out if out is not None else outb).stride(-2), rows, self.d, K, grp, out_grp_rows, out_row_off, tag=tag)
             return out
-        self.call("care_gemm_ln", ptr(A), A.stride(0), _code(A), ptr(W), ptr(bias), ptr(res),
+        self.call("care_gemm_ln", ptr(A), A.stride(0), self._code(A), ptr(W), ptr(bias), ptr(res),
              res.stride(0) if res is not None else 0, ptr(pos), ptr(g), ptr(be), self.eps, ptr(out), ptr(outb),
              (out if out is not None else outb).stride(-2), rows, self.d, K, grp, out_grp_rows, out_row_off, tag=tag)
         return out
@@ -524,10 +586,10 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
     def attention(self, Q, K, V, ctx, kv_batch_stride, kv_row_stride, rows_per_kv, nkeys, anc=None, causal=False,
                   seq=1, pad_tok=None, bias=None, tag=None):
         rows = Q.shape[0]
-        self.call("care_attention", ptr(Q), Q.stride(0), ptr(K), ptr(V), _code(K), kv_batch_stride, kv_row_stride,
+        self.call("care_attention", ptr(Q), Q.stride(0), ptr(K), ptr(V), self._code(K), kv_batch_stride, kv_row_stride,
              rows_per_kv, ptr(anc), anc.stride(0) if anc is not None else 0, nkeys, 1 if causal else 0, seq, 0,
              ptr(pad_tok), pad_tok.stride(0) if pad_tok is not None else 0, PAD, ptr(bias),
-             bias.stride(0) if bias is not None else 0, ptr(ctx), ctx.stride(0), _code(ctx), rows, self.H, tag=tag)
+             bias.stride(0) if bias is not None else 0, ptr(ctx), ctx.stride(0), self._code(ctx), rows, self.H, tag=tag)
         return ctx
 
     def attention_probs(self, Q, K, kv_batch_stride, kv_row_stride, rows_per_kv, nkeys, causal=False, seq=1,
@@ -536,7 +598,7 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         forward; the fused attention kernels never materialise them)."""
         rows = Q.shape[0]
         probs = torch.empty(rows, self.H, nkeys, device=self.device)
-        self.call("care_attention_probs", ptr(Q), Q.stride(0), ptr(K), _code(K), kv_batch_stride, kv_row_stride, rows_per_kv,
+        self.call("care_attention_probs", ptr(Q), Q.stride(0), ptr(K), self._code(K), kv_batch_stride, kv_row_stride, rows_per_kv,
              nkeys, 1 if causal else 0, seq, ptr(pad_tok), pad_tok.stride(0) if pad_tok is not None else 0, PAD,
              ptr(bias), bias.stride(0) if bias is not None else 0, ptr(probs), rows, self.H)
         return probs

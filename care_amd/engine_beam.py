@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import ACT_CODES, CARE_BF16, CARE_F32, ptr
 from .constants import BOS, EOS, PAD
-from .engine_util import _LaneOutputs, _code
+from .engine_util import _LaneOutputs
 
 
 class BeamMixin:
@@ -22,6 +22,11 @@ class BeamMixin:
     # *Measured* round 5 (beam 5, us per step of the whole pass, groups / two-pass): 5120 rows 422 / 497, 10240 rows 726 /
     # 700, 20480 rows 1266 / 1162 - the group maxima are 12 KB per row and step.  Fixed for a pass by its INITIAL row count.
     BEAM_FUSED_MIN_ROWS = int(os.environ.get("CARE_BEAM_FUSED_MIN_ROWS", "8192"))
+
+    def _beam_out_parts(self, B: int, cap: int):
+        """Per-clip results of a beam search as parts of one block (engine.ws_block): nfin [B], fscore / flen [B, cap],
+        fhyp [B, cap, T + 1]."""
+        return [((B,), torch.int32), ((B, cap), torch.float32), ((B, cap), torch.int32), ((B, cap, self.T + 1), torch.int32)]
 
     def _beam_sparse_ws(self, tag: str, rows: int):
         """Workspaces of the sparse second pass (csrc/beam_sparse.hip) - (tile maxima [tiles, rows] fp32, per-tile
@@ -93,20 +98,20 @@ class BeamMixin:
             elif fused_sel:
                 if sparse is not None:
                     # second pass only over the (tile, row) products whose tile maximum reaches the row's threshold
-                    self.call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                    self.call("care_gemm_argmax_bf16_tiles", ptr(xb), d, self._code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
                          ptr(s_pidx), ptr(s_psum), ptr(sparse[0]), N, self.V, d, 8, tag="beam_vocab_stats")
                     self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
                     self.call("care_beam_sparse_collect", ptr(xb), d, ptr(self.w["vocab"]), ptr(sparse[0]), ptr(s_thr),
                          ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap, ptr(sparse[1]), ptr(sparse[2]), N, self.V, d,
                          tag="beam_vocab_collect")
                 else:
-                    self.call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                    self.call("care_gemm_argmax_bf16_min", ptr(xb), d, self._code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
                          ptr(s_pidx), ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
                     self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                    self.call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
+                    self.call("care_gemm_collect_bf16", ptr(xb), d, self._code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
                          ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
                 self.call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
-                     bm, ptr(xb), d, _code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
+                     bm, ptr(xb), d, self._code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
             else:
                 src = xb if xb is not None else x
                 chunk = int(os.environ.get("CARE_BEAM_CHUNK", "0")) or max(128, (176 << 20) // (logits.stride(0) * 4) // 128 * 128)
@@ -130,8 +135,7 @@ class BeamMixin:
         B, T, d = feats[0].shape[0], self.T, self.d
         cap = need + bm
         S = max(1, self.segment_steps) * (1 if B * bm >= 2048 else 2)
-        out = dict(nfin=self.ws("be_out_nfin", (B,), torch.int32), fscore=self.ws("be_out_fscore", (B, cap)),
-                   flen=self.ws("be_out_flen", (B, cap), torch.int32), fhyp=self.ws("be_out_fhyp", (B, cap, T + 1), torch.int32))
+        out = dict(zip(("nfin", "fscore", "flen", "fhyp"), self.ws_block("be_out", self._beam_out_parts(B, cap))))
         idx, cnt = self.ws("be_idx", (B,), torch.int32), self.ws("be_cnt", (1,), torch.int32)
         fkey = (tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
 
@@ -185,7 +189,7 @@ class BeamMixin:
             stats = dict(clips=B, steps=t - 1, row_steps=B * bm * (t - 1), compactions=0)
             self.last_decode = stats
             while True:
-                active = int(cnt.item())
+                active = self._host_count(cnt)
                 if active == 0 or t > T:
                     break
                 m = self._slot_bucket(active, B)
@@ -271,7 +275,7 @@ class BeamMixin:
                 # launch needs - a partition with few CUs, another occupancy): this engine keeps the multi-launch search
                 if "CARE_ESHAPE" not in str(exc):
                     raise
-                self._resident_refused = True
+                self._note_refused("beam", feats[0].shape[0] * bm)
                 out = None
             if out is not None:
                 nb = self.lib.care_decode_resident_beam_scratch(feats[0].shape[0], bm, self.d, self.ff, self.V)
@@ -308,10 +312,8 @@ class BeamMixin:
             a.copy_(rows.unsqueeze(1).expand(N, T + 1))
         scores = self.ws("b_scores", (N,)); scores.zero_()
         done = self.ws("b_done", (B,), torch.int32); done.zero_()
-        nfin = self.ws("b_nfin", (B,), torch.int32); nfin.zero_()
-        fscore = self.ws("b_fscore", (B, cap)); fscore.zero_()
-        flen = self.ws("b_flen", (B, cap), torch.int32); flen.zero_()
-        fhyp = self.ws("b_fhyp", (B, cap, T + 1), torch.int32); fhyp.zero_()
+        nfin, fscore, flen, fhyp = self.ws_block("b_out", self._beam_out_parts(B, cap))
+        nfin.zero_(); fscore.zero_(); flen.zero_(); fhyp.zero_()
         cval = self.ws("b_cval", (N, bm))
         cidx = self.ws("b_cidx", (N, bm), torch.int32)
         vpad = (self.V + 63) // 64 * 64  # 16-byte aligned row stride -> the GEMM's vector store path
@@ -345,20 +347,20 @@ class BeamMixin:
                 # fused selection (csrc/beam.hip): statistics GEMM -> threshold -> candidate pass -> pick;
                 # the [N, V] logits never exist
                 if sparse is not None:
-                    self.call("care_gemm_argmax_bf16_tiles", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                    self.call("care_gemm_argmax_bf16_tiles", ptr(xb), d, self._code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
                          ptr(s_pidx), ptr(s_psum), ptr(sparse[0]), N, self.V, d, 8, tag="beam_vocab_stats")
                     self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
                     self.call("care_beam_sparse_collect", ptr(xb), d, ptr(self.w["vocab"]), ptr(sparse[0]), ptr(s_thr),
                          ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap, ptr(sparse[1]), ptr(sparse[2]), N, self.V, d,
                          tag="beam_vocab_collect")
                 else:
-                    self.call("care_gemm_argmax_bf16_min", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
+                    self.call("care_gemm_argmax_bf16_min", ptr(xb), d, self._code(xb), ptr(self.w["vocab"]), ptr(s_pmax),
                          ptr(s_pidx), ptr(s_psum), N, self.V, d, 8, tag="beam_vocab_stats")
                     self.call("care_beam_threshold", ptr(s_pmax), s_parts, bm, ptr(s_thr), ptr(s_cnt), N)
-                    self.call("care_gemm_collect_bf16", ptr(xb), d, _code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
+                    self.call("care_gemm_collect_bf16", ptr(xb), d, self._code(xb), ptr(self.w["vocab"]), ptr(s_thr), ptr(s_cnt),
                          ptr(s_cval), ptr(s_cidx), s_cap, N, self.V, d, tag="beam_vocab_collect")
                 self.call("care_beam_pick", ptr(s_pmax), ptr(s_psum), s_parts, ptr(s_cnt), ptr(s_cval), ptr(s_cidx), s_cap,
-                     bm, ptr(xb), d, _code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
+                     bm, ptr(xb), d, self._code(xb), ptr(self.w["vocab"]), self.V, d, ptr(cval), ptr(cidx), N)
                 self.call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
                      ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
                 continue

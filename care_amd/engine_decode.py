@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import ACT_CODES, CARE_BF16, CARE_F32, ptr
 from .constants import BOS, EOS, PAD
-from .engine_util import _LaneOutputs, _code
+from .engine_util import _LaneOutputs
 
 
 class DecodeMixin:
@@ -56,7 +56,7 @@ class DecodeMixin:
             # K = ff > 512: split K over blocks into fp32 slabs; the LayerNorm kernel sums them
             ns = self.ff // 512
             f = self.ws(tag + "fslab", (ns, rows, d))
-            self.call("care_gemm_bf16_splitk", ptr(h), h.stride(0), _code(h), ptr(w2), ptr(w[name + "_b2"]), ptr(f), d,
+            self.call("care_gemm_bf16_splitk", ptr(h), h.stride(0), self._code(h), ptr(w2), ptr(w[name + "_b2"]), ptr(f), d,
                  f.stride(0), rows, d, self.ff, tag=gemm_tag)
             return self._res_ln(f, x, w[name + "_g"], w[name + "_be"], out, outb, nslab=ns,
                                 tag="step_add_ln" if gemm_tag else None, **ln_kw)
@@ -379,9 +379,7 @@ class DecodeMixin:
         steps = T if steps is None else steps
         mem = mem.to(self.device, mem.dtype if mem.dtype == self.h16 else torch.float32)  # bf16: lean encode
         sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
-        fed = self.ws("g_fed", (B, T + 1), torch.int32)
-        score = self.ws("g_score", (B,))
-        length = self.ws("g_len", (B,), torch.int32)
+        length, score, fed = self.ws_block("g_out", [((B,), torch.int32), ((B,), torch.float32), ((B, T + 1), torch.int32)])
         fin = self.ws("g_fin", (B,), torch.int32)
         fed.zero_(); fed[:, 0] = BOS
         score.zero_(); length.zero_(); fin.zero_()
@@ -439,9 +437,7 @@ class DecodeMixin:
         # small batches are launch-bound: a segment boundary (one host round trip + one more graph launch,
         # ~40 us) costs as much as several of their steps, so they check twice as rarely and never compact
         S = max(1, self.segment_steps) * (1 if B >= 2048 else 2)
-        out_fed = self.ws("ge_out_fed", (B, T + 1), torch.int32)
-        out_len = self.ws("ge_out_len", (B,), torch.int32)
-        out_score = self.ws("ge_out_score", (B,))
+        out_len, out_score, out_fed = self.ws_block("ge_out", [((B,), torch.int32), ((B,), torch.float32), ((B, T + 1), torch.int32)])
         idx = self.ws("ge_idx", (B,), torch.int32)
         cnt = self.ws("ge_cnt", (1,), torch.int32)
         fkey = (tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
@@ -505,7 +501,7 @@ class DecodeMixin:
             stats = dict(clips=B, steps=t - 1, row_steps=B * (t - 1), compactions=0)
             self.last_decode = stats  # what the last pass actually ran (tests, bench)
             while True:
-                active = int(cnt.item())  # the one host round trip per segment
+                active = self._host_count(cnt)  # the one host round trip per segment
                 if active == 0 or t > T:
                     break
                 n_new = self._slot_bucket(active, B)
@@ -598,7 +594,7 @@ class DecodeMixin:
             except _lib.CareHipError as exc:  # (refused, nothing enqueued: see translate_beam)
                 if "CARE_ESHAPE" not in str(exc):
                     raise
-                self._resident_refused = True
+                self._note_refused("greedy", feats[0].shape[0])
                 out = None
             if out is not None:
                 nb = self.lib.care_decode_resident_scratch(feats[0].shape[0], self.d, self.ff, self.V)

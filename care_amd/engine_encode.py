@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import ACT_CODES, CARE_BF16, CARE_F32, ptr
 from .constants import BOS, EOS, PAD
-from .engine_util import _LaneOutputs, _code
+from .engine_util import _LaneOutputs
 
 
 class EncodeMixin:
@@ -156,7 +156,9 @@ class EncodeMixin:
             out["avg_prob_attr"] = avg
             if self.has_container:
                 labels = new("labels", (B, self.topk), torch.int64)
-                if self.concat:
+                if not self.has_attr_embs:  # (..L0: the labels alone, pred_attribute.py:264,276-277)
+                    dst, dstb, grp_rows, off = None, None, self.topk, 0
+                elif self.concat:
                     dst, dstb, grp_rows, off = mem, memb, self.Lk, self.concept_off
                 else:
                     dst, dstb, grp_rows, off = new("sem_embs", (B, self.topk, d)), None, self.topk, 0
@@ -164,7 +166,7 @@ class EncodeMixin:
                      ptr(w["attr_pos"]), ptr(w["attr_g"]), ptr(w["attr_be"]), self.eps, ptr(labels), ptr(dst),
                      ptr(dstb), d, grp_rows, off, B, d)
                 out["semantic_labels"] = labels
-                out["semantic_embs"] = dst[:, off: off + self.topk]
+                out["semantic_embs"] = dst[:, off: off + self.topk] if dst is not None else None
                 if self.sem:
                     out["semantic_hidden_states"] = self.gemm(preds, w["s2h_w"], w["s2h_b"], new("sem_hidden", (B, d)))
                 else:

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import ACT_CODES, CARE_BF16, CARE_F32, ptr
 from .constants import BOS, EOS, PAD
-from .engine_util import _LaneOutputs, _code
+from .engine_util import _LaneOutputs
 
 
 class ResidentMixin:
@@ -24,6 +24,8 @@ class ResidentMixin:
         larger one (the audit of tests/test_gpu_properties.py counts such rows)."""
         if not (0 < rows <= self.resident_max_rows and self._resident_model_ok()):
             return False
+        if rows >= self._refused_from("greedy"):
+            return False
         if self.d != 512 and rows > self.RESIDENT_WIDE_MAX_ROWS:
             return False
         return self._resident_fits(rows)
@@ -35,14 +37,22 @@ class ResidentMixin:
         bf16 mode; d_model 512 (ff 512 / 1024 / 2048), or - greedy only - d_model 768 / 1024 with ff = 4 d_model."""
         if self.pre_ln:  # (the resident phases normalise AFTER the residual sum: post-LN decoders only)
             return False
-        if getattr(self, "_resident_refused", False):  # a launch was refused on this device (CARE_ESHAPE): multi-launch forms
-            return False
         if not (self.bf and self.wt == self.h16 and self.T <= 128 and self.n_layers <= 4 and
                 (not self.attr_att or self.topk <= 128) and self.V <= self.RESIDENT_MAX_V and self.Lk <= 128):
             return False
         if self.d == 512:
             return bool(self.as_ok and self.ff in (512, 1024, 2048))
         return bool(self.d in (768, 1024) and self.ff == 4 * self.d and self.bf_act)  # (greedy and - round 5 - beam search)
+
+    def _refused_from(self, kind: str) -> int:
+        """Smallest row count at which a resident launch of `kind` ("greedy" / "beam") was refused on this device
+        (CARE_ESHAPE: fewer co-resident workgroups than the launch needs - a partition with few CUs); launches below it are
+        still tried, the chained step (no residency condition) never looks here."""
+        return getattr(self, "_resident_refused", {}).get(kind, 1 << 30)
+
+    def _note_refused(self, kind: str, rows: int) -> None:
+        d = self.__dict__.setdefault("_resident_refused", {})
+        d[kind] = min(d.get(kind, 1 << 30), rows)
 
     def _resident_fits(self, rows: int, per_tile: int = 1) -> bool:
         """one workgroup per CU at most, and at least one per group of `per_tile` 16-row tiles (a partitioned GPU has fewer CUs)"""
@@ -65,6 +75,8 @@ class ResidentMixin:
         rows = clips * bm
         if not (0 < rows <= self.resident_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and
                 self._resident_model_ok(beam=True) and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX):
+            return False
+        if rows >= self._refused_from("beam"):
             return False
         if self.d != 512 and rows > (self.RESIDENT_WIDE_BEAM_MAX_ROWS if self.d <= 768 else min(160, self.RESIDENT_WIDE_BEAM_MAX_ROWS)):
             return False  # (d_model 768 / 1024: the K-split forms; see RESIDENT_WIDE_BEAM_MAX_ROWS)
@@ -124,9 +136,8 @@ class ResidentMixin:
         akv = self.attr_kv(sem_embs, tag="rb_akv") if self.attr_att else None
         tok = self.ws("rb_tok", (N, T + 1), torch.int32)
         anc = [self.ws("rb_anc%d" % i, (N, T + 1), torch.int32) for i in range(2)]
-        scores, done, nfin = self.ws("rb_scores", (N,)), self.ws("rb_done", (B,), torch.int32), self.ws("rb_nfin", (B,), torch.int32)
-        fscore, flen = self.ws("rb_fscore", (B, cap)), self.ws("rb_flen", (B, cap), torch.int32)
-        fhyp = self.ws("rb_fhyp", (B, cap, T + 1), torch.int32)
+        scores, done = self.ws("rb_scores", (N,)), self.ws("rb_done", (B,), torch.int32)
+        nfin, fscore, flen, fhyp = self.ws_block("rb_out", self._beam_out_parts(B, cap))
         layers = self._resident_layers("rb_", N, bm, ckv, akv, Lk)
         nbytes = self.lib.care_decode_resident_beam_scratch(B, bm, d, self.ff, self.V)
         scratch = self.ws("rb_scratch", (nbytes,), torch.uint8)
@@ -144,8 +155,7 @@ class ResidentMixin:
         return dict(tok=self.ws("cb_tok", (N, T + 1), torch.int32),
                     anc=[self.ws("cb_anc%d" % i, (N, T + 1), torch.int32) for i in range(2)],
                     scores=self.ws("cb_scores", (N,)), done=self.ws("cb_done", (B,), torch.int32),
-                    nfin=self.ws("cb_nfin", (B,), torch.int32), fscore=self.ws("cb_fscore", (B, cap)),
-                    flen=self.ws("cb_flen", (B, cap), torch.int32), fhyp=self.ws("cb_fhyp", (B, cap, T + 1), torch.int32),
+                    **dict(zip(("nfin", "fscore", "flen", "fhyp"), self.ws_block("cb_out", self._beam_out_parts(B, cap)))),
                     idx=self.ws("cb_idx", (B,), torch.int32), cnt=self.ws("cb_cnt", (1,), torch.int32))
 
     def beam_chain_steps(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int, t0: int, t1: int,
@@ -201,7 +211,7 @@ class ResidentMixin:
         stats = dict(clips=B, steps=t - 1, row_steps=B * bm * (t - 1), compactions=0, chain=True)
         self.last_decode = stats
         while t <= T:
-            if early_exit and int(v["cnt"].item()) == 0:
+            if early_exit and self._host_count(v["cnt"]) == 0:
                 break
             t1 = min(t + S - 1, T)
             tt = t
@@ -225,8 +235,8 @@ class ResidentMixin:
         sem = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
         ckv = self.cross_kv(mem, tag="r_ckv", resident=True)
         akv = self.attr_kv(sem_embs, tag="r_akv") if self.attr_att else None
-        fed = self.ws("r_fed", (B, T + 1), torch.int32)
-        score, length, fin = self.ws("r_score", (B,)), self.ws("r_len", (B,), torch.int32), self.ws("r_fin", (B,), torch.int32)
+        length, score, fed = self.ws_block("r_out", [((B,), torch.int32), ((B,), torch.float32), ((B, T + 1), torch.int32)])
+        fin = self.ws("r_fin", (B,), torch.int32)
         layers = self._resident_layers("r_", B, 1, ckv, akv, Lk)
         nbytes = self.lib.care_decode_resident_scratch(B, d, self.ff, self.V)
         scratch = self.ws("r_scratch", (nbytes,), torch.uint8)

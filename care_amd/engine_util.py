@@ -3,11 +3,6 @@ from typing import Optional
 
 import torch
 
-from ._lib import CARE_BF16, CARE_F32
-
-
-def _code(t: Optional[torch.Tensor]) -> int:
-    return CARE_BF16 if (t is not None and t.dtype in (torch.bfloat16, torch.float16)) else CARE_F32  # (CARE_BF16: the library's 16-bit type)
 
 
 class _LaneOutputs(dict):

@@ -150,10 +150,11 @@ class SemanticContainer(nn.Module):
 
     def __init__(self, opt):
         super().__init__()
-        if "L0" in opt.get("use_attr_flags", ""):
-            raise ValueError("use_attr_flags with L0 (no local guidance) is outside the hot path")
-        self.attr_embs = _NaiveEmbeddings(opt["attribute_prediction_k"], opt["use_attr_topk"], opt["dim_hidden"],
-                                          opt["layer_norm_eps"])
+        # pred_attribute.py:243-252: no concept embeddings without local guidance (`use_attr_flags` ..L0; the ablation rows of
+        # scripts/exp_ablation_main.sh:34,63 - G1L0 keeps the global guidance `semantic2hidden` alone)
+        if "L0" not in opt.get("use_attr_flags", ""):
+            self.attr_embs = _NaiveEmbeddings(opt["attribute_prediction_k"], opt["use_attr_topk"], opt["dim_hidden"],
+                                              opt["layer_norm_eps"])
         if "emb" in opt.get("use_attr_type", ""):
             self.semantic2hidden = nn.Linear(opt["attribute_prediction_k"], opt["dim_hidden"],
                                              bias="pp_emb" in opt.get("use_attr_type", ""))

@@ -389,16 +389,23 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
             scratch = torch.empty(B * topk, d, device=dev)
             pd = preds.detach().contiguous()
             s2h_in = preds if opt.get("global_semantic_guidance_not_detach") else pd  # pred_attribute.py:279
-            call("care_concept_topk_embed", ptr(pd), k_attr, k_attr, topk, ptr(P[sp + ".attr_embs.word_embeddings.weight"]),
-                 ptr(P[sp + ".attr_embs.position_embeddings.weight"]), ptr(P[sp + ".attr_embs.LayerNorm.weight"]),
-                 ptr(P[sp + ".attr_embs.LayerNorm.bias"]), eps, ptr(labels), ptr(scratch), None, d, topk, 0, B, d)
+            local = "L0" not in opt.get("use_attr_flags", "")  # pred_attribute.py:243-252: no concept embeddings without local guidance
+            if local:
+                call("care_concept_topk_embed", ptr(pd), k_attr, k_attr, topk, ptr(P[sp + ".attr_embs.word_embeddings.weight"]),
+                     ptr(P[sp + ".attr_embs.position_embeddings.weight"]), ptr(P[sp + ".attr_embs.LayerNorm.weight"]),
+                     ptr(P[sp + ".attr_embs.LayerNorm.bias"]), eps, ptr(labels), ptr(scratch), None, d, topk, 0, B, d)
+            else:
+                call("care_concept_topk_embed", ptr(pd), k_attr, k_attr, topk, None, None, None, None, eps, ptr(labels), None, None,
+                     d, topk, 0, B, d)
             out["semantic_labels"] = labels
-            e = _Gather.apply(P[sp + ".attr_embs.word_embeddings.weight"], labels.view(-1).to(torch.int32), -1)
-            e = _AddPosSem.apply(e, P[sp + ".attr_embs.position_embeddings.weight"][:topk], None, topk, topk)
-            e = _AddLN.apply(e, None, P[sp + ".attr_embs.LayerNorm.weight"], P[sp + ".attr_embs.LayerNorm.bias"], eps)
-            if not opt.get("attr_embs_no_dropout", False):
-                e = drop(e, p_hid)
-            sem_embs = e.view(B, topk, d)
+            sem_embs = None
+            if local:
+                e = _Gather.apply(P[sp + ".attr_embs.word_embeddings.weight"], labels.view(-1).to(torch.int32), -1)
+                e = _AddPosSem.apply(e, P[sp + ".attr_embs.position_embeddings.weight"][:topk], None, topk, topk)
+                e = _AddLN.apply(e, None, P[sp + ".attr_embs.LayerNorm.weight"], P[sp + ".attr_embs.LayerNorm.bias"], eps)
+                if not opt.get("attr_embs_no_dropout", False):
+                    e = drop(e, p_hid)
+                sem_embs = e.view(B, topk, d)
             out["semantic_embs"] = sem_embs
             if "concat" in use_attr_type:
                 mem = torch.cat([mem, sem_embs], dim=1)

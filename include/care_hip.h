@@ -313,6 +313,8 @@ int care_concept_finish(const float* scores, int64_t lds, float* preds, int64_t 
  *   labels[b, j] = index of the j-th largest preds[b, :] (order: value desc, index asc;
  *   torch leaves the order of exact ties unspecified);
  *   out[b * out_grp_rows + out_row_off + j, :] = LN(word[labels[b,j]] + pos[j]).
+ *   word == NULL: the labels alone - a model without local guidance (`use_attr_flags` G1L0:
+ *   pred_attribute.py:252 builds no `attr_embs`, :276-277 leaves `semantic_embs` None).
  *   k <= 1024, topk <= 64, d % 4 == 0, d <= 2048.
  */
 int care_concept_topk_embed(const float* preds, int64_t ldp, int k, int topk,

@@ -175,9 +175,12 @@ def encoding_phase(P, opt: dict, feats: List[torch.Tensor]) -> Dict[str, torch.T
         if "SemanticContainer" in opt.get("predictors_to_be_added", []):
             sp = "predictor.nets.1"
             _, labels = preds_attr.topk(opt["use_attr_topk"], dim=1, sorted=True, largest=True)
-            emb = P[sp + ".attr_embs.word_embeddings.weight"][labels]
-            emb = emb + P[sp + ".attr_embs.position_embeddings.weight"][: labels.shape[1]].unsqueeze(0)
-            out["semantic_embs"] = _layer_norm(P, sp + ".attr_embs.LayerNorm", emb, opt["layer_norm_eps"])
+            if "L0" in opt.get("use_attr_flags", ""):  # pred_attribute.py:243-252,276-277: no concept embeddings
+                out["semantic_embs"] = None
+            else:
+                emb = P[sp + ".attr_embs.word_embeddings.weight"][labels]
+                emb = emb + P[sp + ".attr_embs.position_embeddings.weight"][: labels.shape[1]].unsqueeze(0)
+                out["semantic_embs"] = _layer_norm(P, sp + ".attr_embs.LayerNorm", emb, opt["layer_norm_eps"])
             out["semantic_labels"] = labels
             if "emb" in opt.get("use_attr_type", ""):
                 # pred_attribute.py:279: detached unless `global_semantic_guidance_not_detach` (same forward values)

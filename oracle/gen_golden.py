@@ -64,6 +64,11 @@ CASES = [
     ("msrvtt_base_ami_preln_b3", "msrvtt_base_ami", 3, 51, {"transformer_pre_ln": True}, {VOCAB_W: {EOS_ROW: 4.0, PAD_ROW: 3.0}}),
     ("msrvtt_care_preln_beam5_b2", "msrvtt_care_beam5", 2, 52, {"transformer_pre_ln": True}, {VOCAB_W: {EOS_ROW: 4.0}}),
     ("msrvtt_cabase_preln_b2", "msrvtt_cabase", 2, 53, {"transformer_pre_ln": True}, {VOCAB_W: {EOS_ROW: 4.0}}),
+    # the ablation rows of scripts/exp_ablation_main.sh:34,37,63,66: global guidance without the concept rows (G1L0:
+    # use_attr_type "emb_", no hybrid bias), and the concept head beside an unguided decoder (G0L0: use_attr off)
+    ("msrvtt_care_g1l0_b3", "msrvtt_care_g1l0", 3, 61, {}, {VOCAB_W: {EOS_ROW: 4.0, PAD_ROW: 3.0}}),
+    ("msrvtt_care_g1l0_beam5_b2", "msrvtt_care_g1l0", 2, 62, {"beam_size": 5}, {VOCAB_W: {EOS_ROW: 4.0}}),
+    ("msrvtt_care_g0l0_b3", "msrvtt_care_g0l0", 3, 63, {}, {VOCAB_W: {EOS_ROW: 4.0, PAD_ROW: 3.0}}),
 ]
 
 

@@ -40,7 +40,10 @@ def test_encoding_phase_fp32(golden):
     if "preds_attr" in z:
         assert _maxdiff(enc["preds_attr"], z["preds_attr"]) < ATOL_FP32
         assert _maxdiff(enc["avg_prob_attr"], z["avg_prob_attr"]) < ATOL_FP32
-        assert np.array_equal(enc["semantic_labels"].cpu().numpy(), z["semantic_labels"])
+        if "semantic_labels" in z:
+            assert np.array_equal(enc["semantic_labels"].cpu().numpy(), z["semantic_labels"])
+        else:  # (G0L0: the concept head without a SemanticContainer)
+            assert "semantic_labels" not in enc
         if "semantic_hidden_states" in z:
             assert _maxdiff(enc["semantic_hidden_states"], z["semantic_hidden_states"]) < ATOL_FP32
         if "semantic_embs_clip0" in z:
@@ -91,6 +94,41 @@ def test_translate_batch_fp32(golden):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
         assert all(isinstance(s, float) for s in a)
     assert all(isinstance(t, int) for hs in hyps for h in hs for t in h)
+
+
+@pytest.mark.parametrize("config,beam,B,mode", [("msrvtt_base_ami", 1, 96, "bf16"), ("msrvtt_care_beam5", 5, 64, "bf16"),
+                                                 ("msrvtt_base_ami", 1, 3072, "fp16"), ("msrvtt_care_beam5", 5, 640, "bf16"),
+                                                 ("msrvtt_care", 1, 7, "fp32")])
+def test_translate_batches_equals_translate_batch(config, beam, B, mode):
+    """The pipelined entry (lists of batch k assembled while batch k + 1 decodes: in the host waits of the segmented
+    passes, after the asynchronous resident launches) against one translate_batch call per batch, on host-fed batches of
+    different content through FeaturePrefetcher(depth=3) - and CaptionRunner.translate_steps over the same loader.  A model
+    that ends its captions at mixed lengths (EOS row x 5), so slicing, early exit and compaction are all live."""
+    from care_amd import get_translator
+    from care_amd.checkpoint import CaptionRunner
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.data import FeaturePrefetcher
+    from care_amd.synth import synth_state_dict
+
+    opt = make_opt(config, beam_size=beam, topk=min(beam, 2))
+    runner = CaptionRunner(opt)
+    model = runner.captioner.eval()
+    P = synth_state_dict(3, [(k, tuple(v.shape)) for k, v in model.state_dict().items()],
+                         row_scale={"cls_head.tgt_word_prj.weight": {3: 5.0, 0: 2.0}})
+    model.load_state_dict(P, strict=True)
+    model.set_compute_dtype(mode)
+    model.to("cuda:0")
+    tr = get_translator(opt)
+    gen = torch.Generator().manual_seed(11)
+    host = [[torch.randn(s, generator=gen).pin_memory() for s in feat_shapes(opt, B)] for _ in range(4)]
+    loader = lambda: ({"feats": f} for f in FeaturePrefetcher(iter(host), "cuda:0", depth=3))
+    want = [tr.translate_batch([model], b) for b in loader()]
+    assert len({len(h[0]) for hyps, _ in want for h in hyps}) > 3            # mixed lengths
+    assert want[0] != want[1]                                               # different batches
+    for _ in range(3):                                                      # eager, capture, replay
+        assert list(tr.translate_batches([model], loader())) == want
+    assert list(runner.translate_steps(loader())) == want
+    assert model.engine().idle_hook is None
 
 
 # ----------------------------------------------------------------------------- bf16 mode
@@ -150,7 +188,8 @@ def test_encoding_and_teacher_forced_bf16(golden, mode):
         # the concept path keeps fp32 operands in bf16 mode (hi/lo split products, care_gemm_ln_split):
         # same labels; probabilities and memory within the split's error of the reference
         assert _maxdiff(enc["preds_attr"], z["preds_attr"]) < SPLIT_PREDS
-        assert np.array_equal(enc["semantic_labels"].cpu().numpy(), z["semantic_labels"])
+        if "semantic_labels" in z:
+            assert np.array_equal(enc["semantic_labels"].cpu().numpy(), z["semantic_labels"])
         assert _maxdiff(enc["encoder_hidden_states"][0], z["encoder_hidden_states_clip0"]) < SPLIT_MEM
     else:
         assert _maxdiff(enc["encoder_hidden_states"][0], z["encoder_hidden_states_clip0"]) < bar["max"]
@@ -450,7 +489,8 @@ def test_fp16x3_mode_matches_the_reference(golden):
     if "preds_attr" in z:
         rec["preds_max"] = _maxdiff(out["preds_attr"], z["preds_attr"])
         assert rec["preds_max"] < ATOL_FP32
-        assert np.array_equal(out["semantic_labels"].cpu().numpy(), z["semantic_labels"])
+        if "semantic_labels" in z:
+            assert np.array_equal(out["semantic_labels"].cpu().numpy(), z["semantic_labels"])
     _record(golden.name + "#fp16x3", **rec)
     assert hid < ATOL_FP32 and mem < FP16X3_ATOL, rec  # hidden states at north_star's fp32 bar itself
     assert lse < (2e-3 if "peaked" in golden.name else 1e-4), rec

@@ -35,7 +35,7 @@ def _loss(out, gen_dev, seeds=(11, 12)):
 
 
 @pytest.mark.parametrize("name", ["msrvtt_base_ami_b2", "msrvtt_care_b2", "msrvtt_cabase_b3", "msrvtt_base_ami_eos_b4",
-                                  "care_median_gelu_b2", "base_ami_mte_b2"])
+                                  "care_median_gelu_b2", "base_ami_mte_b2", "msrvtt_care_g1l0_b3", "msrvtt_care_g0l0_b3"])
 def test_training_forward_and_gradients_match_the_oracle_autograd(name):
     from conftest import GoldenCase
     from oracle import care_cpu

@@ -215,6 +215,101 @@ def test_translator_result_assembly_matches_reference_quirks():
     assert scores[2] == [-1.0]
 
 
+def _assemble_per_clip(tr, kind, arrays):
+    """The reference's own loops (Translator.py:211-220 over Beam.sort_finished / get_hypothesis, Beam.py:91-132), clip by
+    clip with python scalars: what the vectorised assembly of care_amd/translator.py must reproduce value for value."""
+    hyps, scores, n_best = [], [], tr.topk
+    if kind == "greedy":
+        length, score, fed = arrays
+        for i in range(len(length)):
+            n = int(length[i])
+            n_best = min(n_best, 1)
+            hyps.append([[int(v) for v in fed[i, 1: n + 1]]][:n_best])
+            scores.append([float(score[i]) / (n ** tr.beam_alpha)][:n_best])
+        return hyps, scores
+    nfin, fscore, flen, fhyp = arrays
+    for i in range(len(nfin)):
+        items = [[float(fscore[i, j]) / (int(flen[i, j]) ** tr.beam_alpha), j] for j in range(int(nfin[i]))]
+        items.sort(key=lambda a: -a[0])
+        n_best = min(n_best, len(items))
+        hyps.append([[int(v) for v in fhyp[i, j, : int(flen[i, j])]] for _, j in items[:n_best]])
+        scores.append([s for s, _ in items[:n_best]])
+    return hyps, scores
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.7, 0.0])
+@pytest.mark.parametrize("topk", [1, 3, 8])
+def test_translator_vectorised_assembly_equals_the_per_clip_loops(alpha, topk):
+    """Random finished lists - ties between scores, clips with fewer finished hypotheses than topk (the n_best shrink),
+    every length 1 .. 29 - through the numpy assembly and through the reference's per-clip loops: identical lists and
+    identical doubles.  Chunked conversion (CHUNK_ROWS) included."""
+    from care_amd.translator import Translator_ARFormer
+
+    tr = Translator_ARFormer({"beam_size": 5, "topk": topk, "beam_alpha": alpha, "max_len": 30})
+    tr.CHUNK_ROWS = 7
+    rng = np.random.default_rng(5 + topk)
+    B, cap, T = 61, max(5, topk) + 5, 29
+    nfin = rng.integers(max(1, topk - 1), cap + 1, size=B).astype(np.int32)
+    nfin[40] = min(2, topk)     # from here on at most two hypotheses per clip
+    fscore = np.round(rng.normal(-20, 6, size=(B, cap)), 0).astype(np.float32)   # rounded: many exact ties
+    flen = rng.integers(1, T + 1, size=(B, cap)).astype(np.int32)
+    fhyp = rng.integers(0, 10547, size=(B, cap, T + 1)).astype(np.int32)
+    got = tr._assemble_beam(nfin, fscore, flen, fhyp)
+    want = _assemble_per_clip(tr, "beam", (nfin, fscore, flen, fhyp))
+    assert got == want
+    assert all(type(s) is float for row in got[1] for s in row) and all(type(t) is int for row in got[0] for h in row for t in h)
+    length = rng.integers(1, T + 1, size=B).astype(np.int32)
+    score = rng.normal(-30, 5, size=B).astype(np.float32)
+    fed = rng.integers(0, 10547, size=(B, T + 1)).astype(np.int32)
+    assert tr._assemble_greedy(length, score, fed) == _assemble_per_clip(tr, "greedy", (length, score, fed))
+
+
+def test_translate_batches_is_translate_batch_one_batch_behind():
+    """The pipelined entry on a stand-in engine (host tensors): same results in the same order; a second
+    stand-in whose pass waits on the host calls engine.idle_hook there, and the previous batch's lists are built in those waits."""
+    from care_amd.translator import Translator_ARFormer
+    from care_amd.framework import TransformerSeq2Seq
+
+    tr = Translator_ARFormer({"beam_size": 1, "topk": 1, "beam_alpha": 1.0, "max_len": 30})
+
+    class FakeEngine:
+        T = 29
+
+        def translate_greedy(self, feats, use_graph=True, lean=False):
+            B = feats[0].shape[0]
+            g = torch.Generator().manual_seed(B)
+            return (None, torch.randint(4, 99, (B, 30), generator=g, dtype=torch.int32),
+                    torch.randint(1, 30, (B,), generator=g, dtype=torch.int32), -torch.rand(B, generator=g))
+
+    class FakeModel(TransformerSeq2Seq):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+
+        def engine(self):
+            return FakeEngine()
+
+    model = FakeModel()
+    batches = [{"feats": [torch.zeros(b, 1, 1)]} for b in (3, 9, 2, 17)]
+    one_by_one = [tr.translate_batch([model], b) for b in batches]
+    assert list(tr.translate_batches([model], iter(batches))) == one_by_one
+    assert [len(h) for h, _ in one_by_one] == [3, 9, 2, 17]
+
+    class WaitingEngine(FakeEngine):
+        idle_hook = None
+        pieces = 0
+
+        def translate_greedy(self, feats, use_graph=True, lean=False):
+            while self.idle_hook is not None and self.idle_hook():   # what engine._host_count does between two segments
+                WaitingEngine.pieces += 1
+            return FakeEngine.translate_greedy(self, feats, use_graph, lean)
+
+    eng = WaitingEngine()
+    model.engine = lambda: eng
+    tr.CHUNK_ROWS = 2
+    assert list(tr.translate_batches([model], iter(batches))) == one_by_one
+    assert WaitingEngine.pieces >= (3 + 9 + 2) // 2 and eng.idle_hook is None
+
+
 def test_sharding_bounds_and_records():
     from care_amd.sharding import pack_records, shard_bounds, unpack_records
 
