@@ -538,6 +538,32 @@ def extra_legs(dev, main_dtype, legs):
     legs["api_beam5_B128"] = api_leg("msrvtt_care_beam5", 128, 5, 16, 32)    # translate.py's defaults (translate.py:137,144)
     legs["api_greedy_B32768"] = api_leg("msrvtt_base_ami", 32768, 1, 4, 4)
 
+    # ---- 16-bit agreement at the size of the MSRVTT test split (2990 clips; notebooks/retrieval_robustness.ipynb:188): the
+    # peaked CARE model (a softmax as peaked as a trained model's) through the Translator at translate.py's batch of 128
+    # (the resident launches), greedy and beam 5: captions identical to those of the engine's fp32 mode, per 16-bit mode.
+    # (fp32 mode is identical to the reference on every fixture; tests/test_gpu_scale.py holds the same 2990 clips to the CPU
+    # oracle and audits every differing clip as a near-tie of the reference's own distribution.)
+    opt, eng = build("msrvtt_care", "fp32", row_scale={"cls_head.tgt_word_prj.weight": {**{r: 12.0 for r in range(6, 46)}, 3: 20.0}})
+    model_s = eng_model[0]
+    n_test = 2990
+    gen = torch.Generator().manual_seed(373)
+    host_feats = [torch.randn(sh, generator=gen) for sh in feat_shapes(opt, n_test)]
+    dev_batches = [{"feats": [f[lo: lo + 128].to(dev) for f in host_feats]} for lo in range(0, n_test, 128)]
+    agree = {}
+    for beam in (1, 5):
+        tr = get_translator(dict(opt, beam_size=beam, topk=1))
+        caps = {}
+        for mode in ("fp32", "fp16", "bf16"):
+            model_s.set_compute_dtype(mode)
+            caps[mode] = [h[0] for hyps, _ in tr.translate_batches([model_s], iter(dev_batches)) for h in hyps]
+        agree["greedy" if beam == 1 else "beam5"] = {m: sum(int(a == b) for a, b in zip(caps[m], caps["fp32"])) for m in ("fp16", "bf16")}
+        agree["mean_caption_length_" + ("greedy" if beam == 1 else "beam5")] = round(sum(len(c) for c in caps["fp32"]) / n_test, 2)
+    legs["msrvtt_test_scale_agreement"] = dict(
+        config="msrvtt_care (peaked rows)", clips=n_test, batch=128, through="get_translator(opt).translate_batches",
+        reference="the engine's fp32 mode (identical to the reference on every fixture; held to the CPU oracle on these clips "
+                  "by tests/test_gpu_scale.py)", identical_captions=agree)
+    del model_s, dev_batches, host_feats
+
     # the error of the throughput mode: teacher-forced hidden states, bf16 mode against fp32 mode of this
     # same engine (fp32 mode is within 1e-5 of the reference, tests/test_gpu_parity.py) on the benchmarked model
     if main_dtype == "bf16":
@@ -824,6 +850,12 @@ def main():
             legs["error"] = "{}: {}".format(type(exc).__name__, exc)
             legs["error_where"] = traceback.format_exc().strip().splitlines()[-3:]
         line["legs"] = legs
+        # the same workload in the default 16-bit mode (`fp16`: model.set_compute_dtype("half")) beside the bf16 headline
+        # BASELINE.json names, and what the boundary costs (legs api_*)
+        if "msrvtt_base_ami_fp16" in legs:
+            line["config"]["fp16_mode_captions_per_s"] = legs["msrvtt_base_ami_fp16"]["captions_per_s"]
+        if "api_greedy_B32768" in legs:
+            line["config"]["through_translate_batches_captions_per_s"] = legs["api_greedy_B32768"]["api_pipelined_captions_per_s"]
     print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -64,6 +64,18 @@ def collate_feats(per_video: Sequence[List[np.ndarray]]) -> List[torch.Tensor]:
     return [torch.from_numpy(np.stack([v[m] for v in per_video], axis=0)) for m in range(n_mod)]
 
 
+FP16_MAX = 65504.0
+
+
+def fp16_range_ok(feats: Sequence[torch.Tensor], margin: float = 0.5) -> bool:
+    """Whether a batch's raw features fit the `fp16` compute mode: every |x| below margin x 65504 (the embedder rounds
+    features to IEEE half as it multiplies them; every other 16-bit tensor of the path is a LayerNorm output, an attention
+    context, a projected key / value or an FFN hidden value - O(1 .. 100) whatever the input).  A loader-side check (one
+    reduction per tensor, on the host or the device the tensors live on) - not part of the decode pass.  Post-ReLU CNN /
+    ViT features are O(10); features that fail belong in `bf16` mode (8 exponent bits, no bound)."""
+    return all(bool(torch.isfinite(f).all()) and float(f.abs().max()) < margin * FP16_MAX for f in feats if f.numel())
+
+
 class FeaturePrefetcher:
     """Double-buffered pinned staging + asynchronous H2D on a side stream.
 

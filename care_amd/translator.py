@@ -48,7 +48,7 @@ class _Pending:
 class Translator_ARFormer(object):
     # rows of a result array converted to python lists per piece of the assembly: small enough (~0.2 ms) that a piece
     # run inside a pass's host wait (engine.idle_hook) does not delay that pass's next segment
-    CHUNK_ROWS = 256
+    CHUNK_ROWS = 512
 
     def __init__(self, opt: dict = {}):
         self.beam_size = opt.get("beam_size", 5)
@@ -305,6 +305,11 @@ class Translator_ARFormer(object):
         finally:
             if was:
                 gc.enable()
+        if was and B >= 4096:
+            # the collector's look at the ~3 B new lists happens HERE, as a piece of its own - in the pipelined entry inside the
+            # next pass's host wait - instead of at whatever allocation of the caller's crosses the threshold next
+            yield
+            gc.collect(1)
         return hyps, scores
 
     def _assemble_beam_gen(self, nfin, fscore, flen, fhyp):
