@@ -171,6 +171,27 @@ def kernel_model(tag, eng, B, dtype):
     return None
 
 
+def small_batch_roofline(eng, clips, beam, step_us):
+    """A decoder step of a resident launch against a STATED floor: every byte a step must read once -
+    decoder + vocabulary weights (16-bit), the clips' static K/V (shared by the beams of a clip), the rows' self-attention
+    cache so far - at the 6 TB/s this part sustains, or its FLOPs at the dense 16-bit MFMA peak, whichever is longer, PLUS the
+    hand-offs of the step's dependent phases at the measured floor of a device-wide counter hand-off (1.9 us: two-level
+    counters, profiles/r03_barrier_bench.txt).  frac = floor / measured step; what separates them is named in DESIGN.md 5.1."""
+    d, ff, V, Lk, T, nl = eng.d, eng.ff, eng.V, eng.Lk, eng.T, eng.n_layers
+    rows = clips * beam
+    n_att = 2 if eng.attr_att else 1
+    wbytes = nl * (3 * d * d + d * d + n_att * 2 * d * d + 2 * d * ff) * 2 + V * d * 2
+    kv = nl * (clips * 2 * Lk * d * 2 + rows * 2 * ((T + 1) / 2) * d * 2)
+    flops = rows * 2.0 * (nl * (4 * d * d + n_att * 2 * d * d + 2 * d * ff) + d * V + nl * (2 * Lk * d + (T + 1) * d))
+    handoffs = nl * (3 + 3 * n_att + 2) + 1 + (1 if beam > 1 else 0)
+    hbm_us, mfma_us, ho_us = (wbytes + kv) / 6.0e12 * 1e6, flops / (MFMA_PEAK_TF["bf16"] * 1e12) * 1e6, handoffs * 1.9
+    floor = max(hbm_us, mfma_us) + ho_us
+    return dict(bound="latency: dependent phase hand-offs + hbm", model="max(bytes / 6 TB/s, flops / 2.5 PFLOP/s) + hand-offs x 1.9 us",
+                bytes_per_step=int(wbytes + kv), flops_per_step=int(flops), hbm_us=round(hbm_us, 2), mfma_us=round(mfma_us, 2),
+                handoffs_per_step=handoffs, handoff_floor_us=1.9, floor_us=round(floor, 2), achieved_us=round(step_us, 2),
+                frac=round(floor / step_us, 4), unit="us per decoder step (whole pass / steps: the encoder's share included)")
+
+
 def _timed(fn, iters):
     """Seconds per call of fn (already warmed up)."""
     torch.cuda.synchronize()
@@ -218,8 +239,11 @@ def extra_legs(dev, main_dtype, legs):
         for _ in range(3):
             run()
         dt = _timed(run, iters)
-        return dict(config=config, dtype=dtype, clips_per_step=B, captions_per_s=round(B / dt, 1),
-                    ms_per_pass=round(dt * 1e3, 3), decoder_step_us=round(dt * 1e6 / eng.T, 2)), eng, feats, opt
+        leg = dict(config=config, dtype=dtype, clips_per_step=B, captions_per_s=round(B / dt, 1),
+                   ms_per_pass=round(dt * 1e3, 3), decoder_step_us=round(dt * 1e6 / eng.T, 2))
+        if eng.last_decode.get("resident"):
+            leg["roofline"] = small_batch_roofline(eng, B, 1, dt * 1e6 / eng.T)
+        return leg, eng, feats, opt
 
     # BASELINE configs[2]: the concept-guided (CARE) path
     legs["msrvtt_care_greedy"] = greedy_leg("msrvtt_care", main_dtype, 16384)[0]
@@ -259,6 +283,8 @@ def extra_legs(dev, main_dtype, legs):
                                                   rows_per_decoder_step=5 * B, captions_per_s=round(B / dt, 1),
                                                   ms_per_pass=round(dt * 1e3, 3), decoder_step_us=round(dt * 1e6 / eng.T, 2),
                                                   resident_launch=bool(eng.last_decode.get("resident")))
+        if eng.last_decode.get("resident"):
+            legs["msrvtt_care_beam5_B%d" % B]["roofline"] = small_batch_roofline(eng, B, 5, dt * 1e6 / eng.T)
         if B == 1:
             legs["msrvtt_care_beam5_B1"]["ms_per_caption"] = round(dt * 1e3, 3)
     # ---- batch sweep (B in {1, 64, 128, 256, 1024, 4096}; translate.py:136 lets a user pick any
@@ -306,6 +332,8 @@ def extra_legs(dev, main_dtype, legs):
     legs["vatex_care_large_beam5_B32"] = dict(config="vatex_care_large", dtype=main_dtype, clips_per_step=32, beam_size=5,
                                               rows_per_decoder_step=160, captions_per_s=round(32 / dt, 1), ms_per_pass=round(dt * 1e3, 3),
                                               decoder_step_us=round(dt * 1e6 / eng.T, 2), resident_launch=bool(eng.last_decode.get("resident")))
+    if eng.last_decode.get("resident"):
+        legs["vatex_care_large_beam5_B32"]["roofline"] = small_batch_roofline(eng, 32, 5, dt * 1e6 / eng.T)
     # a model that ENDS its captions (EOS row of the vocabulary projection x 5: mixed lengths, mean ~8 like trained
     # captions; random-init weights never emit EOS): early termination + compaction against the fixed 29 steps
     boost = {"cls_head.tgt_word_prj.weight": {3: 5.0}}

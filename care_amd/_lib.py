@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -34,6 +34,10 @@ SIGNATURES = {
     "care_split2_act": [_P, _L, _P, _I, _I, _P],
     "care_gemm_tile_split3": [_P, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_gemm_tile_split3_argmax": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "care_absmax": [_P, _L, _I, _I, _P, _P],
+    "care_split2_act_scaled": [_P, _L, _P, _I, _I, _P, _P],
+    "care_split3_weight_scaled": [_P, _L, _P, _I, _I, _P, _P],
+    "care_gemm_tile_split3_scaled": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P],
     "care_gemm_tile_batched": [_P, _L, _L, _P, _L, _L, _P, _I, _P, _L, _L, _I, _I, _I, _I, _I, _P],
     "care_gemm_tile_argmax": [_P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "care_score_partials": [_P, _P, _P, _P, _I, _P, _P, _I, _P],

@@ -34,6 +34,7 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
   const bool participant = (int)blockIdx.x < p.nclips;
   float (*s_cv)[RES_BMK] = reinterpret_cast<float (*)[RES_BMK]>(scratch_lds);
   int (*s_ci)[RES_BMK] = reinterpret_cast<int (*)[RES_BMK]>(scratch_lds + 8 * RES_BMK * 4);
+  int* s_tok = reinterpret_cast<int*>(scratch_lds + 16 * RES_BMK * 4);  // the tokens just chosen, slot by slot (RES_BEAM_LDS bytes in all)
   if (gs.dead) return nprod;
   if (participant) gs.wait();
   if (gs.dead) return nprod;
@@ -282,7 +283,7 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
           if (i < bm) {
             const int64_t o = (int64_t)(row0 + i) * stride;
             if (lane < t) cst_i(anc_new + o + lane, st_anc[i]);
-            if (lane == 0) { cst_i(anc_new + o + t, row0 + i); cst_i(p.fed + o + t, p.eos); }
+            if (lane == 0) { cst_i(anc_new + o + t, row0 + i); cst_i(p.fed + o + t, p.eos); s_tok[i] = p.eos; }
           }
       } else {
         // candidate pool, lane = i * bm + j: (value, flat index i * V + col); ended beams offer nothing
@@ -352,7 +353,7 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
           if (i < bm) {
             const int64_t dst = (int64_t)(row0 + i) * stride;
             if (lane < t) cst_i(anc_new + dst + lane, anew[i]);
-            if (lane == 0) { cst_i(anc_new + dst + t, row0 + i); cst_i(p.fed + dst + t, tok[i]); cst_f(p.score + row0 + i, sc[i]); }
+            if (lane == 0) { cst_i(anc_new + dst + t, row0 + i); cst_i(p.fed + dst + t, tok[i]); cst_f(p.score + row0 + i, sc[i]); s_tok[i] = tok[i]; }
           }
         // finished hypotheses, in beam order, stop as soon as `need` are collected (Beam.py:72-77)
         int nf = st_nf;
@@ -402,9 +403,53 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
         }
       }
     }
-    if (c + G < p.nclips) __syncthreads();  // (s_cv is written again)
+    if (t < p.T) {
+      // the input rows of step t + 1, once per row: embedding + LayerNorm of the tokens just chosen (embed_ln_store_row), four
+      // rows per wave side by side; the rows of a clip that is done embed the EOS its table carries - defined bytes, ignored
+      __syncthreads();
+      if (wave * 4 < bm) {
+        const int i = wave * 4 + (lane >> 4);
+        embed_ln_store_row<D>(p, row0 + i, i < bm, s_tok[i < bm ? i : 0], t);
+      }
+    }
+    if (c + G < p.nclips) __syncthreads();  // (s_cv / s_tok are written again)
   }
   gs.mark();
+  gs.arrive(participant);
+  return nprod;
+}
+
+constexpr int RES_BEAM_LDS = 16 * RES_BMK * 4 + 8 * 4;  // s_cv + s_ci + s_tok of beam_advance_phase
+
+// Before step 1: the state of every clip's rows as the host-side initialisation of engine.beam leaves it - token table
+// [BOS, EOS ...], both ancestor tables = the row itself, scores 0, the clip's flags and (zeroed) finished lists - and the
+// input rows of step 1 (BOS at position 0 + the clip's guidance vector, normalised).  One workgroup per clip, like the advance.
+template <int D = 512>
+RES_PHASE_FN unsigned beam_init_phase(const RArgs& p, GridSync& gs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int G = gridDim.x, bm = p.bm, stride = p.fed_stride;
+  const unsigned nprod = (unsigned)(p.nclips < G ? p.nclips : G);
+  const bool participant = (int)blockIdx.x < p.nclips;
+  if (gs.dead) return nprod;
+  for (int c = blockIdx.x; c < p.nclips; c += G) {
+    const int row0 = c * bm;
+    for (int i = wave; i < bm; i += 4) {
+      const int r = row0 + i;
+      for (int col = lane; col <= p.T; col += 64) {
+        cst_i(p.fed + (int64_t)r * stride + col, col == 0 ? p.bos : p.eos);
+        cst_i(p.anc[0] + (int64_t)r * stride + col, r);
+        cst_i(p.anc[1] + (int64_t)r * stride + col, r);
+      }
+      if (lane == 0) cst_f(p.score + r, 0.f);
+    }
+    if (threadIdx.x == 0) { cst_i(p.done + c, 0); cst_i(p.nfin + c, 0); }
+    for (int k = threadIdx.x; k < p.fin_cap; k += 256) { cst_f(p.fscore + (int64_t)c * p.fin_cap + k, 0.f); cst_i(p.flen + (int64_t)c * p.fin_cap + k, 0); }
+    for (int k = threadIdx.x; k < p.fin_cap * stride; k += 256) cst_i(p.fhyp + (int64_t)c * p.fin_cap * stride + k, 0);
+    if (wave * 4 < bm) {
+      const int i = wave * 4 + (lane >> 4);
+      embed_ln_store_row<D>(p, row0 + i, i < bm, p.bos, 0);
+    }
+  }
   gs.arrive(participant);
   return nprod;
 }

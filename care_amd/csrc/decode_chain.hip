@@ -62,9 +62,14 @@ __global__ __launch_bounds__(256, NKB > 8 ? 1 : 2) void chain_attn_shared_kernel
 }
 
 __global__ __launch_bounds__(256, 1) void chain_advance_kernel(RArgs p, int t) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[8 * RES_BMK * 4 * 2];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(RES_BEAM_LDS + 15) / 16 * 16];
   GridSync gs = chain_sync(p);
   beam_advance_phase(p, gs, t, smem);
+}
+
+__global__ __launch_bounds__(256, 1) void chain_init_kernel(RArgs p) {
+  GridSync gs = chain_sync(p);
+  beam_init_phase(p, gs);
 }
 
 // grid of a GEMM phase: 8 XCD slots x row groups x column-item slots per XCD (PhaseMap: workgroup b -> XCD b & 7, slot
@@ -145,7 +150,8 @@ int care_decode_chain_beam(const care_resident_layer* layers, int n_layers, cons
   p.psum = (float*)b; b += R16 * maxparts * 4;
   p.gval = (float*)b; b += R16 * maxparts * RES_BMK * 4;
   p.ggid = (int32_t*)b; b += R16 * maxparts * RES_BMK * 4;
-  p.hn = (bf16_t*)b;
+  p.hn = (bf16_t*)b; b += R16 * d * 2;
+  p.xa = (bf16_t*)b;
 
   // Forms by row count (CARE_CHAIN_CFG / `form` >= 0 force one), the resident beam launch's (same bits in every form of a
   // phase, see gemm_phase): 0 (<= 64 rows) K-split items everywhere, FFN dense2 over two workgroups per column tile;
@@ -186,6 +192,7 @@ int care_decode_chain_beam(const care_resident_layer* layers, int n_layers, cons
   const bf16_t* nob = nullptr;
   const float* nof = nullptr;
 
+  if (t0 == 1) CH_LAUNCH(chain_init_kernel, clips, 0, p);  // the clips' state + the input rows of step 1
   for (int t = t0; t <= t1; ++t) {
     const int32_t* anc_old = p.anc[(t - 1) & 1];
     for (int l = 0; l < p.n_layers; ++l) {
@@ -194,14 +201,14 @@ int care_decode_chain_beam(const care_resident_layer* layers, int n_layers, cons
       // ---- QKV (+ embedding / LayerNorm on load)
       {
         const int N = 3 * d, CI = sm ? (N + 15) / 16 : (N + 63) / 64, RG = (RT + rq - 1) / rq, G = gemm_grid(RG, CI, 0);
-        const void* asrc = l == 0 ? nullptr : (const void*)p.y;
+        const void* asrc = l == 0 ? (const void*)p.xa : (const void*)p.y;  // (layer 0: embedded + normalised by the advance / init kernel)
         const float* g = l == 0 ? p.emb_g : p.L[l - 1].fg;
         const float* be = l == 0 ? p.emb_be : p.L[l - 1].fbe;
         const float* a2 = l == 0 ? nof : y2;
         if (l == 0) {
-          if (sm) CH_LAUNCH((chain_gemm_kernel<512, A_EMBEDB, E_QKV, true, 1, 512, 2>), G, lds_a(1, 512), p, L.qkv_w, L.qkv_b, N, asrc, g, be, 1, t, L.skv, a2);
-          else if (rq == 1) CH_LAUNCH((chain_gemm_kernel<512, A_EMBEDB, E_QKV, false, 1, 512, 2>), G, lds_a(1, 512), p, L.qkv_w, L.qkv_b, N, asrc, g, be, 1, t, L.skv, a2);
-          else CH_LAUNCH((chain_gemm_kernel<512, A_EMBEDB, E_QKV, false, 2, 512, 2>), G, lds_a(2, 512), p, L.qkv_w, L.qkv_b, N, asrc, g, be, 1, t, L.skv, a2);
+          if (sm) CH_LAUNCH((chain_gemm_kernel<512, A_BF16, E_QKV, true, 1, 512, 2>), G, lds_a(1, 512), p, L.qkv_w, L.qkv_b, N, asrc, nof, nof, 0, t, L.skv, nof);
+          else if (rq == 1) CH_LAUNCH((chain_gemm_kernel<512, A_BF16, E_QKV, false, 1, 512, 2>), G, lds_a(1, 512), p, L.qkv_w, L.qkv_b, N, asrc, nof, nof, 0, t, L.skv, nof);
+          else CH_LAUNCH((chain_gemm_kernel<512, A_BF16, E_QKV, false, 2, 512, 2>), G, lds_a(2, 512), p, L.qkv_w, L.qkv_b, N, asrc, nof, nof, 0, t, L.skv, nof);
         } else {
           if (sm) CH_LAUNCH((chain_gemm_kernel<512, A_LN, E_QKV, true, 1, 512, 2>), G, lds_a(1, 512), p, L.qkv_w, L.qkv_b, N, asrc, g, be, 1, t, L.skv, a2);
           else if (rq == 1) CH_LAUNCH((chain_gemm_kernel<512, A_LN, E_QKV, false, 1, 512, 2>), G, lds_a(1, 512), p, L.qkv_w, L.qkv_b, N, asrc, g, be, 1, t, L.skv, a2);

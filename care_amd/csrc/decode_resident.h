@@ -43,6 +43,8 @@ struct RArgs {
   int vcap;                    // workgroups of the vocabulary phase (PhaseMap gcap): parts <= 48
   int fenced;                  // hand-offs with an agent-scope release / acquire pair (GridSync; care_resident_set_fenced)
   bf16_t* hn;                  // the normalised last hidden rows (bf16 [R16, 512]): the B operand of the recomputed logits
+  bf16_t* xa;                  // beam search: the embedded + normalised input rows of the NEXT step (bf16 [R16, d]), written by the
+                               // phase that chooses the tokens (beam_advance_phase / beam_init_phase): the QKV phase's A operand
 };
 
 // The argument block of a resident launch is ~150 pointers and sizes.  Taken by value into a kernel whose step loop calls
@@ -770,6 +772,77 @@ __device__ __forceinline__ void finish_a_rows(const RArgs& p, int r0, const floa
     *reinterpret_cast<bf16x4*>(dst + 64 * k) = ob;
     if (live && ((write_x >> (k & 7)) & 1u)) cst_f4(p.xres + (int64_t)r * d + sub * 4 + 64 * k, o);
     if (live && ((write_hn >> (k & 7)) & 1u)) cst_b4(p.hn + (int64_t)r * d + sub * 4 + 64 * k, ob);
+  }
+}
+
+// LayerNorm ONCE (round 6): Embeddings.forward (models/components/Embeddings.py:134-188) of ONE row per 16-lane DPP row - the
+// word row of `tok`, position `tpos`, the clip's guidance vector, LayerNorm - stored as the fp32 residual row (xres) and the
+// bf16 row the QKV phase multiplies (xa).  Called by the phase that CHOOSES the token (beam search: one workgroup per clip),
+// so the ~250 workgroups of the next QKV phase load 1 KB of finished bf16 per row instead of each repeating token -> word row
+// -> statistics for its 16 - 64 rows (*measured* round 5, 640 rows: 10.3 us of that phase).  Layout and arithmetic are
+// fetch_a_rows<A_EMBEDB> + finish_a_rows: lane `sub` of the row holds columns 4 sub + 64 k.
+template <int D = 512>
+__device__ __forceinline__ void embed_ln_store_row(const RArgs& p, int row, bool valid, int tok, int tpos) {
+  const int sub = threadIdx.x & 15;
+  constexpr int NV = D / 64;
+  const int rc = valid ? row : 0;
+  // every field of the argument block ONCE (each use of `p` is a scalar load of its own, in program order: res_args) and every
+  // vector load - word, position and guidance rows, LayerNorm weights - requested before the first is used: one memory round
+  // trip for the whole row.  (The first version read gamma / beta inside the store loop: eight dependent round trips, 10 us.)
+  const float* word = p.word; const float* pos = p.pos; const float* sem = p.sem; const int sem_div = p.sem_div;
+  const float* eg = p.emb_g; const float* eb = p.emb_be; const float eps = p.eps;
+  float* xres = p.xres; bf16_t* xa = p.xa;
+  float4 v[NV], pv[NV], sv[NV], gg[NV], bb[NV];
+  const float* pp = pos + (int64_t)tpos * D + sub * 4;
+  const float* w = word + (int64_t)(valid ? tok : 0) * D + sub * 4;
+  const float* sm = sem ? sem + (int64_t)(rc / sem_div) * D + sub * 4 : pp;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    v[k] = *reinterpret_cast<const float4*>(w + 64 * k);
+    pv[k] = *reinterpret_cast<const float4*>(pp + 64 * k);
+    sv[k] = *reinterpret_cast<const float4*>(sm + 64 * k);
+    if constexpr (D <= 512) {
+      gg[k] = *reinterpret_cast<const float4*>(eg + sub * 4 + 64 * k);
+      bb[k] = *reinterpret_cast<const float4*>(eb + sub * 4 + 64 * k);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    add4(v[k], pv[k]);
+    if (sem) add4(v[k], sv[k]);
+  }
+  if constexpr (D > 512) {  // (d_model 768 / 1024: five row images at once are 240 - 320 registers; the weights travel under the statistics)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      gg[k] = *reinterpret_cast<const float4*>(eg + sub * 4 + 64 * k);
+      bb[k] = *reinterpret_cast<const float4*>(eb + sub * 4 + 64 * k);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  const float mean = row16_sum(s) * (1.0f / D);
+  float qq = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, e = v[k].w - mean;
+    qq += (a * a + b * b) + (cc * cc + e * e);
+  }
+  const float var = row16_sum(qq) * (1.0f / D);
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float4 o;
+    o.x = (v[k].x - mean) * rstd * gg[k].x + bb[k].x;
+    o.y = (v[k].y - mean) * rstd * gg[k].y + bb[k].y;
+    o.z = (v[k].z - mean) * rstd * gg[k].z + bb[k].z;
+    o.w = (v[k].w - mean) * rstd * gg[k].w + bb[k].w;
+    bf16x4 ob;
+    ob[0] = (bf16_t)o.x; ob[1] = (bf16_t)o.y; ob[2] = (bf16_t)o.z; ob[3] = (bf16_t)o.w;
+    if (valid) {
+      cst_f4(xres + (int64_t)row * D + sub * 4 + 64 * k, o);
+      cst_b4(xa + (int64_t)row * D + sub * 4 + 64 * k, ob);
+    }
   }
 }
 

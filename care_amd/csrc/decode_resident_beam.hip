@@ -58,6 +58,12 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p_by
     ++sl;                                   \
   } while (0)
   int t_run = 0;
+  {  // the clips' state and the input rows of step 1 (beam_init_phase): a hand-off slot of its own, run once
+    gs.prev = 0; gs.want = 0u; gs.cur = RES_MAX_SLOTS - 1;
+    np_prev = beam_init_phase<D>(p, gs);
+    sl_prev = RES_MAX_SLOTS - 1;
+    ex_prev = 1u;
+  }
   for (int t = 1; t <= p.steps && !gs.dead; ++t) {
     gs.slot = (p.prof_step == t && blockIdx.x == 0) ? 0 : -1;
     sl = 0;
@@ -99,7 +105,8 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p_by
     t_run = t;
     for (int l = 0; l < p.n_layers; ++l) {
       const RLayer& L = p.L[l];
-      if (l == 0) RES_PHASE((gemm_phase<D, A_EMBEDB, E_QKV, SM, RQ, D>(p, gs, !first_waited, sA, L.qkv_w, L.qkv_b, 3 * d, nullptr, p.emb_g, p.emb_be, true, t, L.skv)));
+      // (layer 0: the rows come embedded and normalised from the phase that chose their tokens - p.xa, the residual in p.xres)
+      if (l == 0) RES_PHASE((gemm_phase<D, A_BF16, E_QKV, SM, RQ, D>(p, gs, !first_waited, sA, L.qkv_w, L.qkv_b, 3 * d, p.xa, nullptr, nullptr, false, t, L.skv)));
       else RES_PHASE((gemm_phase<D, A_LN, E_QKV, SM, RQ, D>(p, gs, true, sA, L.qkv_w, L.qkv_b, 3 * d, p.y, p.L[l - 1].fg, p.L[l - 1].fbe, true, t, L.skv, y2)));
       RES_PHASE((p.T <= 32 ? attn_phase<true, 4, true, D>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0, p.anc[(t - 1) & 1])
                             : attn_phase<true, RES_MAXKB, true, D>(p, gs, true, L.skv, (int64_t)p.T * 2 * d, 1, t, p.fed, nullptr, 0, p.anc[(t - 1) & 1])));
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p_by
     }
     const RLayer& LL = p.L[p.n_layers - 1];
     RES_PHASE((gemm_phase<D, A_LN, E_VOCABK, WIDE, RV, D>(p, gs, true, sA, p.vocab, nullptr, p.V, p.y, LL.fg, LL.fbe, false, t, nullptr, y2, p.vcap)));
-    RES_PHASE((beam_advance_phase<D>(p, gs, t, smem)));
+    RES_PHASE((beam_advance_phase<D>(p, gs, t, smem)));  // (+ the input rows of step t + 1)
   }
 #undef RES_PHASE
   if (gs.dead) {  // aborted (GridSync::wait): every clip's count of finished hypotheses = -1
@@ -160,7 +167,7 @@ int64_t care_decode_resident_beam_scratch(int clips, int beam, int d, int ff, in
   if (parts > 64 * RES_NP) parts = 64 * RES_NP;
   // sync | xres, y, y2, q fp32 [R16, d] | ctx bf16 [R16, d] | h bf16 [R16, ff] | pmax, pidx, psum [R16, parts] |
   // gval, ggid [R16, parts, RES_BMK] | hn bf16 [R16, d]
-  return RES_SYNC_BYTES + R16 * d * 4 * 4 + R16 * d * 2 + R16 * ff * 2 + R16 * parts * 12 + R16 * parts * RES_BMK * 8 + R16 * d * 2;
+  return RES_SYNC_BYTES + R16 * d * 4 * 4 + R16 * d * 2 + R16 * ff * 2 + R16 * parts * 12 + R16 * parts * RES_BMK * 8 + R16 * d * 2 * 2;  // (... | xa bf16 [R16, d])
 }
 
 int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, const float* word, const float* pos,
@@ -214,7 +221,8 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   p.psum = (float*)b; b += R16 * maxparts * 4;
   p.gval = (float*)b; b += R16 * maxparts * RES_BMK * 4;
   p.ggid = (int32_t*)b; b += R16 * maxparts * RES_BMK * 4;
-  p.hn = (bf16_t*)b;
+  p.hn = (bf16_t*)b; b += R16 * d * 2;
+  p.xa = (bf16_t*)b;
 
   int dev = 0, cus = 0;
   hipError_t e = hipGetDevice(&dev);

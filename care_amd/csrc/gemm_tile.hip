@@ -66,7 +66,20 @@ struct TArgs {
   int tiles_m, tiles_n, group;  // group: row tiles per band of the block -> tile map
   int a_wrap;  // K steps (of 64) after which the A columns start over: see care_gemm_tile_split3 (INT_MAX otherwise)
   int64_t a_bs, w_bs, c_bs; int bias_bs;  // batched launches (blockIdx.y): element offsets per batch of A, W, C0, bias
+  // split products of PRE-SCALED operands (care_gemm_tile_split3_scaled): the |max| bit patterns the two operands' power-of-two
+  // scales were derived from (care_absmax); the epilogue multiplies the accumulators by 1 / (scale_a scale_b).  NULL: no scaling.
+  const unsigned* amax_a; const unsigned* amax_b;
 };
+
+// The power of two that brings a tensor's largest magnitude into [2^14, 2^15) - the top of fp16's range, so that the LOW piece
+// of a hi / lo split (<= 2^-11 of its element) stays a normal fp16 number for every element within 2^-14 of the largest:
+// gradients of ~1e-6 split as exactly as activations of ~1.  bits = the fp32 pattern of the maximum (care_absmax); zero,
+// denormal or non-finite maxima: no scaling.  pow2_unscale: the reciprocal of the product of two such scales.
+__device__ __forceinline__ int pow2_scale_exp(unsigned bits) {
+  const int E = (int)(bits >> 23) & 255;
+  return (E == 0 || E == 255) ? 0 : min(max(141 - E, -100), 100);
+}
+__device__ __forceinline__ float pow2_of(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
 
 enum { EPI_STORE = 0, EPI_ARGMAX = 1, EPI_ARGMAX_LAB = 2, EPI_BEAM = 3 };
 
@@ -118,6 +131,11 @@ __device__ __forceinline__ void tile_epilogue(const TArgs& p, f32x4 (&acc)[MT][4
           if (col0 + j < p.N) bv[j] = p.bias[col0 + j];
       }
     }
+    float alpha = 1.0f;
+    if (p.amax_a) {  // (kernel-uniform) pre-scaled split operands: back to the true magnitude, exactly (a power of two)
+      const int ea = pow2_scale_exp(*p.amax_a), eb = pow2_scale_exp(*p.amax_b);
+      alpha = pow2_of(-ea) * pow2_of(-eb);
+    }
     const bool second = col0 >= p.n_split;  // n_split % 16 == 0: a lane's 16 columns never straddle it
     unsigned char* C = reinterpret_cast<unsigned char*>(second ? p.C1 : p.C0);
     const int64_t ld = second ? p.ldc1 : p.ldc0;
@@ -145,7 +163,7 @@ __device__ __forceinline__ void tile_epilogue(const TArgs& p, f32x4 (&acc)[MT][4
       for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float x = acc[m][n][j] + bv[4 * n + j];
+          float x = (p.amax_a ? acc[m][n][j] * alpha : acc[m][n][j]) + bv[4 * n + j];
           if constexpr (GELU) x = t_gelu(x);
           else x = p.act == CARE_ACT_RELU ? fmaxf(x, 0.0f) : x;
           v[4 * n + j] = x;
@@ -540,13 +558,18 @@ extern "C" int care_gemm_tile_batched(const void* A, int64_t lda, int64_t a_bs, 
   return t256 >= 128 ? launch_tile<4, 4, 1, 2, EPI_STORE>(p, st, batch) : launch_tile<2, 2, 1, 2, EPI_STORE>(p, st, batch);
 }
 
-// fp32 [M, K] -> fp16 pieces [M, 2K]: x_hi = fp16(x) | x_lo = fp16(x - x_hi)
-__global__ void split2_act_kernel(const float* A, int64_t lda, _Float16* out, int M, int K) {
+// fp32 [M, K] -> fp16 pieces [M, 2K]: x_hi = fp16(x) | x_lo = fp16(x - x_hi); amax != NULL: of x * the power-of-two scale of
+// pow2_scale_exp (exact in fp32)
+__global__ void split2_act_kernel(const float* A, int64_t lda, _Float16* out, int M, int K, const unsigned* amax) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 each
   const int kq = K >> 2;
   if (i >= (int64_t)M * kq) return;
   const int r = (int)(i / kq), c = (int)(i % kq) * 4;
-  const f32x4 v = *reinterpret_cast<const f32x4*>(A + (int64_t)r * lda + c);
+  f32x4 v = *reinterpret_cast<const f32x4*>(A + (int64_t)r * lda + c);
+  if (amax) {
+    const float sc = pow2_of(pow2_scale_exp(*amax));
+    v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc;
+  }
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   f16x4 hi, lo;
 #pragma unroll
@@ -561,7 +584,77 @@ extern "C" int care_split2_act(const float* A, int64_t lda, void* A2, int M, int
   if (K % 4 != 0 || lda % 4 != 0 || !care_aligned16(A) || !care_aligned16(A2)) return CARE_EALIGN;
   const int64_t total = (int64_t)M * (K >> 2);
   hipLaunchKernelGGL(split2_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, lda,
-                     reinterpret_cast<_Float16*>(A2), M, K);
+                     reinterpret_cast<_Float16*>(A2), M, K, (const unsigned*)nullptr);
+  return care_launch_status();
+}
+
+extern "C" int care_split2_act_scaled(const float* A, int64_t lda, void* A2, int M, int K, const unsigned* amax, void* stream) {
+  if (!A || !A2 || !amax || M <= 0 || K <= 0) return CARE_EINVAL;
+  if (K % 4 != 0 || lda % 4 != 0 || !care_aligned16(A) || !care_aligned16(A2)) return CARE_EALIGN;
+  const int64_t total = (int64_t)M * (K >> 2);
+  hipLaunchKernelGGL(split2_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, lda,
+                     reinterpret_cast<_Float16*>(A2), M, K, amax);
+  return care_launch_status();
+}
+
+// fp32 [N, K] -> the W operand of the split products [N, 3K] = hi | lo | hi of x * its power-of-two scale (the scaled form of
+// care_split3_weight, csrc/gemm.hip)
+__global__ void split3_scaled_kernel(const float* W, int64_t ldw, _Float16* out, int N, int K, const unsigned* amax) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 each
+  const int kq = K >> 2;
+  if (i >= (int64_t)N * kq) return;
+  const int r = (int)(i / kq), c = (int)(i % kq) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)r * ldw + c);
+  const float sc = pow2_of(pow2_scale_exp(*amax));
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float x = v[j] * sc; hi[j] = (_Float16)x; lo[j] = (_Float16)(x - (float)hi[j]); }
+  _Float16* row = out + (int64_t)r * 3 * K;
+  *reinterpret_cast<f16x4*>(row + c) = hi;
+  *reinterpret_cast<f16x4*>(row + K + c) = lo;
+  *reinterpret_cast<f16x4*>(row + 2 * K + c) = hi;
+}
+
+extern "C" int care_split3_weight_scaled(const float* W, int64_t ldw, void* W3, int N, int K, const unsigned* amax, void* stream) {
+  if (!W || !W3 || !amax || N <= 0 || K <= 0) return CARE_EINVAL;
+  if (K % 4 != 0 || ldw % 4 != 0 || !care_aligned16(W) || !care_aligned16(W3)) return CARE_EALIGN;
+  const int64_t total = (int64_t)N * (K >> 2);
+  hipLaunchKernelGGL(split3_scaled_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw,
+                     reinterpret_cast<_Float16*>(W3), N, K, amax);
+  return care_launch_status();
+}
+
+// max |x| of an fp32 matrix as a bit pattern (non-negative floats order like their patterns): *slot = max(*slot, ...) - the
+// function zeroes the slot first.  NaNs are skipped (their patterns would win every comparison).
+__global__ void absmax_kernel(const float* A, int64_t lda, int M, int K, unsigned* slot) {
+  const int kq = K >> 2;
+  const int64_t total = (int64_t)M * kq;
+  unsigned best = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / kq), c = (int)(i % kq) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(A + (int64_t)r * lda + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned b = __builtin_bit_cast(unsigned, v[j]) & 0x7fffffffu;
+      if (b <= 0x7f800000u) best = max(best, b);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o, 64));
+  if ((threadIdx.x & 63) == 0 && best) atomicMax(slot, best);
+}
+
+extern "C" int care_absmax(const float* A, int64_t lda, int M, int K, void* slot, void* stream) {
+  if (!A || !slot || M <= 0 || K <= 0) return CARE_EINVAL;
+  if (K % 4 != 0 || lda % 4 != 0 || !care_aligned16(A)) return CARE_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const hipError_t e = hipMemsetAsync(slot, 0, 4, st);
+  if (e != hipSuccess) return (int)e;
+  const int64_t total = (int64_t)M * (K >> 2);
+  const int64_t want = (total + 1023) / 1024;
+  const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, A, lda, M, K, reinterpret_cast<unsigned*>(slot));
   return care_launch_status();
 }
 
@@ -589,6 +682,22 @@ extern "C" int care_gemm_tile_split3(const void* A2, const void* W3, const float
   split3_args(p, A2, W3, M, N, K);
   p.bias = bias; p.C0 = C0; p.ldc0 = ldc0; p.c0_bf16 = c0_dtype == CARE_BF16;
   p.C1 = C1; p.ldc1 = ldc1; p.c1_bf16 = c1_dtype == CARE_BF16; p.n_split = n_split; p.act = act;
+  hipStream_t st = (hipStream_t)stream;
+  return pick_cfg(M, N, 3 * K) == 4412 ? launch_tile<4, 4, 1, 2, EPI_STORE, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_STORE, true>(p, st);
+}
+
+// ... of operands split after a power-of-two pre-scale each (care_absmax -> care_split2_act_scaled / care_split3_weight_scaled):
+// C [M, ldc] fp32 = (A2 W3^T) / (scale_a scale_b) + bias.  The training-mode products (care_amd/training.py): gradients of
+// 1e-6 .. 1e-3, whose unscaled low pieces would be fp16 denormals, keep the ~2^-22 product error of the inference mode.
+extern "C" int care_gemm_tile_split3_scaled(const void* A2, const void* W3, const float* bias, float* C, int64_t ldc, int M, int N,
+                                            int K, const void* amax_a, const void* amax_b, void* stream) {
+  int rc = tile_check(A2, 2 * (int64_t)K, W3, M, N, K);
+  if (rc) return rc;
+  if (!C || !amax_a || !amax_b) return CARE_EINVAL;
+  TArgs p{};
+  split3_args(p, A2, W3, M, N, K);
+  p.bias = bias; p.C0 = C; p.ldc0 = ldc; p.c0_bf16 = 0; p.n_split = N; p.act = CARE_ACT_NONE;
+  p.amax_a = reinterpret_cast<const unsigned*>(amax_a); p.amax_b = reinterpret_cast<const unsigned*>(amax_b);
   hipStream_t st = (hipStream_t)stream;
   return pick_cfg(M, N, 3 * K) == 4412 ? launch_tile<4, 4, 1, 2, EPI_STORE, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_STORE, true>(p, st);
 }

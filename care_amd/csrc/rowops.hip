@@ -195,7 +195,9 @@ __global__ __launch_bounds__(256) void concept_finish_kernel(const float* scores
   if (lane == 0) avg[b] = psum / (float)k;
 }
 
-__global__ __launch_bounds__(256) void concept_topk_embed_kernel(const float* preds, int64_t ldp, int k, int topk,
+// (1024 threads: the 30 embedded rows of a clip are dependent load -> LayerNorm -> store chains, a row per wave; four waves took
+// them eight deep - *measured* round 5: 44.6 us per launch at 128 clips, on the critical path of every small concept batch)
+__global__ __launch_bounds__(1024) void concept_topk_embed_kernel(const float* preds, int64_t ldp, int k, int topk,
                                                                  const float* word, const float* pos,
                                                                  const float* gamma, const float* beta, float eps,
                                                                  int64_t* labels, float* out, bf16_t* outb,
@@ -207,9 +209,9 @@ __global__ __launch_bounds__(256) void concept_topk_embed_kernel(const float* pr
   __shared__ int slab[64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int k4 = (k + 3) & ~3;
-  for (int i = tid; i < k4; i += 256) sv[i] = i < k ? preds[(int64_t)b * ldp + i] : -INFINITY;  // pads never outrank
+  for (int i = tid; i < k4; i += 1024) sv[i] = i < k ? preds[(int64_t)b * ldp + i] : -INFINITY;  // pads never outrank
   __syncthreads();
-  for (int i = tid; i < k; i += 256) {
+  for (int i = tid; i < k; i += 1024) {
     const float vi = sv[i];
     int rank = 0;
     for (int j = 0; j < k4; j += 4) {  // four comparands per LDS read
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void concept_topk_embed_kernel(const float* pr
   if (tid < topk) labels[(int64_t)b * topk + tid] = slab[tid];
   if (!word) return;  // labels only: a model without local guidance (use_attr_flags ..L0) has no concept embeddings
   const int lane = tid & 63, wave = tid >> 6, nv4 = d >> 2;
-  for (int j = wave; j < topk; j += 4) {
+  for (int j = wave; j < topk; j += 16) {
     const float* w = word + (int64_t)slab[j] * d;
     const float* pp = pos + (int64_t)j * d;
     float4 v[MAXV];
@@ -486,7 +488,7 @@ extern "C" int care_concept_topk_embed(const float* preds, int64_t ldp, int k, i
   if (!preds || !labels || B <= 0) return CARE_EINVAL;
   if (word && (!pos || !gamma || !beta || !out)) return CARE_EINVAL;  // (word == NULL: the labels alone)
   if (k <= 0 || k > 1024 || topk <= 0 || topk > 64 || topk > k || d % 4 != 0 || d > 2048) return CARE_ESHAPE;
-  hipLaunchKernelGGL(concept_topk_embed_kernel, dim3(B), dim3(256), 0, ST, preds, ldp, k, topk, word, pos, gamma, beta,
+  hipLaunchKernelGGL(concept_topk_embed_kernel, dim3(B), dim3(1024), 0, ST, preds, ldp, k, topk, word, pos, gamma, beta,
                      eps, labels, out, reinterpret_cast<bf16_t*>(out_bf16), ldo, out_grp_rows, out_row_off, d);
   return care_launch_status();
 }

@@ -5,8 +5,11 @@ The reference trains through `LightningModule.training_step` -> `self.captioner(
 PyTorch's autograd recording every op.  Here the same forward is a chain of `torch.autograd.Function`s whose
 forward AND backward are HIP kernels behind the C ABI (include/care_hip.h):
 
-  * every nn.Linear: care_gemm (exact f32 MFMA) forward; backward = care_gemm_kn on the operands as they lie in memory
-    (dx = dy W, dW = dy^T x: no transposed copies) + care_strided_sum for the bias;
+  * every nn.Linear (round 6): forward, dx = dy W and dW = dy^T x as SPLIT PRODUCTS at the 16-bit matrix rate - three fp16 MFMA
+    passes over hi / lo pieces of operands pre-scaled by an exact power of two each (care_absmax -> care_split2_act_scaled /
+    care_split3_weight_scaled -> care_gemm_tile_split3_scaled; ~2^-22 per product, gradients within 1e-4 of the oracle's autograd
+    like the exact-f32 form) + care_strided_sum for the bias; `set_train_gemm("f32")` / CARE_TRAIN_GEMM=f32: care_gemm (exact
+    f32 MFMA) forward and care_gemm_kn on the operands as they lie in memory (no transposed copies) backward;
   * LayerNorm (+ residual): care_add_ln / care_ln_bwd; activations: care_act; dropout: care_dropout (a counter-based
     generator keyed by (seed, element): the backward re-creates the forward's mask; RNG parity with torch is not a
     goal, SURVEY.md 7.7);
@@ -58,6 +61,40 @@ def _mm(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None) 
     return out
 
 
+# GEMM arithmetic of training mode: "fp16x3" (default) = every product as three fp16 MFMA passes over hi / lo pieces of operands
+# pre-scaled by an exact power of two each (care_gemm_tile_split3_scaled: ~2^-22 relative per product - fp32-grade, at the
+# 16-bit matrix rate / 3), "f32" = the exact-f32 MFMA (1/16 of the 16-bit rate).  CARE_TRAIN_GEMM / set_train_gemm().
+import os as _os
+TRAIN_GEMM = _os.environ.get("CARE_TRAIN_GEMM", "fp16x3")
+
+
+def set_train_gemm(mode: str) -> None:
+    global TRAIN_GEMM
+    if mode not in ("fp16x3", "f32"):
+        raise ValueError("training GEMM mode must be 'fp16x3' or 'f32', got {!r}".format(mode))
+    TRAIN_GEMM = mode
+
+
+def _mm_x3(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A [M, K] . Bt [N, K]^T (+ bias) as split products of pre-scaled operands (see TRAIN_GEMM): absolute maxima ->
+    power-of-two scales -> fp16 hi / lo pieces -> one LDS-tiled product over the 3 K virtual columns, unscaled in its epilogue.
+    Every step a kernel on the current stream; the scales stay on the device."""
+    A, Bt = _pad_cols(A, 64), _pad_cols(Bt, 64)
+    M, K = A.shape
+    N = Bt.shape[0]
+    dev = A.device
+    slots = torch.empty(2, device=dev, dtype=torch.int32)
+    call("care_absmax", ptr(A), A.stride(0), M, K, slots.data_ptr())
+    call("care_absmax", ptr(Bt), Bt.stride(0), N, K, slots.data_ptr() + 4)
+    a2 = torch.empty(M, 2 * K, device=dev, dtype=torch.float16)
+    w3 = torch.empty(N, 3 * K, device=dev, dtype=torch.float16)
+    call("care_split2_act_scaled", ptr(A), A.stride(0), ptr(a2), M, K, slots.data_ptr())
+    call("care_split3_weight_scaled", ptr(Bt), Bt.stride(0), ptr(w3), N, K, slots.data_ptr() + 4)
+    out = torch.empty(M, N, device=dev, dtype=torch.float32)
+    call("care_gemm_tile_split3_scaled", ptr(a2), ptr(w3), ptr(bias), ptr(out), N, M, N, K, slots.data_ptr(), slots.data_ptr() + 4)
+    return out
+
+
 def _mm_kn(A: torch.Tensor, B: torch.Tensor, a_is_km: bool) -> torch.Tensor:
     """op(A) . B with B [K, N]; a_is_km: A is stored [K, M] (care_gemm_kn: the operands as they lie, no transposed copies)."""
     K, N = B.shape
@@ -85,12 +122,20 @@ class _Linear(torch.autograd.Function):
         x, W = _f32c(x), _f32c(W)
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        return _mm(x, W, _f32c(b) if b is not None else None)
+        ctx.x3 = TRAIN_GEMM == "fp16x3"
+        return (_mm_x3 if ctx.x3 else _mm)(x, W, _f32c(b) if b is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         dy = _f32c(dy)
+        if ctx.x3:
+            # the same split products; the operands transposed into the [rows, K] layout the tiled kernel streams (torch: data
+            # movement only): dx = dy W = dy (W^T)^T, dW = dy^T x = dy^T (x^T)^T
+            dx = _mm_x3(dy, W.t().contiguous()) if ctx.needs_input_grad[0] else None
+            dW = _mm_x3(dy.t().contiguous(), x.t().contiguous()) if ctx.needs_input_grad[1] else None
+            db = _strided_sum(dy, 1, dy.shape[0], 0, 1).view(-1) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            return dx, dW, db
         dx = _mm_kn(dy, W, False) if ctx.needs_input_grad[0] else None   # dy [M, out] W [out, in]
         dW = _mm_kn(dy, x, True) if ctx.needs_input_grad[1] else None    # dy^T [out, M] x [M, in]
         db = _strided_sum(dy, 1, dy.shape[0], 0, 1).view(-1) if (ctx.has_bias and ctx.needs_input_grad[2]) else None

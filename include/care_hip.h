@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 20
+#define CARE_ABI_VERSION 21
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -145,6 +145,19 @@ int care_split2_act(const float* A, int64_t lda, void* A2, int M, int K, void* s
 int care_gemm_tile_split3(const void* A2, const void* W3, const float* bias, void* C0, int64_t ldc0, int c0_dtype,
                           void* C1, int64_t ldc1, int c1_dtype, int n_split, int M, int N, int K, int act,
                           void* stream);
+/* Split products of PRE-SCALED operands - the GEMMs of training mode (models/Wrapper.py:423-435 -> Framework.py:215-237 under
+ *   autograd: every nn.Linear's forward, dx = dy W and dW = dy^T x; care_amd/training.py).  Gradients are 1e-6 .. 1e-3: the low
+ *   piece of an unscaled hi / lo split would be an fp16 denormal.  care_absmax: *slot (4 bytes, device) = bit pattern of max |A|
+ *   (the function zeroes it first; NaNs skipped).  care_split2_act_scaled / care_split3_weight_scaled: the pieces of A * 2^e, e
+ *   chosen from *amax so that the largest magnitude lies in [2^14, 2^15) (exact in fp32; zero / non-finite maxima: e = 0) -
+ *   layouts of care_split2_act [M, 2K] and care_split3_weight [N, 3K].  care_gemm_tile_split3_scaled: C [M, ldc] fp32 =
+ *   (A2 W3^T) / (2^ea 2^eb) + bias, the exponents re-derived from the same two slots.  No host synchronisation anywhere:
+ *   the scales never leave the device.  K % 64 == 0, lda % 4 == 0. */
+int care_absmax(const float* A, int64_t lda, int M, int K, void* slot, void* stream);
+int care_split2_act_scaled(const float* A, int64_t lda, void* A2, int M, int K, const unsigned* amax, void* stream);
+int care_split3_weight_scaled(const float* W, int64_t ldw, void* W3, int N, int K, const unsigned* amax, void* stream);
+int care_gemm_tile_split3_scaled(const void* A2, const void* W3, const float* bias, float* C, int64_t ldc, int M, int N,
+                                 int K, const void* amax_a, const void* amax_b, void* stream);
 /* ... and the fused vocabulary arg-max (care_gemm_tile_argmax's partials) on the same split products: the `fp16x3`
  *   compute mode (fp32 storage, every GEMM as three fp16 MFMA passes) of care_amd/engine.py. */
 int care_gemm_tile_split3_argmax(const void* A2, const void* W3, float* pmax, int32_t* pidx, float* psum, int M,

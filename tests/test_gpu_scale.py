@@ -102,10 +102,9 @@ def test_greedy_captions_of_2990_clips_against_the_oracle(mode):
 def test_beam5_winners_of_2990_clips(mode):
     """Beam 5 (translate.py:144's default) at the same scale.  The CPU oracle runs beam search at ~15 captions/s, so the
     reference for all 2990 clips is the engine's fp32 mode - itself held to the oracle here on the first 128 clips (identical
-    winners, scores within 1e-4), as it is on every fixture; a differing 16-bit winner must score, under the ORACLE's exact
-    arithmetic, within the tie tolerance of the fp32 winner (it lost or won a near-tie, nothing else)."""
+    winners, scores within 1e-4), as it is on every fixture; a differing 16-bit winner must, in the ORACLE's own
+    search of that clip, show a near-tie the 16-bit noise can flip (see the loop below)."""
     from oracle import care_cpu
-    from test_gpu_parity import BEAM_TIE_TOL
     from test_gpu_properties import _audit_record
 
     opt, P, model, feats = _setup()
@@ -119,12 +118,24 @@ def test_beam5_winners_of_2990_clips(mode):
     ref, ref_scores = _CACHE["fp32_beam"]
     got, got_scores = _translate(model, opt, mode, 5)
     differ = [i for i in range(N_CLIPS) if got[i][0] != ref[i][0]]
-    tol = BEAM_TIE_TOL if mode == "bf16" else 1e-2
-    for i in differ[:64]:  # (the exact rescoring is a full teacher-forced oracle pass per clip)
+    tol = 5e-2 if mode == "bf16" else 1e-2   # (the greedy test's: peaked rows scale the logit noise with them)
+    better = 0
+    for i in differ[:48]:  # (a full oracle search + two exact rescorings per clip)
+        # A beam search is path dependent: a flip at ANY near-tie of the reference search - the beam_size-th against the next
+        # candidate of a step (`select`), the winner's ancestry against pruning (`best_slack`), the finished list's order
+        # (`rank`) - can change the winner, for better or worse.  So a differing clip must show such a near-tie in the ORACLE's
+        # own search of that clip, or score (exactly) within the tolerance of the reference winner.
         one = [f[i: i + 1] for f in feats]
+        o_hyps, o_scores, gaps = care_cpu.translate_batch(P, dict(opt, beam_size=5, topk=1), one, return_gaps=True)
+        assert o_hyps[0][0] == ref[i][0], "clip {}: the fp32-mode winner is not the oracle's".format(i)
         inputs = care_cpu.inputs_for_decoder(opt, care_cpu.encoding_phase(P, opt, one))
         mine, theirs = (care_cpu.score_hypothesis(P, opt, inputs, h) for h in (got[i][0], ref[i][0]))
-        assert abs(mine - theirs) < 4 * tol, "clip {}: the {} winner scores {:.4f}, the fp32 winner {:.4f}".format(i, mode, mine, theirs)
+        better += mine > theirs
+        g = gaps[0]
+        assert abs(mine - theirs) < tol or min(g["select"], g["best_slack"], g["rank"]) < tol, \
+            "clip {}: the {} winner scores {:.4f}, the reference's {:.4f}, and the reference search has no near-tie ({})".format(
+                i, mode, mine, theirs, g)
     same = N_CLIPS - len(differ)
-    _audit_record(test="msrvtt_test_scale_beam5", mode=mode, clips=N_CLIPS, identical=same, differing=differ[:32])
+    _audit_record(test="msrvtt_test_scale_beam5", mode=mode, clips=N_CLIPS, identical=same, differing=differ[:32],
+                  audited=min(len(differ), 48), audited_with_a_better_exact_score=int(better))
     assert same >= (0.98 if mode == "fp16" else 0.93) * N_CLIPS, "{}: {} of {} beam winners identical".format(mode, same, N_CLIPS)

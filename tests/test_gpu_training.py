@@ -36,9 +36,15 @@ def _loss(out, gen_dev, seeds=(11, 12)):
 
 @pytest.mark.parametrize("name", ["msrvtt_base_ami_b2", "msrvtt_care_b2", "msrvtt_cabase_b3", "msrvtt_base_ami_eos_b4",
                                   "care_median_gelu_b2", "base_ami_mte_b2", "msrvtt_care_g1l0_b3", "msrvtt_care_g0l0_b3"])
-def test_training_forward_and_gradients_match_the_oracle_autograd(name):
+@pytest.mark.parametrize("gemm", ["fp16x3", "f32"])
+def test_training_forward_and_gradients_match_the_oracle_autograd(name, gemm):
+    """Both arithmetic forms of the training GEMMs (care_amd/training.py TRAIN_GEMM): split products of pre-scaled operands
+    at the 16-bit matrix rate (the default), and the exact-f32 MFMA - the same bars."""
     from conftest import GoldenCase
     from oracle import care_cpu
+    from care_amd import training
+
+    training.set_train_gemm(gemm)
 
     over = dict(NO_DROP)
     if name == "msrvtt_cabase_b3":
@@ -87,6 +93,28 @@ def test_training_forward_and_gradients_match_the_oracle_autograd(name):
     # padding_idx: the PAD row of the word embedding gets no gradient (nn.Embedding(padding_idx=0))
     assert float(model.decoder.embedding.word_embeddings.weight.grad[0].abs().max()) == 0.0
     print("worst relative gradient error", worst)
+    training.set_train_gemm("fp16x3")
+
+
+def test_scaled_split_product_keeps_tiny_gradients():
+    """care_gemm_tile_split3_scaled through training._mm_x3 on operands of very different magnitudes - an activation of O(1)
+    against a gradient of O(1e-7) with a few entries 1e4 x larger - against the float64 product: errors of ~2^-22 of
+    |a| . |b| accumulated, whatever the operands' scales; the unscaled split (care_gemm_tile_split3's pieces) loses the
+    small entries' low pieces to fp16's denormal range."""
+    from care_amd import training
+
+    gen = torch.Generator(device="cuda:0").manual_seed(3)
+    for M, N, K, sa, sb in ((300, 517, 1000, 1.0, 1e-7), (128, 64, 2048, 3e-6, 40.0), (64, 10547, 512, 1e-3, 1e-3)):
+        A = torch.randn(M, K, generator=gen, device="cuda:0") * sa
+        B = torch.randn(N, K, generator=gen, device="cuda:0") * sb
+        A[::7, ::5] *= 1e4
+        bias = torch.randn(N, generator=gen, device="cuda:0") * sa * sb
+        got = training._mm_x3(A, B, bias)
+        want = A.double() @ B.double().t() + bias.double()
+        bound = (A.abs().double() @ B.abs().double().t())   # sum_k |a| |b|: what a relative error per product accumulates against
+        rel = float(((got.double() - want).abs() / bound).max())
+        assert rel < 2e-6, (M, N, K, rel)
+        assert torch.equal(got, training._mm_x3(A, B, bias))
 
 
 def test_dropout_is_active_seeded_and_differentiable():

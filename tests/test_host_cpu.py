@@ -148,8 +148,9 @@ def test_abi_library_exports_every_declared_symbol():
                      _lib.ResidentAttn.bias.offset]
     assert loaded.care_decode_resident_scratch(1, 512, 2048, 10547) == 53248 + 16 * (512 * 18 + 2048 * 2 + 165 * 12)
     assert loaded.care_decode_resident_scratch(0, 512, 2048, 10547) < 0
-    # ... and of the beam launch: + the group lists [rows16, parts, 5] x (value, group) and the bf16 hidden rows
-    assert loaded.care_decode_resident_beam_scratch(3, 5, 512, 2048, 10547) == 53248 + 16 * (512 * 18 + 2048 * 2 + 165 * 12 + 165 * 40 + 1024)
+    # ... and of the beam launch: + the group lists [rows16, parts, 5] x (value, group), the bf16 hidden rows and (round 6) the
+    # bf16 input rows of the next step
+    assert loaded.care_decode_resident_beam_scratch(3, 5, 512, 2048, 10547) == 53248 + 16 * (512 * 18 + 2048 * 2 + 165 * 12 + 165 * 40 + 1024 + 1024)
     assert loaded.care_decode_resident_beam_scratch(0, 5, 512, 2048, 10547) < 0
     assert loaded.care_version() == int(re.search(r"#define CARE_ABI_VERSION (\d+)", header).group(1))
     assert loaded.care_arch() == b"gfx950"
