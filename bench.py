@@ -436,7 +436,11 @@ def extra_legs(dev, main_dtype, legs):
         torch.autograd.backward([out["logits"]], [g_tr])
 
     fl_tr = 3.0 * fl  # forward + the two backward products of every GEMM, per clip (same shapes as the teacher-forced forward)
-    for Btr, name in ((64, "training_step"), (512, "training_step_B512")):
+    from care_amd import training as _training
+    for Btr, name in ((64, "training_step"), (512, "training_step_B512"), (512, "training_step_B512_fp16x3")):
+        # the last leg: the same step with every nn.Linear's three products as split products of pre-scaled fp16 pieces
+        # (care_amd/training.py TRAIN_GEMM = "fp16x3"; the default is the exact-f32 MFMA)
+        _training.set_train_gemm("fp16x3" if name.endswith("fp16x3") else "f32")
         f_tr = feats_for(opt, Btr)
         ids_tr = synth_input_ids(7, Btr, opt["max_len"] - 1, opt["vocab_size"]).to(dev)
         batch = {"feats": f_tr, "input_ids": ids_tr}
@@ -444,11 +448,12 @@ def extra_legs(dev, main_dtype, legs):
         for _ in range(2):
             train_step()
         dt_tr = _timed(train_step, 5)
-        legs[name] = dict(config="msrvtt_care", dtype="f32", clips_per_step=Btr,
+        legs[name] = dict(config="msrvtt_care", dtype="f32", clips_per_step=Btr, gemm=_training.TRAIN_GEMM,
                           what="model.train(); forward + backward through care_amd/training.py (autograd Functions over HIP kernels), "
                                "gradient of a fixed cotangent on the logits; no loss, no optimiser",
                           ms_per_step=round(dt_tr * 1e3, 3), clips_per_s=round(Btr / dt_tr, 1),
                           tflops=round(fl_tr * Btr / dt_tr / 1e12, 2))
+    _training.set_train_gemm("f32")
     model_tr.eval()
     del model_tr, batch, f_tr, ids_tr, g_tr
 

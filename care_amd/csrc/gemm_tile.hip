@@ -630,18 +630,22 @@ extern "C" int care_split3_weight_scaled(const float* W, int64_t ldw, void* W3, 
 __global__ void absmax_kernel(const float* A, int64_t lda, int M, int K, unsigned* slot) {
   const int kq = K >> 2;
   const int64_t total = (int64_t)M * kq;
+  const bool dense = lda == K;  // (rows back to back: one linear sweep, no division per element - 65 us per call before)
   unsigned best = 0u;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / kq), c = (int)(i % kq) * 4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(A + (int64_t)r * lda + c);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned b = __builtin_bit_cast(unsigned, v[j]) & 0x7fffffffu;
-      if (b <= 0x7f800000u) best = max(best, b);
-    }
+    const int64_t off = dense ? i * 4 : (i / kq) * lda + (i % kq) * 4;
+    const uint4 u = *reinterpret_cast<const uint4*>(A + off);
+    const unsigned b0 = u.x & 0x7fffffffu, b1 = u.y & 0x7fffffffu, b2 = u.z & 0x7fffffffu, b3 = u.w & 0x7fffffffu;
+    if (b0 <= 0x7f800000u && b0 > best) best = b0;
+    if (b1 <= 0x7f800000u && b1 > best) best = b1;
+    if (b2 <= 0x7f800000u && b2 > best) best = b2;
+    if (b3 <= 0x7f800000u && b3 > best) best = b3;
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o, 64));
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned other = (unsigned)__shfl_xor((int)best, o, 64);
+    if (other > best) best = other;
+  }
   if ((threadIdx.x & 63) == 0 && best) atomicMax(slot, best);
 }
 
@@ -652,8 +656,8 @@ extern "C" int care_absmax(const float* A, int64_t lda, int M, int K, void* slot
   const hipError_t e = hipMemsetAsync(slot, 0, 4, st);
   if (e != hipSuccess) return (int)e;
   const int64_t total = (int64_t)M * (K >> 2);
-  const int64_t want = (total + 1023) / 1024;
-  const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+  const int64_t want = (total + 2047) / 2048;  // ~8 float4 per thread, at most 4096 workgroups
+  const unsigned blocks = (unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096);
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, A, lda, M, K, reinterpret_cast<unsigned*>(slot));
   return care_launch_status();
 }
@@ -689,17 +693,22 @@ extern "C" int care_gemm_tile_split3(const void* A2, const void* W3, const float
 // ... of operands split after a power-of-two pre-scale each (care_absmax -> care_split2_act_scaled / care_split3_weight_scaled):
 // C [M, ldc] fp32 = (A2 W3^T) / (scale_a scale_b) + bias.  The training-mode products (care_amd/training.py): gradients of
 // 1e-6 .. 1e-3, whose unscaled low pieces would be fp16 denormals, keep the ~2^-22 product error of the inference mode.
+// slabs > 1 (products with few output tiles and a long reduction - dW = dy^T x, dx = dy W): the operands come as `slabs`
+// consecutive matrices A2 [slabs][M, 2K], W3 [slabs][N, 3K] - K ranges of the real product, split range by range - and slab s
+// is multiplied into C + s M ldc; the caller adds the slabs in order (care_strided_sum).  bias must be NULL then.
 extern "C" int care_gemm_tile_split3_scaled(const void* A2, const void* W3, const float* bias, float* C, int64_t ldc, int M, int N,
-                                            int K, const void* amax_a, const void* amax_b, void* stream) {
+                                            int K, const void* amax_a, const void* amax_b, int slabs, void* stream) {
   int rc = tile_check(A2, 2 * (int64_t)K, W3, M, N, K);
   if (rc) return rc;
-  if (!C || !amax_a || !amax_b) return CARE_EINVAL;
+  if (!C || !amax_a || !amax_b || slabs < 1 || slabs > 65535 || (slabs > 1 && bias)) return CARE_EINVAL;
   TArgs p{};
   split3_args(p, A2, W3, M, N, K);
   p.bias = bias; p.C0 = C; p.ldc0 = ldc; p.c0_bf16 = 0; p.n_split = N; p.act = CARE_ACT_NONE;
   p.amax_a = reinterpret_cast<const unsigned*>(amax_a); p.amax_b = reinterpret_cast<const unsigned*>(amax_b);
+  p.a_bs = (int64_t)M * 2 * K; p.w_bs = (int64_t)N * 3 * K; p.c_bs = (int64_t)M * ldc; p.bias_bs = 0;
   hipStream_t st = (hipStream_t)stream;
-  return pick_cfg(M, N, 3 * K) == 4412 ? launch_tile<4, 4, 1, 2, EPI_STORE, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_STORE, true>(p, st);
+  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * slabs;
+  return t256 >= 192 ? launch_tile<4, 4, 1, 2, EPI_STORE, true>(p, st, slabs) : launch_tile<2, 2, 1, 2, EPI_STORE, true>(p, st, slabs);
 }
 
 // the fused vocabulary arg-max (care_gemm_tile_argmax) on split products: fp32-grade logits, never written

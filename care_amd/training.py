@@ -5,11 +5,13 @@ The reference trains through `LightningModule.training_step` -> `self.captioner(
 PyTorch's autograd recording every op.  Here the same forward is a chain of `torch.autograd.Function`s whose
 forward AND backward are HIP kernels behind the C ABI (include/care_hip.h):
 
-  * every nn.Linear (round 6): forward, dx = dy W and dW = dy^T x as SPLIT PRODUCTS at the 16-bit matrix rate - three fp16 MFMA
-    passes over hi / lo pieces of operands pre-scaled by an exact power of two each (care_absmax -> care_split2_act_scaled /
-    care_split3_weight_scaled -> care_gemm_tile_split3_scaled; ~2^-22 per product, gradients within 1e-4 of the oracle's autograd
-    like the exact-f32 form) + care_strided_sum for the bias; `set_train_gemm("f32")` / CARE_TRAIN_GEMM=f32: care_gemm (exact
-    f32 MFMA) forward and care_gemm_kn on the operands as they lie in memory (no transposed copies) backward;
+  * every nn.Linear: care_gemm (exact f32 MFMA) forward; backward = care_gemm_kn on the operands as they lie in memory
+    (dx = dy W, dW = dy^T x: no transposed copies) + a two-level care_strided_sum for the bias (_colsum);
+    `set_train_gemm("fp16x3")` / CARE_TRAIN_GEMM=fp16x3 (round 6): the three products as SPLIT PRODUCTS at the 16-bit matrix
+    rate - three fp16 MFMA passes over hi / lo pieces of operands pre-scaled by an exact power of two each (care_absmax ->
+    care_split2_act_scaled / care_split3_weight_scaled -> care_gemm_tile_split3_scaled, K in slabs for few-tile products;
+    ~2^-22 per product, gradients within the same 1e-4 of the oracle's autograd) - measured slower at the reference's batch
+    sizes (see TRAIN_GEMM), kept as an option;
   * LayerNorm (+ residual): care_add_ln / care_ln_bwd; activations: care_act; dropout: care_dropout (a counter-based
     generator keyed by (seed, element): the backward re-creates the forward's mask; RNG parity with torch is not a
     goal, SURVEY.md 7.7);
@@ -61,11 +63,15 @@ def _mm(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None) 
     return out
 
 
-# GEMM arithmetic of training mode: "fp16x3" (default) = every product as three fp16 MFMA passes over hi / lo pieces of operands
-# pre-scaled by an exact power of two each (care_gemm_tile_split3_scaled: ~2^-22 relative per product - fp32-grade, at the
-# 16-bit matrix rate / 3), "f32" = the exact-f32 MFMA (1/16 of the 16-bit rate).  CARE_TRAIN_GEMM / set_train_gemm().
+# GEMM arithmetic of training mode: "f32" (default) = the exact-f32 MFMA on the operands as they lie in memory; "fp16x3" = every
+# product as three fp16 MFMA passes over hi / lo pieces of operands pre-scaled by an exact power of two each
+# (care_gemm_tile_split3_scaled: ~2^-22 relative per product - fp32-grade - at the 16-bit matrix rate / 3).  *Measured* round 6
+# (one MI355X, msrvtt_care, forward + backward): 512 clips 19.5 ms (f32) / 22.2 ms (fp16x3), 64 clips 4.5 / 5.8 - at these sizes
+# the split form's extra passes (two |max| sweeps, two piece writes, the transposed slab copies of dy and x, the slab sums) cost
+# more than its matrix rate returns, and neither form touches the 5 ms of the attention backward: the exact form stays the
+# default, the split form an option for larger products.  CARE_TRAIN_GEMM / set_train_gemm().
 import os as _os
-TRAIN_GEMM = _os.environ.get("CARE_TRAIN_GEMM", "fp16x3")
+TRAIN_GEMM = _os.environ.get("CARE_TRAIN_GEMM", "f32")
 
 
 def set_train_gemm(mode: str) -> None:
@@ -75,24 +81,62 @@ def set_train_gemm(mode: str) -> None:
     TRAIN_GEMM = mode
 
 
-def _mm_x3(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """A [M, K] . Bt [N, K]^T (+ bias) as split products of pre-scaled operands (see TRAIN_GEMM): absolute maxima ->
-    power-of-two scales -> fp16 hi / lo pieces -> one LDS-tiled product over the 3 K virtual columns, unscaled in its epilogue.
-    Every step a kernel on the current stream; the scales stay on the device."""
-    A, Bt = _pad_cols(A, 64), _pad_cols(Bt, 64)
-    M, K = A.shape
-    N = Bt.shape[0]
+def _x3_slabs(M: int, N: int, K: int) -> int:
+    """K ranges a split product is cut into: enough 128 x 128 output tiles x slabs to occupy the chip twice over, slabs of at
+    least 256 columns (dW = dy^T x of a d x d weight at 512 clips: 16 tiles over K = 14848 -> 32 slabs of 512)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 256 or K < 1024:
+        return 1
+    return max(1, min((512 + tiles - 1) // tiles, K // 256, 64))
+
+
+def _slab_major(t: torch.Tensor, slabs: int, ks: int, transposed: bool) -> torch.Tensor:
+    """The [rows, K] operand of a split-K product as [slabs * rows, ks] (slab s = columns s ks .. of the zero-padded K), from
+    t = the operand itself ([rows, K]) or, transposed=True, its transpose as it lies in memory ([K, rows]): ONE strided copy
+    either way (torch: data movement only)."""
+    if transposed:
+        K, rows = t.shape
+    else:
+        rows, K = t.shape
+    Kp = slabs * ks
+    if Kp != K:
+        pad = torch.zeros((Kp, rows) if transposed else (rows, Kp), device=t.device, dtype=torch.float32)
+        if transposed:
+            pad[:K] = t
+        else:
+            pad[:, :K] = t
+        t = pad
+    if transposed:   # [Kp, rows] -> [slabs, ks, rows] -> [slabs, rows, ks]
+        return t.view(slabs, ks, rows).transpose(1, 2).contiguous().view(slabs * rows, ks)
+    if slabs == 1:
+        return t.contiguous()
+    return t.view(rows, slabs, ks).transpose(0, 1).contiguous().view(slabs * rows, ks)
+
+
+def _mm_x3(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None, a_t: bool = False, b_t: bool = False) -> torch.Tensor:
+    """op(A) [M, K] . op(Bt) [N, K]^T (+ bias) as split products of pre-scaled operands (see TRAIN_GEMM): absolute maxima ->
+    power-of-two scales -> fp16 hi / lo pieces -> the LDS-tiled product over the 3 K virtual columns, unscaled in its epilogue;
+    K in slabs (added in order) when the output has few tiles.  a_t / b_t: the operand is given TRANSPOSED ([K, M] / [K, N], as
+    dy and x lie in memory for dW = dy^T x) - the slab copy transposes it.  Every step a kernel on the current stream; the
+    scales stay on the device."""
+    M = A.shape[1] if a_t else A.shape[0]
+    K = A.shape[0] if a_t else A.shape[1]
+    N = Bt.shape[1] if b_t else Bt.shape[0]
+    slabs = _x3_slabs(M, N, K) if bias is None else 1
+    ks = ((K + slabs - 1) // slabs + 63) // 64 * 64
     dev = A.device
+    As, Bs = _slab_major(A, slabs, ks, a_t), _slab_major(Bt, slabs, ks, b_t)
     slots = torch.empty(2, device=dev, dtype=torch.int32)
-    call("care_absmax", ptr(A), A.stride(0), M, K, slots.data_ptr())
-    call("care_absmax", ptr(Bt), Bt.stride(0), N, K, slots.data_ptr() + 4)
-    a2 = torch.empty(M, 2 * K, device=dev, dtype=torch.float16)
-    w3 = torch.empty(N, 3 * K, device=dev, dtype=torch.float16)
-    call("care_split2_act_scaled", ptr(A), A.stride(0), ptr(a2), M, K, slots.data_ptr())
-    call("care_split3_weight_scaled", ptr(Bt), Bt.stride(0), ptr(w3), N, K, slots.data_ptr() + 4)
-    out = torch.empty(M, N, device=dev, dtype=torch.float32)
-    call("care_gemm_tile_split3_scaled", ptr(a2), ptr(w3), ptr(bias), ptr(out), N, M, N, K, slots.data_ptr(), slots.data_ptr() + 4)
-    return out
+    call("care_absmax", ptr(As), ks, slabs * M, ks, slots.data_ptr())
+    call("care_absmax", ptr(Bs), ks, slabs * N, ks, slots.data_ptr() + 4)
+    a2 = torch.empty(slabs * M, 2 * ks, device=dev, dtype=torch.float16)
+    w3 = torch.empty(slabs * N, 3 * ks, device=dev, dtype=torch.float16)
+    call("care_split2_act_scaled", ptr(As), ks, ptr(a2), slabs * M, ks, slots.data_ptr())
+    call("care_split3_weight_scaled", ptr(Bs), ks, ptr(w3), slabs * N, ks, slots.data_ptr() + 4)
+    out = torch.empty(slabs * M, N, device=dev, dtype=torch.float32)
+    call("care_gemm_tile_split3_scaled", ptr(a2), ptr(w3), ptr(bias), ptr(out), N, M, N, ks, slots.data_ptr(),
+         slots.data_ptr() + 4, slabs)
+    return out if slabs == 1 else _strided_sum(out, M, slabs, 1, M)
 
 
 def _mm_kn(A: torch.Tensor, B: torch.Tensor, a_is_km: bool) -> torch.Tensor:
@@ -116,6 +160,18 @@ def _strided_sum(x2: torch.Tensor, rows: int, terms: int, row_stride: int, term_
     return out
 
 
+def _colsum(dy: torch.Tensor) -> torch.Tensor:
+    """Column sums of [M, d] (a bias gradient) in two levels: S row slabs summed side by side (S x d / 64 workgroups), then the S
+    partial rows - care_strided_sum twice.  One level is d / 64 workgroups walking all M rows: 250 us per call at M = 14848,
+    a quarter of a 512-clip training step (*measured* round 6, rocprofv3)."""
+    M, d = dy.shape
+    S = next((s for s in range(min(256, M // 8), 1, -1) if M % s == 0), 1)
+    if S < 8:
+        return _strided_sum(dy, 1, M, 0, 1).view(-1)
+    part = _strided_sum(dy, S, M // S, M // S, 1)   # slab s = rows s L .. s L + L - 1
+    return _strided_sum(part, 1, S, 0, 1).view(-1)
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b):
@@ -132,13 +188,13 @@ class _Linear(torch.autograd.Function):
         if ctx.x3:
             # the same split products; the operands transposed into the [rows, K] layout the tiled kernel streams (torch: data
             # movement only): dx = dy W = dy (W^T)^T, dW = dy^T x = dy^T (x^T)^T
-            dx = _mm_x3(dy, W.t().contiguous()) if ctx.needs_input_grad[0] else None
-            dW = _mm_x3(dy.t().contiguous(), x.t().contiguous()) if ctx.needs_input_grad[1] else None
-            db = _strided_sum(dy, 1, dy.shape[0], 0, 1).view(-1) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            dx = _mm_x3(dy, W, b_t=True) if ctx.needs_input_grad[0] else None
+            dW = _mm_x3(dy, x, a_t=True, b_t=True) if ctx.needs_input_grad[1] else None
+            db = _colsum(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
             return dx, dW, db
         dx = _mm_kn(dy, W, False) if ctx.needs_input_grad[0] else None   # dy [M, out] W [out, in]
         dW = _mm_kn(dy, x, True) if ctx.needs_input_grad[1] else None    # dy^T [out, M] x [M, in]
-        db = _strided_sum(dy, 1, dy.shape[0], 0, 1).view(-1) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = _colsum(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db
 
 
@@ -167,6 +223,23 @@ class _AddLN(torch.autograd.Function):
         call("care_ln_bwd", ptr(x), d, ptr(res) if ctx.has_res else None, d if ctx.has_res else 0, ptr(gamma), ptr(dy), d,
              ctx.eps, ptr(ds), d, ptr(dg), ptr(db), rows, d)
         return ds, (ds if ctx.has_res else None), dg, db, None
+
+
+class _Add(torch.autograd.Function):
+    """y = x + res, the plain residual sum of a pre-LN sub-block (SubLayers.py:55,78,140,149: no LayerNorm behind it) -
+    care_add_ln with gamma == beta == NULL forward, the identity twice backward."""
+
+    @staticmethod
+    def forward(ctx, x, res):
+        x, res = _f32c(x), _f32c(res)
+        rows, d = x.shape
+        out = torch.empty_like(x)
+        call("care_add_ln", ptr(x), d, ptr(res), d, None, None, None, 0.0, ptr(out), None, d, rows, d, rows, rows, 0, 1, 0)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
 
 
 class _Act(torch.autograd.Function):
@@ -350,8 +423,9 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
         raise RuntimeError("the model is on `{}`: move it to the MI355X (there is no CPU fallback)".format(dev))
     if opt["encoder"] not in ("Embedder", "MultiTransformerEncoder"):
         raise NotImplementedError("training mode covers the `Embedder` and `MultiTransformerEncoder` encoders")
-    if opt.get("transformer_pre_ln", False):
-        raise NotImplementedError("training mode covers post-LN decoders (the eval-mode path runs pre-LN ones)")
+    pre_ln = bool(opt.get("transformer_pre_ln", False))  # opts.py:68: LayerNorm in FRONT of every sub-block (round 6: trains too)
+    if pre_ln and opt["encoder"] != "Embedder":
+        raise NotImplementedError("transformer_pre_ln with a self-attention encoder is outside the hot path (as in eval mode)")
     d, H = int(opt["dim_hidden"]), int(opt["num_attention_heads"])
     eps = float(opt["layer_norm_eps"])
     act = ACT_CODES[opt["hidden_act"]]
@@ -362,19 +436,27 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
     drop = lambda x, p: _Dropout.apply(x, p, seeds.next()) if p > 0.0 else x
 
     def mha(pre, xq, kv2, nseq, seq, n_keys, causal, pad_tok, bias):
-        """Post-LN multi-head attention sub-block (SubLayers.py:40-81) on [nseq * seq, d] queries."""
+        """Multi-head attention sub-block (SubLayers.py:40-81) on [nseq * seq, d] queries: post-LN, or - pre_ln - LayerNorm first
+        (the normalised rows are the keys / values of a self-attention too, :55-63) and the plain residual sum after."""
         sd = pre + ".SDPA."
-        q = _Linear.apply(xq, P[sd + "query.weight"], P.get(sd + "query.bias"))
-        k = _Linear.apply(kv2, P[sd + "key.weight"], P.get(sd + "key.bias"))
-        v = _Linear.apply(kv2, P[sd + "value.weight"], P.get(sd + "value.bias"))
+        h_in = _AddLN.apply(xq, None, P[pre + ".LayerNorm.weight"], P[pre + ".LayerNorm.bias"], eps) if pre_ln else xq
+        kv_in = h_in if kv2 is xq else kv2
+        q = _Linear.apply(h_in, P[sd + "query.weight"], P.get(sd + "query.bias"))
+        k = _Linear.apply(kv_in, P[sd + "key.weight"], P.get(sd + "key.bias"))
+        v = _Linear.apply(kv_in, P[sd + "value.weight"], P.get(sd + "value.bias"))
         ctx_ = _Attention.apply(q, k, v, bias, pad_tok, nseq, seq, n_keys, H, causal, p_att, seeds.next())
         o = drop(_Linear.apply(ctx_, P[pre + ".dense.weight"], P[pre + ".dense.bias"]), p_hid)
+        if pre_ln:
+            return _Add.apply(o, xq)
         return _AddLN.apply(o, xq, P[pre + ".LayerNorm.weight"], P[pre + ".LayerNorm.bias"], eps)
 
     def ffn(fp, x2):
-        """PositionwiseFeedForward (SubLayers.py:137-152), post-LN."""
-        h = _Act.apply(_Linear.apply(x2, P[fp + ".dense1.weight"], P[fp + ".dense1.bias"]), act)
+        """PositionwiseFeedForward (SubLayers.py:137-152), post-LN or pre-LN."""
+        h_in = _AddLN.apply(x2, None, P[fp + ".LayerNorm.weight"], P[fp + ".LayerNorm.bias"], eps) if pre_ln else x2
+        h = _Act.apply(_Linear.apply(h_in, P[fp + ".dense1.weight"], P[fp + ".dense1.bias"]), act)
         f = drop(_Linear.apply(h, P[fp + ".dense2.weight"], P[fp + ".dense2.bias"]), p_hid)
+        if pre_ln:
+            return _Add.apply(f, x2)
         return _AddLN.apply(f, x2, P[fp + ".LayerNorm.weight"], P[fp + ".LayerNorm.bias"], eps)
 
     modality = opt["modality"]
@@ -471,7 +553,10 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
     pos_table = P[e + ".position_embeddings.weight"] if opt.get("trainable_pe", False) else Bf[e + ".position_embeddings.pe"][0]
     x = _Gather.apply(P[e + ".word_embeddings.weight"], ids32.view(-1), PAD)
     x = _AddPosSem.apply(x, pos_table[:t], sem_hidden, t, t)
-    x = drop(_AddLN.apply(x, None, P[e + ".LayerNorm.weight"], P[e + ".LayerNorm.bias"], eps), p_hid)
+    if pre_ln:  # Embeddings.py:130-131: no LayerNorm behind the embedding sum of a pre-LN decoder
+        x = drop(x, p_hid)
+    else:
+        x = drop(_AddLN.apply(x, None, P[e + ".LayerNorm.weight"], P[e + ".LayerNorm.bias"], eps), p_hid)
 
     attr_att = bool(opt.get("use_attr", False)) and "att" in use_attr_type.lower()
     for li in range(int(opt["num_hidden_layers_decoder"])):
@@ -482,6 +567,8 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
             x2 = mha(lp + ".attr_attention", x2, sem_embs.reshape(B * topk, d), N, t, topk, False, None,
                      P.get(lp + ".attr_attention.SDPA.hybrid_bias"))
         x = ffn(lp + ".ffn", x2)
+    if pre_ln:  # Decoder/Transformer.py:80-81,233-234: the decoder's final LayerNorm, in front of the head
+        x = _AddLN.apply(x, None, P["decoder.LayerNorm.weight"], P["decoder.LayerNorm.bias"], eps)
     hidden = drop(x, p_hid)  # Decoder/Transformer.py:236-237
     logits = _Linear.apply(hidden, P["cls_head.tgt_word_prj.weight"], None)
     out["hidden_states"] = hidden.view(N, t, d)

@@ -152,12 +152,14 @@ int care_gemm_tile_split3(const void* A2, const void* W3, const float* bias, voi
  *   chosen from *amax so that the largest magnitude lies in [2^14, 2^15) (exact in fp32; zero / non-finite maxima: e = 0) -
  *   layouts of care_split2_act [M, 2K] and care_split3_weight [N, 3K].  care_gemm_tile_split3_scaled: C [M, ldc] fp32 =
  *   (A2 W3^T) / (2^ea 2^eb) + bias, the exponents re-derived from the same two slots.  No host synchronisation anywhere:
- *   the scales never leave the device.  K % 64 == 0, lda % 4 == 0. */
+ *   the scales never leave the device.  K % 64 == 0, lda % 4 == 0.  slabs > 1: split-K for products with few output tiles
+ *   (dW = dy^T x): A2 / W3 hold `slabs` matrices of K columns each (consecutive K ranges of the product), slab s goes to
+ *   C + s M ldc, the caller adds them in order (care_strided_sum); bias == NULL then. */
 int care_absmax(const float* A, int64_t lda, int M, int K, void* slot, void* stream);
 int care_split2_act_scaled(const float* A, int64_t lda, void* A2, int M, int K, const unsigned* amax, void* stream);
 int care_split3_weight_scaled(const float* W, int64_t ldw, void* W3, int N, int K, const unsigned* amax, void* stream);
 int care_gemm_tile_split3_scaled(const void* A2, const void* W3, const float* bias, float* C, int64_t ldc, int M, int N,
-                                 int K, const void* amax_a, const void* amax_b, void* stream);
+                                 int K, const void* amax_a, const void* amax_b, int slabs, void* stream);
 /* ... and the fused vocabulary arg-max (care_gemm_tile_argmax's partials) on the same split products: the `fp16x3`
  *   compute mode (fp32 storage, every GEMM as three fp16 MFMA passes) of care_amd/engine.py. */
 int care_gemm_tile_split3_argmax(const void* A2, const void* W3, float* pmax, int32_t* pidx, float* psum, int M,

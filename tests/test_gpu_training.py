@@ -35,11 +35,12 @@ def _loss(out, gen_dev, seeds=(11, 12)):
 
 
 @pytest.mark.parametrize("name", ["msrvtt_base_ami_b2", "msrvtt_care_b2", "msrvtt_cabase_b3", "msrvtt_base_ami_eos_b4",
-                                  "care_median_gelu_b2", "base_ami_mte_b2", "msrvtt_care_g1l0_b3", "msrvtt_care_g0l0_b3"])
+                                  "care_median_gelu_b2", "base_ami_mte_b2", "msrvtt_care_g1l0_b3", "msrvtt_care_g0l0_b3",
+                                  "msrvtt_base_ami_preln_b3", "msrvtt_cabase_preln_b2"])
 @pytest.mark.parametrize("gemm", ["fp16x3", "f32"])
 def test_training_forward_and_gradients_match_the_oracle_autograd(name, gemm):
-    """Both arithmetic forms of the training GEMMs (care_amd/training.py TRAIN_GEMM): split products of pre-scaled operands
-    at the 16-bit matrix rate (the default), and the exact-f32 MFMA - the same bars."""
+    """Both arithmetic forms of the training GEMMs (care_amd/training.py TRAIN_GEMM): the exact-f32 MFMA (the default) and
+    split products of pre-scaled operands at the 16-bit matrix rate - the same bars."""
     from conftest import GoldenCase
     from oracle import care_cpu
     from care_amd import training
@@ -93,7 +94,28 @@ def test_training_forward_and_gradients_match_the_oracle_autograd(name, gemm):
     # padding_idx: the PAD row of the word embedding gets no gradient (nn.Embedding(padding_idx=0))
     assert float(model.decoder.embedding.word_embeddings.weight.grad[0].abs().max()) == 0.0
     print("worst relative gradient error", worst)
-    training.set_train_gemm("fp16x3")
+    training.set_train_gemm("f32")
+
+
+def test_absmax_sees_every_element():
+    """care_absmax: the maximum in any of a float4's four positions, in any row, NaNs skipped, strided rows too.  (Its first
+    version indexed an ext-vector in an unrolled loop and hipcc kept element 0 only: three quarters of every operand unseen,
+    scales up to 4 x too large, fp16 infinities in the pieces - found as NaN gradients on ONE fixture.)"""
+    from care_amd._lib import call
+
+    for M, K, ld in ((512, 320, 320), (87, 64, 64), (3, 4, 4), (129, 64, 96)):
+        for pos in range(min(K, 8)):
+            buf = torch.zeros(M, ld, device="cuda:0")
+            buf[M // 2, pos] = -3.0
+            buf[0, (pos + 1) % 4] = 1.0
+            buf[M - 1, K - 1] = float("nan")
+            slot = torch.zeros(2, device="cuda:0", dtype=torch.int32)
+            call("care_absmax", buf.data_ptr(), ld, M, K, slot.data_ptr())
+            assert float(slot.view(torch.float32)[0]) == 3.0, (M, K, ld, pos)
+    x = torch.randn(20992, 320, device="cuda:0")
+    slot = torch.zeros(2, device="cuda:0", dtype=torch.int32)
+    call("care_absmax", x.data_ptr(), 320, 20992, 320, slot.data_ptr())
+    assert float(slot.view(torch.float32)[0]) == float(x.abs().max())
 
 
 def test_scaled_split_product_keeps_tiny_gradients():
