@@ -3,7 +3,7 @@
 # profiles/<round>_* and regenerates the "Readings" of profiles/README.md):   ROUND=r05 bash tools/profiles.sh
 # Counters are collected in passes of their own (kernel-trace only beside --pmc).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; ROUND=${ROUND:-r05}; O=$R/gpurun_out/${ROUND}prof; mkdir -p $O
+R=$GRAFT_REPO_ROOT; ROUND=${ROUND:-r06}; O=$R/gpurun_out/${ROUND}prof; mkdir -p $O
 B="python3 $R/bench.py --no-cpu-baseline --no-legs"
 stats() {  # name, command...: kernel trace with --stats, keeps the summary csv
   local name=$1; shift
@@ -19,6 +19,10 @@ stats greedy_B1 $B --batch 1 --steps 20 --warmup 3
 stats beam5_B128 $B --batch 128 --beam 5 --config msrvtt_care_beam5 --steps 20 --warmup 3
 stats beam5_B1 $B --batch 1 --beam 5 --config msrvtt_care_beam5 --steps 20 --warmup 3
 stats train_B64 python3 $R/tools/train_prof.py 64 10
+stats train_B512 python3 $R/tools/train_prof.py 512 5
+export CARE_TRAIN_GEMM=fp16x3   # (the split-product form of the training GEMMs; exported here: nothing but the program goes behind `--`)
+stats train_B512_x3 python3 $R/tools/train_prof.py 512 5
+unset CARE_TRAIN_GEMM
 stats trace_fp16 $B --steps 5 --warmup 2 --dtype fp16
 stats beam5_chain_B128 python3 $R/tools/chain_prof.py 128 3
 stats beam5_multilaunch_B512 python3 $R/tools/beam_sweep.py --only multi-launch 512

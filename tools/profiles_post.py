@@ -1,7 +1,7 @@
 """gpurun_out/<round>prof/* (tools/profiles.sh) -> profiles/<round>_*, and the "Readings" section of profiles/README.md
 REGENERATED from the committed files (so the text cannot drift from the data):
 
-    python tools/profiles_post.py [round]          # default r05; copies + regenerates
+    python tools/profiles_post.py [round]          # default r06; copies + regenerates
     python tools/profiles_post.py [round] --readme # only regenerate the readings from profiles/<round>_*
 """
 import collections
@@ -14,14 +14,14 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = next((a for a in sys.argv[1:] if not a.startswith("-")), "r05")
+ROUND = next((a for a in sys.argv[1:] if not a.startswith("-")), "r06")
 SRC = os.path.join(ROOT, "gpurun_out", ROUND + "prof")
 DST = os.path.join(ROOT, "profiles")
 head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 
 STATS = {"trace": "bench_B32768_bf16", "trace_vatex": "vatex_care_large_B4096_bf16", "trace_vatex16k": "vatex_care_large_B16384_bf16", "greedy_B128": "small_batch_greedy_B128",
          "greedy_B1": "small_batch_greedy_B1", "beam5_B128": "small_batch_beam5_B128", "beam5_B1": "small_batch_beam5_B1",
-         "train_B64": "training_step_B64", "trace_fp16": "bench_B32768_fp16", "beam5_chain_B128": "small_batch_beam5_chain_B128",
+         "train_B64": "training_step_B64", "train_B512": "training_step_B512", "train_B512_x3": "training_fp16x3_B512", "trace_fp16": "bench_B32768_fp16", "beam5_chain_B128": "small_batch_beam5_chain_B128",
          "beam5_multilaunch_B512": "mid_batch_beam5_multilaunch_B512"}
 ours = lambda k: ("anonymous namespace" in k or k.startswith("_ZN12_GLOBAL__N_1") or k.startswith("_Z17split2_act")) and "at::native" not in k
 
