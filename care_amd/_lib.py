@@ -35,8 +35,7 @@ SIGNATURES = {
     "care_gemm_tile_split3": [_P, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "care_gemm_tile_split3_argmax": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "care_absmax": [_P, _L, _I, _I, _P, _P],
-    "care_split2_act_scaled": [_P, _L, _P, _I, _I, _P, _P],
-    "care_split3_weight_scaled": [_P, _L, _P, _I, _I, _P, _P],
+    "care_split_pieces": [_P, _L, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "care_gemm_tile_split3_scaled": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _I, _P],
     "care_gemm_tile_batched": [_P, _L, _L, _P, _L, _L, _P, _I, _P, _L, _L, _I, _I, _I, _I, _I, _P],
     "care_gemm_tile_argmax": [_P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

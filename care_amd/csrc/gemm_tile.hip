@@ -588,40 +588,58 @@ extern "C" int care_split2_act(const float* A, int64_t lda, void* A2, int M, int
   return care_launch_status();
 }
 
-extern "C" int care_split2_act_scaled(const float* A, int64_t lda, void* A2, int M, int K, const unsigned* amax, void* stream) {
-  if (!A || !A2 || !amax || M <= 0 || K <= 0) return CARE_EINVAL;
-  if (K % 4 != 0 || lda % 4 != 0 || !care_aligned16(A) || !care_aligned16(A2)) return CARE_EALIGN;
-  const int64_t total = (int64_t)M * (K >> 2);
-  hipLaunchKernelGGL(split2_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, lda,
-                     reinterpret_cast<_Float16*>(A2), M, K, amax);
-  return care_launch_status();
-}
-
-// fp32 [N, K] -> the W operand of the split products [N, 3K] = hi | lo | hi of x * its power-of-two scale (the scaled form of
-// care_split3_weight, csrc/gemm.hip)
-__global__ void split3_scaled_kernel(const float* W, int64_t ldw, _Float16* out, int N, int K, const unsigned* amax) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 each
-  const int kq = K >> 2;
-  if (i >= (int64_t)N * kq) return;
-  const int r = (int)(i / kq), c = (int)(i % kq) * 4;
-  f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)r * ldw + c);
+// The fp16 pieces of one operand of a scaled split product, straight from the tensor as it lies in memory:
+//   src: the operand [rows, K] (ld >= K), or - transposed - its transpose [K, rows] (ld >= rows: dy and x as they lie for
+//        dW = dy^T x, W for dx = dy W);
+//   out: [slabs][rows][pieces * ks] fp16, slab s = columns s ks .. s ks + ks - 1 of the operand (zeros past K), each row
+//        hi | lo (pieces = 2: the A operand) or hi | lo | hi (pieces = 3: the W operand) of x * the power-of-two scale of *amax.
+// One 64 x 64 tile per workgroup through LDS, so that both the reads (along the source's contiguous dimension) and the writes
+// (along kk) are whole cache lines - round 6's first form made a transposed slab-major fp32 copy first (torch) and split that:
+// 3.4 ms of copies per 512-clip training step.
+__global__ __launch_bounds__(256) void split_pieces_kernel(const float* src, int64_t ld, int rows, int K, int transposed, int slabs,
+                                                           int ks, _Float16* out, int pieces, const unsigned* amax) {
+  __shared__ float tile[64][65];
+  const int tiles_k = (slabs * ks) >> 6;                       // ks % 64 == 0
+  const int tk = blockIdx.x % tiles_k, tr = blockIdx.x / tiles_k;
+  const int k0 = tk * 64, r0 = tr * 64;
   const float sc = pow2_of(pow2_scale_exp(*amax));
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  f16x4 hi, lo;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 4 rows of 64 per pass
+  if (transposed) {  // contiguous along r: tile[k][r]
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { const float x = v[j] * sc; hi[j] = (_Float16)x; lo[j] = (_Float16)(x - (float)hi[j]); }
-  _Float16* row = out + (int64_t)r * 3 * K;
-  *reinterpret_cast<f16x4*>(row + c) = hi;
-  *reinterpret_cast<f16x4*>(row + K + c) = lo;
-  *reinterpret_cast<f16x4*>(row + 2 * K + c) = hi;
+    for (int p = 0; p < 16; ++p) {
+      const int k = k0 + p * 4 + ty, r = r0 + tx;
+      tile[p * 4 + ty][tx] = (k < K && r < rows) ? src[(int64_t)k * ld + r] : 0.f;
+    }
+  } else {           // contiguous along k: tile[r][k]
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int r = r0 + p * 4 + ty, k = k0 + tx;
+      tile[p * 4 + ty][tx] = (k < K && r < rows) ? src[(int64_t)r * ld + k] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int slab = k0 / ks, kk = k0 - slab * ks + tx;          // a 64-column tile lies inside one slab (ks % 64 == 0)
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int rr = p * 4 + ty, r = r0 + rr;
+    if (r >= rows) continue;
+    const float x = (transposed ? tile[tx][rr] : tile[rr][tx]) * sc;
+    const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+    _Float16* o = out + ((int64_t)slab * rows + r) * pieces * ks + kk;
+    o[0] = hi;
+    o[ks] = lo;
+    if (pieces == 3) o[2 * ks] = hi;
+  }
 }
 
-extern "C" int care_split3_weight_scaled(const float* W, int64_t ldw, void* W3, int N, int K, const unsigned* amax, void* stream) {
-  if (!W || !W3 || !amax || N <= 0 || K <= 0) return CARE_EINVAL;
-  if (K % 4 != 0 || ldw % 4 != 0 || !care_aligned16(W) || !care_aligned16(W3)) return CARE_EALIGN;
-  const int64_t total = (int64_t)N * (K >> 2);
-  hipLaunchKernelGGL(split3_scaled_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw,
-                     reinterpret_cast<_Float16*>(W3), N, K, amax);
+extern "C" int care_split_pieces(const float* src, int64_t ld, int rows, int K, int transposed, int slabs, int ks, void* out,
+                                 int pieces, const void* amax, void* stream) {
+  if (!src || !out || !amax || rows <= 0 || K <= 0 || slabs <= 0 || ks <= 0 || (pieces != 2 && pieces != 3)) return CARE_EINVAL;
+  if (ks % 64 != 0 || (int64_t)slabs * ks < K || ld < (transposed ? rows : K)) return CARE_ESHAPE;
+  const int64_t blocks = (int64_t)((slabs * (int64_t)ks) >> 6) * ((rows + 63) / 64);
+  if (blocks > 0x7fffffff) return CARE_ESHAPE;
+  hipLaunchKernelGGL(split_pieces_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld, rows, K, transposed, slabs,
+                     ks, reinterpret_cast<_Float16*>(out), pieces, reinterpret_cast<const unsigned*>(amax));
   return care_launch_status();
 }
 
@@ -646,7 +664,16 @@ __global__ void absmax_kernel(const float* A, int64_t lda, int M, int K, unsigne
     const unsigned other = (unsigned)__shfl_xor((int)best, o, 64);
     if (other > best) best = other;
   }
-  if ((threadIdx.x & 63) == 0 && best) atomicMax(slot, best);
+  // ONE atomic per workgroup (16 K wave-level atomics on one address were most of this kernel: 58 us per call on average)
+  __shared__ unsigned wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned b = wmax[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) b = wmax[w] > b ? wmax[w] : b;
+    if (b) atomicMax(slot, b);
+  }
 }
 
 extern "C" int care_absmax(const float* A, int64_t lda, int M, int K, void* slot, void* stream) {
@@ -656,8 +683,8 @@ extern "C" int care_absmax(const float* A, int64_t lda, int M, int K, void* slot
   const hipError_t e = hipMemsetAsync(slot, 0, 4, st);
   if (e != hipSuccess) return (int)e;
   const int64_t total = (int64_t)M * (K >> 2);
-  const int64_t want = (total + 2047) / 2048;  // ~8 float4 per thread, at most 4096 workgroups
-  const unsigned blocks = (unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096);
+  const int64_t want = (total + 2047) / 2048;  // ~8 float4 per thread, at most 2048 workgroups (8 per CU)
+  const unsigned blocks = (unsigned)(want < 2048 ? (want > 0 ? want : 1) : 2048);
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, A, lda, M, K, reinterpret_cast<unsigned*>(slot));
   return care_launch_status();
 }
@@ -690,7 +717,7 @@ extern "C" int care_gemm_tile_split3(const void* A2, const void* W3, const float
   return pick_cfg(M, N, 3 * K) == 4412 ? launch_tile<4, 4, 1, 2, EPI_STORE, true>(p, st) : launch_tile<2, 2, 1, 2, EPI_STORE, true>(p, st);
 }
 
-// ... of operands split after a power-of-two pre-scale each (care_absmax -> care_split2_act_scaled / care_split3_weight_scaled):
+// ... of operands split after a power-of-two pre-scale each (care_absmax -> care_split_pieces):
 // C [M, ldc] fp32 = (A2 W3^T) / (scale_a scale_b) + bias.  The training-mode products (care_amd/training.py): gradients of
 // 1e-6 .. 1e-3, whose unscaled low pieces would be fp16 denormals, keep the ~2^-22 product error of the inference mode.
 // slabs > 1 (products with few output tiles and a long reduction - dW = dy^T x, dx = dy W): the operands come as `slabs`

@@ -118,6 +118,9 @@ class DecodeMixin:
             hb = w["d{}_hb".format(li)]
             q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm")
             kv = ckv[li]
+            if getattr(self, "_tf_join", None) is not None:   # the static K / V come from a side stream (metrics_step)
+                torch.cuda.current_stream().wait_stream(self._tf_join)
+                self._tf_join = None
             self.call("care_attention_seq", ptr(q2), d, ptr(kv), ptr(kv[:, d:]), Lk * 2 * d, 2 * d, per_clip, Lk, 0, t,
                  None, 0, PAD, ptr(hb), hb.stride(0) if hb is not None else 0, ptr(ctx), d, N, H, tag="tf_cross_attn")
             x2, x2b = self.ws("tf_x2", (rows, d)), self.wsb("tf_x2", (rows, d))
@@ -174,7 +177,15 @@ class DecodeMixin:
         x, xb = self.ws("tf_x0", (rows, d)), self.wsb("tf_x0", (rows, d))
         self.call("care_embed_ln", ptr(ids32), t, 0, None, 0, ptr(w["word"]), ptr(w["pos"]), 0, ptr(sem), sem_div,
              ptr(w["emb_g"]), ptr(w["emb_be"]), self.eps, ptr(x), ptr(xb), d, rows, t, d, tag="tf_embed")
-        ckv = self.cross_kv(mem, tag="tf_ckv")
+        ready = getattr(self, "_tf_ckv_ready", None)
+        if ready is not None:   # (metrics_step: projected on a side stream while this stream embeds; joined before its first use)
+            ckv, self._tf_join = ready
+            self._tf_ckv_ready = None
+        else:
+            ckv, self._tf_join = self.cross_kv(mem, tag="tf_ckv"), None
+        if self._tf_join is not None and not self.tf_fast_ok(t, want_aux):
+            torch.cuda.current_stream().wait_stream(self._tf_join)
+            self._tf_join = None
         if self.attr_att and sem_embs is None:
             raise KeyError("this model attends to `semantic_embs` (use_attr_type={!r})".format(self.use_attr_type))
         akv = self.attr_kv(sem_embs, tag="tf_akv") if self.attr_att else None
@@ -277,7 +288,29 @@ class DecodeMixin:
         the concept metrics).  A model without a concept head encodes lean - nothing of the fp32 memory or the frame
         means is read by the scoring - and no [N * t, V] logits exist at any point."""
         self._begin_pass()
-        enc = self.encode(self._prep_feats(feats), lean=not self.has_concepts)
+        feats = self._prep_feats(feats)
+        if (not self.has_concepts and self.tf_fast_ok(input_ids.shape[1], False) and
+                os.environ.get("CARE_TF_OVERLAP", "1") != "0"):
+            # Two independent chains meet at the cross-attention: the encoder + the static K / V projection (HBM-leaning: raw
+            # fp32 features in, 16-bit K / V out), and the decoder's embedding + self-attention block (needs the tokens only;
+            # a model with a concept head needs the encoder's guidance vector there: no overlap).  The first runs on a side
+            # stream, the decoder waits for it in front of its first cross-attention (_decode_full_fast).  Same kernels, same
+            # results; CARE_TF_OVERLAP=0: one stream.
+            if getattr(self, "_tf_side", None) is None:
+                self._tf_side = torch.cuda.Stream(device=self.device)
+            side, cur = self._tf_side, torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                enc = self.encode(feats, lean=True)
+                ckv = self.cross_kv(enc["encoder_hidden_states"], tag="tf_ckv")
+            self._tf_ckv_ready = (ckv, side)
+            try:
+                logp, pred = self.score_teacher_forced(input_ids, labels, enc["encoder_hidden_states"], None)
+            finally:
+                self._tf_ckv_ready = None
+                cur.wait_stream(side)
+            return logp, pred, enc
+        enc = self.encode(feats, lean=not self.has_concepts)
         logp, pred = self.score_teacher_forced(input_ids, labels, enc["encoder_hidden_states"], enc.get("semantic_hidden_states"),
                                                sem_embs=enc.get("semantic_embs"))
         return logp, pred, enc

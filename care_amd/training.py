@@ -9,7 +9,7 @@ forward AND backward are HIP kernels behind the C ABI (include/care_hip.h):
     (dx = dy W, dW = dy^T x: no transposed copies) + a two-level care_strided_sum for the bias (_colsum);
     `set_train_gemm("fp16x3")` / CARE_TRAIN_GEMM=fp16x3 (round 6): the three products as SPLIT PRODUCTS at the 16-bit matrix
     rate - three fp16 MFMA passes over hi / lo pieces of operands pre-scaled by an exact power of two each (care_absmax ->
-    care_split2_act_scaled / care_split3_weight_scaled -> care_gemm_tile_split3_scaled, K in slabs for few-tile products;
+    care_split_pieces (the operands read as they lie, transposed or not) -> care_gemm_tile_split3_scaled, K in slabs for few-tile products;
     ~2^-22 per product, gradients within the same 1e-4 of the oracle's autograd) - measured slower at the reference's batch
     sizes (see TRAIN_GEMM), kept as an option;
   * LayerNorm (+ residual): care_add_ln / care_ln_bwd; activations: care_act; dropout: care_dropout (a counter-based
@@ -90,49 +90,31 @@ def _x3_slabs(M: int, N: int, K: int) -> int:
     return max(1, min((512 + tiles - 1) // tiles, K // 256, 64))
 
 
-def _slab_major(t: torch.Tensor, slabs: int, ks: int, transposed: bool) -> torch.Tensor:
-    """The [rows, K] operand of a split-K product as [slabs * rows, ks] (slab s = columns s ks .. of the zero-padded K), from
-    t = the operand itself ([rows, K]) or, transposed=True, its transpose as it lies in memory ([K, rows]): ONE strided copy
-    either way (torch: data movement only)."""
-    if transposed:
-        K, rows = t.shape
-    else:
-        rows, K = t.shape
-    Kp = slabs * ks
-    if Kp != K:
-        pad = torch.zeros((Kp, rows) if transposed else (rows, Kp), device=t.device, dtype=torch.float32)
-        if transposed:
-            pad[:K] = t
-        else:
-            pad[:, :K] = t
-        t = pad
-    if transposed:   # [Kp, rows] -> [slabs, ks, rows] -> [slabs, rows, ks]
-        return t.view(slabs, ks, rows).transpose(1, 2).contiguous().view(slabs * rows, ks)
-    if slabs == 1:
-        return t.contiguous()
-    return t.view(rows, slabs, ks).transpose(0, 1).contiguous().view(slabs * rows, ks)
-
-
 def _mm_x3(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None, a_t: bool = False, b_t: bool = False) -> torch.Tensor:
     """op(A) [M, K] . op(Bt) [N, K]^T (+ bias) as split products of pre-scaled operands (see TRAIN_GEMM): absolute maxima ->
     power-of-two scales -> fp16 hi / lo pieces -> the LDS-tiled product over the 3 K virtual columns, unscaled in its epilogue;
     K in slabs (added in order) when the output has few tiles.  a_t / b_t: the operand is given TRANSPOSED ([K, M] / [K, N], as
-    dy and x lie in memory for dW = dy^T x) - the slab copy transposes it.  Every step a kernel on the current stream; the
-    scales stay on the device."""
+    dy and x lie in memory for dW = dy^T x) - care_split_pieces reads it as it lies.  Every step a kernel on the current
+    stream; the scales stay on the device."""
+    A, Bt = _f32c(A), _f32c(Bt)
     M = A.shape[1] if a_t else A.shape[0]
     K = A.shape[0] if a_t else A.shape[1]
     N = Bt.shape[1] if b_t else Bt.shape[0]
     slabs = _x3_slabs(M, N, K) if bias is None else 1
     ks = ((K + slabs - 1) // slabs + 63) // 64 * 64
     dev = A.device
-    As, Bs = _slab_major(A, slabs, ks, a_t), _slab_major(Bt, slabs, ks, b_t)
     slots = torch.empty(2, device=dev, dtype=torch.int32)
-    call("care_absmax", ptr(As), ks, slabs * M, ks, slots.data_ptr())
-    call("care_absmax", ptr(Bs), ks, slabs * N, ks, slots.data_ptr() + 4)
+    # (|max| over the tensor as it lies: the layout does not matter; rows are back to back, the last dimension a multiple of 4 or not)
+    for t, slot in ((A, slots.data_ptr()), (Bt, slots.data_ptr() + 4)):
+        flat = t.numel()
+        if flat % 4 == 0:
+            call("care_absmax", ptr(t), flat, 1, flat, slot)
+        else:
+            call("care_absmax", ptr(_pad_cols(t, 4)), (t.shape[1] + 3) // 4 * 4, t.shape[0], (t.shape[1] + 3) // 4 * 4, slot)
     a2 = torch.empty(slabs * M, 2 * ks, device=dev, dtype=torch.float16)
     w3 = torch.empty(slabs * N, 3 * ks, device=dev, dtype=torch.float16)
-    call("care_split2_act_scaled", ptr(As), ks, ptr(a2), slabs * M, ks, slots.data_ptr())
-    call("care_split3_weight_scaled", ptr(Bs), ks, ptr(w3), slabs * N, ks, slots.data_ptr() + 4)
+    call("care_split_pieces", ptr(A), A.stride(0), M, K, int(a_t), slabs, ks, ptr(a2), 2, slots.data_ptr())
+    call("care_split_pieces", ptr(Bt), Bt.stride(0), N, K, int(b_t), slabs, ks, ptr(w3), 3, slots.data_ptr() + 4)
     out = torch.empty(slabs * M, N, device=dev, dtype=torch.float32)
     call("care_gemm_tile_split3_scaled", ptr(a2), ptr(w3), ptr(bias), ptr(out), N, M, N, ks, slots.data_ptr(),
          slots.data_ptr() + 4, slabs)

@@ -148,16 +148,18 @@ int care_gemm_tile_split3(const void* A2, const void* W3, const float* bias, voi
 /* Split products of PRE-SCALED operands - the GEMMs of training mode (models/Wrapper.py:423-435 -> Framework.py:215-237 under
  *   autograd: every nn.Linear's forward, dx = dy W and dW = dy^T x; care_amd/training.py).  Gradients are 1e-6 .. 1e-3: the low
  *   piece of an unscaled hi / lo split would be an fp16 denormal.  care_absmax: *slot (4 bytes, device) = bit pattern of max |A|
- *   (the function zeroes it first; NaNs skipped).  care_split2_act_scaled / care_split3_weight_scaled: the pieces of A * 2^e, e
- *   chosen from *amax so that the largest magnitude lies in [2^14, 2^15) (exact in fp32; zero / non-finite maxima: e = 0) -
- *   layouts of care_split2_act [M, 2K] and care_split3_weight [N, 3K].  care_gemm_tile_split3_scaled: C [M, ldc] fp32 =
+ *   (the function zeroes it first; NaNs skipped).  care_split_pieces: the fp16 pieces of src * 2^e, e chosen from *amax so that
+ *   the largest magnitude lies in [2^14, 2^15) (exact in fp32; zero / non-finite maxima: e = 0), read from the operand as it
+ *   lies - [rows, K], or transposed [K, rows] - and written slab-major: [slabs][rows][pieces ks], pieces = 2 (hi | lo: the A
+ *   operand, care_split2_act's layout per slab) or 3 (hi | lo | hi: the W operand, care_split3_weight's); slab s = columns
+ *   s ks .. of the operand, zeros past K; ks % 64 == 0.  care_gemm_tile_split3_scaled: C [M, ldc] fp32 =
  *   (A2 W3^T) / (2^ea 2^eb) + bias, the exponents re-derived from the same two slots.  No host synchronisation anywhere:
  *   the scales never leave the device.  K % 64 == 0, lda % 4 == 0.  slabs > 1: split-K for products with few output tiles
  *   (dW = dy^T x): A2 / W3 hold `slabs` matrices of K columns each (consecutive K ranges of the product), slab s goes to
  *   C + s M ldc, the caller adds them in order (care_strided_sum); bias == NULL then. */
 int care_absmax(const float* A, int64_t lda, int M, int K, void* slot, void* stream);
-int care_split2_act_scaled(const float* A, int64_t lda, void* A2, int M, int K, const unsigned* amax, void* stream);
-int care_split3_weight_scaled(const float* W, int64_t ldw, void* W3, int N, int K, const unsigned* amax, void* stream);
+int care_split_pieces(const float* src, int64_t ld, int rows, int K, int transposed, int slabs, int ks, void* out,
+                      int pieces, const void* amax, void* stream);
 int care_gemm_tile_split3_scaled(const void* A2, const void* W3, const float* bias, float* C, int64_t ldc, int M, int N,
                                  int K, const void* amax_a, const void* amax_b, int slabs, void* stream);
 /* ... and the fused vocabulary arg-max (care_gemm_tile_argmax's partials) on the same split products: the `fp16x3`

@@ -137,6 +137,12 @@ def test_scaled_split_product_keeps_tiny_gradients():
         rel = float(((got.double() - want).abs() / bound).max())
         assert rel < 2e-6, (M, N, K, rel)
         assert torch.equal(got, training._mm_x3(A, B, bias))
+        # the operands as dy / x / W lie in memory for the backward products: transposed, K in slabs (no bias)
+        want0 = A.double() @ B.double().t()
+        for a_t, b_t in ((False, True), (True, True), (True, False)):
+            got_t = training._mm_x3(A.t().contiguous() if a_t else A, B.t().contiguous() if b_t else B, None, a_t, b_t)
+            rel = float(((got_t.double() - want0).abs() / bound).max())
+            assert rel < 2e-6, (M, N, K, a_t, b_t, rel)
 
 
 def test_dropout_is_active_seeded_and_differentiable():
