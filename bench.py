@@ -212,13 +212,13 @@ def extra_legs(dev, main_dtype, legs):
 
     import gc
 
-    def build(config, dtype, row_scale=None, **over):
+    def build(config, dtype, row_scale=None, seed=0, **over):
         # engines of finished legs (GBs of workspaces, captured graphs, model <-> engine cycles) go before the next one
         gc.collect()
         torch.cuda.empty_cache()
         opt = make_opt(config, **over)
         model = get_framework(opt).eval()
-        P = synth_state_dict(0, [(k, tuple(v.shape)) for k, v in model.state_dict().items()], row_scale=row_scale or {})
+        P = synth_state_dict(seed, [(k, tuple(v.shape)) for k, v in model.state_dict().items()], row_scale=row_scale or {})
         model.load_state_dict(P, strict=True)
         model.set_compute_dtype(dtype)
         model.to(dev)
@@ -398,21 +398,21 @@ def extra_legs(dev, main_dtype, legs):
         tfk = {t: round(sum(s.elapsed_time(e) for s, e in ev), 3) for t, ev in timing.items()}
         legs[leg_name] = dict(config="msrvtt_base_ami", dtype=main_dtype, clips_per_step=Btf, positions=T_,
                               what="engine.metrics_step: encode (lean) + teacher-forced decoder over all positions + fused scoring (no logits "
-                                   "in memory); the encoder + static K/V chain runs on a side stream beside the decoder's self-attention block",
+                                   "in memory)",
                               clips_per_s=round(Btf / dt, 1), ms_per_pass=round(dt * 1e3, 3),
                               gflop_per_clip=round(fl / 1e9, 4), tflops=round(fl * Btf / dt / 1e12, 1),
                               frac_of_bf16_mfma_peak=round(fl * Btf / dt / 1e12 / MFMA_PEAK_TF["bf16"], 4),
                               fast_path=bool(eng.tf_fast_ok(T_, False)),
-                              kernel_ms=dict(sorted(tfk.items(), key=lambda kv: -kv[1])),
-                              kernel_ms_note="HIP events around each launch; launches of the two streams overlap, so the sum exceeds the pass")
+                              kernel_ms=dict(sorted(tfk.items(), key=lambda kv: -kv[1])))
         if Btf == 4096:
-            # the same pass on ONE stream (CARE_TF_OVERLAP=0): what the overlap is worth
-            os.environ["CARE_TF_OVERLAP"] = "0"
+            # the same pass with the encoder + static K/V chain on a side stream beside the decoder's self-attention block
+            # (CARE_TF_OVERLAP=1; off by default: it does not pay)
+            os.environ["CARE_TF_OVERLAP"] = "1"
             for _ in range(2):
                 tf_score()
             dt1 = _timed(tf_score, 10)
             del os.environ["CARE_TF_OVERLAP"]
-            legs[leg_name]["one_stream"] = dict(ms_per_pass=round(dt1 * 1e3, 3), frac_of_bf16_mfma_peak=round(fl * Btf / dt1 / 1e12 / MFMA_PEAK_TF["bf16"], 4))
+            legs[leg_name]["two_streams"] = dict(ms_per_pass=round(dt1 * 1e3, 3), frac_of_bf16_mfma_peak=round(fl * Btf / dt1 / 1e12 / MFMA_PEAK_TF["bf16"], 4))
         if Btf != 4096:
             del feats, ids, labels
     Btf = 4096
@@ -456,10 +456,10 @@ def extra_legs(dev, main_dtype, legs):
 
     fl_tr = 3.0 * fl  # forward + the two backward products of every GEMM, per clip (same shapes as the teacher-forced forward)
     from care_amd import training as _training
-    for Btr, name in ((64, "training_step"), (512, "training_step_B512"), (512, "training_step_B512_fp16x3")):
-        # the last leg: the same step with every nn.Linear's three products as split products of pre-scaled fp16 pieces
-        # (care_amd/training.py TRAIN_GEMM = "fp16x3"; the default is the exact-f32 MFMA)
-        _training.set_train_gemm("fp16x3" if name.endswith("fp16x3") else "f32")
+    for Btr, name in ((64, "training_step"), (512, "training_step_B512"), (512, "training_step_B512_f32")):
+        # the default ("auto": per product the exact-f32 MFMA, or - from a few GFLOP on - split products of pre-scaled fp16
+        # pieces at the 16-bit matrix rate; care_amd/training.py TRAIN_GEMM), and the 512-clip step with every product exact
+        _training.set_train_gemm("f32" if name.endswith("_f32") else "auto")
         f_tr = feats_for(opt, Btr)
         ids_tr = synth_input_ids(7, Btr, opt["max_len"] - 1, opt["vocab_size"]).to(dev)
         batch = {"feats": f_tr, "input_ids": ids_tr}
@@ -472,7 +472,7 @@ def extra_legs(dev, main_dtype, legs):
                                "gradient of a fixed cotangent on the logits; no loss, no optimiser",
                           ms_per_step=round(dt_tr * 1e3, 3), clips_per_s=round(Btr / dt_tr, 1),
                           tflops=round(fl_tr * Btr / dt_tr / 1e12, 2))
-    _training.set_train_gemm("f32")
+    _training.set_train_gemm("auto")
     model_tr.eval()
     del model_tr, batch, f_tr, ids_tr, g_tr
 
@@ -595,7 +595,8 @@ def extra_legs(dev, main_dtype, legs):
     # (the resident launches), greedy and beam 5: captions identical to those of the engine's fp32 mode, per 16-bit mode.
     # (fp32 mode is identical to the reference on every fixture; tests/test_gpu_scale.py holds the same 2990 clips to the CPU
     # oracle and audits every differing clip as a near-tie of the reference's own distribution.)
-    opt, eng = build("msrvtt_care", "fp32", row_scale={"cls_head.tgt_word_prj.weight": {**{r: 12.0 for r in range(6, 46)}, 3: 20.0}})
+    # (seed 373: the weights of the peaked fixtures and of tests/test_gpu_scale.py - a model that ends its captions)
+    opt, eng = build("msrvtt_care", "fp32", row_scale={"cls_head.tgt_word_prj.weight": {**{r: 12.0 for r in range(6, 46)}, 3: 20.0}}, seed=373)
     model_s = eng_model[0]
     n_test = 2990
     gen = torch.Generator().manual_seed(373)

@@ -7,11 +7,10 @@ forward AND backward are HIP kernels behind the C ABI (include/care_hip.h):
 
   * every nn.Linear: care_gemm (exact f32 MFMA) forward; backward = care_gemm_kn on the operands as they lie in memory
     (dx = dy W, dW = dy^T x: no transposed copies) + a two-level care_strided_sum for the bias (_colsum);
-    `set_train_gemm("fp16x3")` / CARE_TRAIN_GEMM=fp16x3 (round 6): the three products as SPLIT PRODUCTS at the 16-bit matrix
+    from a few GFLOP per product on (TRAIN_GEMM "auto", round 6): the three products as SPLIT PRODUCTS at the 16-bit matrix
     rate - three fp16 MFMA passes over hi / lo pieces of operands pre-scaled by an exact power of two each (care_absmax ->
     care_split_pieces (the operands read as they lie, transposed or not) -> care_gemm_tile_split3_scaled, K in slabs for few-tile products;
-    ~2^-22 per product, gradients within the same 1e-4 of the oracle's autograd) - measured slower at the reference's batch
-    sizes (see TRAIN_GEMM), kept as an option;
+    ~2^-22 per product, gradients within the same 1e-4 of the oracle's autograd): 19.5 -> 15.8 ms per 512-clip step;
   * LayerNorm (+ residual): care_add_ln / care_ln_bwd; activations: care_act; dropout: care_dropout (a counter-based
     generator keyed by (seed, element): the backward re-creates the forward's mask; RNG parity with torch is not a
     goal, SURVEY.md 7.7);
@@ -63,21 +62,28 @@ def _mm(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None) 
     return out
 
 
-# GEMM arithmetic of training mode: "f32" (default) = the exact-f32 MFMA on the operands as they lie in memory; "fp16x3" = every
-# product as three fp16 MFMA passes over hi / lo pieces of operands pre-scaled by an exact power of two each
-# (care_gemm_tile_split3_scaled: ~2^-22 relative per product - fp32-grade - at the 16-bit matrix rate / 3).  *Measured* round 6
-# (one MI355X, msrvtt_care, forward + backward): 512 clips 19.5 ms (f32) / 22.2 ms (fp16x3), 64 clips 4.5 / 5.8 - at these sizes
-# the split form's extra passes (two |max| sweeps, two piece writes, the transposed slab copies of dy and x, the slab sums) cost
-# more than its matrix rate returns, and neither form touches the 5 ms of the attention backward: the exact form stays the
-# default, the split form an option for larger products.  CARE_TRAIN_GEMM / set_train_gemm().
+# GEMM arithmetic of training mode (CARE_TRAIN_GEMM / set_train_gemm()):
+#   "f32"    the exact-f32 MFMA on the operands as they lie in memory (care_gemm / care_gemm_kn);
+#   "fp16x3" every product as three fp16 MFMA passes over hi / lo pieces of operands pre-scaled by an exact power of two each
+#            (care_gemm_tile_split3_scaled: ~2^-22 relative per product - fp32-grade - at the 16-bit matrix rate / 3);
+#   "auto"   (default) per product: the split form from X3_MIN_FLOPS on, the exact form below.
+# *Measured* round 6 (one MI355X, msrvtt_care, forward + backward, ms per step, f32 / fp16x3): 512 clips 19.5 / 15.8, 64 clips
+# 4.5 / 5.1 - the split form pays its fixed costs (two |max| sweeps, two piece writes, a slab sum: ~6 launches) back from a few
+# GFLOP per product on; below, the exact kernel on the operands as they lie is faster.  Gradients of both forms meet the same
+# 1e-4 of the oracle's autograd (tests/test_gpu_training.py), so a step may mix them.
 import os as _os
-TRAIN_GEMM = _os.environ.get("CARE_TRAIN_GEMM", "f32")
+TRAIN_GEMM = _os.environ.get("CARE_TRAIN_GEMM", "auto")
+X3_MIN_FLOPS = 6.0e9   # 2 M N K of a product from which "auto" takes the split form (512 clips: every decoder product; 64 clips: the vocabulary's)
+
+
+def _use_x3(M: int, N: int, K: int) -> bool:
+    return TRAIN_GEMM == "fp16x3" or (TRAIN_GEMM == "auto" and 2.0 * M * N * K >= X3_MIN_FLOPS)
 
 
 def set_train_gemm(mode: str) -> None:
     global TRAIN_GEMM
-    if mode not in ("fp16x3", "f32"):
-        raise ValueError("training GEMM mode must be 'fp16x3' or 'f32', got {!r}".format(mode))
+    if mode not in ("auto", "fp16x3", "f32"):
+        raise ValueError("training GEMM mode must be 'auto', 'fp16x3' or 'f32', got {!r}".format(mode))
     TRAIN_GEMM = mode
 
 
@@ -160,7 +166,7 @@ class _Linear(torch.autograd.Function):
         x, W = _f32c(x), _f32c(W)
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        ctx.x3 = TRAIN_GEMM == "fp16x3"
+        ctx.x3 = _use_x3(x.shape[0], W.shape[0], W.shape[1])   # (the three products of a layer have the same 2 M N K)
         return (_mm_x3 if ctx.x3 else _mm)(x, W, _f32c(b) if b is not None else None)
 
     @staticmethod

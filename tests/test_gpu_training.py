@@ -39,8 +39,8 @@ def _loss(out, gen_dev, seeds=(11, 12)):
                                   "msrvtt_base_ami_preln_b3", "msrvtt_cabase_preln_b2"])
 @pytest.mark.parametrize("gemm", ["fp16x3", "f32"])
 def test_training_forward_and_gradients_match_the_oracle_autograd(name, gemm):
-    """Both arithmetic forms of the training GEMMs (care_amd/training.py TRAIN_GEMM): the exact-f32 MFMA (the default) and
-    split products of pre-scaled operands at the 16-bit matrix rate - the same bars."""
+    """Both arithmetic forms of the training GEMMs forced in turn (care_amd/training.py TRAIN_GEMM; the default "auto" picks per
+    product): the exact-f32 MFMA and split products of pre-scaled operands at the 16-bit matrix rate - the same bars."""
     from conftest import GoldenCase
     from oracle import care_cpu
     from care_amd import training
@@ -94,7 +94,7 @@ def test_training_forward_and_gradients_match_the_oracle_autograd(name, gemm):
     # padding_idx: the PAD row of the word embedding gets no gradient (nn.Embedding(padding_idx=0))
     assert float(model.decoder.embedding.word_embeddings.weight.grad[0].abs().max()) == 0.0
     print("worst relative gradient error", worst)
-    training.set_train_gemm("f32")
+    training.set_train_gemm("auto")
 
 
 def test_absmax_sees_every_element():
