@@ -322,6 +322,148 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnBArgs a) {
   }
 }
 
+// The same backward as FOUR small exact-f32 matrix products per (sequence, head) on the matrix cores (round 6; seq <= 32 queries,
+// nkeys <= 128): one workgroup of 4 waves,
+//   dPd^T [keys x queries] = V_h [keys x 64] . dctx_h^T          (v_mfma_f32_16x16x4_f32: bit-wise an fp32 fma chain per output)
+//   dS = P o (dPd o keep - rowsum(dPd o keep o P))               (a wave per query row, lanes over keys)
+//   dQ [queries x 64] = dS . K_h / 8 ;  dK [keys x 64] = dS^T . Q_h / 8 ;  dV [keys x 64] = (P o keep)^T . dctx_h
+// dS and P o keep live in LDS ([32][132] each), Q_h and dctx_h too ([32][68]); K_h / V_h fragments come straight from memory.
+// The one-wave form above walks the queries in series with its dK / dV accumulators in LDS (two read-modify-writes per key and
+// query) and reads V through 64 different cache lines per instruction: *measured* round 6, 512 clips: 2.85 ms per launch for the
+// cross-attention (114 keys), 3.1 ms of a 15.3 ms training step (profiles/r06_training_step_B512_kernel_stats.csv).
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnBArgs a) {
+  __shared__ float sQ[32][68], sD[32][68], sS[32][132], sP[32][132];
+  const int s = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
+  const float* Kb = a.K + (int64_t)s * a.kv_bs + h * 64;
+  const float* Vb = a.V + (int64_t)s * a.kv_bs + h * 64;
+  const int KT = (a.nkeys + 15) >> 4, QT = (a.seq + 15) >> 4;
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int q = i >> 6, e = i & 63;
+    const int64_t row = (int64_t)s * a.seq + q;
+    sQ[q][e] = q < a.seq ? a.Q[row * a.ldq + h * 64 + e] : 0.f;
+    sD[q][e] = q < a.seq ? a.dctx[row * a.ldd + h * 64 + e] : 0.f;
+  }
+  __syncthreads();
+  // ---- dPd[key][query]: tile (kt, qt) -> sS[query][key]
+  for (int ti = wave; ti < KT * QT; ti += 4) {
+    const int kt = ti / QT, qt = ti - kt * QT;
+    const int key = kt * 16 + l16;
+    const float* vrow = Vb + (int64_t)min(key, a.nkeys - 1) * a.kv_rs + kg;
+    float fa[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) fa[ks] = key < a.nkeys ? vrow[4 * ks] : 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks], sD[qt * 16 + l16][4 * ks + kg], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sS[qt * 16 + l16][kt * 16 + 4 * kg + e] = acc[e];
+  }
+  __syncthreads();
+  // ---- softmax backward per query row (rows past the sequence and keys past nkeys: zeros)
+  for (int i = wave; i < 32; i += 4) {
+    const int64_t prow = (((int64_t)s * a.seq + i) * a.heads + h) * a.nkeys;
+    float dP[2], Pv[2], Pk[2];
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = lane + 64 * t;
+      dP[t] = Pv[t] = Pk[t] = 0.f;
+      if (i < a.seq && j < a.nkeys) {
+        const float keep = attn_keep(a, prow + j);
+        Pv[t] = a.P[prow + j];
+        dP[t] = sS[i][j] * keep;
+        Pk[t] = Pv[t] * keep;
+        dot += dP[t] * Pv[t];
+      }
+    }
+    dot = care_wave_sum(dot);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = lane + 64 * t;
+      sS[i][j] = Pv[t] * (dP[t] - dot);
+      sP[i][j] = Pk[t];
+    }
+  }
+  __syncthreads();
+  if (a.dbias && tid < a.nkeys) {  // column sums over this sequence's queries, then one atomic per (head, key)
+    float c = 0.f;
+    for (int i = 0; i < a.seq; ++i) c += sS[i][tid];
+    atomicAdd(a.dbias + (int64_t)h * a.bias_ld + tid, c);
+  }
+  // ---- dQ[query][dim] = dS . K / 8: tile (qt, dt)
+  for (int ti = wave; ti < QT * 4; ti += 4) {
+    const int qt = ti >> 2, dt = ti & 3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KT * 4; ++ks) {
+      const int key = 4 * ks + kg;
+      const float fb = key < a.nkeys ? Kb[(int64_t)key * a.kv_rs + dt * 16 + l16] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sS[qt * 16 + l16][key], fb, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = qt * 16 + 4 * kg + e;
+      if (q < a.seq) a.dQ[((int64_t)s * a.seq + q) * a.lddq + h * 64 + dt * 16 + l16] = acc[e] * 0.125f;
+    }
+  }
+  // ---- dK[key][dim] = dS^T . Q / 8 and dV[key][dim] = (P keep)^T . dctx: tile (kt, dt)
+  for (int ti = wave; ti < KT * 4; ti += 4) {
+    const int kt = ti >> 2, dt = ti & 3;
+    f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks >= QT * 4) break;
+      const int q = 4 * ks + kg;
+      ak = __builtin_amdgcn_mfma_f32_16x16x4f32(sS[q][kt * 16 + l16], sQ[q][dt * 16 + l16], ak, 0, 0, 0);
+      av = __builtin_amdgcn_mfma_f32_16x16x4f32(sP[q][kt * 16 + l16], sD[q][dt * 16 + l16], av, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = kt * 16 + 4 * kg + e;
+      if (key < a.nkeys) {
+        const int64_t o = (int64_t)s * a.dkv_bs + (int64_t)key * a.dkv_rs + h * 64 + dt * 16 + l16;
+        a.dK[o] = ak[e] * 0.125f;
+        a.dV[o] = av[e];
+      }
+    }
+  }
+}
+
+// ... and the forward's ctx = (P o keep) V in the same form (seq <= 32, nkeys <= 128): a workgroup per (sequence, head), the
+// masked probabilities of its <= 32 queries in LDS, ctx[query][dim] tiles on the exact-f32 matrix cores with V_h fragments
+// straight from memory (attn_pv_kernel above: a wave per query walking the keys with readlane broadcasts, 0.78 ms per step at 512 clips).
+__global__ __launch_bounds__(256) void attn_pv_mfma_kernel(AttnBArgs a) {
+  __shared__ float sP[32][132];
+  const int s = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
+  const float* Vb = a.V + (int64_t)s * a.kv_bs + h * 64;
+  const int KT = (a.nkeys + 15) >> 4, QT = (a.seq + 15) >> 4;
+  for (int i = tid; i < 32 * 128; i += 256) {
+    const int q = i >> 7, j = i & 127;
+    float v = 0.f;
+    if (q < a.seq && j < a.nkeys) {
+      const int64_t pidx = (((int64_t)s * a.seq + q) * a.heads + h) * a.nkeys + j;
+      v = a.P[pidx] * attn_keep(a, pidx);
+    }
+    sP[q][j] = v;
+  }
+  __syncthreads();
+  for (int ti = wave; ti < QT * 4; ti += 4) {
+    const int qt = ti >> 2, dt = ti & 3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KT * 4; ++ks) {
+      const int key = 4 * ks + kg;
+      const float fb = key < a.nkeys ? Vb[(int64_t)key * a.kv_rs + dt * 16 + l16] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sP[qt * 16 + l16][key], fb, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = qt * 16 + 4 * kg + e;
+      if (q < a.seq) a.ctx[((int64_t)s * a.seq + q) * a.ldc + h * 64 + dt * 16 + l16] = acc[e];
+    }
+  }
+}
+
 inline unsigned grid1d(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 
@@ -490,6 +632,11 @@ extern "C" int care_attn_pv(const float* P, const float* V, int64_t kv_bs, int64
   AttnBArgs a{};
   a.P = P; a.V = V; a.kv_bs = kv_bs; a.kv_rs = kv_rs; a.ctx = ctx; a.ldc = ldc;
   a.nseq = nseq; a.seq = seq; a.nkeys = nkeys; a.heads = heads; a.p_drop = p_drop; a.seed = seed;
+  static const bool one_wave = [] { const char* e = getenv("CARE_ATTN_BWD_MFMA"); return e && atoi(e) == 0; }();
+  if (seq <= 32 && nkeys <= 128 && !one_wave) {
+    hipLaunchKernelGGL(attn_pv_mfma_kernel, dim3(nseq * heads), dim3(256), 0, BST, a);
+    return care_launch_status();
+  }
   hipLaunchKernelGGL(attn_pv_kernel, dim3((nseq * heads * seq + 3) / 4), dim3(256), 0, BST, a);
   return care_launch_status();
 }
@@ -504,6 +651,11 @@ extern "C" int care_attn_bwd(const float* Q, int64_t ldq, const float* K, const 
   a.Q = Q; a.ldq = ldq; a.K = K; a.V = V; a.kv_bs = kv_bs; a.kv_rs = kv_rs; a.P = P; a.dctx = dctx; a.ldd = ldd;
   a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.dV = dV; a.dkv_bs = dkv_bs; a.dkv_rs = dkv_rs; a.dbias = dbias; a.bias_ld = bias_ld;
   a.nseq = nseq; a.seq = seq; a.nkeys = nkeys; a.heads = heads; a.p_drop = p_drop; a.seed = seed;
+  static const bool one_wave = [] { const char* e = getenv("CARE_ATTN_BWD_MFMA"); return e && atoi(e) == 0; }();
+  if (seq <= 32 && !one_wave) {  // the matrix-core form: a workgroup per (sequence, head)
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(nseq * heads), dim3(256), 0, BST, a);
+    return care_launch_status();
+  }
   const int lds = (384 + 2 * nkeys * 64) * 4;
   static std::atomic<unsigned long long> ok{0};
   if (lds > 64 * 1024)
