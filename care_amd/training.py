@@ -96,12 +96,27 @@ def _x3_slabs(M: int, N: int, K: int) -> int:
     return max(1, min((512 + tiles - 1) // tiles, K // 256, 64))
 
 
-def _mm_x3(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None, a_t: bool = False, b_t: bool = False) -> torch.Tensor:
+def _absmax_slot(t: torch.Tensor) -> torch.Tensor:
+    """|max| of a tensor as the bit pattern care_split_pieces / care_gemm_tile_split3_scaled derive its power-of-two scale from:
+    a 1-element int32 device tensor (care_absmax; the layout does not matter, so the tensor is swept as it lies)."""
+    slot = torch.empty(1, device=t.device, dtype=torch.int32)
+    flat = t.numel()
+    if flat % 4 == 0 and t.is_contiguous():
+        call("care_absmax", ptr(t), flat, 1, flat, slot.data_ptr())
+    else:
+        p4 = _pad_cols(t if t.dim() == 2 else t.reshape(1, -1), 4)
+        call("care_absmax", ptr(p4), p4.shape[1], p4.shape[0], p4.shape[1], slot.data_ptr())
+    return slot
+
+
+def _mm_x3(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None, a_t: bool = False, b_t: bool = False,
+           a_slot: Optional[torch.Tensor] = None, b_slot: Optional[torch.Tensor] = None) -> torch.Tensor:
     """op(A) [M, K] . op(Bt) [N, K]^T (+ bias) as split products of pre-scaled operands (see TRAIN_GEMM): absolute maxima ->
     power-of-two scales -> fp16 hi / lo pieces -> the LDS-tiled product over the 3 K virtual columns, unscaled in its epilogue;
     K in slabs (added in order) when the output has few tiles.  a_t / b_t: the operand is given TRANSPOSED ([K, M] / [K, N], as
-    dy and x lie in memory for dW = dy^T x) - care_split_pieces reads it as it lies.  Every step a kernel on the current
-    stream; the scales stay on the device."""
+    dy and x lie in memory for dW = dy^T x) - care_split_pieces reads it as it lies.  a_slot / b_slot: the operand's |max| from
+    an earlier product of the same tensor (_absmax_slot: x and W in the forward, dy once for dx and dW).  Every step a kernel
+    on the current stream; the scales stay on the device."""
     A, Bt = _f32c(A), _f32c(Bt)
     M = A.shape[1] if a_t else A.shape[0]
     K = A.shape[0] if a_t else A.shape[1]
@@ -109,21 +124,14 @@ def _mm_x3(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = Non
     slabs = _x3_slabs(M, N, K) if bias is None else 1
     ks = ((K + slabs - 1) // slabs + 63) // 64 * 64
     dev = A.device
-    slots = torch.empty(2, device=dev, dtype=torch.int32)
-    # (|max| over the tensor as it lies: the layout does not matter; rows are back to back, the last dimension a multiple of 4 or not)
-    for t, slot in ((A, slots.data_ptr()), (Bt, slots.data_ptr() + 4)):
-        flat = t.numel()
-        if flat % 4 == 0:
-            call("care_absmax", ptr(t), flat, 1, flat, slot)
-        else:
-            call("care_absmax", ptr(_pad_cols(t, 4)), (t.shape[1] + 3) // 4 * 4, t.shape[0], (t.shape[1] + 3) // 4 * 4, slot)
+    a_slot = _absmax_slot(A) if a_slot is None else a_slot
+    b_slot = _absmax_slot(Bt) if b_slot is None else b_slot
     a2 = torch.empty(slabs * M, 2 * ks, device=dev, dtype=torch.float16)
     w3 = torch.empty(slabs * N, 3 * ks, device=dev, dtype=torch.float16)
-    call("care_split_pieces", ptr(A), A.stride(0), M, K, int(a_t), slabs, ks, ptr(a2), 2, slots.data_ptr())
-    call("care_split_pieces", ptr(Bt), Bt.stride(0), N, K, int(b_t), slabs, ks, ptr(w3), 3, slots.data_ptr() + 4)
+    call("care_split_pieces", ptr(A), A.stride(0), M, K, int(a_t), slabs, ks, ptr(a2), 2, a_slot.data_ptr())
+    call("care_split_pieces", ptr(Bt), Bt.stride(0), N, K, int(b_t), slabs, ks, ptr(w3), 3, b_slot.data_ptr())
     out = torch.empty(slabs * M, N, device=dev, dtype=torch.float32)
-    call("care_gemm_tile_split3_scaled", ptr(a2), ptr(w3), ptr(bias), ptr(out), N, M, N, ks, slots.data_ptr(),
-         slots.data_ptr() + 4, slabs)
+    call("care_gemm_tile_split3_scaled", ptr(a2), ptr(w3), ptr(bias), ptr(out), N, M, N, ks, a_slot.data_ptr(), b_slot.data_ptr(), slabs)
     return out if slabs == 1 else _strided_sum(out, M, slabs, 1, M)
 
 
@@ -167,7 +175,10 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
         ctx.x3 = _use_x3(x.shape[0], W.shape[0], W.shape[1])   # (the three products of a layer have the same 2 M N K)
-        return (_mm_x3 if ctx.x3 else _mm)(x, W, _f32c(b) if b is not None else None)
+        if ctx.x3:   # the operands' |max| once: the backward's products of x and W take them from here
+            ctx.slots = (_absmax_slot(x), _absmax_slot(W))
+            return _mm_x3(x, W, _f32c(b) if b is not None else None, a_slot=ctx.slots[0], b_slot=ctx.slots[1])
+        return _mm(x, W, _f32c(b) if b is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
@@ -176,8 +187,9 @@ class _Linear(torch.autograd.Function):
         if ctx.x3:
             # the same split products; the operands transposed into the [rows, K] layout the tiled kernel streams (torch: data
             # movement only): dx = dy W = dy (W^T)^T, dW = dy^T x = dy^T (x^T)^T
-            dx = _mm_x3(dy, W, b_t=True) if ctx.needs_input_grad[0] else None
-            dW = _mm_x3(dy, x, a_t=True, b_t=True) if ctx.needs_input_grad[1] else None
+            dy_slot = _absmax_slot(dy)
+            dx = _mm_x3(dy, W, b_t=True, a_slot=dy_slot, b_slot=ctx.slots[1]) if ctx.needs_input_grad[0] else None
+            dW = _mm_x3(dy, x, a_t=True, b_t=True, a_slot=dy_slot, b_slot=ctx.slots[0]) if ctx.needs_input_grad[1] else None
             db = _colsum(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
             return dx, dW, db
         dx = _mm_kn(dy, W, False) if ctx.needs_input_grad[0] else None   # dy [M, out] W [out, in]
