@@ -430,6 +430,62 @@ __global__ __launch_bounds__(256) void attention_probs_kernel(AttnArgs p, float*
   if (lane < p.nkeys) o[lane] = e0 * inv;        // keys past the causal bound get exactly 0, like the reference's
   if (lane + 64 < p.nkeys) o[lane + 64] = e1 * inv;  // softmax of -1e9-masked scores would in fp32
 }
+// The same probabilities for whole query sequences of <= 32 positions over fp32 keys (the training forward, the auxiliary
+// entries of the teacher-forced decoder): a workgroup per (sequence, head), S^T[key][query] = K_h Q_h^T on the exact-f32 matrix
+// cores (v_mfma_f32_16x16x4_f32: an fp32 fma chain per output, like the loop above), the score rows in LDS, one wave per row
+// for scale / mask / bias / softmax - the same arithmetic per element.  (The per-(row, head) wave above reads its keys through 64
+// different cache lines per instruction: 0.34 ms per launch at 512 clips x 29 positions x 114 keys, rocprofv3 round 6.)
+__global__ __launch_bounds__(256) void attention_probs_seq_kernel(AttnArgs p, float* probs) {
+  __shared__ float sQ[32][68], sS[32][132];
+  const int sq = blockIdx.x / p.heads, h = blockIdx.x % p.heads;          // sequence = rows sq * seq .. + seq - 1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
+  const int r0 = sq * p.seq, kvb = r0 / p.rows_per_kv;                    // (rows_per_kv % seq == 0: one key block per sequence)
+  const float* Kb = reinterpret_cast<const float*>(p.K) + (int64_t)kvb * p.kv_batch_stride + h * 64;
+  const int KT = (p.nkeys + 15) >> 4, QT = (p.seq + 15) >> 4;
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int q = i >> 6, e = i & 63;
+    sQ[q][e] = q < p.seq ? p.Q[(int64_t)(r0 + q) * p.ldq + h * 64 + e] : 0.f;
+  }
+  __syncthreads();
+  for (int ti = wave; ti < KT * QT; ti += 4) {
+    const int kt = ti / QT, qt = ti - kt * QT;
+    const int key = kt * 16 + l16;
+    const float* krow = Kb + (int64_t)min(key, p.nkeys - 1) * p.kv_row_stride + kg;
+    float fa[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) fa[ks] = krow[4 * ks];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks], sQ[qt * 16 + l16][4 * ks + kg], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sS[qt * 16 + l16][kt * 16 + 4 * kg + e] = acc[e];
+  }
+  __syncthreads();
+  for (int i = wave; i < p.seq; i += 4) {
+    int nk = p.nkeys;
+    if (p.causal) nk = min(nk, i + 1 + p.causal_off);
+    float sc[2];
+    float m = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = lane + 64 * u;
+      sc[u] = -INFINITY;
+      if (j < nk) {
+        float d = sS[i][j] * 0.125f;
+        if (p.pad_tok && p.pad_tok[(int64_t)kvb * p.pad_stride + j] == p.pad_id) d = -1e9f;
+        if (p.bias) d += p.bias[h * p.bias_ld + j];
+        sc[u] = d;
+      }
+      m = fmaxf(m, sc[u]);
+    }
+    m = care_wave_max(m);
+    const float e0 = sc[0] == -INFINITY ? 0.f : expf(sc[0] - m), e1 = sc[1] == -INFINITY ? 0.f : expf(sc[1] - m);
+    const float inv = 1.0f / care_wave_sum(e0 + e1);
+    float* o = probs + ((int64_t)(r0 + i) * p.heads + h) * p.nkeys;
+    if (lane < p.nkeys) o[lane] = e0 * inv;
+    if (lane + 64 < p.nkeys) o[lane + 64] = e1 * inv;
+  }
+}
 }  // namespace
 
 extern "C" int care_attention_probs(const float* Q, int64_t ldq, const void* K, int kv_dtype, int64_t kv_batch_stride,
@@ -444,6 +500,12 @@ extern "C" int care_attention_probs(const float* Q, int64_t ldq, const void* K, 
   p.rows_per_kv = rows_per_kv; p.nkeys = nkeys; p.causal = causal; p.seq = seq; p.causal_off = 0;
   p.pad_tok = pad_tok; p.pad_stride = pad_stride; p.pad_id = pad_id; p.bias = bias; p.bias_ld = bias_ld;
   p.rows = rows; p.heads = heads;
+  // whole sequences of <= 32 positions over fp32 keys, one key block per sequence: the matrix-core form
+  static const bool row_form = [] { const char* e = getenv("CARE_PROBS_SEQ"); return e && atoi(e) == 0; }();
+  if (kv_dtype == CARE_F32 && seq >= 8 && seq <= 32 && rows % seq == 0 && rows_per_kv % seq == 0 && !row_form) {
+    hipLaunchKernelGGL(attention_probs_seq_kernel, dim3((rows / seq) * heads), dim3(256), 0, (hipStream_t)stream, p, probs);
+    return care_launch_status();
+  }
   const dim3 grid((rows * heads + 3) / 4), block(256);
   if (kv_dtype == CARE_BF16) hipLaunchKernelGGL(attention_probs_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p, probs);
   else hipLaunchKernelGGL(attention_probs_kernel<float>, grid, block, 0, (hipStream_t)stream, p, probs);
