@@ -10,12 +10,13 @@ forward AND backward are HIP kernels behind the C ABI (include/care_hip.h):
     from a few GFLOP per product on (TRAIN_GEMM "auto", round 6): the three products as SPLIT PRODUCTS at the 16-bit matrix
     rate - three fp16 MFMA passes over hi / lo pieces of operands pre-scaled by an exact power of two each (care_absmax ->
     care_split_pieces (the operands read as they lie, transposed or not) -> care_gemm_tile_split3_scaled, K in slabs for few-tile products;
-    ~2^-22 per product, gradients within the same 1e-4 of the oracle's autograd): 19.5 -> 15.8 ms per 512-clip step;
+    ~2^-22 per product, gradients within the same 1e-4 of the oracle's autograd);
   * LayerNorm (+ residual): care_add_ln / care_ln_bwd; activations: care_act; dropout: care_dropout (a counter-based
     generator keyed by (seed, element): the backward re-creates the forward's mask; RNG parity with torch is not a
     goal, SURVEY.md 7.7);
   * attention: care_attention_probs (softmax(QK^T / 8 + mask + bias), Attention.py:83-118) -> care_attn_pv
-    (dropout(P) V) forward, care_attn_bwd backward (dQ, dK, dV and the hybrid-bias gradient);
+    (dropout(P) V) forward, care_attn_bwd backward (dQ, dK, dV and the hybrid-bias gradient) - each as small exact-f32 MFMA
+    products per (sequence, head) since round 6 (csrc/backward.hip, csrc/attention.hip);
   * embeddings: care_gather_rows / care_scatter_add_rows, care_add_pos_sem; the concept head: care_concept_finish /
     care_concept_bwd; mean pooling: care_group_mean / care_bcast_rows.
 
@@ -67,8 +68,8 @@ def _mm(A: torch.Tensor, Bt: torch.Tensor, bias: Optional[torch.Tensor] = None) 
 #   "fp16x3" every product as three fp16 MFMA passes over hi / lo pieces of operands pre-scaled by an exact power of two each
 #            (care_gemm_tile_split3_scaled: ~2^-22 relative per product - fp32-grade - at the 16-bit matrix rate / 3);
 #   "auto"   (default) per product: the split form from X3_MIN_FLOPS on, the exact form below.
-# *Measured* round 6 (one MI355X, msrvtt_care, forward + backward, ms per step, f32 / fp16x3): 512 clips 19.5 / 15.8, 64 clips
-# 4.5 / 5.1 - the split form pays its fixed costs (two |max| sweeps, two piece writes, a slab sum: ~6 launches) back from a few
+# *Measured* round 6 (one MI355X, msrvtt_care, forward + backward, ms per step, f32 / fp16x3 / auto): 512 clips 15.7 / 11.3 / 10.8,
+# 64 clips 4.0 / 4.6 / 3.9 (19.5 / 15.8 and 4.5 / 5.1 before the attention kernels moved to the matrix cores) - the split form pays its fixed costs (two |max| sweeps, two piece writes, a slab sum: ~6 launches) back from a few
 # GFLOP per product on; below, the exact kernel on the operands as they lie is faster.  Gradients of both forms meet the same
 # 1e-4 of the oracle's autograd (tests/test_gpu_training.py), so a step may mix them.
 import os as _os
