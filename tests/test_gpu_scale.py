@@ -55,6 +55,23 @@ def _translate(model, opt, mode, beam):
     return hyps, scores
 
 
+# Concept selection (pred_attribute.py:262-264: the top-k of sigmoid probabilities, SORTED - the rank is the concept's position
+# embedding) has ties of its own: of these 2990 clips 21 have two neighbours of the sorted top-(k + 1) probabilities within 1e-6
+# of each other and 6 within 3e-7 - five fp32 ulps at 0.76 .. 0.97 (*measured* on the oracle, round 6).  The probabilities come
+# from a sum of 1536 fp32 products, so ANY other summation order - torch's CPU blocking, the exact-f32 matrix cores' K loop, the
+# small batches' K ranges side by side (engine_encode._concept_linear) - may swap such a pair, and with it the semantic memory
+# the whole caption is decoded against.  A clip whose oracle concepts have such a pair is explained by it.
+CONCEPT_TIE = 2e-6
+
+
+def _concept_gap(P, opt, one) -> float:
+    from oracle import care_cpu
+
+    p = care_cpu.encoding_phase(P, opt, one)["preds_attr"]
+    top, _ = p.topk(opt["use_attr_topk"] + 1, dim=1)
+    return float((top[:, :-1] - top[:, 1:]).min())
+
+
 def _oracle_greedy():
     """The CPU oracle's greedy captions, scores and margins of all 2990 clips (once per session: ~25 s on 16 host threads)."""
     from oracle import care_cpu
@@ -85,15 +102,19 @@ def test_greedy_captions_of_2990_clips_against_the_oracle(mode):
     differ = [i for i in range(N_CLIPS) if got[i][0] != ref[i][0]]
     clear = sum(1 for g in gaps if g["select"] >= CLEAR_MARGIN)
     tie_tol = 5e-2 if mode == "bf16" else 1e-2                       # (peaked rows scale the logit noise: test_gpu_properties)
+    concept_ties = []
     for i in differ:
+        one = [f[i: i + 1] for f in feats]
+        if _concept_gap(P, opt, one) < CONCEPT_TIE:   # (see CONCEPT_TIE: another memory, not another decision over the same one)
+            concept_ties.append(i)
+            continue
         assert gaps[i]["select"] < CLEAR_MARGIN, "clip {}: every reference step decided by >= {} but the {} ids differ".format(
             i, CLEAR_MARGIN, mode)
-        one = [f[i: i + 1] for f in feats]
         inputs = care_cpu.inputs_for_decoder(opt, care_cpu.encoding_phase(P, opt, one))
         _audit_greedy(P, opt, inputs, got[i][0], ref[i][0], tie_tol)
     same = N_CLIPS - len(differ)
     _audit_record(test="msrvtt_test_scale_greedy", mode=mode, clips=N_CLIPS, identical=same, clear_margin_clips=clear,
-                  differing=differ[:32])
+                  differing=differ[:32], concept_rank_ties=concept_ties)
     # fp16: >= 99 % of the captions are the reference's; bf16 (8 significand bits): >= 96 %
     assert same >= (0.99 if mode == "fp16" else 0.96) * N_CLIPS, "{}: {} of {} greedy captions identical".format(mode, same, N_CLIPS)
 
@@ -124,13 +145,16 @@ def test_beam5_winners_of_2990_clips(mode):
     # a beam's decisions compare sums of several steps' log-probabilities of two hypotheses, whose errors add (*measured*: the
     # one clip of 2990 that needed more than 0.05 had select 0.058, rank 0.092)
     tol = CLEAR_MARGIN if mode == "bf16" else 1e-2
-    better = 0
+    better, concept_ties = 0, []
     for i in differ[:48]:  # (a full oracle search + two exact rescorings per clip)
         # A beam search is path dependent: a flip at ANY near-tie of the reference search - the beam_size-th against the next
         # candidate of a step (`select`), the winner's ancestry against pruning (`best_slack`), the finished list's order
         # (`rank`) - can change the winner, for better or worse.  So a differing clip must show such a near-tie in the ORACLE's
         # own search of that clip, or score (exactly) within the tolerance of the reference winner.
         one = [f[i: i + 1] for f in feats]
+        if _concept_gap(P, opt, one) < CONCEPT_TIE:   # (see CONCEPT_TIE; also where the fp32 mode and the oracle may part)
+            concept_ties.append(i)
+            continue
         o_hyps, o_scores, gaps = care_cpu.translate_batch(P, dict(opt, beam_size=5, topk=1), one, return_gaps=True)
         assert o_hyps[0][0] == ref[i][0], "clip {}: the fp32-mode winner is not the oracle's".format(i)
         inputs = care_cpu.inputs_for_decoder(opt, care_cpu.encoding_phase(P, opt, one))
@@ -142,5 +166,5 @@ def test_beam5_winners_of_2990_clips(mode):
                 i, mode, mine, theirs, g)
     same = N_CLIPS - len(differ)
     _audit_record(test="msrvtt_test_scale_beam5", mode=mode, clips=N_CLIPS, identical=same, differing=differ[:32],
-                  audited=min(len(differ), 48), audited_with_a_better_exact_score=int(better))
+                  audited=min(len(differ), 48), audited_with_a_better_exact_score=int(better), concept_rank_ties=concept_ties)
     assert same >= (0.98 if mode == "fp16" else 0.93) * N_CLIPS, "{}: {} of {} beam winners identical".format(mode, same, N_CLIPS)

@@ -20,8 +20,8 @@ stats beam5_B128 $B --batch 128 --beam 5 --config msrvtt_care_beam5 --steps 20 -
 stats beam5_B1 $B --batch 1 --beam 5 --config msrvtt_care_beam5 --steps 20 --warmup 3
 stats train_B64 python3 $R/tools/train_prof.py 64 10
 stats train_B512 python3 $R/tools/train_prof.py 512 5
-export CARE_TRAIN_GEMM=fp16x3   # (the split-product form of the training GEMMs; exported here: nothing but the program goes behind `--`)
-stats train_B512_x3 python3 $R/tools/train_prof.py 512 5
+export CARE_TRAIN_GEMM=f32   # (every training product in the exact-f32 form; the default "auto" above takes the split products
+stats train_B512_f32 python3 $R/tools/train_prof.py 512 5   #  for these sizes.  Exported here: nothing but the program goes behind `--`)
 unset CARE_TRAIN_GEMM
 stats trace_fp16 $B --steps 5 --warmup 2 --dtype fp16
 stats beam5_chain_B128 python3 $R/tools/chain_prof.py 128 3

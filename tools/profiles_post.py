@@ -21,7 +21,7 @@ head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture
 
 STATS = {"trace": "bench_B32768_bf16", "trace_vatex": "vatex_care_large_B4096_bf16", "trace_vatex16k": "vatex_care_large_B16384_bf16", "greedy_B128": "small_batch_greedy_B128",
          "greedy_B1": "small_batch_greedy_B1", "beam5_B128": "small_batch_beam5_B128", "beam5_B1": "small_batch_beam5_B1",
-         "train_B64": "training_step_B64", "train_B512": "training_step_B512", "train_B512_x3": "training_fp16x3_B512", "trace_fp16": "bench_B32768_fp16", "beam5_chain_B128": "small_batch_beam5_chain_B128",
+         "train_B64": "training_step_B64", "train_B512": "training_step_B512", "train_B512_f32": "training_f32_B512", "trace_fp16": "bench_B32768_fp16", "beam5_chain_B128": "small_batch_beam5_chain_B128",
          "beam5_multilaunch_B512": "mid_batch_beam5_multilaunch_B512"}
 ours = lambda k: ("anonymous namespace" in k or k.startswith("_ZN12_GLOBAL__N_1") or k.startswith("_Z17split2_act")) and "at::native" not in k
 
@@ -159,6 +159,13 @@ def readings():
         L += ["", "`{}_training_step_B64_kernel_stats.csv` (`tools/train_prof.py 64 10`: 13 steps): {:.2f} ms of kernels and {:.0f} launches per "
               "training step; top: ".format(ROUND, tot / 13 / 1e6, calls / 13) +
               ", ".join("`{}` {:.2f} ms".format(short(r["Name"])[:40], float(r["TotalDurationNs"]) / 13 / 1e6) for r in rows[:5]) + "."]
+    for nm, what, n in (("training_step_B512", "`tools/train_prof.py 512 5`, CARE_TRAIN_GEMM=auto: the split products", 8),
+                        ("training_f32_B512", "the same with CARE_TRAIN_GEMM=f32: every product exact f32", 8)):
+        rows = kernel_stats(nm)
+        if rows:
+            tot = sum(float(r["TotalDurationNs"]) for r in rows)
+            L += ["", "`{}_{}_kernel_stats.csv` ({}; {} steps): {:.2f} ms of kernels per training step of 512 clips; top: ".format(ROUND, nm, what, n, tot / n / 1e6) +
+                  ", ".join("`{}` {:.2f} ms".format(short(r["Name"])[:40], float(r["TotalDurationNs"]) / n / 1e6) for r in rows[:6]) + "."]
     for fname, title in ((ROUND + "_sq_counters.json", "SQ counters at 32768 rows (tools/pmc_target.py)"),
                          (ROUND + "_sq_counters_resident_beam5_B128.json", "SQ counters of the resident beam launch (128 clips x 5)")):
         path = os.path.join(DST, fname)
