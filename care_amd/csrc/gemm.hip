@@ -264,6 +264,57 @@ int launch(const GemmArgs& p, hipStream_t st) {
   return care_launch_status();
 }
 
+// Few output tiles and exact f32 (small batches: the concept head's [clips <= 128, 2048] x [2048, 500] and [clips, 512] x
+// [512, 512]; every Linear of the fp32 mode at a few rows): gemm_kernel gives a wave 2 x 2 tiles of 16 x 16 - four chains of
+// K / 4 dependent 32-cycle MFMAs through one SIMD's matrix pipe, a barrier per 32 columns - on 8 - 16 workgroups: 42 us at 1
+// clip, 53 us at 128 for the concept scores (*measured* rocprofv3 round 6, twice per pass).  Here a wave owns ONE 16 x 16 tile
+// and hands the matrix core the SAME operands in the SAME order straight from registers - a lane's 16 contiguous bytes of its
+// row per 16 K columns, element j to MFMA j: the f32 K order of the header - so the outputs are BIT-IDENTICAL to
+// gemm_kernel<float>'s (tests/test_gpu_kernels.py) and the one chain of K / 4 MFMAs is the whole critical path (K = 2048: 7 us);
+// no LDS, no barrier, 8 blocks of 16 columns in flight per operand (2 when K / 16 is not a multiple of 8).  The four waves of a workgroup share their A rows.
+constexpr long FEW_MAX_TILES = 512;   // 16 x 16 tiles (each streams 2 x 16 x K floats from L2: beyond this the LDS tiles' reuse wins)
+
+template <bool GELU, int U>   // U blocks of 16 columns in flight per operand; K / 16 % U == 0
+__global__ __launch_bounds__(256) void gemm_few_tiles_f32_kernel(GemmArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+  const int tiles_n = (p.N + 15) / 16, groups_n = (tiles_n + 3) / 4;
+  const int tm = blockIdx.x / groups_n, tn = (blockIdx.x % groups_n) * 4 + wave;
+  if (tn >= tiles_n) return;
+  // (rows / columns past M / N are clamped, like gemm_kernel: their products are never stored)
+  const float* a = p.A + (int64_t)min(tm * 16 + fr, p.M - 1) * p.lda + fg * 4;
+  const float* b = reinterpret_cast<const float*>(p.W) + (int64_t)min(tn * 16 + fr, p.N - 1) * p.K + fg * 4;
+  const int nb = p.K / 16;
+  f32x4 ra[U], rb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    ra[u] = *reinterpret_cast<const f32x4*>(a + u * 16);
+    rb[u] = *reinterpret_cast<const f32x4*>(b + u * 16);
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < nb; kb += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[u][j], rb[u][j], acc, 0, 0, 0);
+      const int nxt = min(kb + u + U, nb - 1);   // unconditional refill of the slot just used (the tail re-reads the last block)
+      ra[u] = *reinterpret_cast<const f32x4*>(a + nxt * 16);
+      rb[u] = *reinterpret_cast<const f32x4*>(b + nxt * 16);
+    }
+  }
+  const int col = tn * 16 + fr;
+  if (col >= p.N) return;
+  const float bv = p.bias ? p.bias[col] : 0.0f;
+  const bool second = col >= p.n_split;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = tm * 16 + fg * 4 + j;
+    if (row >= p.M) continue;
+    const float v = apply_act<GELU>(acc[j] + bv, p.act);
+    if (!second) store_out(p.C0, p.ldc0, p.c0_bf16, row, col, v);
+    else store_out(p.C1, p.ldc1, p.c1_bf16, row, col - p.n_split, v);
+  }
+}
+
 // W [N, K] fp32 -> [N, 3K] fp16 pieces  W_hi | W_lo | W_hi  (the operand of care_gemm_split3)
 __global__ void split3_weight_kernel(const float* W, unsigned short* out, int N, int K) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -313,6 +364,17 @@ extern "C" int care_gemm(const float* A, int64_t lda, const void* W, int wdtype,
   if (const char* e = getenv("CARE_GEMM_TILE")) big = atoi(e) >= 128;  // tuning override
   if (wdtype == CARE_BF16)
     return big ? launch<bf16_t, 128, 128, false>(p, st) : launch<bf16_t, 64, 64, false>(p, st);
+  // few 16 x 16 tiles: one per wave, the same bits (CARE_GEMM_FEW_TILES=0: the LDS-tiled kernel at every size - the tests' reference)
+  const long t16 = (long)((M + 15) / 16) * ((N + 15) / 16);
+  const char* few = getenv("CARE_GEMM_FEW_TILES");
+  if (t16 <= FEW_MAX_TILES && !(few && atoi(few) == 0)) {
+    const unsigned groups = (unsigned)(((M + 15) / 16) * (((N + 15) / 16 + 3) / 4));
+#define FEW_LAUNCH(G, U) hipLaunchKernelGGL((gemm_few_tiles_f32_kernel<G, U>), dim3(groups), dim3(256), 0, st, p)
+    if (K % 128 == 0) { if (act == CARE_ACT_GELU) FEW_LAUNCH(true, 8); else FEW_LAUNCH(false, 8); }
+    else { if (act == CARE_ACT_GELU) FEW_LAUNCH(true, 2); else FEW_LAUNCH(false, 2); }   // (K % 32 == 0: check_common)
+#undef FEW_LAUNCH
+    return care_launch_status();
+  }
   return big ? launch<float, 128, 128, false>(p, st) : launch<float, 64, 64, false>(p, st);
 }
 

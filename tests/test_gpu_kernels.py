@@ -1236,3 +1236,35 @@ def test_gemm_kn_transposed_operands(M, N, K, a_is_km):
         _call("care_gemm_kn", _p(Av), Av.stride(0), int(a_is_km), _p(B), B.stride(0), _p(C2), C2.stride(0), M, N, K)
         ref2 = ((Av.t() if a_is_km else Av).double() @ B.double())
         assert (C2[:, :N].double() - ref2).abs().max().item() < 2e-6 * math.sqrt(K) * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 500, 2048), (128, 500, 1536), (128, 512, 512), (5, 33, 96), (17, 1536, 512), (255, 500, 2048),
+                                   (16, 8192, 64)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_f32_gemm_of_few_tiles_is_bit_identical_to_the_lds_tiled_kernel(M, N, K, act, monkeypatch):
+    """care_gemm with fp32 weights and <= 512 tiles of 16 x 16 (the concept head of small batches, the fp32 mode at a few rows): a
+    wave per tile, operands from registers in the LDS-tiled kernel's K order - the SAME BITS as that kernel (CARE_GEMM_FEW_TILES=0),
+    for fp32 and 16-bit outputs, split destinations and leading dimensions beyond the row."""
+    h16 = torch.bfloat16   # (2-byte outputs of the loaded library's 16-bit type, compared as bits)
+    Abig = _rand(M, K + 8, seed=21)
+    A = Abig[:, :K]
+    W = _rand(N, K, seed=22, scale=1 / math.sqrt(K))
+    bias = _rand(N, seed=23)
+    ns = N if N % 32 else N // 2   # split destinations where the kernel takes them (n_split % 16 == 0)
+    outs = {}
+    for few in ("1", "0"):
+        monkeypatch.setenv("CARE_GEMM_FEW_TILES", few)
+        c0 = torch.full((M, ns + 3), float("nan"), device=DEV)
+        c1 = torch.full((M, N - ns + 5), float("nan"), device=DEV, dtype=h16) if ns < N else None
+        _call("care_gemm", _p(A), A.stride(0), _p(W), 0, _p(bias), _p(c0), c0.stride(0), 0, _p(c1) if c1 is not None else None,
+              c1.stride(0) if c1 is not None else 0, 1, ns, M, N, K, act)
+        nb = torch.full((M, N), float("nan"), device=DEV)
+        _call("care_gemm", _p(A), A.stride(0), _p(W), 0, None, _p(nb), N, 0, None, 0, 0, N, M, N, K, 0)
+        torch.cuda.synchronize()
+        outs[few] = (c0, c1, nb)
+    for a, b in zip(outs["1"], outs["0"]):
+        if a is not None:
+            assert torch.equal(a.view(torch.int32 if a.dtype == torch.float32 else torch.int16),
+                               b.view(torch.int32 if b.dtype == torch.float32 else torch.int16))   # (NaN padding included)
+    ref = A.double() @ W.double().t()
+    assert (outs["1"][2].double() - ref).abs().max().item() < 2e-4
