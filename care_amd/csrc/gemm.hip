@@ -266,20 +266,22 @@ int launch(const GemmArgs& p, hipStream_t st) {
 
 // Few output tiles and exact f32 (small batches: the concept head's [clips <= 128, 2048] x [2048, 500] and [clips, 512] x
 // [512, 512]; every Linear of the fp32 mode at a few rows): gemm_kernel gives a wave 2 x 2 tiles of 16 x 16 - four chains of
-// K / 4 dependent 32-cycle MFMAs through one SIMD's matrix pipe, a barrier per 32 columns - on 8 - 16 workgroups: 42 us at 1
-// clip, 53 us at 128 for the concept scores (*measured* rocprofv3 round 6, twice per pass).  Here a wave owns ONE 16 x 16 tile
-// and hands the matrix core the SAME operands in the SAME order straight from registers - a lane's 16 contiguous bytes of its
-// row per 16 K columns, element j to MFMA j: the f32 K order of the header - so the outputs are BIT-IDENTICAL to
-// gemm_kernel<float>'s (tests/test_gpu_kernels.py) and the one chain of K / 4 MFMAs is the whole critical path (K = 2048: 7 us);
-// no LDS, no barrier, 8 blocks of 16 columns in flight per operand (2 when K / 16 is not a multiple of 8).  The four waves of a workgroup share their A rows.
+// K / 4 dependent MFMAs through one SIMD's matrix pipe, a barrier per 32 columns - on 8 - 16 workgroups: 50 us at 1 clip,
+// 53 us at 128 for the concept scores (*measured* rocprofv3 round 6, twice per pass).  Here a wave - a workgroup of its own, so
+// the tiles spread over the chip - owns ONE 16 x 16 tile and hands the matrix core the SAME operands in the SAME order straight
+// from registers - a lane's 16 contiguous bytes of its row per 16 K columns, element j to MFMA j: the f32 K order of the header -
+// so the outputs are BIT-IDENTICAL to gemm_kernel<float>'s (tests/test_gpu_kernels.py) and the one chain of K / 4 MFMAs is the
+// whole critical path; no LDS, no barrier, 8 blocks of 16 columns in flight per operand (4 / 2 when K / 16 is no multiple of 8).
+// *Measured* (tools/few_tiles_probe.py, us, this kernel / the LDS-tiled one): 1 x 500 x 2048 11.8 / 50.3, 128 x 500 x 2048 12.9 /
+// 52.8, 128 x 512 x 512 5.2 / 17.0, 256 x 500 x 2048 17.9 / 53.0; 4 blocks in flight the same, 2: 18 - 22; four waves per
+// workgroup (64 CUs instead of 256): 20 - 32.
 constexpr long FEW_MAX_TILES = 512;   // 16 x 16 tiles (each streams 2 x 16 x K floats from L2: beyond this the LDS tiles' reuse wins)
 
-template <bool GELU, int U>   // U blocks of 16 columns in flight per operand; K / 16 % U == 0
-__global__ __launch_bounds__(256) void gemm_few_tiles_f32_kernel(GemmArgs p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-  const int tiles_n = (p.N + 15) / 16, groups_n = (tiles_n + 3) / 4;
-  const int tm = blockIdx.x / groups_n, tn = (blockIdx.x % groups_n) * 4 + wave;
-  if (tn >= tiles_n) return;
+template <bool GELU, int U>   // U blocks of 16 columns in flight per operand (K / 16 % U == 0)
+__global__ __launch_bounds__(64) void gemm_few_tiles_f32_kernel(GemmArgs p) {
+  const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
+  const int tiles_n = (p.N + 15) / 16;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
   // (rows / columns past M / N are clamped, like gemm_kernel: their products are never stored)
   const float* a = p.A + (int64_t)min(tm * 16 + fr, p.M - 1) * p.lda + fg * 4;
   const float* b = reinterpret_cast<const float*>(p.W) + (int64_t)min(tn * 16 + fr, p.N - 1) * p.K + fg * 4;
@@ -368,10 +370,11 @@ extern "C" int care_gemm(const float* A, int64_t lda, const void* W, int wdtype,
   const long t16 = (long)((M + 15) / 16) * ((N + 15) / 16);
   const char* few = getenv("CARE_GEMM_FEW_TILES");
   if (t16 <= FEW_MAX_TILES && !(few && atoi(few) == 0)) {
-    const unsigned groups = (unsigned)(((M + 15) / 16) * (((N + 15) / 16 + 3) / 4));
-#define FEW_LAUNCH(G, U) hipLaunchKernelGGL((gemm_few_tiles_f32_kernel<G, U>), dim3(groups), dim3(256), 0, st, p)
-    if (K % 128 == 0) { if (act == CARE_ACT_GELU) FEW_LAUNCH(true, 8); else FEW_LAUNCH(false, 8); }
-    else { if (act == CARE_ACT_GELU) FEW_LAUNCH(true, 2); else FEW_LAUNCH(false, 2); }   // (K % 32 == 0: check_common)
+    const unsigned tiles = (unsigned)t16;
+    const bool gelu = act == CARE_ACT_GELU;
+#define FEW_LAUNCH(UU) do { if (gelu) hipLaunchKernelGGL((gemm_few_tiles_f32_kernel<true, UU>), dim3(tiles), dim3(64), 0, st, p); \
+                            else hipLaunchKernelGGL((gemm_few_tiles_f32_kernel<false, UU>), dim3(tiles), dim3(64), 0, st, p); } while (0)
+    if (K % 128 == 0) FEW_LAUNCH(8); else if (K % 64 == 0) FEW_LAUNCH(4); else FEW_LAUNCH(2);   // (K % 32 == 0: check_common)
 #undef FEW_LAUNCH
     return care_launch_status();
   }
