@@ -382,21 +382,33 @@ def translate_batch(P, opt: dict, feats: List[torch.Tensor], return_trace: bool 
     `rank` (neighbours among the n_best + 1 best finished hypotheses, length-normalised) and
     `best_slack` (how close the winning hypothesis' ancestry ever came to being pruned).
     """
+    return translate_batch_ensemble([P], [opt], [feats], return_trace=return_trace, return_gaps=return_gaps)
+
+
+def translate_batch_ensemble(Ps, opts, feats_list, return_trace: bool = False, return_gaps: bool = False):
+    """`Translator_ARFormer.translate_batch` for a LIST of models (models/Translator.py:39-52,112-133: every model encodes its
+    own features - `batch['feats'][index]` when the batch carries one feature list per model, Wrapper.ModelEnsemble - and
+    decodes the shared prefixes; the step's word log-probabilities are the models' log_softmax averaged equally, :130-131).
+    The search options (beam_size, topk, beam_alpha, max_len) are the translator's, i.e. `opts[0]`'s."""
+    opt = opts[0]
     bm = int(opt.get("beam_size", 5))
     n_best = int(opt.get("topk", 1))
     alpha = float(opt.get("beam_alpha", 1.0))
     max_len = int(opt.get("max_len", 30))
     with torch.no_grad():
-        enc = encoding_phase(P, opt, feats)
-        inputs = {k: _repeat_rows(v, bm) for k, v in inputs_for_decoder(opt, enc).items()}
-        n_clips = inputs["encoder_hidden_states"].shape[0] // bm
+        all_inputs = []
+        for P, o, feats in zip(Ps, opts, feats_list):
+            enc = encoding_phase(P, o, feats)
+            all_inputs.append({k: _repeat_rows(v, bm) for k, v in inputs_for_decoder(o, enc).items()})
+        n_clips = all_inputs[0]["encoder_hidden_states"].shape[0] // bm
         beams = [HostBeam(bm, max_len, n_best) for _ in range(n_clips)]
         active = list(range(n_clips))
         margins = []
         for t in range(1, max_len):
             ids = torch.stack([beams[i].prefixes() for i in active]).view(-1, t)
-            logits = decoding_phase(P, opt, ids, inputs, last_time_step_logits=True)["logits"]
-            logp = torch.log_softmax(logits, dim=1)
+            logps = [torch.log_softmax(decoding_phase(P, o, ids, inputs, last_time_step_logits=True)["logits"], dim=1)
+                     for P, o, inputs in zip(Ps, opts, all_inputs)]
+            logp = logps[0] if len(logps) == 1 else torch.stack(logps, dim=0).mean(0)
             if return_trace:
                 top2 = logp.topk(2, dim=1)[0]
                 margins.append(float((top2[:, 0] - top2[:, 1]).min()))
@@ -407,8 +419,9 @@ def translate_batch(P, opt: dict, feats: List[torch.Tensor], return_trace: bool 
             if len(still) != len(active):
                 # models/Translator.py:145-209: finished clips are removed from every cached tensor
                 sel = torch.tensor(still, dtype=torch.long)
-                for k, v in inputs.items():
-                    inputs[k] = v.view(len(active), -1).index_select(0, sel).view(len(still) * bm, *v.shape[1:])
+                for inputs in all_inputs:
+                    for k, v in inputs.items():
+                        inputs[k] = v.view(len(active), -1).index_select(0, sel).view(len(still) * bm, *v.shape[1:])
                 active = [active[pos] for pos in still]
         # models/Translator.py:211-220: `n_best = min(n_best, len(scores))` is re-assigned
         # inside the loop over clips, so once one clip has fewer finished hypotheses than

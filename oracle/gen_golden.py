@@ -184,6 +184,64 @@ def run_case(get_framework, get_translator, name, cfg, B, seed, overrides, row_s
     print("{:32s} params={} hyp_lens={} size={:.0f}KB".format(name, meta["n_params"], lens_s, os.path.getsize(path) / 1024))
 
 
+# Model ensembling (models/Translator.py:39-52,112-133; models/Wrapper.py ModelEnsemble feeds one feature list per model):
+# name, [(config, seed, overrides, row_scale) per model], B, translator overrides (the search options are the FIRST model's opt),
+# whether each model gets feature lists of its own
+ENS_EOS = {VOCAB_W: {EOS_ROW: 4.0, PAD_ROW: 3.0}}
+ENSEMBLE_CASES = [
+    ("ens_care_x2_beam5_b3", [("msrvtt_care_beam5", 17, {}, ENS_EOS), ("msrvtt_care_beam5", 71, {}, ENS_EOS)], 3, {"topk": 2}, False),
+    ("ens_care_base_greedy_b3", [("msrvtt_care", 14, {}, ENS_EOS), ("msrvtt_base_ami", 12, {}, ENS_EOS)], 3, {}, True),
+    ("ens_x3_beam5_b2", [("msrvtt_care_beam5", 15, {}, ENS_EOS), ("msrvtt_base_ami", 20, {}, ENS_EOS),
+                         ("msrvtt_care_g1l0", 62, {}, ENS_EOS)], 2, {"beam_size": 5, "topk": 3}, True),
+]
+ENS_DIR = os.path.join(OUT_DIR, "ensemble")
+
+
+def run_ensemble_case(get_framework, get_translator, name, members, B, t_over, own_feats):
+    """The reference Translator over a list of reference models; stored: the hypotheses and scores, the recipe of every member
+    (tests/conftest.py EnsembleCase regenerates weights and features from the seeds) and the oracle's decision margins."""
+    from oracle import care_cpu
+
+    models, opts, sds, feats_list, metas = [], [], [], [], []
+    for cfg, seed, overrides, row_scale in members:
+        opt = make_opt(cfg, **{**overrides, **(t_over if not models else {})})
+        torch.manual_seed(0)
+        model = get_framework(opt).eval()
+        shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        sd = synth_state_dict(seed, shapes, row_scale=row_scale)
+        model.load_state_dict(sd, strict=True)
+        # one feature list per model (seeded by the member) or the first member's for all (the modalities must agree then)
+        fseed = seed if own_feats else members[0][1]
+        feats = synth_feats(fseed, feat_shapes(opt, B))
+        models.append(model); opts.append(opt); sds.append(sd); feats_list.append(feats)
+        metas.append(dict(config=cfg, seed=seed, feats_seed=fseed, overrides={**overrides, **(t_over if len(models) == 1 else {})},
+                          row_scale={k: {str(r): f for r, f in v.items()} for k, v in row_scale.items()},
+                          state_dict=[[k, list(sh)] for k, sh in shapes],
+                          sha256={"feats0": tensor_sha256(feats[0]), VOCAB_W: tensor_sha256(sd[VOCAB_W])}))
+    translator = get_translator(opts[0])
+    batch = {"feats": [[f.clone() for f in fl] for fl in feats_list] if own_feats else [f.clone() for f in feats_list[0]]}
+    hyps, scores = translator.translate_batch(models, batch)
+    T = opts[0]["max_len"] - 1
+    arr, lens = pad_hyps(hyps, T)
+    sc = np.full(lens.shape, np.nan, dtype=np.float64)
+    for i, s_ in enumerate(scores):
+        sc[i, : len(s_)] = s_
+    o_hyps, o_scores, gaps = care_cpu.translate_batch_ensemble(sds, opts, feats_list, return_gaps=True)
+    assert o_hyps == hyps, "oracle and reference disagree on {}".format(name)
+    assert max(abs(a - b) for x, y in zip(o_scores, scores) for a, b in zip(x, y)) < 1e-5
+    rec = dict(hyps=arr, hyp_lens=lens, hyp_scores=sc,
+               gap_select=np.asarray([g["select"] for g in gaps], dtype=np.float64),
+               gap_rank=np.asarray([min(g["rank"], 1e30) for g in gaps], dtype=np.float64),
+               gap_best_slack=np.asarray([min(g["best_slack"], 1e30) for g in gaps], dtype=np.float64),
+               meta_json=np.array(json.dumps(dict(name=name, batch=B, own_feats=own_feats, members=metas,
+                                                  generator_version=GENERATOR_VERSION, torch_version=torch.__version__))))
+    os.makedirs(ENS_DIR, exist_ok=True)
+    path = os.path.join(ENS_DIR, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("{:32s} members={} hyp_lens={} min gaps select {:.3g} rank {:.3g} size={:.0f}KB".format(
+        name, len(members), lens.tolist(), float(rec["gap_select"].min()), float(rec["gap_rank"].min()), os.path.getsize(path) / 1024))
+
+
 def host_helpers_golden():
     """Known answers of the host-side helpers next to the path: frame sampling
     (misc/utils.py:307-317) and detokenisation (misc/utils.py:117-137), from the reference itself."""
@@ -234,6 +292,10 @@ def main():
         if only and case[0] not in only:
             continue
         run_case(get_framework, get_translator, *case)
+    for case in ENSEMBLE_CASES:
+        if only and case[0] not in only:
+            continue
+        run_ensemble_case(get_framework, get_translator, *case)
 
 
 if __name__ == "__main__":

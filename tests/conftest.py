@@ -71,6 +71,42 @@ class GoldenCase:
         return hyps, scores
 
 
+ENSEMBLE_DIR = os.path.join(GOLDEN_DIR, "ensemble")
+
+
+def ensemble_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(ENSEMBLE_DIR, "*.npz")))
+
+
+class EnsembleCase(GoldenCase):
+    """One model-ensembling fixture (oracle/gen_golden.py ENSEMBLE_CASES): the reference Translator's hypotheses over a LIST of
+    reference models, and the recipe of every member."""
+
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(ENSEMBLE_DIR, name + ".npz"))
+        self.meta = json.loads(str(self.z["meta_json"]))
+
+    def build(self):
+        """(opts, state dicts, feature lists) of the members, regenerated from the seeds."""
+        from care_amd.configs import feat_shapes, make_opt
+        from care_amd.synth import synth_feats, synth_state_dict, tensor_sha256
+
+        if self.name not in GoldenCase._built:
+            opts, Ps, feats = [], [], []
+            for m in self.meta["members"]:
+                opt = make_opt(m["config"], **m["overrides"])
+                row_scale = {k: {int(r): f for r, f in v.items()} for k, v in m["row_scale"].items()}
+                P = synth_state_dict(m["seed"], [(k, tuple(sh)) for k, sh in m["state_dict"]], row_scale=row_scale)
+                f = synth_feats(m["feats_seed"], feat_shapes(opt, self.meta["batch"]))
+                assert tensor_sha256(f[0]) == m["sha256"]["feats0"]
+                assert tensor_sha256(P["cls_head.tgt_word_prj.weight"]) == m["sha256"]["cls_head.tgt_word_prj.weight"]
+                opts.append(opt); Ps.append(P); feats.append(f)
+            GoldenCase._built[self.name] = (opts, Ps, feats)
+        opts, Ps, feats = GoldenCase._built[self.name]
+        return [dict(o) for o in opts], [dict(P) for P in Ps], [list(f) for f in feats]
+
+
 @pytest.fixture(params=golden_names())
 def golden(request):
     return GoldenCase(request.param)

@@ -5,6 +5,7 @@ oracle runs the same torch CPU kernels in the same order as the reference, so in
 practice the match is exact or within one ulp.
 """
 import numpy as np
+import pytest
 import torch
 
 from oracle import care_cpu
@@ -75,6 +76,26 @@ def test_translate_batch_matches_reference(golden):
     for hs in hyps:
         for h in hs:
             assert all(isinstance(t, int) for t in h)
+
+
+@pytest.mark.parametrize("name", __import__("conftest").ensemble_names())
+def test_translate_batch_of_an_ensemble_matches_reference(name):
+    """Model ensembling (models/Translator.py:39-52,112-133): every member encodes its own feature list and decodes the shared
+    prefixes, the step's word log-probabilities are the members' log_softmax averaged - the reference Translator over two and
+    three reference models, greedy and beam 5 (oracle/gen_golden.py ENSEMBLE_CASES)."""
+    from conftest import EnsembleCase
+
+    case = EnsembleCase(name)
+    opts, Ps, feats = case.build()
+    ref_hyps, ref_scores = case.hyps()
+    hyps, scores, gaps = care_cpu.translate_batch_ensemble(Ps, opts, feats, return_gaps=True)
+    assert hyps == ref_hyps
+    for a, b in zip(scores, ref_scores):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-5)
+    np.testing.assert_allclose([g["select"] for g in gaps], case.z["gap_select"], rtol=0, atol=1e-4)
+    # an ensemble of one is the single model (the same code path, no averaging)
+    one, one_scores = care_cpu.translate_batch_ensemble(Ps[:1], opts[:1], feats[:1])
+    assert (one, one_scores) == care_cpu.translate_batch(Ps[0], opts[0], feats[0])
 
 
 def test_state_dict_inventory(golden):
