@@ -12,7 +12,7 @@ import torch
 CARE_F32, CARE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ACT_CODES = {"linear": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _ERRORS = {-1: "CARE_EINVAL (null pointer / bad size)", -2: "CARE_EALIGN (alignment)",
            -3: "CARE_ESHAPE (unsupported shape)", -4: "CARE_EDTYPE (unknown dtype/activation)"}
@@ -72,6 +72,7 @@ SIGNATURES = {
     "care_gemm_tile_beam": [_P, _L, _P, _P, _P, _P, _I, _I, _I, _P],
     "care_beam_pick_groups": [_P, _P, _P, _I, _I, _P, _L, _P, _I, _I, _P, _P, _I, _P],
     "care_beam_select": [_P, _L, _I, _I, _P, _P, _I, _I, _P],
+    "care_ensemble_select": [_P, _I, _L, _I, _I, _P, _P, _I, _P],
     "care_attention_probs": [_P, _L, _P, _I, _L, _L, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     "care_timestamp": [_P, _P],
     "care_decode_resident": [_P, _I, _P, _P, _P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P,

@@ -98,6 +98,90 @@ __global__ __launch_bounds__(256) void beam_select_kernel(const float* logits, i
   }
 }
 
+// Model ensembling (models/Translator.py:112-133): the step's word log-probabilities are the members' log_softmax rows averaged
+// equally, `torch.stack(word_probs).mean(0)`, and Beam.advance takes its top-k from that average.  One workgroup per row: every
+// member's (max, log sum exp) first, then one walk over the columns forming avg[c] = (sum_m ((x_m[c] - max_m) - logsum_m)) / n -
+// torch's log_softmax and mean, member by member in list order - into thread-local top-bm lists, then beam_select_kernel's
+// selection rounds.  The averaged [rows, V] array never exists; an average of log-probabilities is NOT renormalised (the
+// reference does not), which is why care_beam_select (it subtracts the row's own log-sum-exp) cannot be reused on it.
+constexpr int MAX_MODELS = 8;
+struct EnsArgs { const float* x[MAX_MODELS]; int n; };
+
+__global__ __launch_bounds__(256) void ensemble_select_kernel(EnsArgs a, int64_t ldl, int V, int bm, float* cand_val,
+                                                              int32_t* cand_idx, int rows) {
+  __shared__ float sval[256 * MAXBM];
+  __shared__ int sidx[256 * MAXBM];
+  __shared__ float sred[8];
+  __shared__ int sredi[8];
+  __shared__ float s_mx[MAX_MODELS], s_ls[MAX_MODELS];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int m = 0; m < a.n; ++m) {
+    const float* x = a.x[m] + (int64_t)r * ldl;
+    float mx = -INFINITY;
+    for (int c = tid; c < V; c += 256) mx = fmaxf(mx, x[c]);
+    mx = care_wave_max(mx);
+    if (lane == 0) sred[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+    __syncthreads();
+    float se = 0.f;
+    for (int c = tid; c < V; c += 256) se += expf(x[c] - mx);
+    se = care_wave_sum(se);
+    if (lane == 0) sred[wave] = se;
+    __syncthreads();
+    if (tid == 0) { s_mx[m] = mx; s_ls[m] = logf((sred[0] + sred[1]) + (sred[2] + sred[3])); }
+    __syncthreads();
+  }
+  float tv[MAXBM];
+  int ti[MAXBM];
+#pragma unroll
+  for (int j = 0; j < MAXBM; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+  const float fn = (float)a.n;
+  for (int c = tid; c < V; c += 256) {
+    float v = 0.f;
+    for (int m = 0; m < a.n; ++m) v += (a.x[m][(int64_t)r * ldl + c] - s_mx[m]) - s_ls[m];
+    v = v / fn;   // (torch's mean: the sum divided by the count)
+    if (v > tv[bm - 1]) {  // strictly greater: equal values keep the earlier (lower) index
+      float cv = v; int ci = c;
+#pragma unroll
+      for (int j = 0; j < MAXBM; ++j) {
+        if (j < bm && (cv > tv[j])) {
+          const float ov = tv[j]; const int oi = ti[j];
+          tv[j] = cv; ti[j] = ci; cv = ov; ci = oi;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXBM; ++j) { sval[tid * MAXBM + j] = tv[j]; sidx[tid * MAXBM + j] = ti[j]; }
+  __syncthreads();
+  int head = 0;  // next unconsumed entry of this thread's sorted list
+  for (int k = 0; k < bm; ++k) {
+    float v = head < bm ? sval[tid * MAXBM + head] : -INFINITY;
+    int id = head < bm ? sidx[tid * MAXBM + head] : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(id, o, 64);
+      if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; }
+    }
+    if (lane == 0) { sred[wave] = v; sredi[wave] = id; }
+    __syncthreads();
+    if (tid == 0) {
+      float bv = sred[0]; int bi = sredi[0];
+      for (int w = 1; w < 4; ++w)
+        if (sred[w] > bv || (sred[w] == bv && sredi[w] < bi)) { bv = sred[w]; bi = sredi[w]; }
+      sredi[4] = bi;
+      cand_val[(int64_t)r * bm + k] = bv;
+      cand_idx[(int64_t)r * bm + k] = bi == 0x7fffffff ? 0 : bi;
+    }
+    __syncthreads();
+    const int win = sredi[4];
+    if (head < bm && sidx[tid * MAXBM + head] == win) ++head;  // column indices are unique
+    __syncthreads();
+  }
+}
+
 // One WAVE per row, one pass over HBM.  The row is taken in chunks of 64 logits per lane held in
 // registers (16 x 16-byte loads issued together: 16 KiB of the row in flight per wave):
 //   A. branch-free per logit: online (max, sum-exp) with a single exp, and the lane's chunk maximum;
@@ -551,6 +635,20 @@ extern "C" int care_beam_select(const float* logits, int64_t ldl, int V, int bm,
   else
     hipLaunchKernelGGL(beam_select_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, bm, cand_val,
                        cand_idx, rows);
+  return care_launch_status();
+}
+
+extern "C" int care_ensemble_select(const float* const* logits, int n_models, int64_t ldl, int V, int bm, float* cand_val,
+                                    int32_t* cand_idx, int rows, void* stream) {
+  if (!logits || !cand_val || !cand_idx || rows <= 0 || V <= 0 || n_models <= 0 || ldl < V) return CARE_EINVAL;
+  if (bm <= 0 || bm > MAXBM || bm > V || n_models > MAX_MODELS) return CARE_ESHAPE;
+  EnsArgs a{};
+  a.n = n_models;
+  for (int m = 0; m < n_models; ++m) {
+    if (!logits[m]) return CARE_EINVAL;
+    a.x[m] = logits[m];
+  }
+  hipLaunchKernelGGL(ensemble_select_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, ldl, V, bm, cand_val, cand_idx, rows);
   return care_launch_status();
 }
 

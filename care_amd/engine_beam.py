@@ -296,9 +296,37 @@ class BeamMixin:
         key = ("beam", bm, need, self.latent_ok and not self._small_pass, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
         return self._replay(key, run, use_graph)
 
+    def translate_beam_ensemble(self, others: list, feats_list: List[List[torch.Tensor]], bm: int, need: int):
+        """encode + beam search of one batch by a LIST of models (model ensembling, models/Translator.py:39-52,112-133): this
+        engine and `others` each encode their own feature list and decode the SHARED prefixes step by step; the step's word
+        log-probabilities are the members' log_softmax averaged (care_ensemble_select) and ONE beam state machine
+        (care_beam_advance, this engine's) advances on them.  Greedy decoding is bm = 1 (models/Wrapper.py:34-35).  Every member
+        runs its multi-launch step with the vocabulary logits in memory - off the hot path ("out of scope beyond
+        accepting the list"; built in round 6 so that a list of checkpoints decodes at all), eager, no resident launch.
+        Returns (enc_outputs of this engine, nfin, fscore, flen, fhyp) like translate_beam."""
+        engines = [self] + list(others)
+        B = feats_list[0][0].shape[0]
+        for e in engines:
+            if (e.T, e.V) != (self.T, self.V) or e.device != self.device:
+                raise ValueError("ensemble members must share max_len, the vocabulary and the device")
+        if len(engines) > 8:
+            raise ValueError("at most 8 ensemble members (care_ensemble_select)")
+        members, enc0 = [], None
+        for e, feats in zip(engines, feats_list):
+            feats = e._prep_feats(feats)
+            if feats[0].shape[0] != B:
+                raise ValueError("ensemble members must see the same clips")
+            e._begin_pass()
+            e._form_rows = B * bm
+            enc = e.encode(feats, False)
+            enc0 = enc if enc0 is None else enc0
+            members.append((e, enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), enc.get("semantic_embs")))
+        return (enc0,) + tuple(self.beam(members[0][1], members[0][2], bm, need, sem_embs=members[0][3], others=members[1:]))
+
     def beam(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int,
-             sem_embs: Optional[torch.Tensor] = None):
-        """Beam search of B clips x bm beams, state on the device (csrc/beam.hip)."""
+             sem_embs: Optional[torch.Tensor] = None, others=()):
+        """Beam search of B clips x bm beams, state on the device (csrc/beam.hip).  others: further ensemble members as
+        (engine, mem, sem, sem_embs) - see translate_beam_ensemble."""
         B, Lk, d = mem.shape
         T, N = self.T, mem.shape[0] * bm
         mem = mem.to(self.device, mem.dtype if mem.dtype == self.h16 else torch.float32)  # bf16: lean encode
@@ -317,6 +345,28 @@ class BeamMixin:
         cval = self.ws("b_cval", (N, bm))
         cidx = self.ws("b_cidx", (N, bm), torch.int32)
         vpad = (self.V + 63) // 64 * 64  # 16-byte aligned row stride -> the GEMM's vector store path
+        if others:
+            # model ensembling: every member steps on the shared prefixes (tok / ancestors) with state of its own, its
+            # vocabulary logits in memory; the averaged log-probabilities' top bm -> the one state machine
+            per = []
+            for e, m, s_, se in [(self, mem, sem, sem_embs)] + list(others):
+                m = m.to(e.device, m.dtype if m.dtype == e.h16 else torch.float32)
+                s_ = s_.to(e.device, torch.float32).contiguous() if s_ is not None else None
+                per.append(dict(e=e, sem=s_, ckv=e.cross_src(m, N), akv=e.attr_kv(se) if e.attr_att else None, Lk=m.shape[1],
+                                skv=[e.ws("b_skv%d" % li, (N, T, 2 * e.d), e.wt) for li in range(e.n_layers)],
+                                logits=e.ws("b_logits", (N, vpad))))
+            import ctypes
+            rows_ptr = (ctypes.c_void_p * len(per))(*[p["logits"].data_ptr() for p in per])
+            for t in range(1, T + 1):
+                a_old, a_new = anc[(t - 1) & 1], anc[t & 1]
+                for p in per:
+                    e = p["e"]
+                    x, xb = e._decode_step(t, N, bm, tok, a_old, p["sem"], p["ckv"], p["skv"], p["Lk"], "b_", akv=p["akv"])
+                    e.gemm(xb if xb is not None else x, e.w["vocab"], None, p["logits"][:, : self.V])
+                self.call("care_ensemble_select", rows_ptr, len(per), vpad, self.V, bm, ptr(cval), ptr(cidx), N)
+                self.call("care_beam_advance", ptr(cval), ptr(cidx), ptr(scores), bm, ptr(tok), ptr(a_old), ptr(a_new),
+                     ptr(done), ptr(nfin), cap, ptr(fscore), ptr(flen), ptr(fhyp), t, T, need, EOS, self.V, T + 1, B)
+            return nfin, fscore, flen, fhyp
         fused_sel = self.beam_fused_for(B * bm)
         groups_sel = self.beam_groups_for(B * bm, bm)
         if groups_sel:

@@ -96,22 +96,34 @@ class Translator_ARFormer(object):
     _ABORTED = ("the resident decode timed out at a hand-off: its workgroups never became resident together (another "
                 "long-running kernel holds CUs?); set CARE_RESIDENT_MAX_ROWS=0 / CARE_RESIDENT_BEAM_MAX_ROWS=0")
 
-    def _engine_and_feats(self, models, batch):
-        if len(models) != 1:
-            raise NotImplementedError("model ensembling (Translator.py:131) is outside the hot path")
-        model = models[0]
-        if not isinstance(model, TransformerSeq2Seq):
-            raise TypeError("translate_batch needs a care_amd framework module, got {}".format(type(model)))
+    def _engines_and_feats(self, models, batch):
+        """The engines of `models` and each one's feature list: `batch['feats']` is one list of tensors for all of them, or - from
+        Wrapper.ModelEnsemble - one such list per model (models/Translator.py:45-48)."""
+        if len(models) < 1:
+            raise ValueError("translate_batch needs at least one model")
         feats = batch["feats"]
-        if isinstance(feats[0], list):
-            feats = feats[0]
-        engine = model.engine()
-        if engine.T != self.max_len - 1:
-            raise ValueError("translator max_len {} != model max_len {}".format(self.max_len, engine.T + 1))
-        return engine, list(feats)
+        own = isinstance(feats[0], list)
+        if own and len(feats) < len(models):
+            raise ValueError("{} feature lists for {} models".format(len(feats), len(models)))
+        engines, feats_list = [], []
+        for i, model in enumerate(models):
+            if not isinstance(model, TransformerSeq2Seq):
+                raise TypeError("translate_batch needs care_amd framework modules, got {}".format(type(model)))
+            engine = model.engine()
+            if engine.T != self.max_len - 1:
+                raise ValueError("translator max_len {} != model max_len {}".format(self.max_len, engine.T + 1))
+            engines.append(engine)
+            feats_list.append(list(feats[i] if own else feats))
+        return engines, feats_list
+
+    def _engine_and_feats(self, models, batch):
+        engines, feats_list = self._engines_and_feats(models[:1], batch)
+        return engines[0], feats_list[0]
 
     def _launch(self, models, batch, kwargs, overlap: "_Pending" = None) -> _Pending:
         with torch.no_grad():
+            if len(models) > 1:   # model ensembling (Translator.py:112-133): the members step side by side, eager
+                return self._launch_ensemble(*self._engines_and_feats(models, batch))
             engine, feats = self._engine_and_feats(models, batch)
             use_graph = kwargs.get("use_graph", True)
             hook = self._hook_for(overlap) if overlap is not None else None
@@ -124,6 +136,14 @@ class Translator_ARFormer(object):
             finally:
                 if hook is not None:
                     engine.idle_hook = None
+
+    def _launch_ensemble(self, engines, feats_list) -> _Pending:
+        """Several models: their log-probabilities averaged step by step, one beam state machine (greedy = beam_size 1, as in
+        the reference: models/Wrapper.py:34-35); the results come back in the beam search's block."""
+        need = max(self.beam_size, self.topk)
+        _, nfin, fscore, flen, fhyp = engines[0].translate_beam_ensemble(engines[1:], feats_list, self.beam_size, need)
+        event, arrays = self._fetch([nfin, fscore, flen, fhyp])
+        return _Pending("beam", event, arrays, None)
 
     def _launch_greedy(self, engine, feats, use_graph, retry=True) -> _Pending:
         _, fed, length, score = engine.translate_greedy(list(feats), use_graph=use_graph, lean=True)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CARE_ABI_VERSION 21
+#define CARE_ABI_VERSION 22
 
 enum { CARE_F32 = 0, CARE_BF16 = 1 };
 enum { CARE_ACT_NONE = 0, CARE_ACT_RELU = 1, CARE_ACT_GELU = 2 };
@@ -436,6 +436,16 @@ int care_head_reduce(const void* ct, int64_t ldc, const void* wv, const float* b
  */
 int care_beam_select(const float* logits, int64_t ldl, int V, int bm, float* cand_val,
                      int32_t* cand_idx, int rows, int waves_per_row, void* stream);
+
+/*
+ * care_ensemble_select: care_beam_select for a LIST of models (model ensembling, models/Translator.py:112-133): per row the
+ *   beam_size best columns of the members' log_softmax rows AVERAGED equally - torch.stack(word_probs).mean(0), :130-131 - as they
+ *   are (an average of log-probabilities is not renormalised; the reference's Beam.advance adds it to the beam's score as it is).
+ *   logits: HOST array of n_models (<= 8) device pointers, each fp32 [rows, ldl] with V valid columns; cand_val / cand_idx
+ *   [rows, bm] in the format care_beam_advance reads (value desc, column asc); bm <= 8.  The averaged array never exists.
+ */
+int care_ensemble_select(const float* const* logits, int n_models, int64_t ldl, int V, int bm, float* cand_val,
+                         int32_t* cand_idx, int rows, void* stream);
 
 /*
  * Fused beam selection (bf16 mode): the per-row top beam_size of log_softmax(x W^T) without the

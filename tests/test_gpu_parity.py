@@ -96,6 +96,43 @@ def test_translate_batch_fp32(golden):
     assert all(isinstance(t, int) for hs in hyps for h in hs for t in h)
 
 
+@pytest.mark.parametrize("name", __import__("conftest").ensemble_names())
+@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+def test_translate_batch_of_an_ensemble(name, mode):
+    """Model ensembling through the drop-in Translator (models/Translator.py:39-52,112-133): two and three models - CARE, Base,
+    G1L0; one feature list for all or one per model - greedy and beam 5, against the reference Translator's own output over
+    the reference models (tests/golden/ensemble).  fp32 mode: the reference's hypotheses and scores; 16-bit modes: the same
+    unless the fixture's search had a decision closer than the mode's noise (the recorded margins are 2e-4 .. 5e-4)."""
+    from conftest import EnsembleCase
+    from care_amd import get_translator
+
+    case = EnsembleCase(name)
+    opts, Ps, feats = case.build()
+    models = [_model(o, P, mode) for o, P in zip(opts, Ps)]
+    batch = {"feats": [_dev(f) for f in feats]} if case.meta["own_feats"] else {"feats": _dev(feats[0])}
+    hyps, scores = get_translator(opts[0]).translate_batch(models, batch)
+    ref_hyps, ref_scores = case.hyps()
+    assert [len(h) for h in hyps] == [len(h) for h in ref_hyps]
+    assert all(isinstance(t, int) for hs in hyps for h in hs for t in h) and all(isinstance(x, float) for sc in scores for x in sc)
+    if mode == "fp32":
+        assert hyps == ref_hyps
+        for a, b in zip(scores, ref_scores):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+        return
+    tol = 5e-2 if mode == "bf16" else 1e-2
+    z = case.z
+    for i, (hs, rs) in enumerate(zip(hyps, ref_hyps)):
+        if hs == rs:
+            np.testing.assert_allclose(scores[i], ref_scores[i], rtol=0, atol=tol)
+        else:  # a flip needs a near-tie of the reference search of that clip
+            assert min(z["gap_select"][i], z["gap_rank"][i], z["gap_best_slack"][i]) < tol, (i, hs, rs)
+            assert abs(scores[i][0] - ref_scores[i][0]) < 10 * tol
+    # one feature list per model and the same list for all are the same search when the lists are equal
+    if not case.meta["own_feats"] and mode == "fp16":
+        again, again_scores = get_translator(opts[0]).translate_batch(models, {"feats": [_dev(feats[0]) for _ in models]})
+        assert (again, again_scores) == (hyps, scores)
+
+
 @pytest.mark.parametrize("config,beam,B,mode", [("msrvtt_base_ami", 1, 96, "bf16"), ("msrvtt_care_beam5", 5, 64, "bf16"),
                                                  ("msrvtt_base_ami", 1, 3072, "fp16"), ("msrvtt_care_beam5", 5, 640, "bf16"),
                                                  ("msrvtt_care", 1, 7, "fp32")])

@@ -311,6 +311,54 @@ def test_translate_batches_is_translate_batch_one_batch_behind():
     assert WaitingEngine.pieces >= (3 + 9 + 2) // 2 and eng.idle_hook is None
 
 
+def test_translate_batch_hands_a_list_of_models_to_the_ensemble_search():
+    """Several models (models/Translator.py:39-52): the first model's engine runs the search with the others as members; each gets
+    `batch['feats'][index]` when the batch carries one feature list per model (Wrapper.ModelEnsemble), else the same list;
+    greedy is the beam search with beam_size 1; the results are the beam search's block."""
+    from care_amd.translator import Translator_ARFormer
+    from care_amd.framework import TransformerSeq2Seq
+
+    calls = []
+
+    class FakeEngine:
+        T = 29
+
+        def __init__(self, tag):
+            self.tag = tag
+
+        def translate_beam_ensemble(self, others, feats_list, bm, need):
+            calls.append((self.tag, [o.tag for o in others], [[tuple(f.shape) for f in fl] for fl in feats_list], bm, need))
+            B = feats_list[0][0].shape[0]
+            cap = need + bm
+            nfin = torch.full((B,), need, dtype=torch.int32)
+            fscore = -torch.arange(1, B * cap + 1, dtype=torch.float32).view(B, cap)
+            flen = torch.full((B, cap), 2, dtype=torch.int32)
+            fhyp = torch.arange(B * cap * 30, dtype=torch.int32).view(B, cap, 30) % 97
+            return None, nfin, fscore, flen, fhyp
+
+    class FakeModel(TransformerSeq2Seq):
+        def __init__(self, tag):
+            torch.nn.Module.__init__(self)
+            self._e = FakeEngine(tag)
+
+        def engine(self):
+            return self._e
+
+    models = [FakeModel("a"), FakeModel("b"), FakeModel("c")]
+    tr = Translator_ARFormer({"beam_size": 1, "topk": 1, "beam_alpha": 1.0, "max_len": 30})
+    hyps, scores = tr.translate_batch(models, {"feats": [torch.zeros(4, 28, 8), torch.zeros(4, 28, 16)]})
+    assert calls[-1] == ("a", ["b", "c"], [[(4, 28, 8), (4, 28, 16)]] * 3, 1, 1)
+    assert [len(h) for h in hyps] == [1] * 4 and hyps[0][0] == [0, 1] and scores[0] == [-0.5]
+    tr5 = Translator_ARFormer({"beam_size": 5, "topk": 8, "beam_alpha": 1.0, "max_len": 30})
+    own = [[torch.zeros(2, 28, 8)], [torch.zeros(2, 28, 16)], [torch.zeros(2, 28, 4)]]
+    tr5.translate_batch(models, {"feats": own})
+    assert calls[-1] == ("a", ["b", "c"], [[(2, 28, 8)], [(2, 28, 16)], [(2, 28, 4)]], 5, 8)
+    with pytest.raises(ValueError):
+        tr5.translate_batch(models, {"feats": own[:2]})
+    with pytest.raises(TypeError):
+        tr5.translate_batch([models[0], torch.nn.Linear(2, 2)], {"feats": own})
+
+
 def test_sharding_bounds_and_records():
     from care_amd.sharding import pack_records, shard_bounds, unpack_records
 
