@@ -603,6 +603,28 @@ def extra_legs(dev, main_dtype, legs):
     legs["api_beam5_B128"] = api_leg("msrvtt_care_beam5", 128, 5, 16, 32)    # translate.py's defaults (translate.py:137,144)
     legs["api_greedy_B32768"] = api_leg("msrvtt_base_ami", 32768, 1, 4, 4)
 
+    # ---- model ensembling through the same entry (models/Translator.py:39-52,112-133): two CARE models, beam 5, 128 clips - the
+    # members step side by side with their vocabulary logits in memory (eager, off the fast forms)
+    opt, eng = build("msrvtt_care_beam5", main_dtype, beam_size=5, topk=1)
+    m1 = eng_model[0]
+    m2 = get_framework(opt).eval()
+    m2.load_state_dict(synth_state_dict(1, [(k, tuple(v.shape)) for k, v in m2.state_dict().items()]), strict=True)
+    m2.set_compute_dtype(main_dtype)
+    m2.to(dev)
+    tr = get_translator(opt)
+    batch = {"feats": feats_for(opt, 128)}
+    ens = lambda: tr.translate_batch([m1, m2], batch)
+    for _ in range(2):
+        ens()
+    dt_ens = _timed(ens, 4)
+    one = lambda: tr.translate_batch([m1], batch)
+    for _ in range(2):
+        one()
+    legs["ensemble_x2_beam5_B128"] = dict(config="msrvtt_care_beam5 x 2 (seeds 0, 1)", dtype=main_dtype, clips_per_batch=128, beam_size=5,
+                                          captions_per_s=round(128 / dt_ens, 1), ms_per_call=round(dt_ens * 1e3, 3),
+                                          single_model_ms_per_call=round(_timed(one, 8) * 1e3, 3))
+    del m1, m2, tr, batch, ens, one
+
     # ---- 16-bit agreement at the size of the MSRVTT test split (2990 clips; notebooks/retrieval_robustness.ipynb:188): the
     # peaked CARE model (a softmax as peaked as a trained model's) through the Translator at translate.py's batch of 128
     # (the resident launches), greedy and beam 5: captions identical to those of the engine's fp32 mode, per 16-bit mode.

@@ -181,16 +181,93 @@ class CaptionRunner:
             yield self._records(seen.pop(0), hyps, scores, vocab)
 
 
+class EnsembleRunner(CaptionRunner):
+    """`models.Wrapper.ModelEnsemble` (Wrapper.py:617-714) around the hot path: several checkpoints decode together, their word
+    log-probabilities averaged at every step (Translator_ARFormer.translate_batch over the list).  `captioner` is the LIST of
+    frameworks; `opt` is the first checkpoint's with the members' feature paths merged and - when the members' modalities
+    differ - `modality` = the union of theirs, the loader then yields one tensor per modality of the union and
+    `preprocess_batch_before_translate_step` hands every member the tensors of its own modalities (Wrapper.py:680-693).
+    The union's order: first appearance over the members (the reference walks `list(set(...))`, an order that depends on the
+    interpreter's string hashing; any loader built from `get_opt()['modality']` sees the same order as this runner)."""
+
+    def __init__(self, opts, new_opt_used_to_override: Optional[Dict[str, Any]] = None):
+        if not opts:
+            raise ValueError("an ensemble needs at least one checkpoint")
+        opt, modalities, full = None, [], ""
+        for o in opts:
+            modalities.append(o["modality"])
+            full += o["modality"]
+            if opt is None:
+                opt = dict(o)
+                continue
+            for ch in o["modality"]:   # Wrapper.py:653-663: the same modality must mean the same feature files
+                key = "feats_" + ch
+                if ch in opt["modality"]:
+                    if list(o.get(key, [])) != list(opt.get(key, [])):
+                        raise AssertionError("checkpoints disagree on {}: {} / {}".format(key, o.get(key), opt.get(key)))
+                elif key in o:
+                    opt[key] = o[key]
+        self.need_to_split_feats = len(set(modalities)) != 1
+        self.modality_of_all_checkpoints = modalities
+        if self.need_to_split_feats:
+            opt["modality"] = "".join(dict.fromkeys(full))
+        self.opt = opt
+        self.new_opt_used_to_override = dict(new_opt_used_to_override or {})
+        # (the members are built from their own stored options, Wrapper.py:641; the overrides reach the translator only, :676)
+        self.captioner = [get_framework(dict(o)) for o in opts]
+        self.translator = get_translator(self.get_opt())
+
+    def get_keys_to_device(self, *args, **kwargs):
+        return self.captioner[0].get_keys_to_device(*args, **kwargs)
+
+    def eval(self):
+        for m in self.captioner:
+            m.eval()
+        return self
+
+    def to(self, device):
+        for m in self.captioner:
+            m.to(device)
+        return self
+
+    def preprocess_batch_before_translate_step(self, batch):
+        """Wrapper.py:680-693: `batch['feats']` (one tensor per modality of the union) -> one feature list per member."""
+        if self.need_to_split_feats:
+            union = self.get_opt()["modality"]
+            batch = dict(batch)
+            batch["feats"] = [[batch["feats"][union.index(ch)] for ch in modality] for modality in self.modality_of_all_checkpoints]
+        return batch
+
+    def translate_step(self, batch: Dict[str, Any], vocab: Optional[Dict[int, str]] = None):
+        batch = self.preprocess_batch_before_translate_step(batch)
+        hyps, scores = self.translator.translate_batch(models=self.captioner, batch=batch, vocab=vocab)
+        return self._records(batch, hyps, scores, vocab)
+
+    def translate_steps(self, batches, vocab: Optional[Dict[int, str]] = None):
+        for batch in batches:   # (the ensemble search is eager: nothing to pipeline behind it)
+            yield self.translate_step(batch, vocab)
+
+
 def load_model(checkpoint_path: str, new_opt_used_to_override: Optional[Dict[str, Any]] = None, device="cuda:0",
                strict: bool = True, replace_paths: bool = True, base_data_path: Optional[str] = None,
                compute_dtype: Optional[str] = None) -> CaptionRunner:
-    """`models.load_model` (models/__init__.py:93-152) for a single checkpoint.
+    """`models.load_model` (models/__init__.py:93-152): one checkpoint -> CaptionRunner, a list of them -> EnsembleRunner.
 
     Like the reference (`new_opt_used_to_override={}` by default, handed to `load_from_checkpoint`,
     where it REPLACES the saved hyper-parameter), the overrides stored in the checkpoint are dropped
     unless the caller passes them again; `read_checkpoint(path)["new_opt"]` returns the stored ones."""
-    if isinstance(checkpoint_path, (list, tuple)):
-        raise NotImplementedError("ModelEnsemble (several checkpoints) is outside the hot path")
+    if isinstance(checkpoint_path, (list, tuple)):   # models/__init__.py:104-113 -> ModelEnsemble
+        cks = [read_checkpoint(p) for p in checkpoint_path]
+        opts = [replace_data_paths(ck["opt"], base_data_path) if replace_paths else ck["opt"] for ck in cks]
+        runner = EnsembleRunner(opts, dict(new_opt_used_to_override or {}))
+        for model, ck in zip(runner.captioner, cks):
+            missing, unexpected = model.load_state_dict(ck["state_dict"], strict=strict)
+            if strict and (missing or unexpected):
+                raise RuntimeError("checkpoint / model key mismatch: missing {} unexpected {}".format(missing, unexpected))
+            if compute_dtype is not None:
+                model.set_compute_dtype(compute_dtype)
+        runner.eval()
+        return runner.to(device) if device is not None else runner
     ck = read_checkpoint(checkpoint_path)
     override = dict(new_opt_used_to_override or {})
     opt = replace_data_paths(ck["opt"], base_data_path) if replace_paths else ck["opt"]

@@ -420,6 +420,39 @@ def test_checkpoint_ingestion_and_prefetcher_gpu(tmp_path):
     assert out[0]["image_id"] == "video0" and isinstance(out[0]["caption"], str) and isinstance(out[0]["score"], float)
 
 
+def test_checkpoint_list_decodes_as_an_ensemble_gpu(tmp_path):
+    """models.load_model over a list of checkpoints (-> Wrapper.ModelEnsemble) -> EnsembleRunner -> the reference Translator's
+    hypotheses over the same two models (tests/golden/ensemble), fp32 mode; and through translate_step with the union of the
+    members' modalities split per member (Wrapper.py:680-693)."""
+    from care_amd.checkpoint import load_model
+    from conftest import EnsembleCase
+    from test_next_rows_cpu import _fake_lightning_checkpoint
+
+    case = EnsembleCase("ens_care_base_greedy_b3")
+    opts, Ps, feats = case.build()
+    paths = []
+    for i, (o, P) in enumerate(zip(opts, Ps)):
+        paths.append(str(tmp_path / ("m%d.ckpt" % i)))
+        _fake_lightning_checkpoint(paths[-1], o, P, {})
+    runner = load_model(paths, device="cuda:0", replace_paths=False, compute_dtype="fp32")
+    hyps, scores = runner.translator.translate_batch(runner.captioner, {"feats": [_dev(f) for f in feats]})
+    ref_hyps, ref_scores = case.hyps()
+    assert hyps == ref_hyps
+    for a, b in zip(scores, ref_scores):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+    # translate_step: one tensor per modality of the union, every member picks its own
+    union = runner.get_opt()["modality"]
+    by_mod = {}
+    for o, fl in zip(opts, feats):
+        for ch, t in zip(o["modality"], fl):
+            by_mod.setdefault(ch, t)
+    split = runner.preprocess_batch_before_translate_step({"feats": [by_mod[ch].to("cuda:0") for ch in union]})
+    if runner.need_to_split_feats:
+        assert [len(fl) for fl in split["feats"]] == [len(o["modality"]) for o in opts]
+    got = runner.translate_step({"feats": [by_mod[ch].to("cuda:0") for ch in union]})
+    assert len(got[0]) == case.meta["batch"]
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_metrics_step_gpu(golden, dtype):
     """Fused teacher-forced scoring (no logits in HBM in bf16 mode) -> word accuracy / perplexity;

@@ -196,3 +196,39 @@ def test_metric_formulas_match_reference_criteria(golden):
         c = concept_metrics(out["preds_attr"], torch.from_numpy(z["labels_attr"]))
         got = [c["F1-%02d" % k] for k in (5, 10, 20, 30, 40, 50)] + [c["mAP"]]
         np.testing.assert_allclose(got, z["metrics_attr"], rtol=1e-5, atol=1e-7)
+
+
+def test_a_list_of_checkpoints_loads_as_an_ensemble(tmp_path):
+    """models.load_model over a list (models/__init__.py:104-113 -> Wrapper.ModelEnsemble, Wrapper.py:617-693): the members keep
+    their own options and weights, the translator takes the first checkpoint's options + the overrides, differing modalities
+    are merged and every member is handed the tensors of its own modalities."""
+    from care_amd.checkpoint import EnsembleRunner, load_model
+    from care_amd.configs import make_opt
+    from care_amd.framework import get_framework
+    from care_amd.synth import synth_state_dict
+
+    paths, sds = [], []
+    for i, (cfg, extra) in enumerate([("msrvtt_base_ami", {"feats_a": ["/d/a.hdf5"], "feats_m": ["/d/m.hdf5"], "feats_i": ["/d/i.hdf5"]}),
+                                      ("msvd_base_i", {"feats_i": ["/d/i.hdf5"]})]):
+        opt = make_opt(cfg, beam_size=5, **extra)
+        sd = synth_state_dict(9 + i, [(k, tuple(v.shape)) for k, v in get_framework(opt).state_dict().items()])
+        path = str(tmp_path / ("m%d.ckpt" % i))
+        _fake_lightning_checkpoint(path, opt, sd, {})
+        paths.append(path); sds.append(sd)
+    runner = load_model(paths, new_opt_used_to_override={"beam_size": 1, "topk": 1}, device=None, replace_paths=False)
+    assert isinstance(runner, EnsembleRunner) and len(runner.captioner) == 2 and runner.translator.beam_size == 1
+    assert runner.need_to_split_feats and runner.get_opt()["modality"] == "ami"
+    for model, sd in zip(runner.captioner, sds):
+        got = model.state_dict()
+        assert all(torch.equal(got[k], sd[k]) for k in sd) and not model.training
+    a, m, i = torch.zeros(2, 28, 128), torch.zeros(2, 28, 2048), torch.zeros(2, 28, 512)
+    batch = runner.preprocess_batch_before_translate_step({"feats": [a, m, i]})
+    assert [[t.shape[-1] for t in fl] for fl in batch["feats"]] == [[128, 2048, 512], [512]]
+    # the same modality must mean the same feature files (Wrapper.py:653-661)
+    opt = make_opt("msvd_base_i", feats_i=["/other/i.hdf5"])
+    _fake_lightning_checkpoint(paths[1], opt, sds[1], {})
+    with pytest.raises(AssertionError):
+        load_model(paths, device=None, replace_paths=False)
+    # one modality set for all: the batch is passed on as it is
+    same = load_model([paths[0], paths[0]], device=None, replace_paths=False)
+    assert not same.need_to_split_feats and same.preprocess_batch_before_translate_step({"feats": [a, m, i]})["feats"][0] is a
