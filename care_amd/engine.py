@@ -261,6 +261,7 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
                     self._w3[W.data_ptr()] = W3
         self.w = w
         self._graphs.clear()
+        self._epoch = getattr(self, "_epoch", 0) + 1   # (graphs of OTHER engines that stepped this one as an ensemble member: their keys carry it)
 
     def _pack_attn(self, w, sd, p, name, self_attn, wt, f32):
         wq, wk, wv = (sd[p + ".SDPA.{}.weight".format(n)] for n in ("query", "key", "value"))
@@ -401,6 +402,7 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
             self._ws_used.pop(key, None)
             self._ws_bytes -= t.numel() * t.element_size()
         self._graphs.clear()
+        self._epoch = getattr(self, "_epoch", 0) + 1   # (graphs of OTHER engines that stepped this one as an ensemble member: their keys carry it)
 
     @property
     def bf(self) -> bool:

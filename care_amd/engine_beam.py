@@ -296,13 +296,13 @@ class BeamMixin:
         key = ("beam", bm, need, self.latent_ok and not self._small_pass, bool(lean), tuple(f.data_ptr() for f in feats), tuple(tuple(f.shape) for f in feats))
         return self._replay(key, run, use_graph)
 
-    def translate_beam_ensemble(self, others: list, feats_list: List[List[torch.Tensor]], bm: int, need: int):
+    def translate_beam_ensemble(self, others: list, feats_list: List[List[torch.Tensor]], bm: int, need: int, use_graph: bool = True):
         """encode + beam search of one batch by a LIST of models (model ensembling, models/Translator.py:39-52,112-133): this
         engine and `others` each encode their own feature list and decode the SHARED prefixes step by step; the step's word
         log-probabilities are the members' log_softmax averaged (care_ensemble_select) and ONE beam state machine
         (care_beam_advance, this engine's) advances on them.  Greedy decoding is bm = 1 (models/Wrapper.py:34-35).  Every member
         runs its multi-launch step with the vocabulary logits in memory - off the hot path ("out of scope beyond
-        accepting the list"; built in round 6 so that a list of checkpoints decodes at all), eager, no resident launch.
+        accepting the list"; built in round 6 so that a list of checkpoints decodes at all): no resident launch, no fused selection.
         Returns (enc_outputs of this engine, nfin, fscore, flen, fhyp) like translate_beam."""
         engines = [self] + list(others)
         B = feats_list[0][0].shape[0]
@@ -311,17 +311,29 @@ class BeamMixin:
                 raise ValueError("ensemble members must share max_len, the vocabulary and the device")
         if len(engines) > 8:
             raise ValueError("at most 8 ensemble members (care_ensemble_select)")
-        members, enc0 = [], None
+        prepped = []
         for e, feats in zip(engines, feats_list):
             feats = e._prep_feats(feats)
             if feats[0].shape[0] != B:
                 raise ValueError("ensemble members must see the same clips")
             e._begin_pass()
-            e._form_rows = B * bm
-            enc = e.encode(feats, False)
-            enc0 = enc if enc0 is None else enc0
-            members.append((e, enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), enc.get("semantic_embs")))
-        return (enc0,) + tuple(self.beam(members[0][1], members[0][2], bm, need, sem_embs=members[0][3], others=members[1:]))
+            prepped.append(feats)
+
+        def run():
+            members, enc0 = [], None
+            for e, feats in zip(engines, prepped):
+                e._form_rows = B * bm
+                enc = e.encode(feats, False)
+                enc0 = enc if enc0 is None else enc0
+                members.append((e, enc["encoder_hidden_states"], enc.get("semantic_hidden_states"), enc.get("semantic_embs")))
+            # (the engines ride along in the result: a captured graph keeps its members alive, so their ids in the key stay theirs)
+            return (enc0,) + tuple(self.beam(members[0][1], members[0][2], bm, need, sem_embs=members[0][3], others=members[1:])) + (tuple(engines),)
+
+        # replayed from a hipGraph like the single-model passes; the key carries every member's identity, feature buffers and
+        # epoch (an engine that dropped workspaces or re-packed weights since the capture: engine._epoch)
+        key = ("ens", bm, need, tuple((id(e), getattr(e, "_epoch", 0)) for e in engines),
+               tuple(tuple((f.data_ptr(), tuple(f.shape)) for f in feats) for feats in prepped))
+        return self._replay(key, run, use_graph)[:-1]
 
     def beam(self, mem: torch.Tensor, sem: Optional[torch.Tensor], bm: int, need: int,
              sem_embs: Optional[torch.Tensor] = None, others=()):

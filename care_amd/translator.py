@@ -122,8 +122,8 @@ class Translator_ARFormer(object):
 
     def _launch(self, models, batch, kwargs, overlap: "_Pending" = None) -> _Pending:
         with torch.no_grad():
-            if len(models) > 1:   # model ensembling (Translator.py:112-133): the members step side by side, eager
-                return self._launch_ensemble(*self._engines_and_feats(models, batch))
+            if len(models) > 1:   # model ensembling (Translator.py:112-133): the members step side by side
+                return self._launch_ensemble(*self._engines_and_feats(models, batch), use_graph=kwargs.get("use_graph", True))
             engine, feats = self._engine_and_feats(models, batch)
             use_graph = kwargs.get("use_graph", True)
             hook = self._hook_for(overlap) if overlap is not None else None
@@ -137,11 +137,11 @@ class Translator_ARFormer(object):
                 if hook is not None:
                     engine.idle_hook = None
 
-    def _launch_ensemble(self, engines, feats_list) -> _Pending:
+    def _launch_ensemble(self, engines, feats_list, use_graph=True) -> _Pending:
         """Several models: their log-probabilities averaged step by step, one beam state machine (greedy = beam_size 1, as in
         the reference: models/Wrapper.py:34-35); the results come back in the beam search's block."""
         need = max(self.beam_size, self.topk)
-        _, nfin, fscore, flen, fhyp = engines[0].translate_beam_ensemble(engines[1:], feats_list, self.beam_size, need)
+        _, nfin, fscore, flen, fhyp = engines[0].translate_beam_ensemble(engines[1:], feats_list, self.beam_size, need, use_graph=use_graph)
         event, arrays = self._fetch([nfin, fscore, flen, fhyp])
         return _Pending("beam", event, arrays, None)
 

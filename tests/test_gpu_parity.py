@@ -110,7 +110,11 @@ def test_translate_batch_of_an_ensemble(name, mode):
     opts, Ps, feats = case.build()
     models = [_model(o, P, mode) for o, P in zip(opts, Ps)]
     batch = {"feats": [_dev(f) for f in feats]} if case.meta["own_feats"] else {"feats": _dev(feats[0])}
-    hyps, scores = get_translator(opts[0]).translate_batch(models, batch)
+    tr = get_translator(opts[0])
+    eager = tr.translate_batch(models, batch, use_graph=False)
+    hyps, scores = tr.translate_batch(models, batch)
+    for _ in range(3):   # the first pass of a key runs eagerly, the second is captured into a hipGraph, later ones replay it
+        assert tr.translate_batch(models, batch) == (hyps, scores) == eager
     ref_hyps, ref_scores = case.hyps()
     assert [len(h) for h in hyps] == [len(h) for h in ref_hyps]
     assert all(isinstance(t, int) for hs in hyps for h in hs for t in h) and all(isinstance(x, float) for sc in scores for x in sc)

@@ -326,7 +326,7 @@ def test_translate_batch_hands_a_list_of_models_to_the_ensemble_search():
         def __init__(self, tag):
             self.tag = tag
 
-        def translate_beam_ensemble(self, others, feats_list, bm, need):
+        def translate_beam_ensemble(self, others, feats_list, bm, need, use_graph=True):
             calls.append((self.tag, [o.tag for o in others], [[tuple(f.shape) for f in fl] for fl in feats_list], bm, need))
             B = feats_list[0][0].shape[0]
             cap = need + bm
