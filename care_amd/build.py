@@ -28,7 +28,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, ".obj")
 SOURCES = ("gemm.hip", "gemm_as.hip", "gemm_vocab.hip", "gemm_store32.hip", "gemm_tile.hip", "gemm_ln.hip", "rowops.hip",
            "attention.hip", "attention_seq.hip", "attention_latent.hip", "heads.hip", "beam.hip", "beam_sparse.hip", "beam_pick.hip",
-           "compact.hip", "backward.hip", "decode_resident.hip", "decode_resident_beam.hip", "decode_chain.hip")
+           "compact.hip", "backward.hip", "decode_resident.hip", "decode_resident_beam.hip", "decode_resident_beam_wide.hip", "decode_chain.hip")
 VERSION_SRC = "version.hip"  # compiled on every link with the hash / flags of the build
 ARCH = "gfx950"
 BASE_FLAGS = ("--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc")

@@ -446,7 +446,12 @@ __device__ __forceinline__ void advance_state4(const RArgs& p, int rb, int t, in
 
 enum { A_EMBED = 0, A_LN = 1, A_BF16 = 2, A_EMBEDB = 3 };  // A_EMBEDB: beam search - the token is in the table already
 enum { E_QKV = 0, E_Q = 1, E_RES = 2, E_ACT = 3, E_VOCAB = 4, E_VOCABK = 5 };  // E_VOCABK: beam search - best groups per row
-constexpr int RES_BMK = 5;  // beam search: groups kept per (row, vocabulary part) = the largest beam size of the resident form
+// beam search: groups kept per (row, vocabulary part) = the largest beam size of the resident form.  5 everywhere (the reference's
+// default beam) except in decode_resident_beam_wide.hip, which compiles decode_resident_beam.hip once more with 8 for beam sizes 6 .. 8
+#ifndef CARE_RES_BMK
+#define CARE_RES_BMK 5
+#endif
+constexpr int RES_BMK = CARE_RES_BMK;
 
 // Beam search, step 1: the state of rows rb .. rb + 3 as the host-side initialisation of engine.beam leaves it - token
 // table [BOS, EOS ...], both ancestor tables = the row itself, scores 0 - and, by the first row of a clip, the clip's

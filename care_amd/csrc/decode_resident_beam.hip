@@ -160,8 +160,25 @@ inline int beam_parts(int grid, int RG, int CIV) {
 
 extern "C" {
 
+#if CARE_RES_BMK == 5
+// beam sizes 6 .. 8: this file compiled once more with 8 groups per (row, vocabulary part) - decode_resident_beam_wide.hip
+int64_t care_decode_resident_beam8_scratch(int clips, int beam, int d, int ff, int V);
+int care_decode_resident_beam8(const care_resident_layer* layers, int n_layers, const float* word, const float* pos,
+                               const float* sem, const float* emb_g, const float* emb_b, float eps, const void* vocab_w,
+                               int V, int d, int heads, int ff, int act, int clips, int beam, int need, int T, int steps,
+                               int bos, int eos, int pad, int32_t* tok, int stride, int32_t* anc0, int32_t* anc1,
+                               float* scores, int32_t* done, int32_t* nfin, float* fscore, int32_t* flen, int32_t* fhyp,
+                               int fin_cap, void* scratch, int64_t scratch_bytes, int early_exit, int blocks, void* stream);
+#else
+#define care_decode_resident_beam_scratch care_decode_resident_beam8_scratch
+#define care_decode_resident_beam care_decode_resident_beam8
+#endif
+
 int64_t care_decode_resident_beam_scratch(int clips, int beam, int d, int ff, int V) {
   if (clips < 1 || beam < 1 || d < 1 || ff < 1 || V < 1) return CARE_EINVAL;
+#if CARE_RES_BMK == 5
+  if (beam > RES_BMK) return care_decode_resident_beam8_scratch(clips, beam, d, ff, V);
+#endif
   const int64_t rows = (int64_t)clips * beam, R16 = (rows + 15) / 16 * 16;
   int64_t parts = d == 512 ? (V + 63) / 64 : (V + 15) / 16;  // column items of the vocabulary phase (16 columns each when d_model > 512)
   if (parts > 64 * RES_NP) parts = 64 * RES_NP;
@@ -182,6 +199,12 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   if (n_layers < 1 || n_layers > RES_MAX_LAYERS || clips < 1 || beam < 1 || need < 1 || fin_cap < 1 || T < 1 || steps < 1 ||
       steps > T || V < 1 || stride < T + 1)
     return CARE_EINVAL;
+#if CARE_RES_BMK == 5
+  if (beam > RES_BMK && beam <= 8)
+    return care_decode_resident_beam8(layers, n_layers, word, pos, sem, emb_g, emb_b, eps, vocab_w, V, d, heads, ff, act, clips, beam,
+                                      need, T, steps, bos, eos, pad, tok, stride, anc0, anc1, scores, done, nfin, fscore, flen, fhyp,
+                                      fin_cap, scratch, scratch_bytes, early_exit, blocks, stream);
+#endif
   // the advance phase keeps a hypothesis' positions one per lane (T + 1 <= 64), a clip's candidates one per lane
   // (beam^2 <= 64) and RES_BMK groups per row
   const bool wide = d != 512;  // d_model 768 / 1024 with ff = 4 d_model, up to 128 rows (the kernel's D)
@@ -254,7 +277,8 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
   // first vcap workgroups only - 6 per (row group, XCD) where the grid allows: 48 partial lists per row (*measured* 1 clip
   // x beam 5: 165 lists per row made the advance phase 25 us)
   // ... a single row group (<= 16 rows at one tile per workgroup) takes every workgroup and the two-step fetch instead
-  int vcap = RG == 1 ? grid : (48 * RG < grid ? 48 * RG : grid);
+  constexpr int LISTS = 64 * RES_MAXE / RES_BMK >= 48 ? 48 : 64 * RES_MAXE / RES_BMK / 8 * 8;   // (48 at 5 groups per list, 32 at 8)
+  int vcap = RG == 1 ? grid : (LISTS * RG < grid ? LISTS * RG : grid);
   while (vcap > 8 && beam_parts(vcap, RG, CIV) > maxparts) vcap -= 8;
   p.vcap = vcap;
   p.parts = beam_parts(vcap, RG, CIV);

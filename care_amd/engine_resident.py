@@ -62,7 +62,7 @@ class ResidentMixin:
             return ((rows + 15) // 16 + per_tile - 1) // per_tile <= self._cus // 8 * 8
         return True
 
-    RESIDENT_BEAM_MAX = 5  # csrc/decode_resident.h RES_BMK
+    RESIDENT_BEAM_MAX = 8  # csrc/decode_resident.h RES_BMK: 5 in the launch's first instance, 8 in its second (decode_resident_beam_wide.hip)
     # beam search of the d_model 768 / 1024 models as one resident launch up to this many rows (160 at d_model 1024).  *Measured*
     # (round 5, tools/beam_sweep.py, us per step of the whole pass, resident / multi-launch): d_model 1024 - 5 rows 103 / 207, 40
     # rows 131 / 214, 125 rows 171 / 225, 160 rows 196 / 225, 200 rows 232 / 228; d_model 768 - 5 rows 88 / 186, 160 rows 152 / 202,
@@ -71,7 +71,7 @@ class ResidentMixin:
 
     def resident_beam_ok(self, clips: int, bm: int, need: int) -> bool:
         """Beam search over `clips` clips as one resident launch (csrc/decode_resident_beam.hip)?  The limits of
-        care_decode_resident_beam: the greedy launch's, beam_size <= 5, a hypothesis' positions one per lane (T <= 63)."""
+        care_decode_resident_beam: the greedy launch's, beam_size <= 8, a hypothesis' positions one per lane (T <= 63)."""
         rows = clips * bm
         if not (0 < rows <= self.resident_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and
                 self._resident_model_ok(beam=True) and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX):
@@ -90,7 +90,7 @@ class ResidentMixin:
         limits of the resident beam launch (its phases are the chain's kernels); no residency condition, so the row
         count is bounded only by where the large-batch forms take over (`chain_beam_max_rows`)."""
         rows = clips * bm
-        return bool(0 < rows <= self.chain_beam_max_rows and 1 < bm <= self.RESIDENT_BEAM_MAX and need >= 1 and self.d == 512 and
+        return bool(0 < rows <= self.chain_beam_max_rows and 1 < bm <= 5 and need >= 1 and self.d == 512 and   # (RES_BMK of decode_chain.hip)
                     self._resident_model_ok(beam=True) and self.T <= 63 and self.V >= 16 * self.RESIDENT_BEAM_MAX)
 
     def small_forms(self, clips: int) -> bool:

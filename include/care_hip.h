@@ -707,7 +707,8 @@ int care_resident_fenced(void);
  *   >= T + 1] (token table and the two ancestor tables), scores fp32 [clips * beam], done / nfin int32 [clips], fscore fp32 /
  *   flen int32 [clips, fin_cap], fhyp int32 [clips, fin_cap, stride]; fin_cap >= need + beam.  Steps run:
  *   ((int32_t*)scratch)[2].  Aborted launch (see care_decode_resident): EVERY nfin = -1.
- *   Requires heads == d / 64, T <= 63, beam <= 5, V <= 16384 and either d == 512 with ff in {512, 1024, 2048} or d in {768, 1024}
+ *   Requires heads == d / 64, T <= 63, beam <= 8 (beam 6 .. 8: a second instance of the launch with 8 groups kept per list), V <= 16384
+ *   and either d == 512 with ff in {512, 1024, 2048} or d in {768, 1024}
  *   with ff == 4 d and clips * beam <= 128 (config/archs.yaml:15-26: the `median` / `large` architectures - VATEX runs
  *   translate.py with its default beam 5 - in the K-split forms of every phase).
  *   scratch: care_decode_resident_beam_scratch(clips, beam, d, ff, V) bytes, 16-byte aligned.

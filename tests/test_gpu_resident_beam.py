@@ -24,11 +24,15 @@ def _best(nfin, fscore, flen, fhyp, i):
 
 
 # rows = clips x 5: one row tile (5, 15), the K-split forms (60), one row tile per workgroup (65, 255), several row
-# tiles per workgroup and weight fetch (260, 640 = translate.py's default batch)
-@pytest.mark.parametrize("config,B", [("msrvtt_care", 1), ("msrvtt_base_ami", 3), ("msrvtt_care", 12), ("msrvtt_cabase", 13),
-                                      ("msrvtt_base_ami", 51), ("msrvtt_care", 52), ("msrvtt_care", 128), ("msvd_base_i", 128),
-                                      ("vatex_care_large", 1), ("vatex_care_large", 32), ("care_median_gelu", 3), ("care_median_gelu", 40)])
-def test_resident_beam_against_multi_launch_and_oracle(config, B):
+# tiles per workgroup and weight fetch (260, 640 = translate.py's default batch); beam sizes 6 .. 8: the launch's second
+# instance (8 groups kept per list: csrc/decode_resident_beam_wide.hip) over the same forms
+@pytest.mark.parametrize("config,B,bm", [
+    ("msrvtt_care", 1, 5), ("msrvtt_base_ami", 3, 5), ("msrvtt_care", 12, 5), ("msrvtt_cabase", 13, 5), ("msrvtt_base_ami", 51, 5),
+    ("msrvtt_care", 52, 5), ("msrvtt_care", 128, 5), ("msvd_base_i", 128, 5), ("vatex_care_large", 1, 5), ("vatex_care_large", 32, 5),
+    ("care_median_gelu", 3, 5), ("care_median_gelu", 40, 5),
+    ("msrvtt_care", 1, 8), ("msrvtt_care", 12, 8), ("msrvtt_base_ami", 3, 6), ("msrvtt_care", 80, 8), ("msrvtt_care", 40, 7),
+    ("vatex_care_large", 4, 6), ("care_median_gelu", 20, 8)])
+def test_resident_beam_against_multi_launch_and_oracle(config, B, bm):
     """Peaked (trained-like) logits: the resident search and the multi-launch search (projected cross K/V: the same
     rounding points) must report the same winner wherever the oracle's search is decided by clear margins, and nearly
     always otherwise; a sample of clips is audited against the oracle (its winner, or a near-tie under exact scoring)."""
@@ -36,17 +40,17 @@ def test_resident_beam_against_multi_launch_and_oracle(config, B):
     from test_gpu_parity import BEAM_TIE_TOL, BF16_LSE_PEAKED, CLEAR_MARGIN
 
     opt, P, model, feats = _setup(config, B, "bf16", seed=189, boost=PEAKED_ROWS)
-    opt = dict(opt, beam_size=5)
+    opt = dict(opt, beam_size=bm)
     eng = model.engine()
     eng.resident_max_rows = 256  # (the small-batch forms of the encode for both searches)
     eng.resident_beam_max_rows = 0
-    ml = _beam(eng, feats, use_graph=False)
+    ml = _beam(eng, feats, bm, bm, use_graph=False)
     assert not eng.last_decode.get("resident")
     eng.resident_beam_max_rows = 640
-    assert eng.resident_beam_ok(B, 5, 5)
-    rs = _beam(eng, feats, use_graph=False)
+    assert eng.resident_beam_ok(B, bm, bm)
+    rs = _beam(eng, feats, bm, bm, use_graph=False)
     assert eng.last_decode.get("resident") and 1 <= int(eng.last_decode["steps"]) <= eng.T
-    assert int(rs[0].min()) >= 1 and int(rs[0].max()) <= 10
+    assert int(rs[0].min()) >= 1 and int(rs[0].max()) <= 2 * bm
     same = 0
     for i in range(B):
         (ha, sa), (hb, sb) = _best(*rs, i), _best(*ml, i)
@@ -113,7 +117,7 @@ def test_resident_beam_covers_topk_above_beam_size_and_small_beams():
     opt, P, model, feats = _setup("msrvtt_care", 9, "bf16", seed=189, boost=PEAKED_ROWS)
     eng = model.engine()
     eng.resident_max_rows = 256
-    for bm, need in ((5, 8), (2, 2), (3, 4), (4, 4)):
+    for bm, need in ((5, 8), (2, 2), (3, 4), (4, 4), (6, 6), (7, 10), (8, 8)):
         eng.resident_beam_max_rows = 0
         ml = _beam(eng, feats, bm, need, use_graph=False)
         eng.resident_beam_max_rows = 640
@@ -131,7 +135,8 @@ def test_resident_beam_shape_rules():
 
     e = HipEngine(make_opt("msrvtt_care"), "bf16")
     assert e.resident_beam_ok(128, 5, 5) and e.resident_beam_ok(1, 5, 8) and e.resident_beam_ok(1, 2, 2)
-    assert not e.resident_beam_ok(129, 5, 5) and not e.resident_beam_ok(8, 6, 6) and not e.resident_beam_ok(8, 1, 1)
+    assert not e.resident_beam_ok(129, 5, 5) and not e.resident_beam_ok(8, 9, 9) and not e.resident_beam_ok(8, 1, 1)
+    assert e.resident_beam_ok(8, 6, 6) and e.resident_beam_ok(80, 8, 8) and not e.resident_beam_ok(81, 8, 8)   # (640 rows)
     e.resident_beam_max_rows = 0
     assert not e.resident_beam_ok(1, 5, 5)
     assert not HipEngine(make_opt("msrvtt_care"), "fp32").resident_beam_ok(8, 5, 5)

@@ -62,5 +62,7 @@ python3 tools/greedy_sweep.py --config vatex_care_large 1 32 64 128 >> $O/greedy
 python3 tools/resident_prof.py 1 128 > $O/resident_phase_clocks.txt 2>&1
 python3 tools/resident_prof.py --beam 5 --config msrvtt_care 1 128 >> $O/resident_phase_clocks.txt 2>&1
 python3 tools/beam_sweep.py 1 4 16 32 64 128 256 512 819 > $O/beam_sweep.txt 2>&1
+python3 tools/beam_sweep.py --beam 8 1 16 80 >> $O/beam_sweep.txt 2>&1    # beam sizes 6 .. 8: the launch's second instance
+python3 tools/beam_sweep.py --beam 6 1 16 106 >> $O/beam_sweep.txt 2>&1
 tail -1 $O/trace.log | cut -c1-200
 ls -la $O
