@@ -457,7 +457,7 @@ def test_small_batch_form_rules(monkeypatch):
     # beam search: rows = clips x beam_size up to resident_beam_max_rows (640), beam_size <= 5
     assert base.resident_beam_max_rows == 640
     base.resident_max_rows = 256
-    assert base.resident_beam_ok(128, 5, 5) and not base.resident_beam_ok(129, 5, 5) and not base.resident_beam_ok(4, 6, 6)
+    assert base.resident_beam_ok(128, 5, 5) and not base.resident_beam_ok(129, 5, 5) and base.resident_beam_ok(4, 6, 6) and not base.resident_beam_ok(4, 9, 9)
     assert base.resident_beam_ok(1, 5, 8) and not base.resident_beam_ok(1, 1, 1)
     monkeypatch.setenv("CARE_RESIDENT_MAX_ROWS", "64")
     assert HipEngine(make_opt("msrvtt_care"), "bf16").resident_max_rows == 64
