@@ -116,7 +116,8 @@ class DecodeMixin:
             self._dense_ln(ctx, nm, x, x1, x1b, rows, "tf_dxd")
             nm = "d{}_ca".format(li)
             hb = w["d{}_hb".format(li)]
-            q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm")
+            # (d x d with a 16-bit output: the LDS-tiled kernel, as in the decode step - *measured* 118784 rows 94 -> 84 us)
+            q2 = self.gemm(x1b, w[nm + "_q_w"], w[nm + "_q_b"], bfw("tf_q2b", (rows, d)), tag="tf_dxd_gemm", tile=d == 512)
             kv = ckv[li]
             if getattr(self, "_tf_join", None) is not None:   # the static K / V come from a side stream (metrics_step)
                 torch.cuda.current_stream().wait_stream(self._tf_join)
@@ -182,7 +183,7 @@ class DecodeMixin:
             ckv, self._tf_join = ready
             self._tf_ckv_ready = None
         else:
-            ckv, self._tf_join = self.cross_kv(mem, tag="tf_ckv"), None
+            ckv, self._tf_join = self.cross_kv(mem, tag="tf_ckv", tile=True), None
         if self._tf_join is not None and not self.tf_fast_ok(t, want_aux):
             torch.cuda.current_stream().wait_stream(self._tf_join)
             self._tf_join = None
@@ -290,20 +291,22 @@ class DecodeMixin:
         self._begin_pass()
         feats = self._prep_feats(feats)
         if (not self.has_concepts and self.tf_fast_ok(input_ids.shape[1], False) and
-                os.environ.get("CARE_TF_OVERLAP", "0") == "1"):
+                os.environ.get("CARE_TF_OVERLAP", "1") != "0"):
             # Two independent chains meet at the cross-attention: the encoder + the static K / V projection (HBM-leaning: raw
             # fp32 features in, 16-bit K / V out), and the decoder's embedding + self-attention block (needs the tokens only;
-            # a model with a concept head needs the encoder's guidance vector there: no overlap).  CARE_TF_OVERLAP=1 runs the
-            # first on a side stream, the decoder waiting for it in front of its first cross-attention (_decode_full_fast).
-            # Same kernels, same results.  OFF by default: *measured* round 6 (4096 clips x 29, one MI355X) 4.14 ms with the two
-            # chains side by side against 4.09 ms on one stream - every kernel of either chain fills the chip by itself.
+            # a model with a concept head needs the encoder's guidance vector there: no overlap).  The first runs on a side
+            # stream, the decoder waiting for it in front of its first cross-attention (_decode_full_fast); CARE_TF_OVERLAP=0: one
+            # stream.  Same kernels, same results.  *Measured* round 6 (tools/tf_overlap_probe.py, one / two streams, ms per pass,
+            # alternating rounds on one box): 4096 clips 3.97 - 4.00 / 3.91 - 3.94, 16384 clips 15.01 - 15.09 / 14.86 - 14.91, fp16
+            # mode 4.14 - 4.16 / 4.02 - 4.06 - since the static K / V projection runs on the LDS-tiled kernel (cross_kv tile=True;
+            # with the A-stationary kernel there the two chains side by side measured 4.14 against 4.09 and the option was off).
             if getattr(self, "_tf_side", None) is None:
                 self._tf_side = torch.cuda.Stream(device=self.device)
             side, cur = self._tf_side, torch.cuda.current_stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 enc = self.encode(feats, lean=True)
-                ckv = self.cross_kv(enc["encoder_hidden_states"], tag="tf_ckv")
+                ckv = self.cross_kv(enc["encoder_hidden_states"], tag="tf_ckv", tile=True)
             self._tf_ckv_ready = (ckv, side)
             try:
                 logp, pred = self.score_teacher_forced(input_ids, labels, enc["encoder_hidden_states"], None)

@@ -185,12 +185,14 @@ class EncodeMixin:
     # it rides in (84 rows: + 2 us per pass).  -1: the A-stationary kernel instead (tuning).
     RESIDENT_CKV_TILE_ROWS = 0
 
-    def cross_kv(self, mem: torch.Tensor, tag="ckv", resident=False) -> List[torch.Tensor]:
+    def cross_kv(self, mem: torch.Tensor, tag="ckv", resident=False, tile=False) -> List[torch.Tensor]:
         """K/V of the static memory for every decoder layer: [B, Lk, 2d] in the weight dtype.
 
         The reference re-projects them at every step for every beam copy
         (Attention.py:63-67 called from Layers.py:206-213); here once per clip.
         `resident`: for the one-launch decodes of small batches (their own form of the arithmetic already, resident_ok).
+        `tile`: the LDS-tiled kernel at every row count (the teacher-forced pass: *measured* round 6, 344064 x 1024 x 512 in
+        situ 472 -> 410 us, alone 566 -> 420; the two kernels' outputs are bit-identical, tests/test_gpu_kernels.py).
         """
         B, Lk, d = mem.shape
         mem = mem.contiguous()
@@ -202,7 +204,7 @@ class EncodeMixin:
             nm = "d{}_ca".format(li)
             kv = self.ws("{}{}".format(tag, li), (B * Lk, 2 * d), self.wt)
             out.append(self.gemm(src2, self.w[nm + "_kv_w"], self.w[nm + "_kv_b"], kv, tag="cross_kv_gemm",
-                                 tile=resident and src2.dtype == self.h16 and self.RESIDENT_CKV_TILE_ROWS >= 0))
+                                 tile=src2.dtype == self.h16 and (tile or (resident and self.RESIDENT_CKV_TILE_ROWS >= 0))))
         return out
 
     LATENT_MIN_ROWS = 1
