@@ -252,7 +252,7 @@ def extra_legs(dev, main_dtype, legs):
         return leg, eng, feats, opt
 
     # BASELINE configs[2]: the concept-guided (CARE) path
-    legs["msrvtt_care_greedy"] = greedy_leg("msrvtt_care", main_dtype, 16384)[0]
+    legs["msrvtt_care_greedy"] = greedy_leg("msrvtt_care", main_dtype, 32768)[0]   # (*measured* round 6: 452 K at 16384 clips, 499 K at 32768)
     # the headline workload in the OTHER 16-bit mode: fp16 (the same kernels compiled for IEEE half, libcare_hip_f16.so) -
     # bf16's bytes and MFMA rate, 8 x smaller error (fp16_hidden_state_error below)
     if main_dtype == "bf16":
