@@ -608,7 +608,9 @@ def extra_legs(dev, main_dtype, legs):
 
     legs["api_greedy_B128"] = api_leg("msrvtt_base_ami", 128, 1, 16, 32)
     legs["api_beam5_B128"] = api_leg("msrvtt_care_beam5", 128, 5, 16, 32)    # translate.py's defaults (translate.py:137,144)
-    legs["api_greedy_B32768"] = api_leg("msrvtt_base_ami", 32768, 1, 4, 4)
+    # (8 batches per pipelined pass: the last batch's assembly - ~28 ms of list building at 32768 clips - is not hidden behind a
+    # next pass, so a stream of n batches costs about (n x pass + one assembly) / n)
+    legs["api_greedy_B32768"] = api_leg("msrvtt_base_ami", 32768, 1, 8, 8)
 
     # ---- model ensembling through the same entry (models/Translator.py:39-52,112-133): two CARE models, beam 5, 128 clips - the
     # members step side by side with their vocabulary logits in memory (eager, off the fast forms)
