@@ -179,7 +179,7 @@ int care_decode_chain_beam(const care_resident_layer* layers, int n_layers, cons
 
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  if (t0 == 1 && (e = hipMemsetAsync(p.sync, 0, 4096, st)) != hipSuccess) return (int)e;
+  if (t0 == 1 && (e = res_zero_words(p.sync, 4096, st)) != hipSuccess) return (int)e;
   int rc = 0;
 #define CH_LAUNCH(KERNEL, GRID, LDS, ...)                                                               \
   do {                                                                                                  \

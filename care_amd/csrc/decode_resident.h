@@ -1690,6 +1690,21 @@ RES_PHASE_FN unsigned attn_shared_phase(const RArgs& p, GridSync& gs, bool do_wa
 // ------------------------------------------------------------------------------------------------------------------
 // Host side, shared by care_decode_resident and care_decode_resident_beam.
 
+// The launch's sync area is zeroed by a KERNEL of our own in front of it, not by hipMemsetAsync: captured into a hipGraph, the
+// memset node of ROCm 7.2 replays - from the second replay of some graphs on (the d_model 768 / 1024 greedy passes whose input
+// tensors had been freed and allocated again between replays: *measured* round 6) - as a fill with a 16-BYTE PATTERN OF TWO
+// POINTERS (the destination's own address and another): the hand-off counters start at garbage, the count of ended rows at 29355
+// >= rows, and the launch "ends" after its first step with whatever tokens the unsynchronised phases produced.  A kernel node
+// carries its arguments by value.
+__global__ void res_zero_kernel(unsigned* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+inline hipError_t res_zero_words(unsigned* p, int bytes, hipStream_t st) {
+  hipLaunchKernelGGL(res_zero_kernel, dim3((bytes / 4 + 255) / 256), dim3(256), 0, st, p, bytes / 4);
+  return hipGetLastError();
+}
+
 // care_resident_layer[] -> RArgs::L; 0 or a CARE_E* code
 inline int res_fill_layers(RArgs& p, const care_resident_layer* layers, int n_layers) {
   for (int l = 0; l < n_layers; ++l) {

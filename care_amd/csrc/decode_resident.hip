@@ -270,7 +270,7 @@ int care_decode_resident(const care_resident_layer* layers, int n_layers, const 
       if ((rc = res_check_residency(kfn, lds, grid, cus))) return rc;                                                   \
       g_res_ok[SLOT].store(1, std::memory_order_release);                                                               \
     }                                                                                                                   \
-    if ((e = hipMemsetAsync(p.sync, 0, RES_SYNC_BYTES, st)) != hipSuccess) return (int)e;                               \
+    if ((e = res_zero_words(p.sync, RES_SYNC_BYTES, st)) != hipSuccess) return (int)e;                               \
     hipLaunchKernelGGL((decode_resident_kernel<KCF, RB, SM, HF, DM>), g, blk, lds, st, p);                              \
   } while (0)
   // QKV / FFN dense1 in 16-column K-split items up to 64 rows (*measured* us / step with / without: 1 row 43.6 / 47.1,

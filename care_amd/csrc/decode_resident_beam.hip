@@ -299,7 +299,7 @@ int care_decode_resident_beam(const care_resident_layer* layers, int n_layers, c
       if ((rc = res_check_residency(kfn, lds, grid, cus))) return rc;                                                   \
       g_resb_ok[SLOT].store(1, std::memory_order_release);                                                              \
     }                                                                                                                   \
-    if ((e = hipMemsetAsync(p.sync, 0, RES_SYNC_BYTES, st)) != hipSuccess) return (int)e;                               \
+    if ((e = res_zero_words(p.sync, RES_SYNC_BYTES, st)) != hipSuccess) return (int)e;                               \
     hipLaunchKernelGGL((decode_resident_beam_kernel<KCF, RQ, RD, RF, RV, SM, KD, DM>), g, blk, lds, st, p);                 \
   } while (0)
   if (d == 768) RESB_LAUNCH_D(6, 1, 1, 1, 1, true, true, 768, 8);

@@ -676,12 +676,14 @@ __global__ void absmax_kernel(const float* A, int64_t lda, int M, int K, unsigne
   }
 }
 
+// (a kernel, not hipMemsetAsync: a memset node of a captured graph replays wrong on ROCm 7.2 - csrc/decode_resident.h, res_zero_kernel)
+__global__ void absmax_clear_kernel(unsigned* slot) { *slot = 0u; }
+
 extern "C" int care_absmax(const float* A, int64_t lda, int M, int K, void* slot, void* stream) {
   if (!A || !slot || M <= 0 || K <= 0) return CARE_EINVAL;
   if (K % 4 != 0 || lda % 4 != 0 || !care_aligned16(A)) return CARE_EALIGN;
   hipStream_t st = (hipStream_t)stream;
-  const hipError_t e = hipMemsetAsync(slot, 0, 4, st);
-  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(absmax_clear_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned*>(slot));
   const int64_t total = (int64_t)M * (K >> 2);
   const int64_t want = (total + 2047) / 2048;  // ~8 float4 per thread, at most 2048 workgroups (8 per CU)
   const unsigned blocks = (unsigned)(want < 2048 ? (want > 0 ? want : 1) : 2048);

@@ -311,3 +311,41 @@ def test_unsupported_vocabulary_falls_back_to_the_multi_launch_decode():
     assert not eng.last_decode.get("resident") and len(hyps) == 6 and all(1 <= len(h[0]) <= eng.T for h in hyps)
     hyps5, _ = get_translator(dict(opt, beam_size=5)).translate_batch([model], {"feats": feats})
     assert not eng.last_decode.get("resident") and len(hyps5) == 6
+
+
+@pytest.mark.parametrize("config,B,bm", [("vatex_care_large", 32, 1), ("care_median_gelu", 32, 1), ("msrvtt_care", 32, 1),
+                                         ("vatex_care_large", 8, 5), ("msrvtt_care", 16, 5), ("msrvtt_care", 8, 8)])
+def test_graph_replays_over_recycled_input_buffers_equal_eager_passes(config, B, bm):
+    """A loader that frees a batch's device tensors and allocates the next batch's - at the same addresses, so the pass replays
+    its hipGraph - must get what an eager pass over the same data gives, batch after batch.  Round 6 found the d_model 768 /
+    1024 greedy passes ending after ONE step from the second replay on: the launcher cleared the launch's sync area with
+    hipMemsetAsync, and the memset node of a captured graph replayed as a fill with a 16-byte pattern of two pointers (ROCm 7.2) -
+    hand-off counters and the count of ended rows started at garbage.  The launchers zero the area with a kernel of their own
+    now (csrc/decode_resident.h, res_zero_kernel)."""
+    from care_amd.configs import feat_shapes
+    from test_gpu_properties import PEAKED_ROWS, _setup
+
+    opt, P, model, _ = _setup(config, 1, "fp16", seed=189, boost=PEAKED_ROWS)
+    eng = model.engine()
+    eng.resident_max_rows, eng.resident_beam_max_rows = 256, 640
+    gen = torch.Generator().manual_seed(5)
+    host = [torch.randn(s, generator=gen) for s in feat_shapes(opt, 8 * B)]
+    replays = 0
+    for k in range(8):
+        dev = [f[k * B: (k + 1) * B].to("cuda:0") for f in host]
+        before = len([v for v in eng._graphs.values() if v != "seen"])
+        if bm == 1:
+            got = [t.clone() for t in eng.translate_greedy(dev, use_graph=True, lean=True)[1:]]
+            steps = int(eng.last_decode["steps"])
+            want = [t.clone() for t in eng.translate_greedy(dev, use_graph=False, lean=True)[1:]]
+        else:
+            got = [t.clone() for t in eng.translate_beam(dev, bm, bm, use_graph=True, lean=True)[1:]]
+            steps = int(eng.last_decode["steps"])
+            want = [t.clone() for t in eng.translate_beam(dev, bm, bm, use_graph=False, lean=True)[1:]]
+        assert eng.last_decode.get("resident")
+        replays += int(before > 0)
+        assert steps == int(eng.last_decode["steps"]), (k, steps)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), "batch {}: the graph pass and the eager pass differ".format(k)
+        del dev
+    assert replays >= 4, "the recycled buffers did not come back at the same addresses: nothing was replayed ({})".format(replays)
