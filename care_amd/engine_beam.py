@@ -164,7 +164,7 @@ class BeamMixin:
                 a.copy_(rows.unsqueeze(1).expand(N, T + 1))
             for k in ("scores", "done", "nfin", "fscore", "flen", "fhyp"):
                 v[k].zero_()
-            v["clip"].copy_(self._arange(B))
+            torch.add(self._arange(B), 0, out=v["clip"])   # (an elementwise kernel, not a memcpy node in the captured graph: see csrc/decode_resident.h, res_zero_kernel)
             v["sem"] = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
             self._ws_cap = None
             v["ckv"] = self.cross_src(mem, N)

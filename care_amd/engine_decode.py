@@ -521,7 +521,7 @@ class DecodeMixin:
             v = state(0, B)
             v["fed"].zero_(); v["fed"][:, 0] = BOS
             v["score"].zero_(); v["length"].zero_(); v["fin"].zero_()
-            v["clip"].copy_(self._arange(B))
+            torch.add(self._arange(B), 0, out=v["clip"])   # (an elementwise kernel, not a memcpy node in the captured graph: see csrc/decode_resident.h, res_zero_kernel)
             v["sem"] = sem.to(self.device, torch.float32).contiguous() if sem is not None else None
             self._ws_cap = None  # cross_src / attr_kv work on all B clips
             v["ckv"] = self.cross_src(mem, B)
