@@ -353,3 +353,48 @@ def test_graph_replays_over_recycled_input_buffers_equal_eager_passes(config, B,
             assert torch.equal(a, b), "batch {}: the graph pass and the eager pass differ".format(k)
         del dev
     assert replays >= 4, "the recycled buffers did not come back at the same addresses: nothing was replayed ({})".format(replays)
+
+
+def test_mixed_traffic_on_one_engine_equals_eager_passes():
+    """What a service does to one model: batches of changing sizes, greedy and beam, a metrics step in between, another model's
+    passes interleaved, the compute mode switched and switched back, the workspace budget forcing evictions - every graph-path
+    result against an eager pass of the same engine over the same (recycled) tensors."""
+    from care_amd.configs import feat_shapes
+    from test_gpu_properties import PEAKED_ROWS, _setup
+
+    opt, P, model, _ = _setup("msrvtt_care", 1, "fp16", seed=189, boost=PEAKED_ROWS)
+    opt2, P2, other, _ = _setup("vatex_care_large", 1, "fp16", seed=189, boost=PEAKED_ROWS)
+    for m in (model, other):
+        m.engine().resident_max_rows, m.engine().resident_beam_max_rows = 256, 640
+    gen = torch.Generator().manual_seed(11)
+    host = {id(model): [torch.randn(s, generator=gen) for s in feat_shapes(opt, 640)],
+            id(other): [torch.randn(s, generator=gen) for s in feat_shapes(opt2, 640)]}
+    plan = [(model, 128, 1), (model, 64, 5), (other, 32, 1), (model, 128, 1), (model, 300, 1), (other, 32, 5), (model, 64, 5),
+            (model, 128, 5), (model, 128, 1), (other, 32, 1), (model, 46, 1), (model, 128, 1), (model, 300, 1), (other, 32, 1)]
+    checked = 0
+    for round_ in range(3):
+        if round_ == 1:   # the other 16-bit mode and back: engines are rebuilt, graphs and workspaces start over
+            model.set_compute_dtype("bf16")
+            model.set_compute_dtype("fp16")
+            model.engine().resident_max_rows, model.engine().resident_beam_max_rows = 256, 640
+        if round_ == 2:   # a budget that does not hold two shapes' workspaces: every other pass evicts
+            model.engine().ws_budget_bytes = 64 << 20
+        for i, (m, B, bm) in enumerate(plan):
+            eng = m.engine()
+            lo = (37 * (i + round_)) % (640 - B)
+            dev = [f[lo: lo + B].to("cuda:0") for f in host[id(m)]]
+            run = (lambda g: eng.translate_greedy(dev, use_graph=g, lean=True)[1:]) if bm == 1 else \
+                  (lambda g: eng.translate_beam(dev, bm, bm, use_graph=g, lean=True)[1:])
+            got = [t.clone() for t in run(True)]
+            want = [t.clone() for t in run(False)]
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), "round {} pass {} ({} clips, beam {}): graph path and eager pass differ".format(round_, i, B, bm)
+            checked += 1
+            if i % 5 == 4 and m is model:   # a metrics step (teacher-forced pass, its own workspaces and side stream) in between
+                ids = torch.randint(4, opt["vocab_size"], (B, eng.T), device="cuda:0")
+                ids[:, 0] = 1
+                a = eng.metrics_step(dev, ids, ids)[0].clone()
+                b = eng.metrics_step(dev, ids, ids)[0].clone()
+                assert torch.equal(a, b)
+            del dev
+    assert checked == 3 * len(plan)
