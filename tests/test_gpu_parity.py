@@ -115,6 +115,11 @@ def test_translate_batch_of_an_ensemble(name, mode):
     hyps, scores = tr.translate_batch(models, batch)
     for _ in range(3):   # the first pass of a key runs eagerly, the second is captured into a hipGraph, later ones replay it
         assert tr.translate_batch(models, batch) == (hyps, scores) == eager
+    del batch
+    for _ in range(4):   # ... and over recycled device buffers (freed, allocated again at the same addresses: replays)
+        fresh = {"feats": [_dev(f) for f in feats]} if case.meta["own_feats"] else {"feats": _dev(feats[0])}
+        assert tr.translate_batch(models, fresh) == (hyps, scores)
+        del fresh
     ref_hyps, ref_scores = case.hyps()
     assert [len(h) for h in hyps] == [len(h) for h in ref_hyps]
     assert all(isinstance(t, int) for hs in hyps for h in hs for t in h) and all(isinstance(x, float) for sc in scores for x in sc)
