@@ -224,3 +224,50 @@ def test_greedy_captions_of_the_other_models_against_the_oracle(config, LARGE_BA
     # *measured* round 6, vatex_care_large: 1003 of 1024 identical, all 21 others audited near-ties - on a model where only 365 of
     # the 1024 reference searches have every step decided by >= 0.1 (it never emits EOS: 29 decisions per clip)
     assert same >= floor * LARGE_CLIPS, "{} of {} greedy captions identical".format(same, LARGE_CLIPS)
+
+
+def test_beam5_winners_of_the_large_model():
+    """Beam 5 of the d_model 1024 model (translate.py's default decode at BASELINE configs[3]'s 32 clips per GPU: the resident beam
+    launch's K-split forms), 512 clips through the pipelined Translator over recycled device buffers: the fp16 winners against
+    the engine's fp32 mode (multi-launch, exact f32), a sample of the differing clips audited in the ORACLE's own search."""
+    from care_amd import get_framework, get_translator
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_state_dict
+    from oracle import care_cpu
+    from test_gpu_parity import CLEAR_MARGIN
+    from test_gpu_properties import PEAKED_ROWS, _audit_record
+
+    clips, batch = 512, 32
+    opt = make_opt("vatex_care_large")
+    model = get_framework(opt).eval()
+    P = synth_state_dict(LARGE_SEED, [(k, tuple(v.shape)) for k, v in model.state_dict().items()],
+                         row_scale={"cls_head.tgt_word_prj.weight": {**PEAKED_ROWS["cls_head.tgt_word_prj.weight"], 3: 30.0}})
+    model.load_state_dict(P, strict=True)
+    model.to("cuda:0")
+    gen = torch.Generator().manual_seed(LARGE_SEED)
+    feats = [torch.randn(s, generator=gen) for s in feat_shapes(opt, clips)]
+    tr = get_translator(dict(opt, beam_size=5, topk=1))
+    res = {}
+    for mode in ("fp32", "fp16"):
+        model.set_compute_dtype(mode)
+        got = []
+        batches = ({"feats": [f[lo: lo + batch].to("cuda:0") for f in feats]} for lo in range(0, clips, batch))
+        for h, _ in tr.translate_batches([model], batches):
+            got += h
+        res[mode] = got
+        if mode == "fp16":
+            assert model.engine().last_decode.get("resident")
+    differ = [i for i in range(clips) if res["fp16"][i][0] != res["fp32"][i][0]]
+    torch.set_num_threads(16)
+    for i in differ[:6]:
+        one = [f[i: i + 1] for f in feats]
+        if _concept_gap(P, opt, one) < CONCEPT_TIE:
+            continue
+        o_hyps, _, gaps = care_cpu.translate_batch(P, dict(opt, beam_size=5, topk=1), one, return_gaps=True)
+        assert o_hyps[0][0] == res["fp32"][i][0], "clip {}: the fp32-mode winner is not the oracle's".format(i)
+        g = gaps[0]
+        assert min(g["select"], g["best_slack"], g["rank"]) < CLEAR_MARGIN, (i, g)
+    same = clips - len(differ)
+    _audit_record(test="large_model_scale_beam5", mode="fp16", config="vatex_care_large", clips=clips, identical=same, differing=differ[:32],
+                  mean_length=sum(len(h[0]) for h in res["fp32"]) / clips)
+    assert same >= 0.93 * clips, "{} of {} beam winners identical".format(same, clips)
