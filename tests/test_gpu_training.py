@@ -198,3 +198,38 @@ def test_a_few_optimizer_steps_reduce_the_loss():
     model.eval()    # the engine re-packs the updated weights
     out = model.feedforward_step(batch, output_auxiliary=False)
     assert torch.isfinite(out["logits"]).all()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+def test_validation_between_training_epochs_sees_the_updated_weights(mode):
+    """train.py's loop (Lightning: training epochs with a validation epoch of translate_step in between, Wrapper.py:158-212,
+    423-435) on ONE module: captions from the graph-replayed passes, then optimiser steps, then captions again - they must be
+    the captions of a FRESH module loaded with the updated state dict (the engine re-packs its weights and drops the graphs that
+    hold the old ones), twice over."""
+    from conftest import GoldenCase
+    from care_amd import get_framework, get_translator
+
+    opt, P, feats, ids, model = _build(GoldenCase("msrvtt_care_eos_b4"), **NO_DROP)
+    model.set_compute_dtype(mode)
+    tr = get_translator(dict(opt, beam_size=5, topk=2))
+    batch = {"feats": [f.to("cuda:0") for f in feats], "input_ids": ids.to("cuda:0")}
+    labels = torch.roll(ids, -1, dims=1).to("cuda:0")
+    optim = torch.optim.SGD(model.parameters(), lr=0.05)
+    seen = []
+    for epoch in range(3):
+        model.eval()
+        for _ in range(3):   # eager, captured, replayed
+            now = tr.translate_batch([model], batch)
+        fresh = get_framework(opt).eval()
+        fresh.load_state_dict({k: v.detach().clone() for k, v in model.state_dict().items()}, strict=True)
+        fresh.set_compute_dtype(mode)
+        fresh.to("cuda:0")
+        assert now == get_translator(dict(opt, beam_size=5, topk=2)).translate_batch([fresh], batch), "epoch {}".format(epoch)
+        seen.append(now)
+        model.train()
+        for _ in range(4):
+            optim.zero_grad()
+            lg = model(batch)["logits"]
+            torch.nn.functional.cross_entropy(lg.reshape(-1, lg.shape[-1]), labels.reshape(-1)).backward()
+            optim.step()
+    assert seen[0] != seen[-1], "twelve optimiser steps at lr 0.05 did not change one caption: the test does not test"
