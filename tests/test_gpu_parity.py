@@ -587,3 +587,39 @@ def test_fp16x3_mode_matches_the_reference(golden):
     else:
         for a, b in zip(scores, ref_scores):
             np.testing.assert_allclose(a, b, rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("max_len", [12, 45, 64])
+@pytest.mark.parametrize("config,beam", [("msrvtt_care", 1), ("msrvtt_care", 5), ("msrvtt_base_ami", 5)])
+def test_other_caption_lengths_against_the_oracle(config, beam, max_len):
+    """opts.py --max_len (default 30): captions of up to 11, 44 and 63 tokens - the position table, the self-attention cache, the
+    beam tables and the resident launches' lane-per-position layouts (T <= 32 / T <= 63) all follow it.  fp32 mode: the
+    oracle's hypotheses and scores; fp16 mode (the resident launches at 6 clips): the same winners but for near-ties."""
+    from care_amd import get_framework, get_translator
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_feats, synth_state_dict
+    from oracle import care_cpu
+
+    B = 6
+    opt = make_opt(config, max_len=max_len, beam_size=beam, topk=min(beam, 2))
+    model = get_framework(opt).eval()
+    P = synth_state_dict(91 + max_len, [(k, tuple(v.shape)) for k, v in model.state_dict().items()],
+                         row_scale={"cls_head.tgt_word_prj.weight": {3: 2.5 if max_len > 30 else 4.0, 0: 3.0}})
+    model.load_state_dict(P, strict=True)
+    model.to("cuda:0")
+    feats = synth_feats(91 + max_len, feat_shapes(opt, B))
+    ref_hyps, ref_scores, gaps = care_cpu.translate_batch(P, opt, feats, return_gaps=True)
+    assert max(len(h[0]) for h in ref_hyps) > min(max_len - 1, 20) // 2   # captions that do run on
+    tr = get_translator(opt)
+    hyps, scores = tr.translate_batch([model], {"feats": _dev(feats)})
+    assert hyps == ref_hyps
+    for a, b in zip(scores, ref_scores):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+    model.set_compute_dtype("fp16")
+    for _ in range(3):
+        h16, _ = tr.translate_batch([model], {"feats": _dev(feats)})
+    assert model.engine().last_decode.get("resident") == (max_len - 1 <= 63)
+    for i in range(B):
+        if h16[i][0] != ref_hyps[i][0]:
+            g = gaps[i]
+            assert min(g["select"], g["best_slack"], g["rank"]) < 1e-2, (i, g)
