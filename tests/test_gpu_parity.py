@@ -623,3 +623,53 @@ def test_other_caption_lengths_against_the_oracle(config, beam, max_len):
         if h16[i][0] != ref_hyps[i][0]:
             g = gaps[i]
             assert min(g["select"], g["best_slack"], g["rank"]) < 1e-2, (i, g)
+
+
+@pytest.mark.parametrize("name,config,over", [
+    ("frames8", "msrvtt_care", dict(n_frames=8)),                       # opts.py --n_frames (MSVD runs use 8 ... 60 frames)
+    ("frames36", "msrvtt_base_ami", dict(n_frames=36)),                  # 108 memory rows
+    ("frames60", "msrvtt_base_ami", dict(n_frames=60)),                  # 180 memory rows: beyond every attention kernel's 128 keys - REFUSED
+    ("vocab2003", "msrvtt_care", dict(vocab_size=2003)),                # a corpus of its own: V is read from info_corpus.pkl (opts.py:349)
+    ("vocab20011", "msrvtt_base_ami", dict(vocab_size=20011)),          # ... beyond the resident launches' 16384 columns
+    ("alpha07", "msrvtt_care", dict(beam_alpha=0.7)),                   # opts.py --beam_alpha
+    ("topk30k12", "msrvtt_care", dict(use_attr_topk=12, attribute_prediction_k=300)),   # tasks.yaml:40-41 are options too
+    ("d256", "msrvtt_base_ami", dict(dim_hidden=256, num_attention_heads=4, intermediate_size=1024)),   # a width outside archs.yaml
+    ("layers2", "msrvtt_care", dict(num_hidden_layers_decoder=2)),
+])
+def test_options_outside_the_shipped_configurations_against_the_oracle(name, config, over):
+    """The shapes a user's own checkpoint may have - other frame counts, vocabularies, beam_alpha, concept counts, widths and
+    depths than config/*.yaml ships: fp32 mode must give the oracle's beam-5 hypotheses and scores, the 16-bit mode must run
+    (whatever forms the shape admits) and agree but for near-ties - or the model must refuse LOUDLY, never answer wrongly."""
+    from care_amd import get_framework, get_translator
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_feats, synth_state_dict
+    from oracle import care_cpu
+
+    B = 5
+    opt = make_opt(config, beam_size=5, topk=2, **over)
+    try:
+        model = get_framework(opt).eval()
+        P = synth_state_dict(7, [(k, tuple(v.shape)) for k, v in model.state_dict().items()],
+                             row_scale={"cls_head.tgt_word_prj.weight": {3: 4.0, 0: 3.0}})
+        model.load_state_dict(P, strict=True)
+        model.to("cuda:0")
+        feats = synth_feats(7, feat_shapes(opt, B))
+        tr = get_translator(opt)
+        hyps, scores = tr.translate_batch([model], {"feats": _dev(feats)})
+    except (NotImplementedError, ValueError) as exc:   # a loud refusal that names what is outside the path
+        assert name == "frames60" and "128 keys" in str(exc), "{}: refused with `{}`".format(name, exc)
+        return
+    assert name != "frames60"
+    ref_hyps, ref_scores, gaps = care_cpu.translate_batch(P, opt, feats, return_gaps=True)
+    assert hyps == ref_hyps
+    for a, b in zip(scores, ref_scores):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+    model.set_compute_dtype("fp16")
+    for _ in range(3):
+        h16, s16 = tr.translate_batch([model], {"feats": _dev(feats)})
+    for i in range(B):
+        if h16[i][0] != ref_hyps[i][0]:
+            g = gaps[i]
+            assert min(g["select"], g["best_slack"], g["rank"]) < 1e-2, (i, g)
+        else:
+            assert abs(s16[i][0] - ref_scores[i][0]) < 2e-2
