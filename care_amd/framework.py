@@ -252,6 +252,11 @@ def get_framework(opt: Dict[str, Any]) -> nn.Module:
             raise ValueError("We can not find the class `{}` in {}".format(opt[key], __file__))
     if opt.get("with_backbones") or opt.get("pointer") or opt.get("with_category"):
         raise ValueError("backbones / pointer / category inputs are outside the hot path")
+    if opt.get("use_attr", False) and ("pp_emb" in opt.get("use_attr_type", "") or "prefix" in opt.get("use_attr_type", "")):
+        # `use_attr_flags` Gp.. / use_attr_type 'prefix': the guidance vector / the concept rows PREPENDED to the decoder's input
+        # sequence under a mask of their own (Embeddings.py:155-157, Decoder/Transformer.py:131-160) - another decoder layout,
+        # used by no shipped script; refused rather than decoded as the additive form
+        raise ValueError("use_attr_type {!r} (prefix guidance) is outside the hot path".format(opt.get("use_attr_type")))
     keys = ["encoder_hidden_states"]
     if opt.get("use_attr", False) and ("prefix" in opt["use_attr_type"] or "att" in opt["use_attr_type"].lower()):
         keys += ["semantic_embs"]

@@ -635,6 +635,15 @@ def test_other_caption_lengths_against_the_oracle(config, beam, max_len):
     ("topk30k12", "msrvtt_care", dict(use_attr_topk=12, attribute_prediction_k=300)),   # tasks.yaml:40-41 are options too
     ("d256", "msrvtt_base_ami", dict(dim_hidden=256, num_attention_heads=4, intermediate_size=1024)),   # a width outside archs.yaml
     ("layers2", "msrvtt_care", dict(num_hidden_layers_decoder=2)),
+    # options of the classes on the path whose oracle restatement was checked against the reference itself (round 6, CPU):
+    ("sinusoid_pe", "msrvtt_care", dict(trainable_pe=False)),           # Embeddings.py:116-119: the fixed sinusoid table
+    ("no_qkv_bias", "msrvtt_base_ami", dict(mha_exclude_bias=True)),    # opts.py --mha_exclude_bias
+    ("no_hybrid_bias", "msrvtt_care", dict(add_hybrid_attention_bias=False)),
+    ("decoder_mi", "msrvtt_base_ami", dict(modality_for_decoder="mi")), # Encoder.py:125-138: the decoder sees two of three modalities
+    ("predictor_mi", "msrvtt_care", dict(modality_for_predictor="mi")),
+    ("eps1e-6", "msrvtt_base_ami", dict(layer_norm_eps=1e-6)),
+    ("modality_ai", "msrvtt_base_ami", dict(modality="ai")),
+    ("share_prj", "msrvtt_care", dict(attribute_prediction_share_prj=True)),
 ])
 def test_options_outside_the_shipped_configurations_against_the_oracle(name, config, over):
     """The shapes a user's own checkpoint may have - other frame counts, vocabularies, beam_alpha, concept counts, widths and

@@ -461,3 +461,15 @@ def test_small_batch_form_rules(monkeypatch):
     assert base.resident_beam_ok(1, 5, 8) and not base.resident_beam_ok(1, 1, 1)
     monkeypatch.setenv("CARE_RESIDENT_MAX_ROWS", "64")
     assert HipEngine(make_opt("msrvtt_care"), "bf16").resident_max_rows == 64
+
+
+def test_prefix_guidance_is_refused_not_decoded_as_the_additive_form():
+    """`use_attr_flags` Gp.. (use_attr_type 'pp_emb_...') and use_attr_type 'prefix' prepend the guidance to the decoder's input
+    sequence (Embeddings.py:155-157, Decoder/Transformer.py:131-160): a layout this path does not build - it must say so."""
+    from care_amd import get_framework
+    from care_amd.configs import make_opt
+
+    for t in ("pp_emb_concat", "prefix"):
+        with pytest.raises(ValueError, match="prefix guidance"):
+            get_framework(make_opt("msrvtt_care", use_attr_type=t))
+    get_framework(make_opt("msrvtt_care", use_attr_type="emb_concat"))
