@@ -252,6 +252,15 @@ def get_framework(opt: Dict[str, Any]) -> nn.Module:
             raise ValueError("We can not find the class `{}` in {}".format(opt[key], __file__))
     if opt.get("with_backbones") or opt.get("pointer") or opt.get("with_category"):
         raise ValueError("backbones / pointer / category inputs are outside the hot path")
+    # options that change the layout of the modules on the path (other parameters, other shapes: a checkpoint of such a model
+    # would not load) or its decoding scheme - named here rather than ignored
+    if opt.get("decoding_type", "ARFormer") != "ARFormer":
+        raise ValueError("decoding_type {!r}: only the autoregressive decoder is on the hot path".format(opt.get("decoding_type")))
+    if opt.get("fusion", "temporal_concat") != "temporal_concat":
+        raise ValueError("fusion {!r}: only temporal_concat (opts.py:36) is on the hot path".format(opt.get("fusion")))
+    for key in ("RPE", "compositional_intra", "compositional_inter", "compositional_ffn"):
+        if opt.get(key, False):
+            raise ValueError("{} is outside the hot path".format(key))
     if opt.get("use_attr", False) and ("pp_emb" in opt.get("use_attr_type", "") or "prefix" in opt.get("use_attr_type", "")):
         # `use_attr_flags` Gp.. / use_attr_type 'prefix': the guidance vector / the concept rows PREPENDED to the decoder's input
         # sequence under a mask of their own (Embeddings.py:155-157, Decoder/Transformer.py:131-160) - another decoder layout,

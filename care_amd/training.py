@@ -470,6 +470,11 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
         raise NotImplementedError("training mode covers the concept head with attribute_prediction_mean_pooling and "
                                   "attribute_prediction_channel_concat (pred_attribute.py:78-131) only")
     has_container = "SemanticContainer" in opt.get("predictors_to_be_added", [])
+    for key in ("global_semantic_guidance_not_detach", "attr_embs_no_dropout", "attribute_prediction_sparse_sampling"):
+        # (pred_attribute.py:279: gradients through the guidance vector; :251: no dropout on the concept rows; :100-119: the
+        # sparse-sampling branch of the concept head - training-only switches this backward does not implement)
+        if has_concepts and opt.get(key, False):
+            raise NotImplementedError("training mode does not cover `{}`".format(key))
     use_attr_type = opt.get("use_attr_type", "") if has_container else ""
     topk = int(opt.get("use_attr_topk", 30))
 

@@ -473,3 +473,16 @@ def test_prefix_guidance_is_refused_not_decoded_as_the_additive_form():
         with pytest.raises(ValueError, match="prefix guidance"):
             get_framework(make_opt("msrvtt_care", use_attr_type=t))
     get_framework(make_opt("msrvtt_care", use_attr_type="emb_concat"))
+
+
+def test_options_that_change_the_layout_of_the_path_are_named_not_ignored():
+    """A model configured with another decoding scheme, fusion, relative positions or compositional sub-layers is another
+    network: get_framework says so (its checkpoint would not load either)."""
+    from care_amd import get_framework
+    from care_amd.configs import make_opt
+
+    for over in (dict(decoding_type="NARFormer"), dict(fusion="channel_concat"), dict(RPE=True), dict(compositional_intra=True),
+                 dict(compositional_ffn=True), dict(with_category=True), dict(attr_layer_pos="parallel", use_attr_type="_att"),
+                 dict(attribute_prediction_flags="VA"), dict(decoder="SingleLayerRNNDecoder"), dict(encoder="TransformerEncoder")):
+        with pytest.raises(ValueError):
+            get_framework(make_opt("msrvtt_care", **over))
