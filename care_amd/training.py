@@ -81,6 +81,13 @@ def _use_x3(M: int, N: int, K: int) -> bool:
     return TRAIN_GEMM == "fp16x3" or (TRAIN_GEMM == "auto" and 2.0 * M * N * K >= X3_MIN_FLOPS)
 
 
+def _fixed_pe(P, Bf, key):
+    """The sinusoid table of a model without trainable position embeddings: a frozen nn.Parameter `pe` [1, n, d] like the
+    reference's (Embeddings.py:24) - among the module's parameters, not its buffers."""
+    t = P[key] if key in P else Bf[key]
+    return t.detach()[0]
+
+
 def set_train_gemm(mode: str) -> None:
     global TRAIN_GEMM
     if mode not in ("auto", "fp16x3", "f32"):
@@ -495,7 +502,7 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
             h = drop(_AddLN.apply(h, None, P[pre + ".1.weight"], P[pre + ".1.bias"], eps), p_enc)
         else:  # TransformerEncoderBase (Encoder.py:244-298): + position, LayerNorm, dropout, unmasked self-attention + FFN layers
             q1 = pre + ".1"
-            pos_e = P[q1 + ".position_embeddings.weight"] if opt.get("trainable_pe", False) else Bf[q1 + ".position_embeddings.pe"][0]
+            pos_e = P[q1 + ".position_embeddings.weight"] if opt.get("trainable_pe", False) else _fixed_pe(P, Bf, q1 + ".position_embeddings.pe")
             h = _AddPosSem.apply(h, pos_e[:n], None, n, n)
             h = drop(_AddLN.apply(h, None, P[q1 + ".LayerNorm.weight"], P[q1 + ".LayerNorm.bias"], eps), p_hid)
             for li in range(int(opt["num_hidden_layers_encoder"])):
@@ -556,7 +563,7 @@ def training_forward(model, batch: Dict[str, Any], **kwargs) -> Dict[str, Any]:
         raise ValueError("training mode takes one caption per clip ({} captions for {} clips)".format(N, B))
     ids32 = ids.to(torch.int32).contiguous()
     e = "decoder.embedding"
-    pos_table = P[e + ".position_embeddings.weight"] if opt.get("trainable_pe", False) else Bf[e + ".position_embeddings.pe"][0]
+    pos_table = P[e + ".position_embeddings.weight"] if opt.get("trainable_pe", False) else _fixed_pe(P, Bf, e + ".position_embeddings.pe")
     x = _Gather.apply(P[e + ".word_embeddings.weight"], ids32.view(-1), PAD)
     x = _AddPosSem.apply(x, pos_table[:t], sem_hidden, t, t)
     if pre_ln:  # Embeddings.py:130-131: no LayerNorm behind the embedding sum of a pre-LN decoder

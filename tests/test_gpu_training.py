@@ -54,6 +54,13 @@ def test_training_forward_and_gradients_match_the_oracle_autograd(name, gemm):
         # activation keeps what the case is here for - the third attention block over the concept rows - comparable.
         over["hidden_act"] = "gelu"
     opt, P, feats, ids, model = _build(GoldenCase(name), **over)
+    _compare_with_oracle_autograd(opt, P, feats, ids, model)
+    training.set_train_gemm("auto")
+
+
+def _compare_with_oracle_autograd(opt, P, feats, ids, model):
+    from oracle import care_cpu
+
     model.train()
     batch = {"feats": [f.to("cuda:0") for f in feats], "input_ids": ids.to("cuda:0")}
     out = model(batch)
@@ -73,6 +80,9 @@ def test_training_forward_and_gradients_match_the_oracle_autograd(name, gemm):
     checked = 0
     worst = ("", 0.0)
     for k, p in model.named_parameters():
+        if not p.requires_grad:   # (the frozen sinusoid table `pe`, a Parameter in the reference too: Embeddings.py:24)
+            assert p.grad is None
+            continue
         gref = Pc[k].grad
         if gref is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
@@ -94,7 +104,38 @@ def test_training_forward_and_gradients_match_the_oracle_autograd(name, gemm):
     # padding_idx: the PAD row of the word embedding gets no gradient (nn.Embedding(padding_idx=0))
     assert float(model.decoder.embedding.word_embeddings.weight.grad[0].abs().max()) == 0.0
     print("worst relative gradient error", worst)
-    training.set_train_gemm("auto")
+
+
+@pytest.mark.parametrize("name,config,over", [
+    ("sinusoid_pe", "msrvtt_care", dict(trainable_pe=False)),
+    ("no_qkv_bias", "msrvtt_base_ami", dict(mha_exclude_bias=True)),
+    ("no_hybrid_bias", "msrvtt_care", dict(add_hybrid_attention_bias=False)),
+    ("decoder_mi", "msrvtt_base_ami", dict(modality_for_decoder="mi")),
+    ("predictor_mi", "msrvtt_care", dict(modality_for_predictor="mi")),
+    ("modality_ai", "msrvtt_base_ami", dict(modality="ai")),
+    ("share_prj", "msrvtt_care", dict(attribute_prediction_share_prj=True)),
+    ("frames8", "msrvtt_care", dict(n_frames=8)),
+    ("max_len12", "msrvtt_care", dict(max_len=12)),
+    ("layers2", "msrvtt_care", dict(num_hidden_layers_decoder=2)),
+    ("topk12_k300", "msrvtt_care", dict(use_attr_topk=12, attribute_prediction_k=300)),
+])
+def test_training_of_option_variants_matches_the_oracle_autograd(name, config, over):
+    """Training mode on the options tests/test_oracle_vs_reference.py pins the oracle to the reference on: forward and every
+    parameter's gradient against the oracle's autograd, like the fixtures above (the default per-product choice of GEMM form)."""
+    from care_amd import get_framework
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_feats, synth_input_ids, synth_state_dict
+
+    # (GELU: with ReLU, random weights and 178 K FFN pre-activations per batch one |z| < 1e-6 decides a unit's gradient by
+    # the last bit of a 512-term sum - seed 7 has such a unit on three of these variants, see the cabase fixture above; the
+    # options under test do not touch the activation)
+    opt = make_opt(config, **{**NO_DROP, "hidden_act": "gelu", **over})
+    model = get_framework(opt)
+    P = synth_state_dict(7, [(k, tuple(v.shape)) for k, v in model.state_dict().items()])
+    model.load_state_dict(P, strict=True)
+    feats = synth_feats(7, feat_shapes(opt, 3))
+    ids = synth_input_ids(7, 3, opt["max_len"] - 1, opt["vocab_size"])
+    _compare_with_oracle_autograd(opt, P, feats, ids, model.to("cuda:0"))
 
 
 def test_absmax_sees_every_element():
