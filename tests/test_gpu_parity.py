@@ -673,6 +673,16 @@ def test_options_outside_the_shipped_configurations_against_the_oracle(name, con
     assert hyps == ref_hyps
     for a, b in zip(scores, ref_scores):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+    # the teacher-forced forward (Framework.py:215-237) of the same model: hidden states, logits, concept probabilities
+    from care_amd.synth import synth_input_ids
+    ids = synth_input_ids(7, B, opt["max_len"] - 1, opt["vocab_size"])
+    with torch.no_grad():
+        tf_ref = care_cpu.feedforward_step(P, opt, feats, ids)
+    tf = model.feedforward_step({"feats": _dev(feats), "input_ids": ids.to("cuda:0")})
+    assert _maxdiff(tf["hidden_states"], tf_ref["hidden_states"].numpy()) < ATOL_FP32
+    assert _maxdiff(torch.logsumexp(tf["logits"], -1), torch.logsumexp(tf_ref["logits"], -1).numpy()) < 1e-4
+    if "preds_attr" in tf_ref:
+        assert _maxdiff(tf["preds_attr"], tf_ref["preds_attr"].numpy()) < 1e-5
     model.set_compute_dtype("fp16")
     for _ in range(3):
         h16, s16 = tr.translate_batch([model], {"feats": _dev(feats)})
@@ -682,3 +692,8 @@ def test_options_outside_the_shipped_configurations_against_the_oracle(name, con
             assert min(g["select"], g["best_slack"], g["rank"]) < 1e-2, (i, g)
         else:
             assert abs(s16[i][0] - ref_scores[i][0]) < 2e-2
+    tf16 = model.feedforward_step({"feats": _dev(feats), "input_ids": ids.to("cuda:0")})
+    assert _maxdiff(tf16["hidden_states"], tf_ref["hidden_states"].numpy()) < 1e-2
+    logp, pred, _ = model.engine().metrics_step(_dev(feats), ids.to("cuda:0"), torch.roll(ids, -1, 1).to("cuda:0"))
+    want = torch.log_softmax(tf_ref["logits"], -1).gather(-1, torch.roll(ids, -1, 1).unsqueeze(-1)).squeeze(-1)
+    assert _maxdiff(logp.view(B, -1), want.numpy()) < 5e-2
