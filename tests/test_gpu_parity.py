@@ -697,3 +697,48 @@ def test_options_outside_the_shipped_configurations_against_the_oracle(name, con
     logp, pred, _ = model.engine().metrics_step(_dev(feats), ids.to("cuda:0"), torch.roll(ids, -1, 1).to("cuda:0"))
     want = torch.log_softmax(tf_ref["logits"], -1).gather(-1, torch.roll(ids, -1, 1).unsqueeze(-1)).squeeze(-1)
     assert _maxdiff(logp.view(B, -1), want.numpy()) < 5e-2
+
+
+@pytest.mark.parametrize("name", ["msrvtt_care_beam5_eos_b4", "msrvtt_base_ami_eos_b4", "msrvtt_cabase_beam5_long_b3", "msrvtt_care_g1l0_beam5_b2"])
+def test_the_reference_translator_loop_over_this_module(name):
+    """Only `get_framework` swapped: the reference's OWN Translator (models/Translator.py:35-133: encoding_phase ->
+    prepare_inputs_for_decoder -> auto_enlarge -> per step decoding_phase(last_time_step_logits=True, decoder_rnn_hidden_states=None) ->
+    log_softmax -> Beam.advance -> collect_active_part) drives this module's public API - restated here with the oracle's beam
+    (misc/Decoding/Beam.py's semantics) - and must arrive at the reference's hypotheses: every tensor the loop touches (enlarged
+    and index_selected encoder outputs, growing input_ids, [N, V] logits) goes through the module API, not the engine's passes."""
+    from conftest import GoldenCase
+    from oracle.care_cpu import HostBeam
+
+    golden = GoldenCase(name)
+    opt, P, feats, _ = golden.build()
+    model = _model(opt, P)
+    bm, n_best, max_len = int(opt.get("beam_size", 5)), int(opt.get("topk", 1)), int(opt["max_len"])
+    with torch.no_grad():
+        enc = model.encoding_phase(_dev(feats))
+        inputs = model.prepare_inputs_for_decoder(enc, {"feats": _dev(feats)})
+        inputs = {k: v.repeat_interleave(bm, dim=0) if isinstance(v, torch.Tensor) else v for k, v in inputs.items()}
+        n = inputs["encoder_hidden_states"].shape[0] // bm
+        beams = [HostBeam(bm, max_len, n_best) for _ in range(n)]
+        active = list(range(n))
+        for t in range(1, max_len):
+            ids = torch.stack([beams[i].prefixes() for i in active]).view(-1, t).to("cuda:0")
+            out = model.decoding_phase(input_ids=ids, inputs_for_decoder=inputs, decoder_rnn_hidden_states=None, last_time_step_logits=True)
+            logp = torch.log_softmax(out["logits"], dim=1).view(len(active), bm, -1).cpu()
+            still = [pos for pos, i in enumerate(active) if not beams[i].advance(logp[pos])]
+            if not still:
+                break
+            if len(still) != len(active):
+                sel = torch.tensor(still, device="cuda:0")
+                inputs = {k: v.view(len(active), -1).index_select(0, sel).view(len(still) * bm, *v.shape[1:]) if isinstance(v, torch.Tensor) else v
+                          for k, v in inputs.items()}
+                active = [active[pos] for pos in still]
+    hyps, scores = [], []
+    for b in beams:
+        ranked = b.ranked(float(opt.get("beam_alpha", 1.0)))
+        n_best = min(n_best, len(ranked))
+        hyps.append([b.hypothesis(t_, k) for _, t_, k, _ in ranked[:n_best]])
+        scores.append([s for s, _, _, _ in ranked[:n_best]])
+    ref_hyps, ref_scores = golden.hyps()
+    assert hyps == ref_hyps
+    for a, b in zip(scores, ref_scores):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
