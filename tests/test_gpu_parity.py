@@ -742,3 +742,36 @@ def test_the_reference_translator_loop_over_this_module(name):
     assert hyps == ref_hyps
     for a, b in zip(scores, ref_scores):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+def test_feature_tensors_as_a_loader_may_hand_them_over(mode):
+    """The same clips as fp32 contiguous device tensors (the fixture's form), on the CPU, as non-contiguous views, as float64,
+    with extra tensors behind the modalities' (Framework.py:151-159 takes the first len(modality)), one clip at a time - the
+    same captions; as 16-bit tensors (a loader that rounds its features): the captions of the rounded features."""
+    from conftest import GoldenCase
+    from care_amd import get_translator
+
+    golden = GoldenCase("msrvtt_care_beam5_eos_b4")
+    opt, P, feats, _ = golden.build()
+    model = _model(opt, P, mode)
+    tr = get_translator(opt)
+    base = tr.translate_batch([model], {"feats": _dev(feats)})
+    if mode == "fp32":
+        assert base[0] == golden.hyps()[0]
+    assert tr.translate_batch([model], {"feats": [f.clone() for f in feats]}) == base                       # host tensors
+    wide = [torch.cat([f, f], dim=-1).to("cuda:0") for f in feats]
+    assert tr.translate_batch([model], {"feats": [w[..., : f.shape[-1]] for w, f in zip(wide, feats)]}) == base   # strided views
+    assert tr.translate_batch([model], {"feats": [f.double().to("cuda:0") for f in feats]}) == base
+    assert tr.translate_batch([model], {"feats": _dev(feats) + [torch.zeros(4, 3, device="cuda:0")]}) == base
+    one_by_one = [tr.translate_batch([model], {"feats": [f[i: i + 1].to("cuda:0") for f in feats]}) for i in range(4)]
+    if mode == "fp32":
+        assert [h[0][0] for h, _ in one_by_one] == [h[0] for h in base[0]]   # (n_best shrinks across the clips of ONE batch: winners only)
+    for dt in (torch.bfloat16, torch.float16):
+        rounded = [f.to(dt) for f in feats]
+        as16 = tr.translate_batch([model], {"feats": [r.to("cuda:0") for r in rounded]})
+        assert as16 == tr.translate_batch([model], {"feats": [r.float().to("cuda:0") for r in rounded]})
+    with pytest.raises(ValueError):
+        tr.translate_batch([model], {"feats": _dev(feats)[:2]})                                              # a modality is missing
+    with pytest.raises((ValueError, RuntimeError)):
+        tr.translate_batch([model], {"feats": [f[:, :5].to("cuda:0") for f in feats]})                       # 5 frames instead of 28
