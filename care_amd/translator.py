@@ -114,6 +114,9 @@ class Translator_ARFormer(object):
                 raise ValueError("translator max_len {} != model max_len {}".format(self.max_len, engine.T + 1))
             engines.append(engine)
             feats_list.append(list(feats[i] if own else feats))
+            if len(feats_list[-1]) == 0 or feats_list[-1][0].shape[0] == 0:
+                # (the reference fails on such a batch too - torch.stack of no prefixes, Translator.py:106 - a few calls further in)
+                raise ValueError("translate_batch got a batch without clips")
         return engines, feats_list
 
     def _engine_and_feats(self, models, batch):

@@ -775,3 +775,5 @@ def test_feature_tensors_as_a_loader_may_hand_them_over(mode):
         tr.translate_batch([model], {"feats": _dev(feats)[:2]})                                              # a modality is missing
     with pytest.raises((ValueError, RuntimeError)):
         tr.translate_batch([model], {"feats": [f[:, :5].to("cuda:0") for f in feats]})                       # 5 frames instead of 28
+    with pytest.raises(ValueError, match="without clips"):
+        tr.translate_batch([model], {"feats": [f[:0].to("cuda:0") for f in feats]})                          # an empty batch
