@@ -309,6 +309,14 @@ class TransformerSeq2Seq(nn.Module):
                 module.bias.data.zero_()
 
     # -- engine management
+    def __getstate__(self):
+        """Pickling / copy.deepcopy of the module (torch.save(model), DDP's spawn, ModelEnsemble-style copies): the inference
+        engine - device workspaces, captured hipGraphs, the loaded library - is not part of the module's state; a copy
+        builds its own on first use."""
+        state = dict(self.__dict__)
+        state["_engine"], state["_engine_stamp"] = None, None
+        return state
+
     def set_compute_dtype(self, dtype: str) -> "TransformerSeq2Seq":
         """'fp32' (exact f32 MFMA, parity mode), 'bf16' (bf16 MFMA, fp32 accumulation: throughput mode), 'fp16' (the same
         kernels compiled for IEEE half, libcare_hip_f16.so: bf16's bytes and MFMA rate with 11 significand bits instead

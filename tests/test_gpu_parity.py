@@ -777,3 +777,35 @@ def test_feature_tensors_as_a_loader_may_hand_them_over(mode):
         tr.translate_batch([model], {"feats": [f[:, :5].to("cuda:0") for f in feats]})                       # 5 frames instead of 28
     with pytest.raises(ValueError, match="without clips"):
         tr.translate_batch([model], {"feats": [f[:0].to("cuda:0") for f in feats]})                          # an empty batch
+
+
+def test_copies_and_pickles_of_a_used_module_decode_like_the_original():
+    """copy.deepcopy(model) and torch.save(model) / torch.load of a module whose engine already ran (captured graphs, device
+    workspaces): the engine is no part of the module's state - a copy builds its own; in-place edits of the parameters are seen
+    by the next call."""
+    import copy
+    import io
+    from conftest import GoldenCase
+    from care_amd import get_translator
+
+    golden = GoldenCase("msrvtt_care_beam5_eos_b4")
+    opt, P, feats, _ = golden.build()
+    model = _model(opt, P)
+    tr = get_translator(opt)
+    dev = {"feats": _dev(feats)}
+    for _ in range(3):
+        base = tr.translate_batch([model], dev)
+    assert base[0] == golden.hyps()[0]
+    twin = copy.deepcopy(model)
+    assert twin._engine is None and model._engine is not None
+    assert tr.translate_batch([twin], dev) == base == tr.translate_batch([model], dev)
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    assert tr.translate_batch([torch.load(buf, weights_only=False)], dev) == base
+    with torch.no_grad():
+        model.cls_head.tgt_word_prj.weight[3] += 5.0     # the EOS row up: shorter captions
+    after = tr.translate_batch([model], dev)
+    assert after != base and tr.translate_batch([twin], dev) == base
+    fresh = _model(opt, {k: v.detach().cpu() for k, v in model.state_dict().items()})
+    assert after == tr.translate_batch([fresh], dev)
