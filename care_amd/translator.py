@@ -58,6 +58,10 @@ class Translator_ARFormer(object):
         self.ar_token_id = opt.get("ar_token_id", None)
         if self.ar_token_id is not None:
             raise ValueError("`ar_token_id` (NACF joint training) is outside the hot path")
+        if not 1 <= int(self.beam_size) <= 8:
+            # (care_beam_select keeps a row's beam_size best columns in registers, care_beam_advance a clip's beam_size^2
+            # candidates one per lane of a wave: csrc/beam.hip MAXBM)
+            raise ValueError("beam_size {} is outside the hot path: 1 .. 8 (translate.py's default is 5)".format(self.beam_size))
         # length ** beam_alpha (Beam.py:93) for every possible length, computed by the interpreter's own `**` so that the
         # vectorised division below yields the doubles `score / t ** alpha` yields
         tab = []

@@ -486,3 +486,12 @@ def test_options_that_change_the_layout_of_the_path_are_named_not_ignored():
                  dict(attribute_prediction_flags="VA"), dict(decoder="SingleLayerRNNDecoder"), dict(encoder="TransformerEncoder")):
         with pytest.raises(ValueError):
             get_framework(make_opt("msrvtt_care", **over))
+
+
+def test_translator_names_the_beam_sizes_it_covers():
+    from care_amd import get_translator
+
+    for bm in (0, 9, 16):
+        with pytest.raises(ValueError, match="beam_size"):
+            get_translator({"beam_size": bm})
+    assert get_translator({"beam_size": 8}).beam_size == 8
