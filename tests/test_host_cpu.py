@@ -493,5 +493,5 @@ def test_translator_names_the_beam_sizes_it_covers():
 
     for bm in (0, 9, 16):
         with pytest.raises(ValueError, match="beam_size"):
-            get_translator({"beam_size": bm})
-    assert get_translator({"beam_size": 8}).beam_size == 8
+            get_translator({"decoding_type": "ARFormer", "beam_size": bm})
+    assert get_translator({"decoding_type": "ARFormer", "beam_size": 8}).beam_size == 8
