@@ -92,6 +92,8 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         if self.pre_ln and opt["encoder"] != "Embedder":
             raise ValueError("transformer_pre_ln with a self-attention encoder is outside the hot path")
         self.rows_of = {ch: (int(opt["retrieval_topk"]) if ch == "r" else int(opt["n_frames"])) for ch in self.modality}
+        # feature widths that are no multiple of 32 are padded with zero columns to the next multiple of 128 (engine_encode._prep_one)
+        self.feat_pad = {ch: ((-int(opt["dim_" + ch])) % 128 if int(opt["dim_" + ch]) % 32 else 0) for ch in self.modality}
         self.mem_off = {}
         off = 0
         for ch in self.modality:
@@ -171,6 +173,8 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         for ch in self.modality:
             p = "encoder.Encoder_{}".format(ch.upper())
             w["enc_w_" + ch], w["enc_b_" + ch] = enc_wt(sd[p + ".0.weight"]), f32(sd[p + ".0.bias"])
+            if self.feat_pad.get(ch, 0):   # (see _prep_one: zero columns against the zero columns appended to the features)
+                w["enc_w_" + ch] = torch.nn.functional.pad(w["enc_w_" + ch], (0, self.feat_pad[ch])).contiguous()
             if opt["encoder"] == "Embedder":
                 w["enc_g_" + ch], w["enc_be_" + ch] = f32(sd[p + ".1.weight"]), f32(sd[p + ".1.bias"])
             elif opt["encoder"] == "MultiTransformerEncoder":

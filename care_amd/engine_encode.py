@@ -36,13 +36,19 @@ class EncodeMixin:
         return (self.as_ok and self.d == 512 and not self.has_concepts and self.opt["encoder"] == "Embedder" and
                 all(int(self.opt["dim_" + ch]) % 128 == 0 for ch in self.modality))
 
-    def _prep_one(self, f):
+    def _prep_one(self, f, ch=None):
         if f.dtype == self.h16 and self.feats_bf16_ok:
             return f.to(self.device).contiguous()
-        return f.to(self.device, torch.float32).contiguous()
+        f = f.to(self.device, torch.float32)
+        pad = self.feat_pad.get(ch, 0) if ch is not None else 0
+        if pad and f.shape[-1] + pad == self.w["enc_w_" + ch].shape[1]:
+            # a feature width that is no multiple of 32 (no shipped extractor; feats.yaml): zero columns up to the next multiple
+            # of 128, against zero columns of the weight (load_weights) - one more copy of the features, every kernel's K rule met
+            f = torch.nn.functional.pad(f, (0, pad))
+        return f.contiguous()
 
     def _prep_feats(self, feats):
-        return [self._prep_one(f) for f in feats[: len(self.modality)]]
+        return [self._prep_one(f, ch) for f, ch in zip(feats[: len(self.modality)], self.modality)]
 
     def encode(self, feats: List[torch.Tensor], lean: bool = False, static: bool = False, small: bool = False) -> Dict[str, torch.Tensor]:
         """`Seq2SeqBase.encoding_phase` (models/Framework.py:150-187); outputs are fresh tensors.
@@ -76,7 +82,7 @@ class EncodeMixin:
             if st is not None:
                 st.wait_stream(cur)
             with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-                x = self._prep_one(feats[mi])
+                x = self._prep_one(feats[mi], ch)
                 n = x.shape[1]
                 if n != self.rows_of[ch]:
                     raise ValueError("modality `{}`: {} rows, expected {}".format(ch, n, self.rows_of[ch]))

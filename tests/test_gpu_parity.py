@@ -644,6 +644,9 @@ def test_other_caption_lengths_against_the_oracle(config, beam, max_len):
     ("eps1e-6", "msrvtt_base_ami", dict(layer_norm_eps=1e-6)),
     ("modality_ai", "msrvtt_base_ami", dict(modality="ai")),
     ("share_prj", "msrvtt_care", dict(attribute_prediction_share_prj=True)),
+    ("retrieval10", "msrvtt_care", dict(retrieval_topk=10)),            # tasks.yaml:44: rows of the retrieval modality
+    ("dims_64_1024_768", "msrvtt_base_ami", dict(dim_a=64, dim_m=1024, dim_i=768)),   # other feature extractors (feats.yaml)
+    ("dim_i_500", "msvd_base_i", dict(dim_i=500)),                      # a width that is no multiple of 32
 ])
 def test_options_outside_the_shipped_configurations_against_the_oracle(name, config, over):
     """The shapes a user's own checkpoint may have - other frame counts, vocabularies, beam_alpha, concept counts, widths and

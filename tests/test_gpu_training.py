@@ -118,6 +118,11 @@ def _compare_with_oracle_autograd(opt, P, feats, ids, model):
     ("max_len12", "msrvtt_care", dict(max_len=12)),
     ("layers2", "msrvtt_care", dict(num_hidden_layers_decoder=2)),
     ("topk12_k300", "msrvtt_care", dict(use_attr_topk=12, attribute_prediction_k=300)),
+    ("retrieval10", "msrvtt_care", dict(retrieval_topk=10)),
+    ("dims_64_1024_768", "msrvtt_base_ami", dict(dim_a=64, dim_m=1024, dim_i=768)),
+    ("dim_i_500", "msvd_base_i", dict(dim_i=500)),
+    ("vocab2003", "msrvtt_care", dict(vocab_size=2003)),
+    ("d256", "msrvtt_base_ami", dict(dim_hidden=256, num_attention_heads=4, intermediate_size=1024)),
 ])
 def test_training_of_option_variants_matches_the_oracle_autograd(name, config, over):
     """Training mode on the options tests/test_oracle_vs_reference.py pins the oracle to the reference on: forward and every

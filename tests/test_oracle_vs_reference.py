@@ -41,6 +41,9 @@ VARIANTS = [
     ("eps1e-6", "msrvtt_base_ami", dict(layer_norm_eps=1e-6)),
     ("modality_ai", "msrvtt_base_ami", dict(modality="ai")),
     ("share_prj", "msrvtt_care", dict(attribute_prediction_share_prj=True)),
+    ("retrieval10", "msrvtt_care", dict(retrieval_topk=10)),
+    ("dims_64_1024_768", "msrvtt_base_ami", dict(dim_a=64, dim_m=1024, dim_i=768)),
+    ("dim_i_500", "msvd_base_i", dict(dim_i=500)),
 ]
 
 
