@@ -63,6 +63,8 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         if self.d != self.H * 64:
             raise ValueError("the attention kernel is specialised for head dim 64 (archs.yaml:15-26)")
         self.ff = int(opt["intermediate_size"])
+        if self.ff % 64:
+            raise ValueError("intermediate_size {} is no multiple of 64 (the K of FFN dense2 on the matrix cores)".format(self.ff))
         self.V = int(opt["vocab_size"])
         self.T = int(opt["max_len"]) - 1
         self.eps = float(opt["layer_norm_eps"])

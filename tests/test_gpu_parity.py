@@ -647,6 +647,12 @@ def test_other_caption_lengths_against_the_oracle(config, beam, max_len):
     ("retrieval10", "msrvtt_care", dict(retrieval_topk=10)),            # tasks.yaml:44: rows of the retrieval modality
     ("dims_64_1024_768", "msrvtt_base_ami", dict(dim_a=64, dim_m=1024, dim_i=768)),   # other feature extractors (feats.yaml)
     ("dim_i_500", "msvd_base_i", dict(dim_i=500)),                      # a width that is no multiple of 32
+    ("vocab100", "msrvtt_base_ami", dict(vocab_size=100)),              # tiny vocabularies (below the fused selections' minimum)
+    ("vocab130", "msrvtt_care", dict(vocab_size=130)),
+    ("d128", "msrvtt_base_ami", dict(dim_hidden=128, num_attention_heads=2, intermediate_size=512)),
+    ("d192", "msrvtt_care", dict(dim_hidden=192, num_attention_heads=3, intermediate_size=768)),
+    ("d320_ff1280", "msrvtt_base_ami", dict(dim_hidden=320, num_attention_heads=5, intermediate_size=1280)),
+    ("d512_ff1536", "msrvtt_care", dict(intermediate_size=1536)),       # a standard width with an FFN the resident launches do not cover
 ])
 def test_options_outside_the_shipped_configurations_against_the_oracle(name, config, over):
     """The shapes a user's own checkpoint may have - other frame counts, vocabularies, beam_alpha, concept counts, widths and

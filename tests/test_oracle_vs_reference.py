@@ -44,6 +44,9 @@ VARIANTS = [
     ("retrieval10", "msrvtt_care", dict(retrieval_topk=10)),
     ("dims_64_1024_768", "msrvtt_base_ami", dict(dim_a=64, dim_m=1024, dim_i=768)),
     ("dim_i_500", "msvd_base_i", dict(dim_i=500)),
+    ("vocab100", "msrvtt_base_ami", dict(vocab_size=100)),
+    ("d192", "msrvtt_care", dict(dim_hidden=192, num_attention_heads=3, intermediate_size=768)),
+    ("d320_ff1280", "msrvtt_base_ami", dict(dim_hidden=320, num_attention_heads=5, intermediate_size=1280)),
 ]
 
 
