@@ -818,3 +818,38 @@ def test_copies_and_pickles_of_a_used_module_decode_like_the_original():
     assert after != base and tr.translate_batch([twin], dev) == base
     fresh = _model(opt, {k: v.detach().cpu() for k, v in model.state_dict().items()})
     assert after == tr.translate_batch([fresh], dev)
+
+
+def test_ensemble_of_models_of_different_widths_against_the_oracle():
+    """Members need one vocabulary and one max_len, not one architecture: a d_model 512 CARE model, a d_model 1024 one and a Base
+    model (other modalities: a feature list per member) decode together - against the oracle's ensemble search (pinned on the
+    reference Translator by tests/golden/ensemble), fp32 mode; and with the members in DIFFERENT compute modes."""
+    from care_amd import get_framework, get_translator
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_feats, synth_state_dict
+    from oracle import care_cpu
+
+    B = 3
+    opts = [make_opt("msrvtt_care", beam_size=5, topk=2), make_opt("vatex_care_large"), make_opt("msrvtt_base_ami")]
+    models, Ps, feats = [], [], []
+    for i, o in enumerate(opts):
+        m = get_framework(o).eval()
+        P = synth_state_dict(40 + i, [(k, tuple(v.shape)) for k, v in m.state_dict().items()],
+                             row_scale={"cls_head.tgt_word_prj.weight": {3: 4.0, 0: 3.0}})
+        m.load_state_dict(P, strict=True)
+        models.append(m.to("cuda:0")); Ps.append(P); feats.append(synth_feats(40 + i, feat_shapes(o, B)))
+    ref_hyps, ref_scores, gaps = care_cpu.translate_batch_ensemble(Ps, opts, feats, return_gaps=True)
+    tr = get_translator(opts[0])
+    batch = {"feats": [_dev(f) for f in feats]}
+    hyps, scores = tr.translate_batch(models, batch)
+    assert hyps == ref_hyps
+    for a, b in zip(scores, ref_scores):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+    models[1].set_compute_dtype("fp16")
+    models[2].set_compute_dtype("bf16")
+    for _ in range(3):
+        mixed, _ = tr.translate_batch(models, batch)
+    for i in range(B):
+        if mixed[i][0] != ref_hyps[i][0]:
+            g = gaps[i]
+            assert min(g["select"], g["best_slack"], g["rank"]) < 5e-2, (i, g)
