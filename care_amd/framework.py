@@ -18,6 +18,7 @@ dropout; configurations training.py does not cover (other encoders, concept head
 concat, several captions per clip) raise too.
 """
 import math
+import contextlib
 import os
 from typing import Any, Dict, List, Optional
 
@@ -363,9 +364,15 @@ class TransformerSeq2Seq(nn.Module):
                 keys.append(k)
         return keys
 
+    def _on_device(self):
+        """The module's device as the current device of what follows (kernels go to the CURRENT device with this module's
+        pointers; a process that drives several GPUs need not have set it) - a no-op when it already is, or on the CPU."""
+        p = next(self.parameters(), None)
+        return torch.cuda.device(p.device) if p is not None and p.is_cuda else contextlib.nullcontext()
+
     def encoding_phase(self, feats: List[torch.Tensor], **kwargs) -> Dict[str, torch.Tensor]:
         n_mod = len(self.opt["modality"])
-        with torch.no_grad():
+        with torch.no_grad(), self._on_device():
             eng = self.engine()
             eng._begin_pass()
             out = eng.encode(list(feats[:n_mod]))
@@ -394,7 +401,7 @@ class TransformerSeq2Seq(nn.Module):
         # never by decoding) come with every full-sequence call, like there; the per-step calls of a
         # decode loop (last_time_step_logits) skip them unless asked (`output_auxiliary=True`).
         aux = kwargs.get("output_auxiliary", not last_time_step_logits)
-        with torch.no_grad():
+        with torch.no_grad(), self._on_device():
             eng = self.engine()
             eng._begin_pass()
             return eng.decode_full(input_ids, mem, inputs_for_decoder.get("semantic_hidden_states"),
@@ -406,7 +413,8 @@ class TransformerSeq2Seq(nn.Module):
             # models/Wrapper.py:423-435 -> Framework.py:215-237 with dropout active, under autograd: every op's
             # forward and backward is a HIP kernel behind the C ABI (care_amd/training.py)
             from .training import training_forward
-            return training_forward(self, batch, **kwargs)
+            with self._on_device():
+                return training_forward(self, batch, **kwargs)
         enc = self.encoding_phase(batch["feats"], **kwargs)
         inputs = self.prepare_inputs_for_decoder(enc, batch)
         dec = self.decoding_phase(batch["input_ids"], inputs, **kwargs)

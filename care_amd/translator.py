@@ -16,6 +16,7 @@ lists from numpy views with one `.tolist()` per array and list slicing - no per-
 k + 1 runs on the device (what `translate.py`'s loop over the loader does serially: translate.py:34-51) - on the caller's
 own thread, piece by piece: in the host waits of a segmented pass (engine.idle_hook) and after an asynchronous launch.
 """
+import contextlib
 import gc
 from typing import Iterable, List
 
@@ -76,8 +77,16 @@ class Translator_ARFormer(object):
         self._slot = 0
 
     # ------------------------------------------------------------------ the reference's entry point
+    @staticmethod
+    def _device_of(models):
+        """The device the first model lives on, as the CURRENT device of everything below (kernels are launched on the current
+        device with the model's pointers: a process that drives several GPUs need not have set it); a no-op otherwise."""
+        p = next(iter(models[0].parameters()), None) if len(models) else None
+        return torch.cuda.device(p.device) if p is not None and p.is_cuda else contextlib.nullcontext()
+
     def translate_batch(self, models: List[torch.nn.Module], batch: dict, *args, **kwargs):
-        return self._finish(self._launch(models, batch, kwargs))
+        with self._device_of(models):
+            return self._finish(self._launch(models, batch, kwargs))
 
     def translate_batches(self, models: List[torch.nn.Module], batches: Iterable[dict], **kwargs):
         """`translate_batch` over an iterable of batches, one batch behind: yields `(batch_hyps, batch_scores)` of batch k
@@ -89,12 +98,16 @@ class Translator_ARFormer(object):
         else reads them after the launch."""
         prev = None
         for batch in batches:
-            cur = self._launch(models, batch, kwargs, overlap=prev)
-            if prev is not None:
-                yield self._finish(prev)
+            with self._device_of(models):   # (per step: a generator must not hold the caller's current device between yields)
+                cur = self._launch(models, batch, kwargs, overlap=prev)
+                done = self._finish(prev) if prev is not None else None
+            if done is not None:
+                yield done
             prev = cur
         if prev is not None:
-            yield self._finish(prev)
+            with self._device_of(models):
+                done = self._finish(prev)
+            yield done
 
     # ------------------------------------------------------------------ launch: the device pass + one D2H copy
     _ABORTED = ("the resident decode timed out at a hand-off: its workgroups never became resident together (another "
