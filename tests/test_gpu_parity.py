@@ -853,3 +853,47 @@ def test_ensemble_of_models_of_different_widths_against_the_oracle():
         if mixed[i][0] != ref_hyps[i][0]:
             g = gaps[i]
             assert min(g["select"], g["best_slack"], g["rank"]) < 5e-2, (i, g)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+def test_side_streams_and_worker_threads(mode):
+    """A serving process: the call under another current stream, from a worker thread, first used on a worker thread (graph
+    capture off the main thread), and two threads with a model each at the same time (two resident launches competing for
+    the chip in fp16 mode: a launch that times out is decoded again by the multi-launch pass) - always the same captions."""
+    import threading
+    from conftest import GoldenCase
+    from care_amd import get_translator
+
+    golden = GoldenCase("msrvtt_care_beam5_eos_b4")
+    opt, P, feats, _ = golden.build()
+    model, other = _model(opt, P, mode), _model(opt, P, mode)
+    tr, tr2 = get_translator(opt), get_translator(opt)
+    dev = {"feats": _dev(feats)}
+    for _ in range(3):
+        base = tr.translate_batch([model], dev)
+    if mode == "fp32":
+        assert base[0] == golden.hyps()[0]
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            assert tr.translate_batch([model], dev) == base
+    torch.cuda.synchronize()
+    assert tr.translate_batch([model], dev) == base
+
+    def run(box, m, t, n):
+        try:
+            for _ in range(n):
+                box["r"] = t.translate_batch([m], dev)
+        except Exception as exc:   # noqa: BLE001 - reported below
+            box["e"] = repr(exc)
+
+    box = {}
+    th = threading.Thread(target=run, args=(box, other, tr2, 4))   # `other` has never run: its first passes happen on this thread
+    th.start(); th.join()
+    assert box.get("e") is None and box["r"] == base
+    boxes = [{}, {}]
+    ths = [threading.Thread(target=run, args=(boxes[0], model, tr, 20)), threading.Thread(target=run, args=(boxes[1], other, tr2, 20))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert [b.get("e") for b in boxes] == [None, None] and boxes[0]["r"] == base and boxes[1]["r"] == base
