@@ -271,3 +271,41 @@ def test_beam5_winners_of_the_large_model():
     _audit_record(test="large_model_scale_beam5", mode="fp16", config="vatex_care_large", clips=clips, identical=same, differing=differ[:32],
                   mean_length=sum(len(h[0]) for h in res["fp32"]) / clips)
     assert same >= 0.93 * clips, "{} of {} beam winners identical".format(same, clips)
+
+
+@pytest.mark.parametrize("config,B,beam", [("vatex_care_large", 32, 5), ("msrvtt_care", 128, 1), ("care_median_gelu", 40, 1)])
+def test_runner_over_the_prefetcher_equals_eager_passes(config, B, beam):
+    """translate.py's loop as this repository offers it: CaptionRunner.translate_steps over FeaturePrefetcher(depth=3) - pinned
+    staging, H2D on a side stream into three rotating device slots, the pipelined Translator, hipGraph replays per slot - over
+    14 batches (the last one ragged), against one eager pass per batch."""
+    from care_amd.checkpoint import CaptionRunner
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.data import FeaturePrefetcher
+    from care_amd.synth import synth_state_dict
+    from test_gpu_properties import PEAKED_ROWS
+
+    opt = make_opt(config, beam_size=beam, topk=1)
+    runner = CaptionRunner(opt)
+    P = synth_state_dict(LARGE_SEED, [(k, tuple(v.shape)) for k, v in runner.captioner.state_dict().items()], row_scale=PEAKED_ROWS)
+    runner.captioner.load_state_dict(P, strict=True)
+    runner.captioner.set_compute_dtype("fp16")
+    runner.eval().to("cuda:0")
+    n = 13 * B + B // 3
+    gen = torch.Generator().manual_seed(LARGE_SEED + 1)
+    host = [torch.randn(s, generator=gen) for s in feat_shapes(opt, n)]
+    batches = [[f[lo: lo + B] for f in host] for lo in range(0, n, B)]
+    got = []
+    for hyps, _ in runner.translate_steps(({"feats": f} for f in FeaturePrefetcher(batches, "cuda:0", depth=3))):
+        got += hyps
+    assert len(got) == n
+    eng = runner.captioner.engine()
+    want = []
+    for b in batches:
+        dev = [f.to("cuda:0") for f in b]
+        if beam == 1:
+            _, fed, length, _ = eng.translate_greedy(dev, use_graph=False, lean=True)
+            want += [[fed[i, 1: int(length[i]) + 1].tolist()] for i in range(len(length))]
+        else:
+            hyps, _ = runner.translator.translate_batch([runner.captioner], {"feats": dev}, use_graph=False)
+            want += hyps
+    assert got == want
