@@ -279,3 +279,34 @@ def test_validation_between_training_epochs_sees_the_updated_weights(mode):
             torch.nn.functional.cross_entropy(lg.reshape(-1, lg.shape[-1]), labels.reshape(-1)).backward()
             optim.step()
     assert seen[0] != seen[-1], "twelve optimiser steps at lr 0.05 did not change one caption: the test does not test"
+
+
+@pytest.mark.parametrize("gemm", ["f32", "fp16x3"])
+def test_degenerate_gradients_stay_finite(gemm):
+    """The split products scale every operand by a power of two derived from its |max| (care_absmax): an all-zero upstream
+    gradient (|max| = 0), gradients of 1e-30 and 1e30 and all-zero features must come through finite in both GEMM forms - and
+    scale linearly."""
+    from conftest import GoldenCase
+    from care_amd import training
+
+    training.set_train_gemm(gemm)
+    try:
+        opt, P, feats, ids, model = _build(GoldenCase("msrvtt_care_b2"), **NO_DROP)
+        model.train()
+        batch = {"feats": [f.to("cuda:0") for f in feats], "input_ids": ids.to("cuda:0")}
+        largest = {}
+        for what, scale in (("one", 1.0), ("zero", 0.0), ("tiny", 1e-30), ("huge", 1e30)):
+            model.zero_grad()
+            out = model(batch)
+            ((out["logits"] * scale).sum() + (out["preds_attr"] * scale).sum()).backward()
+            grads = [p.grad for p in model.parameters() if p.grad is not None]
+            assert all(torch.isfinite(g_).all() for g_ in grads), what
+            largest[what] = max(float(g_.abs().max()) for g_ in grads)
+        assert largest["zero"] == 0.0
+        assert abs(largest["tiny"] / 1e-30 / largest["one"] - 1) < 1e-3 and abs(largest["huge"] / 1e30 / largest["one"] - 1) < 1e-3
+        model.zero_grad()
+        out = model({"feats": [torch.zeros_like(f) for f in batch["feats"]], "input_ids": batch["input_ids"]})
+        (out["logits"].sum() + out["preds_attr"].sum()).backward()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    finally:
+        training.set_train_gemm("auto")
