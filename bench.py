@@ -246,7 +246,10 @@ def extra_legs(dev, main_dtype, legs):
             run()
         dt = _timed(run, iters)
         leg = dict(config=config, dtype=dtype, clips_per_step=B, captions_per_s=round(B / dt, 1),
-                   ms_per_pass=round(dt * 1e3, 3), decoder_step_us=round(dt * 1e6 / eng.T, 2))
+                   ms_per_pass=round(dt * 1e3, 3), decoder_step_us=round(dt * 1e6 / eng.T, 2),
+                   # the decoder steps the LAST timed pass ran (a replayed pass that ended early would be fast for the wrong reason:
+                   # the captured-memset bug of round 6 did exactly that to passes over recycled buffers)
+                   steps_run=int(eng.last_decode.get("steps", eng.T)))
         if eng.last_decode.get("resident"):
             leg["roofline"] = small_batch_roofline(eng, B, 1, dt * 1e6 / eng.T)
         return leg, eng, feats, opt
@@ -301,7 +304,8 @@ def extra_legs(dev, main_dtype, legs):
         legs["msrvtt_care_beam5_B%d" % B] = dict(config="msrvtt_care_beam5", dtype=main_dtype, clips_per_step=B, beam_size=5,
                                                   rows_per_decoder_step=5 * B, captions_per_s=round(B / dt, 1),
                                                   ms_per_pass=round(dt * 1e3, 3), decoder_step_us=round(dt * 1e6 / eng.T, 2),
-                                                  resident_launch=bool(eng.last_decode.get("resident")))
+                                                  resident_launch=bool(eng.last_decode.get("resident")),
+                                                  steps_run=int(eng.last_decode.get("steps", eng.T)))
         if eng.last_decode.get("resident"):
             legs["msrvtt_care_beam5_B%d" % B]["roofline"] = small_batch_roofline(eng, B, 5, dt * 1e6 / eng.T)
         if B == 1:
@@ -791,6 +795,12 @@ def main():
         elapsed = max(per_rank_s)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
+    # what the last timed pass did (after the clock stopped): decoder steps run, caption lengths - a pass that ended early or
+    # returned a previous batch's rows would be fast for the wrong reason
+    _, length_chk, _ = step()
+    torch.cuda.synchronize()
+    work_done = dict(decoder_steps_run=int(eng.last_decode.get("steps", eng.T)), caption_length_min=int(length_chk.min()),
+                     caption_length_mean=round(float(length_chk.float().mean()), 2), captions=int(length_chk.numel()))
 
     if rank != 0:
         if use_dist:
@@ -927,7 +937,8 @@ def main():
                     config_name=args.config, clips_per_gpu_per_step=B, global_batch=B * world, lanes=args.lanes,
                     parallelism="batch-sharded dp{} (no data-path collective; all-gather of results)".format(world),
                     hip_graph=not args.no_graph, absorbed_cross_attention=bool(eng.latent_for(B)),
-                    lean_encode=bool(eng.lean_ok)),  # the Translator's call: bf16 memory only, no unused fp32 copy / frame means
+                    lean_encode=bool(eng.lean_ok),  # the Translator's call: bf16 memory only, no unused fp32 copy / frame means
+                    work_done_per_step=work_done),
         decoder_step_us=round(ms_per_step * 1e3 * (1 - (kernels.get("enc_gemm", {"total_ms": 0})["total_ms"] +
                                                          kernels.get("cross_kv_gemm", {"total_ms": 0})["total_ms"]) /
                                                     max(tagged_ms, 1e-9)) / T, 2),
