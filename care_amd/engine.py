@@ -20,6 +20,7 @@ import contextlib
 import ctypes
 import functools
 import os
+import threading
 import weakref
 from typing import Dict, List, Optional
 
@@ -33,6 +34,9 @@ from .engine_decode import DecodeMixin
 from .engine_encode import EncodeMixin
 from .engine_resident import ResidentMixin
 from .engine_util import _LaneOutputs  # noqa: F401
+
+
+_CAPTURE_LOCK = threading.Lock()   # hipGraph captures are serialised across engines and threads (HipEngine._replay)
 
 
 class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
@@ -621,10 +625,15 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
             self._graph_put(key, "seen")
             return fn()
         if entry == "seen":
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = fn()
+            # ONE capture at a time in the process (torch registers the default generator's state with the graph being
+            # captured: two threads capturing at once abort the process - "The graph should be registered to the state",
+            # found by tools/soak.py), and in thread-local error mode, so that what OTHER threads do meanwhile - launches,
+            # allocations, event queries of their own passes - does not invalidate this capture
+            with _CAPTURE_LOCK:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    out = fn()
             entry = (graph, out)
             self._graph_put(key, entry)
         entry[0].replay()

@@ -897,3 +897,12 @@ def test_side_streams_and_worker_threads(mode):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert [b.get("e") for b in boxes] == [None, None] and boxes[0]["r"] == base and boxes[1]["r"] == base
+    # two COLD models started on two threads at the same moment: their first passes and graph captures coincide (captures are
+    # serialised process-wide, engine._CAPTURE_LOCK: two at once abort the process inside torch's generator registry)
+    cold = [_model(opt, P, mode), _model(opt, P, mode)]
+    trs = [get_translator(opt), get_translator(opt)]
+    boxes = [{}, {}]
+    ths = [threading.Thread(target=run, args=(boxes[i], cold[i], trs[i], 12)) for i in range(2)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert [b.get("e") for b in boxes] == [None, None] and boxes[0]["r"] == base and boxes[1]["r"] == base

@@ -1,0 +1,58 @@
+"""A soak of the drop-in path: two threads, a model each (d_model 512 and 1024), greedy and beam resident passes over recycled
+device buffers for a few minutes, every result checked against an eager pass computed up front; counts what ran, what had to be
+decoded again (a resident launch that timed out at a hand-off) and what came back wrong.   python tools/soak.py [seconds]"""
+import os
+import sys
+import threading
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from care_amd import get_framework, get_translator
+from care_amd.configs import feat_shapes, make_opt
+from care_amd.synth import synth_state_dict
+
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+stats = {}
+
+
+def worker(name, config, B, seed):
+    opt1, opt5 = make_opt(config, beam_size=1), make_opt(config, beam_size=5)
+    model = get_framework(opt1).eval()
+    model.load_state_dict(synth_state_dict(seed, [(k, tuple(v.shape)) for k, v in model.state_dict().items()],
+                                           row_scale={"cls_head.tgt_word_prj.weight": {3: 6.0}}), strict=True)
+    model.set_compute_dtype("fp16")
+    model.to("cuda:0")
+    tr = {1: get_translator(opt1), 5: get_translator(opt5)}
+    gen = torch.Generator().manual_seed(seed)
+    host = [torch.randn(s, generator=gen) for s in feat_shapes(opt1, 8 * B)]
+    want = {}
+    for k in range(8):
+        dev = {"feats": [f[k * B: (k + 1) * B].to("cuda:0") for f in host]}
+        for bm in (1, 5):
+            want[(k, bm)] = tr[bm].translate_batch([model], dev, use_graph=False)
+    st = stats[name] = dict(passes=0, wrong=0, errors=0, retried=0)
+    t_end = time.time() + SECONDS
+    i = 0
+    while time.time() < t_end:
+        k, bm = i % 8, (1, 5)[(i // 8) % 2]
+        dev = {"feats": [f[k * B: (k + 1) * B].to("cuda:0") for f in host]}
+        try:
+            got = tr[bm].translate_batch([model], dev)
+            st["wrong"] += int(got != want[(k, bm)])
+            st["retried"] += int(not model.engine().last_decode.get("resident"))
+        except Exception as exc:   # noqa: BLE001
+            st["errors"] += 1
+            st["last_error"] = repr(exc)[:200]
+        st["passes"] += 1
+        i += 1
+        del dev
+
+
+threads = [threading.Thread(target=worker, args=("d512", "msrvtt_care", 128, 3)),
+           threading.Thread(target=worker, args=("d1024", "vatex_care_large", 32, 4))]
+t0 = time.time()
+[t.start() for t in threads]
+[t.join() for t in threads]
+print("soak %.0f s:" % (time.time() - t0), stats)
