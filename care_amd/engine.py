@@ -33,7 +33,7 @@ from .engine_beam import BeamMixin
 from .engine_decode import DecodeMixin
 from .engine_encode import EncodeMixin
 from .engine_resident import ResidentMixin
-from .engine_util import _LaneOutputs  # noqa: F401
+from .engine_util import _LaneOutputs, device_props  # noqa: F401
 
 
 _CAPTURE_LOCK = threading.Lock()   # hipGraph captures are serialised across engines and threads (HipEngine._replay)
@@ -401,7 +401,7 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         budget = self.ws_budget_bytes
         if budget is None:
             env = os.environ.get("CARE_WS_BUDGET_GB")
-            budget = int(float(env) * (1 << 30)) if env else int(0.6 * torch.cuda.get_device_properties(self.device).total_memory)
+            budget = int(float(env) * (1 << 30)) if env else int(0.6 * device_props(self.device).total_memory)
             self.ws_budget_bytes = budget
         if self._ws_bytes <= budget:
             return

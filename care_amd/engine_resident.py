@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import ACT_CODES, CARE_BF16, CARE_F32, ptr
 from .constants import BOS, EOS, PAD
-from .engine_util import _LaneOutputs
+from .engine_util import _LaneOutputs, device_props
 
 
 class ResidentMixin:
@@ -58,7 +58,7 @@ class ResidentMixin:
         """one workgroup per CU at most, and at least one per group of `per_tile` 16-row tiles (a partitioned GPU has fewer CUs)"""
         if self.device is not None and torch.cuda.is_available():
             if getattr(self, "_cus", None) is None:
-                self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+                self._cus = device_props(self.device).multi_processor_count
             return ((rows + 15) // 16 + per_tile - 1) // per_tile <= self._cus // 8 * 8
         return True
 

@@ -37,3 +37,19 @@ class _LaneOutputs(dict):
 
     def values(self):
         return [self[k] for k in self]
+
+
+import threading as _threading
+
+_PROPS, _PROPS_LOCK = {}, _threading.Lock()
+
+
+def device_props(device):
+    """torch.cuda.get_device_properties, once per device and under a lock: threads that touch the GPU for the first time at the
+    same moment race inside torch's lazy initialisation ("Invalid device id" from a worker thread; tools/soak.py)."""
+    key = torch.device(device).index or 0
+    with _PROPS_LOCK:
+        if key not in _PROPS:
+            torch.cuda.init()
+            _PROPS[key] = torch.cuda.get_device_properties(key)
+        return _PROPS[key]

@@ -1,6 +1,7 @@
 """A soak of the drop-in path: two threads, a model each (d_model 512 and 1024), greedy and beam resident passes over recycled
-device buffers for a few minutes, every result checked against an eager pass computed up front; counts what ran, what had to be
-decoded again (a resident launch that timed out at a hand-off) and what came back wrong.   python tools/soak.py [seconds]"""
+device buffers for a few minutes, every result checked against an eager pass computed up front; counts what ran, what did not
+run as a resident launch (a batch beyond its rows, or a launch that timed out at a hand-off and was decoded again) and what came
+back wrong.   python tools/soak.py [seconds] [--big]"""
 import os
 import sys
 import threading
@@ -13,7 +14,7 @@ from care_amd import get_framework, get_translator
 from care_amd.configs import feat_shapes, make_opt
 from care_amd.synth import synth_state_dict
 
-SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+SECONDS = float(next((a for a in sys.argv[1:] if not a.startswith("-")), "120"))
 stats = {}
 
 
@@ -32,7 +33,7 @@ def worker(name, config, B, seed):
         dev = {"feats": [f[k * B: (k + 1) * B].to("cuda:0") for f in host]}
         for bm in (1, 5):
             want[(k, bm)] = tr[bm].translate_batch([model], dev, use_graph=False)
-    st = stats[name] = dict(passes=0, wrong=0, errors=0, retried=0)
+    st = stats[name] = dict(passes=0, wrong=0, errors=0, not_resident=0)
     t_end = time.time() + SECONDS
     i = 0
     while time.time() < t_end:
@@ -41,7 +42,7 @@ def worker(name, config, B, seed):
         try:
             got = tr[bm].translate_batch([model], dev)
             st["wrong"] += int(got != want[(k, bm)])
-            st["retried"] += int(not model.engine().last_decode.get("resident"))
+            st["not_resident"] += int(not model.engine().last_decode.get("resident"))
         except Exception as exc:   # noqa: BLE001
             st["errors"] += 1
             st["last_error"] = repr(exc)[:200]
@@ -52,6 +53,8 @@ def worker(name, config, B, seed):
 
 threads = [threading.Thread(target=worker, args=("d512", "msrvtt_care", 128, 3)),
            threading.Thread(target=worker, args=("d1024", "vatex_care_large", 32, 4))]
+if "--big" in sys.argv:   # a third thread with batches of the segmented large-batch forms (early exit: host waits between segments)
+    threads.append(threading.Thread(target=worker, args=("big", "msrvtt_base_ami", 1536, 5)))
 t0 = time.time()
 [t.start() for t in threads]
 [t.join() for t in threads]
