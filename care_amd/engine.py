@@ -116,6 +116,9 @@ class HipEngine(EncodeMixin, DecodeMixin, ResidentMixin, BeamMixin):
         self._ws_used: Dict[tuple, int] = {}     # workspace key -> number of the last pass that asked for it
         self._ws_bytes = 0
         self._gen = 0                            # pass counter (_begin_pass)
+        # one pass at a time per engine: its workspaces, result block and graphs are the engine's, not the caller's - threads
+        # that share a module take turns (the Translator and the module API hold it for the length of a call)
+        self.lock = threading.RLock()
         # rows (clips x beam) the running pass STARTED with: what the row-count switches of a decode step look at
         # (ln_fusable) - compaction shrinks the row count mid-pass, and a clip's arithmetic must not change with it
         self._form_rows: Optional[int] = None

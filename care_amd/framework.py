@@ -20,6 +20,7 @@ concat, several captions per clip) raise too.
 import math
 import contextlib
 import os
+import threading
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -275,6 +276,9 @@ def get_framework(opt: Dict[str, Any]) -> nn.Module:
     return TransformerSeq2Seq(opt, keys)
 
 
+_ENGINE_BUILD_LOCK = threading.Lock()
+
+
 class TransformerSeq2Seq(nn.Module):
     """`Seq2SeqBase` + `TransformerSeq2Seq` (models/Framework.py:54-269) on the HIP engine."""
 
@@ -346,6 +350,12 @@ class TransformerSeq2Seq(nn.Module):
         params = list(self.parameters())
         device = params[0].device
         stamp = (device, self._compute_dtype, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        if self._engine is not None and self._engine_stamp == stamp:
+            return self._engine
+        with _ENGINE_BUILD_LOCK:   # (threads sharing a module: one of them builds / re-packs, the others find it done)
+            return self._engine_locked(stamp, device)
+
+    def _engine_locked(self, stamp, device) -> HipEngine:
         if self._engine is None or self._engine_stamp != stamp:
             if device.type != "cuda":
                 raise RuntimeError("the model is on `{}`: move it to the MI355X (model.to('cuda')); "
@@ -372,7 +382,7 @@ class TransformerSeq2Seq(nn.Module):
 
     def encoding_phase(self, feats: List[torch.Tensor], **kwargs) -> Dict[str, torch.Tensor]:
         n_mod = len(self.opt["modality"])
-        with torch.no_grad(), self._on_device():
+        with torch.no_grad(), self._on_device(), self.engine().lock:
             eng = self.engine()
             eng._begin_pass()
             out = eng.encode(list(feats[:n_mod]))
@@ -401,7 +411,7 @@ class TransformerSeq2Seq(nn.Module):
         # never by decoding) come with every full-sequence call, like there; the per-step calls of a
         # decode loop (last_time_step_logits) skip them unless asked (`output_auxiliary=True`).
         aux = kwargs.get("output_auxiliary", not last_time_step_logits)
-        with torch.no_grad(), self._on_device():
+        with torch.no_grad(), self._on_device(), self.engine().lock:
             eng = self.engine()
             eng._begin_pass()
             return eng.decode_full(input_ids, mem, inputs_for_decoder.get("semantic_hidden_states"),

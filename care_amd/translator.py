@@ -84,8 +84,18 @@ class Translator_ARFormer(object):
         p = next(iter(models[0].parameters()), None) if len(models) else None
         return torch.cuda.device(p.device) if p is not None and p.is_cuda else contextlib.nullcontext()
 
+    @staticmethod
+    @contextlib.contextmanager
+    def _turn(models):
+        """The engines of `models`, held for the length of a call (threads sharing a module take turns: an engine's workspaces
+        and result block are its own) - in a fixed order, so that two ensembles over the same models cannot wait for each other."""
+        with contextlib.ExitStack() as stack:
+            for m in sorted((m for m in models if isinstance(m, TransformerSeq2Seq)), key=id):
+                stack.enter_context(getattr(m.engine(), "lock", contextlib.nullcontext()))
+            yield
+
     def translate_batch(self, models: List[torch.nn.Module], batch: dict, *args, **kwargs):
-        with self._device_of(models):
+        with self._device_of(models), self._turn(models):
             return self._finish(self._launch(models, batch, kwargs))
 
     def translate_batches(self, models: List[torch.nn.Module], batches: Iterable[dict], **kwargs):
@@ -98,14 +108,14 @@ class Translator_ARFormer(object):
         else reads them after the launch."""
         prev = None
         for batch in batches:
-            with self._device_of(models):   # (per step: a generator must not hold the caller's current device between yields)
+            with self._device_of(models), self._turn(models):   # (per step: a generator holds neither the caller's current device nor the engines between yields)
                 cur = self._launch(models, batch, kwargs, overlap=prev)
                 done = self._finish(prev) if prev is not None else None
             if done is not None:
                 yield done
             prev = cur
         if prev is not None:
-            with self._device_of(models):
+            with self._device_of(models), self._turn(models):
                 done = self._finish(prev)
             yield done
 

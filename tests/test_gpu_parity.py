@@ -906,3 +906,42 @@ def test_side_streams_and_worker_threads(mode):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert [b.get("e") for b in boxes] == [None, None] and boxes[0]["r"] == base and boxes[1]["r"] == base
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+def test_threads_sharing_one_module_take_turns(mode):
+    """A thread pool in front of ONE module (an nn.Module in eval mode looks stateless to its callers): four threads, each with
+    clips of its own, 25 calls each through one shared Translator and through the module API - an engine's workspaces, result
+    block and graphs are shared state, so calls take turns (engine.lock) and every thread gets ITS captions."""
+    import threading
+    from care_amd import get_framework, get_translator
+    from care_amd.configs import feat_shapes, make_opt
+    from care_amd.synth import synth_feats, synth_state_dict
+
+    opt = make_opt("msrvtt_care", beam_size=5, topk=1)
+    model = get_framework(opt).eval()
+    model.load_state_dict(synth_state_dict(5, [(k, tuple(v.shape)) for k, v in model.state_dict().items()],
+                                           row_scale={"cls_head.tgt_word_prj.weight": {3: 5.0}}), strict=True)
+    model.set_compute_dtype(mode)
+    model.to("cuda:0")
+    tr = get_translator(opt)
+    inputs = [{"feats": _dev(synth_feats(100 + i, feat_shapes(opt, 6 + i)))} for i in range(4)]
+    want = [tr.translate_batch([model], b, use_graph=False) for b in inputs]
+    want_mem = [model.encoding_phase(b["feats"])["encoder_hidden_states"].clone() for b in inputs]
+    assert len({str(w[0]) for w in want}) == 4
+    errors = []
+
+    def run(i):
+        try:
+            for k in range(25):
+                if tr.translate_batch([model], inputs[i]) != want[i]:
+                    errors.append("thread {} call {}: another thread's captions".format(i, k))
+                if not torch.equal(model.encoding_phase(inputs[i]["feats"])["encoder_hidden_states"], want_mem[i]):
+                    errors.append("thread {} call {}: another thread's memory".format(i, k))
+        except Exception as exc:   # noqa: BLE001
+            errors.append(repr(exc))
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors[:3]
