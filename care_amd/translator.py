@@ -235,8 +235,13 @@ class Translator_ARFormer(object):
 
     @staticmethod
     def _gave_up(p: _Pending) -> bool:
-        first = p.arrays[0]   # length (greedy) / nfin (beam): negative = the resident launch gave up (include/care_hip.h)
-        return bool(first.size) and int(first.min()) < 0
+        # length (greedy) / nfin (beam): negative = the resident launch gave up (include/care_hip.h).  ZERO is no result either - a
+        # finished clip has at least one token / one hypothesis: a clip that comes back without is treated like a launch that gave
+        # up (decoded again by the multi-launch pass; an error if that pass reports the same), never handed on as an empty caption
+        # (seen once, round 6: a greedy job of test_resident_launches_under_contention_never_hang[fenced] came back with lengths 0
+        # in one full-suite run of about ten; not reproduced in isolation)
+        first = p.arrays[0]
+        return bool(first.size) and int(first.min()) <= 0
 
     def _hook_for(self, p: _Pending):
         """engine.idle_hook that advances batch p's assembly by one piece per call (False: nothing left to do here).
