@@ -270,7 +270,9 @@ def test_resident_launches_under_contention_never_hang(handoff):
             with torch.cuda.stream(torch.cuda.Stream()):
                 for _ in range(12):
                     got = tr.translate_batch([model], {"feats": feats}, use_graph=False)
-                    assert got[0] == want[0], "job {}: captions changed under contention".format(k)
+                    assert got[0] == want[0], "job {}: captions changed under contention (last pass: {}; caption lengths {})".format(
+                        k, {a: (int(b) if torch.is_tensor(b) else b) for a, b in model.engine().last_decode.items()},
+                        sorted({len(h[0]) for h in got[0]}))
                     done[k] += 1
         except Exception as exc:  # noqa: BLE001 - reported by the main thread
             errors.append((k, repr(exc)))
