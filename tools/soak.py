@@ -1,7 +1,7 @@
 """A soak of the drop-in path: two threads, a model each (d_model 512 and 1024), greedy and beam resident passes over recycled
 device buffers for a few minutes, every result checked against an eager pass computed up front; counts what ran, what did not
 run as a resident launch (a batch beyond its rows, or a launch that timed out at a hand-off and was decoded again) and what came
-back wrong.   python tools/soak.py [seconds] [--big]"""
+back wrong.   python tools/soak.py [seconds] [--big] [--filler]"""
 import os
 import sys
 import threading
@@ -55,7 +55,25 @@ threads = [threading.Thread(target=worker, args=("d512", "msrvtt_care", 128, 3))
            threading.Thread(target=worker, args=("d1024", "vatex_care_large", 32, 4))]
 if "--big" in sys.argv:   # a third thread with batches of the segmented large-batch forms (early exit: host waits between segments)
     threads.append(threading.Thread(target=worker, args=("big", "msrvtt_base_ami", 1536, 5)))
+stop = threading.Event()
+
+
+def filler():   # keeps the CUs busy on a stream of its own: resident launches must share the chip (tests/test_gpu_resident.py)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        a = torch.randn(4096, 4096, device="cuda:0")
+        while not stop.is_set():
+            for _ in range(20):
+                a = (a @ a).clamp_(-1.0, 1.0)
+            torch.cuda.current_stream().synchronize()
+
+
+fill = threading.Thread(target=filler) if "--filler" in sys.argv else None
 t0 = time.time()
+if fill is not None:
+    fill.start()
 [t.start() for t in threads]
 [t.join() for t in threads]
+stop.set()
+if fill is not None:
+    fill.join()
 print("soak %.0f s:" % (time.time() - t0), stats)
