@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256, 1) void decode_resident_kernel(RArgs p_by_valu
   }
   if (gs.dead) {  // aborted (GridSync::wait): say so where the host looks anyway - EVERY row's length, so that no
     // caller mistakes the previous batch's rows in a re-used workspace for results
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < p.R; r += gridDim.x * 256) cst_i(p.length + r, -1);
+    // (EVERY workgroup that gave up, each for all rows - a few hundred words: striped over the grid, up to 256 rows were workgroup
+    // 0's alone to mark)
+    for (int r = threadIdx.x; r < p.R; r += 256) cst_i(p.length + r, -1);
     if (blockIdx.x == 0 && threadIdx.x == 0) p.sync[2] = 0xffffffffu;
     return;
   }

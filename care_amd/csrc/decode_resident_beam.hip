@@ -136,8 +136,10 @@ __global__ __launch_bounds__(256, 1) void decode_resident_beam_kernel(RArgs p_by
     RES_PHASE((beam_advance_phase<D>(p, gs, t, smem)));  // (+ the input rows of step t + 1)
   }
 #undef RES_PHASE
-  if (gs.dead) {  // aborted (GridSync::wait): every clip's count of finished hypotheses = -1
-    for (int b = blockIdx.x * 256 + threadIdx.x; b < p.nclips; b += gridDim.x * 256) cst_i(p.nfin + b, -1);
+  if (gs.dead) {  // aborted (GridSync::wait): every clip's count of finished hypotheses = -1 - written by EVERY workgroup that gave
+    // up, each for all clips (a few hundred words): the host must see it whichever workgroups gave up (striped over the grid,
+    // 128 clips were workgroup 0's alone to mark)
+    for (int b = threadIdx.x; b < p.nclips; b += 256) cst_i(p.nfin + b, -1);
     if (blockIdx.x == 0 && threadIdx.x == 0) p.sync[2] = 0xffffffffu;
     return;
   }
