@@ -398,7 +398,10 @@ RES_PHASE_FN unsigned beam_advance_phase(const RArgs& p, GridSync& gs, int t, un
           cst_i(p.nfin + b, nf);
           if (is_done) {
             cst_i(p.done + b, 1);
-            __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (the returned value is waited for: the count is at L2 BEFORE this workgroup's arrival is - every workgroup that reads it
+            // behind the hand-off must come to the same `all rows ended` verdict; a fire-and-forget add may land after the arrival)
+            const unsigned ended_before = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(ended_before));
           }
         }
       }

@@ -416,7 +416,10 @@ __device__ __forceinline__ void select4(const RArgs& p, int r0, int ts, int lane
           cst_i(p.length + r, ts);
           if (bi == p.eos || ts >= p.T) {
             cst_i(p.fin + r, 1);
-            __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (the returned value is waited for: the count is at L2 BEFORE this workgroup's arrival is - every workgroup that reads it
+            // behind the hand-off must come to the same `all rows ended` verdict; a fire-and-forget add may land after the arrival)
+            const unsigned ended_before = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(ended_before));
           }
         }
       }
